@@ -1,0 +1,53 @@
+"""Restatement of the three torch_geometric==1.0.3 / torch_scatter==1.1.2 primitives
+the reference hot path calls.  Test infrastructure only (see oracle/__init__.py).
+
+The wheels are pinned at /root/reference/requirements.txt:4-5 and are not vendored, so
+their published behaviour is restated here:
+
+* ``add_self_loops(edge_index, num_nodes)`` (called at chem/model.py:39, bio/model.py:39):
+  in 1.0.3 it returns ONE tensor, ``cat([edge_index, [[0..N-1],[0..N-1]]], dim=1)`` --
+  self loops are appended AFTER the real edges.
+* ``MessagePassing.propagate(aggr, edge_index, **kw)`` (chem/model.py:49,101):
+  arguments whose name ends in ``_j`` are gathered with ``edge_index[1]``, ``_i`` with
+  ``edge_index[0]``; the message is reduced with ``scatter_(aggr, msg, edge_index[0],
+  dim_size=N)``; then ``update``.
+* ``torch_scatter.scatter_add(src, index, dim=0, dim_size=N)`` == a zero tensor that
+  receives ``scatter_add_`` -- on CPU a sequential loop in index order.
+* ``global_mean_pool(x, batch)`` (chem/model.py:326, chem/pretrain_contextpred.py:32):
+  ``size = batch.max()+1``; sum per graph divided by ``count.clamp(min=1)``.
+"""
+import torch
+
+
+def add_self_loops(edge_index, num_nodes):
+    loop = torch.arange(num_nodes, dtype=edge_index.dtype, device=edge_index.device)
+    return torch.cat([edge_index, loop.unsqueeze(0).repeat(2, 1)], dim=1)
+
+
+def scatter_add(src, index, dim_size):
+    out = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    return out.index_add_(0, index, src)
+
+
+def propagate_add(edge_index, x_j_source, per_edge_term, combine, num_nodes):
+    """aggregate at edge_index[0] the message combine(x[edge_index[1]], per_edge_term)."""
+    msg = combine(x_j_source[edge_index[1]], per_edge_term)
+    return scatter_add(msg, edge_index[0], num_nodes)
+
+
+def global_add_pool(x, batch, size=None):
+    size = int(batch.max().item()) + 1 if size is None else size
+    return scatter_add(x, batch, size)
+
+
+def global_mean_pool(x, batch, size=None):
+    size = int(batch.max().item()) + 1 if size is None else size
+    total = scatter_add(x, batch, size)
+    count = scatter_add(torch.ones(x.size(0), dtype=x.dtype, device=x.device), batch, size)
+    return total / count.clamp(min=1).unsqueeze(-1)
+
+
+def global_max_pool(x, batch, size=None):
+    size = int(batch.max().item()) + 1 if size is None else size
+    out = torch.full((size, x.size(1)), float("-inf"), dtype=x.dtype, device=x.device)
+    return out.scatter_reduce(0, batch.unsqueeze(-1).expand_as(x), x, reduce="amax", include_self=True)

@@ -1,0 +1,2 @@
+from .batch import Data  # noqa: F401
+from . import synthetic  # noqa: F401
