@@ -1,0 +1,184 @@
+/* pgnn.h -- C ABI of the MI355X (gfx950) message-passing hot path of pretrain-gnns.
+ *
+ * The reference (snap-stanford/pretrain-gnns) has no FFI layer: its hot path is Python calling
+ * third-party wheels (torch_geometric 1.0.3 / torch_scatter 1.1.2 / torch 1.0.1).  This header is
+ * the boundary a maintainer would bind instead; every entry point cites the reference lines whose
+ * arithmetic it replaces (paths relative to the reference repo).  The ctypes binding that
+ * `pretrain_gnns_amd/_lib.py` uses is the "reference-side stub" shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless marked host; the library never allocates: callers
+ *    pass outputs and workspaces (sizes from the *_workspace_bytes functions);
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *  - node-feature matrices are fp32 row-major with an explicit leading dimension (ld, in floats);
+ *    feature width D must be a multiple of 4 (rows are read as float4);
+ *  - integer graph inputs are int64 exactly as PyG stores them (edge_index [2,E], edge_attr [E,2]);
+ *    the library's own structures are int32 / uint8;
+ *  - return 0 on success, otherwise a PGNN_ERR_* code; pgnn_last_error() gives a message.
+ *  - direction convention (torch_geometric 1.0.3 MessagePassing.propagate): messages flow from
+ *    edge_index[1] ("j", source) to edge_index[0] ("i", destination / aggregation index).
+ */
+#ifndef PGNN_H
+#define PGNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGNN_ABI_VERSION 1
+
+#define PGNN_OK 0
+#define PGNN_ERR_ARG 1
+#define PGNN_ERR_HIP 2
+#define PGNN_ERR_WORKSPACE 3
+
+typedef void* pgnn_stream; /* hipStream_t */
+
+int pgnn_abi_version(void);
+const char* pgnn_last_error(void); /* host string, thread-local */
+
+/* ------------------------------------------------------------------------------------------
+ * Graph structure.  Replaces the per-layer add_self_loops + torch.cat of chem/model.py:39-45,
+ * 84-93 and bio/model.py:39-45,94-100 and the COO gather/scatter inside propagate: built ONCE
+ * per batch and shared by all layers and by the backward pass.
+ *
+ *  in_ptr[N+1], in_src[E]  : CSR by destination (edge_index[0]); inside a row the edges keep
+ *                            their original order (stable), so sums run in the reference's order
+ *  out_ptr[N+1], out_dst[E]: CSR by source (edge_index[1]) -- the transpose, for the backward
+ *  in_code[E]              : chem only, bond code a0*3+a1 (a0 = bond type <6, a1 = direction <3)
+ *  dinv[N]                 : (in_degree+1)^-1/2, the GCN normaliser of chem/model.py:73-82
+ *  cfeat[N,KC]             : per-destination edge-feature sums (self loop included), see below
+ *  status[1]               : incremented once per out-of-range index / attribute found
+ * ------------------------------------------------------------------------------------------ */
+size_t pgnn_graph_workspace_bytes(int64_t num_nodes, int64_t num_edges);
+
+/* chem: cfeat[N,9]; columns 0..5 count in-edges per bond type, 6..8 per bond direction, self loop
+ * counted as type 4 / direction 0 (chem/model.py:42-45).  gcn!=0: each count is weighted by the
+ * edge's symmetric normaliser dinv[i]*dinv[src] (chem/model.py:82).  Used for the bond-embedding
+ * gradients: dE[t] = sum_i cfeat[i,t] * dAgg[i]. */
+int pgnn_chem_graph_build(const int64_t* edge_index, const int64_t* edge_attr, int64_t num_edges,
+                          int64_t num_nodes, int gcn, int32_t* in_ptr, int32_t* in_src,
+                          uint8_t* in_code, int32_t* out_ptr, int32_t* out_dst, float* dinv,
+                          float* cfeat, int32_t* status, void* ws, size_t ws_bytes,
+                          pgnn_stream stream);
+
+/* bio: edge_attr is fp32 [E,9]; cfeat[N,10] = [sum of in-edge attr rows + self-loop row e_7,
+ * in_degree+1] (bio/model.py:42-47), so that sum_e edge_encoder(attr_e) = cfeat[i,:] . [W^T; b].
+ * gcn!=0: rows weighted by dinv[i]*dinv[src] (bio/model.py:79-92). */
+int pgnn_bio_graph_build(const int64_t* edge_index, const float* edge_attr, int64_t num_edges,
+                         int64_t num_nodes, int gcn, int32_t* in_ptr, int32_t* in_src,
+                         int32_t* out_ptr, int32_t* out_dst, float* dinv, float* cfeat,
+                         int32_t* status, void* ws, size_t ws_bytes, pgnn_stream stream);
+
+/* Stable grouping of n_items by key in [0,n_keys): ptr[n_keys+1], perm[n_items] (item ids ordered
+ * by (key, id)).  Keys are read with a stride (in int64 elements) so a column of x[N,2] can be
+ * grouped in place.  Used for pooling (key = batch vector, chem/model.py:369) and for the input
+ * embedding gradient (key = atom type, chem/model.py:264). */
+int pgnn_group_by_key(const int64_t* key, int64_t key_stride, int64_t n_items, int64_t n_keys,
+                      int32_t* ptr, int32_t* perm, int32_t* status, void* ws, size_t ws_bytes,
+                      pgnn_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Aggregation (the scatter_add of propagate, chem/model.py:49-52,101-104; bio/model.py:52-55).
+ * ------------------------------------------------------------------------------------------ */
+
+/* chem GIN (dinv == NULL) / chem GCN (dinv != NULL) forward:
+ *   out[i] = sum_{e in in(i)} w_e * (x[src_e] + (emb1[a0_e] + emb2[a1_e])) + w_ii * (x[i] + (emb1[4] + emb2[0]))
+ * with w = 1 (GIN) or dinv[i]*dinv[src] (GCN); additions in the reference's order (edges in
+ * original order, self loop last), no fused multiply-add. */
+int pgnn_chem_aggregate_fwd(const float* x, int64_t ldx, const int32_t* in_ptr,
+                            const int32_t* in_src, const uint8_t* in_code, const float* emb1,
+                            const float* emb2, const float* dinv, float* out, int64_t ldo,
+                            int64_t num_nodes, int64_t dim, pgnn_stream stream);
+
+/* Plain neighbour sum over any CSR (ptr, nbr):  out[i] = sum_p w * x[nbr_p] + w_ii * x[i].
+ * Serves: backward of every aggregation w.r.t. x (with the transposed CSR: chem/model.py:49-52
+ * under autograd), and the x-half of the bio GIN message concat (bio/model.py:54-55). */
+int pgnn_neighbor_sum(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* nbr,
+                      const float* dinv, float* out, int64_t ldo, int64_t num_nodes, int64_t dim,
+                      pgnn_stream stream);
+
+/* out[i,:] (+)= cfeat[i,0:kc] . table[0:kc,:]   (kc <= 16).  bio edge-encoder term of the
+ * aggregation (bio/model.py:47,55) with table = [W^T; b]; accumulate!=0 adds to out. */
+int pgnn_rowfeat_matmul_fwd(const float* cfeat, int64_t kc, const float* table, int64_t ldt,
+                            float* out, int64_t ldo, int64_t num_nodes, int64_t dim,
+                            int accumulate, pgnn_stream stream);
+
+/* gtable[t,:] = sum_i cfeat[i,t] * g[i,:]   (deterministic two-pass reduction).  Gradient of the
+ * bond embeddings (chem) / of the edge encoder (bio). */
+size_t pgnn_rowfeat_matmul_bwd_workspace_bytes(int64_t num_nodes, int64_t kc, int64_t dim);
+int pgnn_rowfeat_matmul_bwd(const float* cfeat, int64_t kc, const float* g, int64_t ldg,
+                            float* gtable, int64_t ldgt, int64_t num_nodes, int64_t dim, void* ws,
+                            size_t ws_bytes, pgnn_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Input embedding (chem/model.py:264; bio/model.py:49-50) and segment reductions
+ * (global_mean_pool / global_add_pool, chem/model.py:324-326,369; chem/pretrain_contextpred.py:28-34).
+ * ------------------------------------------------------------------------------------------ */
+
+/* out[i] = table1[idx[i*idx_stride]] + (table2 ? table2[idx[i*idx_stride+1]] : 0) */
+int pgnn_embed_fwd(const int64_t* idx, int64_t idx_stride, const float* table1, int64_t rows1,
+                   const float* table2, int64_t rows2, float* out, int64_t ldo, int64_t num_nodes,
+                   int64_t dim, int32_t* status, pgnn_stream stream);
+
+/* out[s] = scale_s * sum_{p in [ptr[s],ptr[s+1])} x[perm ? perm[p] : p]; mean!=0: scale = 1/max(len,1).
+ * Any segment length (two-level, deterministic).  With (ptr, perm) from pgnn_group_by_key this is
+ * both the pooling forward and the embedding-table gradient. */
+size_t pgnn_segment_sum_workspace_bytes(int64_t n_items, int64_t n_segments, int64_t dim);
+int pgnn_segment_sum(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* perm,
+                     int64_t n_items, int64_t n_segments, int mean, float* out, int64_t ldo,
+                     int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream);
+
+/* gx[i] = scale * g[key[i]]  (backward of the pooling; mean!=0 divides by the segment length) */
+int pgnn_segment_broadcast(const float* g, int64_t ldg, const int64_t* key, const int32_t* ptr,
+                           int mean, float* gx, int64_t ldgx, int64_t n_items, int64_t dim,
+                           pgnn_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm1d (+ fused ReLU): chem/model.py:252,269-275 (outer BN), bio/model.py:24 (BN in the mlp).
+ * ------------------------------------------------------------------------------------------ */
+size_t pgnn_bn_workspace_bytes(int64_t num_rows, int64_t dim);
+
+/* training != 0: batch statistics (biased variance for normalisation, unbiased for the running
+ * estimate, momentum as torch), running stats updated in place, save_mean/save_invstd written.
+ * training == 0: running statistics. relu != 0 fuses max(.,0). */
+int pgnn_bn_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                float* running_mean, float* running_var, float momentum, float eps, int training,
+                int relu, float* y, int64_t ldy, float* save_mean, float* save_invstd,
+                int64_t num_rows, int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream);
+
+/* Backward of the above (the ReLU mask is recomputed from x, nothing else is kept). */
+int pgnn_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                const float* beta, const float* save_mean, const float* save_invstd, int training,
+                int relu, float* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t num_rows,
+                int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Linear layers of the GIN mlp / GCN linear (chem/model.py:29,54-55,63,99; bio/model.py:24,67,109):
+ * fp32 MFMA GEMMs (v_mfma_f32_16x16x4_f32), exact fp32 accumulate.
+ * ------------------------------------------------------------------------------------------ */
+
+/* y[M,N] = act(x[M,K] . W[N,K]^T + b) ; relu != 0 -> act = max(.,0) */
+int pgnn_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y,
+                    int64_t ldy, int64_t m, int64_t k, int64_t n, int relu, pgnn_stream stream);
+
+/* dx[M,K] = dy[M,N] . W[N,K] ; if relu_out != NULL: dx *= (relu_out > 0)  (relu_out = the
+ * activation this dx flows into, i.e. the forward output of the preceding Linear+ReLU) */
+int pgnn_linear_bwd_data(const float* dy, int64_t lddy, const float* w, const float* relu_out,
+                         int64_t ldr, float* dx, int64_t lddx, int64_t m, int64_t k, int64_t n,
+                         pgnn_stream stream);
+
+/* dW[N,K] = dy[M,N]^T . x[M,K] ; db[N] = column sums of dy (db may be NULL).  Split over M with a
+ * deterministic second-pass reduction. */
+size_t pgnn_linear_bwd_weight_workspace_bytes(int64_t m, int64_t k, int64_t n);
+int pgnn_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw,
+                           float* db, int64_t m, int64_t k, int64_t n, void* ws, size_t ws_bytes,
+                           pgnn_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGNN_H */

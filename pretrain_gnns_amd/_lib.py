@@ -1,0 +1,96 @@
+"""ctypes binding of ``libpgnn.so`` (the C ABI declared in include/pgnn.h).
+
+This is the same stub a maintainer of the reference would add to bind the library (see
+INTEGRATION.md).  There is no fallback: if the shared object is missing or a symbol is absent the
+import of any op raises -- the product path never silently degrades to PyTorch/CPU code.
+torch must be imported first so that the process-wide HIP runtime (libamdhip64.so.7) is the one
+PyTorch-ROCm ships; the library then shares torch's streams and device memory.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads libamdhip64 before libpgnn)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpgnn.so")
+
+_p = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_i = ctypes.c_int
+_f = ctypes.c_float
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/pgnn.h one to one
+PROTOTYPES = {
+    "pgnn_abi_version": (_i, []),
+    "pgnn_last_error": (ctypes.c_char_p, []),
+    "pgnn_graph_workspace_bytes": (_sz, [_i64, _i64]),
+    "pgnn_chem_graph_build": (_i, [_p, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "pgnn_bio_graph_build": (_i, [_p, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "pgnn_group_by_key": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
+    "pgnn_chem_aggregate_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
+    "pgnn_neighbor_sum": (_i, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
+    "pgnn_rowfeat_matmul_fwd": (_i, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i, _p]),
+    "pgnn_rowfeat_matmul_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "pgnn_rowfeat_matmul_bwd": (_i, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _sz, _p]),
+    "pgnn_embed_fwd": (_i, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _p]),
+    "pgnn_segment_sum_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "pgnn_segment_sum": (_i, [_p, _i64, _p, _p, _i64, _i64, _i, _p, _i64, _i64, _p, _sz, _p]),
+    "pgnn_segment_broadcast": (_i, [_p, _i64, _p, _p, _i, _p, _i64, _i64, _i64, _p]),
+    "pgnn_bn_workspace_bytes": (_sz, [_i64, _i64]),
+    "pgnn_bn_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _f, _f, _i, _i, _p, _i64, _p, _p, _i64, _i64, _p, _sz, _p]),
+    "pgnn_bn_bwd": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i, _i, _p, _i64, _p, _p, _i64, _i64, _p, _sz, _p]),
+    "pgnn_linear_fwd": (_i, [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _p]),
+    "pgnn_linear_bwd_data": (_i, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p]),
+    "pgnn_linear_bwd_weight_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "pgnn_linear_bwd_weight": (_i, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),
+}
+
+ABI_VERSION = 1
+
+_lib = None
+
+
+class PgnnError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libpgnn.so once and bind every prototype; raise loudly if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PgnnError(
+            "%s not found: build it with `python -m pretrain_gnns_amd.build` (needs hipcc, gfx950). "
+            "There is no PyTorch/CPU fallback for the HIP hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise PgnnError("libpgnn.so lacks symbol %s (stale build?)" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pgnn_abi_version() != ABI_VERSION:
+        raise PgnnError("libpgnn.so ABI %d != binding ABI %d" % (lib.pgnn_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().pgnn_last_error()
+        raise PgnnError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise PgnnError(
+                "pretrain_gnns_amd runs the message-passing path on an MI355X only; got a %s tensor. "
+                "Move the model and the batch to the GPU (there is no CPU fallback)." % t.device)

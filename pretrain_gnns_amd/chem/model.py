@@ -1,0 +1,206 @@
+"""Drop-in for the reference's ``chem/model.py`` class surface, backed by the gfx950 HIP kernels.
+
+Same class names, constructor signatures, forward overloads, error behaviour and state-dict keys
+as /root/reference/chem/model.py (GINConv :15-55, GCNConv :58-104, GNN :206-290, GNN_graphpred
+:293-369), so ``pretrain_masking.py`` / ``pretrain_contextpred.py`` / ``finetune.py`` can do
+``from model import GNN, GNN_graphpred`` with this directory on ``sys.path`` and run unchanged.
+
+What differs is everything underneath: the per-layer ``add_self_loops`` / attr ``cat`` / embedding
+gather / COO ``scatter_add`` of the reference is replaced by one CSR build per batch plus a fused
+aggregation kernel per layer; the mlp runs on fp32 MFMA GEMMs; BatchNorm+ReLU is one fused pass.
+Tensors must be on the GPU -- there is no CPU path here (the CPU restatement lives in oracle/).
+"""
+import torch
+import torch.nn.functional as F
+
+from pretrain_gnns_amd import ops
+
+num_atom_type = 120  # including the extra mask token (chem/model.py:9)
+num_chirality_tag = 3
+num_bond_type = 6  # including aromatic, self-loop and mask tokens (chem/model.py:12)
+num_bond_direction = 3
+
+
+def _bond_tables(module, emb_dim):
+    module.edge_embedding1 = torch.nn.Embedding(num_bond_type, emb_dim)
+    module.edge_embedding2 = torch.nn.Embedding(num_bond_direction, emb_dim)
+    torch.nn.init.xavier_uniform_(module.edge_embedding1.weight.data)
+    torch.nn.init.xavier_uniform_(module.edge_embedding2.weight.data)
+
+
+class GINConv(torch.nn.Module):
+    """GIN layer with bond-feature messages: mlp(sum_j (x_j + e_ij) + (x_i + e_selfloop))."""
+
+    def __init__(self, emb_dim, aggr="add"):
+        super().__init__()
+        if aggr != "add":
+            raise NotImplementedError("only aggr='add' is on the HIP path")
+        self.mlp = torch.nn.Sequential(torch.nn.Linear(emb_dim, 2 * emb_dim), torch.nn.ReLU(),
+                                       torch.nn.Linear(2 * emb_dim, emb_dim))
+        _bond_tables(self, emb_dim)
+        self.aggr = aggr
+
+    def forward(self, x, edge_index, edge_attr, graph=None):
+        if graph is None:
+            graph = ops.build_chem_graph(edge_index, edge_attr, x.size(0), gcn=False)
+        agg = ops.ChemAggregate.apply(x, self.edge_embedding1.weight, self.edge_embedding2.weight, graph)
+        return ops.MLP2.apply(agg, self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias)
+
+
+class GCNConv(torch.nn.Module):
+    """GCN layer: sum_j deg_i^-1/2 deg_j^-1/2 (W x_j + b + e_ij), self loop included."""
+
+    def __init__(self, emb_dim, aggr="add"):
+        super().__init__()
+        if aggr != "add":
+            raise NotImplementedError("only aggr='add' is on the HIP path")
+        self.emb_dim = emb_dim
+        self.linear = torch.nn.Linear(emb_dim, emb_dim)
+        _bond_tables(self, emb_dim)
+        self.aggr = aggr
+
+    def forward(self, x, edge_index, edge_attr, graph=None):
+        if graph is None:
+            graph = ops.build_chem_graph(edge_index, edge_attr, x.size(0), gcn=True)
+        h = ops.linear(x, self.linear)
+        return ops.ChemAggregate.apply(h, self.edge_embedding1.weight, self.edge_embedding2.weight, graph)
+
+
+class GNN(torch.nn.Module):
+    """Node-embedding network: atom embedding, ``num_layer`` x (conv, BatchNorm, ReLU, dropout).
+
+    Args / output as the reference (chem/model.py:206-221): JK in last|concat|max|sum,
+    gnn_type in gin|gcn (gat / graphsage are not on the HIP hot path).
+    """
+
+    def __init__(self, num_layer, emb_dim, JK="last", drop_ratio=0, gnn_type="gin"):
+        super().__init__()
+        self.num_layer = num_layer
+        self.drop_ratio = drop_ratio
+        self.JK = JK
+        self.gnn_type = gnn_type
+        if self.num_layer < 2:
+            raise ValueError("Number of GNN layers must be greater than 1.")
+
+        self.x_embedding1 = torch.nn.Embedding(num_atom_type, emb_dim)
+        self.x_embedding2 = torch.nn.Embedding(num_chirality_tag, emb_dim)
+        torch.nn.init.xavier_uniform_(self.x_embedding1.weight.data)
+        torch.nn.init.xavier_uniform_(self.x_embedding2.weight.data)
+
+        self.gnns = torch.nn.ModuleList()
+        for _ in range(num_layer):
+            if gnn_type == "gin":
+                self.gnns.append(GINConv(emb_dim, aggr="add"))
+            elif gnn_type == "gcn":
+                self.gnns.append(GCNConv(emb_dim))
+            else:
+                raise NotImplementedError(
+                    "gnn_type=%r: only 'gin' and 'gcn' are implemented on the MI355X hot path" % (gnn_type,))
+
+        self.batch_norms = torch.nn.ModuleList(torch.nn.BatchNorm1d(emb_dim) for _ in range(num_layer))
+
+    def forward(self, *argv):
+        if len(argv) == 3:
+            x, edge_index, edge_attr = argv[0], argv[1], argv[2]
+        elif len(argv) == 1:
+            data = argv[0]
+            x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
+        else:
+            raise ValueError("unmatched number of arguments.")
+
+        # one structure build for all layers, forward and backward
+        graph = ops.build_chem_graph(edge_index, edge_attr, x.size(0), gcn=(self.gnn_type == "gcn"))
+        h = ops.Embed.apply(x, self.x_embedding1.weight, self.x_embedding2.weight)
+
+        h_list = [h]
+        for layer in range(self.num_layer):
+            h = self.gnns[layer](h_list[layer], edge_index, edge_attr, graph)
+            last = layer == self.num_layer - 1
+            h = ops.batch_norm(h, self.batch_norms[layer], relu=not last)  # no ReLU after the last layer
+            if self.drop_ratio > 0:
+                h = F.dropout(h, self.drop_ratio, training=self.training)
+            h_list.append(h)
+
+        if self.JK == "concat":
+            node_representation = torch.cat(h_list, dim=1)
+        elif self.JK == "last":
+            node_representation = h_list[-1]
+        elif self.JK == "max":
+            node_representation = torch.max(torch.stack(h_list, dim=0), dim=0)[0]
+        elif self.JK == "sum":
+            # the reference indexes [0] after the layer sum and so returns node 0's row only
+            # (chem/model.py:286-288); kept for drop-in equality.
+            node_representation = torch.sum(torch.stack(h_list, dim=0), dim=0)[0]
+        else:
+            raise ValueError("unknown JK mode %r" % (self.JK,))
+        return node_representation
+
+
+def global_add_pool(x, batch, size=None):
+    return ops.global_add_pool(x, batch, size)
+
+
+def global_mean_pool(x, batch, size=None):
+    return ops.global_mean_pool(x, batch, size)
+
+
+def global_max_pool(x, batch, size=None):
+    """not on the hot path: plain torch scatter-max on the GPU."""
+    size = int(batch.max().item()) + 1 if size is None else size
+    out = torch.full((size, x.size(1)), float("-inf"), dtype=x.dtype, device=x.device)
+    return out.scatter_reduce(0, batch.unsqueeze(-1).expand_as(x), x, reduce="amax", include_self=True)
+
+
+class GNN_graphpred(torch.nn.Module):
+    """Graph-level head: GNN -> pooling -> Linear (chem/model.py:293-369).
+
+    graph_pooling in sum|mean|max (attention / set2set are outside the hot path).
+    """
+
+    def __init__(self, num_layer, emb_dim, num_tasks, JK="last", drop_ratio=0, graph_pooling="mean", gnn_type="gin"):
+        super().__init__()
+        self.num_layer = num_layer
+        self.drop_ratio = drop_ratio
+        self.JK = JK
+        self.emb_dim = emb_dim
+        self.num_tasks = num_tasks
+        if self.num_layer < 2:
+            raise ValueError("Number of GNN layers must be greater than 1.")
+
+        self.gnn = GNN(num_layer, emb_dim, JK, drop_ratio, gnn_type=gnn_type)
+
+        if graph_pooling == "sum":
+            self.pool = global_add_pool
+        elif graph_pooling == "mean":
+            self.pool = global_mean_pool
+        elif graph_pooling == "max":
+            self.pool = global_max_pool
+        elif graph_pooling == "attention" or graph_pooling[:-1] == "set2set":
+            raise NotImplementedError("graph_pooling=%r is not implemented on the MI355X hot path" % (graph_pooling,))
+        else:
+            raise ValueError("Invalid graph pooling type.")
+
+        self.mult = 1
+        if self.JK == "concat":
+            self.graph_pred_linear = torch.nn.Linear(self.mult * (self.num_layer + 1) * self.emb_dim, self.num_tasks)
+        else:
+            self.graph_pred_linear = torch.nn.Linear(self.mult * self.emb_dim, self.num_tasks)
+
+    def from_pretrained(self, model_file):
+        self.gnn.load_state_dict(torch.load(model_file, map_location=lambda storage, loc: storage))
+
+    def forward(self, *argv):
+        if len(argv) == 4:
+            x, edge_index, edge_attr, batch = argv[0], argv[1], argv[2], argv[3]
+        elif len(argv) == 1:
+            data = argv[0]
+            x, edge_index, edge_attr, batch = data.x, data.edge_index, data.edge_attr, data.batch
+        else:
+            raise ValueError("unmatched number of arguments.")
+
+        node_representation = self.gnn(x, edge_index, edge_attr)
+        return self.graph_pred_linear(self.pool(node_representation, batch))
+
+
+if __name__ == "__main__":
+    pass

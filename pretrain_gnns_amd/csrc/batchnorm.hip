@@ -1,0 +1,294 @@
+// BatchNorm1d (+ fused ReLU) forward / backward over [N, D] fp32 node features (gfx950).
+// Replaces the ATen/cuDNN batch_norm the reference reaches through chem/model.py:252,269-275 and
+// bio/model.py:24.  Pure HBM-bound column reductions + one elementwise pass:
+//   pass 1: per-block partial column sums (float4 loads, rows strided over 4 row-lanes per block)
+//   pass 2: per-column finalize in double (fixed block order -> deterministic)
+//   pass 3: elementwise normalise (+ReLU) / gradient, float4.
+// Statistics use sums shifted by row 0 (K = x[0,:]) so that var = E[(x-K)^2] - E[x-K]^2 does not
+// cancel catastrophically when |mean| >> std.
+#include "common.h"
+
+namespace pgnn {
+namespace {
+
+constexpr int kMaxBlocks = 1024;
+
+// thread t of a (dim/4 x 4)-shaped block: column group c4 = t % d4, row lane rl = t / d4
+// blockDim.x = 4 * d4 rounded up to a multiple of 64.
+__device__ __forceinline__ void block_col_reduce2(float4 a, float4 b, int d4, float* lds, float* dst_a,
+                                                  float* dst_b) {
+  // lds: [2][4][d4*4] floats
+  const int t = threadIdx.x, c4 = t % d4, rl = t / d4, dim = d4 * 4;
+  if (rl < 4) {
+    reinterpret_cast<float4*>(lds + (0 * 4 + rl) * dim)[c4] = a;
+    reinterpret_cast<float4*>(lds + (1 * 4 + rl) * dim)[c4] = b;
+  }
+  __syncthreads();
+  for (int q = t; q < dim; q += blockDim.x) {
+    dst_a[q] = (lds[q] + lds[dim + q]) + (lds[2 * dim + q] + lds[3 * dim + q]);
+    dst_b[q] = (lds[4 * dim + q] + lds[5 * dim + q]) + (lds[6 * dim + q] + lds[7 * dim + q]);
+  }
+}
+
+__global__ void k_bn_stats_partial(const float* __restrict__ x, int64_t ldx, int n, int d4,
+                                   float* __restrict__ partial /*[nblk][2][dim]*/) {
+  extern __shared__ __align__(16) float lds[];
+  const int t = threadIdx.x, c4 = t % d4, rl = t / d4, dim = d4 * 4;
+  const int per = (n + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * per, r1 = min(n, r0 + per);
+  float4 s1 = f4_zero(), s2 = f4_zero();
+  if (rl < 4) {
+    const float4 k = reinterpret_cast<const float4*>(x)[c4];  // shift = row 0
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const float4 v = reinterpret_cast<const float4*>(x + (int64_t)r * ldx)[c4];
+      const float dx = v.x - k.x, dy = v.y - k.y, dz = v.z - k.z, dw = v.w - k.w;
+      s1.x += dx; s1.y += dy; s1.z += dz; s1.w += dw;
+      s2.x = fmaf(dx, dx, s2.x); s2.y = fmaf(dy, dy, s2.y); s2.z = fmaf(dz, dz, s2.z); s2.w = fmaf(dw, dw, s2.w);
+    }
+  }
+  float* p = partial + (size_t)blockIdx.x * 2 * dim;
+  block_col_reduce2(s1, s2, d4, lds, p, p + dim);
+}
+
+// coef[0][dim] = scale a, coef[1][dim] = shift b  (y = a*x + b)
+__global__ void k_bn_stats_final(const float* __restrict__ partial, int nblk, const float* __restrict__ x,
+                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 float* __restrict__ running_mean, float* __restrict__ running_var,
+                                 float momentum, float eps, int training, int n, int dim,
+                                 float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                 float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= dim) return;
+  float mean, invstd;
+  if (training) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+      s1 += (double)partial[(size_t)b * 2 * dim + c];
+      s2 += (double)partial[(size_t)b * 2 * dim + dim + c];
+    }
+    const double m1 = s1 / n;
+    double var = s2 / n - m1 * m1;
+    if (var < 0.0) var = 0.0;
+    mean = (float)((double)x[c] + m1);
+    invstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+      const double unbiased = n > 1 ? var * ((double)n / (double)(n - 1)) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  } else {
+    mean = running_mean[c];
+    invstd = 1.0f / sqrtf(running_var[c] + eps);
+  }
+  if (save_mean) {
+    save_mean[c] = mean;
+    save_invstd[c] = invstd;
+  }
+  const float a = invstd * gamma[c];
+  coef[c] = a;
+  coef[dim + c] = beta[c] - mean * a;
+}
+
+__global__ void k_bn_apply(const float* __restrict__ x, int64_t ldx, const float* __restrict__ coef,
+                           int relu, float* __restrict__ y, int64_t ldy, int n, int d4) {
+  const int t = threadIdx.x, c4 = t % d4, rl = t / d4, dim = d4 * 4;
+  if (rl >= 4) return;
+  const float4 a = reinterpret_cast<const float4*>(coef)[c4];
+  const float4 b = reinterpret_cast<const float4*>(coef + dim)[c4];
+  for (int64_t r = (int64_t)blockIdx.x * 4 + rl; r < n; r += (int64_t)gridDim.x * 4) {
+    const float4 v = reinterpret_cast<const float4*>(x + r * ldx)[c4];
+    float4 o = make_float4(fmaf(a.x, v.x, b.x), fmaf(a.y, v.y, b.y), fmaf(a.z, v.z, b.z), fmaf(a.w, v.w, b.w));
+    if (relu) {
+      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    }
+    reinterpret_cast<float4*>(y + r * ldy)[c4] = o;
+  }
+}
+
+// backward pass 1: partial sums of dyr and dyr*xhat (dyr = dy masked by the recomputed ReLU)
+__global__ void k_bn_bwd_partial(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+                                 int64_t ldx, const float* __restrict__ coef /*a,b,mean,invstd*/, int relu,
+                                 int n, int d4, float* __restrict__ partial) {
+  extern __shared__ __align__(16) float lds[];
+  const int t = threadIdx.x, c4 = t % d4, rl = t / d4, dim = d4 * 4;
+  const int per = (n + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * per, r1 = min(n, r0 + per);
+  float4 s1 = f4_zero(), s2 = f4_zero();
+  if (rl < 4) {
+    const float4 a = reinterpret_cast<const float4*>(coef)[c4];
+    const float4 b = reinterpret_cast<const float4*>(coef + dim)[c4];
+    const float4 mu = reinterpret_cast<const float4*>(coef + 2 * dim)[c4];
+    const float4 is = reinterpret_cast<const float4*>(coef + 3 * dim)[c4];
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const float4 v = reinterpret_cast<const float4*>(x + (int64_t)r * ldx)[c4];
+      float4 g = reinterpret_cast<const float4*>(dy + (int64_t)r * lddy)[c4];
+      if (relu) {
+        if (!(fmaf(a.x, v.x, b.x) > 0.f)) g.x = 0.f;
+        if (!(fmaf(a.y, v.y, b.y) > 0.f)) g.y = 0.f;
+        if (!(fmaf(a.z, v.z, b.z) > 0.f)) g.z = 0.f;
+        if (!(fmaf(a.w, v.w, b.w) > 0.f)) g.w = 0.f;
+      }
+      s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+      s2.x = fmaf(g.x, (v.x - mu.x) * is.x, s2.x);
+      s2.y = fmaf(g.y, (v.y - mu.y) * is.y, s2.y);
+      s2.z = fmaf(g.z, (v.z - mu.z) * is.z, s2.z);
+      s2.w = fmaf(g.w, (v.w - mu.w) * is.w, s2.w);
+    }
+  }
+  float* p = partial + (size_t)blockIdx.x * 2 * dim;
+  block_col_reduce2(s1, s2, d4, lds, p, p + dim);
+}
+
+// coef layout for backward: [a, b, mean, invstd, k1, k2, k3] each [dim]
+//   dx = k1*dyr + k2*(x-mean) + k3   with k1 = gamma*invstd;
+//   training: k2 = -k1*invstd*mean(dyr*xhat), k3 = -k1*mean(dyr); eval: k2 = k3 = 0
+__global__ void k_bn_bwd_prepare(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                 int dim, float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= dim) return;
+  const float a = save_invstd[c] * gamma[c];
+  coef[c] = a;
+  coef[dim + c] = beta[c] - save_mean[c] * a;
+  coef[2 * dim + c] = save_mean[c];
+  coef[3 * dim + c] = save_invstd[c];
+}
+
+__global__ void k_bn_bwd_final(const float* __restrict__ partial, int nblk, int training, int n, int dim,
+                               const float* __restrict__ gamma, float* __restrict__ coef,
+                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= dim) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s1 += (double)partial[(size_t)b * 2 * dim + c];
+    s2 += (double)partial[(size_t)b * 2 * dim + dim + c];
+  }
+  if (dgamma) dgamma[c] = (float)s2;
+  if (dbeta) dbeta[c] = (float)s1;
+  const float invstd = coef[3 * dim + c];
+  const float k1 = gamma[c] * invstd;
+  // dx = k1 * (dyr - s1/n - xhat * s2/n),  xhat = (x - mean)*invstd
+  float k2 = 0.f, k3 = 0.f;
+  if (training) {
+    const float m1 = (float)(s1 / n), m2 = (float)(s2 / n);
+    k2 = -k1 * invstd * m2;  // multiplies (x - mean)
+    k3 = -k1 * m1;
+  }
+  coef[4 * dim + c] = k1;
+  coef[5 * dim + c] = k2;
+  coef[6 * dim + c] = k3;
+}
+
+__global__ void k_bn_bwd_apply(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+                               int64_t ldx, const float* __restrict__ coef, int relu, float* __restrict__ dx,
+                               int64_t lddx, int n, int d4) {
+  const int t = threadIdx.x, c4 = t % d4, rl = t / d4, dim = d4 * 4;
+  if (rl >= 4) return;
+  const float4 a = reinterpret_cast<const float4*>(coef)[c4];
+  const float4 b = reinterpret_cast<const float4*>(coef + dim)[c4];
+  const float4 mu = reinterpret_cast<const float4*>(coef + 2 * dim)[c4];
+  const float4 k1 = reinterpret_cast<const float4*>(coef + 4 * dim)[c4];
+  const float4 k2 = reinterpret_cast<const float4*>(coef + 5 * dim)[c4];
+  const float4 k3 = reinterpret_cast<const float4*>(coef + 6 * dim)[c4];
+  for (int64_t r = (int64_t)blockIdx.x * 4 + rl; r < n; r += (int64_t)gridDim.x * 4) {
+    const float4 v = reinterpret_cast<const float4*>(x + r * ldx)[c4];
+    float4 g = reinterpret_cast<const float4*>(dy + r * lddy)[c4];
+    if (relu) {
+      if (!(fmaf(a.x, v.x, b.x) > 0.f)) g.x = 0.f;
+      if (!(fmaf(a.y, v.y, b.y) > 0.f)) g.y = 0.f;
+      if (!(fmaf(a.z, v.z, b.z) > 0.f)) g.z = 0.f;
+      if (!(fmaf(a.w, v.w, b.w) > 0.f)) g.w = 0.f;
+    }
+    float4 o;
+    o.x = fmaf(k1.x, g.x, fmaf(k2.x, v.x - mu.x, k3.x));
+    o.y = fmaf(k1.y, g.y, fmaf(k2.y, v.y - mu.y, k3.y));
+    o.z = fmaf(k1.z, g.z, fmaf(k2.z, v.z - mu.z, k3.z));
+    o.w = fmaf(k1.w, g.w, fmaf(k2.w, v.w - mu.w, k3.w));
+    reinterpret_cast<float4*>(dx + r * lddx)[c4] = o;
+  }
+}
+
+inline int stat_blocks(int64_t n) {
+  return (int)std::min<int64_t>(std::max<int64_t>(ceil_div(n, 32), 1), kMaxBlocks);
+}
+inline int stat_threads(int64_t dim) { return (int)align_up((size_t)dim, 64); }  // 4 row lanes x dim/4
+
+inline int check_args(int64_t n, int64_t dim) {
+  if (n <= 0 || dim <= 0 || dim % 4 != 0 || dim > 1024) {
+    set_error("batchnorm: need N > 0 and feature width a multiple of 4 in (0,1024] (N=%lld D=%lld)",
+              (long long)n, (long long)dim);
+    return PGNN_ERR_ARG;
+  }
+  return PGNN_OK;
+}
+
+}  // namespace
+}  // namespace pgnn
+
+using namespace pgnn;
+
+extern "C" {
+
+size_t pgnn_bn_workspace_bytes(int64_t n, int64_t dim) {
+  return align_up((size_t)stat_blocks(n) * 2 * dim * sizeof(float), 256) + align_up((size_t)7 * dim * sizeof(float), 256);
+}
+
+int pgnn_bn_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* running_mean,
+                float* running_var, float momentum, float eps, int training, int relu, float* y, int64_t ldy,
+                float* save_mean, float* save_invstd, int64_t n, int64_t dim, void* ws, size_t ws_bytes,
+                pgnn_stream stream) {
+  if (int rc = check_args(n, dim)) return rc;
+  PGNN_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "batchnorm: leading dimensions must be multiples of 4");
+  PGNN_REQUIRE(training || (running_mean && running_var), "batchnorm eval needs running statistics");
+  if (ws_bytes < pgnn_bn_workspace_bytes(n, dim)) {
+    set_error("batchnorm workspace too small");
+    return PGNN_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  Carver cv(ws);
+  const int nblk = stat_blocks(n);
+  float* partial = cv.take<float>((size_t)nblk * 2 * dim);
+  float* coef = cv.take<float>((size_t)7 * dim);
+  const int d4 = (int)(dim / 4);
+  if (training) {
+    hipLaunchKernelGGL(k_bn_stats_partial, dim3(nblk), dim3(stat_threads(dim)), (size_t)8 * dim * sizeof(float),
+                       st, x, ldx, (int)n, d4, partial);
+  }
+  hipLaunchKernelGGL(k_bn_stats_final, dim3((int)ceil_div(dim, 256)), dim3(256), 0, st, partial, nblk, x, gamma,
+                     beta, running_mean, running_var, momentum, eps, training, (int)n, (int)dim, save_mean,
+                     save_invstd, coef);
+  const int grid = (int)std::min<int64_t>(ceil_div(n, 4), (int64_t)kNumCU * 16);
+  hipLaunchKernelGGL(k_bn_apply, dim3(grid), dim3(stat_threads(dim)), 0, st, x, ldx, coef, relu, y, ldy, (int)n, d4);
+  return check_launch("bn_fwd");
+}
+
+int pgnn_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                const float* beta, const float* save_mean, const float* save_invstd, int training, int relu,
+                float* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t n, int64_t dim, void* ws,
+                size_t ws_bytes, pgnn_stream stream) {
+  if (int rc = check_args(n, dim)) return rc;
+  PGNN_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "batchnorm: leading dimensions must be multiples of 4");
+  if (ws_bytes < pgnn_bn_workspace_bytes(n, dim)) {
+    set_error("batchnorm workspace too small");
+    return PGNN_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  Carver cv(ws);
+  const int nblk = stat_blocks(n);
+  float* partial = cv.take<float>((size_t)nblk * 2 * dim);
+  float* coef = cv.take<float>((size_t)7 * dim);
+  const int d4 = (int)(dim / 4);
+  const int cb = (int)ceil_div(dim, 256);
+  hipLaunchKernelGGL(k_bn_bwd_prepare, dim3(cb), dim3(256), 0, st, gamma, beta, save_mean, save_invstd, (int)dim, coef);
+  hipLaunchKernelGGL(k_bn_bwd_partial, dim3(nblk), dim3(stat_threads(dim)), (size_t)8 * dim * sizeof(float), st, dy,
+                     lddy, x, ldx, coef, relu, (int)n, d4, partial);
+  hipLaunchKernelGGL(k_bn_bwd_final, dim3(cb), dim3(256), 0, st, partial, nblk, training, (int)n, (int)dim, gamma,
+                     coef, dgamma, dbeta);
+  const int grid = (int)std::min<int64_t>(ceil_div(n, 4), (int64_t)kNumCU * 16);
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid), dim3(stat_threads(dim)), 0, st, dy, lddy, x, ldx, coef, relu, dx, lddx,
+                     (int)n, d4);
+  return check_launch("bn_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+// Shared host/device helpers for the pgnn HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/pgnn.h"
+
+namespace pgnn {
+
+constexpr int kWave = 64;         // CDNA wavefront
+constexpr int kNumCU = 256;       // MI355X
+constexpr int kNumXCD = 8;
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return PGNN_ERR_HIP;
+  }
+  return PGNN_OK;
+}
+
+#define PGNN_REQUIRE(cond, ...)        \
+  do {                                 \
+    if (!(cond)) {                     \
+      ::pgnn::set_error(__VA_ARGS__);  \
+      return PGNN_ERR_ARG;             \
+    }                                  \
+  } while (0)
+
+#define PGNN_HIP(call)                                                    \
+  do {                                                                    \
+    hipError_t e_ = (call);                                               \
+    if (e_ != hipSuccess) {                                               \
+      ::pgnn::set_error("%s: %s", #call, hipGetErrorString(e_));          \
+      return PGNN_ERR_HIP;                                                \
+    }                                                                     \
+  } while (0)
+
+// dynamic LDS above the 64 KiB default needs an explicit opt-in (gfx950 has 160 KiB per CU)
+inline void allow_big_lds(const void* func, size_t bytes) {
+  if (bytes > 64 * 1024) (void)hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Carve sub-buffers out of a caller-provided workspace (256 B aligned).
+struct Carver {
+  char* base;
+  size_t used = 0;
+  explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+  template <typename T>
+  T* take(size_t n) {
+    T* p = reinterpret_cast<T*>(base + used);
+    used += align_up(n * sizeof(T), 256);
+    return p;
+  }
+};
+
+// XCD-aware block remap: consecutive logical blocks land on the same XCD (same L2) instead of
+// being dealt round-robin over the 8 XCDs.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  const int q = nblocks / kNumXCD, r = nblocks % kNumXCD;
+  const int xcd = bid % kNumXCD, slot = bid / kNumXCD;
+  const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + slot;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+// wave-uniform broadcast of lane `src`'s value into a scalar register
+__device__ __forceinline__ int bcast_i32(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__device__ __forceinline__ float4 f4_scale(float4 a, float s) {
+  return make_float4(a.x * s, a.y * s, a.z * s, a.w * s);
+}
+__device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+}  // namespace pgnn

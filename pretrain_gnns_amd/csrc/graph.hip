@@ -1,0 +1,370 @@
+// Graph-structure construction for the message-passing hot path (gfx950).
+//
+// Replaces, once per batch, what the reference redoes in every layer: add_self_loops + attr cat
+// (chem/model.py:39-45, bio/model.py:39-45) and the COO gather/scatter of propagate.  Output is a
+// stable CSR by destination (forward) and by source (backward) in int32, a packed bond code per
+// edge, the GCN normaliser, and per-node edge-feature sums ("cfeat") that turn the edge-embedding
+// gradients into a tall-skinny reduction.  All kernels are HBM/latency-bound integer work.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace pgnn {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+namespace {
+
+constexpr int kScanItems = 1024;  // per block: 256 threads x 4
+constexpr int kSmallSeg = 16;
+
+struct GroupJob {
+  const int64_t* key;
+  int64_t stride;
+  int32_t* ptr;     // [n_keys+1]
+  int32_t* perm;    // [n_items]  final (sorted inside each segment)
+  int32_t* cursor;  // [n_keys]   zeroed
+  int32_t* tmp;     // [n_items]  unsorted fill
+  int32_t* bsum;    // [ceil((n_keys+1)/kScanItems)]
+};
+struct GroupJobs {
+  GroupJob j[2];
+};
+
+__global__ void k_hist(GroupJobs jobs, int64_t n_items, int64_t n_keys, int32_t* status) {
+  const GroupJob& job = jobs.j[blockIdx.y];
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n_items;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t k = job.key[e * job.stride];
+    if (k < 0 || k >= n_keys) {
+      atomicAdd(status, 1);
+      k = 0;  // clamp: keeps every later access in bounds; the caller inspects status
+    }
+    atomicAdd(&job.ptr[k + 1], 1);
+  }
+}
+
+__device__ __forceinline__ int block_scan_256(int v, int* lds, int& block_total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    int t = __shfl_up(v, off);
+    if (lane >= off) v += t;
+  }
+  if (lane == 63) lds[w] = v;
+  __syncthreads();
+  int add = 0;
+  for (int i = 0; i < w; ++i) add += lds[i];
+  block_total = lds[0] + lds[1] + lds[2] + lds[3];
+  __syncthreads();
+  return v + add;
+}
+
+// in-place inclusive scan of each 1024-item chunk; chunk totals to bsum
+__global__ void __launch_bounds__(256) k_scan_local(GroupJobs jobs, int64_t n) {
+  __shared__ int lds[4];
+  const GroupJob& job = jobs.j[blockIdx.y];
+  int32_t* d = job.ptr;
+  const int64_t base = (int64_t)blockIdx.x * kScanItems + threadIdx.x * 4;
+  int v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = (base + i < n) ? d[base + i] : 0;
+  v[1] += v[0];
+  v[2] += v[1];
+  v[3] += v[2];
+  int total;
+  const int incl = block_scan_256(v[3], lds, total);
+  const int excl = incl - v[3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (base + i < n) d[base + i] = v[i] + excl;
+  if (threadIdx.x == 0) job.bsum[blockIdx.x] = total;
+}
+
+// exclusive scan of the chunk totals (single block per job, any count)
+__global__ void __launch_bounds__(256) k_scan_bsum(GroupJobs jobs, int nb) {
+  __shared__ int lds[4];
+  int32_t* b = jobs.j[blockIdx.y].bsum;
+  int carry = 0;
+  for (int base = 0; base < nb; base += 256) {
+    const int i = base + threadIdx.x;
+    const int v = i < nb ? b[i] : 0;
+    int total;
+    const int incl = block_scan_256(v, lds, total);
+    if (i < nb) b[i] = carry + incl - v;
+    carry += total;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_scan_add(GroupJobs jobs, int64_t n) {
+  const GroupJob& job = jobs.j[blockIdx.y];
+  const int add = job.bsum[blockIdx.x + 1];
+  const int64_t base = (int64_t)(blockIdx.x + 1) * kScanItems + threadIdx.x * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (base + i < n) job.ptr[base + i] += add;
+}
+
+__global__ void k_fill(GroupJobs jobs, int64_t n_items, int64_t n_keys) {
+  const GroupJob& job = jobs.j[blockIdx.y];
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n_items;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t k = job.key[e * job.stride];
+    if (k < 0 || k >= n_keys) k = 0;
+    const int pos = atomicAdd(&job.cursor[k], 1);
+    job.tmp[job.ptr[k] + pos] = (int32_t)e;
+  }
+}
+
+// The atomic fill is order-nondeterministic; ranking the (unique) item ids inside each segment
+// restores the original order => stable grouping, bitwise-reproducible downstream sums.
+__global__ void __launch_bounds__(256) k_sort_segments(GroupJobs jobs, int64_t n_keys) {
+  const GroupJob& job = jobs.j[blockIdx.y];
+  const int64_t seg = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int beg = 0, len = 0;
+  if (seg < n_keys) {
+    beg = job.ptr[seg];
+    len = job.ptr[seg + 1] - beg;
+  }
+  if (len <= kSmallSeg) {
+    for (int a = 0; a < len; ++a) {
+      const int v = job.tmp[beg + a];
+      int rank = 0;
+      for (int b = 0; b < len; ++b) rank += job.tmp[beg + b] < v;
+      job.perm[beg + rank] = v;
+    }
+  }
+  unsigned long long m = __ballot(len > kSmallSeg);
+  const int lane = lane_id();
+  while (m) {
+    const int src = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const int b = __shfl(beg, src), l = __shfl(len, src);
+    for (int p = lane; p < l; p += kWave) {
+      const int v = job.tmp[b + p];
+      int rank = 0;
+      for (int q = 0; q < l; ++q) rank += job.tmp[b + q] < v;
+      job.perm[b + rank] = v;
+    }
+  }
+}
+
+int run_group(GroupJobs jobs, int njobs, int64_t n_items, int64_t n_keys, int32_t* status,
+              hipStream_t st) {
+  const int64_t n = n_keys + 1;
+  const int nb = (int)ceil_div(n, kScanItems);
+  const int gi = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(n_items, 256), 1), 4096);
+  if (n_items > 0) {
+    hipLaunchKernelGGL(k_hist, dim3(gi, njobs), dim3(256), 0, st, jobs, n_items, n_keys, status);
+  }
+  hipLaunchKernelGGL(k_scan_local, dim3(nb, njobs), dim3(256), 0, st, jobs, n);
+  if (nb > 1) {
+    hipLaunchKernelGGL(k_scan_bsum, dim3(1, njobs), dim3(256), 0, st, jobs, nb);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb - 1, njobs), dim3(256), 0, st, jobs, n);
+  }
+  if (n_items > 0) {
+    hipLaunchKernelGGL(k_fill, dim3(gi, njobs), dim3(256), 0, st, jobs, n_items, n_keys);
+    hipLaunchKernelGGL(k_sort_segments, dim3((int)ceil_div(n_keys, 256), njobs), dim3(256), 0, st,
+                       jobs, n_keys);
+  }
+  return check_launch("group_by_key");
+}
+
+size_t group_ws_bytes(int64_t n_keys, int64_t n_items) {
+  return align_up((size_t)n_keys * 4, 256) + align_up((size_t)n_items * 4, 256) +
+         align_up((size_t)ceil_div(n_keys + 1, kScanItems) * 4, 256);
+}
+
+__global__ void k_dinv(const int32_t* __restrict__ in_ptr, float* __restrict__ dinv, int64_t n) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) dinv[i] = 1.0f / sqrtf((float)(in_ptr[i + 1] - in_ptr[i] + 1));
+}
+
+__global__ void __launch_bounds__(256)
+k_chem_payload(const int64_t* __restrict__ ei, const int64_t* __restrict__ ea, int64_t E, int64_t N,
+               int gcn, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ perm_in,
+               int32_t* __restrict__ in_src, uint8_t* __restrict__ in_code,
+               const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ perm_out,
+               int32_t* __restrict__ out_dst, const float* __restrict__ dinv,
+               float* __restrict__ cfeat, int32_t* status) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float di = dinv[i];
+  float c[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) c[t] = 0.f;
+  for (int p = in_ptr[i]; p < in_ptr[i + 1]; ++p) {
+    const int e = perm_in[p];
+    int64_t s = ei[E + e];
+    if (s < 0 || s >= N) s = 0;  // already counted in status by the histogram of the source keys
+    int64_t a0 = ea[2 * (int64_t)e], a1 = ea[2 * (int64_t)e + 1];
+    if (a0 < 0 || a0 >= 6 || a1 < 0 || a1 >= 3) {
+      atomicAdd(status, 1);
+      a0 = 0;
+      a1 = 0;
+    }
+    in_src[p] = (int32_t)s;
+    in_code[p] = (uint8_t)(a0 * 3 + a1);
+    const float w = gcn ? di * dinv[s] : 1.0f;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) c[t] += (a0 == t) ? w : 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) c[6 + t] += (a1 == t) ? w : 0.f;
+  }
+  const float ws = gcn ? di * di : 1.0f;  // self loop: bond type 4, direction 0
+  c[4] += ws;
+  c[6] += ws;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) cfeat[i * 9 + t] = c[t];
+  for (int p = out_ptr[i]; p < out_ptr[i + 1]; ++p) {
+    int64_t d = ei[perm_out[p]];
+    if (d < 0 || d >= N) d = 0;
+    out_dst[p] = (int32_t)d;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_bio_payload(const int64_t* __restrict__ ei, const float* __restrict__ ea, int64_t E, int64_t N,
+              int gcn, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ perm_in,
+              int32_t* __restrict__ in_src, const int32_t* __restrict__ out_ptr,
+              const int32_t* __restrict__ perm_out, int32_t* __restrict__ out_dst,
+              const float* __restrict__ dinv, float* __restrict__ cfeat) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float di = dinv[i];
+  float c[10];
+#pragma unroll
+  for (int t = 0; t < 10; ++t) c[t] = 0.f;
+  for (int p = in_ptr[i]; p < in_ptr[i + 1]; ++p) {
+    const int e = perm_in[p];
+    int64_t s = ei[E + e];
+    if (s < 0 || s >= N) s = 0;
+    in_src[p] = (int32_t)s;
+    const float w = gcn ? di * dinv[s] : 1.0f;
+    const float* a = ea + (int64_t)e * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) c[t] += w * a[t];
+    c[9] += w;
+  }
+  const float ws = gcn ? di * di : 1.0f;  // self loop attr = one-hot(7), bio/model.py:42-43
+  c[7] += ws;
+  c[9] += ws;
+#pragma unroll
+  for (int t = 0; t < 10; ++t) cfeat[i * 10 + t] = c[t];
+  for (int p = out_ptr[i]; p < out_ptr[i + 1]; ++p) {
+    int64_t d = ei[perm_out[p]];
+    if (d < 0 || d >= N) d = 0;
+    out_dst[p] = (int32_t)d;
+  }
+}
+
+struct GraphWs {
+  GroupJobs jobs;
+  int32_t *perm_in, *perm_out;
+};
+
+int prepare_graph_jobs(const int64_t* ei, int64_t E, int64_t N, int32_t* in_ptr, int32_t* out_ptr,
+                       void* ws, size_t ws_bytes, hipStream_t st, GraphWs& g) {
+  if (ws_bytes < pgnn_graph_workspace_bytes(N, E)) {
+    set_error("graph workspace too small: %zu < %zu", ws_bytes, pgnn_graph_workspace_bytes(N, E));
+    return PGNN_ERR_WORKSPACE;
+  }
+  Carver cv(ws);
+  int32_t* cursors = cv.take<int32_t>(2 * (size_t)N);
+  g.perm_in = cv.take<int32_t>((size_t)E);
+  g.perm_out = cv.take<int32_t>((size_t)E);
+  int32_t* tmp_in = cv.take<int32_t>((size_t)E);
+  int32_t* tmp_out = cv.take<int32_t>((size_t)E);
+  const size_t nb = (size_t)ceil_div(N + 1, kScanItems);
+  int32_t* bs_in = cv.take<int32_t>(nb);
+  int32_t* bs_out = cv.take<int32_t>(nb);
+  PGNN_HIP(hipMemsetAsync(cursors, 0, 2 * (size_t)N * 4, st));
+  PGNN_HIP(hipMemsetAsync(in_ptr, 0, (size_t)(N + 1) * 4, st));
+  PGNN_HIP(hipMemsetAsync(out_ptr, 0, (size_t)(N + 1) * 4, st));
+  g.jobs.j[0] = GroupJob{ei, 1, in_ptr, g.perm_in, cursors, tmp_in, bs_in};           // by destination
+  g.jobs.j[1] = GroupJob{ei + E, 1, out_ptr, g.perm_out, cursors + N, tmp_out, bs_out};  // by source
+  return PGNN_OK;
+}
+
+}  // namespace
+}  // namespace pgnn
+
+using namespace pgnn;
+
+extern "C" {
+
+int pgnn_abi_version(void) { return PGNN_ABI_VERSION; }
+const char* pgnn_last_error(void) { return pgnn::g_err; }
+
+size_t pgnn_graph_workspace_bytes(int64_t N, int64_t E) {
+  return align_up(2 * (size_t)N * 4, 256) + 4 * align_up((size_t)E * 4, 256) +
+         2 * align_up((size_t)ceil_div(N + 1, kScanItems) * 4, 256) + 256;
+}
+
+int pgnn_chem_graph_build(const int64_t* ei, const int64_t* ea, int64_t E, int64_t N, int gcn,
+                          int32_t* in_ptr, int32_t* in_src, uint8_t* in_code, int32_t* out_ptr,
+                          int32_t* out_dst, float* dinv, float* cfeat, int32_t* status, void* ws,
+                          size_t ws_bytes, pgnn_stream stream) {
+  PGNN_REQUIRE(N > 0 && E >= 0 && N < (1ll << 31) && E < (1ll << 31), "bad graph size N=%lld E=%lld",
+               (long long)N, (long long)E);
+  hipStream_t st = (hipStream_t)stream;
+  GraphWs g;
+  int rc = prepare_graph_jobs(ei, E, N, in_ptr, out_ptr, ws, ws_bytes, st, g);
+  if (rc) return rc;
+  rc = run_group(g.jobs, 2, E, N, status, st);
+  if (rc) return rc;
+  const int nbk = (int)ceil_div(N, 256);
+  hipLaunchKernelGGL(k_dinv, dim3(nbk), dim3(256), 0, st, in_ptr, dinv, N);
+  hipLaunchKernelGGL(k_chem_payload, dim3(nbk), dim3(256), 0, st, ei, ea, E, N, gcn, in_ptr,
+                     g.perm_in, in_src, in_code, out_ptr, g.perm_out, out_dst, dinv, cfeat, status);
+  return check_launch("chem_graph_build");
+}
+
+int pgnn_bio_graph_build(const int64_t* ei, const float* ea, int64_t E, int64_t N, int gcn,
+                         int32_t* in_ptr, int32_t* in_src, int32_t* out_ptr, int32_t* out_dst,
+                         float* dinv, float* cfeat, int32_t* status, void* ws, size_t ws_bytes,
+                         pgnn_stream stream) {
+  PGNN_REQUIRE(N > 0 && E >= 0 && N < (1ll << 31) && E < (1ll << 31), "bad graph size N=%lld E=%lld",
+               (long long)N, (long long)E);
+  hipStream_t st = (hipStream_t)stream;
+  GraphWs g;
+  int rc = prepare_graph_jobs(ei, E, N, in_ptr, out_ptr, ws, ws_bytes, st, g);
+  if (rc) return rc;
+  rc = run_group(g.jobs, 2, E, N, status, st);
+  if (rc) return rc;
+  const int nbk = (int)ceil_div(N, 256);
+  hipLaunchKernelGGL(k_dinv, dim3(nbk), dim3(256), 0, st, in_ptr, dinv, N);
+  hipLaunchKernelGGL(k_bio_payload, dim3(nbk), dim3(256), 0, st, ei, ea, E, N, gcn, in_ptr,
+                     g.perm_in, in_src, out_ptr, g.perm_out, out_dst, dinv, cfeat);
+  return check_launch("bio_graph_build");
+}
+
+int pgnn_group_by_key(const int64_t* key, int64_t key_stride, int64_t n_items, int64_t n_keys,
+                      int32_t* ptr, int32_t* perm, int32_t* status, void* ws, size_t ws_bytes,
+                      pgnn_stream stream) {
+  PGNN_REQUIRE(n_keys > 0 && n_items >= 0 && key_stride >= 1, "bad group_by_key sizes");
+  if (ws_bytes < group_ws_bytes(n_keys, n_items)) {
+    set_error("group_by_key workspace too small");
+    return PGNN_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  Carver cv(ws);
+  GroupJobs jobs;
+  int32_t* cursor = cv.take<int32_t>((size_t)n_keys);
+  int32_t* tmp = cv.take<int32_t>((size_t)n_items);
+  int32_t* bsum = cv.take<int32_t>((size_t)ceil_div(n_keys + 1, kScanItems));
+  PGNN_HIP(hipMemsetAsync(cursor, 0, (size_t)n_keys * 4, st));
+  PGNN_HIP(hipMemsetAsync(ptr, 0, (size_t)(n_keys + 1) * 4, st));
+  jobs.j[0] = GroupJob{key, key_stride, ptr, perm, cursor, tmp, bsum};
+  jobs.j[1] = jobs.j[0];
+  return run_group(jobs, 1, n_items, n_keys, status, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,464 @@
+"""torch.autograd bindings of the HIP hot path (include/pgnn.h) -- host-side plumbing only.
+
+Every function here launches hand-written gfx950 kernels through the C ABI on
+``torch.cuda.current_stream()``; PyTorch supplies device memory, streams and the autograd tape,
+nothing else.  Inputs must live on the GPU: there is deliberately no CPU / eager fallback.
+"""
+import os
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from ._lib import check, load, require_cuda, stream_ptr
+
+_CHECK_INDICES = os.environ.get("PGNN_CHECK_INDICES", "0") == "1"
+_ws_cache = {}
+
+
+def _ws_bytes(fn_name, *shape):
+    key = (fn_name,) + shape
+    v = _ws_cache.get(key)
+    if v is None:
+        v = int(getattr(load(), fn_name)(*shape))
+        _ws_cache[key] = v
+    return v
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise _lib.PgnnError("expected float32 tensor, got %s" % t.dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _rows2d(t):
+    """accept a 2-D fp32 tensor whose rows are contiguous (row stride = leading dimension)."""
+    if t.dtype != torch.float32:
+        raise _lib.PgnnError("expected float32 tensor, got %s" % t.dtype)
+    if t.dim() != 2 or t.stride(1) != 1 or t.stride(0) % 4 != 0 or t.data_ptr() % 16 != 0:
+        t = t.contiguous()
+    return t
+
+
+# ------------------------------------------------------------------------------------ graph
+class GraphStruct:
+    """CSR-by-destination + CSR-by-source + per-node edge-feature sums of one batch."""
+
+    __slots__ = ("kind", "gcn", "n", "e", "in_ptr", "in_src", "in_code", "out_ptr", "out_dst", "dinv", "cfeat",
+                 "status")
+
+    @property
+    def kc(self):
+        return self.cfeat.size(1)
+
+    def check(self):
+        bad = int(self.status.item())
+        if bad:
+            raise IndexError("%d out-of-range node indices / edge attributes in the batch" % bad)
+
+
+def _build_graph(kind, edge_index, edge_attr, num_nodes, gcn):
+    require_cuda(edge_index, edge_attr)
+    lib = load()
+    dev = edge_index.device
+    if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
+        raise _lib.PgnnError("edge_index must be int64 [2, E]")
+    ei = edge_index.contiguous()
+    e, n = ei.size(1), int(num_nodes)
+    g = GraphStruct()
+    g.kind, g.gcn, g.n, g.e = kind, bool(gcn), n, e
+    g.in_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    g.out_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    g.in_src = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+    g.out_dst = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+    g.dinv = torch.empty(n, dtype=torch.float32, device=dev)
+    g.status = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = _workspace(_ws_bytes("pgnn_graph_workspace_bytes", n, e), dev)
+    if kind == "chem":
+        if edge_attr.dtype != torch.int64 or edge_attr.dim() != 2 or edge_attr.size(1) != 2:
+            raise _lib.PgnnError("chem edge_attr must be int64 [E, 2]")
+        ea = edge_attr.contiguous()
+        g.in_code = torch.empty(max(e, 1), dtype=torch.uint8, device=dev)
+        g.cfeat = torch.empty(n, 9, dtype=torch.float32, device=dev)
+        check(lib.pgnn_chem_graph_build(ei.data_ptr(), ea.data_ptr(), e, n, int(g.gcn), g.in_ptr.data_ptr(),
+                                        g.in_src.data_ptr(), g.in_code.data_ptr(), g.out_ptr.data_ptr(),
+                                        g.out_dst.data_ptr(), g.dinv.data_ptr(), g.cfeat.data_ptr(),
+                                        g.status.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()),
+              "pgnn_chem_graph_build")
+    else:
+        if edge_attr.dim() != 2 or edge_attr.size(1) != 9:
+            raise _lib.PgnnError("bio edge_attr must be [E, 9]")
+        ea = edge_attr.to(torch.float32).contiguous()
+        g.in_code = None
+        g.cfeat = torch.empty(n, 10, dtype=torch.float32, device=dev)
+        check(lib.pgnn_bio_graph_build(ei.data_ptr(), ea.data_ptr(), e, n, int(g.gcn), g.in_ptr.data_ptr(),
+                                       g.in_src.data_ptr(), g.out_ptr.data_ptr(), g.out_dst.data_ptr(),
+                                       g.dinv.data_ptr(), g.cfeat.data_ptr(), g.status.data_ptr(), ws.data_ptr(),
+                                       ws.numel(), stream_ptr()),
+              "pgnn_bio_graph_build")
+    if _CHECK_INDICES:
+        g.check()
+    return g
+
+
+def build_chem_graph(edge_index, edge_attr, num_nodes, gcn=False):
+    return _build_graph("chem", edge_index, edge_attr, num_nodes, gcn)
+
+
+def build_bio_graph(edge_index, edge_attr, num_nodes, gcn=False):
+    return _build_graph("bio", edge_index, edge_attr, num_nodes, gcn)
+
+
+def group_by_key(key, n_keys, stride=1, offset=0):
+    """stable grouping of items by int64 key -> (ptr[n_keys+1], perm[n_items]) int32."""
+    require_cuda(key)
+    dev = key.device
+    n_items = key.numel() // stride
+    ptr = torch.empty(n_keys + 1, dtype=torch.int32, device=dev)
+    perm = torch.empty(max(n_items, 1), dtype=torch.int32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = _workspace(_ws_bytes("pgnn_graph_workspace_bytes", n_keys, n_items), dev)
+    check(load().pgnn_group_by_key(key.data_ptr() + 8 * offset, stride, n_items, n_keys, ptr.data_ptr(),
+                                   perm.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()),
+          "pgnn_group_by_key")
+    if _CHECK_INDICES and int(status.item()):
+        raise IndexError("key out of range in group_by_key")
+    return ptr, perm
+
+
+# ------------------------------------------------------------------------------------ raw launches
+def _neighbor_sum(x, ptr, nbr, dinv, n, dim, out=None):
+    x = _rows2d(x)
+    if out is None:
+        out = torch.empty(n, dim, dtype=torch.float32, device=x.device)
+    check(load().pgnn_neighbor_sum(x.data_ptr(), x.stride(0), ptr.data_ptr(), nbr.data_ptr(),
+                                   dinv.data_ptr() if dinv is not None else None, out.data_ptr(), out.stride(0),
+                                   n, dim, stream_ptr()), "pgnn_neighbor_sum")
+    return out
+
+
+def _rowfeat_bwd(cfeat, g, dim):
+    g = _rows2d(g)
+    n, kc = cfeat.size(0), cfeat.size(1)
+    gt = torch.empty(kc, dim, dtype=torch.float32, device=g.device)
+    ws = _workspace(_ws_bytes("pgnn_rowfeat_matmul_bwd_workspace_bytes", n, kc, dim), g.device)
+    check(load().pgnn_rowfeat_matmul_bwd(cfeat.data_ptr(), kc, g.data_ptr(), g.stride(0), gt.data_ptr(), dim, n, dim,
+                                         ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_rowfeat_matmul_bwd")
+    return gt
+
+
+def _rowfeat_fwd(cfeat, table, out, dim, accumulate):
+    table = _f32c(table)
+    check(load().pgnn_rowfeat_matmul_fwd(cfeat.data_ptr(), cfeat.size(1), table.data_ptr(), table.stride(0),
+                                         out.data_ptr(), out.stride(0), cfeat.size(0), dim, int(accumulate),
+                                         stream_ptr()), "pgnn_rowfeat_matmul_fwd")
+
+
+# ------------------------------------------------------------------------------------ aggregation
+class ChemAggregate(Function):
+    """chem GINConv / GCNConv message + scatter_add (chem/model.py:47-52, 95-104)."""
+
+    @staticmethod
+    def forward(ctx, x, emb1, emb2, graph):
+        require_cuda(x, emb1, emb2)
+        x, emb1, emb2 = _rows2d(x), _f32c(emb1), _f32c(emb2)
+        n, dim = x.shape
+        if n != graph.n or emb1.shape != (6, dim) or emb2.shape != (3, dim):
+            raise _lib.PgnnError("chem aggregate: shape mismatch")
+        out = torch.empty(n, dim, dtype=torch.float32, device=x.device)
+        check(load().pgnn_chem_aggregate_fwd(x.data_ptr(), x.stride(0), graph.in_ptr.data_ptr(),
+                                             graph.in_src.data_ptr(), graph.in_code.data_ptr(), emb1.data_ptr(),
+                                             emb2.data_ptr(), graph.dinv.data_ptr() if graph.gcn else None,
+                                             out.data_ptr(), out.stride(0), n, dim, stream_ptr()),
+              "pgnn_chem_aggregate_fwd")
+        ctx.graph = graph
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        graph = ctx.graph
+        g = _rows2d(g)
+        n, dim = g.shape
+        gx = ge1 = ge2 = None
+        if ctx.needs_input_grad[0]:
+            gx = _neighbor_sum(g, graph.out_ptr, graph.out_dst, graph.dinv if graph.gcn else None, n, dim)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            gt = _rowfeat_bwd(graph.cfeat, g, dim)
+            ge1, ge2 = gt[:6], gt[6:9]
+        return gx, ge1, ge2, None
+
+
+class BioAggregate(Function):
+    """bio GINConv (concat message, bio/model.py:47,52-55) / GCNConv (bio/model.py:98-114) aggregation.
+
+    GIN: out[N,2D] = [sum_e x_j + x_i , cfeat . [W^T; b]]; GCN: out[N,D] = sum_e n_e x_j + cfeat . [W^T; b].
+    """
+
+    @staticmethod
+    def forward(ctx, x, enc_w, enc_b, graph):
+        require_cuda(x, enc_w, enc_b)
+        x = _rows2d(x)
+        n, dim = x.shape
+        if n != graph.n or enc_w.shape != (dim, 9):
+            raise _lib.PgnnError("bio aggregate: shape mismatch")
+        table = torch.cat([enc_w.t(), enc_b.unsqueeze(0)], dim=0).contiguous()  # [10, D]
+        if graph.gcn:
+            out = _neighbor_sum(x, graph.in_ptr, graph.in_src, graph.dinv, n, dim)
+            _rowfeat_fwd(graph.cfeat, table, out, dim, True)
+        else:
+            out = torch.empty(n, 2 * dim, dtype=torch.float32, device=x.device)
+            _neighbor_sum(x, graph.in_ptr, graph.in_src, None, n, dim, out=out[:, :dim])
+            _rowfeat_fwd(graph.cfeat, table, out[:, dim:], dim, False)
+        ctx.graph, ctx.dim = graph, dim
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        graph, dim = ctx.graph, ctx.dim
+        g = _rows2d(g)
+        n = g.size(0)
+        gx_part, ge_part = (g, g) if graph.gcn else (g[:, :dim], g[:, dim:])
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _neighbor_sum(gx_part, graph.out_ptr, graph.out_dst, graph.dinv if graph.gcn else None, n, dim)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            gt = _rowfeat_bwd(graph.cfeat, ge_part, dim)
+            gw, gb = gt[:9].t(), gt[9]
+        return gx, gw, gb, None
+
+
+# ------------------------------------------------------------------------------------ embedding
+class Embed(Function):
+    """x_embedding1(x[:,0]) + x_embedding2(x[:,1]) (chem/model.py:264) or a single table
+    (bio/model.py:49-50).  ``idx`` is int64 [N, ncol]."""
+
+    @staticmethod
+    def forward(ctx, idx, table1, table2):
+        require_cuda(idx, table1, table2)
+        if idx.dtype != torch.int64:
+            raise _lib.PgnnError("embedding indices must be int64")
+        idx = idx.contiguous()
+        n = idx.size(0)
+        stride = idx.size(1) if idx.dim() == 2 else 1
+        t1 = _f32c(table1)
+        t2 = _f32c(table2) if table2 is not None else None
+        dim = t1.size(1)
+        out = torch.empty(n, dim, dtype=torch.float32, device=idx.device)
+        status = torch.zeros(1, dtype=torch.int32, device=idx.device)
+        check(load().pgnn_embed_fwd(idx.data_ptr(), stride, t1.data_ptr(), t1.size(0),
+                                    t2.data_ptr() if t2 is not None else None, t2.size(0) if t2 is not None else 0,
+                                    out.data_ptr(), dim, n, dim, status.data_ptr(), stream_ptr()), "pgnn_embed_fwd")
+        if _CHECK_INDICES and int(status.item()):
+            raise IndexError("embedding index out of range")
+        ctx.idx, ctx.stride, ctx.rows = idx, stride, (t1.size(0), t2.size(0) if t2 is not None else 0)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g = _rows2d(g)
+        idx, stride = ctx.idx, ctx.stride
+        grads = []
+        for col, rows in enumerate(ctx.rows):
+            if rows == 0 or not ctx.needs_input_grad[1 + col]:
+                grads.append(None)
+                continue
+            ptr, perm = group_by_key(idx, rows, stride=stride, offset=col)
+            grads.append(segment_sum_raw(g, ptr, perm, idx.size(0), rows, mean=False))
+        return None, grads[0], grads[1]
+
+
+def segment_sum_raw(x, ptr, perm, n_items, n_seg, mean):
+    x = _rows2d(x)
+    dim = x.size(1)
+    out = torch.empty(n_seg, dim, dtype=torch.float32, device=x.device)
+    ws = _workspace(_ws_bytes("pgnn_segment_sum_workspace_bytes", n_items, n_seg, dim), x.device)
+    check(load().pgnn_segment_sum(x.data_ptr(), x.stride(0), ptr.data_ptr(), perm.data_ptr() if perm is not None else None,
+                                  n_items, n_seg, int(mean), out.data_ptr(), dim, dim, ws.data_ptr(), ws.numel(),
+                                  stream_ptr()), "pgnn_segment_sum")
+    return out
+
+
+class SegmentPool(Function):
+    """global_add_pool / global_mean_pool (chem/model.py:324-326; torch_geometric 1.0.3 scatter_)."""
+
+    @staticmethod
+    def forward(ctx, x, batch, size, mean):
+        require_cuda(x, batch)
+        x = _rows2d(x)
+        batch = batch.contiguous()
+        ptr, perm = group_by_key(batch, size)
+        out = segment_sum_raw(x, ptr, perm, x.size(0), size, mean)
+        ctx.batch, ctx.ptr, ctx.mean = batch, ptr, mean
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g = _rows2d(g)
+        n, dim = ctx.batch.numel(), g.size(1)
+        gx = torch.empty(n, dim, dtype=torch.float32, device=g.device)
+        check(load().pgnn_segment_broadcast(g.data_ptr(), g.stride(0), ctx.batch.data_ptr(), ctx.ptr.data_ptr(),
+                                            int(ctx.mean), gx.data_ptr(), dim, n, dim, stream_ptr()),
+              "pgnn_segment_broadcast")
+        return gx, None, None, None
+
+
+def global_add_pool(x, batch, size=None):
+    size = int(batch.max().item()) + 1 if size is None else size
+    return SegmentPool.apply(x, batch, size, False)
+
+
+def global_mean_pool(x, batch, size=None):
+    size = int(batch.max().item()) + 1 if size is None else size
+    return SegmentPool.apply(x, batch, size, True)
+
+
+# ------------------------------------------------------------------------------------ batch norm
+class BatchNormReLU(Function):
+    """BatchNorm1d (+ optional fused ReLU); chem/model.py:269-275, bio/model.py:24."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+        require_cuda(x, gamma, beta)
+        x = _rows2d(x)
+        n, dim = x.shape
+        if training and n <= 1:
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
+        y = torch.empty(n, dim, dtype=torch.float32, device=x.device)
+        save_mean = torch.empty(dim, dtype=torch.float32, device=x.device)
+        save_invstd = torch.empty(dim, dtype=torch.float32, device=x.device)
+        ws = _workspace(_ws_bytes("pgnn_bn_workspace_bytes", n, dim), x.device)
+        check(load().pgnn_bn_fwd(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(),
+                                 running_mean.data_ptr() if running_mean is not None else None,
+                                 running_var.data_ptr() if running_var is not None else None, float(momentum),
+                                 float(eps), int(training), int(relu), y.data_ptr(), dim, save_mean.data_ptr(),
+                                 save_invstd.data_ptr(), n, dim, ws.data_ptr(), ws.numel(), stream_ptr()),
+              "pgnn_bn_fwd")
+        ctx.save_for_backward(x, gamma, beta, save_mean, save_invstd)
+        ctx.training, ctx.relu = bool(training), bool(relu)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, gamma, beta, save_mean, save_invstd = ctx.saved_tensors
+        dy = _rows2d(dy)
+        n, dim = x.shape
+        dx = torch.empty(n, dim, dtype=torch.float32, device=x.device)
+        dgamma = torch.empty(dim, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(dim, dtype=torch.float32, device=x.device)
+        ws = _workspace(_ws_bytes("pgnn_bn_workspace_bytes", n, dim), x.device)
+        check(load().pgnn_bn_bwd(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), gamma.data_ptr(),
+                                 beta.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(), int(ctx.training),
+                                 int(ctx.relu), dx.data_ptr(), dim, dgamma.data_ptr(), dbeta.data_ptr(), n, dim,
+                                 ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_bn_bwd")
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def batch_norm(x, bn, relu):
+    """apply a torch.nn.BatchNorm1d module's parameters/buffers with the HIP kernels."""
+    training = bn.training or bn.running_mean is None
+    momentum = 0.0 if bn.momentum is None else bn.momentum
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        if bn.momentum is None:
+            momentum = 1.0 / float(bn.num_batches_tracked)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    if not bn.affine:
+        raise _lib.PgnnError("BatchNorm1d without affine parameters is not on the hot path")
+    return BatchNormReLU.apply(x, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, relu)
+
+
+# ------------------------------------------------------------------------------------ linear layers
+def _linear_fwd(x, w, b, relu):
+    m, k = x.shape
+    n = w.size(0)
+    y = torch.empty(m, n, dtype=torch.float32, device=x.device)
+    check(load().pgnn_linear_fwd(x.data_ptr(), x.stride(0), w.data_ptr(), b.data_ptr() if b is not None else None,
+                                 y.data_ptr(), n, m, k, n, int(relu), stream_ptr()), "pgnn_linear_fwd")
+    return y
+
+
+def _linear_bwd_data(dy, w, relu_out):
+    m, n = dy.shape
+    k = w.size(1)
+    dx = torch.empty(m, k, dtype=torch.float32, device=dy.device)
+    check(load().pgnn_linear_bwd_data(dy.data_ptr(), dy.stride(0), w.data_ptr(),
+                                      relu_out.data_ptr() if relu_out is not None else None,
+                                      relu_out.stride(0) if relu_out is not None else 0, dx.data_ptr(), k, m, k, n,
+                                      stream_ptr()), "pgnn_linear_bwd_data")
+    return dx
+
+
+def _linear_bwd_weight(dy, x, need_bias):
+    m, n = dy.shape
+    k = x.size(1)
+    dw = torch.empty(n, k, dtype=torch.float32, device=dy.device)
+    db = torch.empty(n, dtype=torch.float32, device=dy.device) if need_bias else None
+    ws = _workspace(_ws_bytes("pgnn_linear_bwd_weight_workspace_bytes", m, k, n), dy.device)
+    check(load().pgnn_linear_bwd_weight(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(),
+                                        db.data_ptr() if db is not None else None, m, k, n, ws.data_ptr(), ws.numel(),
+                                        stream_ptr()), "pgnn_linear_bwd_weight")
+    return dw, db
+
+
+class Linear(Function):
+    """y = x W^T + b (GCN linear chem/model.py:99; bio mlp layers bio/model.py:24)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        require_cuda(x, w, b)
+        x, w = _rows2d(x), _f32c(w)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return _linear_fwd(x, w, _f32c(b) if b is not None else None, False)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _rows2d(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _linear_bwd_data(dy, w, None)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = _linear_bwd_weight(dy, x, ctx.has_bias)
+        return dx, dw, db
+
+
+class MLP2(Function):
+    """GIN update: Linear -> ReLU -> Linear (chem/model.py:29,54-55) with the hidden activation kept
+    once and the ReLU mask fused into the backward-data GEMM epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        require_cuda(x, w1, b1, w2, b2)
+        x, w1, w2 = _rows2d(x), _f32c(w1), _f32c(w2)
+        hid = _linear_fwd(x, w1, _f32c(b1), True)
+        out = _linear_fwd(hid, w2, _f32c(b2), False)
+        ctx.save_for_backward(x, w1, w2, hid)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        x, w1, w2, hid = ctx.saved_tensors
+        dout = _rows2d(dout)
+        dw2, db2 = _linear_bwd_weight(dout, hid, True)
+        dhid = _linear_bwd_data(dout, w2, hid)  # masked by hid > 0
+        dw1, db1 = _linear_bwd_weight(dhid, x, True)
+        dx = _linear_bwd_data(dhid, w1, None) if ctx.needs_input_grad[0] else None
+        return dx, dw1, db1, dw2, db2
+
+
+def linear(x, layer):
+    return Linear.apply(x, layer.weight, layer.bias)

@@ -1,0 +1,310 @@
+"""-m gpu: kernel-level parity of the C-ABI entry points against torch-CPU / the oracle.
+
+Bars: bit-exact for integer structures and for the chem GIN aggregation (same addition order as
+the reference's sequential CPU scatter_add); fp32 tolerance 1e-5 relative for everything else at
+kernel level (the end-to-end 1e-4 bar of BASELINE.json is in test_gpu_models.py).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import chem as ochem
+from oracle import pyg_semantics as pyg
+from pretrain_gnns_amd.data import synthetic
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from pretrain_gnns_amd import ops
+    return ops
+
+
+def _rand_graph(n, e, seed, paired=True):
+    g = torch.Generator().manual_seed(seed)
+    if paired:
+        half = torch.randint(0, n, (2, e // 2), generator=g)
+        ei = torch.empty(2, 2 * (e // 2), dtype=torch.int64)
+        ei[:, 0::2] = half
+        ei[:, 1::2] = half.flip(0)
+    else:
+        ei = torch.randint(0, n, (2, e), generator=g)
+    ea = torch.stack([torch.randint(0, 6, (ei.size(1),), generator=g), torch.randint(0, 3, (ei.size(1),), generator=g)], 1)
+    return ei, ea
+
+
+def _ref_csr(keys, n):
+    order = np.argsort(keys, kind="stable")
+    ptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(ptr, keys + 1, 1)
+    return np.cumsum(ptr), order
+
+
+@pytest.mark.parametrize("n,e,paired", [(50, 120, True), (1000, 2200, True), (300, 5000, False), (7, 0, True), (40000, 90000, True)])
+def test_chem_graph_build(n, e, paired):
+    ops = _ops()
+    ei, ea = _rand_graph(n, e, seed=n + e, paired=paired)
+    if n == 300:  # a hub with > 64 and > 16 in-edges exercises the cooperative segment sort
+        ei[0, :200] = 5
+    g = ops.build_chem_graph(ei.to(DEV), ea.to(DEV), n, gcn=True)
+    g.check()
+    ein = ei.numpy()
+    in_ptr, in_perm = _ref_csr(ein[0], n)
+    out_ptr, out_perm = _ref_csr(ein[1], n)
+    E = ei.size(1)
+    assert np.array_equal(g.in_ptr.cpu().numpy(), in_ptr)
+    assert np.array_equal(g.out_ptr.cpu().numpy(), out_ptr)
+    assert np.array_equal(g.in_src.cpu().numpy()[:E], ein[1][in_perm])
+    assert np.array_equal(g.out_dst.cpu().numpy()[:E], ein[0][out_perm])
+    code = (ea[:, 0] * 3 + ea[:, 1]).numpy()
+    assert np.array_equal(g.in_code.cpu().numpy()[:E], code[in_perm])
+    deg = np.diff(in_ptr) + 1
+    dinv = 1.0 / np.sqrt(deg.astype(np.float32))
+    np.testing.assert_allclose(g.dinv.cpu().numpy(), dinv, rtol=1e-6)
+    # cfeat (gcn-weighted): compare with a dense construction
+    w = dinv[ein[0]] * dinv[ein[1]]
+    cf = np.zeros((n, 9), dtype=np.float64)
+    np.add.at(cf, (ein[0], ea[:, 0].numpy()), w)
+    np.add.at(cf, (ein[0], 6 + ea[:, 1].numpy()), w)
+    cf[:, 4] += dinv * dinv
+    cf[:, 6] += dinv * dinv
+    np.testing.assert_allclose(g.cfeat.cpu().numpy(), cf, rtol=1e-5, atol=1e-6)
+
+
+def test_graph_build_flags_bad_indices():
+    ops = _ops()
+    ei, ea = _rand_graph(20, 40, seed=1)
+    ei[0, 3] = 25
+    ea[5, 0] = 9
+    g = ops.build_chem_graph(ei.to(DEV), ea.to(DEV), 20)
+    with pytest.raises(IndexError):
+        g.check()
+
+
+@pytest.mark.parametrize("dim", [300, 32, 512, 600])
+@pytest.mark.parametrize("n,e", [(64, 150), (2000, 4400), (333, 4000)])
+def test_chem_gin_aggregate_bit_exact(n, e, dim):
+    ops = _ops()
+    torch.manual_seed(n + dim)
+    ei, ea = _rand_graph(n, e, seed=e)
+    if n == 333:
+        ei[0, :300] = 7  # high in-degree node: several 64-edge rounds
+    conv = ochem.GINConv(dim)
+    x = torch.randn(n, dim)
+    want = conv.aggregate(x, ei, ea)
+    g = ops.build_chem_graph(ei.to(DEV), ea.to(DEV), n)
+    got = ops.ChemAggregate.apply(x.to(DEV), conv.edge_embedding1.weight.detach().to(DEV),
+                                  conv.edge_embedding2.weight.detach().to(DEV), g)
+    assert torch.equal(got.cpu(), want.detach()), (got.cpu() - want).abs().max()
+
+
+def test_chem_aggregate_backward_and_gcn():
+    ops = _ops()
+    n, dim = 500, 300
+    ei, ea = _rand_graph(n, 1200, seed=3, paired=False)  # asymmetric graph: CSR != CSC
+    for gcn in (False, True):
+        torch.manual_seed(1)
+        conv = ochem.GCNConv(dim) if gcn else ochem.GINConv(dim)
+        x = torch.randn(n, dim, requires_grad=True)
+        if gcn:
+            ei2, ea2 = ochem._with_self_loops(ei, ea, n)
+            nrm = conv.norm(ei2, n, x.dtype)
+            want = pyg.propagate_add(ei2, x, conv.bond_embedding(ea2), lambda xj, e: nrm.view(-1, 1) * (xj + e), n)
+        else:
+            want = conv.aggregate(x, ei, ea)
+        gout = torch.randn(n, dim)
+        want.backward(gout)
+        g = ops.build_chem_graph(ei.to(DEV), ea.to(DEV), n, gcn=gcn)
+        xd = x.detach().to(DEV).requires_grad_(True)
+        e1 = conv.edge_embedding1.weight.detach().to(DEV).requires_grad_(True)
+        e2 = conv.edge_embedding2.weight.detach().to(DEV).requires_grad_(True)
+        got = ops.ChemAggregate.apply(xd, e1, e2, g)
+        got.backward(gout.to(DEV))
+        torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(e1.grad.cpu(), conv.edge_embedding1.weight.grad, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(e2.grad.cpu(), conv.edge_embedding2.weight.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("gcn", [False, True])
+def test_bio_aggregate_fwd_bwd(gcn):
+    from oracle import bio as obio
+    ops = _ops()
+    b = synthetic.bio_masking_batch(6, seed=4)
+    n, dim = b.x.size(0), 300
+    torch.manual_seed(2)
+    conv = (obio.GCNConv if gcn else obio.GINConv)(dim)
+    x = torch.randn(n, dim, requires_grad=True)
+    if gcn:
+        conv.linear = torch.nn.Identity()
+        want = conv(x, b.edge_index, b.edge_attr)
+    else:
+        want = conv.aggregate(x, b.edge_index, b.edge_attr)
+    gout = torch.randn_like(want)
+    want.backward(gout)
+    g = ops.build_bio_graph(b.edge_index.to(DEV), b.edge_attr.to(DEV), n, gcn=gcn)
+    g.check()
+    xd = x.detach().to(DEV).requires_grad_(True)
+    w = conv.edge_encoder.weight.detach().to(DEV).requires_grad_(True)
+    bb = conv.edge_encoder.bias.detach().to(DEV).requires_grad_(True)
+    got = ops.BioAggregate.apply(xd, w, bb, g)
+    got.backward(gout.to(DEV))
+    torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(w.grad.cpu(), conv.edge_encoder.weight.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(bb.grad.cpu(), conv.edge_encoder.bias.grad, rtol=1e-4, atol=1e-3)
+
+
+def test_embed_fwd_bwd():
+    ops = _ops()
+    n, dim = 3000, 300
+    torch.manual_seed(0)
+    t1 = torch.randn(120, dim, requires_grad=True)
+    t2 = torch.randn(3, dim, requires_grad=True)
+    idx = torch.stack([torch.randint(0, 120, (n,)), torch.randint(0, 3, (n,))], 1)
+    idx[: n // 2, 0] = 5  # skewed like carbon: one long segment
+    want = t1[idx[:, 0]] + t2[idx[:, 1]]
+    gout = torch.randn(n, dim)
+    want.backward(gout)
+    a = t1.detach().to(DEV).requires_grad_(True)
+    b = t2.detach().to(DEV).requires_grad_(True)
+    got = ops.Embed.apply(idx.to(DEV), a, b)
+    got.backward(gout.to(DEV))
+    assert torch.equal(got.detach().cpu(), want.detach())
+    torch.testing.assert_close(a.grad.cpu(), t1.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(b.grad.cpu(), t2.grad, rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("mean", [False, True])
+def test_segment_pool(mean):
+    ops = _ops()
+    torch.manual_seed(0)
+    sizes = [1, 3, 70, 0, 200, 27, 64, 65, 5]  # includes an empty graph id and chunk-straddling segments
+    batch = torch.cat([torch.full((s,), i, dtype=torch.long) for i, s in enumerate(sizes)])
+    n, dim = batch.numel(), 300
+    x = torch.randn(n, dim, requires_grad=True)
+    size = len(sizes)
+    want = (pyg.global_mean_pool if mean else pyg.global_add_pool)(x, batch, size)
+    gout = torch.randn(size, dim)
+    want.backward(gout)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    got = (ops.global_mean_pool if mean else ops.global_add_pool)(xd, batch.to(DEV), size)
+    got.backward(gout.to(DEV))
+    torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-6, atol=1e-6)
+    # unsorted batch vector as well
+    perm = torch.randperm(n)
+    got2 = (ops.global_mean_pool if mean else ops.global_add_pool)(x.detach()[perm].to(DEV), batch[perm].to(DEV), size)
+    torch.testing.assert_close(got2.cpu(), want.detach(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,dim", [(2, 300), (777, 300), (5000, 600), (100, 32)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_batchnorm_train_fwd_bwd(n, dim, relu):
+    ops = _ops()
+    torch.manual_seed(n)
+    bn = torch.nn.BatchNorm1d(dim)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    x = (torch.randn(n, dim) * 2 + 3).requires_grad_(True)
+    bn_d = torch.nn.BatchNorm1d(dim)
+    bn_d.load_state_dict(bn.state_dict())
+    bn_d = bn_d.to(DEV)
+    want = bn(x)
+    if relu:
+        want = torch.relu(want)
+    gout = torch.randn(n, dim)
+    want.backward(gout)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    got = ops.batch_norm(xd, bn_d, relu)
+    got.backward(gout.to(DEV))
+    tol = dict(rtol=2e-5, atol=2e-5) if n > 2 else dict(rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(got.detach().cpu(), want.detach(), **tol)
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-4, atol=2e-5 if n > 2 else 1e-2)
+    torch.testing.assert_close(bn_d.weight.grad.cpu(), bn.weight.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(bn_d.bias.grad.cpu(), bn.bias.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(bn_d.running_mean.cpu(), bn.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bn_d.running_var.cpu(), bn.running_var, rtol=1e-5, atol=1e-6)
+    assert int(bn_d.num_batches_tracked) == 1
+
+
+def test_batchnorm_eval_and_errors():
+    ops = _ops()
+    bn = torch.nn.BatchNorm1d(300)
+    bn.running_mean.normal_()
+    bn.running_var.uniform_(0.5, 2)
+    bn.eval()
+    x = torch.randn(50, 300)
+    bn_d = torch.nn.BatchNorm1d(300)
+    bn_d.load_state_dict(bn.state_dict())
+    bn_d = bn_d.to(DEV).eval()
+    torch.testing.assert_close(ops.batch_norm(x.to(DEV), bn_d, False).cpu(), bn(x), rtol=1e-5, atol=1e-5)
+    bn_d.train()
+    with pytest.raises(ValueError):
+        ops.batch_norm(x[:1].to(DEV), bn_d, False)
+
+
+@pytest.mark.parametrize("m,k,n", [(1, 300, 600), (130, 300, 600), (1000, 600, 300), (4097, 300, 300), (257, 64, 32), (515, 600, 600)])
+def test_linear_fwd_bwd(m, k, n):
+    ops = _ops()
+    torch.manual_seed(m)
+    lin = torch.nn.Linear(k, n)
+    x = torch.randn(m, k, requires_grad=True)
+    want = lin(x)
+    gout = torch.randn(m, n)
+    want.backward(gout)
+    lin_d = torch.nn.Linear(k, n)
+    lin_d.load_state_dict(lin.state_dict())
+    lin_d = lin_d.to(DEV)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    got = ops.linear(xd, lin_d)
+    got.backward(gout.to(DEV))
+    torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(lin_d.weight.grad.cpu(), lin.weight.grad, rtol=1e-4, atol=1e-4 * max(1, m / 1000))
+    torch.testing.assert_close(lin_d.bias.grad.cpu(), lin.bias.grad, rtol=1e-4, atol=1e-4 * max(1, m / 1000))
+
+
+def test_linear_layout_asymmetric():
+    """A = identity-like check with an asymmetric weight catches row/col swaps of the MFMA C layout."""
+    ops = _ops()
+    k = n = 64
+    w = torch.arange(n * k, dtype=torch.float32).view(n, k) / 100.0
+    lin = torch.nn.Linear(k, n, bias=False)
+    with torch.no_grad():
+        lin.weight.copy_(w)
+    x = torch.eye(k)[:40]
+    got = ops.Linear.apply(x.to(DEV), lin.weight.detach().to(DEV), None).cpu()
+    assert torch.equal(got, w.t()[:40].contiguous())
+
+
+def test_mlp2_fwd_bwd():
+    ops = _ops()
+    torch.manual_seed(0)
+    m, d = 900, 300
+    mlp = torch.nn.Sequential(torch.nn.Linear(d, 2 * d), torch.nn.ReLU(), torch.nn.Linear(2 * d, d))
+    x = torch.randn(m, d, requires_grad=True)
+    want = mlp(x)
+    gout = torch.randn(m, d)
+    want.backward(gout)
+    mlp_d = torch.nn.Sequential(torch.nn.Linear(d, 2 * d), torch.nn.ReLU(), torch.nn.Linear(2 * d, d))
+    mlp_d.load_state_dict(mlp.state_dict())
+    mlp_d = mlp_d.to(DEV)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    got = ops.MLP2.apply(xd, mlp_d[0].weight, mlp_d[0].bias, mlp_d[2].weight, mlp_d[2].bias)
+    got.backward(gout.to(DEV))
+    torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-5, atol=2e-5)
+    for pd, pc in zip(mlp_d.parameters(), mlp.parameters()):
+        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-4, atol=2e-4)
+
+
+def test_cpu_tensors_rejected():
+    ops = _ops()
+    from pretrain_gnns_amd._lib import PgnnError
+    ei, ea = _rand_graph(10, 20, seed=0)
+    with pytest.raises(PgnnError):
+        ops.build_chem_graph(ei, ea, 10)
