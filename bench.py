@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: edges/sec through the 5-layer GIN (emb_dim 300) masking pre-train step.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+          --master-port P bench.py --gpus N --steps K --warmup W)
+
+One "step" = the loop body of the reference train() (chem/pretrain_masking.py:47-76): GNN forward
+(CSR build + 5 x [aggregation, mlp, BatchNorm]) -> masked-atom head -> float64 CE -> backward ->
+3 x Adam, on ONE synthetic ZINC-2M-shaped BatchMasking batch of 256 graphs per GPU (BASELINE.json
+configs[1]; weak scaling: every rank has its own 256 graphs, one flat-bucket gradient all-reduce per
+step).  Inputs are resident in HBM before the timed region.  edges = edge_index.size(1) (directed,
+self loops excluded), counted once per step.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      : the aggregation kernel (pgnn_chem_aggregate_fwd) on a roofline-sized batch
+                  (>= 16384 graphs, working set > the 256 MB Infinity Cache), algorithmic bytes =
+                  2400 N + 6 E + 4 (N+1) per launch / HIP-event time per launch, vs 8 TB/s;
+  roofline_mlp  : the fp32 MFMA GEMM that dominates the step time, vs 157.3 TFLOP/s;
+  cpu_baseline  : the CPU oracle's identical train step on the host cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32 MFMA dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--graphs-per-gpu", type=int, default=256)
+    ap.add_argument("--roofline-graphs", type=int, default=16384)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def make_models(dev, seed=0):
+    from pretrain_gnns_amd.chem import model as hmodel
+
+    torch.manual_seed(seed)
+    model = hmodel.GNN(5, 300, JK="last", drop_ratio=0, gnn_type="gin").to(dev)
+    atoms = torch.nn.Linear(300, 119).to(dev)
+    bonds = torch.nn.Linear(300, 4).to(dev)
+    return [model, atoms, bonds]
+
+
+def event_time_ms(fn, iters, warmup=3):
+    """average ms per call measured with HIP events on torch's current stream (the stream the
+    C-ABI kernels are launched on)."""
+    for _ in range(warmup):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def roofline_aggregation(dev, graphs):
+    """time the GIN aggregation kernel alone at a batch whose working set exceeds the Infinity Cache."""
+    from pretrain_gnns_amd import ops
+    from pretrain_gnns_amd.data import synthetic
+
+    base = synthetic.chem_masking_batch(2048, seed=123)
+    big = synthetic.tile_batch(base, max(1, graphs // 2048)).to(dev)
+    n, e = big.x.size(0), big.edge_index.size(1)
+    g = ops.build_chem_graph(big.edge_index, big.edge_attr, n)
+    torch.manual_seed(0)
+    x = torch.randn(n, 300, device=dev)
+    e1, e2 = torch.randn(6, 300, device=dev), torch.randn(3, 300, device=dev)
+    out = torch.empty(n, 300, device=dev)
+    lib = ops.load()
+    sp = ops.stream_ptr()
+
+    def launch():
+        ops.check(lib.pgnn_chem_aggregate_fwd(x.data_ptr(), 300, g.in_ptr.data_ptr(), g.in_src.data_ptr(),
+                                              g.in_code.data_ptr(), e1.data_ptr(), e2.data_ptr(), None,
+                                              out.data_ptr(), 300, n, 300, sp), "aggregate")
+
+    ms = event_time_ms(launch, iters=20)
+    alg_bytes = 2400.0 * n + 6.0 * e + 4.0 * (n + 1)
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "k_aggregate<2,TABLE,-> (pgnn_chem_aggregate_fwd)", "achieved": round(gbs, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "ms_per_launch": round(ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+            "bytes_per_edge_per_layer": round(alg_bytes / e, 1), "graphs": int(big.batch[-1].item()) + 1,
+            "nodes": n, "edges": e}
+
+
+def roofline_mlp(dev, rows):
+    """time the fp32 MFMA GEMM of the GIN mlp (first Linear 300->600 + bias + ReLU) alone."""
+    from pretrain_gnns_amd import ops
+
+    torch.manual_seed(0)
+    x = torch.randn(rows, 300, device=dev)
+    w = torch.randn(600, 300, device=dev) * 0.05
+    b = torch.randn(600, device=dev)
+    y = torch.empty(rows, 600, device=dev)
+    lib, sp = ops.load(), ops.stream_ptr()
+
+    def launch():
+        ops.check(lib.pgnn_linear_fwd(x.data_ptr(), 300, w.data_ptr(), b.data_ptr(), y.data_ptr(), 600, rows, 300, 600,
+                                      1, sp), "linear")
+
+    ms = event_time_ms(launch, iters=20)
+    tf = 2.0 * rows * 300 * 600 / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "k_gemm<128,128,16> (pgnn_linear_fwd 300->600)", "achieved": round(tf, 2),
+            "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
+            "ms_per_launch": round(ms, 4), "rows": rows}
+
+
+def usable_cores():
+    """host cores this process may really use: min(affinity, cgroup cpu quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(graphs, seconds):
+    """the oracle's train step (same synthetic batch shape) on the host cores."""
+    from oracle import chem as ochem
+    from oracle import steps
+    from pretrain_gnns_amd.data import synthetic
+
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    batch = synthetic.chem_masking_batch(graphs, seed=0)
+    mods = [ochem.GNN(5, 300), torch.nn.Linear(300, 119), torch.nn.Linear(300, 4)]
+    opts = [torch.optim.Adam(m.parameters(), lr=1e-3) for m in mods]
+    for _ in range(2):
+        steps.chem_masking_step(mods, opts, batch)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        steps.chem_masking_step(mods, opts, batch)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds or n >= 200:
+            break
+    e = batch.edge_index.size(1)
+    return {"value": round(e * n / el, 1), "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": "%d train steps (fwd+bwd+3xAdam) of the torch-CPU oracle on one %d-graph batch (%d edges), %.1f s"
+                      % (n, graphs, e, el)}
+
+
+def main():
+    args = parse()
+    from pretrain_gnns_amd import parallel
+    from pretrain_gnns_amd.data import synthetic
+    from pretrain_gnns_amd import train as steps
+
+    rank, local, world = parallel.init_from_env()
+    if world != args.gpus:
+        if args.gpus > 1 and world == 1:
+            raise SystemExit("--gpus %d needs a torchrun launch (see the module docstring)" % args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    mods = make_models(dev)
+    parallel.broadcast_parameters(mods)
+    opts = [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0) for m in mods]
+    if world > 1:
+        opts = parallel.AllReduceOptimizers(opts)
+    batch = synthetic.chem_masking_batch(args.graphs_per_gpu, seed=rank).to(dev)
+    edges_local = batch.edge_index.size(1)
+
+    def step():
+        return steps.chem_masking_step(mods, list(opts), batch, mask_edge=False)
+
+    for _ in range(args.warmup):
+        step()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()[0]
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    etot = torch.tensor([float(edges_local)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(etot, op=dist.ReduceOp.SUM)
+    elapsed, edges_total = float(tmax.item()), float(etot.item())
+
+    if rank == 0:
+        res = {
+            "metric": "edges/sec through 5-layer GIN (emb_dim=300) masking pre-train step (fwd+bwd+Adam)",
+            "value": round(edges_total * args.steps / elapsed, 1), "unit": "edges/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "chem/pretrain_masking.py train step, 5-layer GIN emb_dim=300, "
+                                   "batch_size=%d ZINC-2M-shaped graphs per GPU, HIP scatter_add GINConv (BASELINE configs[1])"
+                                   % args.graphs_per_gpu,
+                       "graphs_per_gpu": args.graphs_per_gpu, "global_batch": args.graphs_per_gpu * world,
+                       "nodes_per_gpu": int(batch.x.size(0)), "edges_per_gpu": int(edges_local),
+                       "parallelism": "dp%d" % world, "last_loss": round(float(loss), 5)},
+        }
+        if not args.no_roofline:
+            res["roofline"] = roofline_aggregation(dev, args.roofline_graphs)
+            res["roofline_mlp"] = roofline_mlp(dev, 262144)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.graphs_per_gpu, args.cpu_seconds)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

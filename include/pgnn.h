@@ -75,8 +75,10 @@ int pgnn_bio_graph_build(const int64_t* edge_index, const float* edge_attr, int6
 
 /* Stable grouping of n_items by key in [0,n_keys): ptr[n_keys+1], perm[n_items] (item ids ordered
  * by (key, id)).  Keys are read with a stride (in int64 elements) so a column of x[N,2] can be
- * grouped in place.  Used for pooling (key = batch vector, chem/model.py:369) and for the input
+ * grouped in place.  n_keys <= 1024: one stable radix pass (any segment length, O(n)); more keys:
+ * CSR fill + in-segment ranking (meant for short segments such as node neighbourhoods).  Used for pooling (key = batch vector, chem/model.py:369) and for the input
  * embedding gradient (key = atom type, chem/model.py:264). */
+size_t pgnn_group_workspace_bytes(int64_t n_keys, int64_t n_items);
 int pgnn_group_by_key(const int64_t* key, int64_t key_stride, int64_t n_items, int64_t n_keys,
                       int32_t* ptr, int32_t* perm, int32_t* status, void* ws, size_t ws_bytes,
                       pgnn_stream stream);

@@ -1,0 +1,65 @@
+"""Generate tests/golden/*.pt from the reference's shipped checkpoints.  Test infrastructure only.
+
+Run in the BUILD container (needs /root/reference):  python -m oracle.make_golden
+
+What gets pinned: the reference ships real GCN weights + BatchNorm running
+statistics (chem/model_architecture/gcn_contextpred.pth, bio/model_architecture/gcn_masking.pth;
+the GIN blobs are absent from the repo).  Each fixture stores
+  * the checkpoint's state dict exactly as shipped (the key/shape contract),
+  * a small seeded synthetic batch,
+  * the oracle's eval-mode node embeddings on it (and train-mode embeddings + one gradient).
+The oracle strict-loads the state dict (= the drop-in key contract); the -m gpu tests then load
+the same dict into the HIP-backed classes and must reproduce the stored outputs to 1e-4.
+/root/reference does not exist on the GPU box, hence the committed fixtures.
+"""
+import os
+
+import torch
+
+from oracle import bio as obio
+from oracle import chem as ochem
+from pretrain_gnns_amd.data import synthetic
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _fixture(kind, ckpt, model, batch):
+    sd = torch.load(os.path.join(REF, ckpt), map_location="cpu")
+    missing = model.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    model.eval()
+    with torch.no_grad():
+        out_eval = model(batch.x, batch.edge_index, batch.edge_attr)
+    model.train()
+    out_train = model(batch.x, batch.edge_index, batch.edge_attr)
+    out_train.square().mean().backward()
+    first = next(n for n, _ in model.named_parameters() if n.endswith("linear.weight"))
+    grad = dict(model.named_parameters())[first].grad.clone()
+    return {
+        "kind": kind, "checkpoint": ckpt, "state_dict": {k: v.clone() for k, v in sd.items()},
+        "batch": {k: getattr(batch, k) for k in ("x", "edge_index", "edge_attr")},
+        "out_eval": out_eval, "out_train": out_train.detach(), "grad_name": first, "grad": grad,
+    }
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    fx = _fixture("chem", "chem/model_architecture/gcn_contextpred.pth", ochem.GNN(5, 300, gnn_type="gcn"),
+                  synthetic.chem_plain_batch(6, seed=11))
+    torch.save(fx, os.path.join(OUT, "chem_gcn_contextpred.pt"))
+    fx = _fixture("bio", "bio/model_architecture/gcn_masking.pth", obio.GNN(5, 300, gnn_type="gcn"),
+                  synthetic.bio_masking_batch(3, seed=12))
+    torch.save(fx, os.path.join(OUT, "bio_gcn_masking.pt"))
+    # vocabulary / layout constants the reference fixes (chem/model.py:9-13,43; chem/util.py:212-213)
+    torch.save({"num_atom_type": 120, "num_chirality_tag": 3, "num_bond_type": 6, "num_bond_direction": 3,
+                "self_loop_bond_type": 4, "atom_mask_token": 119, "bond_mask_token": 5,
+                "edge_order_example": torch.tensor([[0, 1, 1, 2, 2, 3], [1, 0, 2, 1, 3, 2]])},
+               os.path.join(OUT, "constants.pt"))
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

@@ -279,11 +279,11 @@ k_rowfeat_bwd_partial(const float* __restrict__ cfeat, const float* __restrict__
 __global__ void __launch_bounds__(kBlock)
 k_rowfeat_bwd_final(const float* __restrict__ partial, int nblocks, int kc, int dim,
                     float* __restrict__ gtable, int64_t ldgt) {
-  const int q = blockIdx.x * kBlock + threadIdx.x;
-  if (q >= kc * dim) return;
-  float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * kc * dim + q];
-  gtable[(int64_t)(q / dim) * ldgt + (q % dim)] = s;
+  const int sl = threadIdx.x & 15;
+  const int qq = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int q = min(qq, kc * dim - 1);
+  const double s = slice_sum16(partial + q, (size_t)kc * dim, nblocks, sl);
+  if (sl == 0 && qq < kc * dim) gtable[(int64_t)(q / dim) * ldgt + (q % dim)] = (float)s;
 }
 
 inline int rowfeat_bwd_blocks(int64_t n) {
@@ -518,7 +518,7 @@ int pgnn_rowfeat_matmul_bwd(const float* cfeat, int64_t kc, const float* g, int6
       hipLaunchKernelGGL((k_rowfeat_bwd_partial<RR, 10>), dim3(nb), dim3(kBlock), lds, st, cfeat, g, ldg, partial, (int)n, (int)dim);
     });
   }
-  hipLaunchKernelGGL(k_rowfeat_bwd_final, dim3((int)ceil_div(kc * dim, kBlock)), dim3(kBlock), 0, st,
+  hipLaunchKernelGGL(k_rowfeat_bwd_final, dim3((int)ceil_div(kc * dim, 16)), dim3(kBlock), 0, st,
                      partial, nb, (int)kc, (int)dim, gtable, ldgt);
   return check_launch("rowfeat_matmul_bwd");
 }

@@ -57,15 +57,15 @@ __global__ void k_bn_stats_final(const float* __restrict__ partial, int nblk, co
                                  float momentum, float eps, int training, int n, int dim,
                                  float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                  float* __restrict__ coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= dim) return;
+  // 256 threads = 16 columns x 16 slices
+  const int sl = threadIdx.x & 15;
+  const int c = min(blockIdx.x * 16 + (threadIdx.x >> 4), dim - 1);
+  const bool writer = sl == 0 && (blockIdx.x * 16 + (threadIdx.x >> 4)) < dim;
   float mean, invstd;
   if (training) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-      s1 += (double)partial[(size_t)b * 2 * dim + c];
-      s2 += (double)partial[(size_t)b * 2 * dim + dim + c];
-    }
+    const double s1 = slice_sum16(partial + c, (size_t)2 * dim, nblk, sl);
+    const double s2 = slice_sum16(partial + dim + c, (size_t)2 * dim, nblk, sl);
+    if (!writer) return;
     const double m1 = s1 / n;
     double var = s2 / n - m1 * m1;
     if (var < 0.0) var = 0.0;
@@ -77,6 +77,7 @@ __global__ void k_bn_stats_final(const float* __restrict__ partial, int nblk, co
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
   } else {
+    if (!writer) return;
     mean = running_mean[c];
     invstd = 1.0f / sqrtf(running_var[c] + eps);
   }
@@ -157,13 +158,12 @@ __global__ void k_bn_bwd_prepare(const float* __restrict__ gamma, const float* _
 __global__ void k_bn_bwd_final(const float* __restrict__ partial, int nblk, int training, int n, int dim,
                                const float* __restrict__ gamma, float* __restrict__ coef,
                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= dim) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s1 += (double)partial[(size_t)b * 2 * dim + c];
-    s2 += (double)partial[(size_t)b * 2 * dim + dim + c];
-  }
+  const int sl = threadIdx.x & 15;
+  const int c = min(blockIdx.x * 16 + (threadIdx.x >> 4), dim - 1);
+  const bool writer = sl == 0 && (blockIdx.x * 16 + (threadIdx.x >> 4)) < dim;
+  const double s1 = slice_sum16(partial + c, (size_t)2 * dim, nblk, sl);
+  const double s2 = slice_sum16(partial + dim + c, (size_t)2 * dim, nblk, sl);
+  if (!writer) return;
   if (dgamma) dgamma[c] = (float)s2;
   if (dbeta) dbeta[c] = (float)s1;
   const float invstd = coef[3 * dim + c];
@@ -255,7 +255,7 @@ int pgnn_bn_fwd(const float* x, int64_t ldx, const float* gamma, const float* be
     hipLaunchKernelGGL(k_bn_stats_partial, dim3(nblk), dim3(stat_threads(dim)), (size_t)8 * dim * sizeof(float),
                        st, x, ldx, (int)n, d4, partial);
   }
-  hipLaunchKernelGGL(k_bn_stats_final, dim3((int)ceil_div(dim, 256)), dim3(256), 0, st, partial, nblk, x, gamma,
+  hipLaunchKernelGGL(k_bn_stats_final, dim3((int)ceil_div(dim, 16)), dim3(256), 0, st, partial, nblk, x, gamma,
                      beta, running_mean, running_var, momentum, eps, training, (int)n, (int)dim, save_mean,
                      save_invstd, coef);
   const int grid = (int)std::min<int64_t>(ceil_div(n, 4), (int64_t)kNumCU * 16);
@@ -283,7 +283,7 @@ int pgnn_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, cons
   hipLaunchKernelGGL(k_bn_bwd_prepare, dim3(cb), dim3(256), 0, st, gamma, beta, save_mean, save_invstd, (int)dim, coef);
   hipLaunchKernelGGL(k_bn_bwd_partial, dim3(nblk), dim3(stat_threads(dim)), (size_t)8 * dim * sizeof(float), st, dy,
                      lddy, x, ldx, coef, relu, (int)n, d4, partial);
-  hipLaunchKernelGGL(k_bn_bwd_final, dim3(cb), dim3(256), 0, st, partial, nblk, training, (int)n, (int)dim, gamma,
+  hipLaunchKernelGGL(k_bn_bwd_final, dim3((int)ceil_div(dim, 16)), dim3(256), 0, st, partial, nblk, training, (int)n, (int)dim, gamma,
                      coef, dgamma, dbeta);
   const int grid = (int)std::min<int64_t>(ceil_div(n, 4), (int64_t)kNumCU * 16);
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid), dim3(stat_threads(dim)), 0, st, dy, lddy, x, ldx, coef, relu, dx, lddx,

@@ -83,4 +83,15 @@ __device__ __forceinline__ float4 f4_scale(float4 a, float s) {
 }
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// Second-pass reduction helper: 16 lanes share one output column; lane s sums the partials
+// b = s, s+16, ... in double, then an xor-butterfly combines the 16 slices (every lane ends with the
+// same bits: fixed association order => deterministic).  Call with all 16 lanes of the group active.
+__device__ __forceinline__ double slice_sum16(const float* __restrict__ p, size_t stride, int count, int s) {
+  double a = 0.0;
+  for (int b = s; b < count; b += 16) a += (double)p[(size_t)b * stride];
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) a += __shfl_xor(a, off);
+  return a;
+}
+
 }  // namespace pgnn

@@ -156,6 +156,108 @@ __global__ void __launch_bounds__(256) k_sort_segments(GroupJobs jobs, int64_t n
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Stable partition for FEW keys with LONG segments (atom types, chirality tags, graph ids of a
+// small batch): one LSD-radix pass with the key as the digit.  Tile = 256 items; per-tile key
+// histograms are laid out key-major, so one exclusive scan over [n_keys][n_tiles] yields, for every
+// (key, tile), the output offset of that tile's first item with that key.  Inside a tile the rank of
+// an item among equal keys comes from wave ballots (lanes are in item order) plus the counts of the
+// earlier waves.  O(n), deterministic, no sort.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPartTile = 256;
+constexpr int kPartMaxKeys = 1024;
+
+__global__ void __launch_bounds__(kPartTile)
+k_part_hist(const int64_t* __restrict__ key, int64_t stride, int64_t n_items, int n_keys, int n_tiles,
+            int32_t* __restrict__ offs /*[n_keys*n_tiles + 1], element 0 reserved*/, int32_t* status) {
+  extern __shared__ int lh[];
+  for (int k = threadIdx.x; k < n_keys; k += kPartTile) lh[k] = 0;
+  __syncthreads();
+  const int64_t e = (int64_t)blockIdx.x * kPartTile + threadIdx.x;
+  if (e < n_items) {
+    int64_t k = key[e * stride];
+    if (k < 0 || k >= n_keys) {
+      atomicAdd(status, 1);
+      k = 0;
+    }
+    atomicAdd(&lh[k], 1);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < n_keys; k += kPartTile) offs[(size_t)k * n_tiles + blockIdx.x + 1] = lh[k];
+}
+
+__global__ void __launch_bounds__(kPartTile)
+k_part_scatter(const int64_t* __restrict__ key, int64_t stride, int64_t n_items, int n_keys, int n_tiles,
+               const int32_t* __restrict__ offs, int32_t* __restrict__ ptr, int32_t* __restrict__ perm) {
+  extern __shared__ int wh[];  // [4][n_keys] per-wave key counts
+  for (int q = threadIdx.x; q < 4 * n_keys; q += kPartTile) wh[q] = 0;
+  __syncthreads();
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * kPartTile + threadIdx.x;
+  const bool valid = e < n_items;
+  int k = 0;
+  if (valid) {
+    int64_t kk = key[e * stride];
+    k = (kk < 0 || kk >= n_keys) ? 0 : (int)kk;
+  }
+  int rank = 0;
+  unsigned long long todo = __ballot(valid);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int kl = __shfl(k, leader);
+    const unsigned long long m = __ballot(valid && k == kl);
+    if (valid && k == kl) rank = __popcll(m & lt);
+    if (lane == leader) wh[w * n_keys + kl] = __popcll(m);
+    todo &= ~m;
+  }
+  __syncthreads();
+  if (valid) {
+    int base = offs[(size_t)k * n_tiles + blockIdx.x];
+    for (int ww = 0; ww < w; ++ww) base += wh[ww * n_keys + k];
+    perm[base + rank] = (int32_t)e;
+  }
+  if (blockIdx.x == 0) {
+    for (int q = threadIdx.x; q < n_keys; q += kPartTile) ptr[q] = offs[(size_t)q * n_tiles];
+    if (threadIdx.x == 0) ptr[n_keys] = (int32_t)n_items;
+  }
+}
+
+inline bool use_partition(int64_t n_keys, int64_t n_items) {
+  return n_keys <= kPartMaxKeys && n_keys * ceil_div(std::max<int64_t>(n_items, 1), kPartTile) <= (1ll << 24);
+}
+
+size_t partition_ws_bytes(int64_t n_keys, int64_t n_items) {
+  const int64_t tiles = ceil_div(std::max<int64_t>(n_items, 1), kPartTile);
+  const int64_t len = n_keys * tiles + 1;
+  return align_up((size_t)len * 4, 256) + align_up((size_t)ceil_div(len, kScanItems) * 4, 256);
+}
+
+int run_partition(const int64_t* key, int64_t stride, int64_t n_items, int64_t n_keys, int32_t* ptr,
+                  int32_t* perm, int32_t* status, void* ws, hipStream_t st) {
+  const int n_tiles = (int)ceil_div(std::max<int64_t>(n_items, 1), kPartTile);
+  const int64_t len = n_keys * n_tiles + 1;
+  Carver cv(ws);
+  int32_t* offs = cv.take<int32_t>((size_t)len);
+  int32_t* bsum = cv.take<int32_t>((size_t)ceil_div(len, kScanItems));
+  PGNN_HIP(hipMemsetAsync(offs, 0, 4, st));  // element 0; the rest is fully written by k_part_hist
+  hipLaunchKernelGGL(k_part_hist, dim3(n_tiles), dim3(kPartTile), (size_t)n_keys * 4, st, key, stride, n_items,
+                     (int)n_keys, n_tiles, offs, status);
+  GroupJobs jobs;
+  jobs.j[0] = GroupJob{nullptr, 1, offs, nullptr, nullptr, nullptr, bsum};
+  jobs.j[1] = jobs.j[0];
+  const int nb = (int)ceil_div(len, kScanItems);
+  hipLaunchKernelGGL(k_scan_local, dim3(nb, 1), dim3(256), 0, st, jobs, len);
+  if (nb > 1) {
+    hipLaunchKernelGGL(k_scan_bsum, dim3(1, 1), dim3(256), 0, st, jobs, nb);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb - 1, 1), dim3(256), 0, st, jobs, len);
+  }
+  hipLaunchKernelGGL(k_part_scatter, dim3(n_tiles), dim3(kPartTile), (size_t)4 * n_keys * 4, st, key, stride,
+                     n_items, (int)n_keys, n_tiles, offs, ptr, perm);
+  return check_launch("group_by_key(partition)");
+}
+
 int run_group(GroupJobs jobs, int njobs, int64_t n_items, int64_t n_keys, int32_t* status,
               hipStream_t st) {
   const int64_t n = n_keys + 1;
@@ -346,15 +448,20 @@ int pgnn_bio_graph_build(const int64_t* ei, const float* ea, int64_t E, int64_t 
   return check_launch("bio_graph_build");
 }
 
+size_t pgnn_group_workspace_bytes(int64_t n_keys, int64_t n_items) {
+  return (use_partition(n_keys, n_items) ? partition_ws_bytes(n_keys, n_items) : group_ws_bytes(n_keys, n_items)) + 256;
+}
+
 int pgnn_group_by_key(const int64_t* key, int64_t key_stride, int64_t n_items, int64_t n_keys,
                       int32_t* ptr, int32_t* perm, int32_t* status, void* ws, size_t ws_bytes,
                       pgnn_stream stream) {
-  PGNN_REQUIRE(n_keys > 0 && n_items >= 0 && key_stride >= 1, "bad group_by_key sizes");
-  if (ws_bytes < group_ws_bytes(n_keys, n_items)) {
+  PGNN_REQUIRE(n_keys > 0 && n_items >= 0 && key_stride >= 1 && n_items < (1ll << 31), "bad group_by_key sizes");
+  if (ws_bytes < pgnn_group_workspace_bytes(n_keys, n_items)) {
     set_error("group_by_key workspace too small");
     return PGNN_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (use_partition(n_keys, n_items)) return run_partition(key, key_stride, n_items, n_keys, ptr, perm, status, ws, st);
   Carver cv(ws);
   GroupJobs jobs;
   int32_t* cursor = cv.take<int32_t>((size_t)n_keys);

@@ -201,24 +201,29 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
   }
 }
 
-// column sums of dy[M, N] -> partial[blk][N]; then final
-__global__ void __launch_bounds__(256) k_colsum_partial(const float* __restrict__ dy, int64_t ld, int m, int n,
-                                                        float* __restrict__ partial) {
+// column sums of dy[M, N] -> partial[blk][N] (float4 columns x 4 row lanes per block); then final
+__global__ void k_colsum_partial(const float* __restrict__ dy, int64_t ld, int m, int n4,
+                                 float* __restrict__ partial) {
+  extern __shared__ __align__(16) float lds[];  // [4][n]
+  const int t = threadIdx.x, c4 = t % n4, rl = t / n4, n = n4 * 4;
   const int per = (m + gridDim.x - 1) / gridDim.x;
   const int r0 = blockIdx.x * per, r1 = min(m, r0 + per);
-  for (int c = threadIdx.x; c < n; c += blockDim.x) {
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += dy[(int64_t)r * ld + c];
-    partial[(size_t)blockIdx.x * n + c] = s;
+  float4 s = f4_zero();
+  if (rl < 4) {
+    for (int r = r0 + rl; r < r1; r += 4) s = f4_add(s, reinterpret_cast<const float4*>(dy + (int64_t)r * ld)[c4]);
+    reinterpret_cast<float4*>(lds + rl * n)[c4] = s;
   }
+  __syncthreads();
+  for (int q = t; q < n; q += blockDim.x)
+    partial[(size_t)blockIdx.x * n + q] = (lds[q] + lds[n + q]) + (lds[2 * n + q] + lds[3 * n + q]);
 }
 __global__ void __launch_bounds__(256) k_colsum_final(const float* __restrict__ partial, int nblk, int n,
                                                       float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * n + c];
-  out[c] = (float)s;
+  const int sl = threadIdx.x & 15;
+  const int cc = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int c = min(cc, n - 1);
+  const double s = slice_sum16(partial + c, (size_t)n, nblk, sl);
+  if (sl == 0 && cc < n) out[c] = (float)s;
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI>
@@ -232,7 +237,7 @@ int launch_gemm(const GemmArgs& p, int nsplit, hipStream_t st) {
   return check_launch("gemm");
 }
 
-inline int colsum_blocks(int64_t m) { return (int)std::min<int64_t>(std::max<int64_t>(ceil_div(m, 64), 1), 512); }
+inline int colsum_blocks(int64_t m) { return (int)std::min<int64_t>(std::max<int64_t>(ceil_div(m, 32), 1), 1024); }
 
 constexpr int kWgtBM = 64, kWgtBN = 64, kWgtBK = 16;
 
@@ -281,6 +286,7 @@ int pgnn_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_
                            int64_t m, int64_t k, int64_t n, void* ws, size_t ws_bytes, pgnn_stream stream) {
   PGNN_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0,
                "linear_bwd_weight: K, N and leading dimensions must be multiples of 4");
+  PGNN_REQUIRE(n <= 1024, "linear_bwd_weight: output width > 1024 not supported");
   if (ws_bytes < pgnn_linear_bwd_weight_workspace_bytes(m, k, n)) {
     set_error("linear_bwd_weight workspace too small");
     return PGNN_ERR_WORKSPACE;
@@ -312,8 +318,9 @@ int pgnn_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_
   }
   if (db) {
     const int nb = colsum_blocks(m);
-    hipLaunchKernelGGL(k_colsum_partial, dim3(nb), dim3(256), 0, st, dy, lddy, (int)m, (int)n, colpart);
-    hipLaunchKernelGGL(k_colsum_final, dim3((int)ceil_div(n, 256)), dim3(256), 0, st, colpart, nb, (int)n, db);
+    hipLaunchKernelGGL(k_colsum_partial, dim3(nb), dim3((int)align_up((size_t)n, 64)), (size_t)4 * n * sizeof(float), st,
+                       dy, lddy, (int)m, (int)(n / 4), colpart);
+    hipLaunchKernelGGL(k_colsum_final, dim3((int)ceil_div(n, 16)), dim3(256), 0, st, colpart, nb, (int)n, db);
   }
   return check_launch("linear_bwd_weight");
 }

@@ -122,7 +122,7 @@ def group_by_key(key, n_keys, stride=1, offset=0):
     ptr = torch.empty(n_keys + 1, dtype=torch.int32, device=dev)
     perm = torch.empty(max(n_items, 1), dtype=torch.int32, device=dev)
     status = torch.zeros(1, dtype=torch.int32, device=dev)
-    ws = _workspace(_ws_bytes("pgnn_graph_workspace_bytes", n_keys, n_items), dev)
+    ws = _workspace(_ws_bytes("pgnn_group_workspace_bytes", n_keys, n_items), dev)
     check(load().pgnn_group_by_key(key.data_ptr() + 8 * offset, stride, n_items, n_keys, ptr.data_ptr(),
                                    perm.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()),
           "pgnn_group_by_key")

@@ -1,0 +1,84 @@
+"""Host-side mirror of the reference's per-batch ``train()`` loop bodies, for the HIP-backed models.
+
+The reference scripts can call the drop-in ``model.GNN`` unchanged; these functions exist so that
+``bench.py`` and users without rdkit/torch_geometric can drive the same step without the scripts'
+dataset plumbing.  Same statements, same order, same dtypes (float64 losses) as
+chem/pretrain_masking.py:47-76, bio/pretrain_masking.py:39-64, chem/pretrain_contextpred.py:51-100.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+def compute_accuracy(pred, target):
+    return float(torch.sum(torch.max(pred.detach(), dim=1)[1] == target).cpu().item()) / len(pred)
+
+
+def chem_masking_step(model_list, optimizer_list, batch, mask_edge=False):
+    model, linear_pred_atoms, linear_pred_bonds = model_list
+    node_rep = model(batch.x, batch.edge_index, batch.edge_attr)
+    pred_node = linear_pred_atoms(node_rep[batch.masked_atom_indices])
+    loss = F.cross_entropy(pred_node.double(), batch.mask_node_label[:, 0])
+    acc_node = compute_accuracy(pred_node, batch.mask_node_label[:, 0])
+    acc_edge = 0.0
+    if mask_edge:
+        masked_edge_index = batch.edge_index[:, batch.connected_edge_indices]
+        edge_rep = node_rep[masked_edge_index[0]] + node_rep[masked_edge_index[1]]
+        pred_edge = linear_pred_bonds(edge_rep)
+        loss = loss + F.cross_entropy(pred_edge.double(), batch.mask_edge_label[:, 0])
+        acc_edge = compute_accuracy(pred_edge, batch.mask_edge_label[:, 0])
+    for opt in optimizer_list:
+        opt.zero_grad()
+    loss.backward()
+    for opt in optimizer_list:
+        opt.step()
+    return float(loss.cpu().item()), acc_node, acc_edge
+
+
+def bio_masking_step(model_list, optimizer_list, batch):
+    model, linear_pred_edges = model_list
+    node_rep = model(batch.x, batch.edge_index, batch.edge_attr)
+    masked_edge_index = batch.edge_index[:, batch.masked_edge_idx]
+    edge_rep = node_rep[masked_edge_index[0]] + node_rep[masked_edge_index[1]]
+    pred_edge = linear_pred_edges(edge_rep)
+    edge_label = torch.argmax(batch.mask_edge_label, dim=1)
+    acc_edge = compute_accuracy(pred_edge, edge_label)
+    for opt in optimizer_list:
+        opt.zero_grad()
+    loss = F.cross_entropy(pred_edge, edge_label)
+    loss.backward()
+    for opt in optimizer_list:
+        opt.step()
+    return float(loss.cpu().item()), acc_edge
+
+
+def cycle_index(num, shift):
+    arr = torch.arange(num) + shift
+    arr[-shift:] = torch.arange(shift)
+    return arr
+
+
+def chem_contextpred_step(model_substruct, model_context, optimizer_substruct, optimizer_context, batch, neg_samples=1):
+    """cbow mode with mean context pooling (the reference defaults)."""
+    substruct_rep = model_substruct(batch.x_substruct, batch.edge_index_substruct,
+                                    batch.edge_attr_substruct)[batch.center_substruct_idx]
+    overlapped_node_rep = model_context(batch.x_context, batch.edge_index_context,
+                                        batch.edge_attr_context)[batch.overlap_context_substruct_idx]
+    context_rep = ops.global_mean_pool(overlapped_node_rep, batch.batch_overlapped_context)
+    neg_context_rep = torch.cat([context_rep[cycle_index(len(context_rep), i + 1).to(context_rep.device)]
+                                 for i in range(neg_samples)], dim=0)
+    pred_pos = torch.sum(substruct_rep * context_rep, dim=1)
+    pred_neg = torch.sum(substruct_rep.repeat((neg_samples, 1)) * neg_context_rep, dim=1)
+    loss_pos = F.binary_cross_entropy_with_logits(pred_pos.double(), torch.ones_like(pred_pos).double())
+    loss_neg = F.binary_cross_entropy_with_logits(pred_neg.double(), torch.zeros_like(pred_neg).double())
+    optimizer_substruct.zero_grad()
+    optimizer_context.zero_grad()
+    loss = loss_pos + neg_samples * loss_neg
+    loss.backward()
+    optimizer_substruct.step()
+    optimizer_context.step()
+    balanced = float(loss_pos.detach().cpu().item() + loss_neg.detach().cpu().item())
+    acc = 0.5 * (float(torch.sum(pred_pos > 0).detach().cpu().item()) / len(pred_pos)
+                 + float(torch.sum(pred_neg < 0).detach().cpu().item()) / len(pred_neg))
+    return balanced, acc

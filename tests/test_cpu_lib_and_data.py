@@ -1,0 +1,170 @@
+"""CPU (-m "not gpu"): the C-ABI library loads and exports exactly what include/pgnn.h declares,
+the host-side class surface mirrors the reference's, and the synthetic generators obey the
+reference's data contracts.  No compute call is made (no GPU here)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from pretrain_gnns_amd import _lib
+from pretrain_gnns_amd.data import synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "pgnn.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b(pgnn_[a-z0-9_]+)\s*\(", src))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()  # raises if libpgnn.so is missing or a prototype cannot be bound
+    declared = _header_functions()
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.pgnn_abi_version() == _lib.ABI_VERSION
+    # pure host-side helpers are callable without a GPU
+    assert lib.pgnn_graph_workspace_bytes(100, 300) > 0
+    assert lib.pgnn_bn_workspace_bytes(1000, 300) > 0
+    assert lib.pgnn_linear_bwd_weight_workspace_bytes(1000, 300, 600) >= 600 * 300 * 4
+
+
+def test_product_path_has_no_cpu_fallback():
+    from pretrain_gnns_amd import ops
+    from pretrain_gnns_amd.chem import model as hchem
+    m = hchem.GNN(2, 32)
+    b = synthetic.chem_plain_batch(2, seed=0)
+    with pytest.raises(_lib.PgnnError, match="no CPU fallback"):
+        m(b.x, b.edge_index, b.edge_attr)
+    with pytest.raises(_lib.PgnnError):
+        ops.global_mean_pool(torch.zeros(4, 8), torch.zeros(4, dtype=torch.long), 1)
+    # nothing under the package imports the oracle
+    pkg = os.path.join(ROOT, "pretrain_gnns_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read().replace("oracle/", ""), f
+
+
+def test_class_surface_matches_reference_contract():
+    from oracle import bio as obio
+    from oracle import chem as ochem
+    from pretrain_gnns_amd.bio import model as hbio
+    from pretrain_gnns_amd.chem import model as hchem
+    for gnn_type in ("gin", "gcn"):
+        a, b = ochem.GNN(5, 300, gnn_type=gnn_type).state_dict(), hchem.GNN(5, 300, gnn_type=gnn_type).state_dict()
+        assert list(a) == list(b) and all(a[k].shape == b[k].shape for k in a)
+        a, b = obio.GNN(5, 300, gnn_type=gnn_type).state_dict(), hbio.GNN(5, 300, gnn_type=gnn_type).state_dict()
+        assert list(a) == list(b) and all(a[k].shape == b[k].shape for k in a)
+    a, b = ochem.GNN_graphpred(5, 300, 12).state_dict(), hchem.GNN_graphpred(5, 300, 12).state_dict()
+    assert list(a) == list(b)
+    # identical seeded initialisation (construction order preserved)
+    torch.manual_seed(0)
+    r = ochem.GNN(3, 16)
+    torch.manual_seed(0)
+    h = hchem.GNN(3, 16)
+    assert all(torch.equal(p, q) for p, q in zip(r.state_dict().values(), h.state_dict().values()))
+    g = hchem.GNN_graphpred(5, 300, 3)
+    assert hasattr(g, "gnn") and hasattr(g, "pool") and hasattr(g, "graph_pred_linear")
+    with pytest.raises(ValueError, match="greater than 1"):
+        hchem.GNN(1, 8)
+    with pytest.raises(ValueError, match="greater than 1"):
+        hbio.GNN_graphpred(1, 8, 2)
+    with pytest.raises(ValueError, match="Invalid graph pooling"):
+        hchem.GNN_graphpred(2, 8, 1, graph_pooling="nope")
+    with pytest.raises(ValueError, match="unmatched number"):
+        hchem.GNN(2, 8)(torch.zeros(1), torch.zeros(1))
+    with pytest.raises(ValueError, match="unmatched number"):
+        hchem.GNN_graphpred(2, 8, 1)(torch.zeros(1), torch.zeros(1))
+
+
+def test_golden_checkpoints_strict_load_into_hip_classes():
+    from pretrain_gnns_amd.bio import model as hbio
+    from pretrain_gnns_amd.chem import model as hchem
+    for name, cls in (("chem_gcn_contextpred", hchem.GNN), ("bio_gcn_masking", hbio.GNN)):
+        fx = torch.load(os.path.join(ROOT, "tests", "golden", name + ".pt"), map_location="cpu")
+        res = cls(5, 300, gnn_type="gcn").load_state_dict(fx["state_dict"], strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+
+
+def test_zinc_like_batches_follow_reference_layout():
+    b = synthetic.chem_masking_batch(64, seed=3, mask_edge=True)
+    n, e = b.x.size(0), b.edge_index.size(1)
+    assert b.x.dtype == b.edge_index.dtype == b.edge_attr.dtype == torch.int64
+    assert b.x.shape == (n, 2) and b.edge_attr.shape == (e, 2) and b.batch.shape == (n,)
+    # both directions of a bond are adjacent and carry identical attributes (chem/util.py:212-213)
+    assert torch.equal(b.edge_index[:, 0::2], b.edge_index[:, 1::2].flip(0))
+    assert torch.equal(b.edge_attr[0::2], b.edge_attr[1::2])
+    # no edge crosses graphs; batch vector sorted
+    assert torch.equal(b.batch[b.edge_index[0]], b.batch[b.edge_index[1]])
+    assert bool((b.batch[1:] >= b.batch[:-1]).all())
+    # MaskAtom: masked rows are [119, 0], labels are real atoms, count = sum int(n_g*0.15+1)
+    assert torch.equal(b.x[b.masked_atom_indices], torch.tensor([[119, 0]]).repeat(b.masked_atom_indices.numel(), 1))
+    assert int(b.mask_node_label[:, 0].max()) < 119
+    sizes = torch.bincount(b.batch)
+    assert b.masked_atom_indices.numel() == int(sum(int(int(s) * 0.15 + 1) for s in sizes))
+    assert torch.equal(torch.bincount(b.batch[b.masked_atom_indices], minlength=64),
+                       torch.tensor([int(int(s) * 0.15 + 1) for s in sizes]))
+    # mask_edge: every edge touching a masked atom is [5, 0]; labels are real bond types
+    touched = torch.isin(b.edge_index[0], b.masked_atom_indices) | torch.isin(b.edge_index[1], b.masked_atom_indices)
+    assert torch.equal(b.edge_attr[touched], torch.tensor([[5, 0]]).repeat(int(touched.sum()), 1))
+    assert int(b.edge_attr[~touched][:, 0].max()) <= 3 and int(b.mask_edge_label[:, 0].max()) <= 3
+    assert b.connected_edge_indices.numel() * 2 == int(touched.sum())
+    # vocabulary bounds the kernels rely on
+    assert int(b.x[:, 0].max()) < 120 and int(b.x[:, 1].max()) < 3
+    deg = torch.bincount(b.edge_index[0], minlength=n)
+    assert int(deg.max()) <= 5
+
+
+def test_shape_statistics_are_zinc_and_ppi_like():
+    b = synthetic.chem_plain_batch(1024, seed=1)
+    assert 25.5 < b.x.size(0) / 1024 < 27.5 and 55 < b.edge_index.size(1) / 1024 < 60  # 26.6 / 57.7
+    p = synthetic.bio_masking_batch(64, seed=1)
+    assert 36 < p.x.size(0) / 64 < 44 and 600 < p.edge_index.size(1) / 64 < 860          # 39.8 / ~730
+    assert p.x.dtype == torch.float32 and p.edge_attr.shape[1] == 9 and p.center_node_idx.numel() == 64
+    # MaskEdge: both directions of a masked edge carry the mask row; labels have >= 1 evidence bit
+    m = p.masked_edge_idx
+    mask_row = torch.tensor([0.0] * 8 + [1.0])
+    assert torch.equal(p.edge_attr[m], mask_row.repeat(m.numel(), 1)) and torch.equal(p.edge_attr[m + 1], p.edge_attr[m])
+    assert bool((p.mask_edge_label[:, :7].sum(1) >= 1).all()) and float(p.mask_edge_label[:, 7:].sum()) == 0
+    assert bool((m % 2 == 0).all())
+
+
+def test_substruct_context_extraction_invariants():
+    """the disabled asserts of chem/util.py:294-345, restated on a synthetic molecule."""
+    rng = np.random.default_rng(0)
+    g = synthetic.zinc_like_graph(rng)
+    n = g.x.size(0)
+    big = synthetic.extract_substruct_context(g, rng, k=10 ** 6, l1=0 - 1, l2=10 ** 6, root=3)
+    assert big.x_substruct.size(0) == n and torch.equal(big.x_substruct, g.x)          # huge k: substruct == molecule
+    assert big.edge_index_substruct.size(1) == g.edge_index.size(1)
+    for i in range(1, 6):                                                             # k = l1 = i: disjoint cover
+        d = synthetic.extract_substruct_context(g, rng, k=i, l1=i, l2=10 ** 6, root=3)
+        n_ctx = d.x_context.size(0) if hasattr(d, "x_context") else 0
+        assert d.x_substruct.size(0) + n_ctx == n
+        assert not hasattr(d, "overlap_context_substruct_idx")
+    d = synthetic.extract_substruct_context(g, rng, k=5, l1=4, l2=7, root=0)
+    assert int(d.center_substruct_idx) == 0
+    if hasattr(d, "overlap_context_substruct_idx"):
+        assert int(d.overlap_context_substruct_idx.max()) < d.x_context.size(0)
+    b = synthetic.chem_contextpred_batch(32, seed=5)
+    m = b.center_substruct_idx.numel()
+    assert b.overlapped_context_size.numel() == m and int(b.batch_overlapped_context.max()) == m - 1
+    assert int(b.edge_index_substruct.max()) < b.x_substruct.size(0)
+    assert int(b.edge_index_context.max()) < b.x_context.size(0)
+    assert int(b.overlapped_context_size.sum()) == b.overlap_context_substruct_idx.numel()
+
+
+def test_tile_batch_offsets():
+    b = synthetic.chem_masking_batch(8, seed=0)
+    t = synthetic.tile_batch(b, 3)
+    n, e = b.x.size(0), b.edge_index.size(1)
+    assert t.x.size(0) == 3 * n and t.edge_index.size(1) == 3 * e
+    assert torch.equal(t.edge_index[:, e:2 * e], b.edge_index + n)
+    assert torch.equal(t.masked_atom_indices[b.masked_atom_indices.numel():2 * b.masked_atom_indices.numel()],
+                       b.masked_atom_indices + n)
+    assert int(t.batch[-1]) == 23

@@ -1,0 +1,129 @@
+"""CPU (-m "not gpu"): the oracle against everything the reference pins for the hot path.
+
+SURVEY.md §8c: the reference has no numerical test of GNN.forward ("parity unpinned" at the
+arithmetic level).  What it does pin -- and what is checked here -- is (i) the shipped GCN
+checkpoints (state-dict contract + real weights and BatchNorm running statistics), through the
+committed fixtures of oracle/make_golden.py, (ii) the vocabulary constants, (iii) the edge-order and
+masking contracts documented in chem/util.py:212-241 and the disabled asserts of chem/util.py:365-419.
+"""
+import os
+
+import pytest
+import torch
+
+from oracle import bio as obio
+from oracle import chem as ochem
+from oracle import pyg_semantics as pyg
+from oracle import steps
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name,cls", [("chem_gcn_contextpred", ochem.GNN), ("bio_gcn_masking", obio.GNN)])
+def test_oracle_reproduces_golden_checkpoint_outputs(name, cls):
+    fx = torch.load(os.path.join(GOLDEN, name + ".pt"), map_location="cpu")
+    m = cls(5, 300, gnn_type="gcn")
+    res = m.load_state_dict(fx["state_dict"], strict=True)  # the drop-in key/shape contract
+    assert not res.missing_keys and not res.unexpected_keys
+    b = fx["batch"]
+    m.eval()
+    with torch.no_grad():
+        out = m(b["x"], b["edge_index"], b["edge_attr"])
+    torch.testing.assert_close(out, fx["out_eval"], rtol=1e-4, atol=1e-5)
+    m.train()
+    out = m(b["x"], b["edge_index"], b["edge_attr"])
+    torch.testing.assert_close(out.detach(), fx["out_train"], rtol=1e-4, atol=1e-5)
+
+
+def test_checkpoint_key_contract():
+    fx = torch.load(os.path.join(GOLDEN, "chem_gcn_contextpred.pt"), map_location="cpu")
+    keys = set(fx["state_dict"])
+    assert {"x_embedding1.weight", "x_embedding2.weight", "gnns.0.linear.weight", "gnns.0.linear.bias",
+            "gnns.4.edge_embedding1.weight", "gnns.4.edge_embedding2.weight", "batch_norms.0.running_mean",
+            "batch_norms.4.num_batches_tracked"} <= keys
+    assert fx["state_dict"]["x_embedding1.weight"].shape == (120, 300)
+    assert fx["state_dict"]["gnns.0.edge_embedding1.weight"].shape == (6, 300)
+    gin = set(ochem.GNN(5, 300).state_dict())
+    assert {"gnns.0.mlp.0.weight", "gnns.0.mlp.2.bias"} <= gin
+    bio = obio.GNN(5, 300).state_dict()
+    assert bio["gnns.0.mlp.0.weight"].shape == (600, 600) and bio["gnns.0.mlp.3.weight"].shape == (300, 600)
+    assert bio["gnns.0.edge_encoder.weight"].shape == (300, 9) and "gnns.0.input_node_embeddings.weight" in bio
+    assert "gnns.1.input_node_embeddings.weight" not in bio
+
+
+def test_constants():
+    c = torch.load(os.path.join(GOLDEN, "constants.pt"))
+    assert (ochem.NUM_ATOM_TYPE, ochem.NUM_CHIRALITY_TAG, ochem.NUM_BOND_TYPE, ochem.NUM_BOND_DIRECTION) == (
+        c["num_atom_type"], c["num_chirality_tag"], c["num_bond_type"], c["num_bond_direction"])
+    assert ochem.SELF_LOOP_BOND_TYPE == c["self_loop_bond_type"]
+    from pretrain_gnns_amd.data import synthetic
+    assert synthetic.ATOM_MASK_TOKEN == c["atom_mask_token"] and synthetic.BOND_MASK_TOKEN == c["bond_mask_token"]
+
+
+def test_pyg_semantics():
+    ei = torch.tensor([[0, 1, 1, 2, 2, 3], [1, 0, 2, 1, 3, 2]])
+    full = pyg.add_self_loops(ei, 4)
+    assert full.shape == (2, 10) and torch.equal(full[:, 6:], torch.arange(4).repeat(2, 1))  # loops appended last
+    x = torch.arange(8, dtype=torch.float32).view(4, 2)
+    # aggregate at edge_index[0] the features gathered at edge_index[1]
+    agg = pyg.propagate_add(ei, x, None, lambda xj, _: xj, 4)
+    assert torch.equal(agg, torch.stack([x[1], x[0] + x[2], x[1] + x[3], x[2]]))
+    batch = torch.tensor([0, 0, 2, 2])
+    mean = pyg.global_mean_pool(x, batch)
+    assert mean.shape == (3, 2) and torch.equal(mean[1], torch.zeros(2))  # empty graph: sum 0 / clamp(count,1)
+    assert torch.equal(mean[0], (x[0] + x[1]) / 2)
+
+
+def test_gin_layer_matches_hand_computation():
+    torch.manual_seed(0)
+    conv = ochem.GINConv(8)
+    x = torch.randn(3, 8)
+    ei = torch.tensor([[0, 1], [1, 0]])
+    ea = torch.tensor([[2, 1], [2, 1]])
+    e = conv.edge_embedding1.weight[2] + conv.edge_embedding2.weight[1]
+    loop = conv.edge_embedding1.weight[4] + conv.edge_embedding2.weight[0]
+    want = torch.stack([(x[1] + e) + (x[0] + loop), (x[0] + e) + (x[1] + loop), x[2] + loop])
+    assert torch.equal(conv.aggregate(x, ei, ea), want)
+
+
+def test_gcn_norm_and_jk_sum_quirk():
+    ei = torch.tensor([[0, 1, 1, 2], [1, 0, 2, 1]])
+    full = pyg.add_self_loops(ei, 3)
+    nrm = ochem.GCNConv.norm(full, 3, torch.float32)
+    deg = torch.tensor([2.0, 3.0, 2.0])
+    want = deg[full[0]].pow(-0.5) * deg[full[1]].pow(-0.5)
+    torch.testing.assert_close(nrm, want)
+    m = ochem.GNN(2, 8, JK="sum")
+    out = m(torch.zeros(4, 2, dtype=torch.long), ei[:, :2], torch.zeros(2, 2, dtype=torch.long))
+    assert out.shape == (8,)  # the reference returns node 0's row only (chem/model.py:286-288)
+
+
+def test_argument_errors_match_reference():
+    with pytest.raises(ValueError, match="greater than 1"):
+        ochem.GNN(1, 8)
+    with pytest.raises(ValueError, match="unmatched number"):
+        ochem.GNN(2, 8)(torch.zeros(1), torch.zeros(1))
+    with pytest.raises(ValueError, match="Invalid graph pooling"):
+        ochem.GNN_graphpred(2, 8, 1, graph_pooling="nope")
+
+
+def test_cycle_index_and_contextpred_logits():
+    assert steps.cycle_index(5, 1).tolist() == [1, 2, 3, 4, 0]
+    assert steps.cycle_index(5, 2).tolist() == [2, 3, 4, 0, 1]
+    from pretrain_gnns_amd.data import synthetic
+    b = synthetic.chem_contextpred_batch(8, seed=0)
+    torch.manual_seed(0)
+    ms, mc = ochem.GNN(5, 16), ochem.GNN(3, 16)
+    pos, neg = steps.contextpred_logits(ms, mc, b)
+    n = b.center_substruct_idx.numel()
+    assert pos.shape == (n,) and neg.shape == (n,)
+
+
+def test_masking_step_decreases_loss():
+    from pretrain_gnns_amd.data import synthetic
+    torch.manual_seed(0)
+    b = synthetic.chem_masking_batch(8, seed=0)
+    mods = [ochem.GNN(5, 32), torch.nn.Linear(32, 119), torch.nn.Linear(32, 4)]
+    opts = [torch.optim.Adam(m.parameters(), lr=1e-3) for m in mods]
+    losses = [steps.chem_masking_step(mods, opts, b)[0] for _ in range(8)]
+    assert losses[-1] < losses[0]

@@ -1,0 +1,285 @@
+"""-m gpu: model-level parity of the HIP-backed GNN / GNN_graphpred classes against the CPU oracle.
+
+Bar (BASELINE.json north_star): node embeddings and masked-atom logits within 1e-4 (fp32) of the
+reference CPU path; here |a-b| <= 1e-4 + 1e-4*|b|.  Gradients and multi-step training are checked
+with the tolerances written next to each assert.
+"""
+import os
+
+import pytest
+import torch
+
+from oracle import bio as obio
+from oracle import chem as ochem
+from oracle import pyg_semantics as pyg
+from oracle import steps
+from pretrain_gnns_amd.data import synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = dict(rtol=1e-4, atol=1e-4)
+
+
+def _hip():
+    from pretrain_gnns_amd.bio import model as hbio
+    from pretrain_gnns_amd.chem import model as hchem
+    return hchem, hbio
+
+
+def _pair(ocls, hcls, *args, seed=0, **kw):
+    torch.manual_seed(seed)
+    ref = ocls(*args, **kw)
+    hip = hcls(*args, **kw)
+    hip.load_state_dict(ref.state_dict())
+    return ref, hip.to(DEV)
+
+
+def _grads_close(ref, hip, batch_args, weight, l2_tol=2e-2):
+    """Gradient parity against the FLOAT64 oracle in relative L2 norm, robust to ReLU mask flips.
+
+    A pre-activation within rounding distance of zero lands on different sides in two fp32
+    implementations; one flipped unit perturbs the gradients of everything upstream by ~1e-3
+    (dense, because weight gradients sum over all nodes).  Measured on the MI355X host with
+    tools/debug_layers.py: torch-CPU fp32 vs fp64 deviates by 1e-3..5e-2 (max-norm) on the very
+    batch where this stack sits at 1e-6.  Hence the model-level bar is a relative L2 error of
+    ``l2_tol`` per parameter (real kernel bugs are O(10%) and the op-level tests in
+    test_gpu_ops.py hold each kernel to 1e-5); analytically-zero gradients (biases feeding a
+    BatchNorm) are normalised by the model's largest gradient instead of their own.
+    """
+    import copy
+    ref64 = copy.deepcopy(ref).double()
+    ref64.zero_grad()
+    out = ref64(*batch_args)
+    (out * weight.double()).sum().backward()
+    g64 = {n: p.grad for n, p in ref64.named_parameters()}
+    gscale = max(float(g.abs().max()) for g in g64.values() if g is not None)
+    bad = []
+    for name, ph in hip.named_parameters():
+        g = g64[name]
+        if g is None:
+            assert ph.grad is None or float(ph.grad.abs().max()) == 0.0, name
+            continue
+        err = (ph.grad.detach().cpu().double() - g)
+        l2 = float(err.norm() / (g.norm() + 1e-3 * gscale * g.numel() ** 0.5))
+        if not l2 <= l2_tol:
+            bad.append((name, l2))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("gnn_type", ["gin", "gcn"])
+@pytest.mark.parametrize("graphs", [1, 32])
+def test_chem_gnn_forward_backward(gnn_type, graphs):
+    hchem, _ = _hip()
+    ref, hip = _pair(ochem.GNN, hchem.GNN, 5, 300, gnn_type=gnn_type)
+    b = synthetic.chem_masking_batch(graphs, seed=graphs)
+    d = b.clone().to(DEV)
+    out_ref = ref(b.x, b.edge_index, b.edge_attr)
+    out_hip = hip(d.x, d.edge_index, d.edge_attr)
+    torch.testing.assert_close(out_hip.detach().cpu(), out_ref.detach(), **TOL)
+    w = torch.randn_like(out_ref)
+    (out_hip * w.to(DEV)).sum().backward()
+    _grads_close(ref, hip, (b.x, b.edge_index, b.edge_attr), w)
+    # data-object overload and eval mode
+    ref.eval(), hip.eval()
+    with torch.no_grad():
+        torch.testing.assert_close(hip(d).cpu(), ref(b), **TOL)
+
+
+def test_chem_masked_atom_logits_match():
+    """the quantity BASELINE.json names: masked-atom logits within 1e-4."""
+    hchem, _ = _hip()
+    ref, hip = _pair(ochem.GNN, hchem.GNN, 5, 300)
+    torch.manual_seed(5)
+    head = torch.nn.Linear(300, 119)
+    head_d = torch.nn.Linear(300, 119)
+    head_d.load_state_dict(head.state_dict())
+    head_d = head_d.to(DEV)
+    b = synthetic.chem_masking_batch(256, seed=0)
+    d = b.clone().to(DEV)
+    lr = head(ref(b.x, b.edge_index, b.edge_attr)[b.masked_atom_indices])
+    lh = head_d(hip(d.x, d.edge_index, d.edge_attr)[d.masked_atom_indices])
+    torch.testing.assert_close(lh.detach().cpu(), lr.detach(), **TOL)
+    assert steps.compute_accuracy(lh.cpu(), b.mask_node_label[:, 0]) == steps.compute_accuracy(lr, b.mask_node_label[:, 0])
+
+
+@pytest.mark.parametrize("jk", ["concat", "max", "sum"])
+def test_chem_jk_modes(jk):
+    hchem, _ = _hip()
+    ref, hip = _pair(ochem.GNN, hchem.GNN, 3, 64, JK=jk)
+    b = synthetic.chem_plain_batch(4, seed=2)
+    d = b.clone().to(DEV)
+    torch.testing.assert_close(hip(d.x, d.edge_index, d.edge_attr).detach().cpu(),
+                               ref(b.x, b.edge_index, b.edge_attr).detach(), **TOL)
+
+
+@pytest.mark.parametrize("pool", ["mean", "sum", "max"])
+def test_chem_graphpred(pool):
+    hchem, _ = _hip()
+    ref, hip = _pair(ochem.GNN_graphpred, hchem.GNN_graphpred, 5, 300, 12, graph_pooling=pool)
+    b = synthetic.chem_plain_batch(16, seed=3)
+    d = b.clone().to(DEV)
+    out_ref = ref(b.x, b.edge_index, b.edge_attr, b.batch)
+    out_hip = hip(d.x, d.edge_index, d.edge_attr, d.batch)
+    torch.testing.assert_close(out_hip.detach().cpu(), out_ref.detach(), **TOL)
+    out_hip.sum().backward()
+    _grads_close(ref, hip, (b.x, b.edge_index, b.edge_attr, b.batch), torch.ones_like(out_ref))
+    torch.testing.assert_close(hip(d).detach().cpu(), ref(b).detach(), **TOL)
+
+
+@pytest.mark.parametrize("gnn_type", ["gin", "gcn"])
+def test_bio_gnn_forward_backward(gnn_type):
+    _, hbio = _hip()
+    ref, hip = _pair(obio.GNN, hbio.GNN, 5, 300, gnn_type=gnn_type)
+    b = synthetic.bio_masking_batch(8, seed=1)
+    d = b.clone().to(DEV)
+    out_ref = ref(b.x, b.edge_index, b.edge_attr)
+    out_hip = hip(d.x, d.edge_index, d.edge_attr)
+    torch.testing.assert_close(out_hip.detach().cpu(), out_ref.detach(), **TOL)
+    w = torch.randn_like(out_ref)
+    (out_hip * w.to(DEV)).sum().backward()
+    _grads_close(ref, hip, (b.x.double(), b.edge_index, b.edge_attr.double()), w)
+
+
+def test_bio_graphpred():
+    _, hbio = _hip()
+    ref, hip = _pair(obio.GNN_graphpred, hbio.GNN_graphpred, 5, 300, 40)
+    b = synthetic.bio_masking_batch(8, seed=2)
+    d = b.clone().to(DEV)
+    torch.testing.assert_close(hip(d).detach().cpu(), ref(b).detach(), **TOL)
+
+
+def _opt(*mods):
+    return [torch.optim.Adam(m.parameters(), lr=1e-3) for m in mods]
+
+
+@pytest.mark.parametrize("mask_edge", [False, True])
+def test_chem_masking_train_steps(mask_edge):
+    """reference train() body (chem/pretrain_masking.py:47-76) driven through both stacks."""
+    hchem, _ = _hip()
+    ref, hip = _pair(ochem.GNN, hchem.GNN, 5, 300)
+    torch.manual_seed(9)
+    heads = [torch.nn.Linear(300, 119), torch.nn.Linear(300, 4)]
+    heads_d = [torch.nn.Linear(300, 119), torch.nn.Linear(300, 4)]
+    for a, c in zip(heads_d, heads):
+        a.load_state_dict(c.state_dict())
+    heads_d = [h.to(DEV) for h in heads_d]
+    opt_r, opt_h = _opt(ref, *heads), _opt(hip, *heads_d)
+    for step in range(4):
+        b = synthetic.chem_masking_batch(32, seed=100 + step, mask_edge=mask_edge)
+        lr, ar, er = steps.chem_masking_step([ref] + heads, opt_r, b, mask_edge)
+        lh, ah, eh = steps.chem_masking_step([hip] + heads_d, opt_h, b.clone().to(DEV), mask_edge)
+        assert abs(lr - lh) < (1e-4 if step == 0 else 2e-2) * max(1.0, abs(lr)), (step, lr, lh)
+        assert abs(ar - ah) <= 0.02 and abs(er - eh) <= 0.02
+    for (n, pr), (_, ph) in zip(ref.named_parameters(), hip.named_parameters()):
+        # Adam moves every coordinate by ~lr per step whatever the gradient size, so coordinates whose
+        # gradient is rounding noise (e.g. biases in front of a BatchNorm) random-walk: bound = 4 steps x 2 lr
+        assert float((ph.detach().cpu() - pr.detach()).abs().max()) < 1e-2, n
+
+
+def test_chem_contextpred_train_steps():
+    hchem, _ = _hip()
+    ref_s, hip_s = _pair(ochem.GNN, hchem.GNN, 5, 300, seed=1)
+    ref_c, hip_c = _pair(ochem.GNN, hchem.GNN, 3, 300, seed=2)
+    o_rs, o_rc = _opt(ref_s, ref_c)
+    o_hs, o_hc = _opt(hip_s, hip_c)
+    for step in range(3):
+        b = synthetic.chem_contextpred_batch(32, seed=50 + step)
+        lr, ar = steps.chem_contextpred_step(ref_s, ref_c, o_rs, o_rc, b)
+        lh, ah = steps.chem_contextpred_step(hip_s, hip_c, o_hs, o_hc, b.clone().to(DEV), pool=hchem.global_mean_pool)
+        assert abs(lr - lh) < (1e-4 if step == 0 else 3e-2) * max(1.0, abs(lr)), (step, lr, lh)
+        assert abs(ar - ah) <= 0.05
+
+
+def test_bio_masking_train_steps():
+    _, hbio = _hip()
+    ref, hip = _pair(obio.GNN, hbio.GNN, 5, 300)
+    torch.manual_seed(3)
+    head = torch.nn.Linear(300, 7)
+    head_d = torch.nn.Linear(300, 7)
+    head_d.load_state_dict(head.state_dict())
+    head_d = head_d.to(DEV)
+    opt_r, opt_h = _opt(ref, head), _opt(hip, head_d)
+    for step in range(3):
+        b = synthetic.bio_masking_batch(8, seed=70 + step)
+        lr, ar = steps.bio_masking_step([ref, head], opt_r, b)
+        lh, ah = steps.bio_masking_step([hip, head_d], opt_h, b.clone().to(DEV))
+        assert abs(lr - lh) < (1e-4 if step == 0 else 3e-2) * max(1.0, abs(lr)), (step, lr, lh)
+        assert abs(ar - ah) <= 0.02
+
+
+@pytest.mark.parametrize("name", ["chem_gcn_contextpred", "bio_gcn_masking"])
+def test_golden_checkpoint_parity(name):
+    """real shipped GCN weights + BN running stats: strict load into the HIP classes, eval- and
+    train-mode embeddings and one gradient must match the fixture (oracle on the reference blob)."""
+    hchem, hbio = _hip()
+    fx = torch.load(os.path.join(GOLDEN, name + ".pt"), map_location="cpu")
+    cls = hchem.GNN if fx["kind"] == "chem" else hbio.GNN
+    m = cls(5, 300, gnn_type="gcn")
+    res = m.load_state_dict(fx["state_dict"], strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    m = m.to(DEV)
+    bt = {k: v.to(DEV) for k, v in fx["batch"].items()}
+    m.eval()
+    with torch.no_grad():
+        out = m(bt["x"], bt["edge_index"], bt["edge_attr"])
+    scale = float(fx["out_eval"].abs().max())
+    assert float((out.cpu() - fx["out_eval"]).abs().max()) <= 1e-4 * max(1.0, scale)
+    m.train()
+    out = m(bt["x"], bt["edge_index"], bt["edge_attr"])
+    assert float((out.detach().cpu() - fx["out_train"]).abs().max()) <= 1e-4 * max(1.0, float(fx["out_train"].abs().max()))
+    out.square().mean().backward()
+    g = dict(m.named_parameters())[fx["grad_name"]].grad.cpu()
+    assert float((g - fx["grad"]).abs().max()) <= 2e-3 * float(fx["grad"].abs().max()) + 1e-7
+
+
+def test_forward_is_bitwise_deterministic():
+    hchem, _ = _hip()
+    _, hip = _pair(ochem.GNN, hchem.GNN, 5, 300)
+    d = synthetic.chem_masking_batch(64, seed=4).to(DEV)
+    outs, grads = [], []
+    for _ in range(3):
+        hip.zero_grad()
+        o = hip(d.x, d.edge_index, d.edge_attr)
+        o.square().sum().backward()
+        outs.append(o.detach().clone())
+        grads.append(torch.cat([p.grad.flatten() for p in hip.parameters()]).clone())
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    assert all(torch.equal(grads[0], g) for g in grads[1:])
+
+
+def test_large_batch_properties():
+    """BASELINE full size (2048 graphs): size-independent checks instead of a slow oracle run --
+    linearity of the aggregation in x and agreement of the aggregation with a torch index_add on GPU."""
+    from pretrain_gnns_amd import ops
+    b = synthetic.chem_masking_batch(2048, seed=8).to(DEV)
+    n = b.x.size(0)
+    g = ops.build_chem_graph(b.edge_index, b.edge_attr, n)
+    g.check()
+    torch.manual_seed(0)
+    e1 = torch.randn(6, 300, device=DEV)
+    e2 = torch.randn(3, 300, device=DEV)
+    x = torch.randn(n, 300, device=DEV)
+    y = torch.randn(n, 300, device=DEV)
+    z = torch.zeros(6, 300, device=DEV), torch.zeros(3, 300, device=DEV)
+    ax = ops.ChemAggregate.apply(x, *z, g)
+    ay = ops.ChemAggregate.apply(y, *z, g)
+    axy = ops.ChemAggregate.apply(x + y, *z, g)
+    torch.testing.assert_close(axy, ax + ay, rtol=1e-5, atol=1e-5)
+    full = ops.ChemAggregate.apply(x, e1, e2, g)
+    ei = torch.cat([b.edge_index, torch.arange(n, device=DEV).repeat(2, 1)], 1)
+    ea = torch.cat([b.edge_attr, torch.tensor([[4, 0]], device=DEV).repeat(n, 1)], 0)
+    msg = x[ei[1]] + (e1[ea[:, 0]] + e2[ea[:, 1]])
+    want = torch.zeros(n, 300, device=DEV).index_add_(0, ei[0], msg)
+    torch.testing.assert_close(full, want, rtol=1e-5, atol=1e-5)
+
+
+def test_class_surface_errors():
+    hchem, hbio = _hip()
+    with pytest.raises(ValueError):
+        hchem.GNN(1, 300)
+    with pytest.raises(ValueError):
+        hchem.GNN_graphpred(5, 300, 1, graph_pooling="bogus")
+    m = hchem.GNN(2, 32).to(DEV)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1), torch.zeros(1))
