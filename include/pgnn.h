@@ -180,6 +180,10 @@ int pgnn_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_
                            float* db, int64_t m, int64_t k, int64_t n, void* ws, size_t ws_bytes,
                            pgnn_stream stream);
 
+/* diagnostics: plain float4 grid-stride copy (the HBM streaming ceiling bench.py quotes next to the
+ * aggregation kernel).  Not part of the hot path. */
+int pgnn_debug_stream_copy(const float* src, float* dst, int64_t n_floats, int64_t blocks, pgnn_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

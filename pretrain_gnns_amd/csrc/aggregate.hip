@@ -10,6 +10,8 @@
 // XCD-aware so that the rows a molecule's atoms gather from each other stay in one XCD's L2.
 // All reductions are sequential in a fixed order: results are bitwise reproducible, and the chem
 // aggregation reproduces the reference's CPU scatter_add order exactly.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace pgnn {
@@ -175,10 +177,578 @@ inline int pick_grid(int64_t n, int waves_per_node_chunk, int blocks_per_cu, int
   return (int)std::max<int64_t>(blocks, 1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Group-per-node variant: a node row is owned by dim/4 consecutive THREADS (75 for D = 300), so a
+// 320-thread block works on 4 nodes at once with one float4 accumulator per thread (94 % of the
+// lanes busy instead of 59 % for the wave-per-node mapping, ~40 VGPRs -> 8 waves/SIMD).  The
+// groups of a block take interleaved consecutive nodes, so the rows neighbouring atoms gather from
+// each other are in flight in the same CU.  Per-lane control flow (a wave straddles two nodes);
+// neighbour loads of one node are issued four at a time before the (ordered) accumulation.
+// ---------------------------------------------------------------------------------------------
+constexpr int kGrpBlock = 320;
+
+inline int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+template <bool TABLE, bool WEIGHT>
+__global__ void __launch_bounds__(kGrpBlock)
+k_aggregate_grp(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ ptr,
+                const int32_t* __restrict__ nbr, const uint8_t* __restrict__ code,
+                const float* __restrict__ emb1, const float* __restrict__ emb2,
+                const float* __restrict__ dinv, float* __restrict__ out, int64_t ldo, int n, int dim,
+                int groups, int nodes_per_block, int front) {
+#pragma clang fp contract(off)
+  extern __shared__ __align__(16) float T[];  // [18][dim] when TABLE
+  if (TABLE) {
+    for (int q = threadIdx.x; q < kNumCodes * dim; q += kGrpBlock) {
+      const int c = q / dim, d = q - c * dim;
+      T[q] = emb1[(c / 3) * dim + d] + emb2[(c % 3) * dim + d];
+    }
+    __syncthreads();
+  }
+  const int gs = dim >> 2;
+  const int g = threadIdx.x / gs, c4 = threadIdx.x - g * gs;
+  if (g >= groups) return;
+  // Scheduling.  front == 0: block b owns one contiguous node range.  front == 1: the node array is
+  // cut into one contiguous slab per XCD (blocks are dealt to XCDs round-robin: xcd = blockIdx % 8);
+  // the blocks of an XCD sweep their slab together as ONE narrow front (`groups` nodes per block per
+  // step), so neighbour rows are shared through that XCD's L2 while HBM sees 8 sequential streams.
+  int i_first, i_end, i_step;
+  if (front) {
+    const int xcd = blockIdx.x % kNumXCD, j = blockIdx.x / kNumXCD, nbx = gridDim.x / kNumXCD;
+    const int slab = ((n + kNumXCD - 1) / kNumXCD + groups - 1) / groups * groups;
+    i_first = xcd * slab + j * groups + g;
+    i_end = min(n, (xcd + 1) * slab);
+    i_step = nbx * groups;
+  } else {
+    const int b = xcd_remap(blockIdx.x, gridDim.x);
+    i_first = b * nodes_per_block + g;
+    i_end = min(n, b * nodes_per_block + nodes_per_block);
+    i_step = groups;
+  }
+  const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+  const float4* __restrict__ T4 = reinterpret_cast<const float4*>(T);
+  const int64_t ldx4 = ldx >> 2, ldo4 = ldo >> 2;
+  for (int i = i_first; i < i_end; i += i_step) {
+    const int beg = ptr[i], end = ptr[i + 1];
+    const float4 self = x4[(int64_t)i * ldx4 + c4];
+    float di = 1.f;
+    if (WEIGHT) di = dinv[i];
+    float4 acc = f4_zero();
+    for (int p = beg; p < end; p += 4) {
+      int s[4], cd[4];
+      float w[4];
+      float4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (p + j < end) {
+          s[j] = nbr[p + j];
+          if (TABLE) cd[j] = code[p + j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (p + j < end) {
+          v[j] = x4[(int64_t)s[j] * ldx4 + c4];
+          if (WEIGHT) w[j] = di * dinv[s[j]];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (p + j < end) {
+          float4 m = v[j];
+          if (TABLE) m = f4_add(m, T4[cd[j] * gs + c4]);
+          if (WEIGHT) m = f4_scale(m, w[j]);
+          acc = f4_add(acc, m);
+        }
+      }
+    }
+    float4 m = self;
+    if (TABLE) m = f4_add(m, T4[kSelfLoopCode * gs + c4]);
+    if (WEIGHT) m = f4_scale(m, di * di);
+    acc = f4_add(acc, m);
+    reinterpret_cast<float4*>(out)[(int64_t)i * ldo4 + c4] = acc;
+  }
+}
+
+template <bool TABLE, bool WEIGHT>
+int launch_aggregate_grp(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* nbr,
+                         const uint8_t* code, const float* emb1, const float* emb2, const float* dinv,
+                         float* out, int64_t ldo, int64_t n, int64_t dim, hipStream_t st) {
+  const int gs = (int)(dim / 4);
+  if (gs > kGrpBlock) {
+    set_error("feature width %lld > %d not supported", (long long)dim, 4 * kGrpBlock);
+    return PGNN_ERR_ARG;
+  }
+  const int groups = kGrpBlock / gs;
+  const size_t lds = TABLE ? (size_t)kNumCodes * dim * sizeof(float) : 0;
+  const int bpc = env_int("PGNN_AGG_BLOCKS_PER_CU", TABLE ? 6 : 6);
+  const int64_t max_blocks = (int64_t)kNumCU * bpc;
+  int64_t npb = std::max<int64_t>(ceil_div(n, max_blocks), groups);
+  npb = ceil_div(npb, groups) * groups;
+  int grid = (int)ceil_div(n, npb);
+  const int front = env_int("PGNN_AGG_FRONT", 1);
+  if (front) grid = (int)std::max<int64_t>(kNumXCD, std::min<int64_t>(max_blocks, ceil_div(ceil_div(n, groups), kNumXCD) * kNumXCD) / kNumXCD * kNumXCD);
+  allow_big_lds((const void*)k_aggregate_grp<TABLE, WEIGHT>, lds);
+  hipLaunchKernelGGL((k_aggregate_grp<TABLE, WEIGHT>), dim3(grid), dim3(kGrpBlock), lds, st, x, ldx, ptr, nbr, code,
+                     emb1, emb2, dinv, out, ldo, (int)n, (int)dim, groups, (int)npb, front);
+  return check_launch("aggregate_grp");
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-ring variant (the production path for D <= 320): batches are block-diagonal, so a node's
+// neighbours sit a few rows away.  A block sweeps a contiguous node range G nodes per step and
+// keeps a sliding window of 32 feature rows in LDS: every row of x is streamed from HBM exactly
+// once per block (perfectly coalesced G*D*4-byte reads, prefetched one step ahead through
+// registers), neighbour gathers are ds_read_b128 from the ring, rows outside the window (rare)
+// fall back to a global load, and the G result rows go back as one coalesced write.  Edge indices
+// of a step are fetched once by wave 0 and shared through LDS, so the only vector-memory
+// instructions per node are ~1 row load and ~1 row store.  One barrier per step; the ring is sized
+// (2*Lh+2)*G <= 32 rows so the write of step s+Lh can never overwrite what step s-1 still reads.
+// Accumulation order per node = original edge order, self loop last (bit-exact vs the reference).
+// ---------------------------------------------------------------------------------------------
+constexpr int kRingRows = 32;       // power of two
+constexpr int kRingEdges = 64;      // edge slots staged per step
+constexpr int kRingMaxNodes = 1024;  // nodes per block (ptr slice kept in LDS)
+constexpr int kRingThreads = 640;
+
+template <bool TABLE, bool WEIGHT, int P>
+__global__ void __launch_bounds__(kRingThreads)
+k_aggregate_ring(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ ptr,
+                 const int32_t* __restrict__ nbr, const uint8_t* __restrict__ code,
+                 const float* __restrict__ emb1, const float* __restrict__ emb2,
+                 const float* __restrict__ dinv, float* __restrict__ out, int64_t ldo, int n, int dim,
+                 int G, int Lh, int npb) {
+#pragma clang fp contract(off)
+  extern __shared__ __align__(16) float smem[];
+  const int gs = dim >> 2;
+  float* T = smem;                                                         // [18][dim] (TABLE only)
+  float4* ring = reinterpret_cast<float4*>(smem + (TABLE ? kNumCodes * dim : 0));  // [32][gs]
+  int* ptrL = reinterpret_cast<int*>(ring + kRingRows * gs);               // [npb + 1]
+  int* idxL = ptrL + (kRingMaxNodes + 4);                                  // [2][64]
+  int* codeL = idxL + 2 * kRingEdges;                                      // [2][64]
+  float* wL = reinterpret_cast<float*>(codeL + 2 * kRingEdges);            // [2][64]
+  const float4* __restrict__ T4 = reinterpret_cast<const float4*>(T);
+  const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+  const int64_t ldx4 = ldx >> 2, ldo4 = ldo >> 2;
+
+  const int t = threadIdx.x;
+  const int g = t / gs, c4 = t - g * gs;
+  const bool active = g < G;
+  const int n0 = blockIdx.x * npb, n1 = min(n, n0 + npb);
+  const int cnt = n1 - n0;
+  const int nsteps = (cnt + G - 1) / G;
+
+  if (TABLE) {
+    for (int q = t; q < kNumCodes * dim; q += kRingThreads) {
+      const int c = q / dim, d = q - c * dim;
+      T[q] = emb1[(c / 3) * dim + d] + emb2[(c % 3) * dim + d];
+    }
+  }
+  for (int q = t; q <= cnt; q += kRingThreads) ptrL[q] = ptr[n0 + q];
+
+  // row of load-step q owned by this thread: n0 + q*G + g
+  auto row_of = [&](int q) { return n0 + q * G + g; };
+  auto load_row = [&](int q) -> float4 {
+    const int r = row_of(q);
+    if (active && r >= 0 && r < n) return x4[(int64_t)r * ldx4 + c4];
+    return f4_zero();
+  };
+  auto put_row = [&](int q, float4 v) {
+    const int r = row_of(q);
+    if (active && r >= 0 && r < n) ring[(r & (kRingRows - 1)) * gs + c4] = v;
+  };
+
+  // prologue: window of step 0 = load-steps -Lh .. Lh-1 synchronously; the next P load-steps are
+  // put in flight into the register queue pre[] (row data lands P steps before it is needed)
+  for (int q = -Lh; q < Lh; ++q) put_row(q, load_row(q));
+  float4 pre[P];
+#pragma unroll
+  for (int u = 0; u < P; ++u) pre[u] = load_row(Lh + u);
+  __syncthreads();  // ptrL, T visible
+
+  // edge staging registers (threads < 64): indices of the NEXT step
+  int my_nbr = 0, my_code = 0;
+  float my_w = 0.f;
+  auto fetch_edges = [&](int s) {
+    if (t < kRingEdges && s < nsteps) {
+      const int e0 = ptrL[s * G], e1 = ptrL[min(s * G + G, cnt)];
+      const int p = e0 + t;
+      if (p < e1) {
+        my_nbr = nbr[p];
+        if (TABLE) my_code = code[p];
+        if (WEIGHT) my_w = dinv[my_nbr];
+      }
+    }
+  };
+  fetch_edges(0);
+
+  for (int s0 = 0; s0 < nsteps; s0 += P) {
+#pragma unroll
+   for (int u = 0; u < P; ++u) {
+    const int s = s0 + u;
+    if (s >= nsteps) break;  // block-uniform
+    const int buf = s & 1;
+    if (t < kRingEdges) {
+      idxL[buf * kRingEdges + t] = my_nbr;
+      if (TABLE) codeL[buf * kRingEdges + t] = my_code;
+      if (WEIGHT) wL[buf * kRingEdges + t] = my_w;
+    }
+    put_row(s + Lh, pre[u]);
+    pre[u] = load_row(s + Lh + P);
+    __syncthreads();
+    fetch_edges(s + 1);
+
+    const int li = s * G + g;  // node index relative to n0
+    if (active && li < cnt) {
+      const int i = n0 + li;
+      const int base = n0 + s * G;
+      const int win_lo = max(base - Lh * G, 0), win_hi = min(base + G + Lh * G, n);
+      const int e0 = ptrL[s * G];
+      const int beg = ptrL[li], end = ptrL[li + 1];
+      float di = 1.f;
+      if (WEIGHT) di = dinv[i];
+      float4 acc = f4_zero();
+      for (int p = beg; p < end; p += 4) {
+        int sidx[4], cd[4];
+        float w[4];
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (p + j < end) {
+            const int k = p + j - e0;
+            if (k < kRingEdges) {
+              sidx[j] = idxL[buf * kRingEdges + k];
+              if (TABLE) cd[j] = codeL[buf * kRingEdges + k];
+              if (WEIGHT) w[j] = wL[buf * kRingEdges + k];
+            } else {  // more edges in this step than staging slots: read them directly
+              sidx[j] = nbr[p + j];
+              if (TABLE) cd[j] = code[p + j];
+              if (WEIGHT) w[j] = dinv[sidx[j]];
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (p + j < end) {
+            const int sj = sidx[j];
+            if (sj >= win_lo && sj < win_hi) v[j] = ring[(sj & (kRingRows - 1)) * gs + c4];
+            else v[j] = x4[(int64_t)sj * ldx4 + c4];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (p + j < end) {
+            float4 m = v[j];
+            if (TABLE) m = f4_add(m, T4[cd[j] * gs + c4]);
+            if (WEIGHT) m = f4_scale(m, di * w[j]);
+            acc = f4_add(acc, m);
+          }
+        }
+      }
+      float4 m = ring[(i & (kRingRows - 1)) * gs + c4];
+      if (TABLE) m = f4_add(m, T4[kSelfLoopCode * gs + c4]);
+      if (WEIGHT) m = f4_scale(m, di * di);
+      acc = f4_add(acc, m);
+      reinterpret_cast<float4*>(out)[(int64_t)i * ldo4 + c4] = acc;
+    }
+   }
+  }
+}
+
+template <bool TABLE, bool WEIGHT>
+int launch_aggregate_ring(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* nbr,
+                          const uint8_t* code, const float* emb1, const float* emb2, const float* dinv,
+                          float* out, int64_t ldo, int64_t n, int64_t dim, hipStream_t st) {
+  const int gs = (int)(dim / 4);
+  int G = std::min(8, kRingThreads / gs);
+  G = env_int("PGNN_RING_G", G);
+  const int Lh = std::max(0, (kRingRows / G - 2) / 2);
+  const size_t lds = (size_t)(TABLE ? kNumCodes * dim : 0) * 4 + (size_t)kRingRows * dim * 4 +
+                     (size_t)(kRingMaxNodes + 4) * 4 + (size_t)6 * kRingEdges * 4;
+  const int resident = (int)std::max<size_t>(1, (160 * 1024) / lds);
+  const int64_t target_blocks = (int64_t)kNumCU * std::min(resident, env_int("PGNN_RING_BPC", 2));
+  int64_t npb = ceil_div(n, target_blocks);
+  npb = std::min<int64_t>(std::max<int64_t>(npb, 4 * G), kRingMaxNodes);
+  npb = npb / G * G;
+  const int grid = (int)ceil_div(n, npb);
+#define PGNN_LAUNCH_RING(PP)                                                                                     \
+  allow_big_lds((const void*)k_aggregate_ring<TABLE, WEIGHT, PP>, lds);                                            \
+  hipLaunchKernelGGL((k_aggregate_ring<TABLE, WEIGHT, PP>), dim3(grid), dim3(kRingThreads), lds, st, x, ldx, ptr, \
+                     nbr, code, emb1, emb2, dinv, out, ldo, (int)n, (int)dim, G, Lh, (int)npb)
+  switch (env_int("PGNN_RING_P", 4)) {
+    case 1: PGNN_LAUNCH_RING(1); break;
+    case 2: PGNN_LAUNCH_RING(2); break;
+    case 8: PGNN_LAUNCH_RING(8); break;
+    default: PGNN_LAUNCH_RING(4); break;
+  }
+#undef PGNN_LAUNCH_RING
+  return check_launch("aggregate_ring");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Producer/consumer LDS-DMA variant (production path for unweighted aggregation, D <= 320).
+//   * wave CW (the last wave) is a LOADER: each step it streams the next 8 feature rows and the next
+//     step's edge indices / bond codes straight into LDS with global_load_lds (no VGPR round trip).
+//     It never stores and issues nothing else, so "s_waitcnt vmcnt(0); barrier" is exact: every row of
+//     x leaves HBM once per block, as contiguous 8*D*4-byte bursts, one step ahead of its use.
+//   * waves 0..CW-1 are CONSUMERS: 75 threads per node (D = 300), 8 nodes per step.  Neighbour rows
+//     and bond-table rows are ds_read_b128 from LDS, results go out as coalesced stores that are never
+//     waited for.  A chunk of edges whose source row is outside the 24-row window (or beyond the 64
+//     staged edge slots) takes a wave-uniform slow path that reads from global memory instead.
+//   * ring = 4 regions of 8 rows: compute(s) reads regions s-1, s, s+1 while the loader fills s+2.
+// One barrier per step.  Sums run in original edge order, self loop last: bit-exact vs the reference.
+// ---------------------------------------------------------------------------------------------
+constexpr int kDmaG = 8;                      // nodes per step
+constexpr int kDmaEdges = 64;                 // staged edge slots per step
+constexpr int kDmaMaxNodes = 1024;            // nodes per block
+
+#define PGNN_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define PGNN_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// s_waitcnt vmcnt(n) needs an immediate; n = (prefetch depth - 1) * DMA instructions per step
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define PGNN_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n) {
+    PGNN_W(1) PGNN_W(2) PGNN_W(3) PGNN_W(4) PGNN_W(5) PGNN_W(6) PGNN_W(7) PGNN_W(8) PGNN_W(9) PGNN_W(10) PGNN_W(11)
+    PGNN_W(12) PGNN_W(13) PGNN_W(14) PGNN_W(15) PGNN_W(16) PGNN_W(17) PGNN_W(18) PGNN_W(19) PGNN_W(20) PGNN_W(21)
+    PGNN_W(22) PGNN_W(23) PGNN_W(24) PGNN_W(25) PGNN_W(26) PGNN_W(27) PGNN_W(28) PGNN_W(29) PGNN_W(30) PGNN_W(31)
+    PGNN_W(32) PGNN_W(33) PGNN_W(34) PGNN_W(35) PGNN_W(36)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef PGNN_W
+}
+
+// P = prefetch depth in steps; the ring holds P+3 regions of 8 rows: compute(s) reads regions
+// s-1, s, s+1, regions s+2..s+P are landed or in flight, region s+1+P is being issued.
+// NROW = ceil(8*gs/64) row-DMA instructions per step when known at compile time (their per-lane
+// byte offsets are then hoisted into registers: the loader issues a step with ~2 instructions per
+// KiB); NROW = 0 selects a generic run-time loop for other feature widths.
+template <bool TABLE, int P, int NROW>
+__global__ void __launch_bounds__(704)
+k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ ptr,
+                const int32_t* __restrict__ nbr, const uint8_t* __restrict__ code,
+                const float* __restrict__ emb1, const float* __restrict__ emb2, float* __restrict__ out,
+                int64_t ldo, int n, int dim, int npb) {
+#pragma clang fp contract(off)
+  constexpr int NREG = P + 3, NBUF = P + 1;
+  extern __shared__ __align__(16) float smem[];
+  const int gs = dim >> 2;
+  const int row_f4 = kDmaG * gs;  // float4 per ring region
+  float* T = smem;                                                                   // [18][dim]
+  float4* ring = reinterpret_cast<float4*>(smem + (TABLE ? kNumCodes * dim : 0));    // [NREG][8][gs]
+  int* ptrL = reinterpret_cast<int*>(ring + NREG * row_f4);                          // [npb+1]
+  int* idxL = ptrL + (kDmaMaxNodes + 4);                                             // [NBUF][64]
+  int* codeL = idxL + NBUF * kDmaEdges;                                              // [NBUF][64] (byte DMA lands as dwords)
+  const float4* __restrict__ T4 = reinterpret_cast<const float4*>(T);
+  const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+  const int64_t ldx4 = ldx >> 2, ldo4 = ldo >> 2;
+
+  const int cthreads = (int)blockDim.x - kWave;  // consumer threads
+  const int t = threadIdx.x;
+  const int n0 = blockIdx.x * npb, n1 = min(n, n0 + npb);
+  const int cnt = n1 - n0;
+  const int nsteps = (cnt + kDmaG - 1) / kDmaG;
+  auto slot_of = [&](int r) { return (((r >> 3) % NREG) << 3) + (r & 7); };
+
+  if (t >= cthreads) {
+    // ------------------------------------------------------------------ loader wave
+    const int lane = t - cthreads;
+    const int ne = ptr[n];  // total edge count (clamps the staged-edge reads at the array end)
+    const int nrow = (row_f4 + kWave - 1) / kWave;
+    const int K = nrow + (ne > 0 ? (TABLE ? 2 : 1) : 0);  // DMA instructions issued per step
+    const int g_lane = lane / gs, c_lane = lane - g_lane * gs;
+    constexpr int NR = NROW > 0 ? NROW : 1;
+    unsigned off[NR];  // byte offset of this lane's float4 inside an 8-row step, per DMA instruction
+    bool val[NR];
+    if (NROW > 0) {
+      int g = g_lane, c4 = c_lane;
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        val[k] = k * kWave + lane < row_f4;
+        off[k] = (unsigned)(g * (int)ldx * 4 + c4 * 16);
+        c4 += kWave;
+        while (c4 >= gs) { c4 -= gs; ++g; }
+      }
+    }
+    auto issue_rows = [&](int q) {  // load-step q: rows n0 + 8q .. +7 -> ring region (always nrow instructions)
+      const int r0 = n0 + q * kDmaG;
+      float4* dst0 = ring + (((max(r0, 0)) >> 3) % NREG) * row_f4;
+      if (NROW > 0 && r0 >= 0 && r0 + kDmaG <= n) {  // wave-uniform fast path: SGPR row base + hoisted lane offsets
+        const char* base = reinterpret_cast<const char*>(x) + (int64_t)r0 * ldx * 4;
+#pragma unroll
+        for (int k = 0; k < NR; ++k)  // only the last instruction of a step can be partial
+          if (k + 1 < NR || val[k])
+            __builtin_amdgcn_global_load_lds(PGNN_GPTR(base + off[k]), PGNN_LPTR(dst0 + k * kWave), 16, 0, 0);
+        return;
+      }
+      int g = g_lane, c4 = c_lane;
+      for (int k = 0; k < nrow; ++k) {
+        if (k * kWave + lane < row_f4) {
+          const int r = min(max(r0 + g, 0), n - 1);  // out-of-range rows: harmless duplicates, never read
+          __builtin_amdgcn_global_load_lds(PGNN_GPTR(x4 + (int64_t)r * ldx4 + c4), PGNN_LPTR(dst0 + k * kWave), 16, 0, 0);
+        }
+        c4 += kWave;
+        while (c4 >= gs) { c4 -= gs; ++g; }
+      }
+    };
+    auto issue_edges = [&](int s, int e0) {  // edge slots of step s -> idxL/codeL[s % NBUF]
+      if (ne == 0) return;
+      const int p = min(e0 + lane, ne - 1);
+      __builtin_amdgcn_global_load_lds(PGNN_GPTR(nbr + p), PGNN_LPTR(idxL + (s % NBUF) * kDmaEdges), 4, 0, 0);
+      if (TABLE)
+        __builtin_amdgcn_global_load_lds(PGNN_GPTR(code + p), PGNN_LPTR(codeL + (s % NBUF) * kDmaEdges), 1, 0, 0);
+    };
+    if (n0 > 0) issue_rows(-1);
+    for (int q = 0; q <= P; ++q) issue_rows(q);
+    for (int q = 0; q < P; ++q) issue_edges(q, ptr[min(n0 + q * kDmaG, n1)]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // prologue: T, ptrL (consumers) and the first window (loader) are in LDS
+    for (int s = 0; s < nsteps; ++s) {
+      wait_vmcnt(min(s, P - 1) * K);  // everything issued >= P steps ago (rows <= s+1, edges(s)) has landed
+      __syncthreads();                // B(s)
+      issue_rows(s + 1 + P);
+      issue_edges(s + P, ptrL[min((s + P) * kDmaG, cnt)]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the block's LDS allocation
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumer waves
+  const int g = t / gs, c4 = t - g * gs;
+  const bool active = g < kDmaG;
+  if (TABLE) {
+    for (int q = t; q < kNumCodes * dim; q += cthreads) {
+      const int c = q / dim, d = q - c * dim;
+      T[q] = emb1[(c / 3) * dim + d] + emb2[(c % 3) * dim + d];
+    }
+  }
+  for (int q = t; q <= cnt; q += cthreads) ptrL[q] = ptr[n0 + q];
+  __syncthreads();  // prologue
+
+  for (int s = 0; s < nsteps; ++s) {
+    __syncthreads();  // B(s)
+    const int li = s * kDmaG + g;
+    if (!(active && li < cnt)) continue;
+    const int i = n0 + li;
+    const int base = n0 + s * kDmaG;
+    const int win_lo = max(base - kDmaG, 0), win_hi = min(base + 2 * kDmaG, n);
+    const int e0 = ptrL[s * kDmaG];
+    const int beg = ptrL[li], end = ptrL[li + 1];
+    const int* idxB = idxL + (s % NBUF) * kDmaEdges;
+    const int* codeB = codeL + (s % NBUF) * kDmaEdges;
+    float4 acc = f4_zero();
+    for (int p = beg; p < end; p += 4) {
+      int sidx[4], cd[4];
+      bool slow = false;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sidx[j] = 0;
+        cd[j] = 0;
+        if (p + j < end) {
+          const int k = p + j - e0;
+          if (k < kDmaEdges) {
+            sidx[j] = idxB[k];
+            if (TABLE) cd[j] = codeB[k] & 0xff;
+            slow |= (sidx[j] < win_lo) | (sidx[j] >= win_hi);
+          } else {
+            slow = true;
+          }
+        }
+      }
+      if (__any(slow)) {
+        // rare: a source row outside the LDS window, or more edges in this step than staged slots
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (p + j < end) {
+            const int sj = nbr[p + j];
+            float4 m = x4[(int64_t)sj * ldx4 + c4];
+            if (TABLE) m = f4_add(m, T4[(int)code[p + j] * gs + c4]);
+            acc = f4_add(acc, m);
+          }
+        }
+      } else {
+        float4 v[4], tv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (p + j < end) {
+            v[j] = ring[slot_of(sidx[j]) * gs + c4];
+            if (TABLE) tv[j] = T4[cd[j] * gs + c4];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (p + j < end) {
+            float4 m = v[j];
+            if (TABLE) m = f4_add(m, tv[j]);
+            acc = f4_add(acc, m);
+          }
+        }
+      }
+    }
+    float4 m = ring[slot_of(i) * gs + c4];
+    if (TABLE) m = f4_add(m, T4[kSelfLoopCode * gs + c4]);
+    acc = f4_add(acc, m);
+    reinterpret_cast<float4*>(out)[(int64_t)i * ldo4 + c4] = acc;
+  }
+}
+
+template <bool TABLE, int P, int NROW>
+int launch_aggregate_dma_p(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* nbr, const uint8_t* code,
+                           const float* emb1, const float* emb2, float* out, int64_t ldo, int64_t n, int64_t dim,
+                           hipStream_t st) {
+  const int gs = (int)(dim / 4);
+  const int cthreads = (int)align_up((size_t)kDmaG * gs, kWave);
+  const int threads = cthreads + kWave;
+  const size_t lds = (size_t)(TABLE ? kNumCodes * dim : 0) * 4 + (size_t)(P + 3) * kDmaG * dim * 4 +
+                     (size_t)(kDmaMaxNodes + 4) * 4 + (size_t)2 * (P + 1) * kDmaEdges * 4 + 64;
+  const int resident = (int)std::max<size_t>(1, (160 * 1024) / lds);
+  const int64_t target_blocks = (int64_t)kNumCU * std::min(resident, env_int("PGNN_DMA_BPC", 2));
+  int64_t npb = ceil_div(n, target_blocks);
+  npb = std::min<int64_t>(std::max<int64_t>(npb, 4 * kDmaG), kDmaMaxNodes);
+  npb = ceil_div(npb, kDmaG) * kDmaG;
+  if (npb > kDmaMaxNodes) npb = kDmaMaxNodes;
+  const int grid = (int)ceil_div(n, npb);
+  allow_big_lds((const void*)k_aggregate_dma<TABLE, P, NROW>, lds);
+  hipLaunchKernelGGL((k_aggregate_dma<TABLE, P, NROW>), dim3(grid), dim3(threads), lds, st, x, ldx, ptr, nbr, code,
+                     emb1, emb2, out, ldo, (int)n, (int)dim, (int)npb);
+  return check_launch("aggregate_dma");
+}
+
+template <bool TABLE>
+int launch_aggregate_dma(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* nbr, const uint8_t* code,
+                         const float* emb1, const float* emb2, float* out, int64_t ldo, int64_t n, int64_t dim,
+                         hipStream_t st) {
+  const int nrow = (int)ceil_div(kDmaG * (dim / 4), kWave);
+  const bool small_ld = ldx * 4 * kDmaG < (1ll << 31);
+#define PGNN_DMA_ARGS x, ldx, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st
+  if (env_int("PGNN_DMA_P", 2) == 1) return launch_aggregate_dma_p<TABLE, 1, 0>(PGNN_DMA_ARGS);
+  if (!small_ld || env_int("PGNN_DMA_GENERIC", 0)) return launch_aggregate_dma_p<TABLE, 2, 0>(PGNN_DMA_ARGS);
+  if (nrow == 10 && env_int("PGNN_DMA_P", 2) == 3) return launch_aggregate_dma_p<TABLE, 3, 10>(PGNN_DMA_ARGS);
+  switch (nrow) {
+    case 10: return launch_aggregate_dma_p<TABLE, 2, 10>(PGNN_DMA_ARGS);  // D = 300 (the reference's emb_dim)
+    case 8: return launch_aggregate_dma_p<TABLE, 2, 8>(PGNN_DMA_ARGS);    // D = 256
+    case 4: return launch_aggregate_dma_p<TABLE, 2, 4>(PGNN_DMA_ARGS);    // D = 128
+    case 2: return launch_aggregate_dma_p<TABLE, 2, 2>(PGNN_DMA_ARGS);    // D = 64
+    case 1: return launch_aggregate_dma_p<TABLE, 2, 1>(PGNN_DMA_ARGS);    // D = 32
+    default: return launch_aggregate_dma_p<TABLE, 2, 0>(PGNN_DMA_ARGS);
+  }
+#undef PGNN_DMA_ARGS
+}
+
 template <bool TABLE, bool WEIGHT>
 int launch_aggregate(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* nbr,
                      const uint8_t* code, const float* emb1, const float* emb2, const float* dinv,
                      float* out, int64_t ldo, int64_t n, int64_t dim, hipStream_t st) {
+  const int variant = env_int("PGNN_AGG_VARIANT", dim <= 320 ? (WEIGHT ? 1 : 3) : 1);
+  if (variant == 3 && dim <= 320 && !WEIGHT)
+    return launch_aggregate_dma<TABLE>(x, ldx, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st);
+  if (variant == 2 && dim <= 320)
+    return launch_aggregate_ring<TABLE, WEIGHT>(x, ldx, ptr, nbr, code, emb1, emb2, dinv, out, ldo, n, dim, st);
+  if (variant >= 1)
+    return launch_aggregate_grp<TABLE, WEIGHT>(x, ldx, ptr, nbr, code, emb1, emb2, dinv, out, ldo, n, dim, st);
   const int R = (int)ceil_div(dim / 4, kWave);
   const size_t lds = TABLE ? (size_t)kNumCodes * dim * sizeof(float) : 0;
   int npc;
@@ -460,6 +1030,16 @@ int pgnn_chem_aggregate_fwd(const float* x, int64_t ldx, const int32_t* in_ptr, 
   hipStream_t st = (hipStream_t)stream;
   if (dinv) return launch_aggregate<true, true>(x, ldx, in_ptr, in_src, in_code, emb1, emb2, dinv, out, ldo, n, dim, st);
   return launch_aggregate<true, false>(x, ldx, in_ptr, in_src, in_code, emb1, emb2, dinv, out, ldo, n, dim, st);
+}
+
+// diagnostics: plain float4 grid-stride copy -- the streaming ceiling the aggregation is measured against
+__global__ void __launch_bounds__(256) k_debug_copy(const float4* __restrict__ a, float4* __restrict__ b, int64_t n4) {
+  for (int64_t q = blockIdx.x * (int64_t)256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) b[q] = a[q];
+}
+int pgnn_debug_stream_copy(const float* src, float* dst, int64_t n_floats, int64_t blocks, pgnn_stream stream) {
+  hipLaunchKernelGGL(k_debug_copy, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n_floats / 4);
+  return check_launch("debug_stream_copy");
 }
 
 int pgnn_neighbor_sum(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* nbr,
