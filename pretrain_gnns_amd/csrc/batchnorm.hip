@@ -87,7 +87,7 @@ __global__ void k_bn_stats_final(const float* __restrict__ partial, int nblk, co
   }
   const float a = invstd * gamma[c];
   coef[c] = a;
-  coef[dim + c] = beta[c] - mean * a;
+  coef[dim + c] = fmaf(-mean, a, beta[c]);  // same expression as the backward's recomputation
 }
 
 __global__ void k_bn_apply(const float* __restrict__ x, int64_t ldx, const float* __restrict__ coef,
@@ -108,7 +108,9 @@ __global__ void k_bn_apply(const float* __restrict__ x, int64_t ldx, const float
 
 // backward pass 1: partial sums of dyr and dyr*xhat (dyr = dy masked by the recomputed ReLU)
 __global__ void k_bn_bwd_partial(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
-                                 int64_t ldx, const float* __restrict__ coef /*a,b,mean,invstd*/, int relu,
+                                 int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                 float* __restrict__ coef /*out (block 0): a,b,mean,invstd*/, int relu,
                                  int n, int d4, float* __restrict__ partial) {
   extern __shared__ __align__(16) float lds[];
   const int t = threadIdx.x, c4 = t % d4, rl = t / d4, dim = d4 * 4;
@@ -116,10 +118,18 @@ __global__ void k_bn_bwd_partial(const float* __restrict__ dy, int64_t lddy, con
   const int r0 = blockIdx.x * per, r1 = min(n, r0 + per);
   float4 s1 = f4_zero(), s2 = f4_zero();
   if (rl < 4) {
-    const float4 a = reinterpret_cast<const float4*>(coef)[c4];
-    const float4 b = reinterpret_cast<const float4*>(coef + dim)[c4];
-    const float4 mu = reinterpret_cast<const float4*>(coef + 2 * dim)[c4];
-    const float4 is = reinterpret_cast<const float4*>(coef + 3 * dim)[c4];
+    // forward coefficients y = a*x + b, recomputed exactly as k_bn_stats_final formed them
+    const float4 gm = reinterpret_cast<const float4*>(gamma)[c4], bt = reinterpret_cast<const float4*>(beta)[c4];
+    const float4 mu = reinterpret_cast<const float4*>(save_mean)[c4];
+    const float4 is = reinterpret_cast<const float4*>(save_invstd)[c4];
+    const float4 a = make_float4(is.x * gm.x, is.y * gm.y, is.z * gm.z, is.w * gm.w);
+    const float4 b = make_float4(fmaf(-mu.x, a.x, bt.x), fmaf(-mu.y, a.y, bt.y), fmaf(-mu.z, a.z, bt.z), fmaf(-mu.w, a.w, bt.w));
+    if (blockIdx.x == 0 && rl == 0) {
+      reinterpret_cast<float4*>(coef)[c4] = a;
+      reinterpret_cast<float4*>(coef + dim)[c4] = b;
+      reinterpret_cast<float4*>(coef + 2 * dim)[c4] = mu;
+      reinterpret_cast<float4*>(coef + 3 * dim)[c4] = is;
+    }
     for (int r = r0 + rl; r < r1; r += 4) {
       const float4 v = reinterpret_cast<const float4*>(x + (int64_t)r * ldx)[c4];
       float4 g = reinterpret_cast<const float4*>(dy + (int64_t)r * lddy)[c4];
@@ -143,18 +153,6 @@ __global__ void k_bn_bwd_partial(const float* __restrict__ dy, int64_t lddy, con
 // coef layout for backward: [a, b, mean, invstd, k1, k2, k3] each [dim]
 //   dx = k1*dyr + k2*(x-mean) + k3   with k1 = gamma*invstd;
 //   training: k2 = -k1*invstd*mean(dyr*xhat), k3 = -k1*mean(dyr); eval: k2 = k3 = 0
-__global__ void k_bn_bwd_prepare(const float* __restrict__ gamma, const float* __restrict__ beta,
-                                 const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
-                                 int dim, float* __restrict__ coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= dim) return;
-  const float a = save_invstd[c] * gamma[c];
-  coef[c] = a;
-  coef[dim + c] = beta[c] - save_mean[c] * a;
-  coef[2 * dim + c] = save_mean[c];
-  coef[3 * dim + c] = save_invstd[c];
-}
-
 __global__ void k_bn_bwd_final(const float* __restrict__ partial, int nblk, int training, int n, int dim,
                                const float* __restrict__ gamma, float* __restrict__ coef,
                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
@@ -279,10 +277,8 @@ int pgnn_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, cons
   float* partial = cv.take<float>((size_t)nblk * 2 * dim);
   float* coef = cv.take<float>((size_t)7 * dim);
   const int d4 = (int)(dim / 4);
-  const int cb = (int)ceil_div(dim, 256);
-  hipLaunchKernelGGL(k_bn_bwd_prepare, dim3(cb), dim3(256), 0, st, gamma, beta, save_mean, save_invstd, (int)dim, coef);
   hipLaunchKernelGGL(k_bn_bwd_partial, dim3(nblk), dim3(stat_threads(dim)), (size_t)8 * dim * sizeof(float), st, dy,
-                     lddy, x, ldx, coef, relu, (int)n, d4, partial);
+                     lddy, x, ldx, gamma, beta, save_mean, save_invstd, coef, relu, (int)n, d4, partial);
   hipLaunchKernelGGL(k_bn_bwd_final, dim3((int)ceil_div(dim, 16)), dim3(256), 0, st, partial, nblk, training, (int)n, (int)dim, gamma,
                      coef, dgamma, dbeta);
   const int grid = (int)std::min<int64_t>(ceil_div(n, 4), (int64_t)kNumCU * 16);

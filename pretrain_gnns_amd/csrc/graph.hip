@@ -103,6 +103,47 @@ __global__ void __launch_bounds__(256) k_scan_bsum(GroupJobs jobs, int nb) {
   }
 }
 
+__global__ void k_scan_add(GroupJobs jobs, int64_t n);
+
+// whole scan in ONE block (any n, meant for n <= ~32k): chunks of 1024 with a running carry
+__global__ void __launch_bounds__(256) k_scan_single(GroupJobs jobs, int64_t n) {
+  __shared__ int lds[4];
+  int32_t* d = jobs.j[blockIdx.y].ptr;
+  int carry = 0;
+  for (int64_t base0 = 0; base0 < n; base0 += kScanItems) {
+    const int64_t base = base0 + threadIdx.x * 4;
+    int v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (base + i < n) ? d[base + i] : 0;
+    v[1] += v[0];
+    v[2] += v[1];
+    v[3] += v[2];
+    int total;
+    const int incl = block_scan_256(v[3], lds, total);
+    const int excl = carry + incl - v[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (base + i < n) d[base + i] = v[i] + excl;
+    carry += total;
+  }
+}
+
+constexpr int64_t kScanSingleMax = 32768;
+
+// in-place inclusive scan of jobs.j[0..njobs).ptr[0..n)
+inline void launch_scan(GroupJobs jobs, int njobs, int64_t n, hipStream_t st) {
+  if (n <= kScanSingleMax) {
+    hipLaunchKernelGGL(k_scan_single, dim3(1, njobs), dim3(256), 0, st, jobs, n);
+    return;
+  }
+  const int nb = (int)ceil_div(n, kScanItems);
+  hipLaunchKernelGGL(k_scan_local, dim3(nb, njobs), dim3(256), 0, st, jobs, n);
+  if (nb > 1) {
+    hipLaunchKernelGGL(k_scan_bsum, dim3(1, njobs), dim3(256), 0, st, jobs, nb);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb - 1, njobs), dim3(256), 0, st, jobs, n);
+  }
+}
+
 __global__ void __launch_bounds__(256) k_scan_add(GroupJobs jobs, int64_t n) {
   const GroupJob& job = jobs.j[blockIdx.y];
   const int add = job.bsum[blockIdx.x + 1];
@@ -247,12 +288,7 @@ int run_partition(const int64_t* key, int64_t stride, int64_t n_items, int64_t n
   GroupJobs jobs;
   jobs.j[0] = GroupJob{nullptr, 1, offs, nullptr, nullptr, nullptr, bsum};
   jobs.j[1] = jobs.j[0];
-  const int nb = (int)ceil_div(len, kScanItems);
-  hipLaunchKernelGGL(k_scan_local, dim3(nb, 1), dim3(256), 0, st, jobs, len);
-  if (nb > 1) {
-    hipLaunchKernelGGL(k_scan_bsum, dim3(1, 1), dim3(256), 0, st, jobs, nb);
-    hipLaunchKernelGGL(k_scan_add, dim3(nb - 1, 1), dim3(256), 0, st, jobs, len);
-  }
+  launch_scan(jobs, 1, len, st);
   hipLaunchKernelGGL(k_part_scatter, dim3(n_tiles), dim3(kPartTile), (size_t)4 * n_keys * 4, st, key, stride,
                      n_items, (int)n_keys, n_tiles, offs, ptr, perm);
   return check_launch("group_by_key(partition)");
@@ -261,16 +297,11 @@ int run_partition(const int64_t* key, int64_t stride, int64_t n_items, int64_t n
 int run_group(GroupJobs jobs, int njobs, int64_t n_items, int64_t n_keys, int32_t* status,
               hipStream_t st) {
   const int64_t n = n_keys + 1;
-  const int nb = (int)ceil_div(n, kScanItems);
   const int gi = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(n_items, 256), 1), 4096);
   if (n_items > 0) {
     hipLaunchKernelGGL(k_hist, dim3(gi, njobs), dim3(256), 0, st, jobs, n_items, n_keys, status);
   }
-  hipLaunchKernelGGL(k_scan_local, dim3(nb, njobs), dim3(256), 0, st, jobs, n);
-  if (nb > 1) {
-    hipLaunchKernelGGL(k_scan_bsum, dim3(1, njobs), dim3(256), 0, st, jobs, nb);
-    hipLaunchKernelGGL(k_scan_add, dim3(nb - 1, njobs), dim3(256), 0, st, jobs, n);
-  }
+  launch_scan(jobs, njobs, n, st);
   if (n_items > 0) {
     hipLaunchKernelGGL(k_fill, dim3(gi, njobs), dim3(256), 0, st, jobs, n_items, n_keys);
     hipLaunchKernelGGL(k_sort_segments, dim3((int)ceil_div(n_keys, 256), njobs), dim3(256), 0, st,

@@ -16,14 +16,14 @@
 // transposing 4 x ds_write_b32 for k-contiguous operands, ds_write_b128 for the others) and is
 // double-buffered: tile t+1's global loads are issued before tile t's MFMAs, one barrier per tile.
 // The block->tile map is XCD-aware (tiles sharing an A row-panel run on one XCD's L2).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace pgnn {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kThreads = 256;
 
 struct GemmArgs {
   const float* A;
@@ -39,91 +39,97 @@ struct GemmArgs {
   int64_t ldmask;
   int kchunk;          // split-K: k range per blockIdx.y
   int64_t split_stride;  // split-K: floats between partial C matrices
+  float* colsum;       // ONES: receives sum_k Aop(m,k) (one value per m), same split stride
 };
 
 enum { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_MASK = 2 };
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI>
-__global__ void __launch_bounds__(kThreads) k_gemm(GemmArgs p) {
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+__device__ float4 g_zero_page[4];  // zero-initialised: DMA source for lanes past the K / M / N edge
+__device__ float4 g_ones_page[1] = {{1.f, 0.f, 0.f, 0.f}};  // DMA source of the "ones column" (bias gradient)
+
+#define PGNN_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define PGNN_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// C[m,n] = sum_k Aop(m,k) * Bop(n,k);  N and ldc must be multiples of 4 (float4 epilogue).
+//
+// Staging: each 16-deep k-step's A and B tiles go HBM -> LDS by global_load_lds (1 KiB per wave
+// instruction, no VGPR round trip, no ds_write), double-buffered: the DMA of step t+1 is issued
+// before the MFMAs of step t and is drained by the vmcnt(0)+barrier that ends the step.  LDS images
+// are un-padded (a DMA writes lane-linear):  k-contiguous operands as [row][16], read back as ONE
+// ds_read_b128 per fragment (4 k's per lane; MFMA r of a step then covers k = 4*(lane>>4)+r, the
+// same permutation on both operands);  row-contiguous operands as [16][rows], read as ds_read_b32
+// with that same k mapping.  Lanes beyond an edge fetch from a zero page instead of being masked,
+// so stale LDS contents can never leak into the accumulators.
+// The MFMA is issued with the operands swapped (D = Bfrag x Afrag), so a lane ends up holding FOUR
+// CONSECUTIVE COLUMNS of one C row: the epilogue is one float4 store (+ float4 bias / mask load) per
+// 16x16 block.
+// ONES (weight-gradient product only): the B tile gets one extra column n == N whose entries are 1,
+// fetched from a constant page, so C[m][N] = sum_k Aop(m,k) -- the bias gradient -- falls out of the
+// same MFMAs and lands in p.colsum instead of needing its own column-sum kernels.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES = false>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
+  constexpr int BK = 16;
+  constexpr int NW = WAVES_M * WAVES_N;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MI = WM / 16, NI = WN / 16;
-  static_assert(WM % 16 == 0 && WN % 16 == 0 && BK % 4 == 0, "tile shape");
-  constexpr int LDA_S = BM + (A_KMAJOR ? 1 : 4);
-  constexpr int LDB_S = BN + (B_KMAJOR ? 1 : 4);
-  constexpr int PA = BM * BK / (4 * kThreads), PB = BN * BK / (4 * kThreads);
-  static_assert(PA >= 1 && PB >= 1 && (BM * BK) % (4 * kThreads) == 0 && (BN * BK) % (4 * kThreads) == 0, "staging");
+  static_assert(WM % 16 == 0 && WN % 16 == 0 && BM % 16 == 0 && BN % 16 == 0, "tile shape");
+  constexpr int PA = BM / 16, PB = BN / 16;        // 1-KiB DMA pieces per k-step
+  constexpr int NP = PA + PB, NJ = (NP + NW - 1) / NW;  // pieces per wave
+  constexpr int TILE = (BM + BN) * BK;              // floats per stage
 
   extern __shared__ __align__(16) float smem[];
-  auto As = [&](int buf) { return smem + buf * (BK * LDA_S); };
-  auto Bs = [&](int buf) { return smem + 2 * BK * LDA_S + buf * (BK * LDB_S); };
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_n = (p.N + (ONES ? 4 : 0) + BN - 1) / BN;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
   const int kbeg = blockIdx.y * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
   const int nk = (kend - kbeg + BK - 1) / BK;
 
-  float4 ra[PA], rb[PB];
-
-  auto load_tiles = [&](int k0) {
+  // ---- per-wave DMA pieces: piece d < PA is float4 [64d, 64d+64) of the A tile, else of the B tile
+  const float* src[NJ];   // this lane's source at k-step 0
+  int kofs[NJ];           // k index (relative to the k-step start) this lane covers
+  int64_t kstride[NJ];    // floats to advance per k-step
+  bool rowok[NJ], ones[NJ];
 #pragma unroll
-    for (int q = 0; q < PA; ++q) {
-      const int idx = tid + q * kThreads;
-      float4 v = f4_zero();
-      if (A_KMAJOR) {
-        const int row = idx / (BK / 4), kq = idx % (BK / 4);
-        const int m = m0 + row, k = k0 + 4 * kq;
-        if (m < p.M && k < kend) v = *reinterpret_cast<const float4*>(p.A + (int64_t)m * p.lda + k);
+  for (int j = 0; j < NJ; ++j) {
+    const int d = wave + j * NW;
+    src[j] = nullptr; kofs[j] = 0; kstride[j] = 0; rowok[j] = false; ones[j] = false;
+    if (d < NP) {
+      const bool isA = d < PA;
+      const int idx = (isA ? d : d - PA) * 64 + lane;  // float4 index inside the tile
+      const float* base = isA ? p.A : p.B;
+      const int64_t ld = isA ? p.lda : p.ldb;
+      const int r0 = isA ? m0 : n0, rmax = isA ? p.M : p.N;
+      const bool kmajor = isA ? A_KMAJOR : B_KMAJOR;
+      const int rows = isA ? BM : BN;
+      if (kmajor) {
+        const int row = idx >> 2, kq = idx & 3;
+        rowok[j] = r0 + row < rmax;
+        kofs[j] = 4 * kq;
+        src[j] = base + (int64_t)(r0 + row) * ld + kbeg + 4 * kq;
+        kstride[j] = BK;
       } else {
-        const int kr = idx / (BM / 4), mq = idx % (BM / 4);
-        const int m = m0 + 4 * mq, k = k0 + kr;
-        if (m < p.M && k < kend) v = *reinterpret_cast<const float4*>(p.A + (int64_t)k * p.lda + m);
-      }
-      ra[q] = v;
-    }
-#pragma unroll
-    for (int q = 0; q < PB; ++q) {
-      const int idx = tid + q * kThreads;
-      float4 v = f4_zero();
-      if (B_KMAJOR) {
-        const int row = idx / (BK / 4), kq = idx % (BK / 4);
-        const int n = n0 + row, k = k0 + 4 * kq;
-        if (n < p.N && k < kend) v = *reinterpret_cast<const float4*>(p.B + (int64_t)n * p.ldb + k);
-      } else {
-        const int kr = idx / (BN / 4), nq = idx % (BN / 4);
-        const int n = n0 + 4 * nq, k = k0 + kr;
-        if (n < p.N && k < kend) v = *reinterpret_cast<const float4*>(p.B + (int64_t)k * p.ldb + n);
-      }
-      rb[q] = v;
-    }
-  };
-
-  auto store_tiles = [&](int buf) {
-#pragma unroll
-    for (int q = 0; q < PA; ++q) {
-      const int idx = tid + q * kThreads;
-      if (A_KMAJOR) {
-        const int row = idx / (BK / 4), kq = idx % (BK / 4);
-        float* d = As(buf) + (4 * kq) * LDA_S + row;
-        d[0] = ra[q].x; d[LDA_S] = ra[q].y; d[2 * LDA_S] = ra[q].z; d[3 * LDA_S] = ra[q].w;
-      } else {
-        const int kr = idx / (BM / 4), mq = idx % (BM / 4);
-        *reinterpret_cast<float4*>(As(buf) + kr * LDA_S + 4 * mq) = ra[q];
+        const int kr = idx / (rows / 4), rq = idx % (rows / 4);
+        rowok[j] = r0 + 4 * rq < rmax;
+        ones[j] = ONES && !isA && r0 + 4 * rq == rmax;
+        kofs[j] = kr;
+        src[j] = base + (int64_t)(kbeg + kr) * ld + r0 + 4 * rq;
+        kstride[j] = BK * ld;
       }
     }
+  }
+  auto issue = [&](int stage, int it) {
+    float* st = smem + stage * TILE;
+    const int k0 = kbeg + it * BK;
 #pragma unroll
-    for (int q = 0; q < PB; ++q) {
-      const int idx = tid + q * kThreads;
-      if (B_KMAJOR) {
-        const int row = idx / (BK / 4), kq = idx % (BK / 4);
-        float* d = Bs(buf) + (4 * kq) * LDB_S + row;
-        d[0] = rb[q].x; d[LDB_S] = rb[q].y; d[2 * LDB_S] = rb[q].z; d[3 * LDB_S] = rb[q].w;
-      } else {
-        const int kr = idx / (BN / 4), nq = idx % (BN / 4);
-        *reinterpret_cast<float4*>(Bs(buf) + kr * LDB_S + 4 * nq) = rb[q];
+    for (int j = 0; j < NJ; ++j) {
+      const int d = wave + j * NW;
+      if (d < NP) {
+        const bool kok = k0 + kofs[j] < kend;
+        const float* g = (rowok[j] && kok) ? src[j] + (int64_t)it * kstride[j]
+                                           : reinterpret_cast<const float*>((ONES && ones[j] && kok) ? g_ones_page : g_zero_page);
+        __builtin_amdgcn_global_load_lds(PGNN_GPTR(g), PGNN_LPTR(st + d * 256), 16, 0, 0);
       }
     }
   };
@@ -137,116 +143,166 @@ __global__ void __launch_bounds__(kThreads) k_gemm(GemmArgs p) {
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
   const int fr = lane & 15, fk = lane >> 4;
 
-  if (nk > 0) {
-    load_tiles(kbeg);
-    store_tiles(0);
-  }
+  if (nk > 0) issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int it = 0; it < nk; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < nk) load_tiles(kbeg + (it + 1) * BK);
-    const float* a_base = As(buf) + fk * LDA_S + wm0 + fr;
-    const float* b_base = Bs(buf) + fk * LDB_S + wn0 + fr;
+    const int stage = it & 1;
+    if (it + 1 < nk) issue(stage ^ 1, it + 1);
+    const float* At = smem + stage * TILE;
+    const float* Bt = At + BM * BK;
+    f32x4 a[MI], b[NI];
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 4) {
-      float a[MI], b[NI];
+    for (int i = 0; i < MI; ++i) {
+      const int m = wm0 + i * 16 + fr;
+      if (A_KMAJOR) {
+        a[i] = *reinterpret_cast<const f32x4*>(At + m * BK + fk * 4);
+      } else {
 #pragma unroll
-      for (int i = 0; i < MI; ++i) a[i] = a_base[kk * LDA_S + i * 16];
+        for (int r = 0; r < 4; ++r) a[i][r] = At[(fk * 4 + r) * BM + m];
+      }
+    }
 #pragma unroll
-      for (int j = 0; j < NI; ++j) b[j] = b_base[kk * LDB_S + j * 16];
+    for (int j = 0; j < NI; ++j) {
+      const int n = wn0 + j * 16 + fr;
+      if (B_KMAJOR) {
+        b[j] = *reinterpret_cast<const f32x4*>(Bt + n * BK + fk * 4);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[j][r] = Bt[(fk * 4 + r) * BN + n];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    if (it + 1 < nk) store_tiles(buf ^ 1);
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][r], a[i][r], acc[i][j], 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
-  // epilogue: lane holds C[row = (lane>>4)*4 + r][col = lane&15] of each 16x16 block
+  // epilogue: lane holds C[m = .. + (lane & 15)][n = .. + (lane >> 4) * 4 + 0..3] of each 16x16 block
   float* C = p.C + (int64_t)blockIdx.y * p.split_stride;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
-    const int n = n0 + wn0 + j * 16 + fr;
+    const int n = n0 + wn0 + j * 16 + fk * 4;
+    if (ONES && n == p.N) {  // the ones column: per-row sums of Aop
+      float* cs = p.colsum + (int64_t)blockIdx.y * p.split_stride;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm0 + i * 16 + fr;
+        if (m < p.M) cs[m] = acc[i][j][0];
+      }
+      continue;
+    }
     if (n >= p.N) continue;
-    float bv = 0.f;
-    if (EPI == EPI_BIAS && p.bias) bv = p.bias[n];
+    float4 bv = f4_zero();
+    if (EPI == EPI_BIAS && p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm0 + i * 16 + fk * 4 + r;
-        if (m >= p.M) continue;
-        float v = acc[i][j][r];
-        if (EPI == EPI_BIAS) {
-          v += bv;
-          if (p.relu) v = fmaxf(v, 0.f);
+      const int m = m0 + wm0 + i * 16 + fr;
+      if (m >= p.M) continue;
+      float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      if (EPI == EPI_BIAS) {
+        v = f4_add(v, bv);
+        if (p.relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        if (EPI == EPI_MASK) {
-          if (!(p.mask[(int64_t)m * p.ldmask + n] > 0.f)) v = 0.f;
-        }
-        C[(int64_t)m * p.ldc + n] = v;
       }
+      if (EPI == EPI_MASK) {
+        const float4 mk = *reinterpret_cast<const float4*>(p.mask + (int64_t)m * p.ldmask + n);
+        if (!(mk.x > 0.f)) v.x = 0.f;
+        if (!(mk.y > 0.f)) v.y = 0.f;
+        if (!(mk.z > 0.f)) v.z = 0.f;
+        if (!(mk.w > 0.f)) v.w = 0.f;
+      }
+      *reinterpret_cast<float4*>(C + (int64_t)m * p.ldc + n) = v;
     }
   }
 }
 
 // dst[i] = sum_z partial[z][i]  (fixed order), float4
+// partial matrices are [nsplit][n4a + n4b] float4: the first n4a go to dst_a (dW), the rest to dst_b (db)
 __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__ partial, int nsplit,
-                                                       int64_t stride, float* __restrict__ dst, int64_t n4) {
-  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+                                                       int64_t stride, float* __restrict__ dst_a, int64_t n4a,
+                                                       float* __restrict__ dst_b, int64_t n4b) {
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n4a + n4b;
+       q += (int64_t)gridDim.x * blockDim.x) {
     float4 s = reinterpret_cast<const float4*>(partial)[q];
     for (int z = 1; z < nsplit; ++z) s = f4_add(s, reinterpret_cast<const float4*>(partial + z * stride)[q]);
-    reinterpret_cast<float4*>(dst)[q] = s;
+    if (q < n4a) reinterpret_cast<float4*>(dst_a)[q] = s;
+    else reinterpret_cast<float4*>(dst_b)[q - n4a] = s;
   }
 }
 
-// column sums of dy[M, N] -> partial[blk][N] (float4 columns x 4 row lanes per block); then final
-__global__ void k_colsum_partial(const float* __restrict__ dy, int64_t ld, int m, int n4,
-                                 float* __restrict__ partial) {
-  extern __shared__ __align__(16) float lds[];  // [4][n]
-  const int t = threadIdx.x, c4 = t % n4, rl = t / n4, n = n4 * 4;
-  const int per = (m + gridDim.x - 1) / gridDim.x;
-  const int r0 = blockIdx.x * per, r1 = min(m, r0 + per);
-  float4 s = f4_zero();
-  if (rl < 4) {
-    for (int r = r0 + rl; r < r1; r += 4) s = f4_add(s, reinterpret_cast<const float4*>(dy + (int64_t)r * ld)[c4]);
-    reinterpret_cast<float4*>(lds + rl * n)[c4] = s;
-  }
-  __syncthreads();
-  for (int q = t; q < n; q += blockDim.x)
-    partial[(size_t)blockIdx.x * n + q] = (lds[q] + lds[n + q]) + (lds[2 * n + q] + lds[3 * n + q]);
-}
-__global__ void __launch_bounds__(256) k_colsum_final(const float* __restrict__ partial, int nblk, int n,
-                                                      float* __restrict__ out) {
-  const int sl = threadIdx.x & 15;
-  const int cc = blockIdx.x * 16 + (threadIdx.x >> 4);
-  const int c = min(cc, n - 1);
-  const double s = slice_sum16(partial + c, (size_t)n, nblk, sl);
-  if (sl == 0 && cc < n) out[c] = (float)s;
-}
-
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES = false>
 int launch_gemm(const GemmArgs& p, int nsplit, hipStream_t st) {
-  constexpr int LDA_S = BM + (A_KMAJOR ? 1 : 4), LDB_S = BN + (B_KMAJOR ? 1 : 4);
-  constexpr size_t lds = (size_t)2 * BK * (LDA_S + LDB_S) * sizeof(float);
+  constexpr size_t lds = (size_t)2 * 16 * (BM + BN) * sizeof(float);
   static_assert(lds <= 64 * 1024, "LDS budget");
-  const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N, BN));
-  hipLaunchKernelGGL((k_gemm<BM, BN, BK, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI>), dim3(tiles, nsplit),
-                     dim3(kThreads), lds, st, p);
+  const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N + (ONES ? 4 : 0), BN));
+  hipLaunchKernelGGL((k_gemm<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES>), dim3(tiles, nsplit),
+                     dim3(64 * WAVES_M * WAVES_N), lds, st, p);
   return check_launch("gemm");
 }
 
-inline int colsum_blocks(int64_t m) { return (int)std::min<int64_t>(std::max<int64_t>(ceil_div(m, 32), 1), 1024); }
+// Tile configurations (all 4 waves, BK = 16).  N = 300 / 600 are 18.75 / 37.5 MFMA blocks wide, so the
+// 304-wide tiles (19 blocks) waste 1.3 % and the 160-wide ones (10 blocks) 6.7 %, against 22 % for a
+// power-of-two 128.  Small M (one 256-graph batch is ~6.8k rows) is a quantisation problem -- the
+// whole product is only ~8 MFMA blocks per SIMD -- so it gets the smallest wave tiles that still
+// give every SIMD a wave; large M gets the widest tile (least re-reading of the A panel).
+enum TileCfg { T128x304 = 0, T64x160 = 1, T128x160 = 2, T128x128 = 3, T64x64 = 4, kNumCfg = 5 };
+struct CfgInfo { int bm, bn, wave_blocks; };
+static const CfgInfo kCfg[kNumCfg] = {{128, 304, 38}, {64, 160, 10}, {128, 160, 20}, {128, 128, 16}, {64, 64, 4}};
 
-constexpr int kWgtBM = 64, kWgtBN = 64, kWgtBK = 16;
+inline int env_cfg() {
+  const char* v = getenv("PGNN_GEMM_CFG");
+  return v ? atoi(v) : -1;
+}
 
-inline int weight_splits(int64_t m, int64_t k, int64_t n) {
-  // enough (tile x split) blocks to fill the chip ~2x, at least 4 k-tiles per split
-  const int64_t tiles = ceil_div(n, kWgtBM) * ceil_div(k, kWgtBN);
+// kind: 0 = forward (both operands k-contiguous), 1 = backward-data (weights row-contiguous).
+// Measured on MI355X (tools/gemm_bench.py, M = 262144 / 6747, N,K in {300,600}): forward is best on
+// 64x160 / 64x64 at every M; backward-data prefers 128x304 once M is large, 64x160 below.
+inline TileCfg pick_cfg(int64_t m, int64_t n, int kind) {
+  const int forced = env_cfg();
+  if (forced >= 0 && forced < kNumCfg) return (TileCfg)forced;
+  double best = 1e30;
+  int arg = T64x64;
+  for (int c = 0; c < kNumCfg; ++c) {
+    if (c == T128x304 && (kind == 0 || m < 32768)) continue;
+    if (c == T128x160) continue;
+    const int64_t tiles = ceil_div(m, kCfg[c].bm) * ceil_div(n, kCfg[c].bn);
+    const int64_t per_simd = ceil_div(tiles * 4, 4 * kNumCU);             // waves each SIMD must run
+    const double t = (double)per_simd * (kCfg[c].wave_blocks + 5.0);     // + fixed per-tile overhead
+    if (t < best) { best = t; arg = c; }
+  }
+  return (TileCfg)arg;
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES = false>
+int launch_cfg(TileCfg c, const GemmArgs& p, int nsplit, hipStream_t st) {
+  switch (c) {
+    case T128x304: return launch_gemm<128, 304, 4, 1, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
+    case T64x160: return launch_gemm<64, 160, 2, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
+    case T128x160: return launch_gemm<128, 160, 2, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
+    case T128x128: return launch_gemm<128, 128, 2, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
+    default: return launch_gemm<64, 64, 2, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
+  }
+}
+
+constexpr int kWgtBK = 16;
+
+// split count for dW = dy^T x: every SIMD should get ~2 waves, each split at least 4 k-tiles deep
+inline int weight_splits(int64_t m, int64_t k, int64_t n, int bm, int bn) {
+  const int64_t tiles = ceil_div(n, bm) * ceil_div(k, bn);
   int64_t s = ceil_div(2 * kNumCU, tiles);
   s = std::min<int64_t>(s, std::max<int64_t>(m / (4 * kWgtBK), 1));
   return (int)std::max<int64_t>(std::min<int64_t>(s, 256), 1);
+}
+inline TileCfg weight_cfg() {
+  const int forced = env_cfg();
+  return (forced == T64x64 || forced == T128x128 || forced == T128x160) ? (TileCfg)forced : T64x160;
 }
 
 }  // namespace
@@ -258,11 +314,12 @@ extern "C" {
 
 int pgnn_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy,
                     int64_t m, int64_t k, int64_t n, int relu, pgnn_stream stream) {
-  PGNN_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && ldx % 4 == 0, "linear_fwd: K and ldx must be multiples of 4");
+  PGNN_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0,
+               "linear_fwd: K, N and the leading dimensions must be multiples of 4");
   GemmArgs p{};
   p.A = x; p.lda = ldx; p.B = w; p.ldb = k; p.C = y; p.ldc = ldy;
   p.M = (int)m; p.N = (int)n; p.K = (int)k; p.bias = bias; p.relu = relu; p.kchunk = (int)k; p.split_stride = 0;
-  return launch_gemm<128, 128, 16, 2, 2, true, true, EPI_BIAS>(p, 1, (hipStream_t)stream);
+  return launch_cfg<true, true, EPI_BIAS>(pick_cfg(m, n, 0), p, 1, (hipStream_t)stream);
 }
 
 int pgnn_linear_bwd_data(const float* dy, int64_t lddy, const float* w, const float* relu_out, int64_t ldr,
@@ -273,54 +330,50 @@ int pgnn_linear_bwd_data(const float* dy, int64_t lddy, const float* w, const fl
   // C = dx [m, k] ; reduction over n ; A = dy (n contiguous) ; B(kcol, nn) = w[nn*k + kcol]
   p.A = dy; p.lda = lddy; p.B = w; p.ldb = k; p.C = dx; p.ldc = lddx;
   p.M = (int)m; p.N = (int)k; p.K = (int)n; p.mask = relu_out; p.ldmask = ldr; p.kchunk = (int)n; p.split_stride = 0;
-  if (relu_out) return launch_gemm<128, 128, 16, 2, 2, true, false, EPI_MASK>(p, 1, (hipStream_t)stream);
-  return launch_gemm<128, 128, 16, 2, 2, true, false, EPI_PLAIN>(p, 1, (hipStream_t)stream);
+  const TileCfg c = pick_cfg(m, k, 1);
+  if (relu_out) return launch_cfg<true, false, EPI_MASK>(c, p, 1, (hipStream_t)stream);
+  return launch_cfg<true, false, EPI_PLAIN>(c, p, 1, (hipStream_t)stream);
 }
 
 size_t pgnn_linear_bwd_weight_workspace_bytes(int64_t m, int64_t k, int64_t n) {
-  return align_up((size_t)weight_splits(m, k, n) * n * k * sizeof(float), 256) +
-         align_up((size_t)colsum_blocks(m) * n * sizeof(float), 256);
+  const TileCfg c = weight_cfg();
+  return align_up((size_t)weight_splits(m, k, n, kCfg[c].bm, kCfg[c].bn) * (n * k + n) * sizeof(float), 256) + 256;
 }
 
 int pgnn_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, float* db,
                            int64_t m, int64_t k, int64_t n, void* ws, size_t ws_bytes, pgnn_stream stream) {
   PGNN_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0,
                "linear_bwd_weight: K, N and leading dimensions must be multiples of 4");
-  PGNN_REQUIRE(n <= 1024, "linear_bwd_weight: output width > 1024 not supported");
   if (ws_bytes < pgnn_linear_bwd_weight_workspace_bytes(m, k, n)) {
     set_error("linear_bwd_weight workspace too small");
     return PGNN_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
   Carver cv(ws);
-  const int nsplit = weight_splits(m, k, n);
-  float* partial = cv.take<float>((size_t)nsplit * n * k);
-  float* colpart = cv.take<float>((size_t)colsum_blocks(m) * n);
+  const TileCfg cfg = weight_cfg();
+  const int nsplit = weight_splits(m, k, n, kCfg[cfg].bm, kCfg[cfg].bn);
+  float* partial = cv.take<float>((size_t)nsplit * (n * k + n));
   GemmArgs p{};
   // C = dW [n, k] ; reduction over rows m ; A(nout, r) = dy[r*lddy + nout] ; B(kcol, r) = x[r*ldx + kcol]
+  // db[nout] = sum_r dy[r, nout] rides along as the "ones column" of B.
   p.A = dy; p.lda = lddy; p.B = x; p.ldb = ldx;
   p.M = (int)n; p.N = (int)k; p.K = (int)m;
   int64_t chunk = ceil_div(m, nsplit);
   chunk = ceil_div(chunk, kWgtBK) * kWgtBK;
   p.kchunk = (int)chunk;
   const int used = (int)ceil_div(m, chunk);
-  if (used == 1) {
-    p.C = dw; p.ldc = k; p.split_stride = 0;
-  } else {
-    p.C = partial; p.ldc = k; p.split_stride = n * k;
-  }
-  int rc = launch_gemm<kWgtBM, kWgtBN, kWgtBK, 2, 2, false, false, EPI_PLAIN>(p, used, st);
+  const bool direct = used == 1;
+  p.C = direct ? dw : partial;
+  p.ldc = k;
+  p.split_stride = direct ? 0 : n * k + n;
+  p.colsum = direct ? db : partial + n * k;
+  int rc = db ? launch_cfg<false, false, EPI_PLAIN, true>(cfg, p, used, st)
+              : launch_cfg<false, false, EPI_PLAIN, false>(cfg, p, used, st);
   if (rc) return rc;
-  if (used > 1) {
-    const int64_t n4 = n * k / 4;
-    hipLaunchKernelGGL(k_splitk_reduce, dim3((int)std::min<int64_t>(ceil_div(n4, 256), 1024)), dim3(256), 0, st,
-                       partial, used, n * k, dw, n4);
-  }
-  if (db) {
-    const int nb = colsum_blocks(m);
-    hipLaunchKernelGGL(k_colsum_partial, dim3(nb), dim3((int)align_up((size_t)n, 64)), (size_t)4 * n * sizeof(float), st,
-                       dy, lddy, (int)m, (int)(n / 4), colpart);
-    hipLaunchKernelGGL(k_colsum_final, dim3((int)ceil_div(n, 16)), dim3(256), 0, st, colpart, nb, (int)n, db);
+  if (!direct) {
+    const int64_t n4a = n * k / 4, n4b = db ? n / 4 : 0;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((int)std::min<int64_t>(ceil_div(n4a + n4b, 256), 1024)), dim3(256), 0, st,
+                       partial, used, n * k + n, dw, n4a, db, n4b);
   }
   return check_launch("linear_bwd_weight");
 }

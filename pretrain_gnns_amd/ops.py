@@ -26,8 +26,22 @@ def _ws_bytes(fn_name, *shape):
     return v
 
 
+_ws_pool = {}
+
+
 def _workspace(nbytes, device):
-    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    """scratch for ONE C call.  Every library call finishes with its workspace before it returns
+    control to the stream's next kernel (all work is enqueued in order on the current stream), so a
+    single grow-only buffer per (device, stream) replaces one allocator round trip per op."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws_pool.get(key)
+    need = max(int(nbytes), 256)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(max(need, 1 << 20) * 2 if buf is not None else max(need, 1 << 22), dtype=torch.uint8,
+                          device=device)
+        _ws_pool[key] = buf
+    return buf
 
 
 def _f32c(t):
