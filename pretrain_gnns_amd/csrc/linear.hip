@@ -66,7 +66,24 @@ __device__ float4 g_ones_page[1] = {{1.f, 0.f, 0.f, 0.f}};  // DMA source of the
 // ONES (weight-gradient product only): the B tile gets one extra column n == N whose entries are 1,
 // fetched from a constant page, so C[m][N] = sum_k Aop(m,k) -- the bias gradient -- falls out of the
 // same MFMAs and lands in p.colsum instead of needing its own column-sum kernels.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES = false>
+//
+// STAGES-deep LDS ring: the DMA of step t+STAGES-1 is issued while step t is computed and each
+// step waits only for ITS OWN pieces with a counted s_waitcnt vmcnt (every vector-memory instruction
+// in the k-loop is one of this wave's DMA pieces, so the count is exact), then one raw s_barrier.
+// With ~1-2 waves per SIMD (a 256-graph batch is only ~1.7 tiles per CU) this is what hides the HBM
+// latency of a k-step; a plain __syncthreads() would drain vmcnt to 0 and serialise load and MFMA.
+__device__ __forceinline__ void gemm_wait_vmcnt(int n) {
+#define PGNN_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n) {
+    PGNN_W(1) PGNN_W(2) PGNN_W(3) PGNN_W(4) PGNN_W(5) PGNN_W(6) PGNN_W(7) PGNN_W(8) PGNN_W(9) PGNN_W(10) PGNN_W(11)
+    PGNN_W(12) PGNN_W(13) PGNN_W(14) PGNN_W(15) PGNN_W(16) PGNN_W(17) PGNN_W(18) PGNN_W(19) PGNN_W(20) PGNN_W(21)
+    PGNN_W(22) PGNN_W(23) PGNN_W(24) PGNN_W(25) PGNN_W(26) PGNN_W(27) PGNN_W(28)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef PGNN_W
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, int STAGES>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
   constexpr int BK = 16;
   constexpr int NW = WAVES_M * WAVES_N;
@@ -143,12 +160,18 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
   const int fr = lane & 15, fk = lane >> 4;
 
-  if (nk > 0) issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  int npw = 0;  // DMA pieces this wave issues per k-step
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) npw += (wave + j * NW < NP) ? 1 : 0;
+#pragma unroll
+  for (int q = 0; q < STAGES - 1; ++q)
+    if (q < nk) issue(q, q);
   for (int it = 0; it < nk; ++it) {
-    const int stage = it & 1;
-    if (it + 1 < nk) issue(stage ^ 1, it + 1);
+    const int stage = it % STAGES;
+    gemm_wait_vmcnt(min(STAGES - 2, nk - 1 - it) * npw);  // step `it` has landed; younger steps stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave's pieces of step `it` are in LDS; buffer (it-1)%STAGES is free
+    if (it + STAGES - 1 < nk) issue((it + STAGES - 1) % STAGES, it + STAGES - 1);
     const float* At = smem + stage * TILE;
     const float* Bt = At + BM * BK;
     f32x4 a[MI], b[NI];
@@ -179,8 +202,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][r], a[i][r], acc[i][j], 0, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
   }
 
   // epilogue: lane holds C[m = .. + (lane & 15)][n = .. + (lane >> 4) * 4 + 0..3] of each 16x16 block
@@ -237,14 +258,28 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES = false>
-int launch_gemm(const GemmArgs& p, int nsplit, hipStream_t st) {
-  constexpr size_t lds = (size_t)2 * 16 * (BM + BN) * sizeof(float);
-  static_assert(lds <= 64 * 1024, "LDS budget");
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, int STAGES>
+int launch_gemm_s(const GemmArgs& p, int nsplit, hipStream_t st) {
+  constexpr size_t lds = (size_t)STAGES * 16 * (BM + BN) * sizeof(float);
   const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N + (ONES ? 4 : 0), BN));
-  hipLaunchKernelGGL((k_gemm<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES>), dim3(tiles, nsplit),
+  allow_big_lds((const void*)k_gemm<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, STAGES>, lds);
+  hipLaunchKernelGGL((k_gemm<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, STAGES>), dim3(tiles, nsplit),
                      dim3(64 * WAVES_M * WAVES_N), lds, st, p);
   return check_launch("gemm");
+}
+
+inline int env_stages(int dflt) {
+  const char* v = getenv("PGNN_GEMM_STAGES");
+  return v ? atoi(v) : dflt;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES = false>
+int launch_gemm(const GemmArgs& p, int nsplit, hipStream_t st) {
+  // Measured (tools/gemm_bench.py, M = 6747 and 262144): 2 stages beat 3 and 4 at both sizes -- the
+  // k-step is MFMA-bound, not latency-bound, and a deeper ring only costs LDS occupancy.  The 3-stage
+  // build stays selectable (PGNN_GEMM_STAGES=3) for re-measurement on other shapes.
+  if (env_stages(2) >= 3) return launch_gemm_s<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, 3>(p, nsplit, st);
+  return launch_gemm_s<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, 2>(p, nsplit, st);
 }
 
 // Tile configurations (all 4 waves, BK = 16).  N = 300 / 600 are 18.75 / 37.5 MFMA blocks wide, so the
