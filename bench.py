@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--foreach-adam", action="store_true", help="torch's default multi-kernel Adam instead of fused")
+    ap.add_argument("--readback", default="end", choices=["end", "inline"],
+                    help="where loss/accuracy are read back to the host (inline = the reference's two syncs per step)")
     return ap.parse_args()
 
 
@@ -182,14 +185,17 @@ def main():
 
     mods = make_models(dev)
     parallel.broadcast_parameters(mods)
-    opts = [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0) for m in mods]
+    # same optimizer as chem/pretrain_masking.py:134-136 (Adam, lr 1e-3, decay 0); `fused=True` selects
+    # torch's single-kernel implementation of that same update instead of the multi-kernel foreach one
+    adam_kw = {} if args.foreach_adam else {"fused": True}
+    opts = [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0, **adam_kw) for m in mods]
     if world > 1:
         opts = parallel.AllReduceOptimizers(opts)
     batch = synthetic.chem_masking_batch(args.graphs_per_gpu, seed=rank).to(dev)
     edges_local = batch.edge_index.size(1)
 
     def step():
-        return steps.chem_masking_step(mods, list(opts), batch, mask_edge=False)
+        return steps.chem_masking_step(mods, list(opts), batch, mask_edge=False, readback=args.readback)
 
     for _ in range(args.warmup):
         step()
@@ -225,7 +231,8 @@ def main():
                                    % args.graphs_per_gpu,
                        "graphs_per_gpu": args.graphs_per_gpu, "global_batch": args.graphs_per_gpu * world,
                        "nodes_per_gpu": int(batch.x.size(0)), "edges_per_gpu": int(edges_local),
-                       "parallelism": "dp%d" % world, "last_loss": round(float(loss), 5)},
+                       "parallelism": "dp%d" % world, "last_loss": round(float(loss), 5),
+                       "adam": "foreach" if args.foreach_adam else "fused", "metrics_readback": args.readback},
         }
         if not args.no_roofline:
             res["roofline"] = roofline_aggregation(dev, args.roofline_graphs)

@@ -180,6 +180,30 @@ int pgnn_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_
                            float* db, int64_t m, int64_t k, int64_t n, void* ws, size_t ws_bytes,
                            pgnn_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Layer-level composition (host-side only: each call enqueues the per-op kernels above in order).
+ * One chem GIN layer + its outer BatchNorm (chem/model.py:37-55,269-275):
+ *   agg = aggregate(x) ; hid = relu(agg W1^T + b1) ; z = hid W2^T + b2 ; y = BN(z) [ReLU]
+ * agg [n,dim], hid [n,2dim], z [n,dim] are caller-owned and are what the backward needs.
+ * ------------------------------------------------------------------------------------------ */
+size_t pgnn_chem_gin_layer_workspace_bytes(int64_t n, int64_t dim);
+int pgnn_chem_gin_layer_fwd(const float* x, int64_t ldx, const int32_t* in_ptr, const int32_t* in_src,
+                            const uint8_t* in_code, const float* emb1, const float* emb2, const float* w1,
+                            const float* b1, const float* w2, const float* b2, const float* gamma,
+                            const float* beta, float* running_mean, float* running_var, float momentum,
+                            float eps, int training, int relu, float* agg, float* hid, float* z, float* y,
+                            float* save_mean, float* save_invstd, int64_t n, int64_t dim, void* ws,
+                            size_t ws_bytes, pgnn_stream stream);
+/* backward: dx may be NULL (layer 0 input needs no gradient path other than the embedding's);
+ * demb is [9, dim]: rows 0..5 = d edge_embedding1, rows 6..8 = d edge_embedding2. */
+int pgnn_chem_gin_layer_bwd(const float* dy, int64_t lddy, const float* agg, const float* hid, const float* z,
+                            const int32_t* out_ptr, const int32_t* out_dst, const float* cfeat,
+                            const float* w1, const float* w2, const float* gamma, const float* beta,
+                            const float* save_mean, const float* save_invstd, int training, int relu,
+                            float* dx, float* demb, float* dw1, float* db1, float* dw2, float* db2,
+                            float* dgamma, float* dbeta, int64_t n, int64_t dim, void* ws, size_t ws_bytes,
+                            pgnn_stream stream);
+
 /* diagnostics: plain float4 grid-stride copy (the HBM streaming ceiling bench.py quotes next to the
  * aggregation kernel).  Not part of the hot path. */
 int pgnn_debug_stream_copy(const float* src, float* dst, int64_t n_floats, int64_t blocks, pgnn_stream stream);

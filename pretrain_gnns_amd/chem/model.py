@@ -113,10 +113,14 @@ class GNN(torch.nn.Module):
         h = ops.Embed.apply(x, self.x_embedding1.weight, self.x_embedding2.weight)
 
         h_list = [h]
+        fused = self.gnn_type == "gin" and type(self.gnns[0]) is GINConv and self.batch_norms[0].affine
         for layer in range(self.num_layer):
-            h = self.gnns[layer](h_list[layer], edge_index, edge_attr, graph)
-            last = layer == self.num_layer - 1
-            h = ops.batch_norm(h, self.batch_norms[layer], relu=not last)  # no ReLU after the last layer
+            last = layer == self.num_layer - 1  # no ReLU after the last layer
+            if fused:  # conv + BatchNorm(+ReLU) of a layer as one library call per direction
+                h = ops.chem_gin_layer(h_list[layer], self.gnns[layer], self.batch_norms[layer], graph, relu=not last)
+            else:
+                h = self.gnns[layer](h_list[layer], edge_index, edge_attr, graph)
+                h = ops.batch_norm(h, self.batch_norms[layer], relu=not last)
             if self.drop_ratio > 0:
                 h = F.dropout(h, self.drop_ratio, training=self.training)
             h_list.append(h)

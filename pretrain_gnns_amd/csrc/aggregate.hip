@@ -893,7 +893,7 @@ k_embed_fwd(const int64_t* __restrict__ idx, int64_t stride, const float* __rest
 // ---------------------------------------------------------------------------------------------
 // two-level deterministic segment sum over a grouped item list (see pgnn.h)
 // ---------------------------------------------------------------------------------------------
-constexpr int kSegChunk = 64;
+constexpr int kSegChunk = 32;
 
 template <int R>
 __global__ void __launch_bounds__(kBlock)
@@ -921,11 +921,19 @@ k_segsum_chunks(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
   int j = 0;
   while (j < cnt) {
     const int run_end = min(cnt, seg_end - p0);  // positions [j, run_end) belong to `seg`
-    for (; j < run_end; ++j) {
-      Row<R> v;
-      row_load<R>(v, x + (int64_t)bcast_i32(item, j) * ldx, lane, d4);
+    while (j < run_end) {  // four row loads in flight, added in position order
+      const int m = min(4, run_end - j);
+      Row<R> v[4];
 #pragma unroll
-      for (int r = 0; r < R; ++r) acc.v[r] = f4_add(acc.v[r], v.v[r]);
+      for (int u = 0; u < 4; ++u)
+        if (u < m) row_load<R>(v[u], x + (int64_t)bcast_i32(item, j + u) * ldx, lane, d4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (u < m) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc.v[r] = f4_add(acc.v[r], v[u].v[r]);
+        }
+      j += m;
     }
     const bool whole = seg_beg >= p0 && seg_end <= p0 + kSegChunk;  // segment inside this chunk
     if (whole) {
@@ -957,12 +965,21 @@ k_segsum_final(const int32_t* __restrict__ ptr, int n_seg, int mean, float* __re
   if (e > s) {
     const int c0 = s / kSegChunk, c1 = (e - 1) / kSegChunk;
     if (c0 == c1) return;  // written directly by k_segsum_chunks
-    for (int c = c0; c <= c1; ++c) {
-      const int slot = (c * kSegChunk > s) ? 0 : 1;
-      Row<R> v;
-      row_load<R>(v, partial + ((size_t)c * 2 + slot) * dim, lane, d4);
+    for (int c = c0; c <= c1; c += 4) {  // four partial rows in flight, added in chunk order
+      const int m = min(4, c1 - c + 1);
+      Row<R> v[4];
 #pragma unroll
-      for (int r = 0; r < R; ++r) acc.v[r] = f4_add(acc.v[r], v.v[r]);
+      for (int u = 0; u < 4; ++u)
+        if (u < m) {
+          const int slot = ((c + u) * kSegChunk > s) ? 0 : 1;
+          row_load<R>(v[u], partial + ((size_t)(c + u) * 2 + slot) * dim, lane, d4);
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (u < m) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc.v[r] = f4_add(acc.v[r], v[u].v[r]);
+        }
     }
     if (mean) {
       const float sc = 1.f / (float)(e - s);

@@ -476,3 +476,78 @@ class MLP2(Function):
 
 def linear(x, layer):
     return Linear.apply(x, layer.weight, layer.bias)
+
+
+# ------------------------------------------------------------------------------------ fused chem GIN layer
+class ChemGINLayer(Function):
+    """One chem GIN layer + its outer BatchNorm (+ReLU) as ONE library call per direction
+    (pgnn_chem_gin_layer_fwd / _bwd): chem/model.py:37-55 and :269-275.  Same kernels, same order and
+    therefore bit-identical results to ChemAggregate -> MLP2 -> BatchNormReLU; it exists because at the
+    reference's batch size a Python/ctypes/allocator round trip per kernel costs more than the kernel."""
+
+    @staticmethod
+    def forward(ctx, x, emb1, emb2, w1, b1, w2, b2, gamma, beta, graph, running_mean, running_var, training,
+                momentum, eps, relu):
+        require_cuda(x, emb1, emb2, w1, b1, w2, b2, gamma, beta)
+        x = _rows2d(x)
+        n, dim = x.shape
+        if training and n <= 1:
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
+        dev = x.device
+        acts = torch.empty(3, n, dim, dtype=torch.float32, device=dev)  # agg, z, y
+        agg, z, y = acts[0], acts[1], acts[2]
+        hid = torch.empty(n, 2 * dim, dtype=torch.float32, device=dev)
+        stats = torch.empty(2, dim, dtype=torch.float32, device=dev)
+        ws = _workspace(_ws_bytes("pgnn_chem_gin_layer_workspace_bytes", n, dim), dev)
+        emb1, emb2, w1, b1, w2, b2 = (_f32c(t) for t in (emb1, emb2, w1, b1, w2, b2))
+        check(load().pgnn_chem_gin_layer_fwd(
+            x.data_ptr(), x.stride(0), graph.in_ptr.data_ptr(), graph.in_src.data_ptr(), graph.in_code.data_ptr(),
+            emb1.data_ptr(), emb2.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+            gamma.data_ptr(), beta.data_ptr(),
+            running_mean.data_ptr() if running_mean is not None else None,
+            running_var.data_ptr() if running_var is not None else None, float(momentum), float(eps), int(training),
+            int(relu), agg.data_ptr(), hid.data_ptr(), z.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
+            stats[1].data_ptr(), n, dim, ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_chem_gin_layer_fwd")
+        ctx.save_for_backward(acts, hid, stats, w1, w2, gamma, beta)
+        ctx.graph, ctx.training, ctx.relu = graph, bool(training), bool(relu)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        acts, hid, stats, w1, w2, gamma, beta = ctx.saved_tensors
+        graph = ctx.graph
+        dy = _rows2d(dy)
+        agg, z = acts[0], acts[1]
+        n, dim = agg.shape
+        dev = dy.device
+        sizes = [9 * dim, 2 * dim * dim, 2 * dim, 2 * dim * dim, dim, dim, dim]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        demb, dw1, db1, dw2, db2, dgamma, dbeta = torch.split(flat, sizes)
+        dx = torch.empty(n, dim, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        ws = _workspace(_ws_bytes("pgnn_chem_gin_layer_workspace_bytes", n, dim), dev)
+        check(load().pgnn_chem_gin_layer_bwd(
+            dy.data_ptr(), dy.stride(0), agg.data_ptr(), hid.data_ptr(), z.data_ptr(), graph.out_ptr.data_ptr(),
+            graph.out_dst.data_ptr(), graph.cfeat.data_ptr(), w1.data_ptr(), w2.data_ptr(), gamma.data_ptr(),
+            beta.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), int(ctx.training), int(ctx.relu),
+            dx.data_ptr() if dx is not None else None, demb.data_ptr(), dw1.data_ptr(), db1.data_ptr(),
+            dw2.data_ptr(), db2.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), n, dim, ws.data_ptr(), ws.numel(),
+            stream_ptr()), "pgnn_chem_gin_layer_bwd")
+        demb = demb.view(9, dim)
+        return (dx, demb[:6], demb[6:9], dw1.view(2 * dim, dim), db1, dw2.view(dim, 2 * dim), db2, dgamma, dbeta,
+                None, None, None, None, None, None, None)
+
+
+def chem_gin_layer(x, conv, bn, graph, relu):
+    """apply GINConv ``conv`` + BatchNorm1d ``bn`` (+ReLU) through the fused layer call."""
+    training = bn.training or bn.running_mean is None
+    momentum = 0.0 if bn.momentum is None else bn.momentum
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        if bn.momentum is None:
+            momentum = 1.0 / float(bn.num_batches_tracked)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return ChemGINLayer.apply(x, conv.edge_embedding1.weight, conv.edge_embedding2.weight, conv.mlp[0].weight,
+                              conv.mlp[0].bias, conv.mlp[2].weight, conv.mlp[2].bias, bn.weight, bn.bias, graph, rm, rv,
+                              training, momentum, bn.eps, relu)

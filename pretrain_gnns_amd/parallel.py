@@ -27,7 +27,7 @@ def broadcast_parameters(modules, src=0):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
     tensors = [t for m in modules for t in list(m.parameters()) + list(m.buffers())]
-    for dtype in {t.dtype for t in tensors}:
+    for dtype in sorted({t.dtype for t in tensors}, key=str):  # identical order on every rank
         group = [t.data for t in tensors if t.dtype == dtype]
         flat = torch.cat([t.reshape(-1) for t in group])
         dist.broadcast(flat, src)

@@ -15,25 +15,42 @@ def compute_accuracy(pred, target):
     return float(torch.sum(torch.max(pred.detach(), dim=1)[1] == target).cpu().item()) / len(pred)
 
 
-def chem_masking_step(model_list, optimizer_list, batch, mask_edge=False):
+def _correct(pred, target):
+    """numerator of compute_accuracy, left on the device"""
+    return torch.sum(torch.max(pred.detach(), dim=1)[1] == target)
+
+
+def chem_masking_step(model_list, optimizer_list, batch, mask_edge=False, readback="end"):
+    """One iteration of chem/pretrain_masking.py:46-76.
+
+    readback="inline" reads accuracy and loss back exactly where the reference does (a device->host
+    sync between forward and backward, another after the optimizer).  readback="end" (default) computes
+    the same three numbers from the same tensors but fetches them with ONE transfer after
+    ``optimizer.step()``, so the GPU is not left idle mid-step waiting for Python to resume."""
     model, linear_pred_atoms, linear_pred_bonds = model_list
     node_rep = model(batch.x, batch.edge_index, batch.edge_attr)
     pred_node = linear_pred_atoms(node_rep[batch.masked_atom_indices])
     loss = F.cross_entropy(pred_node.double(), batch.mask_node_label[:, 0])
-    acc_node = compute_accuracy(pred_node, batch.mask_node_label[:, 0])
-    acc_edge = 0.0
+    inline = readback == "inline"
+    acc_node = compute_accuracy(pred_node, batch.mask_node_label[:, 0]) if inline else _correct(pred_node, batch.mask_node_label[:, 0])
+    n_node, n_edge = len(pred_node), 1
+    acc_edge = 0.0 if inline else torch.zeros((), dtype=torch.long, device=loss.device)
     if mask_edge:
         masked_edge_index = batch.edge_index[:, batch.connected_edge_indices]
         edge_rep = node_rep[masked_edge_index[0]] + node_rep[masked_edge_index[1]]
         pred_edge = linear_pred_bonds(edge_rep)
         loss = loss + F.cross_entropy(pred_edge.double(), batch.mask_edge_label[:, 0])
-        acc_edge = compute_accuracy(pred_edge, batch.mask_edge_label[:, 0])
+        n_edge = len(pred_edge)
+        acc_edge = compute_accuracy(pred_edge, batch.mask_edge_label[:, 0]) if inline else _correct(pred_edge, batch.mask_edge_label[:, 0])
     for opt in optimizer_list:
         opt.zero_grad()
     loss.backward()
     for opt in optimizer_list:
         opt.step()
-    return float(loss.cpu().item()), acc_node, acc_edge
+    if inline:
+        return float(loss.cpu().item()), acc_node, acc_edge
+    vals = torch.stack([loss.detach(), acc_node.double(), acc_edge.double()]).cpu().tolist()
+    return vals[0], vals[1] / n_node, vals[2] / n_edge
 
 
 def bio_masking_step(model_list, optimizer_list, batch):

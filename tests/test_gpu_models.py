@@ -177,6 +177,30 @@ def test_chem_masking_train_steps(mask_edge):
         assert float((ph.detach().cpu() - pr.detach()).abs().max()) < 1e-2, n
 
 
+def test_product_train_step_mirrors_oracle_step():
+    """pretrain_gnns_amd.train (what bench.py times) == oracle.steps on the same HIP model, for both
+    readback placements, including with torch's fused Adam."""
+    from pretrain_gnns_amd import train as ptrain
+    hchem, _ = _hip()
+    b = synthetic.chem_masking_batch(16, seed=5, mask_edge=True).to(DEV)
+    results = []
+    for mode in ("oracle", "inline", "end"):
+        torch.manual_seed(0)
+        mods = [hchem.GNN(5, 300).to(DEV), torch.nn.Linear(300, 119).to(DEV), torch.nn.Linear(300, 4).to(DEV)]
+        opts = [torch.optim.Adam(m.parameters(), lr=1e-3, fused=(mode == "end")) for m in mods]
+        out = []
+        for _ in range(3):
+            if mode == "oracle":
+                out.append(steps.chem_masking_step(mods, opts, b, True))
+            else:
+                out.append(ptrain.chem_masking_step(mods, opts, b, True, readback=mode))
+        results.append(out)
+    for a, c in zip(results[0], results[1]):
+        assert a == c  # identical code path, identical kernels: bitwise equal
+    for a, c in zip(results[0], results[2]):
+        assert abs(a[0] - c[0]) < 1e-3 * abs(a[0]) and abs(a[1] - c[1]) < 0.02 and abs(a[2] - c[2]) < 0.02
+
+
 def test_chem_contextpred_train_steps():
     hchem, _ = _hip()
     ref_s, hip_s = _pair(ochem.GNN, hchem.GNN, 5, 300, seed=1)
