@@ -189,7 +189,7 @@ def main():
     # torch's single-kernel implementation of that same update instead of the multi-kernel foreach one
     adam_kw = {} if args.foreach_adam else {"fused": True}
     opts = [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0, **adam_kw) for m in mods]
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         opts = parallel.AllReduceOptimizers(opts)
     batch = synthetic.chem_masking_batch(args.graphs_per_gpu, seed=rank).to(dev)
     edges_local = batch.edge_index.size(1)
@@ -240,7 +240,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.graphs_per_gpu, args.cpu_seconds)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -58,18 +58,17 @@ class GradBucket:
         return self.flat.numel() * self.flat.element_size()
 
     def allreduce(self, weight=None):
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+        if not dist.is_initialized():
             return
         world = dist.get_world_size()
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
         torch._foreach_copy_(self.views, grads)
         self.flat.mul_(weight if weight is not None else 1.0 / world)
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        for p, v in zip(self.params, self.views):
+        for p, g in zip(self.params, grads):
             if p.grad is None:
-                p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
+                p.grad = g
+        torch._foreach_copy_(grads, self.views)  # one multi-tensor kernel back into the .grad tensors
 
 
 class AllReduceOptimizers:
@@ -123,7 +122,7 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("PGNN_DP_FORCE_INIT") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
