@@ -163,18 +163,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
   int npw = 0;  // DMA pieces this wave issues per k-step
 #pragma unroll
   for (int j = 0; j < NJ; ++j) npw += (wave + j * NW < NP) ? 1 : 0;
-#pragma unroll
-  for (int q = 0; q < STAGES - 1; ++q)
-    if (q < nk) issue(q, q);
-  for (int it = 0; it < nk; ++it) {
-    const int stage = it % STAGES;
-    gemm_wait_vmcnt(min(STAGES - 2, nk - 1 - it) * npw);  // step `it` has landed; younger steps stay in flight
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // every wave's pieces of step `it` are in LDS; buffer (it-1)%STAGES is free
-    if (it + STAGES - 1 < nk) issue((it + STAGES - 1) % STAGES, it + STAGES - 1);
+
+  auto load_frags = [&](int stage, f32x4 (&a)[MI], f32x4 (&b)[NI]) {
     const float* At = smem + stage * TILE;
     const float* Bt = At + BM * BK;
-    f32x4 a[MI], b[NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = wm0 + i * 16 + fr;
@@ -195,6 +187,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
         for (int r = 0; r < 4; ++r) b[j][r] = Bt[(fk * 4 + r) * BN + n];
       }
     }
+  };
+  auto mfma_step = [&](const f32x4 (&a)[MI], const f32x4 (&b)[NI]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -202,6 +196,62 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][r], a[i][r], acc[i][j], 0, 0, 0);
+  };
+
+  // "touch": an empty asm that reads+writes the fragment registers.  The compiler must make the LDS
+  // reads that produced them complete BEFORE this point (while only those are outstanding), and treats
+  // them as ready afterwards -- so the fragment reads of the NEXT step, issued after the touch, stay in
+  // flight across the MFMA burst instead of being drained by a conservative lgkmcnt(0).
+  auto touch = [&](f32x4 (&a)[MI], f32x4 (&b)[NI]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(a[i]));
+#pragma unroll
+    for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(b[j]));
+  };
+
+  if (STAGES == 3) {
+    // Software-pipelined k-loop: three LDS stages + two register sets of fragments.  While the MFMAs
+    // of step t run, the fragments of step t+1 are already being read from LDS and the DMA of step
+    // t+2 is in flight, so neither the LDS latency nor the DMA issue sits between two MFMA bursts --
+    // which is what an occupancy of 1-2 waves per SIMD (one 256-graph batch) cannot hide otherwise.
+    f32x4 a0[MI], b0[NI], a1[MI], b1[NI];
+    if (nk > 0) issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    gemm_wait_vmcnt(nk > 1 ? npw : 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (nk > 0) load_frags(0, a0, b0);
+    for (int it = 0; it < nk; it += 2) {
+      // ---- even step: compute with (a0,b0), prefetch (a1,b1)
+      touch(a0, b0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA(it+1), issued a full step ago
+      __builtin_amdgcn_s_barrier();
+      if (it + 2 < nk) issue((it + 2) % 3, it + 2);
+      if (it + 1 < nk) load_frags((it + 1) % 3, a1, b1);
+      mfma_step(a0, b0);
+      if (it + 1 >= nk) break;
+      // ---- odd step: compute with (a1,b1), prefetch (a0,b0)
+      touch(a1, b1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (it + 3 < nk) issue((it + 3) % 3, it + 3);
+      if (it + 2 < nk) load_frags((it + 2) % 3, a0, b0);
+      mfma_step(a1, b1);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < STAGES - 1; ++q)
+      if (q < nk) issue(q, q);
+    for (int it = 0; it < nk; ++it) {
+      const int stage = it % STAGES;
+      gemm_wait_vmcnt(min(STAGES - 2, nk - 1 - it) * npw);  // step `it` has landed; younger steps stay in flight
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave's pieces of step `it` are in LDS; buffer (it-1)%STAGES is free
+      if (it + STAGES - 1 < nk) issue((it + STAGES - 1) % STAGES, it + STAGES - 1);
+      f32x4 a[MI], b[NI];
+      load_frags(stage, a, b);
+      mfma_step(a, b);
+    }
   }
 
   // epilogue: lane holds C[m = .. + (lane & 15)][n = .. + (lane >> 4) * 4 + 0..3] of each 16x16 block
@@ -275,9 +325,13 @@ inline int env_stages(int dflt) {
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES = false>
 int launch_gemm(const GemmArgs& p, int nsplit, hipStream_t st) {
-  // Measured (tools/gemm_bench.py, M = 6747 and 262144): 2 stages beat 3 and 4 at both sizes -- the
-  // k-step is MFMA-bound, not latency-bound, and a deeper ring only costs LDS occupancy.  The 3-stage
-  // build stays selectable (PGNN_GEMM_STAGES=3) for re-measurement on other shapes.
+  // Measured (tools/gemm_bench.py, tools/gemm_ksweep.py; M = 6747 and 262144): the 2-stage loop is as
+  // fast as the 3-stage software-pipelined one (fragments of step t+1 and the DMA of step t+2 in flight
+  // behind the MFMAs of step t).  Ablation (a diagnostic build that skips one component at a time) shows why: DMA issue, fragment reads and
+  // the barrier each cost ~10 % of the k-step *as issue time*, not latency -- both waves of a SIMD run
+  // them in lockstep in front of their MFMA burst.  Hiding them needs the instructions interleaved
+  // between the MFMAs (hand scheduling), which is the next step; PGNN_GEMM_STAGES=3 keeps the pipelined
+  // build selectable.
   if (env_stages(2) >= 3) return launch_gemm_s<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, 3>(p, nsplit, st);
   return launch_gemm_s<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, 2>(p, nsplit, st);
 }
@@ -287,9 +341,10 @@ int launch_gemm(const GemmArgs& p, int nsplit, hipStream_t st) {
 // power-of-two 128.  Small M (one 256-graph batch is ~6.8k rows) is a quantisation problem -- the
 // whole product is only ~8 MFMA blocks per SIMD -- so it gets the smallest wave tiles that still
 // give every SIMD a wave; large M gets the widest tile (least re-reading of the A panel).
-enum TileCfg { T128x304 = 0, T64x160 = 1, T128x160 = 2, T128x128 = 3, T64x64 = 4, kNumCfg = 5 };
+enum TileCfg { T128x304 = 0, T64x160 = 1, T128x160 = 2, T128x128 = 3, T64x64 = 4, T64x160w8 = 5, kNumCfg = 6 };
 struct CfgInfo { int bm, bn, wave_blocks; };
-static const CfgInfo kCfg[kNumCfg] = {{128, 304, 38}, {64, 160, 10}, {128, 160, 20}, {128, 128, 16}, {64, 64, 4}};
+static const CfgInfo kCfg[kNumCfg] = {{128, 304, 38}, {64, 160, 10}, {128, 160, 20}, {128, 128, 16}, {64, 64, 4},
+                                      {64, 160, 5}};
 
 inline int env_cfg() {
   const char* v = getenv("PGNN_GEMM_CFG");
@@ -306,7 +361,7 @@ inline TileCfg pick_cfg(int64_t m, int64_t n, int kind) {
   int arg = T64x64;
   for (int c = 0; c < kNumCfg; ++c) {
     if (c == T128x304 && (kind == 0 || m < 32768)) continue;
-    if (c == T128x160) continue;
+    if (c == T128x160 || c == T64x160) continue;  // the 8-wave 64x160 build beats the 4-wave one everywhere measured
     const int64_t tiles = ceil_div(m, kCfg[c].bm) * ceil_div(n, kCfg[c].bn);
     const int64_t per_simd = ceil_div(tiles * 4, 4 * kNumCU);             // waves each SIMD must run
     const double t = (double)per_simd * (kCfg[c].wave_blocks + 5.0);     // + fixed per-tile overhead
@@ -322,6 +377,7 @@ int launch_cfg(TileCfg c, const GemmArgs& p, int nsplit, hipStream_t st) {
     case T64x160: return launch_gemm<64, 160, 2, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
     case T128x160: return launch_gemm<128, 160, 2, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
     case T128x128: return launch_gemm<128, 128, 2, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
+    case T64x160w8: return launch_gemm<64, 160, 4, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
     default: return launch_gemm<64, 64, 2, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
   }
 }
@@ -337,7 +393,7 @@ inline int weight_splits(int64_t m, int64_t k, int64_t n, int bm, int bn) {
 }
 inline TileCfg weight_cfg() {
   const int forced = env_cfg();
-  return (forced == T64x64 || forced == T128x128 || forced == T128x160) ? (TileCfg)forced : T64x160;
+  return (forced == T64x64 || forced == T128x128 || forced == T128x160 || forced == T64x160) ? (TileCfg)forced : T64x160w8;
 }
 
 }  // namespace
