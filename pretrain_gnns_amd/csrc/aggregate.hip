@@ -640,11 +640,14 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
     const int* idxB = idxL + (s % NBUF) * kDmaEdges;
     const int* codeB = codeL + (s % NBUF) * kDmaEdges;
     float4 acc = f4_zero();
-    for (int p = beg; p < end; p += 4) {
-      int sidx[4], cd[4];
+    // edges gathered per batch.  Measured on the roofline batch: 2 -> 225-234 us, 1 -> 240, 3/4 -> 245;
+    // keeping the common bond-table rows in registers (select chain) was a loss (320-360 us).
+    constexpr int CH = 2;
+    for (int p = beg; p < end; p += CH) {
+      int sidx[CH], cd[CH];
       bool slow = false;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < CH; ++j) {
         sidx[j] = 0;
         cd[j] = 0;
         if (p + j < end) {
@@ -661,7 +664,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
       if (__any(slow)) {
         // rare: a source row outside the LDS window, or more edges in this step than staged slots
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < CH; ++j) {
           if (p + j < end) {
             const int sj = nbr[p + j];
             float4 m = x4[(int64_t)sj * ldx4 + c4];
@@ -670,16 +673,16 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
           }
         }
       } else {
-        float4 v[4], tv[4];
+        float4 v[CH], tv[CH];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < CH; ++j) {
           if (p + j < end) {
             v[j] = ring[slot_of(sidx[j]) * gs + c4];
             if (TABLE) tv[j] = T4[cd[j] * gs + c4];
           }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < CH; ++j) {
           if (p + j < end) {
             float4 m = v[j];
             if (TABLE) m = f4_add(m, tv[j]);
