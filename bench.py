@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--sweep-graphs", default="2048,16384",
+                    help="extra per-GPU batch sizes reported under `large_batch` (same step, same code); '' disables")
     ap.add_argument("--foreach-adam", action="store_true", help="torch's default multi-kernel Adam instead of fused")
     ap.add_argument("--readback", default="end", choices=["end", "inline"],
                     help="where loss/accuracy are read back to the host (inline = the reference's two syncs per step)")
@@ -142,6 +144,35 @@ def usable_cores():
     return n
 
 
+def large_batch_sweep(dev, sizes, args):
+    """the same train step at larger per-GPU batches (informational: the 256-graph step of the reference is
+    launch/tile-quantisation bound on an MI355X; these show what the kernels sustain once the chip is filled)."""
+    from pretrain_gnns_amd import train as steps
+    from pretrain_gnns_amd.data import synthetic
+
+    out = {}
+    base = synthetic.chem_masking_batch(2048, seed=7)
+    for g in sizes:
+        batch = (synthetic.tile_batch(base, g // 2048) if g >= 2048 else synthetic.chem_masking_batch(g, seed=7)).to(dev)
+        mods = make_models(dev)
+        adam_kw = {} if args.foreach_adam else {"fused": True}
+        opts = [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0, **adam_kw) for m in mods]
+        for _ in range(2):
+            steps.chem_masking_step(mods, opts, batch, readback=args.readback)
+        torch.cuda.synchronize()
+        t0, n = time.perf_counter(), 5
+        for _ in range(n):
+            steps.chem_masking_step(mods, opts, batch, readback=args.readback)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        e = batch.edge_index.size(1)
+        out[str(g)] = {"edges_per_s": round(e / dt, 1), "ms_per_step": round(dt * 1e3, 3), "edges": int(e),
+                       "mlp_tflops": round(3 * 5 * 720000.0 * batch.x.size(0) / dt / 1e12, 1)}
+        del batch, mods, opts
+        torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(graphs, seconds):
     """the oracle's train step (same synthetic batch shape) on the host cores."""
     from oracle import chem as ochem
@@ -234,6 +265,8 @@ def main():
                        "parallelism": "dp%d" % world, "last_loss": round(float(loss), 5),
                        "adam": "foreach" if args.foreach_adam else "fused", "metrics_readback": args.readback},
         }
+        if args.sweep_graphs and world == 1:
+            res["large_batch"] = large_batch_sweep(dev, [int(g) for g in args.sweep_graphs.split(",") if g], args)
         if not args.no_roofline:
             res["roofline"] = roofline_aggregation(dev, args.roofline_graphs)
             res["roofline_mlp"] = roofline_mlp(dev, 262144)

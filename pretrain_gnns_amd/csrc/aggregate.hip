@@ -14,6 +14,13 @@
 
 #include "common.h"
 
+#ifndef PGNN_DMA_AUX
+#define PGNN_DMA_AUX 0
+#endif
+#ifndef PGNN_DMA_NTSTORE
+#define PGNN_DMA_NTSTORE 0
+#endif
+
 namespace pgnn {
 namespace {
 
@@ -581,7 +588,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
 #pragma unroll
         for (int k = 0; k < NR; ++k)  // only the last instruction of a step can be partial
           if (k + 1 < NR || val[k])
-            __builtin_amdgcn_global_load_lds(PGNN_GPTR(base + off[k]), PGNN_LPTR(dst0 + k * kWave), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(PGNN_GPTR(base + off[k]), PGNN_LPTR(dst0 + k * kWave), 16, 0, PGNN_DMA_AUX);
         return;
       }
       int g = g_lane, c4 = c_lane;
@@ -694,7 +701,14 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
     float4 m = ring[slot_of(i) * gs + c4];
     if (TABLE) m = f4_add(m, T4[kSelfLoopCode * gs + c4]);
     acc = f4_add(acc, m);
+#if PGNN_DMA_NTSTORE
+    __builtin_nontemporal_store(acc.x, out + ((int64_t)i * ldo4 + c4) * 4 + 0);
+    __builtin_nontemporal_store(acc.y, out + ((int64_t)i * ldo4 + c4) * 4 + 1);
+    __builtin_nontemporal_store(acc.z, out + ((int64_t)i * ldo4 + c4) * 4 + 2);
+    __builtin_nontemporal_store(acc.w, out + ((int64_t)i * ldo4 + c4) * 4 + 3);
+#else
     reinterpret_cast<float4*>(out)[(int64_t)i * ldo4 + c4] = acc;
+#endif
   }
 }
 

@@ -92,7 +92,8 @@ int pgnn_chem_gin_layer_bwd(const float* dy, int64_t lddy, const float* agg, con
   float* dagg = cv.take<float>((size_t)n * dim);
   float* dz = cv.take<float>((size_t)n * dim);
   hipStream_t main = (hipStream_t)stream;
-  Side* sd = use_side_stream() ? side_for_current_device() : nullptr;
+  // concurrency only pays while one GEMM cannot fill the chip; at large n the branches just thrash L2
+  Side* sd = (use_side_stream() && n <= 32768) ? side_for_current_device() : nullptr;
   hipStream_t aux = sd ? sd->stream : main;
   char* aux_ws = sd ? op2 : op;
   auto fork = [&](int i) -> int {  // aux stream continues after everything enqueued on main so far

@@ -341,10 +341,10 @@ int launch_gemm(const GemmArgs& p, int nsplit, hipStream_t st) {
 // power-of-two 128.  Small M (one 256-graph batch is ~6.8k rows) is a quantisation problem -- the
 // whole product is only ~8 MFMA blocks per SIMD -- so it gets the smallest wave tiles that still
 // give every SIMD a wave; large M gets the widest tile (least re-reading of the A panel).
-enum TileCfg { T128x304 = 0, T64x160 = 1, T128x160 = 2, T128x128 = 3, T64x64 = 4, T64x160w8 = 5, kNumCfg = 6 };
+enum TileCfg { T128x304 = 0, T64x160 = 1, T128x160 = 2, T128x128 = 3, T64x64 = 4, T64x160w8 = 5, T320x160 = 6, kNumCfg = 7 };
 struct CfgInfo { int bm, bn, wave_blocks; };
 static const CfgInfo kCfg[kNumCfg] = {{128, 304, 38}, {64, 160, 10}, {128, 160, 20}, {128, 128, 16}, {64, 64, 4},
-                                      {64, 160, 5}};
+                                      {64, 160, 5}, {320, 160, 25}};
 
 inline int env_cfg() {
   const char* v = getenv("PGNN_GEMM_CFG");
@@ -361,7 +361,7 @@ inline TileCfg pick_cfg(int64_t m, int64_t n, int kind) {
   int arg = T64x64;
   for (int c = 0; c < kNumCfg; ++c) {
     if (c == T128x304 && (kind == 0 || m < 32768)) continue;
-    if (c == T128x160 || c == T64x160) continue;  // the 8-wave 64x160 build beats the 4-wave one everywhere measured
+    if (c == T128x160 || c == T64x160 || c == T320x160) continue;  // 8-wave 64x160 beats the 4-wave one everywhere measured
     const int64_t tiles = ceil_div(m, kCfg[c].bm) * ceil_div(n, kCfg[c].bn);
     const int64_t per_simd = ceil_div(tiles * 4, 4 * kNumCU);             // waves each SIMD must run
     const double t = (double)per_simd * (kCfg[c].wave_blocks + 5.0);     // + fixed per-tile overhead
@@ -378,6 +378,7 @@ int launch_cfg(TileCfg c, const GemmArgs& p, int nsplit, hipStream_t st) {
     case T128x160: return launch_gemm<128, 160, 2, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
     case T128x128: return launch_gemm<128, 128, 2, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
     case T64x160w8: return launch_gemm<64, 160, 4, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
+    case T320x160: return launch_gemm<320, 160, 4, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
     default: return launch_gemm<64, 64, 2, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
   }
 }
@@ -391,9 +392,16 @@ inline int weight_splits(int64_t m, int64_t k, int64_t n, int bm, int bn) {
   s = std::min<int64_t>(s, std::max<int64_t>(m / (4 * kWgtBK), 1));
   return (int)std::max<int64_t>(std::min<int64_t>(s, 256), 1);
 }
-inline TileCfg weight_cfg() {
+// Weight-gradient product dW[Nout,Kin] = dy^T x reduces over the M rows, so every tile re-streams its
+// dy / x panels from memory: traffic = |dy| * ceil(Kin/BN) + |x| * ceil(Nout/BM).  With 64x160 tiles that
+// is 7.4 GB per product at M = 438k (measured 69 TFLOP/s = L2/HBM-bound); 320x160 halves it to 3.2 GB.
+// Small M keeps the small tile: there the split count, not the traffic, is what fills the chip.
+inline TileCfg weight_cfg(int64_t m) {
   const int forced = env_cfg();
-  return (forced == T64x64 || forced == T128x128 || forced == T128x160 || forced == T64x160) ? (TileCfg)forced : T64x160w8;
+  if (forced == T64x64 || forced == T128x128 || forced == T128x160 || forced == T64x160 || forced == T64x160w8 ||
+      forced == T320x160)
+    return (TileCfg)forced;
+  return m >= 32768 ? T320x160 : T64x160w8;
 }
 
 }  // namespace
@@ -427,7 +435,7 @@ int pgnn_linear_bwd_data(const float* dy, int64_t lddy, const float* w, const fl
 }
 
 size_t pgnn_linear_bwd_weight_workspace_bytes(int64_t m, int64_t k, int64_t n) {
-  const TileCfg c = weight_cfg();
+  const TileCfg c = weight_cfg(m);
   return align_up((size_t)weight_splits(m, k, n, kCfg[c].bm, kCfg[c].bn) * (n * k + n) * sizeof(float), 256) + 256;
 }
 
@@ -441,7 +449,7 @@ int pgnn_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_
   }
   hipStream_t st = (hipStream_t)stream;
   Carver cv(ws);
-  const TileCfg cfg = weight_cfg();
+  const TileCfg cfg = weight_cfg(m);
   const int nsplit = weight_splits(m, k, n, kCfg[cfg].bm, kCfg[cfg].bn);
   float* partial = cv.take<float>((size_t)nsplit * (n * k + n));
   GemmArgs p{};
