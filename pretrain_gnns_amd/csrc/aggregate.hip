@@ -1007,6 +1007,82 @@ k_segsum_final(const int32_t* __restrict__ ptr, int n_seg, int mean, float* __re
   row_store<R>(acc, out + (int64_t)seg * ldo, lane, d4);
 }
 
+// Long segments (a few table rows that collect hundreds of thousands of items, e.g. the carbon row of
+// the atom-embedding gradient at a 16k-graph batch): one wave walking ~10^4 partial rows serially took
+// 4 ms.  Split every segment's partial range over kSegSplit waves, then add the <= kSegSplit results.
+constexpr int kSegSplit = 64;
+
+template <int R>
+__global__ void __launch_bounds__(kBlock)
+k_segsum_mid(const int32_t* __restrict__ ptr, int n_seg, const float* __restrict__ partial,
+             float* __restrict__ partial2, int dim) {
+  const int lane = lane_id(), d4 = dim >> 2;
+  const int w = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int seg = w / kSegSplit, split = w % kSegSplit;
+  if (seg >= n_seg) return;
+  const int s = ptr[seg], e = ptr[seg + 1];
+  Row<R> acc;
+  row_zero<R>(acc);
+  if (e > s) {
+    const int c0 = s / kSegChunk, c1 = (e - 1) / kSegChunk;
+    if (c0 == c1) return;  // written directly by k_segsum_chunks; final2 skips it too
+    const int per = (c1 - c0 + 1 + kSegSplit - 1) / kSegSplit;
+    const int a = c0 + split * per, b = min(c1 + 1, a + per);
+    for (int c = a; c < b; c += 4) {
+      const int m = min(4, b - c);
+      Row<R> v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (u < m) {
+          const int slot = ((c + u) * kSegChunk > s) ? 0 : 1;
+          row_load<R>(v[u], partial + ((size_t)(c + u) * 2 + slot) * dim, lane, d4);
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (u < m) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc.v[r] = f4_add(acc.v[r], v[u].v[r]);
+        }
+    }
+  }
+  row_store<R>(acc, partial2 + (size_t)w * dim, lane, d4);
+}
+
+template <int R>
+__global__ void __launch_bounds__(kBlock)
+k_segsum_final2(const int32_t* __restrict__ ptr, int n_seg, int mean, float* __restrict__ out, int64_t ldo,
+                const float* __restrict__ partial2, int dim) {
+  const int lane = lane_id(), d4 = dim >> 2;
+  const int seg = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (seg >= n_seg) return;
+  const int s = ptr[seg], e = ptr[seg + 1];
+  Row<R> acc;
+  row_zero<R>(acc);
+  if (e > s) {
+    if (s / kSegChunk == (e - 1) / kSegChunk) return;
+    for (int q = 0; q < kSegSplit; q += 4) {
+      Row<R> v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) row_load<R>(v[u], partial2 + ((size_t)seg * kSegSplit + q + u) * dim, lane, d4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc.v[r] = f4_add(acc.v[r], v[u].v[r]);
+      }
+    }
+    if (mean) {
+      const float sc = 1.f / (float)(e - s);
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc.v[r] = f4_scale(acc.v[r], sc);
+    }
+  }
+  row_store<R>(acc, out + (int64_t)seg * ldo, lane, d4);
+}
+
+inline bool segsum_two_level(int64_t n_items, int64_t n_segments) {
+  return n_segments <= 256 && ceil_div(std::max<int64_t>(n_items, 1), kSegChunk) > 2048;
+}
+
 template <int R>
 __global__ void __launch_bounds__(kBlock)
 k_segment_broadcast(const float* __restrict__ g, int64_t ldg, const int64_t* __restrict__ key,
@@ -1151,8 +1227,9 @@ int pgnn_embed_fwd(const int64_t* idx, int64_t idx_stride, const float* table1, 
 }
 
 size_t pgnn_segment_sum_workspace_bytes(int64_t n_items, int64_t n_segments, int64_t dim) {
-  (void)n_segments;
-  return (size_t)ceil_div(std::max<int64_t>(n_items, 1), kSegChunk) * 2 * dim * sizeof(float) + 256;
+  size_t b = align_up((size_t)ceil_div(std::max<int64_t>(n_items, 1), kSegChunk) * 2 * dim * sizeof(float), 256);
+  if (segsum_two_level(n_items, n_segments)) b += align_up((size_t)n_segments * kSegSplit * dim * sizeof(float), 256);
+  return b + 256;
 }
 
 int pgnn_segment_sum(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* perm, int64_t n_items,
@@ -1172,6 +1249,15 @@ int pgnn_segment_sum(const float* x, int64_t ldx, const int32_t* ptr, const int3
     PGNN_DISPATCH_R(R, hipLaunchKernelGGL((k_segsum_chunks<RR>), dim3((int)ceil_div(nchunks, kWavesPerBlock)),
                                           dim3(kBlock), 0, st, x, ldx, ptr, perm, (int)n_items, (int)n_segments,
                                           mean, out, ldo, partial, (int)dim));
+  }
+  if (segsum_two_level(n_items, n_segments)) {
+    float* partial2 = partial + align_up((size_t)nchunks * 2 * dim * sizeof(float), 256) / sizeof(float);
+    PGNN_DISPATCH_R(R, hipLaunchKernelGGL((k_segsum_mid<RR>), dim3((int)ceil_div(n_segments * kSegSplit, kWavesPerBlock)),
+                                          dim3(kBlock), 0, st, ptr, (int)n_segments, partial, partial2, (int)dim));
+    PGNN_DISPATCH_R(R, hipLaunchKernelGGL((k_segsum_final2<RR>), dim3((int)ceil_div(n_segments, kWavesPerBlock)),
+                                          dim3(kBlock), 0, st, ptr, (int)n_segments, mean, out, ldo, partial2,
+                                          (int)dim));
+    return check_launch("segment_sum");
   }
   PGNN_DISPATCH_R(R, hipLaunchKernelGGL((k_segsum_final<RR>), dim3((int)ceil_div(n_segments, kWavesPerBlock)),
                                         dim3(kBlock), 0, st, ptr, (int)n_segments, mean, out, ldo, partial,

@@ -177,6 +177,24 @@ def test_embed_fwd_bwd():
     torch.testing.assert_close(b.grad.cpu(), t2.grad, rtol=1e-4, atol=2e-3)
 
 
+def test_embed_bwd_long_segments_two_level():
+    """>2048 chunks and few table rows: exercises the split second-level reduction."""
+    ops = _ops()
+    n, dim = 90000, 64
+    torch.manual_seed(1)
+    t1 = torch.randn(120, dim, requires_grad=True)
+    idx = torch.stack([torch.randint(0, 120, (n,)), torch.zeros(n, dtype=torch.long)], 1)
+    idx[: 2 * n // 3, 0] = 5
+    want = t1[idx[:, 0]]
+    gout = torch.randn(n, dim)
+    want.backward(gout)
+    a = t1.detach().to(DEV).requires_grad_(True)
+    got = ops.Embed.apply(idx[:, :1].contiguous().to(DEV), a, None)
+    got.backward(gout.to(DEV))
+    ref = t1.grad
+    torch.testing.assert_close(a.grad.cpu(), ref, rtol=1e-4, atol=2e-4 * float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("mean", [False, True])
 def test_segment_pool(mean):
     ops = _ops()
