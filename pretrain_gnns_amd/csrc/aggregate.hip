@@ -635,17 +635,28 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
   for (int q = t; q <= cnt; q += cthreads) ptrL[q] = ptr[n0 + q];
   __syncthreads();  // prologue
 
+  // per-step row pointers are read one step ahead (they sit in LDS for the whole block), so the chain
+  // after a barrier is only: edge indices -> rows -> adds -> store
+  int nb_e0 = ptrL[0], nb_beg = 0, nb_end = 0;
+  if (active && g < cnt) { nb_beg = ptrL[g]; nb_end = ptrL[g + 1]; }
   for (int s = 0; s < nsteps; ++s) {
     __syncthreads();  // B(s)
     const int li = s * kDmaG + g;
+    const int e0 = nb_e0, beg = nb_beg, end = nb_end;
+    {
+      const int ln = li + kDmaG;
+      nb_e0 = ptrL[min((s + 1) * kDmaG, cnt)];
+      if (active && ln < cnt) { nb_beg = ptrL[ln]; nb_end = ptrL[ln + 1]; }
+    }
     if (!(active && li < cnt)) continue;
     const int i = n0 + li;
     const int base = n0 + s * kDmaG;
     const int win_lo = max(base - kDmaG, 0), win_hi = min(base + 2 * kDmaG, n);
-    const int e0 = ptrL[s * kDmaG];
-    const int beg = ptrL[li], end = ptrL[li + 1];
     const int* idxB = idxL + (s % NBUF) * kDmaEdges;
     const int* codeB = codeL + (s % NBUF) * kDmaEdges;
+    // the node's own row (self loop) does not depend on the edge list: fetch it first
+    float4 self = ring[slot_of(i) * gs + c4];
+    if (TABLE) self = f4_add(self, T4[kSelfLoopCode * gs + c4]);
     float4 acc = f4_zero();
     // edges gathered per batch.  Measured on the roofline batch: 2 -> 225-234 us, 1 -> 240, 3/4 -> 245;
     // keeping the common bond-table rows in registers (select chain) was a loss (320-360 us).
@@ -698,9 +709,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
         }
       }
     }
-    float4 m = ring[slot_of(i) * gs + c4];
-    if (TABLE) m = f4_add(m, T4[kSelfLoopCode * gs + c4]);
-    acc = f4_add(acc, m);
+    acc = f4_add(acc, self);
 #if PGNN_DMA_NTSTORE
     __builtin_nontemporal_store(acc.x, out + ((int64_t)i * ldo4 + c4) * 4 + 0);
     __builtin_nontemporal_store(acc.y, out + ((int64_t)i * ldo4 + c4) * 4 + 1);
