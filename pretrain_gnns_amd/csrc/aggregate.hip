@@ -1,6 +1,13 @@
 // Aggregation kernels of the message-passing hot path (gfx950, wave64).
 //
-// Work decomposition shared by every kernel here: ONE WAVE OWNS ONE NODE ROW AT A TIME.  A row of
+// Three implementations of out[i] = sum_e w_e (x[nbr_e] + T[code_e]) + w_ii (x[i] + T[self]) live here,
+// selected in launch_aggregate (PGNN_AGG_VARIANT overrides for A/B measurements):
+//   k_aggregate_dma  (3) production, unweighted, D <= 320: loader wave + LDS ring + consumer waves
+//   k_aggregate_grp  (1) D/4 threads per node, neighbour rows from L2: GCN weights, wide rows
+//   k_aggregate      (0) one wave per node: the first kernel, kept as the bit-exact A/B reference
+// The small reductions that surround them (edge-feature matmuls, embedding, segment sums) follow.
+//
+// Work decomposition of the helper kernels: ONE WAVE OWNS ONE NODE ROW AT A TIME.  A row of
 // D fp32 features is D/4 float4 chunks; lane l owns chunks l, l+64, ... (R = ceil(D/256) of them,
 // D = 300 -> 64 + 11 lanes), so every neighbour-row read and every result-row write is a fully
 // coalesced 16 B/lane access, partial sums live in registers, and the only scattered accesses are
@@ -13,13 +20,6 @@
 #include <stdlib.h>
 
 #include "common.h"
-
-#ifndef PGNN_DMA_AUX
-#define PGNN_DMA_AUX 0
-#endif
-#ifndef PGNN_DMA_NTSTORE
-#define PGNN_DMA_NTSTORE 0
-#endif
 
 namespace pgnn {
 namespace {
@@ -172,7 +172,7 @@ k_aggregate(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict_
   }
 }
 
-inline int pick_grid(int64_t n, int waves_per_node_chunk, int blocks_per_cu, int* nodes_per_chunk) {
+inline int pick_grid(int64_t n, int blocks_per_cu, int* nodes_per_chunk) {
   // spread small inputs over many waves, give big inputs 16-node chunks
   const int64_t max_waves = (int64_t)kNumCU * blocks_per_cu * kWavesPerBlock;
   int64_t npc = ceil_div(n, max_waves);
@@ -180,7 +180,6 @@ inline int pick_grid(int64_t n, int waves_per_node_chunk, int blocks_per_cu, int
   *nodes_per_chunk = (int)npc;
   const int64_t chunks = ceil_div(n, npc);
   const int64_t blocks = std::min<int64_t>(ceil_div(chunks, kWavesPerBlock), (int64_t)kNumCU * blocks_per_cu);
-  (void)waves_per_node_chunk;
   return (int)std::max<int64_t>(blocks, 1);
 }
 
@@ -305,197 +304,6 @@ int launch_aggregate_grp(const float* x, int64_t ldx, const int32_t* ptr, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS-ring variant (the production path for D <= 320): batches are block-diagonal, so a node's
-// neighbours sit a few rows away.  A block sweeps a contiguous node range G nodes per step and
-// keeps a sliding window of 32 feature rows in LDS: every row of x is streamed from HBM exactly
-// once per block (perfectly coalesced G*D*4-byte reads, prefetched one step ahead through
-// registers), neighbour gathers are ds_read_b128 from the ring, rows outside the window (rare)
-// fall back to a global load, and the G result rows go back as one coalesced write.  Edge indices
-// of a step are fetched once by wave 0 and shared through LDS, so the only vector-memory
-// instructions per node are ~1 row load and ~1 row store.  One barrier per step; the ring is sized
-// (2*Lh+2)*G <= 32 rows so the write of step s+Lh can never overwrite what step s-1 still reads.
-// Accumulation order per node = original edge order, self loop last (bit-exact vs the reference).
-// ---------------------------------------------------------------------------------------------
-constexpr int kRingRows = 32;       // power of two
-constexpr int kRingEdges = 64;      // edge slots staged per step
-constexpr int kRingMaxNodes = 1024;  // nodes per block (ptr slice kept in LDS)
-constexpr int kRingThreads = 640;
-
-template <bool TABLE, bool WEIGHT, int P>
-__global__ void __launch_bounds__(kRingThreads)
-k_aggregate_ring(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ ptr,
-                 const int32_t* __restrict__ nbr, const uint8_t* __restrict__ code,
-                 const float* __restrict__ emb1, const float* __restrict__ emb2,
-                 const float* __restrict__ dinv, float* __restrict__ out, int64_t ldo, int n, int dim,
-                 int G, int Lh, int npb) {
-#pragma clang fp contract(off)
-  extern __shared__ __align__(16) float smem[];
-  const int gs = dim >> 2;
-  float* T = smem;                                                         // [18][dim] (TABLE only)
-  float4* ring = reinterpret_cast<float4*>(smem + (TABLE ? kNumCodes * dim : 0));  // [32][gs]
-  int* ptrL = reinterpret_cast<int*>(ring + kRingRows * gs);               // [npb + 1]
-  int* idxL = ptrL + (kRingMaxNodes + 4);                                  // [2][64]
-  int* codeL = idxL + 2 * kRingEdges;                                      // [2][64]
-  float* wL = reinterpret_cast<float*>(codeL + 2 * kRingEdges);            // [2][64]
-  const float4* __restrict__ T4 = reinterpret_cast<const float4*>(T);
-  const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
-  const int64_t ldx4 = ldx >> 2, ldo4 = ldo >> 2;
-
-  const int t = threadIdx.x;
-  const int g = t / gs, c4 = t - g * gs;
-  const bool active = g < G;
-  const int n0 = blockIdx.x * npb, n1 = min(n, n0 + npb);
-  const int cnt = n1 - n0;
-  const int nsteps = (cnt + G - 1) / G;
-
-  if (TABLE) {
-    for (int q = t; q < kNumCodes * dim; q += kRingThreads) {
-      const int c = q / dim, d = q - c * dim;
-      T[q] = emb1[(c / 3) * dim + d] + emb2[(c % 3) * dim + d];
-    }
-  }
-  for (int q = t; q <= cnt; q += kRingThreads) ptrL[q] = ptr[n0 + q];
-
-  // row of load-step q owned by this thread: n0 + q*G + g
-  auto row_of = [&](int q) { return n0 + q * G + g; };
-  auto load_row = [&](int q) -> float4 {
-    const int r = row_of(q);
-    if (active && r >= 0 && r < n) return x4[(int64_t)r * ldx4 + c4];
-    return f4_zero();
-  };
-  auto put_row = [&](int q, float4 v) {
-    const int r = row_of(q);
-    if (active && r >= 0 && r < n) ring[(r & (kRingRows - 1)) * gs + c4] = v;
-  };
-
-  // prologue: window of step 0 = load-steps -Lh .. Lh-1 synchronously; the next P load-steps are
-  // put in flight into the register queue pre[] (row data lands P steps before it is needed)
-  for (int q = -Lh; q < Lh; ++q) put_row(q, load_row(q));
-  float4 pre[P];
-#pragma unroll
-  for (int u = 0; u < P; ++u) pre[u] = load_row(Lh + u);
-  __syncthreads();  // ptrL, T visible
-
-  // edge staging registers (threads < 64): indices of the NEXT step
-  int my_nbr = 0, my_code = 0;
-  float my_w = 0.f;
-  auto fetch_edges = [&](int s) {
-    if (t < kRingEdges && s < nsteps) {
-      const int e0 = ptrL[s * G], e1 = ptrL[min(s * G + G, cnt)];
-      const int p = e0 + t;
-      if (p < e1) {
-        my_nbr = nbr[p];
-        if (TABLE) my_code = code[p];
-        if (WEIGHT) my_w = dinv[my_nbr];
-      }
-    }
-  };
-  fetch_edges(0);
-
-  for (int s0 = 0; s0 < nsteps; s0 += P) {
-#pragma unroll
-   for (int u = 0; u < P; ++u) {
-    const int s = s0 + u;
-    if (s >= nsteps) break;  // block-uniform
-    const int buf = s & 1;
-    if (t < kRingEdges) {
-      idxL[buf * kRingEdges + t] = my_nbr;
-      if (TABLE) codeL[buf * kRingEdges + t] = my_code;
-      if (WEIGHT) wL[buf * kRingEdges + t] = my_w;
-    }
-    put_row(s + Lh, pre[u]);
-    pre[u] = load_row(s + Lh + P);
-    __syncthreads();
-    fetch_edges(s + 1);
-
-    const int li = s * G + g;  // node index relative to n0
-    if (active && li < cnt) {
-      const int i = n0 + li;
-      const int base = n0 + s * G;
-      const int win_lo = max(base - Lh * G, 0), win_hi = min(base + G + Lh * G, n);
-      const int e0 = ptrL[s * G];
-      const int beg = ptrL[li], end = ptrL[li + 1];
-      float di = 1.f;
-      if (WEIGHT) di = dinv[i];
-      float4 acc = f4_zero();
-      for (int p = beg; p < end; p += 4) {
-        int sidx[4], cd[4];
-        float w[4];
-        float4 v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (p + j < end) {
-            const int k = p + j - e0;
-            if (k < kRingEdges) {
-              sidx[j] = idxL[buf * kRingEdges + k];
-              if (TABLE) cd[j] = codeL[buf * kRingEdges + k];
-              if (WEIGHT) w[j] = wL[buf * kRingEdges + k];
-            } else {  // more edges in this step than staging slots: read them directly
-              sidx[j] = nbr[p + j];
-              if (TABLE) cd[j] = code[p + j];
-              if (WEIGHT) w[j] = dinv[sidx[j]];
-            }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (p + j < end) {
-            const int sj = sidx[j];
-            if (sj >= win_lo && sj < win_hi) v[j] = ring[(sj & (kRingRows - 1)) * gs + c4];
-            else v[j] = x4[(int64_t)sj * ldx4 + c4];
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (p + j < end) {
-            float4 m = v[j];
-            if (TABLE) m = f4_add(m, T4[cd[j] * gs + c4]);
-            if (WEIGHT) m = f4_scale(m, di * w[j]);
-            acc = f4_add(acc, m);
-          }
-        }
-      }
-      float4 m = ring[(i & (kRingRows - 1)) * gs + c4];
-      if (TABLE) m = f4_add(m, T4[kSelfLoopCode * gs + c4]);
-      if (WEIGHT) m = f4_scale(m, di * di);
-      acc = f4_add(acc, m);
-      reinterpret_cast<float4*>(out)[(int64_t)i * ldo4 + c4] = acc;
-    }
-   }
-  }
-}
-
-template <bool TABLE, bool WEIGHT>
-int launch_aggregate_ring(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* nbr,
-                          const uint8_t* code, const float* emb1, const float* emb2, const float* dinv,
-                          float* out, int64_t ldo, int64_t n, int64_t dim, hipStream_t st) {
-  const int gs = (int)(dim / 4);
-  int G = std::min(8, kRingThreads / gs);
-  G = env_int("PGNN_RING_G", G);
-  const int Lh = std::max(0, (kRingRows / G - 2) / 2);
-  const size_t lds = (size_t)(TABLE ? kNumCodes * dim : 0) * 4 + (size_t)kRingRows * dim * 4 +
-                     (size_t)(kRingMaxNodes + 4) * 4 + (size_t)6 * kRingEdges * 4;
-  const int resident = (int)std::max<size_t>(1, (160 * 1024) / lds);
-  const int64_t target_blocks = (int64_t)kNumCU * std::min(resident, env_int("PGNN_RING_BPC", 2));
-  int64_t npb = ceil_div(n, target_blocks);
-  npb = std::min<int64_t>(std::max<int64_t>(npb, 4 * G), kRingMaxNodes);
-  npb = npb / G * G;
-  const int grid = (int)ceil_div(n, npb);
-#define PGNN_LAUNCH_RING(PP)                                                                                     \
-  allow_big_lds((const void*)k_aggregate_ring<TABLE, WEIGHT, PP>, lds);                                            \
-  hipLaunchKernelGGL((k_aggregate_ring<TABLE, WEIGHT, PP>), dim3(grid), dim3(kRingThreads), lds, st, x, ldx, ptr, \
-                     nbr, code, emb1, emb2, dinv, out, ldo, (int)n, (int)dim, G, Lh, (int)npb)
-  switch (env_int("PGNN_RING_P", 4)) {
-    case 1: PGNN_LAUNCH_RING(1); break;
-    case 2: PGNN_LAUNCH_RING(2); break;
-    case 8: PGNN_LAUNCH_RING(8); break;
-    default: PGNN_LAUNCH_RING(4); break;
-  }
-#undef PGNN_LAUNCH_RING
-  return check_launch("aggregate_ring");
-}
-
-// ---------------------------------------------------------------------------------------------
 // Producer/consumer LDS-DMA variant (production path for unweighted aggregation, D <= 320).
 //   * wave CW (the last wave) is a LOADER: each step it streams the next 8 feature rows and the next
 //     step's edge indices / bond codes straight into LDS with global_load_lds (no VGPR round trip).
@@ -588,7 +396,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
 #pragma unroll
         for (int k = 0; k < NR; ++k)  // only the last instruction of a step can be partial
           if (k + 1 < NR || val[k])
-            __builtin_amdgcn_global_load_lds(PGNN_GPTR(base + off[k]), PGNN_LPTR(dst0 + k * kWave), 16, 0, PGNN_DMA_AUX);
+            __builtin_amdgcn_global_load_lds(PGNN_GPTR(base + off[k]), PGNN_LPTR(dst0 + k * kWave), 16, 0, 0);
         return;
       }
       int g = g_lane, c4 = c_lane;
@@ -710,14 +518,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
       }
     }
     acc = f4_add(acc, self);
-#if PGNN_DMA_NTSTORE
-    __builtin_nontemporal_store(acc.x, out + ((int64_t)i * ldo4 + c4) * 4 + 0);
-    __builtin_nontemporal_store(acc.y, out + ((int64_t)i * ldo4 + c4) * 4 + 1);
-    __builtin_nontemporal_store(acc.z, out + ((int64_t)i * ldo4 + c4) * 4 + 2);
-    __builtin_nontemporal_store(acc.w, out + ((int64_t)i * ldo4 + c4) * 4 + 3);
-#else
     reinterpret_cast<float4*>(out)[(int64_t)i * ldo4 + c4] = acc;
-#endif
   }
 }
 
@@ -771,14 +572,12 @@ int launch_aggregate(const float* x, int64_t ldx, const int32_t* ptr, const int3
   const int variant = env_int("PGNN_AGG_VARIANT", dim <= 320 ? (WEIGHT ? 1 : 3) : 1);
   if (variant == 3 && dim <= 320 && !WEIGHT)
     return launch_aggregate_dma<TABLE>(x, ldx, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st);
-  if (variant == 2 && dim <= 320)
-    return launch_aggregate_ring<TABLE, WEIGHT>(x, ldx, ptr, nbr, code, emb1, emb2, dinv, out, ldo, n, dim, st);
   if (variant >= 1)
     return launch_aggregate_grp<TABLE, WEIGHT>(x, ldx, ptr, nbr, code, emb1, emb2, dinv, out, ldo, n, dim, st);
   const int R = (int)ceil_div(dim / 4, kWave);
   const size_t lds = TABLE ? (size_t)kNumCodes * dim * sizeof(float) : 0;
   int npc;
-  const int grid = pick_grid(n, 1, TABLE ? 6 : 8, &npc);
+  const int grid = pick_grid(n, TABLE ? 6 : 8, &npc);
 #define PGNN_LAUNCH_AGG(RR)                                                                         \
   allow_big_lds((const void*)k_aggregate<RR, TABLE, WEIGHT>, lds);                                  \
   hipLaunchKernelGGL((k_aggregate<RR, TABLE, WEIGHT>), dim3(grid), dim3(kBlock), lds, st, x, ldx,  \

@@ -298,6 +298,24 @@ def test_large_batch_properties():
     torch.testing.assert_close(full, want, rtol=1e-5, atol=1e-5)
 
 
+def test_single_tiny_graph_and_eval_mode():
+    """one 6-atom molecule (N = 6 < one aggregation step), train and eval"""
+    hchem, _ = _hip()
+    ref, hip = _pair(ochem.GNN, hchem.GNN, 5, 300)
+    import numpy as np
+    rng = np.random.default_rng(3)
+    g = synthetic.zinc_like_graph(rng)
+    keep = 6
+    sel = (g.edge_index[0] < keep) & (g.edge_index[1] < keep)
+    x, ei, ea = g.x[:keep], g.edge_index[:, sel], g.edge_attr[sel]
+    out_ref = ref(x, ei, ea)
+    out_hip = hip(x.to(DEV), ei.to(DEV), ea.to(DEV))
+    torch.testing.assert_close(out_hip.detach().cpu(), out_ref.detach(), rtol=1e-3, atol=1e-3)  # BN over 6 rows
+    ref.eval(), hip.eval()
+    with torch.no_grad():
+        torch.testing.assert_close(hip(x.to(DEV), ei.to(DEV), ea.to(DEV)).cpu(), ref(x, ei, ea), **TOL)
+
+
 def test_class_surface_errors():
     hchem, hbio = _hip()
     with pytest.raises(ValueError):

@@ -100,6 +100,44 @@ def test_chem_gin_aggregate_bit_exact(n, e, dim):
     assert torch.equal(got.cpu(), want.detach()), (got.cpu() - want).abs().max()
 
 
+@pytest.mark.parametrize("n,e", [(1, 0), (2, 2), (7, 0), (9, 16), (33, 70), (1025, 2200)])
+def test_chem_aggregate_tiny_and_ragged(n, e):
+    """single node, no edges, sizes straddling the 8-node step / 1024-node block of the DMA kernel"""
+    ops = _ops()
+    torch.manual_seed(n)
+    ei, ea = _rand_graph(n, e, seed=n + 5) if e else (torch.zeros(2, 0, dtype=torch.long), torch.zeros(0, 2, dtype=torch.long))
+    conv = ochem.GINConv(300)
+    x = torch.randn(n, 300, requires_grad=True)
+    want = conv.aggregate(x, ei, ea)
+    gout = torch.randn(n, 300)
+    want.backward(gout)
+    g = ops.build_chem_graph(ei.to(DEV), ea.to(DEV), n)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    e1 = conv.edge_embedding1.weight.detach().to(DEV).requires_grad_(True)
+    e2 = conv.edge_embedding2.weight.detach().to(DEV).requires_grad_(True)
+    got = ops.ChemAggregate.apply(xd, e1, e2, g)
+    got.backward(gout.to(DEV))
+    assert torch.equal(got.detach().cpu(), want.detach())
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(e1.grad.cpu(), conv.edge_embedding1.weight.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_aggregate_variants_agree_bitwise(monkeypatch):
+    """the three aggregation kernels (wave-per-node, group-per-node, loader/consumer DMA) are interchangeable"""
+    ops = _ops()
+    b = synthetic.chem_masking_batch(96, seed=9).to(DEV)
+    n = b.x.size(0)
+    g = ops.build_chem_graph(b.edge_index, b.edge_attr, n)
+    torch.manual_seed(0)
+    x = torch.randn(n, 300, device=DEV)
+    e1, e2 = torch.randn(6, 300, device=DEV), torch.randn(3, 300, device=DEV)
+    outs = []
+    for v in ("0", "1", "3"):
+        monkeypatch.setenv("PGNN_AGG_VARIANT", v)
+        outs.append(ops.ChemAggregate.apply(x, e1, e2, g).clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_chem_aggregate_backward_and_gcn():
     ops = _ops()
     n, dim = 500, 300
