@@ -818,15 +818,16 @@ k_segsum_final(const int32_t* __restrict__ ptr, int n_seg, int mean, float* __re
 // Long segments (a few table rows that collect hundreds of thousands of items, e.g. the carbon row of
 // the atom-embedding gradient at a 16k-graph batch): one wave walking ~10^4 partial rows serially took
 // 4 ms.  Split every segment's partial range over kSegSplit waves, then add the <= kSegSplit results.
-constexpr int kSegSplit = 64;
+constexpr int kSegSplitMax = 64;
+inline int seg_split(int64_t nchunks) { return nchunks <= 512 ? 8 : (nchunks <= 8192 ? 32 : kSegSplitMax); }
 
 template <int R>
 __global__ void __launch_bounds__(kBlock)
 k_segsum_mid(const int32_t* __restrict__ ptr, int n_seg, const float* __restrict__ partial,
-             float* __restrict__ partial2, int dim) {
+             float* __restrict__ partial2, int dim, int nsplit) {
   const int lane = lane_id(), d4 = dim >> 2;
   const int w = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  const int seg = w / kSegSplit, split = w % kSegSplit;
+  const int seg = w / nsplit, split = w % nsplit;
   if (seg >= n_seg) return;
   const int s = ptr[seg], e = ptr[seg + 1];
   Row<R> acc;
@@ -834,7 +835,7 @@ k_segsum_mid(const int32_t* __restrict__ ptr, int n_seg, const float* __restrict
   if (e > s) {
     const int c0 = s / kSegChunk, c1 = (e - 1) / kSegChunk;
     if (c0 == c1) return;  // written directly by k_segsum_chunks; final2 skips it too
-    const int per = (c1 - c0 + 1 + kSegSplit - 1) / kSegSplit;
+    const int per = (c1 - c0 + 1 + nsplit - 1) / nsplit;
     const int a = c0 + split * per, b = min(c1 + 1, a + per);
     for (int c = a; c < b; c += 4) {
       const int m = min(4, b - c);
@@ -859,7 +860,7 @@ k_segsum_mid(const int32_t* __restrict__ ptr, int n_seg, const float* __restrict
 template <int R>
 __global__ void __launch_bounds__(kBlock)
 k_segsum_final2(const int32_t* __restrict__ ptr, int n_seg, int mean, float* __restrict__ out, int64_t ldo,
-                const float* __restrict__ partial2, int dim) {
+                const float* __restrict__ partial2, int dim, int nsplit) {
   const int lane = lane_id(), d4 = dim >> 2;
   const int seg = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (seg >= n_seg) return;
@@ -868,10 +869,10 @@ k_segsum_final2(const int32_t* __restrict__ ptr, int n_seg, int mean, float* __r
   row_zero<R>(acc);
   if (e > s) {
     if (s / kSegChunk == (e - 1) / kSegChunk) return;
-    for (int q = 0; q < kSegSplit; q += 4) {
+    for (int q = 0; q < nsplit; q += 4) {  // nsplit is a multiple of 4
       Row<R> v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) row_load<R>(v[u], partial2 + ((size_t)seg * kSegSplit + q + u) * dim, lane, d4);
+      for (int u = 0; u < 4; ++u) row_load<R>(v[u], partial2 + ((size_t)seg * nsplit + q + u) * dim, lane, d4);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
 #pragma unroll
@@ -888,7 +889,7 @@ k_segsum_final2(const int32_t* __restrict__ ptr, int n_seg, int mean, float* __r
 }
 
 inline bool segsum_two_level(int64_t n_items, int64_t n_segments) {
-  return n_segments <= 256 && ceil_div(std::max<int64_t>(n_items, 1), kSegChunk) > 2048;
+  return n_segments <= 256 && ceil_div(std::max<int64_t>(n_items, 1), kSegChunk) > 64;
 }
 
 template <int R>
@@ -1036,7 +1037,7 @@ int pgnn_embed_fwd(const int64_t* idx, int64_t idx_stride, const float* table1, 
 
 size_t pgnn_segment_sum_workspace_bytes(int64_t n_items, int64_t n_segments, int64_t dim) {
   size_t b = align_up((size_t)ceil_div(std::max<int64_t>(n_items, 1), kSegChunk) * 2 * dim * sizeof(float), 256);
-  if (segsum_two_level(n_items, n_segments)) b += align_up((size_t)n_segments * kSegSplit * dim * sizeof(float), 256);
+  if (segsum_two_level(n_items, n_segments)) b += align_up((size_t)n_segments * kSegSplitMax * dim * sizeof(float), 256);
   return b + 256;
 }
 
@@ -1060,11 +1061,12 @@ int pgnn_segment_sum(const float* x, int64_t ldx, const int32_t* ptr, const int3
   }
   if (segsum_two_level(n_items, n_segments)) {
     float* partial2 = partial + align_up((size_t)nchunks * 2 * dim * sizeof(float), 256) / sizeof(float);
-    PGNN_DISPATCH_R(R, hipLaunchKernelGGL((k_segsum_mid<RR>), dim3((int)ceil_div(n_segments * kSegSplit, kWavesPerBlock)),
-                                          dim3(kBlock), 0, st, ptr, (int)n_segments, partial, partial2, (int)dim));
+    const int ns = seg_split(nchunks);
+    PGNN_DISPATCH_R(R, hipLaunchKernelGGL((k_segsum_mid<RR>), dim3((int)ceil_div(n_segments * ns, kWavesPerBlock)),
+                                          dim3(kBlock), 0, st, ptr, (int)n_segments, partial, partial2, (int)dim, ns));
     PGNN_DISPATCH_R(R, hipLaunchKernelGGL((k_segsum_final2<RR>), dim3((int)ceil_div(n_segments, kWavesPerBlock)),
                                           dim3(kBlock), 0, st, ptr, (int)n_segments, mean, out, ldo, partial2,
-                                          (int)dim));
+                                          (int)dim, ns));
     return check_launch("segment_sum");
   }
   PGNN_DISPATCH_R(R, hipLaunchKernelGGL((k_segsum_final<RR>), dim3((int)ceil_div(n_segments, kWavesPerBlock)),

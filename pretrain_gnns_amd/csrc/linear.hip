@@ -302,7 +302,15 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
   for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n4a + n4b;
        q += (int64_t)gridDim.x * blockDim.x) {
     float4 s = reinterpret_cast<const float4*>(partial)[q];
-    for (int z = 1; z < nsplit; ++z) s = f4_add(s, reinterpret_cast<const float4*>(partial + z * stride)[q]);
+    int z = 1;
+    for (; z + 4 <= nsplit; z += 4) {  // four independent loads in flight, added in split order
+      const float4 v0 = reinterpret_cast<const float4*>(partial + (z + 0) * stride)[q];
+      const float4 v1 = reinterpret_cast<const float4*>(partial + (z + 1) * stride)[q];
+      const float4 v2 = reinterpret_cast<const float4*>(partial + (z + 2) * stride)[q];
+      const float4 v3 = reinterpret_cast<const float4*>(partial + (z + 3) * stride)[q];
+      s = f4_add(f4_add(f4_add(f4_add(s, v0), v1), v2), v3);
+    }
+    for (; z < nsplit; ++z) s = f4_add(s, reinterpret_cast<const float4*>(partial + z * stride)[q]);
     if (q < n4a) reinterpret_cast<float4*>(dst_a)[q] = s;
     else reinterpret_cast<float4*>(dst_b)[q - n4a] = s;
   }
