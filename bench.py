@@ -39,13 +39,14 @@ MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32 MFMA dense peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--graphs-per-gpu", type=int, default=256)
     ap.add_argument("--roofline-graphs", type=int, default=16384)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-hipgraph", action="store_true")
     ap.add_argument("--sweep-graphs", default="2048,16384",
                     help="extra per-GPU batch sizes reported under `large_batch` (same step, same code); '' disables")
     ap.add_argument("--foreach-adam", action="store_true", help="torch's default multi-kernel Adam instead of fused")
@@ -144,6 +145,29 @@ def usable_cores():
     return n
 
 
+def hipgraph_replay(dev, args, batch):
+    """the identical step captured into one HIP graph and replayed (fixed shapes only; informational --
+    `value` above is the eager, shape-agnostic path)."""
+    from pretrain_gnns_amd import train as steps
+
+    try:
+        mods = make_models(dev)
+        opts = [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0, fused=True, capturable=True) for m in mods]
+        g = steps.GraphedChemMaskingStep(mods, opts, batch)
+        for _ in range(5):
+            g()
+        torch.cuda.synchronize()
+        t0, n = time.perf_counter(), max(args.steps, 20)
+        for _ in range(n):
+            loss = g()[0]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        e = batch.edge_index.size(1)
+        return {"edges_per_s": round(e / dt, 1), "ms_per_step": round(dt * 1e3, 4), "last_loss": round(loss, 5)}
+    except Exception as ex:  # capture support differs between ROCm/torch builds; never break the headline run
+        return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
+
+
 def large_batch_sweep(dev, sizes, args):
     """the same train step at larger per-GPU batches (informational: the 256-graph step of the reference is
     launch/tile-quantisation bound on an MI355X; these show what the kernels sustain once the chip is filled)."""
@@ -237,12 +261,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import gc
+    gc.collect()
+    gc.disable()  # keep collector pauses of the host interpreter out of the timed region
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()[0]
     sync()
     elapsed = time.perf_counter() - t0
+    gc.enable()
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     etot = torch.tensor([float(edges_local)], dtype=torch.float64, device=dev)
@@ -265,6 +293,8 @@ def main():
                        "parallelism": "dp%d" % world, "last_loss": round(float(loss), 5),
                        "adam": "foreach" if args.foreach_adam else "fused", "metrics_readback": args.readback},
         }
+        if world == 1 and not args.no_hipgraph:
+            res["hipgraph_replay"] = hipgraph_replay(dev, args, batch)
         if args.sweep_graphs and world == 1:
             res["large_batch"] = large_batch_sweep(dev, [int(g) for g in args.sweep_graphs.split(",") if g], args)
         if not args.no_roofline:

@@ -53,6 +53,54 @@ def chem_masking_step(model_list, optimizer_list, batch, mask_edge=False, readba
     return vals[0], vals[1] / n_node, vals[2] / n_edge
 
 
+class GraphedChemMaskingStep:
+    """The same masking train step captured ONCE into a HIP graph and replayed (torch.cuda.CUDAGraph;
+    the library's launches, memsets and its side-stream fork/join are ordinary stream work and are
+    captured like torch's own kernels).  Valid only while the batch keeps its shape -- node / edge /
+    masked-atom counts are baked into the captured launches -- so it serves fixed-shape replay
+    (benchmarks, bucketed/padded loaders); variable-shape training uses ``chem_masking_step``.
+    Optimizers must be built with ``capturable=True``."""
+
+    def __init__(self, model_list, optimizer_list, batch, mask_edge=False, warmup=3):
+        self.model_list, self.optimizer_list, self.batch, self.mask_edge = model_list, optimizer_list, batch, mask_edge
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._core()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._core()
+
+    def _core(self):
+        model, linear_pred_atoms, linear_pred_bonds = self.model_list
+        b = self.batch
+        node_rep = model(b.x, b.edge_index, b.edge_attr)
+        pred_node = linear_pred_atoms(node_rep[b.masked_atom_indices])
+        loss = F.cross_entropy(pred_node.double(), b.mask_node_label[:, 0])
+        acc_node = _correct(pred_node, b.mask_node_label[:, 0])
+        acc_edge = torch.zeros((), dtype=torch.long, device=loss.device)
+        self.n_node, self.n_edge = len(pred_node), 1
+        if self.mask_edge:
+            mei = b.edge_index[:, b.connected_edge_indices]
+            pred_edge = linear_pred_bonds(node_rep[mei[0]] + node_rep[mei[1]])
+            loss = loss + F.cross_entropy(pred_edge.double(), b.mask_edge_label[:, 0])
+            acc_edge = _correct(pred_edge, b.mask_edge_label[:, 0])
+            self.n_edge = len(pred_edge)
+        for opt in self.optimizer_list:
+            opt.zero_grad(set_to_none=True)
+        loss.backward()
+        for opt in self.optimizer_list:
+            opt.step()
+        return torch.stack([loss.detach(), acc_node.double(), acc_edge.double()])
+
+    def __call__(self):
+        self.graph.replay()
+        vals = self.out.cpu().tolist()
+        return vals[0], vals[1] / self.n_node, vals[2] / self.n_edge
+
+
 def bio_masking_step(model_list, optimizer_list, batch):
     model, linear_pred_edges = model_list
     node_rep = model(batch.x, batch.edge_index, batch.edge_attr)
