@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-hipgraph", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="run only the two roofline kernels (for `rocprofv3 --kernel-trace --stats`: the profile then "
+                         "holds exactly the launches `roofline.achieved` is computed from)")
     ap.add_argument("--sweep-graphs", default="2048,16384",
                     help="extra per-GPU batch sizes reported under `large_batch` (same step, same code); '' disables")
     ap.add_argument("--foreach-adam", action="store_true", help="torch's default multi-kernel Adam instead of fused")
@@ -104,11 +107,39 @@ def roofline_aggregation(dev, graphs):
     ms = event_time_ms(launch, iters=20)
     alg_bytes = 2400.0 * n + 6.0 * e + 4.0 * (n + 1)
     gbs = alg_bytes / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "k_aggregate<2,TABLE,-> (pgnn_chem_aggregate_fwd)", "achieved": round(gbs, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-            "ms_per_launch": round(ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+    traffic, traffic_src = pmc_traffic(n, e)
+    return {"bound": "hbm", "kernel": "k_aggregate_dma<true,2,10> (pgnn_chem_aggregate_fwd)", "achieved": round(gbs, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_source": traffic_src, "ms_per_launch": round(ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
             "bytes_per_edge_per_layer": round(alg_bytes / e, 1), "graphs": int(big.batch[-1].item()) + 1,
             "nodes": n, "edges": e}
+
+
+def pmc_traffic(n, e):
+    """HBM bytes per launch of the aggregation kernel from the committed rocprofv3 PMC pass
+    (profiles/r01/agg_pmc_traffic.json: FETCH_SIZE x2 (gfx950 half-count) + WRITE_SIZE, separate --pmc
+    run of tools/agg_bench.py on this same batch).  Counters cannot be read from inside this process, so
+    the figure is only quoted when the recorded batch shape matches; otherwise null."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "agg_pmc_traffic.json")
+    try:
+        rec = json.load(open(path))
+        if rec["nodes"] == n and rec["edges"] == e:
+            return int(rec["hbm_bytes_per_launch"]), "profiles/r01/agg_pmc_traffic.json"
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
+
+
+def forward_only(dev, mods, batch, iters):
+    """edges/s of the GNN forward alone (training-mode BatchNorm, no autograd tape): SURVEY 8(d)(ii)."""
+    model = mods[0]
+
+    def fwd():
+        with torch.no_grad():
+            model(batch.x, batch.edge_index, batch.edge_attr)
+
+    ms = event_time_ms(fwd, iters=iters, warmup=5)
+    return {"edges_per_s": round(batch.edge_index.size(1) / (ms * 1e-3), 1), "ms_per_pass": round(ms, 4)}
 
 
 def roofline_mlp(dev, rows):
@@ -128,7 +159,7 @@ def roofline_mlp(dev, rows):
 
     ms = event_time_ms(launch, iters=20)
     tf = 2.0 * rows * 300 * 600 / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "k_gemm<128,128,16> (pgnn_linear_fwd 300->600)", "achieved": round(tf, 2),
+    return {"bound": "mfma", "kernel": "k_gemm<64,160,4,2,true,true,EPI_BIAS> (pgnn_linear_fwd 300->600)", "achieved": round(tf, 2),
             "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
             "ms_per_launch": round(ms, 4), "rows": rows}
 
@@ -238,6 +269,10 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
+    if args.roofline_only:
+        print(json.dumps({"roofline": roofline_aggregation(dev, args.roofline_graphs),
+                          "roofline_mlp": roofline_mlp(dev, 262144)}), flush=True)
+        return
     mods = make_models(dev)
     parallel.broadcast_parameters(mods)
     # same optimizer as chem/pretrain_masking.py:134-136 (Adam, lr 1e-3, decay 0); `fused=True` selects
@@ -293,6 +328,8 @@ def main():
                        "parallelism": "dp%d" % world, "last_loss": round(float(loss), 5),
                        "adam": "foreach" if args.foreach_adam else "fused", "metrics_readback": args.readback},
         }
+        if world == 1:
+            res["forward_only"] = forward_only(dev, mods, batch, max(args.steps, 20))
         if world == 1 and not args.no_hipgraph:
             res["hipgraph_replay"] = hipgraph_replay(dev, args, batch)
         if args.sweep_graphs and world == 1:

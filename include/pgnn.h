@@ -204,6 +204,39 @@ int pgnn_chem_gin_layer_bwd(const float* dy, int64_t lddy, const float* agg, con
                             float* dgamma, float* dbeta, int64_t n, int64_t dim, void* ws, size_t ws_bytes,
                             pgnn_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The whole node-embedding network as ONE call per direction: chem/model.py:258-277 with JK="last"
+ * and no dropout -- x_embedding1(x[:,0]) + x_embedding2(x[:,1]), then num_layer x (GINConv,
+ * BatchNorm1d, ReLU except after the last layer) -- and, backward, everything autograd would run for
+ * it including the two atom-embedding table gradients.  Same kernels and order as the per-layer calls
+ * (bit-identical results).  Activations are caller-owned and contiguous:
+ *   h0 [n,dim]; acts [num_layer][3][n][dim] = (agg, z, y) per layer; hid [num_layer][n][2dim];
+ *   stats [num_layer][2][dim] = (batch mean, 1/std).  The output is acts[num_layer-1][2].
+ * ------------------------------------------------------------------------------------------ */
+typedef struct pgnn_gin_layer {
+  const float *emb1, *emb2;           /* edge_embedding1 [6,dim], edge_embedding2 [3,dim]   (model.py:32-33) */
+  const float *w1, *b1, *w2, *b2;     /* mlp: [2dim,dim], [2dim], [dim,2dim], [dim]         (model.py:29)    */
+  const float *gamma, *beta;          /* batch_norms[l] affine                              (model.py:252)   */
+  float *running_mean, *running_var;  /* NULL: not tracked */
+  float momentum, eps;
+  /* gradients, written by the backward only */
+  float *demb /* [9,dim]: rows 0..5 d emb1, 6..8 d emb2 */, *dw1, *db1, *dw2, *db2, *dgamma, *dbeta;
+} pgnn_gin_layer;
+
+size_t pgnn_chem_gin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t rows1, int64_t rows2);
+int pgnn_chem_gin_stack_fwd(const int64_t* x_idx /* [n,2] atom type, chirality */, const float* xemb1,
+                            int64_t rows1, const float* xemb2, int64_t rows2, const int32_t* in_ptr,
+                            const int32_t* in_src, const uint8_t* in_code, const pgnn_gin_layer* layers,
+                            int num_layer, int training, float* h0, float* acts, float* hid, float* stats,
+                            int32_t* status, int64_t n, int64_t dim, void* ws, size_t ws_bytes,
+                            pgnn_stream stream);
+/* dy: gradient of acts[num_layer-1][2].  dxemb1 [rows1,dim] / dxemb2 [rows2,dim] may be NULL. */
+int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx, int64_t rows1, int64_t rows2,
+                            const int32_t* out_ptr, const int32_t* out_dst, const float* cfeat,
+                            const pgnn_gin_layer* layers, int num_layer, int training, const float* acts,
+                            const float* hid, const float* stats, float* dxemb1, float* dxemb2, int64_t n,
+                            int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream);
+
 /* diagnostics: plain float4 grid-stride copy (the HBM streaming ceiling bench.py quotes next to the
  * aggregation kernel).  Not part of the hot path. */
 int pgnn_debug_stream_copy(const float* src, float* dst, int64_t n_floats, int64_t blocks, pgnn_stream stream);

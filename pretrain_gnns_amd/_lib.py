@@ -50,10 +50,23 @@ PROTOTYPES = {
                                      _p, _p, _p, _p, _p, _p, _i64, _i64, _p, _sz, _p]),
     "pgnn_chem_gin_layer_bwd": (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i,
                                      _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p, _sz, _p]),
+    "pgnn_chem_gin_stack_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "pgnn_chem_gin_stack_fwd": (_i, [_p, _p, _i64, _p, _i64, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _i64, _i64,
+                                     _p, _sz, _p]),
+    "pgnn_chem_gin_stack_bwd": (_i, [_p, _i64, _p, _i64, _i64, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _i64, _i64,
+                                     _p, _sz, _p]),
     "pgnn_debug_stream_copy": (_i, [_p, _p, _i64, _i64, _p]),
 }
 
 ABI_VERSION = 1
+
+
+class GinLayer(ctypes.Structure):
+    """``pgnn_gin_layer`` of include/pgnn.h (per-layer parameter / gradient pointers of the stack calls)."""
+
+    _fields_ = [(k, _p) for k in ("emb1", "emb2", "w1", "b1", "w2", "b2", "gamma", "beta", "running_mean",
+                                  "running_var")] + [("momentum", _f), ("eps", _f)] + \
+               [(k, _p) for k in ("demb", "dw1", "db1", "dw2", "db2", "dgamma", "dbeta")]
 
 _lib = None
 

@@ -10,6 +10,8 @@ gather / COO ``scatter_add`` of the reference is replaced by one CSR build per b
 aggregation kernel per layer; the mlp runs on fp32 MFMA GEMMs; BatchNorm+ReLU is one fused pass.
 Tensors must be on the GPU -- there is no CPU path here (the CPU restatement lives in oracle/).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -19,6 +21,9 @@ num_atom_type = 120  # including the extra mask token (chem/model.py:9)
 num_chirality_tag = 3
 num_bond_type = 6  # including aromatic, self-loop and mask tokens (chem/model.py:12)
 num_bond_direction = 3
+
+# PGNN_STACK_CALL=0 keeps the per-layer calls even where the one-call network path applies (debugging)
+_STACK_CALL = os.environ.get("PGNN_STACK_CALL", "1") != "0"
 
 
 def _bond_tables(module, emb_dim):
@@ -110,10 +115,13 @@ class GNN(torch.nn.Module):
 
         # one structure build for all layers, forward and backward
         graph = ops.build_chem_graph(edge_index, edge_attr, x.size(0), gcn=(self.gnn_type == "gcn"))
+        fused = self.gnn_type == "gin" and type(self.gnns[0]) is GINConv and self.batch_norms[0].affine
+        if fused and self.JK == "last" and (self.drop_ratio == 0 or not self.training) and _STACK_CALL:
+            # the pre-training configuration: the whole network is one library call per direction
+            return ops.chem_gin_stack(x, graph, self.x_embedding1, self.x_embedding2, self.gnns, self.batch_norms)
         h = ops.Embed.apply(x, self.x_embedding1.weight, self.x_embedding2.weight)
 
         h_list = [h]
-        fused = self.gnn_type == "gin" and type(self.gnns[0]) is GINConv and self.batch_norms[0].affine
         for layer in range(self.num_layer):
             last = layer == self.num_layer - 1  # no ReLU after the last layer
             if fused:  # conv + BatchNorm(+ReLU) of a layer as one library call per direction

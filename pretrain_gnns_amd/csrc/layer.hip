@@ -14,10 +14,12 @@ namespace {
 // tiles, so the weight-gradient product (needs dz/dhid + saved activations) runs concurrently with the
 // data-gradient product that the rest of the chain is waiting for: fork with an event after each
 // producer, join once before returning.  Streams/events are created once per device and reused.
+constexpr int64_t kSideMaxRows = 32768;
 struct Side {
   hipStream_t stream = nullptr;
   hipEvent_t fork[3] = {nullptr, nullptr, nullptr};
   hipEvent_t join = nullptr;
+  hipEvent_t lag[2] = {nullptr, nullptr};  // stack backward: "aux finished with buffer set p"
   bool ok = false;
 };
 Side* side_for_current_device() {
@@ -30,6 +32,8 @@ Side* side_for_current_device() {
     for (auto& e : s.fork)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    for (auto& e : s.lag)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
     s.ok = true;
   }
   return &s;
@@ -93,7 +97,7 @@ int pgnn_chem_gin_layer_bwd(const float* dy, int64_t lddy, const float* agg, con
   float* dz = cv.take<float>((size_t)n * dim);
   hipStream_t main = (hipStream_t)stream;
   // concurrency only pays while one GEMM cannot fill the chip; at large n the branches just thrash L2
-  Side* sd = (use_side_stream() && n <= 32768) ? side_for_current_device() : nullptr;
+  Side* sd = (use_side_stream() && n <= kSideMaxRows) ? side_for_current_device() : nullptr;
   hipStream_t aux = sd ? sd->stream : main;
   char* aux_ws = sd ? op2 : op;
   auto fork = [&](int i) -> int {  // aux stream continues after everything enqueued on main so far
@@ -122,6 +126,158 @@ int pgnn_chem_gin_layer_bwd(const float* dy, int64_t lddy, const float* agg, con
     PGNN_HIP(hipEventRecord(sd->join, sd->stream));
     PGNN_HIP(hipStreamWaitEvent(main, sd->join, 0));
   }
+  return PGNN_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * The whole node-embedding network of chem/model.py:258-277 (JK="last", no dropout) as one call per
+ * direction: atom embedding -> num_layer x (GIN conv, BatchNorm, ReLU except after the last layer).
+ * Same kernels in the same order as the per-layer calls, hence bit-identical results; what changes
+ * is the host side: one Python/ctypes round trip per direction instead of one per layer, and in the
+ * backward ONE fork per layer -- the side stream runs a layer's three parameter-gradient products
+ * (dW2, dW1, bond tables) back to back while the main stream is already in the next layer's chain.
+ * dz/dhid/dagg are double-buffered by layer parity so that overlap is safe; `lag` events stop the
+ * main stream from re-using a buffer set before the side stream is done with it.
+ * --------------------------------------------------------------------------------------------- */
+namespace {
+inline size_t stack_group_ws(int64_t n, int64_t rows1, int64_t rows2) {
+  return align_up(std::max(pgnn_group_workspace_bytes(std::max<int64_t>(rows1, 1), n),
+                           pgnn_group_workspace_bytes(std::max<int64_t>(rows2, 1), n)), 256);
+}
+inline size_t stack_segsum_ws(int64_t n, int64_t dim, int64_t rows1, int64_t rows2) {
+  return align_up(std::max(pgnn_segment_sum_workspace_bytes(n, std::max<int64_t>(rows1, 1), dim),
+                           pgnn_segment_sum_workspace_bytes(n, std::max<int64_t>(rows2, 1), dim)), 256);
+}
+}  // namespace
+
+size_t pgnn_chem_gin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t rows1, int64_t rows2) {
+  const size_t nd = align_up((size_t)n * dim * 4, 256);
+  // 2 x op scratch + 2 x (dz, dagg, dx: nd each; dhid: 2 nd) + group-by-key of the two atom columns
+  return 2 * op_ws_bytes(n, dim) + 2 * 5 * nd + 2 * align_up((size_t)n * 4, 256) +
+         2 * align_up((size_t)(std::max(rows1, rows2) + 1) * 4, 256) + 256 + stack_group_ws(n, rows1, rows2) +
+         stack_segsum_ws(n, dim, rows1, rows2) + 256;
+}
+
+int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t rows1, const float* xemb2,
+                            int64_t rows2, const int32_t* in_ptr, const int32_t* in_src, const uint8_t* in_code,
+                            const pgnn_gin_layer* layers, int num_layer, int training, float* h0, float* acts,
+                            float* hid, float* stats, int32_t* status, int64_t n, int64_t dim, void* ws,
+                            size_t ws_bytes, pgnn_stream stream) {
+  if (num_layer < 1 || !layers) {
+    set_error("chem_gin_stack_fwd: no layers");
+    return PGNN_ERR_ARG;
+  }
+  if (ws_bytes < op_ws_bytes(n, dim)) {
+    set_error("chem_gin_stack_fwd workspace too small");
+    return PGNN_ERR_WORKSPACE;
+  }
+  int rc;
+  if ((rc = pgnn_embed_fwd(x_idx, 2, xemb1, rows1, xemb2, rows2, h0, dim, n, dim, status, stream))) return rc;
+  const size_t nd = (size_t)n * dim;
+  const float* h = h0;
+  for (int l = 0; l < num_layer; ++l) {
+    const pgnn_gin_layer& p = layers[l];
+    float* a = acts + (size_t)l * 3 * nd;
+    if ((rc = pgnn_chem_gin_layer_fwd(h, dim, in_ptr, in_src, in_code, p.emb1, p.emb2, p.w1, p.b1, p.w2, p.b2, p.gamma,
+                                      p.beta, p.running_mean, p.running_var, p.momentum, p.eps, training,
+                                      l != num_layer - 1, a, hid + (size_t)l * 2 * nd, a + nd, a + 2 * nd,
+                                      stats + (size_t)l * 2 * dim, stats + (size_t)l * 2 * dim + dim, n, dim, ws, ws_bytes,
+                                      stream)))
+      return rc;
+    h = a + 2 * nd;
+  }
+  return PGNN_OK;
+}
+
+int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx, int64_t rows1, int64_t rows2,
+                            const int32_t* out_ptr, const int32_t* out_dst, const float* cfeat,
+                            const pgnn_gin_layer* layers, int num_layer, int training, const float* acts,
+                            const float* hid, const float* stats, float* dxemb1, float* dxemb2, int64_t n,
+                            int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream) {
+  if (num_layer < 1 || !layers) {
+    set_error("chem_gin_stack_bwd: no layers");
+    return PGNN_ERR_ARG;
+  }
+  if (ws_bytes < pgnn_chem_gin_stack_workspace_bytes(n, dim, rows1, rows2)) {
+    set_error("chem_gin_stack_bwd workspace too small");
+    return PGNN_ERR_WORKSPACE;
+  }
+  const size_t nd = (size_t)n * dim;
+  Carver cv(ws);
+  const size_t opb = op_ws_bytes(n, dim);
+  char* op = cv.take<char>(opb);
+  char* op2 = cv.take<char>(opb);
+  float *dz[2], *dhid[2], *dagg[2], *dxb[2];
+  for (int p = 0; p < 2; ++p) {
+    dz[p] = cv.take<float>(nd);
+    dhid[p] = cv.take<float>(2 * nd);
+    dagg[p] = cv.take<float>(nd);
+    dxb[p] = cv.take<float>(nd);
+  }
+  int32_t* gptr[2];
+  int32_t* gperm[2];
+  for (int c = 0; c < 2; ++c) {
+    gptr[c] = cv.take<int32_t>((size_t)std::max(rows1, rows2) + 1);
+    gperm[c] = cv.take<int32_t>((size_t)n);
+  }
+  int32_t* gstatus = cv.take<int32_t>(64);
+  const size_t grp_b = stack_group_ws(n, rows1, rows2);
+  char* grp_ws = cv.take<char>(grp_b);
+  const size_t seg_b = stack_segsum_ws(n, dim, rows1, rows2);
+  char* seg_ws = cv.take<char>(seg_b);
+
+  hipStream_t main = (hipStream_t)stream;
+  Side* sd = (use_side_stream() && n <= kSideMaxRows) ? side_for_current_device() : nullptr;
+  hipStream_t aux = sd ? sd->stream : main;
+  char* aux_ws = sd ? op2 : op;
+  int rc;
+  // the atom-type / chirality groupings only depend on x_idx: first thing on the side stream
+  if (sd) {
+    PGNN_HIP(hipEventRecord(sd->fork[0], main));
+    PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[0], 0));
+  }
+  const int64_t rows[2] = {rows1, rows2};
+  float* dxemb[2] = {dxemb1, dxemb2};
+  PGNN_HIP(hipMemsetAsync(gstatus, 0, sizeof(int32_t), aux));
+  for (int c = 0; c < 2; ++c)
+    if (dxemb[c] && (rc = pgnn_group_by_key(x_idx + c, 2, n, rows[c], gptr[c], gperm[c], gstatus, grp_ws, grp_b, aux)))
+      return rc;
+
+  const float* g = dy;
+  int64_t ldg = lddy;
+  for (int l = num_layer - 1; l >= 0; --l) {
+    const pgnn_gin_layer& p = layers[l];
+    const int b = l & 1;
+    const float* a = acts + (size_t)l * 3 * nd;  // agg, z, y
+    const float* agg = a;
+    const float* z = a + nd;
+    const float* hd = hid + (size_t)l * 2 * nd;
+    const float* mean = stats + (size_t)l * 2 * dim;
+    // buffer set b was last read by the side stream two layers ago
+    if (sd && l + 2 <= num_layer - 1) PGNN_HIP(hipStreamWaitEvent(main, sd->lag[b], 0));
+    if ((rc = pgnn_bn_bwd(g, ldg, z, dim, p.gamma, p.beta, mean, mean + dim, training, l != num_layer - 1, dz[b], dim,
+                          p.dgamma, p.dbeta, n, dim, op, opb, main))) return rc;
+    if ((rc = pgnn_linear_bwd_data(dz[b], dim, p.w2, hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main))) return rc;
+    if ((rc = pgnn_linear_bwd_data(dhid[b], 2 * dim, p.w1, nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main))) return rc;
+    if (sd) {
+      PGNN_HIP(hipEventRecord(sd->fork[1], main));
+      PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[1], 0));
+    }
+    if ((rc = pgnn_linear_bwd_weight(dz[b], dim, hd, 2 * dim, p.dw2, p.db2, n, 2 * dim, dim, aux_ws, opb, aux))) return rc;
+    if ((rc = pgnn_linear_bwd_weight(dhid[b], 2 * dim, agg, dim, p.dw1, p.db1, n, dim, 2 * dim, aux_ws, opb, aux))) return rc;
+    if ((rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, aux_ws, opb, aux))) return rc;
+    if (sd) PGNN_HIP(hipEventRecord(sd->lag[b], aux));
+    if ((rc = pgnn_neighbor_sum(dagg[b], dim, out_ptr, out_dst, nullptr, dxb[b], dim, n, dim, main))) return rc;
+    g = dxb[b];
+    ldg = dim;
+  }
+  if (sd) {  // join before the embedding gradients (they need the groupings) and before returning
+    PGNN_HIP(hipEventRecord(sd->join, aux));
+    PGNN_HIP(hipStreamWaitEvent(main, sd->join, 0));
+  }
+  for (int c = 0; c < 2; ++c)
+    if (dxemb[c] && (rc = pgnn_segment_sum(g, dim, gptr[c], gperm[c], n, rows[c], 0, dxemb[c], dim, dim, seg_ws, seg_b, main)))
+      return rc;
   return PGNN_OK;
 }
 

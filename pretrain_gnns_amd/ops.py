@@ -551,3 +551,130 @@ def chem_gin_layer(x, conv, bn, graph, relu):
     return ChemGINLayer.apply(x, conv.edge_embedding1.weight, conv.edge_embedding2.weight, conv.mlp[0].weight,
                               conv.mlp[0].bias, conv.mlp[2].weight, conv.mlp[2].bias, bn.weight, bn.bias, graph, rm, rv,
                               training, momentum, bn.eps, relu)
+
+
+# ------------------------------------------------------------------------------------ whole chem GIN network
+class ChemGINStack(Function):
+    """Atom embedding + every (GINConv, BatchNorm, ReLU) layer of chem/model.py:258-277 as ONE library
+    call per direction (pgnn_chem_gin_stack_fwd / _bwd).  Bit-identical to the per-layer path; valid
+    for JK="last" without dropout (the pre-training configuration), which is when ``GNN.forward``
+    selects it.  Flat inputs: x_idx, graph, meta, xemb1, xemb2, then 9 tensors per layer
+    (emb1, emb2, w1, b1, w2, b2, gamma, beta) -- see ``chem_gin_stack``."""
+
+    PER_LAYER = 8
+
+    @staticmethod
+    def forward(ctx, x_idx, graph, meta, xemb1, xemb2, *params):
+        require_cuda(x_idx, xemb1, xemb2, *params)
+        if x_idx.dtype != torch.int64 or x_idx.dim() != 2 or x_idx.size(1) != 2:
+            raise _lib.PgnnError("chem node features must be int64 [N, 2]")
+        x_idx = x_idx.contiguous()
+        training, bns = meta
+        L = len(params) // ChemGINStack.PER_LAYER
+        n, dim = x_idx.size(0), xemb1.size(1)
+        if training and n <= 1:
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s" % ((n, dim),))
+        dev = x_idx.device
+        xemb1, xemb2 = _f32c(xemb1), _f32c(xemb2)
+        params = [_f32c(t) for t in params]
+        h0 = torch.empty(n, dim, dtype=torch.float32, device=dev)
+        acts = torch.empty(L, 3, n, dim, dtype=torch.float32, device=dev)
+        hid = torch.empty(L, n, 2 * dim, dtype=torch.float32, device=dev)
+        stats = torch.empty(L, 2, dim, dtype=torch.float32, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        layers = (_lib.GinLayer * L)()
+        for l in range(L):
+            s, p = layers[l], params[l * 8:l * 8 + 8]
+            (s.emb1, s.emb2, s.w1, s.b1, s.w2, s.b2, s.gamma, s.beta) = [t.data_ptr() for t in p]
+            rm, rv, momentum, eps = bns[l]
+            s.running_mean = rm.data_ptr() if rm is not None else None
+            s.running_var = rv.data_ptr() if rv is not None else None
+            s.momentum, s.eps = momentum, eps
+        ws = _workspace(_ws_bytes("pgnn_chem_gin_layer_workspace_bytes", n, dim), dev)
+        check(load().pgnn_chem_gin_stack_fwd(
+            x_idx.data_ptr(), xemb1.data_ptr(), xemb1.size(0), xemb2.data_ptr(), xemb2.size(0), graph.in_ptr.data_ptr(),
+            graph.in_src.data_ptr(), graph.in_code.data_ptr(), layers, L, int(training), h0.data_ptr(), acts.data_ptr(),
+            hid.data_ptr(), stats.data_ptr(), status.data_ptr(), n, dim, ws.data_ptr(), ws.numel(), stream_ptr()),
+            "pgnn_chem_gin_stack_fwd")
+        if _CHECK_INDICES and int(status.item()):
+            raise IndexError("embedding index out of range")
+        ctx.save_for_backward(acts, hid, stats, *params)
+        ctx.x_idx, ctx.graph, ctx.training, ctx.layers, ctx.rows = x_idx, graph, bool(training), layers, (xemb1.size(0), xemb2.size(0))
+        return acts[L - 1, 2]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        saved = ctx.saved_tensors
+        acts, hid, stats = saved[0], saved[1], saved[2]
+        L, _, n, dim = acts.shape
+        dy = _rows2d(dy)
+        dev = dy.device
+        rows1, rows2 = ctx.rows
+        sizes, shapes, byte_off = _stack_grad_layout(L, dim, rows1, rows2)
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        base = flat.data_ptr()
+        layers = ctx.layers
+        for l in range(L):
+            s, o = layers[l], byte_off[l]
+            s.demb, s.dw1, s.db1, s.dw2, s.db2, s.dgamma, s.dbeta = [base + b for b in o]
+        dx1, dx2 = base + byte_off[L][0], base + byte_off[L][1]
+        ws = _workspace(_ws_bytes("pgnn_chem_gin_stack_workspace_bytes", n, dim, rows1, rows2), dev)
+        g = ctx.graph
+        check(load().pgnn_chem_gin_stack_bwd(
+            dy.data_ptr(), dy.stride(0), ctx.x_idx.data_ptr(), rows1, rows2, g.out_ptr.data_ptr(), g.out_dst.data_ptr(),
+            g.cfeat.data_ptr(), layers, L, int(ctx.training), acts.data_ptr(), hid.data_ptr(), stats.data_ptr(),
+            dx1 if ctx.needs_input_grad[3] else None, dx2 if ctx.needs_input_grad[4] else None, n, dim, ws.data_ptr(),
+            ws.numel(), stream_ptr()), "pgnn_chem_gin_stack_bwd")
+        pieces = flat.split_with_sizes(sizes)
+        return (None, None, None) + tuple(t if shp is None else t.view(shp) for t, shp in zip(pieces, shapes))
+
+
+_stack_layouts = {}
+
+
+def _stack_grad_layout(L, dim, rows1, rows2):
+    """one flat gradient buffer for the stack backward: sizes / 2-D shapes of its pieces in the order
+    ChemGINStack.forward takes the parameters, and the byte offsets the C structs point at."""
+    key = (L, dim, rows1, rows2)
+    lay = _stack_layouts.get(key)
+    if lay is None:
+        sizes = [rows1 * dim, rows2 * dim]
+        shapes = [(rows1, dim), (rows2, dim)]
+        byte_off = []
+        for _ in range(L):
+            off = sum(sizes) * 4
+            # emb1 [6,d] and emb2 [3,d] are adjacent: together they are the C side's demb [9,d]
+            per = [(6 * dim, (6, dim)), (3 * dim, (3, dim)), (2 * dim * dim, (2 * dim, dim)), (2 * dim, None),
+                   (2 * dim * dim, (dim, 2 * dim)), (dim, None), (dim, None), (dim, None)]
+            starts, o = [], off
+            for sz, _shp in per:
+                starts.append(o)
+                o += sz * 4
+            byte_off.append([starts[0]] + starts[2:])  # demb, dw1, db1, dw2, db2, dgamma, dbeta
+            sizes += [sz for sz, _ in per]
+            shapes += [shp for _, shp in per]
+        byte_off.append([0, rows1 * dim * 4])
+        lay = _stack_layouts[key] = (sizes, shapes, byte_off)
+    return lay
+
+
+def chem_gin_stack(x_idx, graph, x_embedding1, x_embedding2, convs, bns):
+    """run the atom embedding and all (conv, bn) layers through the stack call; ReLU after every layer
+    but the last, as GNN.forward of the reference does."""
+    training = bns[0].training or bns[0].running_mean is None
+    meta, flat = [], []
+    counters = []
+    for conv, bn in zip(convs, bns):
+        momentum = 0.0 if bn.momentum is None else bn.momentum
+        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            counters.append(bn.num_batches_tracked)
+            if bn.momentum is None:
+                momentum = 1.0 / float(bn.num_batches_tracked + 1)
+        meta.append((bn.running_mean if bn.track_running_stats else None,
+                     bn.running_var if bn.track_running_stats else None, float(momentum), float(bn.eps)))
+        flat += [conv.edge_embedding1.weight, conv.edge_embedding2.weight, conv.mlp[0].weight, conv.mlp[0].bias,
+                 conv.mlp[2].weight, conv.mlp[2].bias, bn.weight, bn.bias]
+    if counters:
+        torch._foreach_add_(counters, 1)  # num_batches_tracked of every layer in one launch
+    return ChemGINStack.apply(x_idx, graph, (training, meta), x_embedding1.weight, x_embedding2.weight, *flat)

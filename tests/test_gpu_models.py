@@ -272,6 +272,33 @@ def test_forward_is_bitwise_deterministic():
     assert all(torch.equal(grads[0], g) for g in grads[1:])
 
 
+@pytest.mark.parametrize("graphs,layers,training", [(48, 5, True), (3, 2, True), (48, 3, False), (1500, 5, True)])
+def test_one_call_network_equals_per_layer_path(graphs, layers, training, monkeypatch):
+    """pgnn_chem_gin_stack_fwd/_bwd (whole network, one call per direction; side-stream overlap across
+    layers) must be BIT-identical to the per-layer calls: outputs, every gradient, BN running stats."""
+    import copy
+    hchem, _ = _hip()
+    _, a = _pair(ochem.GNN, hchem.GNN, layers, 300, seed=5)
+    b = copy.deepcopy(a)
+    a.train(training), b.train(training)
+    d = synthetic.chem_masking_batch(graphs, seed=6).to(DEV)
+    w = torch.randn(d.x.size(0), 300, device=DEV)
+    res = []
+    for m, flag in ((a, True), (b, False)):
+        monkeypatch.setattr(hchem, "_STACK_CALL", flag)
+        for _ in range(2):  # twice: running statistics and counters advance identically
+            m.zero_grad()
+            out = m(d.x, d.edge_index, d.edge_attr)
+            (out * w).sum().backward()
+        res.append((out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                    {k: v.clone() for k, v in m.named_buffers()}))
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
+
+
 def test_large_batch_properties():
     """BASELINE full size (2048 graphs): size-independent checks instead of a slow oracle run --
     linearity of the aggregation in x and agreement of the aggregation with a torch index_add on GPU."""
