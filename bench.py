@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-hipgraph", action="store_true")
+    ap.add_argument("--no-loader", action="store_true", help="skip the device-side loader leg")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the two roofline kernels (for `rocprofv3 --kernel-trace --stats`: the profile then "
                          "holds exactly the launches `roofline.achieved` is computed from)")
@@ -140,6 +141,52 @@ def forward_only(dev, mods, batch, iters):
 
     ms = event_time_ms(fwd, iters=iters, warmup=5)
     return {"edges_per_s": round(batch.edge_index.size(1) / (ms * 1e-3), 1), "ms_per_pass": round(ms, 4)}
+
+
+def resident_loader_leg(dev, args, steps_n):
+    """every step draws a NEW 256-graph batch from a dataset resident in HBM
+    (device-side collate + MaskAtom, csrc/loader.hip) and trains on it -- the end-to-end rate with the
+    loader inside the timed region; beside it the host cost of the reference-style collate (MaskAtom per
+    graph + BatchMasking.from_data_list + H2D) for the same batches."""
+    import numpy as np
+    from pretrain_gnns_amd import train as steps
+    from pretrain_gnns_amd.data import resident, synthetic
+
+    rng = np.random.default_rng(1234)
+    graphs = [synthetic.zinc_like_graph(rng) for _ in range(4096)]
+    ds = resident.ResidentDataset.from_graphs(graphs, dev)
+    loader = resident.ResidentLoader(ds, args.graphs_per_gpu, shuffle=True, seed=1, mask_rate=0.15, drop_last=True)
+    mods = make_models(dev)
+    opts = [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0, fused=True) for m in mods]
+    edges, done, t0 = 0, 0, None
+    while done < steps_n + 5:
+        for batch in loader:
+            if done == 5:  # warm-up done
+                torch.cuda.synchronize()
+                t0, edges = time.perf_counter(), 0
+            steps.chem_masking_step(mods, opts, batch)
+            edges += batch.edge_index.size(1)
+            done += 1
+            if done >= steps_n + 5:
+                break
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ids = loader.batch_ids(0)[:8]
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for i in ids:
+        ds.collate(i, mask_rate=0.15, seed=3)
+    e.record()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in ids[:4]:
+        synthetic.collate([synthetic.mask_atoms(graphs[j], rng) for j in i]).to(dev)
+    torch.cuda.synchronize()
+    host_ms = (time.perf_counter() - t1) / 4 * 1e3
+    return {"edges_per_s": round(edges / dt, 1), "ms_per_step": round(dt / steps_n * 1e3, 4),
+            "device_collate_mask_ms": round(s.elapsed_time(e) / len(ids), 4), "host_collate_mask_h2d_ms": round(host_ms, 3),
+            "dataset_graphs": len(graphs)}
 
 
 def roofline_mlp(dev, rows):
@@ -330,6 +377,8 @@ def main():
         }
         if world == 1:
             res["forward_only"] = forward_only(dev, mods, batch, max(args.steps, 20))
+        if world == 1 and not args.no_loader:
+            res["resident_loader"] = resident_loader_leg(dev, args, max(args.steps, 20))
         if world == 1 and not args.no_hipgraph:
             res["hipgraph_replay"] = hipgraph_replay(dev, args, batch)
         if args.sweep_graphs and world == 1:

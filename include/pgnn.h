@@ -237,6 +237,41 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
                             const float* hid, const float* stats, float* dxemb1, float* dxemb2, int64_t n,
                             int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Device-side batching over a dataset resident in HBM.  The dataset is kept in
+ * the concatenated (data, slices) form InMemoryDataset stores (chem/loader.py MoleculeDataset,
+ * bio/loader.py BioDataset): x_all [sum n, *], edge_index_all [2, sum e] with graph-local node ids,
+ * edge_attr_all [sum e, *], node_slice / edge_slice [G+1].  Replaces, for a list of graph ids,
+ * BatchMasking.from_data_list (chem/batch.py:17-52; bio/batch.py:70-106) and MaskAtom
+ * (chem/util.py:225-244).  All sizes are known to the host from its copy of the slices, so no call
+ * synchronises; `status` collects bit 0 = graph id out of range, bit 1 = totals differ from the
+ * caller's, bit 2 = masked index out of range.
+ * ------------------------------------------------------------------------------------------ */
+/* node_off / edge_off / mask_off [num_graphs+1]: exclusive sums of the batch's per-graph node, edge and
+ * masked-atom counts; masked atoms per graph = int(n * mask_rate + 1) (chem/util.py:232), 0 if rate == 0 */
+int pgnn_batch_offsets(const int64_t* graph_ids, int64_t num_graphs, int64_t dataset_graphs,
+                       const int64_t* node_slice, const int64_t* edge_slice, double mask_rate,
+                       int64_t* node_off, int64_t* edge_off, int64_t* mask_off, int64_t expect_nodes,
+                       int64_t expect_edges, int64_t expect_masked, int32_t* status, pgnn_stream stream);
+/* x [N, x_row_bytes], edge_index [2, E] = local ids + the graph's node offset (batch.py:38-39),
+ * edge_attr [E, attr_row_bytes], batch [N] = position of the graph in graph_ids (batch.py:36) */
+int pgnn_collate_graphs(const int64_t* graph_ids, int64_t num_graphs, int64_t dataset_graphs,
+                        const int64_t* node_slice, const int64_t* edge_slice, const int64_t* node_off,
+                        const int64_t* edge_off, const void* x_all, int64_t x_row_bytes,
+                        const int64_t* edge_index_all, int64_t edges_all, const void* edge_attr_all,
+                        int64_t attr_row_bytes, int64_t num_nodes, int64_t num_edges, void* x,
+                        int64_t* edge_index, void* edge_attr, int64_t* batch, pgnn_stream stream);
+/* masked_atom_indices [M]: per graph, int(n*rate+1) distinct atoms drawn uniformly (counter-based keys
+ * from (seed, graph id, atom): the same graph gets the same draw wherever it sits in a batch), as batch
+ * node positions (batch.py:39-40) */
+int pgnn_mask_atoms_select(const int64_t* graph_ids, int64_t num_graphs, const int64_t* node_off,
+                           const int64_t* mask_off, int64_t num_nodes, uint64_t seed,
+                           int64_t* masked_atom_indices, pgnn_stream stream);
+/* mask_node_label[i] = x[idx_i] ; x[idx_i] = [mask_token, 0, ...]   (chem/util.py:236-244) */
+int pgnn_mask_atoms_apply(const int64_t* masked_atom_indices, int64_t num_masked, int64_t* x, int64_t x_cols,
+                          int64_t num_nodes, int64_t mask_token, int64_t* mask_node_label, int32_t* status,
+                          pgnn_stream stream);
+
 /* diagnostics: plain float4 grid-stride copy (the HBM streaming ceiling bench.py quotes next to the
  * aggregation kernel).  Not part of the hot path. */
 int pgnn_debug_stream_copy(const float* src, float* dst, int64_t n_floats, int64_t blocks, pgnn_stream stream);

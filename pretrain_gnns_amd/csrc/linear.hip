@@ -83,16 +83,17 @@ __device__ __forceinline__ void gemm_wait_vmcnt(int n) {
 #undef PGNN_W
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, int STAGES>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, int KS>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
-  constexpr int BK = 16;
+  constexpr int BK = 16;       // depth of one LDS image (= 4 MFMA k-steps)
+  constexpr int STAGES = 2;    // LDS ring; each stage holds KS images = 16*KS of k per barrier
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MI = WM / 16, NI = WN / 16;
   static_assert(WM % 16 == 0 && WN % 16 == 0 && BM % 16 == 0 && BN % 16 == 0, "tile shape");
-  constexpr int PA = BM / 16, PB = BN / 16;        // 1-KiB DMA pieces per k-step
-  constexpr int NP = PA + PB, NJ = (NP + NW - 1) / NW;  // pieces per wave
-  constexpr int TILE = (BM + BN) * BK;              // floats per stage
+  constexpr int PA = BM / 16, PB = BN / 16;        // 1-KiB DMA pieces per image
+  constexpr int NP = PA + PB, NJ = (KS * NP + NW - 1) / NW;  // pieces per wave and k-step
+  constexpr int TILE = (BM + BN) * BK;              // floats per image
 
   extern __shared__ __align__(16) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -101,7 +102,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
   const int kbeg = blockIdx.y * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
-  const int nk = (kend - kbeg + BK - 1) / BK;
+  const int nk16 = (kend - kbeg + BK - 1) / BK;  // images to consume
+  const int nk = (nk16 + KS - 1) / KS;           // k-steps (barriers)
 
   // ---- per-wave DMA pieces: piece d < PA is float4 [64d, 64d+64) of the A tile, else of the B tile
   const float* src[NJ];   // this lane's source at k-step 0
@@ -110,9 +112,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
   bool rowok[NJ], ones[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int d = wave + j * NW;
+    const int dd = wave + j * NW;
     src[j] = nullptr; kofs[j] = 0; kstride[j] = 0; rowok[j] = false; ones[j] = false;
-    if (d < NP) {
+    if (dd < KS * NP) {
+      const int sub = dd / NP, d = dd % NP;  // image inside the k-step, piece inside the image
       const bool isA = d < PA;
       const int idx = (isA ? d : d - PA) * 64 + lane;  // float4 index inside the tile
       const float* base = isA ? p.A : p.B;
@@ -123,26 +126,26 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
       if (kmajor) {
         const int row = idx >> 2, kq = idx & 3;
         rowok[j] = r0 + row < rmax;
-        kofs[j] = 4 * kq;
-        src[j] = base + (int64_t)(r0 + row) * ld + kbeg + 4 * kq;
-        kstride[j] = BK;
+        kofs[j] = sub * BK + 4 * kq;
+        src[j] = base + (int64_t)(r0 + row) * ld + kbeg + kofs[j];
+        kstride[j] = BK * KS;
       } else {
         const int kr = idx / (rows / 4), rq = idx % (rows / 4);
         rowok[j] = r0 + 4 * rq < rmax;
         ones[j] = ONES && !isA && r0 + 4 * rq == rmax;
-        kofs[j] = kr;
-        src[j] = base + (int64_t)(kbeg + kr) * ld + r0 + 4 * rq;
-        kstride[j] = BK * ld;
+        kofs[j] = sub * BK + kr;
+        src[j] = base + (int64_t)(kbeg + kofs[j]) * ld + r0 + 4 * rq;
+        kstride[j] = BK * KS * ld;
       }
     }
   }
   auto issue = [&](int stage, int it) {
-    float* st = smem + stage * TILE;
-    const int k0 = kbeg + it * BK;
+    float* st = smem + stage * (KS * TILE);
+    const int k0 = kbeg + it * (BK * KS);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int d = wave + j * NW;
-      if (d < NP) {
+      if (d < KS * NP) {
         const bool kok = k0 + kofs[j] < kend;
         const float* g = (rowok[j] && kok) ? src[j] + (int64_t)it * kstride[j]
                                            : reinterpret_cast<const float*>((ONES && ones[j] && kok) ? g_ones_page : g_zero_page);
@@ -162,10 +165,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
 
   int npw = 0;  // DMA pieces this wave issues per k-step
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) npw += (wave + j * NW < NP) ? 1 : 0;
+  for (int j = 0; j < NJ; ++j) npw += (wave + j * NW < KS * NP) ? 1 : 0;
 
-  auto load_frags = [&](int stage, f32x4 (&a)[MI], f32x4 (&b)[NI]) {
-    const float* At = smem + stage * TILE;
+  auto load_frags = [&](int stage, int sub, f32x4 (&a)[MI], f32x4 (&b)[NI]) {
+    const float* At = smem + (stage * KS + sub) * TILE;
     const float* Bt = At + BM * BK;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -198,47 +201,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][r], a[i][r], acc[i][j], 0, 0, 0);
   };
 
-  // "touch": an empty asm that reads+writes the fragment registers.  The compiler must make the LDS
-  // reads that produced them complete BEFORE this point (while only those are outstanding), and treats
-  // them as ready afterwards -- so the fragment reads of the NEXT step, issued after the touch, stay in
-  // flight across the MFMA burst instead of being drained by a conservative lgkmcnt(0).
-  auto touch = [&](f32x4 (&a)[MI], f32x4 (&b)[NI]) {
-#pragma unroll
-    for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(a[i]));
-#pragma unroll
-    for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(b[j]));
-  };
-
-  if (STAGES == 3) {
-    // Software-pipelined k-loop: three LDS stages + two register sets of fragments.  While the MFMAs
-    // of step t run, the fragments of step t+1 are already being read from LDS and the DMA of step
-    // t+2 is in flight, so neither the LDS latency nor the DMA issue sits between two MFMA bursts --
-    // which is what an occupancy of 1-2 waves per SIMD (one 256-graph batch) cannot hide otherwise.
-    f32x4 a0[MI], b0[NI], a1[MI], b1[NI];
-    if (nk > 0) issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    gemm_wait_vmcnt(nk > 1 ? npw : 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (nk > 0) load_frags(0, a0, b0);
-    for (int it = 0; it < nk; it += 2) {
-      // ---- even step: compute with (a0,b0), prefetch (a1,b1)
-      touch(a0, b0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA(it+1), issued a full step ago
-      __builtin_amdgcn_s_barrier();
-      if (it + 2 < nk) issue((it + 2) % 3, it + 2);
-      if (it + 1 < nk) load_frags((it + 1) % 3, a1, b1);
-      mfma_step(a0, b0);
-      if (it + 1 >= nk) break;
-      // ---- odd step: compute with (a1,b1), prefetch (a0,b0)
-      touch(a1, b1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (it + 3 < nk) issue((it + 3) % 3, it + 3);
-      if (it + 2 < nk) load_frags((it + 2) % 3, a0, b0);
-      mfma_step(a1, b1);
-    }
-  } else {
+  {
 #pragma unroll
     for (int q = 0; q < STAGES - 1; ++q)
       if (q < nk) issue(q, q);
@@ -248,9 +211,13 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // every wave's pieces of step `it` are in LDS; buffer (it-1)%STAGES is free
       if (it + STAGES - 1 < nk) issue((it + STAGES - 1) % STAGES, it + STAGES - 1);
-      f32x4 a[MI], b[NI];
-      load_frags(stage, a, b);
-      mfma_step(a, b);
+#pragma unroll
+      for (int sub = 0; sub < KS; ++sub) {
+        if (sub > 0 && it * KS + sub >= nk16) break;  // K tail: the last k-step may hold fewer images
+        f32x4 a[MI], b[NI];
+        load_frags(stage, sub, a, b);
+        mfma_step(a, b);
+      }
     }
   }
 
@@ -316,32 +283,31 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, int STAGES>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, int KS>
 int launch_gemm_s(const GemmArgs& p, int nsplit, hipStream_t st) {
-  constexpr size_t lds = (size_t)STAGES * 16 * (BM + BN) * sizeof(float);
+  constexpr size_t lds = (size_t)2 * KS * 16 * (BM + BN) * sizeof(float);
   const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N + (ONES ? 4 : 0), BN));
-  allow_big_lds((const void*)k_gemm<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, STAGES>, lds);
-  hipLaunchKernelGGL((k_gemm<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, STAGES>), dim3(tiles, nsplit),
+  allow_big_lds((const void*)k_gemm<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, KS>, lds);
+  hipLaunchKernelGGL((k_gemm<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, KS>), dim3(tiles, nsplit),
                      dim3(64 * WAVES_M * WAVES_N), lds, st, p);
   return check_launch("gemm");
 }
 
-inline int env_stages(int dflt) {
-  const char* v = getenv("PGNN_GEMM_STAGES");
+constexpr int kDefaultKS = 1;
+inline int env_ks(int dflt) {
+  const char* v = getenv("PGNN_GEMM_KS");
   return v ? atoi(v) : dflt;
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES = false>
 int launch_gemm(const GemmArgs& p, int nsplit, hipStream_t st) {
-  // Measured (tools/gemm_bench.py, tools/gemm_ksweep.py; M = 6747 and 262144): the 2-stage loop is as
-  // fast as the 3-stage software-pipelined one (fragments of step t+1 and the DMA of step t+2 in flight
-  // behind the MFMAs of step t).  Ablation (a diagnostic build that skips one component at a time) shows why: DMA issue, fragment reads and
-  // the barrier each cost ~10 % of the k-step *as issue time*, not latency -- both waves of a SIMD run
-  // them in lockstep in front of their MFMA burst.  Hiding them needs the instructions interleaved
-  // between the MFMAs (hand scheduling), which is the next step; PGNN_GEMM_STAGES=3 keeps the pipelined
-  // build selectable.
-  if (env_stages(2) >= 3) return launch_gemm_s<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, 3>(p, nsplit, st);
-  return launch_gemm_s<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, 2>(p, nsplit, st);
+  // KS = LDS images (16 of k each) per barrier.  History: a 3-stage ring and a software-pipelined loop
+  // (fragments of step t+1 and the DMA of step t+2 in flight behind the MFMAs of step t) measured no
+  // faster than the plain 2-stage loop -- DMA issue, fragment reads and the barrier are *issue-time*
+  // costs that both waves of a SIMD pay in lockstep in front of their MFMA burst -- so the lever is
+  // fewer barriers per FLOP, i.e. a deeper k-step.
+  if (env_ks(kDefaultKS) >= 2) return launch_gemm_s<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, 2>(p, nsplit, st);
+  return launch_gemm_s<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, 1>(p, nsplit, st);
 }
 
 // Tile configurations (all 4 waves, BK = 16).  N = 300 / 600 are 18.75 / 37.5 MFMA blocks wide, so the

@@ -62,6 +62,9 @@ class Data:
 
     @property
     def num_graphs(self):
+        known = self.__dict__.get("_num_graphs")  # set by collates that know it (avoids a device sync)
+        if known is not None:
+            return known
         b = getattr(self, "batch", None)
         return None if b is None else int(b[-1].item()) + 1
 

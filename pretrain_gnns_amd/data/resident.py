@@ -1,0 +1,202 @@
+"""Dataset resident in HBM + device-side collate / MaskAtom.
+
+The reference keeps graphs on the host, runs ``MaskAtom`` per graph in DataLoader workers
+(chem/util.py:225-277, chem/dataloader.py:25-42) and concatenates ~256 small tensors per batch in
+``BatchMasking.from_data_list`` (chem/batch.py:17-52) before the int64 COO batch crosses PCIe.  On an
+MI355X the whole corpus fits next to the model (ZINC-2M is ~4.5 GB of 288 GB), so this module keeps
+it on the GPU in the concatenated ``(data, slices)`` layout ``InMemoryDataset`` already stores
+(chem/loader.py ``MoleculeDataset.processed``: ``data.x``, ``data.edge_index``, ``data.edge_attr``,
+``slices``) and builds every batch with the kernels of csrc/loader.hip from a list of graph ids.
+The host keeps only the two slice vectors (to size outputs without a device sync) and the sampler.
+
+Output batches have the field layout of ``BatchMasking`` / the synthetic collate in this package
+(x, edge_index, edge_attr, batch, masked_atom_indices, mask_node_label, [connected_edge_indices,
+mask_edge_label]), so ``train.chem_masking_step`` consumes them unchanged.
+"""
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import check, load, stream_ptr
+from .batch import Data
+
+ATOM_MASK_TOKEN = 119  # num_atom_type - 1 (chem/pretrain_masking.py:122)
+BOND_MASK_TOKEN = 5    # num_edge_type - 1
+
+
+def mask_counts(nodes_per_graph, mask_rate):
+    """int(n * rate + 1) per graph, evaluated like the reference (Python float = IEEE double)."""
+    n = np.asarray(nodes_per_graph, dtype=np.int64)
+    k = (n.astype(np.float64) * float(mask_rate) + 1.0).astype(np.int64)
+    return np.where(n > 0, np.minimum(k, n), 0)
+
+
+class ResidentDataset:
+    """All graphs of a dataset, concatenated, on one GPU.
+
+    x [sum n, cx] and edge_attr [sum e, ca] keep the dtype they have in the reference's processed
+    files (chem: int64 / int64, bio: float32 / float32); edge_index [2, sum e] int64 holds graph-local
+    node ids; node_slice / edge_slice [G+1] int64 are InMemoryDataset's ``slices['x']`` /
+    ``slices['edge_attr']``.
+    """
+
+    def __init__(self, x, edge_index, edge_attr, node_slice, edge_slice, device="cuda"):
+        node_slice = torch.as_tensor(node_slice, dtype=torch.int64).cpu()
+        edge_slice = torch.as_tensor(edge_slice, dtype=torch.int64).cpu()
+        if node_slice.numel() != edge_slice.numel() or node_slice.numel() < 2:
+            raise ValueError("node_slice and edge_slice must both be [G+1]")
+        if int(node_slice[-1]) != x.size(0) or int(edge_slice[-1]) != edge_index.size(1) or edge_attr.size(0) != edge_index.size(1):
+            raise ValueError("slices do not match the concatenated tensors")
+        if x.dim() != 2 or edge_attr.dim() != 2 or edge_index.dtype != torch.int64:
+            raise ValueError("x / edge_attr must be 2-D, edge_index int64 [2, E]")
+        if (x.element_size() * x.size(1)) % 4 or (edge_attr.element_size() * edge_attr.size(1)) % 4:
+            raise ValueError("feature rows must be multiples of 4 bytes")
+        self.device = torch.device(device)
+        self.x = x.contiguous().to(self.device)
+        self.edge_index = edge_index.contiguous().to(self.device)
+        self.edge_attr = edge_attr.contiguous().to(self.device)
+        self.node_slice = node_slice.to(self.device)
+        self.edge_slice = edge_slice.to(self.device)
+        # host copies: sizes of any batch are known without asking the device
+        self._nodes = np.diff(node_slice.numpy())
+        self._edges = np.diff(edge_slice.numpy())
+        self.num_graphs = int(self._nodes.size)
+
+    def __len__(self):
+        return self.num_graphs
+
+    @classmethod
+    def from_graphs(cls, graphs, device="cuda"):
+        """from a list of per-graph ``Data`` objects (x, edge_index, edge_attr)"""
+        ns = np.cumsum([0] + [g.x.size(0) for g in graphs])
+        es = np.cumsum([0] + [g.edge_index.size(1) for g in graphs])
+        return cls(torch.cat([g.x for g in graphs], 0), torch.cat([g.edge_index for g in graphs], 1),
+                   torch.cat([g.edge_attr for g in graphs], 0), ns, es, device)
+
+    @classmethod
+    def from_inmemory(cls, data, slices, device="cuda"):
+        """from the ``(data, slices)`` pair of a torch_geometric InMemoryDataset processed file
+        (what ``torch.load(processed_paths[0])`` returns in chem/loader.py / bio/loader.py)"""
+        return cls(data.x, data.edge_index, data.edge_attr, slices["x"], slices["edge_attr"], device)
+
+    # ------------------------------------------------------------------ batching
+    def _ids(self, graph_ids):
+        ids_host = np.asarray(graph_ids, dtype=np.int64).reshape(-1)
+        if ids_host.size == 0:
+            raise ValueError("empty batch")
+        if ids_host.min() < 0 or ids_host.max() >= self.num_graphs:
+            raise IndexError("graph id out of range")
+        return ids_host, torch.from_numpy(ids_host).to(self.device, non_blocking=True)
+
+    def collate(self, graph_ids, mask_rate=0.0, seed=0, mask_edge=False, masked_atom_indices=None):
+        """BatchMasking.from_data_list over ``graph_ids`` (+ MaskAtom when ``mask_rate`` > 0 or explicit
+        ``masked_atom_indices`` -- batch node positions, the reference's debugging hook -- are given)."""
+        lib, sp, dev = load(), stream_ptr(), self.device
+        ids_host, ids = self._ids(graph_ids)
+        b = ids_host.size
+        n, e = int(self._nodes[ids_host].sum()), int(self._edges[ids_host].sum())
+        explicit = masked_atom_indices is not None
+        rate = 0.0 if explicit else float(mask_rate)
+        m = int(mask_counts(self._nodes[ids_host], rate).sum()) if rate > 0 else 0
+        offs = torch.empty(3, b + 1, dtype=torch.int64, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        check(lib.pgnn_batch_offsets(ids.data_ptr(), b, self.num_graphs, self.node_slice.data_ptr(),
+                                     self.edge_slice.data_ptr(), rate, offs[0].data_ptr(), offs[1].data_ptr(),
+                                     offs[2].data_ptr(), n, e, m, status.data_ptr(), sp), "pgnn_batch_offsets")
+        out = Data()
+        out.x = torch.empty(n, self.x.size(1), dtype=self.x.dtype, device=dev)
+        out.edge_index = torch.empty(2, e, dtype=torch.int64, device=dev)
+        out.edge_attr = torch.empty(e, self.edge_attr.size(1), dtype=self.edge_attr.dtype, device=dev)
+        out.batch = torch.empty(n, dtype=torch.int64, device=dev)
+        check(lib.pgnn_collate_graphs(ids.data_ptr(), b, self.num_graphs, self.node_slice.data_ptr(),
+                                      self.edge_slice.data_ptr(), offs[0].data_ptr(), offs[1].data_ptr(),
+                                      self.x.data_ptr(), self.x.element_size() * self.x.size(1),
+                                      self.edge_index.data_ptr(), self.edge_index.size(1), self.edge_attr.data_ptr(),
+                                      self.edge_attr.element_size() * self.edge_attr.size(1), n, e, out.x.data_ptr(),
+                                      out.edge_index.data_ptr(), out.edge_attr.data_ptr(), out.batch.data_ptr(), sp),
+              "pgnn_collate_graphs")
+        out._num_graphs = b
+        out._status, out._node_off = status, offs[0]
+        if rate > 0 or explicit:
+            if self.x.dtype != torch.int64:
+                raise _lib.PgnnError("MaskAtom needs integer atom features (chem datasets)")
+            if explicit:
+                idx = torch.as_tensor(masked_atom_indices, dtype=torch.int64).to(dev).contiguous()
+                m = idx.numel()
+            else:
+                idx = torch.empty(m, dtype=torch.int64, device=dev)
+                check(lib.pgnn_mask_atoms_select(ids.data_ptr(), b, offs[0].data_ptr(), offs[2].data_ptr(), n,
+                                                 int(seed) & 0xFFFFFFFFFFFFFFFF, idx.data_ptr(), sp),
+                      "pgnn_mask_atoms_select")
+            out.masked_atom_indices = idx
+            out.mask_node_label = torch.empty(m, self.x.size(1), dtype=torch.int64, device=dev)
+            check(lib.pgnn_mask_atoms_apply(idx.data_ptr(), m, out.x.data_ptr(), self.x.size(1), n, ATOM_MASK_TOKEN,
+                                            out.mask_node_label.data_ptr(), status.data_ptr(), sp),
+                  "pgnn_mask_atoms_apply")
+            if mask_edge:
+                _mask_connected_edges(out)
+        return out
+
+    def check(self, batch):
+        """raise if any kernel of ``collate`` flagged an inconsistency (one device sync)"""
+        bits = int(batch._status.item())
+        if bits:
+            raise RuntimeError("device collate status 0x%x (1: graph id range, 2: size mismatch, 4: masked index range)" % bits)
+
+
+def _mask_connected_edges(batch):
+    """bond masking of MaskAtom (chem/util.py:246-273): bonds touching a masked atom, one direction of
+    each adjacent pair as label carrier, both directions overwritten with [5, 0].  The number of such
+    bonds is data dependent, so this (optional, off in the reference's defaults) part is plain torch on
+    the device and costs one sync in ``nonzero``."""
+    n = batch.x.size(0)
+    flag = torch.zeros(n, dtype=torch.bool, device=batch.x.device)
+    flag[batch.masked_atom_indices] = True
+    hit = flag[batch.edge_index[0]] | flag[batch.edge_index[1]]
+    connected = hit.nonzero().view(-1)
+    first = connected[::2]
+    batch.mask_edge_label = batch.edge_attr[first].clone()
+    batch.edge_attr[connected] = torch.tensor([BOND_MASK_TOKEN, 0], dtype=batch.edge_attr.dtype, device=batch.x.device)
+    batch.connected_edge_indices = first
+
+
+class ResidentLoader:
+    """Epoch iterator over a ResidentDataset: the host draws the permutation (seeded, identical on
+    every rank), each rank takes its contiguous share of every global batch (``parallel.shard_graphs``
+    semantics), the device builds the batch.  ``drop_last`` as torch's DataLoader."""
+
+    def __init__(self, dataset, batch_size, shuffle=True, seed=0, mask_rate=0.0, mask_edge=False, rank=0,
+                 world_size=1, drop_last=False):
+        self.ds, self.batch_size, self.shuffle, self.seed = dataset, int(batch_size), shuffle, int(seed)
+        self.mask_rate, self.mask_edge, self.rank, self.world = float(mask_rate), bool(mask_edge), int(rank), int(world_size)
+        self.drop_last = drop_last
+        self.epoch = 0
+
+    def __len__(self):
+        n = len(self.ds) // self.batch_size
+        return n if self.drop_last or len(self.ds) % self.batch_size == 0 else n + 1
+
+    def batch_ids(self, epoch=None):
+        """list of this rank's graph-id arrays for one epoch"""
+        epoch = self.epoch if epoch is None else epoch
+        order = np.arange(len(self.ds), dtype=np.int64)
+        if self.shuffle:
+            np.random.default_rng([self.seed, epoch]).shuffle(order)
+        out = []
+        for s in range(0, len(order), self.batch_size):
+            glob = order[s:s + self.batch_size]
+            if glob.size < self.batch_size and self.drop_last:
+                break
+            base, rem = divmod(glob.size, self.world)
+            lo = self.rank * base + min(self.rank, rem)
+            hi = lo + base + (1 if self.rank < rem else 0)
+            if hi > lo:
+                out.append(glob[lo:hi])
+        return out
+
+    def __iter__(self):
+        epoch = self.epoch
+        self.epoch += 1
+        for step, ids in enumerate(self.batch_ids(epoch)):
+            yield self.ds.collate(ids, mask_rate=self.mask_rate, seed=(self.seed * 1000003 + epoch) * 1000003 + step,
+                                  mask_edge=self.mask_edge)

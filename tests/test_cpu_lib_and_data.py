@@ -168,3 +168,31 @@ def test_tile_batch_offsets():
     assert torch.equal(t.masked_atom_indices[b.masked_atom_indices.numel():2 * b.masked_atom_indices.numel()],
                        b.masked_atom_indices + n)
     assert int(t.batch[-1]) == 23
+
+
+def test_resident_loader_sharding_and_mask_counts():
+    """host-side logic of the device loader: every global batch is split over ranks without loss or
+    overlap, the permutation is identical on every rank, and the masked-atom count is the reference's
+    int(n * rate + 1) (chem/util.py:232)."""
+    import numpy as np
+    from pretrain_gnns_amd.data import resident
+
+    class FakeDataset:
+        def __len__(self):
+            return 103
+
+    per_rank = [resident.ResidentLoader(FakeDataset(), 16, shuffle=True, seed=5, rank=r, world_size=3).batch_ids(epoch=2)
+                for r in range(3)]
+    single = resident.ResidentLoader(FakeDataset(), 16, shuffle=True, seed=5).batch_ids(epoch=2)
+    assert len(single) == 7 and sorted(np.concatenate(single).tolist()) == list(range(103))
+    for step, glob in enumerate(single):
+        parts = [per_rank[r][step] for r in range(3)]
+        assert np.array_equal(np.concatenate(parts), glob)
+        sizes = [p.size for p in parts]
+        assert max(sizes) - min(sizes) <= 1
+    other_epoch = resident.ResidentLoader(FakeDataset(), 16, shuffle=True, seed=5).batch_ids(epoch=3)
+    assert not np.array_equal(np.concatenate(other_epoch), np.concatenate(single))
+    dropped = resident.ResidentLoader(FakeDataset(), 16, shuffle=False, drop_last=True)
+    assert len(dropped) == 6 and len(dropped.batch_ids()) == 6
+    ns = [1, 6, 7, 13, 14, 20, 26, 27, 60, 1000]
+    assert resident.mask_counts(ns, 0.15).tolist() == [int(n * 0.15 + 1) for n in ns]

@@ -1,0 +1,191 @@
+"""Device-side collate / MaskAtom over an HBM-resident dataset (csrc/loader.hip, data/resident.py)
+against the host collate that restates BatchMasking.from_data_list (chem/batch.py:17-52) and MaskAtom
+(chem/util.py:225-277).  Integer / byte work: every comparison is bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from pretrain_gnns_amd.data import Data, resident, synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _chem_graphs(count, seed=0):
+    rng = np.random.default_rng(seed)
+    return [synthetic.zinc_like_graph(rng) for _ in range(count)]
+
+
+def _same(batch, want, keys=("x", "edge_index", "edge_attr", "batch")):
+    for k in keys:
+        got, ref = getattr(batch, k).cpu(), getattr(want, k)
+        assert got.dtype == ref.dtype and got.shape == ref.shape, k
+        assert torch.equal(got, ref), k
+
+
+@pytest.mark.parametrize("batch_size", [1, 7, 64, 2500])
+def test_collate_matches_host_collate_chem(batch_size):
+    graphs = _chem_graphs(50, seed=1)
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    ids = np.random.default_rng(batch_size).integers(0, len(graphs), size=batch_size)  # with repeats; > 1024 ids = scan carry
+    out = ds.collate(ids)
+    ds.check(out)
+    _same(out, synthetic.collate([graphs[i] for i in ids]))
+    assert out.num_graphs == batch_size
+
+
+def test_collate_matches_host_collate_bio():
+    rng = np.random.default_rng(2)
+    graphs = [synthetic.ppi_like_graph(rng) for _ in range(12)]
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    ids = [3, 3, 0, 11, 7]
+    out = ds.collate(ids)
+    ds.check(out)
+    _same(out, synthetic.collate([graphs[i] for i in ids]))
+
+
+def test_collate_ragged_and_empty_graphs():
+    """a single-atom molecule (no bonds), a two-atom one, and regular ones, in every position"""
+    lone = Data(x=torch.tensor([[5, 0]]), edge_index=torch.zeros(2, 0, dtype=torch.int64),
+                edge_attr=torch.zeros(0, 2, dtype=torch.int64))
+    pair = Data(x=torch.tensor([[6, 0], [7, 1]]), edge_index=torch.tensor([[0, 1], [1, 0]]),
+                edge_attr=torch.tensor([[1, 0], [1, 0]]))
+    graphs = [lone, pair] + _chem_graphs(3, seed=3)
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    for ids in ([0], [0, 0, 0], [0, 1, 2], [2, 0, 3, 0, 1], [1, 0]):
+        out = ds.collate(ids)
+        ds.check(out)
+        _same(out, synthetic.collate([graphs[i] for i in ids]))
+
+
+def test_bad_graph_ids_are_refused():
+    ds = resident.ResidentDataset.from_graphs(_chem_graphs(4), DEV)
+    with pytest.raises(IndexError):
+        ds.collate([0, 4])
+    with pytest.raises(ValueError):
+        ds.collate([])
+
+
+def test_mask_atoms_properties_and_determinism():
+    graphs = _chem_graphs(40, seed=4)
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    ids = np.arange(40)[::-1].copy()
+    plain = ds.collate(ids)
+    a = ds.collate(ids, mask_rate=0.15, seed=11)
+    b = ds.collate(ids, mask_rate=0.15, seed=11)
+    c = ds.collate(ids, mask_rate=0.15, seed=12)
+    ds.check(a)
+    assert torch.equal(a.masked_atom_indices, b.masked_atom_indices) and torch.equal(a.x, b.x)
+    assert not torch.equal(a.masked_atom_indices, c.masked_atom_indices)
+    idx = a.masked_atom_indices.cpu()
+    sizes = [graphs[i].x.size(0) for i in ids]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    pos = 0
+    for g, n in enumerate(sizes):
+        k = int(n * 0.15 + 1)  # chem/util.py:232
+        mine = idx[pos:pos + k]
+        pos += k
+        assert len(set(mine.tolist())) == k  # distinct
+        assert int(mine.min()) >= off[g] and int(mine.max()) < off[g + 1]  # inside its own graph
+    assert pos == idx.numel()
+    # labels are the original rows, masked rows carry the mask token, every other row is untouched
+    assert torch.equal(a.mask_node_label.cpu(), plain.x.cpu()[idx])
+    x = a.x.cpu()
+    assert torch.equal(x[idx], torch.tensor([[119, 0]]).repeat(idx.numel(), 1))
+    keep = torch.ones(x.size(0), dtype=torch.bool)
+    keep[idx] = False
+    assert torch.equal(x[keep], plain.x.cpu()[keep])
+    # the draw belongs to the graph, not to its position in the batch
+    d = ds.collate(ids[::-1].copy(), mask_rate=0.15, seed=11)
+    first_graph = int(ids[0])
+    k0 = int(sizes[0] * 0.15 + 1)
+    local_a = (a.masked_atom_indices[:k0] - 0).cpu()
+    n_before = sum(graphs[i].x.size(0) for i in ids[::-1][:-1])
+    local_d = (d.masked_atom_indices[-k0:] - n_before).cpu()
+    assert torch.equal(local_a, local_d), first_graph
+
+
+def test_mask_atoms_is_uniform():
+    """every atom of a 20-atom graph is picked with frequency k/n = 4/20 over many seeds"""
+    g = Data(x=torch.tensor([[5, 0]] * 20), edge_index=torch.zeros(2, 0, dtype=torch.int64),
+             edge_attr=torch.zeros(0, 2, dtype=torch.int64))
+    ds = resident.ResidentDataset.from_graphs([g], DEV)
+    counts = torch.zeros(20)
+    trials = 600
+    for seed in range(trials):
+        counts[ds.collate([0], mask_rate=0.15, seed=seed).masked_atom_indices.cpu()] += 1
+    freq = counts / trials
+    assert float(counts.sum()) == trials * 4
+    assert float(freq.min()) > 0.13 and float(freq.max()) < 0.27, freq  # 0.2 +- 4 sigma (sigma = 0.016)
+
+
+@pytest.mark.parametrize("mask_edge", [False, True])
+def test_explicit_indices_match_host_maskatom(mask_edge):
+    """MaskAtom's debugging hook (masked_atom_indices given): the device result equals the host
+    restatement applied per graph, then collated -- node labels, masked rows, bond labels, bond rows."""
+    graphs = _chem_graphs(16, seed=5)
+    rng = np.random.default_rng(6)
+    masked, picks = [], []
+    off = 0
+    for g in graphs:
+        n = g.x.size(0)
+        idx = rng.choice(n, int(n * 0.15 + 1), replace=False).astype(np.int64)
+        d = g.clone()
+        d.mask_node_label = d.x[idx].clone()
+        d.masked_atom_indices = torch.from_numpy(idx)
+        d.x[idx] = torch.tensor([119, 0])
+        if mask_edge:
+            ei = d.edge_index.numpy()
+            connected = np.nonzero(np.isin(ei[0], idx) | np.isin(ei[1], idx))[0]
+            first = connected[::2]
+            d.mask_edge_label = d.edge_attr[first].clone()
+            d.edge_attr[connected] = torch.tensor([5, 0])
+            d.connected_edge_indices = torch.from_numpy(first.astype(np.int64))
+        masked.append(d)
+        picks.append(idx + off)
+        off += n
+    want = synthetic.collate(masked)
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    out = ds.collate(np.arange(16), masked_atom_indices=np.concatenate(picks), mask_edge=mask_edge)
+    ds.check(out)
+    keys = ["x", "edge_index", "edge_attr", "batch", "masked_atom_indices", "mask_node_label"]
+    if mask_edge:
+        keys += ["connected_edge_indices", "mask_edge_label"]
+    _same(out, want, keys)
+
+
+def test_resident_batch_drives_the_train_step_identically():
+    """same graphs + same masked atoms => the train step sees bit-identical inputs => identical loss"""
+    from pretrain_gnns_amd import train
+    from pretrain_gnns_amd.chem import model as hmodel
+    host = synthetic.chem_masking_batch(32, seed=9)
+    rng = np.random.default_rng(9)  # chem_masking_batch draws graph, mask, graph, mask, ... from this stream
+    graphs = []
+    for _ in range(32):
+        g = synthetic.zinc_like_graph(rng)
+        synthetic.mask_atoms(g, rng)
+        graphs.append(g)
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    dev_batch = ds.collate(np.arange(32), masked_atom_indices=host.masked_atom_indices)
+    _same(dev_batch, host, ("x", "edge_index", "edge_attr", "batch", "masked_atom_indices", "mask_node_label"))
+    losses = []
+    for batch in (host.to(DEV), dev_batch):
+        torch.manual_seed(0)
+        mods = [hmodel.GNN(5, 300).to(DEV), torch.nn.Linear(300, 119).to(DEV), torch.nn.Linear(300, 4).to(DEV)]
+        opts = [torch.optim.Adam(m.parameters(), lr=1e-3) for m in mods]
+        losses.append([train.chem_masking_step(mods, opts, batch)[0] for _ in range(2)])
+    assert losses[0] == losses[1]
+
+
+def test_loader_epoch_covers_dataset_once():
+    graphs = _chem_graphs(37, seed=7)
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    loader = resident.ResidentLoader(ds, batch_size=8, shuffle=True, seed=3, mask_rate=0.15)
+    seen_nodes, batches = 0, 0
+    for batch in loader:
+        ds.check(batch)
+        seen_nodes += batch.x.size(0)
+        batches += 1
+        assert batch.masked_atom_indices.numel() == batch.mask_node_label.size(0) > 0
+    assert batches == len(loader) == 5
+    assert seen_nodes == sum(g.x.size(0) for g in graphs)
