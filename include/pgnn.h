@@ -242,15 +242,16 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
  * the concatenated (data, slices) form InMemoryDataset stores (chem/loader.py MoleculeDataset,
  * bio/loader.py BioDataset): x_all [sum n, *], edge_index_all [2, sum e] with graph-local node ids,
  * edge_attr_all [sum e, *], node_slice / edge_slice [G+1].  Replaces, for a list of graph ids,
- * BatchMasking.from_data_list (chem/batch.py:17-52; bio/batch.py:70-106) and MaskAtom
- * (chem/util.py:225-244).  All sizes are known to the host from its copy of the slices, so no call
+ * BatchMasking.from_data_list (chem/batch.py:17-52; bio/batch.py:70-106), MaskAtom
+ * (chem/util.py:225-244) and bio MaskEdge (bio/util.py:77-102).  All sizes are known to the host from its copy of the slices, so no call
  * synchronises; `status` collects bit 0 = graph id out of range, bit 1 = totals differ from the
  * caller's, bit 2 = masked index out of range.
  * ------------------------------------------------------------------------------------------ */
 /* node_off / edge_off / mask_off [num_graphs+1]: exclusive sums of the batch's per-graph node, edge and
- * masked-atom counts; masked atoms per graph = int(n * mask_rate + 1) (chem/util.py:232), 0 if rate == 0 */
+ * masked-item counts.  mask_unit 0: none; 1: atoms, int(n * mask_rate + 1) per graph (chem/util.py:232);
+ * 2: undirected edges, int(e/2 * mask_rate + 1) per graph (bio/util.py:79-80) */
 int pgnn_batch_offsets(const int64_t* graph_ids, int64_t num_graphs, int64_t dataset_graphs,
-                       const int64_t* node_slice, const int64_t* edge_slice, double mask_rate,
+                       const int64_t* node_slice, const int64_t* edge_slice, double mask_rate, int mask_unit,
                        int64_t* node_off, int64_t* edge_off, int64_t* mask_off, int64_t expect_nodes,
                        int64_t expect_edges, int64_t expect_masked, int32_t* status, pgnn_stream stream);
 /* x [N, x_row_bytes], edge_index [2, E] = local ids + the graph's node offset (batch.py:38-39),
@@ -261,15 +262,23 @@ int pgnn_collate_graphs(const int64_t* graph_ids, int64_t num_graphs, int64_t da
                         const int64_t* edge_index_all, int64_t edges_all, const void* edge_attr_all,
                         int64_t attr_row_bytes, int64_t num_nodes, int64_t num_edges, void* x,
                         int64_t* edge_index, void* edge_attr, int64_t* batch, pgnn_stream stream);
-/* masked_atom_indices [M]: per graph, int(n*rate+1) distinct atoms drawn uniformly (counter-based keys
- * from (seed, graph id, atom): the same graph gets the same draw wherever it sits in a batch), as batch
- * node positions (batch.py:39-40) */
-int pgnn_mask_atoms_select(const int64_t* graph_ids, int64_t num_graphs, const int64_t* node_off,
-                           const int64_t* mask_off, int64_t num_nodes, uint64_t seed,
-                           int64_t* masked_atom_indices, pgnn_stream stream);
+/* masked_indices [M]: per graph, its share of distinct items drawn uniformly (counter-based keys from
+ * (seed, graph id, item): the same graph gets the same draw wherever it sits in a batch).
+ * unit_div 1: items = atoms, unit_off = node_off, output = batch node positions (batch.py:39-40);
+ * unit_div 2: items = undirected edges, unit_off = edge_off, output = batch index of the pair's first
+ * direction (bio/util.py:82-83, bio/batch.py masked_edge_idx + edge cumsum). */
+int pgnn_mask_select(const int64_t* graph_ids, int64_t num_graphs, const int64_t* unit_off, int unit_div,
+                     const int64_t* mask_off, int64_t num_units, uint64_t seed, int64_t* masked_indices,
+                     pgnn_stream stream);
 /* mask_node_label[i] = x[idx_i] ; x[idx_i] = [mask_token, 0, ...]   (chem/util.py:236-244) */
 int pgnn_mask_atoms_apply(const int64_t* masked_atom_indices, int64_t num_masked, int64_t* x, int64_t x_cols,
                           int64_t num_nodes, int64_t mask_token, int64_t* mask_node_label, int32_t* status,
+                          pgnn_stream stream);
+
+/* mask_edge_label[i] = edge_attr[idx_i] ; edge_attr[idx_i] = edge_attr[idx_i + 1] = [0,...,0,1]
+ * (bio/util.py:85-102) */
+int pgnn_mask_edges_apply(const int64_t* masked_edge_idx, int64_t num_masked, float* edge_attr,
+                          int64_t attr_cols, int64_t num_edges, float* mask_edge_label, int32_t* status,
                           pgnn_stream stream);
 
 /* diagnostics: plain float4 grid-stride copy (the HBM streaming ceiling bench.py quotes next to the

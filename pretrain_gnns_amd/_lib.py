@@ -55,10 +55,11 @@ PROTOTYPES = {
                                      _p, _sz, _p]),
     "pgnn_chem_gin_stack_bwd": (_i, [_p, _i64, _p, _i64, _i64, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _i64, _i64,
                                      _p, _sz, _p]),
-    "pgnn_batch_offsets": (_i, [_p, _i64, _i64, _p, _p, ctypes.c_double, _p, _p, _p, _i64, _i64, _i64, _p, _p]),
+    "pgnn_batch_offsets": (_i, [_p, _i64, _i64, _p, _p, ctypes.c_double, _i, _p, _p, _p, _i64, _i64, _i64, _p, _p]),
     "pgnn_collate_graphs": (_i, [_p, _i64, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _p,
                                  _p, _p]),
-    "pgnn_mask_atoms_select": (_i, [_p, _i64, _p, _p, _i64, ctypes.c_uint64, _p, _p]),
+    "pgnn_mask_select": (_i, [_p, _i64, _p, _i, _p, _i64, ctypes.c_uint64, _p, _p]),
+    "pgnn_mask_edges_apply": (_i, [_p, _i64, _p, _i64, _i64, _p, _p, _p]),
     "pgnn_mask_atoms_apply": (_i, [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _p]),
     "pgnn_debug_stream_copy": (_i, [_p, _p, _i64, _i64, _p]),
 }

@@ -38,7 +38,7 @@ __device__ __forceinline__ int64_t mask_count(int64_t n, double rate) {
 __global__ void __launch_bounds__(1024) k_batch_offsets(const int64_t* __restrict__ ids, int64_t B, int64_t G,
                                                         const int64_t* __restrict__ node_slice,
                                                         const int64_t* __restrict__ edge_slice, double rate,
-                                                        int64_t* __restrict__ node_off, int64_t* __restrict__ edge_off,
+                                                        int unit, int64_t* __restrict__ node_off, int64_t* __restrict__ edge_off,
                                                         int64_t* __restrict__ mask_off, int64_t want_n, int64_t want_e,
                                                         int64_t want_m, int32_t* __restrict__ status) {
   __shared__ int64_t sh[3][1024];
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(1024) k_batch_offsets(const int64_t* __restric
       }
       v[0] = node_slice[g + 1] - node_slice[g];
       v[1] = edge_slice[g + 1] - edge_slice[g];
-      v[2] = rate > 0.0 ? mask_count(v[0], rate) : 0;
+      v[2] = unit == 1 ? mask_count(v[0], rate) : unit == 2 ? mask_count(v[1] / 2, rate) : 0;
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) sh[c][t] = v[c];
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(1024) k_batch_offsets(const int64_t* __restric
     node_off[B] = carry[0];
     edge_off[B] = carry[1];
     mask_off[B] = carry[2];
-    if (carry[0] != want_n || carry[1] != want_e || (rate > 0.0 && carry[2] != want_m)) atomicOr(status, 2);
+    if (carry[0] != want_n || carry[1] != want_e || (unit != 0 && carry[2] != want_m)) atomicOr(status, 2);
   }
 }
 
@@ -136,18 +136,21 @@ __global__ void __launch_bounds__(kBlock) k_gather_edges(const int64_t* __restri
   }
 }
 
-// MaskAtom selection: atom (graph g, local a) is masked iff fewer than k_g atoms of its graph have a
-// smaller (key, local) pair; its position among the graph's masked atoms is that rank, so the k_g
-// indices come out in random-key order (random.sample order is random too, chem/util.py:233).
+// MaskAtom / MaskEdge selection.  Items are atoms (div = 1, unit_off = node offsets) or undirected
+// edges (div = 2, unit_off = directed-edge offsets; the reference stores both directions adjacently and
+// samples pairs, bio/util.py:77-83).  Item (graph g, local a) is masked iff fewer than k_g items of its
+// graph have a smaller (key, local) pair; its position among the graph's masked items is that rank, so
+// the k_g indices come out in random-key order (random.sample order is random too, chem/util.py:233).
+// Output = batch position of the atom, or of the FIRST direction of the edge pair.
 __global__ void __launch_bounds__(kBlock) k_mask_select(const int64_t* __restrict__ ids, int64_t B,
-                                                        const int64_t* __restrict__ node_off,
+                                                        const int64_t* __restrict__ unit_off, int div,
                                                         const int64_t* __restrict__ mask_off, uint64_t seed,
                                                         int64_t* __restrict__ masked_idx) {
-  const int64_t n = node_off[B];
+  const int64_t n = unit_off[B] / div;
   for (int64_t p = blockIdx.x * (int64_t)kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
-    const int64_t g = find_graph(node_off, B, p);
-    const int64_t n_g = node_off[g + 1] - node_off[g], k_g = mask_off[g + 1] - mask_off[g];
-    const int64_t a = p - node_off[g];
+    const int64_t g = find_graph(unit_off, B, p * div);
+    const int64_t n_g = (unit_off[g + 1] - unit_off[g]) / div, k_g = mask_off[g + 1] - mask_off[g];
+    const int64_t a = p - unit_off[g] / div;
     const uint64_t stream = graph_stream(seed, ids[g]);
     const uint64_t mine = atom_key(stream, a);
     int64_t rank = 0;
@@ -155,7 +158,28 @@ __global__ void __launch_bounds__(kBlock) k_mask_select(const int64_t* __restric
       const uint64_t other = atom_key(stream, o);
       rank += (other < mine || (other == mine && o < a)) ? 1 : 0;
     }
-    if (rank < k_g) masked_idx[mask_off[g] + rank] = p;
+    if (rank < k_g) masked_idx[mask_off[g] + rank] = p * div;
+  }
+}
+
+// bio MaskEdge (bio/util.py:85-102): label := attr row of the first direction; both directions :=
+// [0,0,0,0,0,0,0,0,1] (generally: zeros with a one in the last column).  Pairs are distinct.
+__global__ void __launch_bounds__(kBlock) k_mask_edges_apply(const int64_t* __restrict__ masked_idx, int64_t m,
+                                                             float* __restrict__ attr, int cols, int64_t e,
+                                                             float* __restrict__ label, int32_t* __restrict__ status) {
+  for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t q = masked_idx[i];
+    if (q < 0 || q + 1 >= e || (q & 1)) {
+      atomicOr(status, 4);
+      for (int c = 0; c < cols; ++c) label[i * cols + c] = 0.f;
+      continue;
+    }
+    for (int c = 0; c < cols; ++c) {
+      label[i * cols + c] = attr[q * cols + c];
+      const float v = c == cols - 1 ? 1.f : 0.f;
+      attr[q * cols + c] = v;
+      attr[(q + 1) * cols + c] = v;
+    }
   }
 }
 
@@ -185,12 +209,14 @@ inline int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64
 extern "C" {
 
 int pgnn_batch_offsets(const int64_t* graph_ids, int64_t num_graphs, int64_t dataset_graphs, const int64_t* node_slice,
-                       const int64_t* edge_slice, double mask_rate, int64_t* node_off, int64_t* edge_off,
+                       const int64_t* edge_slice, double mask_rate, int mask_unit, int64_t* node_off, int64_t* edge_off,
                        int64_t* mask_off, int64_t expect_nodes, int64_t expect_edges, int64_t expect_masked,
                        int32_t* status, pgnn_stream stream) {
-  PGNN_REQUIRE(num_graphs > 0 && dataset_graphs > 0 && mask_rate >= 0.0 && mask_rate <= 1.0, "bad batch_offsets arguments");
+  PGNN_REQUIRE(num_graphs > 0 && dataset_graphs > 0 && mask_rate >= 0.0 && mask_rate <= 1.0 && mask_unit >= 0 &&
+                   mask_unit <= 2,
+               "bad batch_offsets arguments");
   hipLaunchKernelGGL(k_batch_offsets, dim3(1), dim3(1024), 0, (hipStream_t)stream, graph_ids, num_graphs, dataset_graphs,
-                     node_slice, edge_slice, mask_rate, node_off, edge_off, mask_off, expect_nodes, expect_edges,
+                     node_slice, edge_slice, mask_rate, mask_unit, node_off, edge_off, mask_off, expect_nodes, expect_edges,
                      expect_masked, status);
   return check_launch("batch_offsets");
 }
@@ -214,12 +240,24 @@ int pgnn_collate_graphs(const int64_t* graph_ids, int64_t num_graphs, int64_t da
   return check_launch("collate_graphs");
 }
 
-int pgnn_mask_atoms_select(const int64_t* graph_ids, int64_t num_graphs, const int64_t* node_off, const int64_t* mask_off,
-                           int64_t num_nodes, uint64_t seed, int64_t* masked_atom_indices, pgnn_stream stream) {
-  PGNN_REQUIRE(num_graphs > 0 && num_nodes > 0, "bad mask_atoms_select arguments");
-  hipLaunchKernelGGL(k_mask_select, dim3(grid_for(num_nodes)), dim3(kBlock), 0, (hipStream_t)stream, graph_ids, num_graphs,
-                     node_off, mask_off, seed, masked_atom_indices);
-  return check_launch("mask_atoms_select");
+int pgnn_mask_select(const int64_t* graph_ids, int64_t num_graphs, const int64_t* unit_off, int unit_div,
+                     const int64_t* mask_off, int64_t num_units, uint64_t seed, int64_t* masked_indices,
+                     pgnn_stream stream) {
+  PGNN_REQUIRE(num_graphs > 0 && num_units >= 0 && (unit_div == 1 || unit_div == 2) && num_units % unit_div == 0,
+               "bad mask_select arguments");
+  if (num_units == 0) return PGNN_OK;
+  hipLaunchKernelGGL(k_mask_select, dim3(grid_for(num_units / unit_div)), dim3(kBlock), 0, (hipStream_t)stream, graph_ids,
+                     num_graphs, unit_off, unit_div, mask_off, seed, masked_indices);
+  return check_launch("mask_select");
+}
+
+int pgnn_mask_edges_apply(const int64_t* masked_edge_idx, int64_t num_masked, float* edge_attr, int64_t attr_cols,
+                          int64_t num_edges, float* mask_edge_label, int32_t* status, pgnn_stream stream) {
+  PGNN_REQUIRE(num_masked >= 0 && attr_cols > 0 && num_edges >= 0, "bad mask_edges_apply arguments");
+  if (num_masked == 0) return PGNN_OK;
+  hipLaunchKernelGGL(k_mask_edges_apply, dim3(grid_for(num_masked)), dim3(kBlock), 0, (hipStream_t)stream, masked_edge_idx,
+                     num_masked, edge_attr, (int)attr_cols, num_edges, mask_edge_label, status);
+  return check_launch("mask_edges_apply");
 }
 
 int pgnn_mask_atoms_apply(const int64_t* masked_atom_indices, int64_t num_masked, int64_t* x, int64_t x_cols,

@@ -11,7 +11,8 @@ The host keeps only the two slice vectors (to size outputs without a device sync
 
 Output batches have the field layout of ``BatchMasking`` / the synthetic collate in this package
 (x, edge_index, edge_attr, batch, masked_atom_indices, mask_node_label, [connected_edge_indices,
-mask_edge_label]), so ``train.chem_masking_step`` consumes them unchanged.
+mask_edge_label]; bio: masked_edge_idx, mask_edge_label), so ``train.chem_masking_step`` /
+``train.bio_masking_step`` consume them unchanged.
 """
 import numpy as np
 import torch
@@ -88,20 +89,35 @@ class ResidentDataset:
             raise IndexError("graph id out of range")
         return ids_host, torch.from_numpy(ids_host).to(self.device, non_blocking=True)
 
-    def collate(self, graph_ids, mask_rate=0.0, seed=0, mask_edge=False, masked_atom_indices=None):
-        """BatchMasking.from_data_list over ``graph_ids`` (+ MaskAtom when ``mask_rate`` > 0 or explicit
-        ``masked_atom_indices`` -- batch node positions, the reference's debugging hook -- are given)."""
+    def collate(self, graph_ids, mask_rate=0.0, seed=0, mask_edge=False, masked_atom_indices=None,
+                masked_edge_idx=None, mask_target=None):
+        """BatchMasking.from_data_list over ``graph_ids``, plus the masking transform when ``mask_rate`` > 0:
+        ``mask_target`` "atom" = chem MaskAtom (default for integer node features; ``mask_edge`` adds its
+        bond masking), "edge" = bio MaskEdge (default for float features).  Explicit
+        ``masked_atom_indices`` / ``masked_edge_idx`` (batch positions; the reference's debugging hook)
+        replace the random draw."""
         lib, sp, dev = load(), stream_ptr(), self.device
         ids_host, ids = self._ids(graph_ids)
         b = ids_host.size
         n, e = int(self._nodes[ids_host].sum()), int(self._edges[ids_host].sum())
-        explicit = masked_atom_indices is not None
-        rate = 0.0 if explicit else float(mask_rate)
-        m = int(mask_counts(self._nodes[ids_host], rate).sum()) if rate > 0 else 0
+        if mask_target is None:
+            mask_target = "atom" if self.x.dtype == torch.int64 else "edge"
+        if mask_target not in ("atom", "edge"):
+            raise ValueError("mask_target must be 'atom' or 'edge'")
+        explicit = masked_atom_indices if mask_target == "atom" else masked_edge_idx
+        rate = 0.0 if explicit is not None else float(mask_rate)
+        unit = 0 if rate <= 0 else (1 if mask_target == "atom" else 2)
+        m = 0
+        if unit == 1:
+            m = int(mask_counts(self._nodes[ids_host], rate).sum())
+        elif unit == 2:
+            if (self._edges[ids_host] % 2).any():
+                raise _lib.PgnnError("MaskEdge needs both directions of every edge stored adjacently")
+            m = int(mask_counts(self._edges[ids_host] // 2, rate).sum())
         offs = torch.empty(3, b + 1, dtype=torch.int64, device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         check(lib.pgnn_batch_offsets(ids.data_ptr(), b, self.num_graphs, self.node_slice.data_ptr(),
-                                     self.edge_slice.data_ptr(), rate, offs[0].data_ptr(), offs[1].data_ptr(),
+                                     self.edge_slice.data_ptr(), rate, unit, offs[0].data_ptr(), offs[1].data_ptr(),
                                      offs[2].data_ptr(), n, e, m, status.data_ptr(), sp), "pgnn_batch_offsets")
         out = Data()
         out.x = torch.empty(n, self.x.size(1), dtype=self.x.dtype, device=dev)
@@ -117,17 +133,19 @@ class ResidentDataset:
               "pgnn_collate_graphs")
         out._num_graphs = b
         out._status, out._node_off = status, offs[0]
-        if rate > 0 or explicit:
+        if unit == 0 and explicit is None:
+            return out
+        if explicit is not None:
+            idx = torch.as_tensor(explicit, dtype=torch.int64).to(dev).contiguous()
+            m = idx.numel()
+        else:
+            idx = torch.empty(m, dtype=torch.int64, device=dev)
+            unit_off, div, units = (offs[0], 1, n) if unit == 1 else (offs[1], 2, e)
+            check(lib.pgnn_mask_select(ids.data_ptr(), b, unit_off.data_ptr(), div, offs[2].data_ptr(), units,
+                                       int(seed) & 0xFFFFFFFFFFFFFFFF, idx.data_ptr(), sp), "pgnn_mask_select")
+        if mask_target == "atom":
             if self.x.dtype != torch.int64:
                 raise _lib.PgnnError("MaskAtom needs integer atom features (chem datasets)")
-            if explicit:
-                idx = torch.as_tensor(masked_atom_indices, dtype=torch.int64).to(dev).contiguous()
-                m = idx.numel()
-            else:
-                idx = torch.empty(m, dtype=torch.int64, device=dev)
-                check(lib.pgnn_mask_atoms_select(ids.data_ptr(), b, offs[0].data_ptr(), offs[2].data_ptr(), n,
-                                                 int(seed) & 0xFFFFFFFFFFFFFFFF, idx.data_ptr(), sp),
-                      "pgnn_mask_atoms_select")
             out.masked_atom_indices = idx
             out.mask_node_label = torch.empty(m, self.x.size(1), dtype=torch.int64, device=dev)
             check(lib.pgnn_mask_atoms_apply(idx.data_ptr(), m, out.x.data_ptr(), self.x.size(1), n, ATOM_MASK_TOKEN,
@@ -135,6 +153,14 @@ class ResidentDataset:
                   "pgnn_mask_atoms_apply")
             if mask_edge:
                 _mask_connected_edges(out)
+        else:
+            if self.edge_attr.dtype != torch.float32:
+                raise _lib.PgnnError("MaskEdge needs float32 edge attributes (bio datasets)")
+            out.masked_edge_idx = idx
+            out.mask_edge_label = torch.empty(m, self.edge_attr.size(1), dtype=torch.float32, device=dev)
+            check(lib.pgnn_mask_edges_apply(idx.data_ptr(), m, out.edge_attr.data_ptr(), self.edge_attr.size(1), e,
+                                            out.mask_edge_label.data_ptr(), status.data_ptr(), sp),
+                  "pgnn_mask_edges_apply")
         return out
 
     def check(self, batch):

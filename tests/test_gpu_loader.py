@@ -154,6 +154,45 @@ def test_explicit_indices_match_host_maskatom(mask_edge):
     _same(out, want, keys)
 
 
+def test_bio_mask_edge_matches_host_and_properties():
+    """bio MaskEdge (bio/util.py:77-102): explicit pairs bit-exact vs the host restatement; random draw:
+    k = int(E/2 * rate + 1) distinct even indices inside each graph's edge range, both directions
+    overwritten with the mask row, labels = original rows."""
+    rng = np.random.default_rng(8)
+    graphs = [synthetic.ppi_like_graph(rng) for _ in range(6)]
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    masked = [synthetic.mask_edges(g, rng) for g in graphs]
+    want = synthetic.collate(masked)
+    out = ds.collate(np.arange(6), masked_edge_idx=want.masked_edge_idx)
+    ds.check(out)
+    _same(out, want, ("x", "edge_index", "edge_attr", "batch", "masked_edge_idx", "mask_edge_label"))
+
+    plain = ds.collate(np.arange(6))
+    a = ds.collate(np.arange(6), mask_rate=0.15, seed=5)
+    b = ds.collate(np.arange(6), mask_rate=0.15, seed=5)
+    ds.check(a)
+    assert torch.equal(a.masked_edge_idx, b.masked_edge_idx) and torch.equal(a.edge_attr, b.edge_attr)
+    idx = a.masked_edge_idx.cpu()
+    eoff = np.concatenate([[0], np.cumsum([g.edge_index.size(1) for g in graphs])])
+    pos = 0
+    for g in range(6):
+        k = int((eoff[g + 1] - eoff[g]) // 2 * 0.15 + 1)
+        mine = idx[pos:pos + k]
+        pos += k
+        assert len(set(mine.tolist())) == k and bool((mine % 2 == 0).all())
+        assert int(mine.min()) >= eoff[g] and int(mine.max()) < eoff[g + 1]
+    assert pos == idx.numel()
+    assert torch.equal(a.mask_edge_label.cpu(), plain.edge_attr.cpu()[idx])
+    row = torch.zeros(9)
+    row[8] = 1
+    attr = a.edge_attr.cpu()
+    assert torch.equal(attr[idx], row.repeat(idx.numel(), 1)) and torch.equal(attr[idx + 1], row.repeat(idx.numel(), 1))
+    keep = torch.ones(attr.size(0), dtype=torch.bool)
+    keep[idx] = False
+    keep[idx + 1] = False
+    assert torch.equal(attr[keep], plain.edge_attr.cpu()[keep])
+
+
 def test_resident_batch_drives_the_train_step_identically():
     """same graphs + same masked atoms => the train step sees bit-identical inputs => identical loss"""
     from pretrain_gnns_amd import train
