@@ -94,3 +94,59 @@ def chem_contextpred_step(model_substruct, model_context, optimizer_substruct, o
     acc = 0.5 * (float(torch.sum(pred_pos > 0).detach().cpu().item()) / len(pred_pos)
                  + float(torch.sum(pred_neg < 0).detach().cpu().item()) / len(pred_neg))
     return balanced, acc
+
+
+def chem_finetune_step(model, optimizer, batch):
+    """chem/finetune.py:27-49 (loop body of train()): multi-task BCE-with-logits in float64 over the
+    non-null labels (y in {-1, 0 = missing, +1})."""
+    pred = model(batch.x, batch.edge_index, batch.edge_attr, batch.batch)
+    y = batch.y.view(pred.shape).to(torch.float64)
+    is_valid = y ** 2 > 0
+    loss_mat = F.binary_cross_entropy_with_logits(pred.double(), (y + 1) / 2, reduction="none")
+    loss_mat = torch.where(is_valid, loss_mat, torch.zeros(loss_mat.shape).to(loss_mat.device).to(loss_mat.dtype))
+    optimizer.zero_grad()
+    loss = torch.sum(loss_mat) / torch.sum(is_valid)
+    loss.backward()
+    optimizer.step()
+    return float(loss.detach().cpu().item())
+
+
+def roc_auc(labels01, scores):
+    """rank-based ROC-AUC with midranks for ties (= sklearn.metrics.roc_auc_score, which
+    chem/finetune.py:73 calls)."""
+    import numpy as np
+    labels01, scores = np.asarray(labels01, dtype=np.float64), np.asarray(scores, dtype=np.float64)
+    order = np.argsort(scores, kind="mergesort")
+    ranks = np.empty(len(scores), dtype=np.float64)
+    s = scores[order]
+    i = 0
+    while i < len(s):
+        j = i
+        while j + 1 < len(s) and s[j + 1] == s[i]:
+            j += 1
+        ranks[order[i:j + 1]] = 0.5 * (i + j) + 1.0
+        i = j + 1
+    pos = labels01 == 1
+    n_pos, n_neg = pos.sum(), (~pos).sum()
+    return float((ranks[pos].sum() - n_pos * (n_pos + 1) / 2.0) / (n_pos * n_neg))
+
+
+def chem_eval(model, batches):
+    """chem/finetune.py:52-77: eval-mode forward over the loader, mean ROC-AUC over the tasks that have
+    both classes, computed on the valid (non-zero) labels."""
+    import numpy as np
+    model.eval()
+    y_true, y_scores = [], []
+    for batch in batches:
+        with torch.no_grad():
+            pred = model(batch.x, batch.edge_index, batch.edge_attr, batch.batch)
+        y_true.append(batch.y.view(pred.shape))
+        y_scores.append(pred)
+    y_true = torch.cat(y_true, dim=0).cpu().numpy()
+    y_scores = torch.cat(y_scores, dim=0).cpu().numpy()
+    roc_list = []
+    for i in range(y_true.shape[1]):
+        if np.sum(y_true[:, i] == 1) > 0 and np.sum(y_true[:, i] == -1) > 0:
+            is_valid = y_true[:, i] ** 2 > 0
+            roc_list.append(roc_auc((y_true[is_valid, i] + 1) / 2, y_scores[is_valid, i]))
+    return sum(roc_list) / len(roc_list)

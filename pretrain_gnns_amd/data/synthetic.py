@@ -244,6 +244,20 @@ def chem_plain_batch(num_graphs, seed=0):
     return collate([zinc_like_graph(rng) for _ in range(num_graphs)])
 
 
+def chem_finetune_batch(num_graphs, num_tasks=12, seed=0, missing=0.2):
+    """labelled batch in the layout of the MoleculeNet datasets of chem/loader.py: per graph a row of
+    ``num_tasks`` labels in {-1, +1}, 0 where the label is missing; ``y`` is their concatenation."""
+    rng = np.random.default_rng(seed)
+    graphs = []
+    for _ in range(num_graphs):
+        g = zinc_like_graph(rng)
+        y = rng.choice([-1, 1], size=num_tasks)
+        y[rng.random(num_tasks) < missing] = 0
+        g.y = torch.from_numpy(y.astype(np.int64))
+        graphs.append(g)
+    return collate(graphs)
+
+
 def chem_contextpred_batch(num_graphs, seed=0, num_layer=5, csize=3):
     """k = num_layer, l1 = num_layer-1, l2 = l1+csize (chem/pretrain_contextpred.py:145-152)."""
     rng = np.random.default_rng(seed)

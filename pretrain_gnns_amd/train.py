@@ -147,3 +147,50 @@ def chem_contextpred_step(model_substruct, model_context, optimizer_substruct, o
     acc = 0.5 * (float(torch.sum(pred_pos > 0).detach().cpu().item()) / len(pred_pos)
                  + float(torch.sum(pred_neg < 0).detach().cpu().item()) / len(pred_neg))
     return balanced, acc
+
+
+def chem_finetune_step(model, optimizer, batch):
+    """One iteration of chem/finetune.py:27-49: ``GNN_graphpred`` forward (dropout active), float64
+    BCE-with-logits over the non-null labels (y in {-1, 0 = missing, +1}), backward, optimizer step."""
+    pred = model(batch.x, batch.edge_index, batch.edge_attr, batch.batch)
+    y = batch.y.view(pred.shape).to(torch.float64)
+    is_valid = y ** 2 > 0
+    loss_mat = F.binary_cross_entropy_with_logits(pred.double(), (y + 1) / 2, reduction="none")
+    loss_mat = torch.where(is_valid, loss_mat, torch.zeros_like(loss_mat))
+    optimizer.zero_grad()
+    loss = torch.sum(loss_mat) / torch.sum(is_valid)
+    loss.backward()
+    optimizer.step()
+    return float(loss.detach().cpu().item())
+
+
+def _roc_auc(labels01, scores):
+    """ROC-AUC with midranks for ties (what sklearn.metrics.roc_auc_score returns; chem/finetune.py:73)"""
+    import numpy as np
+    from scipy.stats import rankdata
+    labels01 = np.asarray(labels01)
+    ranks = rankdata(np.asarray(scores, dtype=np.float64))
+    pos = labels01 == 1
+    n_pos, n_neg = int(pos.sum()), int((~pos).sum())
+    return float((ranks[pos].sum() - n_pos * (n_pos + 1) / 2.0) / (n_pos * n_neg))
+
+
+def chem_eval(model, batches):
+    """chem/finetune.py:52-77: eval-mode scores for every batch, then the mean ROC-AUC over the tasks
+    that have both classes, on their valid (non-zero) labels."""
+    import numpy as np
+    model.eval()
+    y_true, y_scores = [], []
+    for batch in batches:
+        with torch.no_grad():
+            pred = model(batch.x, batch.edge_index, batch.edge_attr, batch.batch)
+        y_true.append(batch.y.view(pred.shape))
+        y_scores.append(pred)
+    y_true = torch.cat(y_true, dim=0).cpu().numpy()
+    y_scores = torch.cat(y_scores, dim=0).cpu().numpy()
+    roc_list = []
+    for i in range(y_true.shape[1]):
+        if np.sum(y_true[:, i] == 1) > 0 and np.sum(y_true[:, i] == -1) > 0:
+            is_valid = y_true[:, i] ** 2 > 0
+            roc_list.append(_roc_auc((y_true[is_valid, i] + 1) / 2, y_scores[is_valid, i]))
+    return sum(roc_list) / len(roc_list)

@@ -127,3 +127,18 @@ def test_masking_step_decreases_loss():
     opts = [torch.optim.Adam(m.parameters(), lr=1e-3) for m in mods]
     losses = [steps.chem_masking_step(mods, opts, b)[0] for _ in range(8)]
     assert losses[-1] < losses[0]
+
+
+def test_roc_auc_restatement_matches_sklearn():
+    """the oracle's (and the product's) rank-based ROC-AUC equals sklearn.metrics.roc_auc_score, the
+    function chem/finetune.py:73 calls -- including tied scores"""
+    import numpy as np
+    from sklearn.metrics import roc_auc_score
+    from oracle import steps
+    from pretrain_gnns_amd import train
+    rng = np.random.default_rng(0)
+    for digits in (1, 6):
+        s = np.round(rng.normal(size=300), digits)
+        y = rng.integers(0, 2, 300)
+        want = roc_auc_score(y, s)
+        assert abs(steps.roc_auc(y, s) - want) < 1e-12 and abs(train._roc_auc(y, s) - want) < 1e-12

@@ -232,6 +232,48 @@ def test_bio_masking_train_steps():
         assert abs(ar - ah) <= 0.02
 
 
+@pytest.mark.parametrize("gnn_type", ["gin", "gcn"])
+def test_chem_finetune_steps_and_eval(gnn_type):
+    """chem/finetune.py train() body and eval(): GNN_graphpred (mean pooling) + masked multi-task BCE in
+    float64, then eval-mode scores -> ROC-AUC.  drop_ratio = 0 so both sides are deterministic."""
+    from pretrain_gnns_amd import train
+    hchem, _ = _hip()
+    ref, hip = _pair(ochem.GNN_graphpred, hchem.GNN_graphpred, 5, 300, 12, gnn_type=gnn_type, seed=11)
+    b = synthetic.chem_finetune_batch(48, num_tasks=12, seed=3)
+    bd = synthetic.chem_finetune_batch(48, num_tasks=12, seed=3).to(DEV)
+    o_ref, o_hip = torch.optim.Adam(ref.parameters(), lr=1e-3), torch.optim.Adam(hip.parameters(), lr=1e-3)
+    for step in range(3):
+        l_ref, l_hip = steps.chem_finetune_step(ref, o_ref, b), train.chem_finetune_step(hip, o_hip, bd)
+        assert abs(l_ref - l_hip) <= (1e-4 if step == 0 else 3e-2) * max(1.0, abs(l_ref)), (step, l_ref, l_hip)
+    hip.load_state_dict(ref.state_dict())  # same weights again: eval parity is then a pure forward check
+    val = synthetic.chem_finetune_batch(64, num_tasks=12, seed=4)
+    auc_ref = steps.chem_eval(ref, [b, val])
+    auc_hip = train.chem_eval(hip, [bd, synthetic.chem_finetune_batch(64, num_tasks=12, seed=4).to(DEV)])
+    assert abs(auc_ref - auc_hip) <= 1e-3, (auc_ref, auc_hip)  # "within +-0.1 % absolute" (SURVEY 8d)
+
+
+def test_chem_finetune_with_dropout_runs_and_regularises():
+    """drop_ratio = 0.5 (chem/finetune.py default): the training forward differs run to run and from
+    the eval forward, eval is deterministic, the loss goes down over a few steps"""
+    from pretrain_gnns_amd import train
+    hchem, _ = _hip()
+    torch.manual_seed(0)
+    hip = hchem.GNN_graphpred(5, 300, 12, drop_ratio=0.5).to(DEV)
+    bd = synthetic.chem_finetune_batch(64, num_tasks=12, seed=5).to(DEV)
+    hip.train()
+    a = hip(bd.x, bd.edge_index, bd.edge_attr, bd.batch).detach()
+    b = hip(bd.x, bd.edge_index, bd.edge_attr, bd.batch).detach()
+    assert not torch.equal(a, b)
+    hip.eval()
+    with torch.no_grad():
+        c = hip(bd).clone()
+        assert torch.equal(c, hip(bd))
+    hip.train()
+    opt = torch.optim.Adam(hip.parameters(), lr=1e-3)
+    losses = [train.chem_finetune_step(hip, opt, bd) for _ in range(12)]
+    assert all(l == l for l in losses) and sum(losses[-3:]) < sum(losses[:3])
+
+
 @pytest.mark.parametrize("name", ["chem_gcn_contextpred", "bio_gcn_masking"])
 def test_golden_checkpoint_parity(name):
     """real shipped GCN weights + BN running stats: strict load into the HIP classes, eval- and
