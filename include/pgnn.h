@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PGNN_ABI_VERSION 1
+#define PGNN_ABI_VERSION 2
 
 #define PGNN_OK 0
 #define PGNN_ERR_ARG 1
@@ -149,14 +149,19 @@ size_t pgnn_bn_workspace_bytes(int64_t num_rows, int64_t dim);
  * training == 0: running statistics. relu != 0 fuses max(.,0). */
 int pgnn_bn_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta,
                 float* running_mean, float* running_var, float momentum, float eps, int training,
-                int relu, float* y, int64_t ldy, float* save_mean, float* save_invstd,
-                int64_t num_rows, int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream);
+                int relu, float* y, int64_t ldy, float* save_mean, float* save_invstd, float drop_p,
+                uint64_t drop_seed, int64_t num_rows, int64_t dim, void* ws, size_t ws_bytes,
+                pgnn_stream stream);
+/* drop_p > 0 fuses the F.dropout that follows (chem/model.py:271-275): inverted dropout with keep
+ * bits from a counter-based generator over (drop_seed, element) -- 16 bits per element, p resolved to
+ * 1/65536 -- so the backward regenerates the mask from the same seed instead of reading it. */
 
-/* Backward of the above (the ReLU mask is recomputed from x, nothing else is kept). */
+/* Backward of the above (ReLU and dropout masks are recomputed, nothing else is kept). */
 int pgnn_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                 const float* beta, const float* save_mean, const float* save_invstd, int training,
-                int relu, float* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t num_rows,
-                int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream);
+                int relu, float* dx, int64_t lddx, float* dgamma, float* dbeta, float drop_p,
+                uint64_t drop_seed, int64_t num_rows, int64_t dim, void* ws, size_t ws_bytes,
+                pgnn_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Linear layers of the GIN mlp / GCN linear (chem/model.py:29,54-55,63,99; bio/model.py:24,67,109):
@@ -192,8 +197,8 @@ int pgnn_chem_gin_layer_fwd(const float* x, int64_t ldx, const int32_t* in_ptr, 
                             const float* b1, const float* w2, const float* b2, const float* gamma,
                             const float* beta, float* running_mean, float* running_var, float momentum,
                             float eps, int training, int relu, float* agg, float* hid, float* z, float* y,
-                            float* save_mean, float* save_invstd, int64_t n, int64_t dim, void* ws,
-                            size_t ws_bytes, pgnn_stream stream);
+                            float* save_mean, float* save_invstd, float drop_p, uint64_t drop_seed,
+                            int64_t n, int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream);
 /* backward: dx may be NULL (layer 0 input needs no gradient path other than the embedding's);
  * demb is [9, dim]: rows 0..5 = d edge_embedding1, rows 6..8 = d edge_embedding2. */
 int pgnn_chem_gin_layer_bwd(const float* dy, int64_t lddy, const float* agg, const float* hid, const float* z,
@@ -201,8 +206,8 @@ int pgnn_chem_gin_layer_bwd(const float* dy, int64_t lddy, const float* agg, con
                             const float* w1, const float* w2, const float* gamma, const float* beta,
                             const float* save_mean, const float* save_invstd, int training, int relu,
                             float* dx, float* demb, float* dw1, float* db1, float* dw2, float* db2,
-                            float* dgamma, float* dbeta, int64_t n, int64_t dim, void* ws, size_t ws_bytes,
-                            pgnn_stream stream);
+                            float* dgamma, float* dbeta, float drop_p, uint64_t drop_seed, int64_t n,
+                            int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * The whole node-embedding network as ONE call per direction: chem/model.py:258-277 with JK="last"
@@ -228,14 +233,17 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx /* [n,2] atom type, chirality *
                             int64_t rows1, const float* xemb2, int64_t rows2, const int32_t* in_ptr,
                             const int32_t* in_src, const uint8_t* in_code, const pgnn_gin_layer* layers,
                             int num_layer, int training, float* h0, float* acts, float* hid, float* stats,
-                            int32_t* status, int64_t n, int64_t dim, void* ws, size_t ws_bytes,
-                            pgnn_stream stream);
+                            int32_t* status, float drop_p, uint64_t drop_seed, int64_t n, int64_t dim,
+                            void* ws, size_t ws_bytes, pgnn_stream stream);
+/* drop_p > 0: dropout after every layer (layer l uses seed drop_seed + l), as GNN.forward does when
+ * drop_ratio > 0 in training mode. */
 /* dy: gradient of acts[num_layer-1][2].  dxemb1 [rows1,dim] / dxemb2 [rows2,dim] may be NULL. */
 int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx, int64_t rows1, int64_t rows2,
                             const int32_t* out_ptr, const int32_t* out_dst, const float* cfeat,
                             const pgnn_gin_layer* layers, int num_layer, int training, const float* acts,
-                            const float* hid, const float* stats, float* dxemb1, float* dxemb2, int64_t n,
-                            int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream);
+                            const float* hid, const float* stats, float* dxemb1, float* dxemb2, float drop_p,
+                            uint64_t drop_seed, int64_t n, int64_t dim, void* ws, size_t ws_bytes,
+                            pgnn_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Device-side batching over a dataset resident in HBM.  The dataset is kept in

@@ -19,6 +19,7 @@ _i64 = ctypes.c_int64
 _i = ctypes.c_int
 _f = ctypes.c_float
 _sz = ctypes.c_size_t
+_u64 = ctypes.c_uint64
 
 # name -> (restype, argtypes); mirrors include/pgnn.h one to one
 PROTOTYPES = {
@@ -39,32 +40,33 @@ PROTOTYPES = {
     "pgnn_segment_sum": (_i, [_p, _i64, _p, _p, _i64, _i64, _i, _p, _i64, _i64, _p, _sz, _p]),
     "pgnn_segment_broadcast": (_i, [_p, _i64, _p, _p, _i, _p, _i64, _i64, _i64, _p]),
     "pgnn_bn_workspace_bytes": (_sz, [_i64, _i64]),
-    "pgnn_bn_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _f, _f, _i, _i, _p, _i64, _p, _p, _i64, _i64, _p, _sz, _p]),
-    "pgnn_bn_bwd": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i, _i, _p, _i64, _p, _p, _i64, _i64, _p, _sz, _p]),
+    "pgnn_bn_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _f, _f, _i, _i, _p, _i64, _p, _p, _f, _u64, _i64, _i64, _p, _sz, _p]),
+    "pgnn_bn_bwd": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i, _i, _p, _i64, _p, _p, _f, _u64, _i64, _i64, _p, _sz,
+                         _p]),
     "pgnn_linear_fwd": (_i, [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _p]),
     "pgnn_linear_bwd_data": (_i, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p]),
     "pgnn_linear_bwd_weight_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "pgnn_linear_bwd_weight": (_i, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),
     "pgnn_chem_gin_layer_workspace_bytes": (_sz, [_i64, _i64]),
     "pgnn_chem_gin_layer_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _i,
-                                     _p, _p, _p, _p, _p, _p, _i64, _i64, _p, _sz, _p]),
+                                     _p, _p, _p, _p, _p, _p, _f, _u64, _i64, _i64, _p, _sz, _p]),
     "pgnn_chem_gin_layer_bwd": (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i,
-                                     _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p, _sz, _p]),
+                                     _p, _p, _p, _p, _p, _p, _p, _p, _f, _u64, _i64, _i64, _p, _sz, _p]),
     "pgnn_chem_gin_stack_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
-    "pgnn_chem_gin_stack_fwd": (_i, [_p, _p, _i64, _p, _i64, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _i64, _i64,
-                                     _p, _sz, _p]),
-    "pgnn_chem_gin_stack_bwd": (_i, [_p, _i64, _p, _i64, _i64, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _i64, _i64,
-                                     _p, _sz, _p]),
+    "pgnn_chem_gin_stack_fwd": (_i, [_p, _p, _i64, _p, _i64, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _f, _u64,
+                                     _i64, _i64, _p, _sz, _p]),
+    "pgnn_chem_gin_stack_bwd": (_i, [_p, _i64, _p, _i64, _i64, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _f, _u64,
+                                     _i64, _i64, _p, _sz, _p]),
     "pgnn_batch_offsets": (_i, [_p, _i64, _i64, _p, _p, ctypes.c_double, _i, _p, _p, _p, _i64, _i64, _i64, _p, _p]),
     "pgnn_collate_graphs": (_i, [_p, _i64, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _p,
                                  _p, _p]),
-    "pgnn_mask_select": (_i, [_p, _i64, _p, _i, _p, _i64, ctypes.c_uint64, _p, _p]),
+    "pgnn_mask_select": (_i, [_p, _i64, _p, _i, _p, _i64, _u64, _p, _p]),
     "pgnn_mask_edges_apply": (_i, [_p, _i64, _p, _i64, _i64, _p, _p, _p]),
     "pgnn_mask_atoms_apply": (_i, [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _p]),
     "pgnn_debug_stream_copy": (_i, [_p, _p, _i64, _i64, _p]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class GinLayer(ctypes.Structure):

@@ -116,21 +116,26 @@ class GNN(torch.nn.Module):
         # one structure build for all layers, forward and backward
         graph = ops.build_chem_graph(edge_index, edge_attr, x.size(0), gcn=(self.gnn_type == "gcn"))
         fused = self.gnn_type == "gin" and type(self.gnns[0]) is GINConv and self.batch_norms[0].affine
-        if fused and self.JK == "last" and (self.drop_ratio == 0 or not self.training) and _STACK_CALL:
-            # the pre-training configuration: the whole network is one library call per direction
-            return ops.chem_gin_stack(x, graph, self.x_embedding1, self.x_embedding2, self.gnns, self.batch_norms)
+        # F.dropout of the reference (chem/model.py:271-275) is fused into the BatchNorm(+ReLU) pass
+        drop_p = float(self.drop_ratio) if (self.training and self.drop_ratio > 0) else 0.0
+        if fused and self.JK == "last" and _STACK_CALL and drop_p < 1.0:
+            # the pre-training / fine-tuning configuration: the whole network is one library call per direction
+            return ops.chem_gin_stack(x, graph, self.x_embedding1, self.x_embedding2, self.gnns, self.batch_norms,
+                                      drop_p)
         h = ops.Embed.apply(x, self.x_embedding1.weight, self.x_embedding2.weight)
 
         h_list = [h]
         for layer in range(self.num_layer):
             last = layer == self.num_layer - 1  # no ReLU after the last layer
-            if fused:  # conv + BatchNorm(+ReLU) of a layer as one library call per direction
-                h = ops.chem_gin_layer(h_list[layer], self.gnns[layer], self.batch_norms[layer], graph, relu=not last)
+            if drop_p >= 1.0:  # degenerate p = 1: everything is dropped; keep torch's semantics
+                h = self.gnns[layer](h_list[layer], edge_index, edge_attr, graph)
+                h = F.dropout(ops.batch_norm(h, self.batch_norms[layer], relu=not last), drop_p, training=True)
+            elif fused:  # conv + BatchNorm(+ReLU, +dropout) of a layer as one library call per direction
+                h = ops.chem_gin_layer(h_list[layer], self.gnns[layer], self.batch_norms[layer], graph, relu=not last,
+                                       drop_p=drop_p)
             else:
                 h = self.gnns[layer](h_list[layer], edge_index, edge_attr, graph)
-                h = ops.batch_norm(h, self.batch_norms[layer], relu=not last)
-            if self.drop_ratio > 0:
-                h = F.dropout(h, self.drop_ratio, training=self.training)
+                h = ops.batch_norm(h, self.batch_norms[layer], relu=not last, drop_p=drop_p)
             h_list.append(h)
 
         if self.JK == "concat":

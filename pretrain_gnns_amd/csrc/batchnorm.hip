@@ -13,6 +13,35 @@ namespace {
 
 constexpr int kMaxBlocks = 1024;
 
+// Inverted dropout fused into the normalise pass (F.dropout after the ReLU, chem/model.py:271-275).
+// Counter-based: the keep bits of float4 (row r, column group c4) come from one splitmix64 of
+// (seed, r*d4 + c4), 16 bits per element, keep iff bits >= p*65536 -- so the backward regenerates the
+// mask from the seed instead of storing it.  thresh == 0 disables (wave-uniform branch).
+struct Drop {
+  uint64_t seed;
+  uint32_t thresh;  // round(p * 65536)
+  float scale;      // 1 / (1 - p)
+};
+inline Drop make_drop(float p, uint64_t seed) {
+  Drop d;
+  d.seed = seed;
+  d.thresh = p > 0.f ? (uint32_t)(p * 65536.f + 0.5f) : 0u;
+  d.scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  return d;
+}
+__device__ __forceinline__ float4 drop_factors(const Drop& d, int64_t r, int d4, int c4) {
+  uint64_t z = d.seed + (uint64_t)(r * d4 + c4) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  float4 f;
+  f.x = ((uint32_t)(z) & 0xFFFFu) >= d.thresh ? d.scale : 0.f;
+  f.y = ((uint32_t)(z >> 16) & 0xFFFFu) >= d.thresh ? d.scale : 0.f;
+  f.z = ((uint32_t)(z >> 32) & 0xFFFFu) >= d.thresh ? d.scale : 0.f;
+  f.w = ((uint32_t)(z >> 48) & 0xFFFFu) >= d.thresh ? d.scale : 0.f;
+  return f;
+}
+
 // thread t of a (dim/4 x 4)-shaped block: column group c4 = t % d4, row lane rl = t / d4
 // blockDim.x = 4 * d4 rounded up to a multiple of 64.
 __device__ __forceinline__ void block_col_reduce2(float4 a, float4 b, int d4, float* lds, float* dst_a,
@@ -91,7 +120,7 @@ __global__ void k_bn_stats_final(const float* __restrict__ partial, int nblk, co
 }
 
 __global__ void k_bn_apply(const float* __restrict__ x, int64_t ldx, const float* __restrict__ coef,
-                           int relu, float* __restrict__ y, int64_t ldy, int n, int d4) {
+                           int relu, float* __restrict__ y, int64_t ldy, int n, int d4, Drop drop) {
   const int t = threadIdx.x, c4 = t % d4, rl = t / d4, dim = d4 * 4;
   if (rl >= 4) return;
   const float4 a = reinterpret_cast<const float4*>(coef)[c4];
@@ -102,6 +131,10 @@ __global__ void k_bn_apply(const float* __restrict__ x, int64_t ldx, const float
     if (relu) {
       o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
     }
+    if (drop.thresh) {
+      const float4 f = drop_factors(drop, r, d4, c4);
+      o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
+    }
     reinterpret_cast<float4*>(y + r * ldy)[c4] = o;
   }
 }
@@ -111,7 +144,7 @@ __global__ void k_bn_bwd_partial(const float* __restrict__ dy, int64_t lddy, con
                                  int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
                                  const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                                  float* __restrict__ coef /*out (block 0): a,b,mean,invstd*/, int relu,
-                                 int n, int d4, float* __restrict__ partial) {
+                                 int n, int d4, float* __restrict__ partial, Drop drop) {
   extern __shared__ __align__(16) float lds[];
   const int t = threadIdx.x, c4 = t % d4, rl = t / d4, dim = d4 * 4;
   const int per = (n + gridDim.x - 1) / gridDim.x;
@@ -133,6 +166,10 @@ __global__ void k_bn_bwd_partial(const float* __restrict__ dy, int64_t lddy, con
     for (int r = r0 + rl; r < r1; r += 4) {
       const float4 v = reinterpret_cast<const float4*>(x + (int64_t)r * ldx)[c4];
       float4 g = reinterpret_cast<const float4*>(dy + (int64_t)r * lddy)[c4];
+      if (drop.thresh) {
+        const float4 f = drop_factors(drop, r, d4, c4);
+        g.x *= f.x; g.y *= f.y; g.z *= f.z; g.w *= f.w;
+      }
       if (relu) {
         if (!(fmaf(a.x, v.x, b.x) > 0.f)) g.x = 0.f;
         if (!(fmaf(a.y, v.y, b.y) > 0.f)) g.y = 0.f;
@@ -180,7 +217,7 @@ __global__ void k_bn_bwd_final(const float* __restrict__ partial, int nblk, int 
 
 __global__ void k_bn_bwd_apply(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
                                int64_t ldx, const float* __restrict__ coef, int relu, float* __restrict__ dx,
-                               int64_t lddx, int n, int d4) {
+                               int64_t lddx, int n, int d4, Drop drop) {
   const int t = threadIdx.x, c4 = t % d4, rl = t / d4, dim = d4 * 4;
   if (rl >= 4) return;
   const float4 a = reinterpret_cast<const float4*>(coef)[c4];
@@ -192,6 +229,10 @@ __global__ void k_bn_bwd_apply(const float* __restrict__ dy, int64_t lddy, const
   for (int64_t r = (int64_t)blockIdx.x * 4 + rl; r < n; r += (int64_t)gridDim.x * 4) {
     const float4 v = reinterpret_cast<const float4*>(x + r * ldx)[c4];
     float4 g = reinterpret_cast<const float4*>(dy + r * lddy)[c4];
+    if (drop.thresh) {
+      const float4 f = drop_factors(drop, r, d4, c4);
+      g.x *= f.x; g.y *= f.y; g.z *= f.z; g.w *= f.w;
+    }
     if (relu) {
       if (!(fmaf(a.x, v.x, b.x) > 0.f)) g.x = 0.f;
       if (!(fmaf(a.y, v.y, b.y) > 0.f)) g.y = 0.f;
@@ -234,10 +275,11 @@ size_t pgnn_bn_workspace_bytes(int64_t n, int64_t dim) {
 
 int pgnn_bn_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* running_mean,
                 float* running_var, float momentum, float eps, int training, int relu, float* y, int64_t ldy,
-                float* save_mean, float* save_invstd, int64_t n, int64_t dim, void* ws, size_t ws_bytes,
-                pgnn_stream stream) {
+                float* save_mean, float* save_invstd, float drop_p, uint64_t drop_seed, int64_t n, int64_t dim,
+                void* ws, size_t ws_bytes, pgnn_stream stream) {
   if (int rc = check_args(n, dim)) return rc;
   PGNN_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "batchnorm: leading dimensions must be multiples of 4");
+  PGNN_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "batchnorm: dropout probability must be in [0, 1)");
   PGNN_REQUIRE(training || (running_mean && running_var), "batchnorm eval needs running statistics");
   if (ws_bytes < pgnn_bn_workspace_bytes(n, dim)) {
     set_error("batchnorm workspace too small");
@@ -257,15 +299,18 @@ int pgnn_bn_fwd(const float* x, int64_t ldx, const float* gamma, const float* be
                      beta, running_mean, running_var, momentum, eps, training, (int)n, (int)dim, save_mean,
                      save_invstd, coef);
   const int grid = (int)std::min<int64_t>(ceil_div(n, 4), (int64_t)kNumCU * 16);
-  hipLaunchKernelGGL(k_bn_apply, dim3(grid), dim3(stat_threads(dim)), 0, st, x, ldx, coef, relu, y, ldy, (int)n, d4);
+  hipLaunchKernelGGL(k_bn_apply, dim3(grid), dim3(stat_threads(dim)), 0, st, x, ldx, coef, relu, y, ldy, (int)n, d4,
+                     make_drop(drop_p, drop_seed));
   return check_launch("bn_fwd");
 }
 
 int pgnn_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                 const float* beta, const float* save_mean, const float* save_invstd, int training, int relu,
-                float* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t n, int64_t dim, void* ws,
-                size_t ws_bytes, pgnn_stream stream) {
+                float* dx, int64_t lddx, float* dgamma, float* dbeta, float drop_p, uint64_t drop_seed, int64_t n,
+                int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream) {
   if (int rc = check_args(n, dim)) return rc;
+  PGNN_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "batchnorm: dropout probability must be in [0, 1)");
+  const Drop drop = make_drop(drop_p, drop_seed);
   PGNN_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "batchnorm: leading dimensions must be multiples of 4");
   if (ws_bytes < pgnn_bn_workspace_bytes(n, dim)) {
     set_error("batchnorm workspace too small");
@@ -278,12 +323,12 @@ int pgnn_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, cons
   float* coef = cv.take<float>((size_t)7 * dim);
   const int d4 = (int)(dim / 4);
   hipLaunchKernelGGL(k_bn_bwd_partial, dim3(nblk), dim3(stat_threads(dim)), (size_t)8 * dim * sizeof(float), st, dy,
-                     lddy, x, ldx, gamma, beta, save_mean, save_invstd, coef, relu, (int)n, d4, partial);
+                     lddy, x, ldx, gamma, beta, save_mean, save_invstd, coef, relu, (int)n, d4, partial, drop);
   hipLaunchKernelGGL(k_bn_bwd_final, dim3((int)ceil_div(dim, 16)), dim3(256), 0, st, partial, nblk, training, (int)n, (int)dim, gamma,
                      coef, dgamma, dbeta);
   const int grid = (int)std::min<int64_t>(ceil_div(n, 4), (int64_t)kNumCU * 16);
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid), dim3(stat_threads(dim)), 0, st, dy, lddy, x, ldx, coef, relu, dx, lddx,
-                     (int)n, d4);
+                     (int)n, d4, drop);
   return check_launch("bn_bwd");
 }
 

@@ -64,8 +64,8 @@ int pgnn_chem_gin_layer_fwd(const float* x, int64_t ldx, const int32_t* in_ptr, 
                             const float* b1, const float* w2, const float* b2, const float* gamma,
                             const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                             int training, int relu, float* agg, float* hid, float* z, float* y, float* save_mean,
-                            float* save_invstd, int64_t n, int64_t dim, void* ws, size_t ws_bytes,
-                            pgnn_stream stream) {
+                            float* save_invstd, float drop_p, uint64_t drop_seed, int64_t n, int64_t dim, void* ws,
+                            size_t ws_bytes, pgnn_stream stream) {
   if (ws_bytes < op_ws_bytes(n, dim)) {
     set_error("chem_gin_layer_fwd workspace too small");
     return PGNN_ERR_WORKSPACE;
@@ -75,15 +75,15 @@ int pgnn_chem_gin_layer_fwd(const float* x, int64_t ldx, const int32_t* in_ptr, 
   if ((rc = pgnn_linear_fwd(agg, dim, w1, b1, hid, 2 * dim, n, dim, 2 * dim, 1, stream))) return rc;
   if ((rc = pgnn_linear_fwd(hid, 2 * dim, w2, b2, z, dim, n, 2 * dim, dim, 0, stream))) return rc;
   return pgnn_bn_fwd(z, dim, gamma, beta, running_mean, running_var, momentum, eps, training, relu, y, dim, save_mean,
-                     save_invstd, n, dim, ws, ws_bytes, stream);
+                     save_invstd, drop_p, drop_seed, n, dim, ws, ws_bytes, stream);
 }
 
 int pgnn_chem_gin_layer_bwd(const float* dy, int64_t lddy, const float* agg, const float* hid, const float* z,
                             const int32_t* out_ptr, const int32_t* out_dst, const float* cfeat, const float* w1,
                             const float* w2, const float* gamma, const float* beta, const float* save_mean,
                             const float* save_invstd, int training, int relu, float* dx, float* demb /*[9,dim]*/,
-                            float* dw1, float* db1, float* dw2, float* db2, float* dgamma, float* dbeta, int64_t n,
-                            int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream) {
+                            float* dw1, float* db1, float* dw2, float* db2, float* dgamma, float* dbeta, float drop_p,
+                            uint64_t drop_seed, int64_t n, int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream) {
   if (ws_bytes < pgnn_chem_gin_layer_workspace_bytes(n, dim)) {
     set_error("chem_gin_layer_bwd workspace too small");
     return PGNN_ERR_WORKSPACE;
@@ -108,8 +108,8 @@ int pgnn_chem_gin_layer_bwd(const float* dy, int64_t lddy, const float* agg, con
   };
   int rc;
   // BatchNorm(+ReLU) backward -> dz
-  if ((rc = pgnn_bn_bwd(dy, lddy, z, dim, gamma, beta, save_mean, save_invstd, training, relu, dz, dim, dgamma, dbeta, n,
-                        dim, op, opb, main))) return rc;
+  if ((rc = pgnn_bn_bwd(dy, lddy, z, dim, gamma, beta, save_mean, save_invstd, training, relu, dz, dim, dgamma, dbeta,
+                        drop_p, drop_seed, n, dim, op, opb, main))) return rc;
   // second Linear: dW2, db2 (aux) || dhid = (dz . W2) masked by hid > 0 (main)
   if ((rc = fork(0))) return rc;
   if ((rc = pgnn_linear_bwd_weight(dz, dim, hid, 2 * dim, dw2, db2, n, 2 * dim, dim, aux_ws, opb, aux))) return rc;
@@ -161,8 +161,8 @@ size_t pgnn_chem_gin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t rows1
 int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t rows1, const float* xemb2,
                             int64_t rows2, const int32_t* in_ptr, const int32_t* in_src, const uint8_t* in_code,
                             const pgnn_gin_layer* layers, int num_layer, int training, float* h0, float* acts,
-                            float* hid, float* stats, int32_t* status, int64_t n, int64_t dim, void* ws,
-                            size_t ws_bytes, pgnn_stream stream) {
+                            float* hid, float* stats, int32_t* status, float drop_p, uint64_t drop_seed, int64_t n,
+                            int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream) {
   if (num_layer < 1 || !layers) {
     set_error("chem_gin_stack_fwd: no layers");
     return PGNN_ERR_ARG;
@@ -181,8 +181,8 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
     if ((rc = pgnn_chem_gin_layer_fwd(h, dim, in_ptr, in_src, in_code, p.emb1, p.emb2, p.w1, p.b1, p.w2, p.b2, p.gamma,
                                       p.beta, p.running_mean, p.running_var, p.momentum, p.eps, training,
                                       l != num_layer - 1, a, hid + (size_t)l * 2 * nd, a + nd, a + 2 * nd,
-                                      stats + (size_t)l * 2 * dim, stats + (size_t)l * 2 * dim + dim, n, dim, ws, ws_bytes,
-                                      stream)))
+                                      stats + (size_t)l * 2 * dim, stats + (size_t)l * 2 * dim + dim, drop_p,
+                                      drop_seed + (uint64_t)l, n, dim, ws, ws_bytes, stream)))
       return rc;
     h = a + 2 * nd;
   }
@@ -192,8 +192,8 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
 int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx, int64_t rows1, int64_t rows2,
                             const int32_t* out_ptr, const int32_t* out_dst, const float* cfeat,
                             const pgnn_gin_layer* layers, int num_layer, int training, const float* acts,
-                            const float* hid, const float* stats, float* dxemb1, float* dxemb2, int64_t n,
-                            int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream) {
+                            const float* hid, const float* stats, float* dxemb1, float* dxemb2, float drop_p,
+                            uint64_t drop_seed, int64_t n, int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream) {
   if (num_layer < 1 || !layers) {
     set_error("chem_gin_stack_bwd: no layers");
     return PGNN_ERR_ARG;
@@ -256,7 +256,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     // buffer set b was last read by the side stream two layers ago
     if (sd && l + 2 <= num_layer - 1) PGNN_HIP(hipStreamWaitEvent(main, sd->lag[b], 0));
     if ((rc = pgnn_bn_bwd(g, ldg, z, dim, p.gamma, p.beta, mean, mean + dim, training, l != num_layer - 1, dz[b], dim,
-                          p.dgamma, p.dbeta, n, dim, op, opb, main))) return rc;
+                          p.dgamma, p.dbeta, drop_p, drop_seed + (uint64_t)l, n, dim, op, opb, main))) return rc;
     if ((rc = pgnn_linear_bwd_data(dz[b], dim, p.w2, hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main))) return rc;
     if ((rc = pgnn_linear_bwd_data(dhid[b], 2 * dim, p.w1, nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main))) return rc;
     if (sd) {

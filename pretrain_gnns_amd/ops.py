@@ -340,7 +340,8 @@ class BatchNormReLU(Function):
     """BatchNorm1d (+ optional fused ReLU); chem/model.py:269-275, bio/model.py:24."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, drop_p=0.0,
+                drop_seed=0):
         require_cuda(x, gamma, beta)
         x = _rows2d(x)
         n, dim = x.shape
@@ -354,10 +355,11 @@ class BatchNormReLU(Function):
                                  running_mean.data_ptr() if running_mean is not None else None,
                                  running_var.data_ptr() if running_var is not None else None, float(momentum),
                                  float(eps), int(training), int(relu), y.data_ptr(), dim, save_mean.data_ptr(),
-                                 save_invstd.data_ptr(), n, dim, ws.data_ptr(), ws.numel(), stream_ptr()),
+                                 save_invstd.data_ptr(), float(drop_p), int(drop_seed), n, dim, ws.data_ptr(),
+                                 ws.numel(), stream_ptr()),
               "pgnn_bn_fwd")
         ctx.save_for_backward(x, gamma, beta, save_mean, save_invstd)
-        ctx.training, ctx.relu = bool(training), bool(relu)
+        ctx.training, ctx.relu, ctx.drop = bool(training), bool(relu), (float(drop_p), int(drop_seed))
         return y
 
     @staticmethod
@@ -372,13 +374,20 @@ class BatchNormReLU(Function):
         ws = _workspace(_ws_bytes("pgnn_bn_workspace_bytes", n, dim), x.device)
         check(load().pgnn_bn_bwd(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), gamma.data_ptr(),
                                  beta.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(), int(ctx.training),
-                                 int(ctx.relu), dx.data_ptr(), dim, dgamma.data_ptr(), dbeta.data_ptr(), n, dim,
-                                 ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_bn_bwd")
-        return dx, dgamma, dbeta, None, None, None, None, None, None
+                                 int(ctx.relu), dx.data_ptr(), dim, dgamma.data_ptr(), dbeta.data_ptr(), ctx.drop[0],
+                                 ctx.drop[1], n, dim, ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_bn_bwd")
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
-def batch_norm(x, bn, relu):
-    """apply a torch.nn.BatchNorm1d module's parameters/buffers with the HIP kernels."""
+def dropout_seed():
+    """64-bit seed for one fused-dropout call, drawn from torch's CPU generator (so torch.manual_seed
+    makes runs reproducible) without touching the device."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+def batch_norm(x, bn, relu, drop_p=0.0):
+    """apply a torch.nn.BatchNorm1d module's parameters/buffers with the HIP kernels; ``drop_p`` > 0
+    fuses the inverted dropout that follows it in GNN.forward."""
     training = bn.training or bn.running_mean is None
     momentum = 0.0 if bn.momentum is None else bn.momentum
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
@@ -389,7 +398,8 @@ def batch_norm(x, bn, relu):
     rv = bn.running_var if bn.track_running_stats else None
     if not bn.affine:
         raise _lib.PgnnError("BatchNorm1d without affine parameters is not on the hot path")
-    return BatchNormReLU.apply(x, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, relu)
+    return BatchNormReLU.apply(x, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, relu, drop_p,
+                               dropout_seed() if drop_p > 0 else 0)
 
 
 # ------------------------------------------------------------------------------------ linear layers
@@ -487,7 +497,7 @@ class ChemGINLayer(Function):
 
     @staticmethod
     def forward(ctx, x, emb1, emb2, w1, b1, w2, b2, gamma, beta, graph, running_mean, running_var, training,
-                momentum, eps, relu):
+                momentum, eps, relu, drop_p=0.0, drop_seed=0):
         require_cuda(x, emb1, emb2, w1, b1, w2, b2, gamma, beta)
         x = _rows2d(x)
         n, dim = x.shape
@@ -507,9 +517,10 @@ class ChemGINLayer(Function):
             running_mean.data_ptr() if running_mean is not None else None,
             running_var.data_ptr() if running_var is not None else None, float(momentum), float(eps), int(training),
             int(relu), agg.data_ptr(), hid.data_ptr(), z.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
-            stats[1].data_ptr(), n, dim, ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_chem_gin_layer_fwd")
+            stats[1].data_ptr(), float(drop_p), int(drop_seed), n, dim, ws.data_ptr(), ws.numel(), stream_ptr()),
+            "pgnn_chem_gin_layer_fwd")
         ctx.save_for_backward(acts, hid, stats, w1, w2, gamma, beta)
-        ctx.graph, ctx.training, ctx.relu = graph, bool(training), bool(relu)
+        ctx.graph, ctx.training, ctx.relu, ctx.drop = graph, bool(training), bool(relu), (float(drop_p), int(drop_seed))
         return y
 
     @staticmethod
@@ -531,15 +542,15 @@ class ChemGINLayer(Function):
             graph.out_dst.data_ptr(), graph.cfeat.data_ptr(), w1.data_ptr(), w2.data_ptr(), gamma.data_ptr(),
             beta.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), int(ctx.training), int(ctx.relu),
             dx.data_ptr() if dx is not None else None, demb.data_ptr(), dw1.data_ptr(), db1.data_ptr(),
-            dw2.data_ptr(), db2.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), n, dim, ws.data_ptr(), ws.numel(),
-            stream_ptr()), "pgnn_chem_gin_layer_bwd")
+            dw2.data_ptr(), db2.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ctx.drop[0], ctx.drop[1], n, dim,
+            ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_chem_gin_layer_bwd")
         demb = demb.view(9, dim)
         return (dx, demb[:6], demb[6:9], dw1.view(2 * dim, dim), db1, dw2.view(dim, 2 * dim), db2, dgamma, dbeta,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None)
 
 
-def chem_gin_layer(x, conv, bn, graph, relu):
-    """apply GINConv ``conv`` + BatchNorm1d ``bn`` (+ReLU) through the fused layer call."""
+def chem_gin_layer(x, conv, bn, graph, relu, drop_p=0.0):
+    """apply GINConv ``conv`` + BatchNorm1d ``bn`` (+ReLU, +dropout) through the fused layer call."""
     training = bn.training or bn.running_mean is None
     momentum = 0.0 if bn.momentum is None else bn.momentum
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
@@ -550,7 +561,7 @@ def chem_gin_layer(x, conv, bn, graph, relu):
     rv = bn.running_var if bn.track_running_stats else None
     return ChemGINLayer.apply(x, conv.edge_embedding1.weight, conv.edge_embedding2.weight, conv.mlp[0].weight,
                               conv.mlp[0].bias, conv.mlp[2].weight, conv.mlp[2].bias, bn.weight, bn.bias, graph, rm, rv,
-                              training, momentum, bn.eps, relu)
+                              training, momentum, bn.eps, relu, drop_p, dropout_seed() if drop_p > 0 else 0)
 
 
 # ------------------------------------------------------------------------------------ whole chem GIN network
@@ -569,7 +580,7 @@ class ChemGINStack(Function):
         if x_idx.dtype != torch.int64 or x_idx.dim() != 2 or x_idx.size(1) != 2:
             raise _lib.PgnnError("chem node features must be int64 [N, 2]")
         x_idx = x_idx.contiguous()
-        training, bns = meta
+        training, bns, drop_p, drop_seed = meta
         L = len(params) // ChemGINStack.PER_LAYER
         n, dim = x_idx.size(0), xemb1.size(1)
         if training and n <= 1:
@@ -594,12 +605,13 @@ class ChemGINStack(Function):
         check(load().pgnn_chem_gin_stack_fwd(
             x_idx.data_ptr(), xemb1.data_ptr(), xemb1.size(0), xemb2.data_ptr(), xemb2.size(0), graph.in_ptr.data_ptr(),
             graph.in_src.data_ptr(), graph.in_code.data_ptr(), layers, L, int(training), h0.data_ptr(), acts.data_ptr(),
-            hid.data_ptr(), stats.data_ptr(), status.data_ptr(), n, dim, ws.data_ptr(), ws.numel(), stream_ptr()),
-            "pgnn_chem_gin_stack_fwd")
+            hid.data_ptr(), stats.data_ptr(), status.data_ptr(), float(drop_p), int(drop_seed), n, dim, ws.data_ptr(),
+            ws.numel(), stream_ptr()), "pgnn_chem_gin_stack_fwd")
         if _CHECK_INDICES and int(status.item()):
             raise IndexError("embedding index out of range")
         ctx.save_for_backward(acts, hid, stats, *params)
         ctx.x_idx, ctx.graph, ctx.training, ctx.layers, ctx.rows = x_idx, graph, bool(training), layers, (xemb1.size(0), xemb2.size(0))
+        ctx.drop = (float(drop_p), int(drop_seed))
         return acts[L - 1, 2]
 
     @staticmethod
@@ -624,8 +636,8 @@ class ChemGINStack(Function):
         check(load().pgnn_chem_gin_stack_bwd(
             dy.data_ptr(), dy.stride(0), ctx.x_idx.data_ptr(), rows1, rows2, g.out_ptr.data_ptr(), g.out_dst.data_ptr(),
             g.cfeat.data_ptr(), layers, L, int(ctx.training), acts.data_ptr(), hid.data_ptr(), stats.data_ptr(),
-            dx1 if ctx.needs_input_grad[3] else None, dx2 if ctx.needs_input_grad[4] else None, n, dim, ws.data_ptr(),
-            ws.numel(), stream_ptr()), "pgnn_chem_gin_stack_bwd")
+            dx1 if ctx.needs_input_grad[3] else None, dx2 if ctx.needs_input_grad[4] else None, ctx.drop[0], ctx.drop[1],
+            n, dim, ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_chem_gin_stack_bwd")
         pieces = flat.split_with_sizes(sizes)
         return (None, None, None) + tuple(t if shp is None else t.view(shp) for t, shp in zip(pieces, shapes))
 
@@ -659,9 +671,9 @@ def _stack_grad_layout(L, dim, rows1, rows2):
     return lay
 
 
-def chem_gin_stack(x_idx, graph, x_embedding1, x_embedding2, convs, bns):
+def chem_gin_stack(x_idx, graph, x_embedding1, x_embedding2, convs, bns, drop_p=0.0):
     """run the atom embedding and all (conv, bn) layers through the stack call; ReLU after every layer
-    but the last, as GNN.forward of the reference does."""
+    but the last and (``drop_p`` > 0) dropout after every layer, as GNN.forward of the reference does."""
     training = bns[0].training or bns[0].running_mean is None
     meta, flat = [], []
     counters = []
@@ -677,4 +689,5 @@ def chem_gin_stack(x_idx, graph, x_embedding1, x_embedding2, convs, bns):
                  conv.mlp[2].weight, conv.mlp[2].bias, bn.weight, bn.bias]
     if counters:
         torch._foreach_add_(counters, 1)  # num_batches_tracked of every layer in one launch
-    return ChemGINStack.apply(x_idx, graph, (training, meta), x_embedding1.weight, x_embedding2.weight, *flat)
+    return ChemGINStack.apply(x_idx, graph, (training, meta, drop_p, dropout_seed() if drop_p > 0 else 0),
+                              x_embedding1.weight, x_embedding2.weight, *flat)

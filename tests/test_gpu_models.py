@@ -252,6 +252,28 @@ def test_chem_finetune_steps_and_eval(gnn_type):
     assert abs(auc_ref - auc_hip) <= 1e-3, (auc_ref, auc_hip)  # "within +-0.1 % absolute" 
 
 
+@pytest.mark.parametrize("stack", [True, False])
+def test_dropout_is_reproducible_under_manual_seed(stack, monkeypatch):
+    """fused dropout draws its seeds from torch's CPU generator: torch.manual_seed pins the whole
+    forward/backward, on the one-call path and on the per-layer path"""
+    hchem, _ = _hip()
+    monkeypatch.setattr(hchem, "_STACK_CALL", stack)
+    torch.manual_seed(0)
+    m = hchem.GNN(3, 300, drop_ratio=0.5).to(DEV)
+    d = synthetic.chem_plain_batch(24, seed=2).to(DEV)
+    runs = []
+    for seed in (7, 7, 8):
+        torch.manual_seed(seed)
+        m.zero_grad()
+        out = m(d.x, d.edge_index, d.edge_attr)
+        out.square().sum().backward()
+        runs.append((out.detach().clone(), torch.cat([p.grad.flatten() for p in m.parameters()]).clone()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    assert not torch.equal(runs[0][0], runs[2][0])
+    zero_frac = float((runs[0][0] == 0).float().mean())
+    assert 0.45 < zero_frac < 0.55  # last layer: no ReLU, so exactly the dropped half is zero
+
+
 def test_chem_finetune_with_dropout_runs_and_regularises():
     """drop_ratio = 0.5 (chem/finetune.py default): the training forward differs run to run and from
     the eval forward, eval is deterministic, the loss goes down over a few steps"""

@@ -364,3 +364,39 @@ def test_cpu_tensors_rejected():
     ei, ea = _rand_graph(10, 20, seed=0)
     with pytest.raises(PgnnError):
         ops.build_chem_graph(ei, ea, 10)
+
+
+@pytest.mark.parametrize("p,relu", [(0.5, True), (0.3, True), (0.5, False)])
+def test_fused_dropout_in_batchnorm(p, relu):
+    """F.dropout fused into the BatchNorm(+ReLU) pass (chem/model.py:271-275): the output is the
+    undropped output times an inverted-dropout mask, the backward is exactly the undropped backward of
+    the masked upstream gradient, the mask is a function of the seed only, and the drop rate is p."""
+    from pretrain_gnns_amd import ops
+    torch.manual_seed(1)
+    n, d = 6747, 300
+    x = torch.randn(n, d, device=DEV) * 2 + 0.5
+    gamma, beta = torch.rand(d, device=DEV) + 0.5, torch.randn(d, device=DEV) * 0.1
+    dy = torch.randn(n, d, device=DEV)
+
+    def run(drop_p, seed, upstream):
+        xx, g, b = x.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+        y = ops.BatchNormReLU.apply(xx, g, b, None, None, True, 0.1, 1e-5, relu, drop_p, seed)
+        y.backward(upstream)
+        return y.detach(), xx.grad, g.grad, b.grad
+
+    y0 = run(0.0, 0, dy)[0]
+    y1, dx1, dg1, db1 = run(p, 1234, dy)
+    scale = torch.tensor(1.0, dtype=torch.float32) / (torch.tensor(1.0, dtype=torch.float32) - torch.tensor(p, dtype=torch.float32))
+    kept = (y1 != 0) | (y0 == 0)
+    assert torch.equal(y1[kept], (y0 * scale.to(DEV))[kept])
+    live = y0 != 0  # where the drop decision is observable
+    rate = 1.0 - float(kept[live].float().mean())
+    assert abs(rate - p) < 0.005, rate
+    # the mask only depends on the seed: recover it from a ReLU-free run with the same seed, then the
+    # undropped op fed the masked gradient must reproduce the fused backward bit for bit
+    probe = ops.BatchNormReLU.apply(x, gamma + 0, beta + 10.0, None, None, True, 0.1, 1e-5, False, p, 1234)
+    mask = (probe != 0).float() * scale.to(DEV)
+    _, dx0, dg0, db0 = run(0.0, 0, dy * mask)
+    assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert torch.equal(run(p, 1234, dy)[0], y1)         # same seed, same mask
+    assert not torch.equal(run(p, 1235, dy)[0], y1)     # another seed, another mask
