@@ -164,6 +164,19 @@ int pgnn_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, cons
                 pgnn_stream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * GraphSAGE update (chem/model.py:165-202, bio/model.py:183-224): aggr="mean" + F.normalize(p=2).
+ * `sum` is the unweighted aggregation incl. the self loop (pgnn_chem_aggregate_fwd with dinv == NULL, or
+ * pgnn_neighbor_sum + pgnn_rowfeat_matmul_fwd for bio); in_ptr is the CSR-by-destination row pointer.
+ *   v = sum / (in_ptr[i+1] - in_ptr[i] + 1) ;  norm = ||v||_2 ;  y = v / max(norm, 1e-12)
+ * ------------------------------------------------------------------------------------------ */
+int pgnn_mean_l2norm_fwd(const float* sum, int64_t ld_sum, const int32_t* in_ptr, float* y, int64_t ldy,
+                         float* norm /*[n]*/, int64_t num_nodes, int64_t dim, pgnn_stream stream);
+/* dsum = gradient w.r.t. `sum` */
+int pgnn_mean_l2norm_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* norm,
+                         const int32_t* in_ptr, float* dsum, int64_t ld_dsum, int64_t num_nodes, int64_t dim,
+                         pgnn_stream stream);
+
+/* ------------------------------------------------------------------------------------------
  * Linear layers of the GIN mlp / GCN linear (chem/model.py:29,54-55,63,99; bio/model.py:24,67,109):
  * fp32 MFMA GEMMs (v_mfma_f32_16x16x4_f32), exact fp32 accumulate.
  * ------------------------------------------------------------------------------------------ */

@@ -85,6 +85,25 @@ class GCNConv(_InputLayerMixin, nn.Module):
         return pyg.propagate_add(ei, x, ee, lambda x_j, e: nrm.view(-1, 1) * (x_j + e), x.size(0))
 
 
+class GraphSAGEConv(_InputLayerMixin, nn.Module):
+    """bio/model.py:183-224."""
+
+    def __init__(self, emb_dim, aggr="mean", input_layer=False):
+        super().__init__()
+        self.emb_dim = emb_dim
+        self.linear = nn.Linear(emb_dim, emb_dim)
+        self._make_edge_and_input(emb_dim, input_layer)
+        self.aggr = aggr
+
+    def forward(self, x, edge_index, edge_attr):
+        ei, ea = _with_self_loops(edge_index, edge_attr, x.size(0))
+        ee = self.edge_encoder(ea)
+        x = self._maybe_embed_input(x)
+        x = self.linear(x)
+        out = pyg.propagate_mean(ei, x, ee, lambda x_j, e: x_j + e, x.size(0))
+        return F.normalize(out, p=2, dim=-1)
+
+
 class GNN(nn.Module):
     """bio/model.py:227-290 (JK last / sum)."""
 
@@ -93,7 +112,7 @@ class GNN(nn.Module):
         self.num_layer, self.drop_ratio, self.JK = num_layer, drop_ratio, JK
         if num_layer < 2:
             raise ValueError("Number of GNN layers must be greater than 1.")
-        conv = {"gin": GINConv, "gcn": GCNConv}[gnn_type]
+        conv = {"gin": GINConv, "gcn": GCNConv, "graphsage": GraphSAGEConv}[gnn_type]
         self.gnns = nn.ModuleList([conv(emb_dim, input_layer=(layer == 0)) for layer in range(num_layer)])
 
     def forward(self, x, edge_index, edge_attr):

@@ -88,6 +88,27 @@ class GCNConv(_BondEmbedding, nn.Module):
         return pyg.propagate_add(ei, x, ee, lambda x_j, e: nrm.view(-1, 1) * (x_j + e), x.size(0))  # :103-104
 
 
+class GraphSAGEConv(_BondEmbedding, nn.Module):
+    """chem/model.py:165-202: mean over (x_j W^T + b + e_ij) incl. the self loop, then L2-normalise."""
+
+    def __init__(self, emb_dim, aggr="mean"):
+        super().__init__()
+        self.emb_dim = emb_dim
+        self.linear = nn.Linear(emb_dim, emb_dim)
+        self.edge_embedding1 = nn.Embedding(NUM_BOND_TYPE, emb_dim)
+        self.edge_embedding2 = nn.Embedding(NUM_BOND_DIRECTION, emb_dim)
+        nn.init.xavier_uniform_(self.edge_embedding1.weight.data)
+        nn.init.xavier_uniform_(self.edge_embedding2.weight.data)
+        self.aggr = aggr
+
+    def forward(self, x, edge_index, edge_attr):
+        ei, ea = _with_self_loops(edge_index, edge_attr, x.size(0))
+        ee = self.bond_embedding(ea)
+        x = self.linear(x)  # :194
+        out = pyg.propagate_mean(ei, x, ee, lambda x_j, e: x_j + e, x.size(0))  # :196-199
+        return F.normalize(out, p=2, dim=-1)  # update, :201-202
+
+
 class GNN(nn.Module):
     """chem/model.py:206-290."""
 
@@ -100,7 +121,7 @@ class GNN(nn.Module):
         self.x_embedding2 = nn.Embedding(NUM_CHIRALITY_TAG, emb_dim)
         nn.init.xavier_uniform_(self.x_embedding1.weight.data)
         nn.init.xavier_uniform_(self.x_embedding2.weight.data)
-        conv = {"gin": GINConv, "gcn": GCNConv}[gnn_type]
+        conv = {"gin": GINConv, "gcn": GCNConv, "graphsage": GraphSAGEConv}[gnn_type]
         self.gnns = nn.ModuleList([conv(emb_dim) for _ in range(num_layer)])
         self.batch_norms = nn.ModuleList([nn.BatchNorm1d(emb_dim) for _ in range(num_layer)])
 

@@ -52,6 +52,12 @@ def main():
     fx = _fixture("bio", "bio/model_architecture/gcn_masking.pth", obio.GNN(5, 300, gnn_type="gcn"),
                   synthetic.bio_masking_batch(3, seed=12))
     torch.save(fx, os.path.join(OUT, "bio_gcn_masking.pt"))
+    fx = _fixture("chem", "chem/model_architecture/graphsage_contextpred.pth", ochem.GNN(5, 300, gnn_type="graphsage"),
+                  synthetic.chem_plain_batch(6, seed=13))
+    torch.save(fx, os.path.join(OUT, "chem_graphsage_contextpred.pt"))
+    fx = _fixture("bio", "bio/model_architecture/graphsage_masking.pth", obio.GNN(5, 300, gnn_type="graphsage"),
+                  synthetic.bio_masking_batch(3, seed=14))
+    torch.save(fx, os.path.join(OUT, "bio_graphsage_masking.pt"))
     # vocabulary / layout constants the reference fixes (chem/model.py:9-13,43; chem/util.py:212-213)
     torch.save({"num_atom_type": 120, "num_chirality_tag": 3, "num_bond_type": 6, "num_bond_direction": 3,
                 "self_loop_bond_type": 4, "atom_mask_token": 119, "bond_mask_token": 5,

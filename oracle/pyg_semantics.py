@@ -35,6 +35,19 @@ def propagate_add(edge_index, x_j_source, per_edge_term, combine, num_nodes):
     return scatter_add(msg, edge_index[0], num_nodes)
 
 
+def scatter_mean(src, index, dim_size):
+    """torch_scatter 1.1.2 scatter_mean: the sum divided by the per-index count clamped to >= 1."""
+    total = scatter_add(src, index, dim_size)
+    count = scatter_add(torch.ones(src.size(0), dtype=src.dtype, device=src.device), index, dim_size)
+    return total / count.clamp(min=1).unsqueeze(-1)
+
+
+def propagate_mean(edge_index, x_j_source, per_edge_term, combine, num_nodes):
+    """aggr='mean' of MessagePassing.propagate (GraphSAGEConv, chem/model.py:167,196)."""
+    msg = combine(x_j_source[edge_index[1]], per_edge_term)
+    return scatter_mean(msg, edge_index[0], num_nodes)
+
+
 def global_add_pool(x, batch, size=None):
     size = int(batch.max().item()) + 1 if size is None else size
     return scatter_add(x, batch, size)

@@ -43,6 +43,8 @@ PROTOTYPES = {
     "pgnn_bn_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _f, _f, _i, _i, _p, _i64, _p, _p, _f, _u64, _i64, _i64, _p, _sz, _p]),
     "pgnn_bn_bwd": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i, _i, _p, _i64, _p, _p, _f, _u64, _i64, _i64, _p, _sz,
                          _p]),
+    "pgnn_mean_l2norm_fwd": (_i, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _p]),
+    "pgnn_mean_l2norm_bwd": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _p]),
     "pgnn_linear_fwd": (_i, [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _p]),
     "pgnn_linear_bwd_data": (_i, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p]),
     "pgnn_linear_bwd_weight_workspace_bytes": (_sz, [_i64, _i64, _i64]),

@@ -68,9 +68,30 @@ class GCNConv(torch.nn.Module):
         return ops.BioAggregate.apply(h, self.edge_encoder.weight, self.edge_encoder.bias, graph)
 
 
+class GraphSAGEConv(torch.nn.Module):
+    """bio/model.py:183-224: L2-normalised mean over (W x_j + b + enc(e_ij)), self loop included."""
+
+    def __init__(self, emb_dim, aggr="mean", input_layer=False):
+        super().__init__()
+        if aggr != "mean":
+            raise NotImplementedError("only aggr='mean' is on the HIP path")
+        self.emb_dim = emb_dim
+        self.linear = torch.nn.Linear(emb_dim, emb_dim)
+        _edge_and_input(self, emb_dim, input_layer)
+        self.aggr = aggr
+
+    def forward(self, x, edge_index, edge_attr, graph=None):
+        x = _embed_input(self, x)
+        if graph is None:
+            graph = ops.build_bio_graph(edge_index, edge_attr, x.size(0), gcn=False)
+        h = ops.linear(x, self.linear)
+        total = ops.BioSumAggregate.apply(h, self.edge_encoder.weight, self.edge_encoder.bias, graph)
+        return ops.MeanL2Normalize.apply(total, graph)
+
+
 class GNN(torch.nn.Module):
     """bio/model.py:227-290: ``num_layer`` convs with ReLU between them (no outer BatchNorm);
-    JK in last|sum; gnn_type in gin|gcn on the HIP path."""
+    JK in last|sum; gnn_type in gin|gcn|graphsage on the HIP path."""
 
     def __init__(self, num_layer, emb_dim, JK="last", drop_ratio=0, gnn_type="gin"):
         super().__init__()
@@ -88,9 +109,11 @@ class GNN(torch.nn.Module):
                 self.gnns.append(GINConv(emb_dim, aggr="add", input_layer=input_layer))
             elif gnn_type == "gcn":
                 self.gnns.append(GCNConv(emb_dim, input_layer=input_layer))
+            elif gnn_type == "graphsage":
+                self.gnns.append(GraphSAGEConv(emb_dim, input_layer=input_layer))
             else:
                 raise NotImplementedError(
-                    "gnn_type=%r: only 'gin' and 'gcn' are implemented on the MI355X hot path" % (gnn_type,))
+                    "gnn_type=%r: only 'gin', 'gcn' and 'graphsage' are implemented on the MI355X path" % (gnn_type,))
 
     def forward(self, x, edge_index, edge_attr):
         graph = ops.build_bio_graph(edge_index, edge_attr, x.size(0), gcn=(self.gnn_type == "gcn"))

@@ -71,11 +71,32 @@ class GCNConv(torch.nn.Module):
         return ops.ChemAggregate.apply(h, self.edge_embedding1.weight, self.edge_embedding2.weight, graph)
 
 
+class GraphSAGEConv(torch.nn.Module):
+    """GraphSAGE layer (chem/model.py:165-202): L2-normalised mean over (W x_j + b + e_ij), self loop
+    included.  The sum runs on the GIN aggregation kernel; mean + normalise is one row pass."""
+
+    def __init__(self, emb_dim, aggr="mean"):
+        super().__init__()
+        if aggr != "mean":
+            raise NotImplementedError("only aggr='mean' is on the HIP path")
+        self.emb_dim = emb_dim
+        self.linear = torch.nn.Linear(emb_dim, emb_dim)
+        _bond_tables(self, emb_dim)
+        self.aggr = aggr
+
+    def forward(self, x, edge_index, edge_attr, graph=None):
+        if graph is None:
+            graph = ops.build_chem_graph(edge_index, edge_attr, x.size(0), gcn=False)
+        h = ops.linear(x, self.linear)
+        total = ops.ChemAggregate.apply(h, self.edge_embedding1.weight, self.edge_embedding2.weight, graph)
+        return ops.MeanL2Normalize.apply(total, graph)
+
+
 class GNN(torch.nn.Module):
     """Node-embedding network: atom embedding, ``num_layer`` x (conv, BatchNorm, ReLU, dropout).
 
     Args / output as the reference (chem/model.py:206-221): JK in last|concat|max|sum,
-    gnn_type in gin|gcn (gat / graphsage are not on the HIP hot path).
+    gnn_type in gin|gcn|graphsage (gat is not on the HIP path).
     """
 
     def __init__(self, num_layer, emb_dim, JK="last", drop_ratio=0, gnn_type="gin"):
@@ -98,9 +119,11 @@ class GNN(torch.nn.Module):
                 self.gnns.append(GINConv(emb_dim, aggr="add"))
             elif gnn_type == "gcn":
                 self.gnns.append(GCNConv(emb_dim))
+            elif gnn_type == "graphsage":
+                self.gnns.append(GraphSAGEConv(emb_dim))
             else:
                 raise NotImplementedError(
-                    "gnn_type=%r: only 'gin' and 'gcn' are implemented on the MI355X hot path" % (gnn_type,))
+                    "gnn_type=%r: only 'gin', 'gcn' and 'graphsage' are implemented on the MI355X path" % (gnn_type,))
 
         self.batch_norms = torch.nn.ModuleList(torch.nn.BatchNorm1d(emb_dim) for _ in range(num_layer))
 

@@ -248,6 +248,67 @@ class BioAggregate(Function):
         return gx, gw, gb, None
 
 
+class BioSumAggregate(Function):
+    """bio GraphSAGEConv message + unweighted sum (bio/model.py:200-221): out[N,D] = sum_e (x_j + enc(e_ij))
+    incl. the self loop; ``graph`` must be built with gcn=False (plain per-node edge-feature sums)."""
+
+    @staticmethod
+    def forward(ctx, x, enc_w, enc_b, graph):
+        require_cuda(x, enc_w, enc_b)
+        x = _rows2d(x)
+        n, dim = x.shape
+        if n != graph.n or enc_w.shape != (dim, 9) or graph.gcn:
+            raise _lib.PgnnError("bio sum aggregate: shape mismatch / graph built with GCN weights")
+        table = torch.cat([enc_w.t(), enc_b.unsqueeze(0)], dim=0).contiguous()  # [10, D]
+        out = _neighbor_sum(x, graph.in_ptr, graph.in_src, None, n, dim)
+        _rowfeat_fwd(graph.cfeat, table, out, dim, True)
+        ctx.graph, ctx.dim = graph, dim
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        graph, dim = ctx.graph, ctx.dim
+        g = _rows2d(g)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _neighbor_sum(g, graph.out_ptr, graph.out_dst, None, g.size(0), dim)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            gt = _rowfeat_bwd(graph.cfeat, g, dim)
+            gw, gb = gt[:9].t(), gt[9]
+        return gx, gw, gb, None
+
+
+class MeanL2Normalize(Function):
+    """GraphSAGE update on top of an unweighted aggregation: divide by (in-degree + 1), then
+    F.normalize(p=2, dim=-1)  (chem/model.py:167,201-202; bio/model.py:183,223-224)."""
+
+    @staticmethod
+    def forward(ctx, total, graph):
+        require_cuda(total)
+        total = _rows2d(total)
+        n, dim = total.shape
+        y = torch.empty(n, dim, dtype=torch.float32, device=total.device)
+        norm = torch.empty(n, dtype=torch.float32, device=total.device)
+        check(load().pgnn_mean_l2norm_fwd(total.data_ptr(), total.stride(0), graph.in_ptr.data_ptr(), y.data_ptr(), dim,
+                                          norm.data_ptr(), n, dim, stream_ptr()), "pgnn_mean_l2norm_fwd")
+        ctx.save_for_backward(y, norm)
+        ctx.graph = graph
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        y, norm = ctx.saved_tensors
+        dy = _rows2d(dy)
+        n, dim = y.shape
+        d = torch.empty(n, dim, dtype=torch.float32, device=y.device)
+        check(load().pgnn_mean_l2norm_bwd(dy.data_ptr(), dy.stride(0), y.data_ptr(), dim, norm.data_ptr(),
+                                          ctx.graph.in_ptr.data_ptr(), d.data_ptr(), dim, n, dim, stream_ptr()),
+              "pgnn_mean_l2norm_bwd")
+        return d, None
+
+
 # ------------------------------------------------------------------------------------ embedding
 class Embed(Function):
     """x_embedding1(x[:,0]) + x_embedding2(x[:,1]) (chem/model.py:264) or a single table

@@ -19,10 +19,11 @@ from oracle import steps
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("name,cls", [("chem_gcn_contextpred", ochem.GNN), ("bio_gcn_masking", obio.GNN)])
+@pytest.mark.parametrize("name,cls", [("chem_gcn_contextpred", ochem.GNN), ("bio_gcn_masking", obio.GNN),
+                                      ("chem_graphsage_contextpred", ochem.GNN), ("bio_graphsage_masking", obio.GNN)])
 def test_oracle_reproduces_golden_checkpoint_outputs(name, cls):
     fx = torch.load(os.path.join(GOLDEN, name + ".pt"), map_location="cpu")
-    m = cls(5, 300, gnn_type="gcn")
+    m = cls(5, 300, gnn_type=name.split("_")[1])
     res = m.load_state_dict(fx["state_dict"], strict=True)  # the drop-in key/shape contract
     assert not res.missing_keys and not res.unexpected_keys
     b = fx["batch"]

@@ -67,7 +67,7 @@ def _grads_close(ref, hip, batch_args, weight, l2_tol=2e-2):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("gnn_type", ["gin", "gcn"])
+@pytest.mark.parametrize("gnn_type", ["gin", "gcn", "graphsage"])
 @pytest.mark.parametrize("graphs", [1, 32])
 def test_chem_gnn_forward_backward(gnn_type, graphs):
     hchem, _ = _hip()
@@ -127,7 +127,7 @@ def test_chem_graphpred(pool):
     torch.testing.assert_close(hip(d).detach().cpu(), ref(b).detach(), **TOL)
 
 
-@pytest.mark.parametrize("gnn_type", ["gin", "gcn"])
+@pytest.mark.parametrize("gnn_type", ["gin", "gcn", "graphsage"])
 def test_bio_gnn_forward_backward(gnn_type):
     _, hbio = _hip()
     ref, hip = _pair(obio.GNN, hbio.GNN, 5, 300, gnn_type=gnn_type)
@@ -296,14 +296,15 @@ def test_chem_finetune_with_dropout_runs_and_regularises():
     assert all(l == l for l in losses) and sum(losses[-3:]) < sum(losses[:3])
 
 
-@pytest.mark.parametrize("name", ["chem_gcn_contextpred", "bio_gcn_masking"])
+@pytest.mark.parametrize("name", ["chem_gcn_contextpred", "bio_gcn_masking", "chem_graphsage_contextpred",
+                                  "bio_graphsage_masking"])
 def test_golden_checkpoint_parity(name):
-    """real shipped GCN weights + BN running stats: strict load into the HIP classes, eval- and
+    """real shipped GCN / GraphSAGE weights + BN running stats: strict load into the HIP classes, eval- and
     train-mode embeddings and one gradient must match the fixture (oracle on the reference blob)."""
     hchem, hbio = _hip()
     fx = torch.load(os.path.join(GOLDEN, name + ".pt"), map_location="cpu")
     cls = hchem.GNN if fx["kind"] == "chem" else hbio.GNN
-    m = cls(5, 300, gnn_type="gcn")
+    m = cls(5, 300, gnn_type=name.split("_")[1])
     res = m.load_state_dict(fx["state_dict"], strict=True)
     assert not res.missing_keys and not res.unexpected_keys
     m = m.to(DEV)

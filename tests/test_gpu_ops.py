@@ -400,3 +400,33 @@ def test_fused_dropout_in_batchnorm(p, relu):
     assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
     assert torch.equal(run(p, 1234, dy)[0], y1)         # same seed, same mask
     assert not torch.equal(run(p, 1235, dy)[0], y1)     # another seed, another mask
+
+
+@pytest.mark.parametrize("n,dim", [(1, 300), (517, 300), (64, 8), (100, 1024)])
+def test_mean_l2norm_fwd_bwd(n, dim):
+    """GraphSAGE update (chem/model.py:167,201-202): scatter_mean's division by the neighbour count,
+    then F.normalize -- against torch on the CPU, forward and backward, incl. all-zero rows (the clamp)."""
+    from pretrain_gnns_amd import ops
+    torch.manual_seed(n)
+    total = torch.randn(n, dim)
+    if n > 3:
+        total[3] = 0  # ||v|| = 0: y = 0, gradient = dy / (count * eps)
+    deg = torch.randint(0, 6, (n,))
+    ptr = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(deg, 0)]).to(torch.int32)
+
+    class G:
+        in_ptr = ptr.to(DEV)
+
+    t_ref = total.clone().requires_grad_()
+    y_ref = torch.nn.functional.normalize(t_ref / (deg + 1).float().unsqueeze(1), p=2, dim=-1)
+    w = torch.randn(n, dim)
+    (y_ref * w).sum().backward()
+    t = total.to(DEV).requires_grad_()
+    y = ops.MeanL2Normalize.apply(t, G)
+    (y * w.to(DEV)).sum().backward()
+    torch.testing.assert_close(y.detach().cpu(), y_ref.detach(), rtol=1e-5, atol=1e-6)
+    ok = torch.ones(n, dtype=torch.bool)
+    if n > 3:
+        ok[3] = False
+        assert torch.isfinite(t.grad[3]).all()
+    torch.testing.assert_close(t.grad.cpu()[ok], t_ref.grad[ok], rtol=1e-4, atol=1e-5)
