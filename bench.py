@@ -275,14 +275,12 @@ def large_batch_sweep(dev, sizes, args):
     return out
 
 
-def cpu_baseline(graphs, seconds):
-    """the oracle's train step (same synthetic batch shape) on the host cores."""
+def _cpu_rate(graphs, threads, seconds):
     from oracle import chem as ochem
     from oracle import steps
     from pretrain_gnns_amd.data import synthetic
 
-    cores = usable_cores()
-    torch.set_num_threads(cores)
+    torch.set_num_threads(threads)
     torch.manual_seed(0)
     batch = synthetic.chem_masking_batch(graphs, seed=0)
     mods = [ochem.GNN(5, 300), torch.nn.Linear(300, 119), torch.nn.Linear(300, 4)]
@@ -297,9 +295,23 @@ def cpu_baseline(graphs, seconds):
         if el > seconds or n >= 200:
             break
     e = batch.edge_index.size(1)
-    return {"value": round(e * n / el, 1), "unit": "edges/s", "cores": cores, "kind": "port",
+    return e * n / el, n, e, el
+
+
+def cpu_baseline(graphs, seconds):
+    """the oracle's train step (same synthetic batch shape) on the host cores; SURVEY 8(d) also asks for
+    the reference's CPU-runnable config (batch 32) and a single-thread figure -- short samples of both
+    ride along under `also`."""
+    cores = usable_cores()
+    rate, n, e, el = _cpu_rate(graphs, cores, seconds)
+    also = {}
+    for name, g, t in (("batch32_%dthreads" % cores, 32, cores), ("batch%d_1thread" % graphs, graphs, 1)):
+        r, n2, _, el2 = _cpu_rate(g, t, seconds / 4)
+        also[name] = {"edges_per_s": round(r, 1), "steps": n2, "seconds": round(el2, 1)}
+    torch.set_num_threads(cores)
+    return {"value": round(rate, 1), "unit": "edges/s", "cores": cores, "kind": "port",
             "sample": "%d train steps (fwd+bwd+3xAdam) of the torch-CPU oracle on one %d-graph batch (%d edges), %.1f s"
-                      % (n, graphs, e, el)}
+                      % (n, graphs, e, el), "also": also}
 
 
 def main():

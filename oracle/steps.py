@@ -150,3 +150,20 @@ def chem_eval(model, batches):
             is_valid = y_true[:, i] ** 2 > 0
             roc_list.append(roc_auc((y_true[is_valid, i] + 1) / 2, y_scores[is_valid, i]))
     return sum(roc_list) / len(roc_list)
+
+
+def chem_masking_epoch(model_list, optimizer_list, loader, mask_edge=False, device=None):
+    """chem/pretrain_masking.py:37-78 (train()): one pass over ``loader``; the three averages divide by
+    the LAST step index, not the number of steps (:78) -- preserved."""
+    for m in model_list:
+        m.train()
+    loss_accum = acc_node_accum = acc_edge_accum = 0.0
+    step = 0
+    for step, batch in enumerate(loader):
+        if device is not None:
+            batch = batch.to(device)
+        loss, acc_node, acc_edge = chem_masking_step(model_list, optimizer_list, batch, mask_edge)
+        loss_accum += loss
+        acc_node_accum += acc_node
+        acc_edge_accum += acc_edge
+    return loss_accum / step, acc_node_accum / step, acc_edge_accum / step

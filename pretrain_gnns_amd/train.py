@@ -53,6 +53,24 @@ def chem_masking_step(model_list, optimizer_list, batch, mask_edge=False, readba
     return vals[0], vals[1] / n_node, vals[2] / n_edge
 
 
+def chem_masking_epoch(model_list, optimizer_list, loader, mask_edge=False, device=None, readback="end"):
+    """train() of chem/pretrain_masking.py:37-78: one pass over ``loader`` (a ResidentLoader yields batches
+    that already live on the GPU; host batches are moved with ``.to(device)``).  Returns the reference's
+    three epoch averages, which divide by the LAST step index rather than the step count (:78)."""
+    for m in model_list:
+        m.train()
+    loss_accum = acc_node_accum = acc_edge_accum = 0.0
+    step = 0
+    for step, batch in enumerate(loader):
+        if device is not None:
+            batch = batch.to(device)
+        loss, acc_node, acc_edge = chem_masking_step(model_list, optimizer_list, batch, mask_edge, readback)
+        loss_accum += loss
+        acc_node_accum += acc_node
+        acc_edge_accum += acc_edge
+    return loss_accum / step, acc_node_accum / step, acc_edge_accum / step
+
+
 class GraphedChemMaskingStep:
     """The same masking train step captured ONCE into a HIP graph and replayed (torch.cuda.CUDAGraph;
     the library's launches, memsets and its side-stream fork/join are ordinary stream work and are

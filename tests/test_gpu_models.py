@@ -177,6 +177,26 @@ def test_chem_masking_train_steps(mask_edge):
         assert float((ph.detach().cpu() - pr.detach()).abs().max()) < 1e-2, n
 
 
+def test_epoch_accuracy_matches_oracle_within_a_tenth_of_a_percent():
+    """SURVEY 8(d) accuracy check: the reference's own metric (compute_accuracy averaged over an epoch,
+    chem/pretrain_masking.py:30-31,54-55,78) from identical init and an identical stream of BASELINE-size
+    batches (256 graphs, ~1150 masked atoms each) must agree with the CPU oracle to +-0.1 % absolute."""
+    from pretrain_gnns_amd import train as ptrain
+    hchem, _ = _hip()
+    ref, hip = _pair(ochem.GNN, hchem.GNN, 5, 300, seed=21)
+    torch.manual_seed(22)
+    heads = [torch.nn.Linear(300, 119), torch.nn.Linear(300, 4)]
+    heads_d = [torch.nn.Linear(300, 119), torch.nn.Linear(300, 4)]
+    for a, b in zip(heads, heads_d):
+        b.load_state_dict(a.state_dict())
+    heads_d = [h.to(DEV) for h in heads_d]
+    stream = [synthetic.chem_masking_batch(256, seed=100 + i) for i in range(9)]
+    ref_out = steps.chem_masking_epoch([ref] + heads, _opt(ref, *heads), stream)
+    hip_out = ptrain.chem_masking_epoch([hip] + heads_d, _opt(hip, *heads_d), [b.clone() for b in stream], device=DEV)
+    assert abs(ref_out[1] - hip_out[1]) <= 1e-3, (ref_out, hip_out)          # epoch accuracy
+    assert abs(ref_out[0] - hip_out[0]) <= 2e-2 * abs(ref_out[0]), (ref_out, hip_out)  # epoch loss
+
+
 def test_product_train_step_mirrors_oracle_step():
     """pretrain_gnns_amd.train (what bench.py times) == oracle.steps on the same HIP model, for both
     readback placements, including with torch's fused Adam."""
