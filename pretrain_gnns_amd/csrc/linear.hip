@@ -325,6 +325,10 @@ inline int env_cfg() {
   return v ? atoi(v) : -1;
 }
 
+// At M = 6747 every tiling tried (64x160 with 4 or 8 waves, 64x64, 32x160, 32x320, 128x128; 2 or 3
+// stages; 16- or 32-deep k-steps) lands at 36-42 us per product, as does rocBLAS: 2.43 GFLOP is ~24 us at
+// the large-M rate plus a fixed ~10 us of dispatch ramp and drain, so that regime is bound by kernel
+// granularity, not by the tile shape.
 // kind: 0 = forward (both operands k-contiguous), 1 = backward-data (weights row-contiguous).
 // Measured on MI355X (tools/gemm_bench.py, M = 262144 / 6747, N,K in {300,600}): forward is best on
 // 64x160 / 64x64 at every M; backward-data prefers 128x304 once M is large, 64x160 below.
