@@ -125,9 +125,12 @@ def init_from_env(backend=None):
     if (world > 1 or os.environ.get("PGNN_DP_FORCE_INIT") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
-        if backend == "nccl":
+        if backend is None:  # "nccl" is RCCL on ROCm; PGNN_DP_BACKEND=gloo is a debugging aid
+            backend = os.environ.get("PGNN_DP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            # one process per GPU; more ranks than GPUs (several ranks sharing a device) only makes sense
+            # for functional tests with gloo -- RCCL refuses duplicate devices
+            local = local % torch.cuda.device_count() if backend != "nccl" else local
             torch.cuda.set_device(local)
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local, world
