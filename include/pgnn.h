@@ -96,6 +96,14 @@ int pgnn_chem_aggregate_fwd(const float* x, int64_t ldx, const int32_t* in_ptr,
                             const float* emb2, const float* dinv, float* out, int64_t ldo,
                             int64_t num_nodes, int64_t dim, pgnn_stream stream);
 
+/* chem GIN aggregation of h = relu?(coef[0]*z + coef[1]) computed on read: the BatchNorm(+ReLU) between
+ * two GIN layers (chem/model.py:269-273) folded into the next layer's gather, so h is never written to
+ * memory.  Bit-identical to pgnn_bn_fwd followed by pgnn_chem_aggregate_fwd.  dim <= 320. */
+int pgnn_chem_aggregate_bn_fwd(const float* z, int64_t ldz, const float* coef /*[2,dim]*/, int relu,
+                               const int32_t* in_ptr, const int32_t* in_src, const uint8_t* in_code,
+                               const float* emb1, const float* emb2, float* out, int64_t ldo,
+                               int64_t num_nodes, int64_t dim, pgnn_stream stream);
+
 /* Plain neighbour sum over any CSR (ptr, nbr):  out[i] = sum_p w * x[nbr_p] + w_ii * x[i].
  * Serves: backward of every aggregation w.r.t. x (with the transposed CSR: chem/model.py:49-52
  * under autograd), and the x-half of the bio GIN message concat (bio/model.py:54-55). */
@@ -155,6 +163,14 @@ int pgnn_bn_fwd(const float* x, int64_t ldx, const float* gamma, const float* be
 /* drop_p > 0 fuses the F.dropout that follows (chem/model.py:271-275): inverted dropout with keep
  * bits from a counter-based generator over (drop_seed, element) -- 16 bits per element, p resolved to
  * 1/65536 -- so the backward regenerates the mask from the same seed instead of reading it. */
+
+/* Statistics only: what pgnn_bn_fwd does before its normalise pass.  coef [2, dim] receives the
+ * affine form of the layer, y = coef[0]*x + coef[1], for a consumer that applies it on read
+ * (pgnn_chem_aggregate_bn_fwd). */
+int pgnn_bn_stats_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float momentum, float eps, int training,
+                      float* save_mean, float* save_invstd, float* coef, int64_t num_rows, int64_t dim,
+                      void* ws, size_t ws_bytes, pgnn_stream stream);
 
 /* Backward of the above (ReLU and dropout masks are recomputed, nothing else is kept). */
 int pgnn_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
@@ -229,7 +245,10 @@ int pgnn_chem_gin_layer_bwd(const float* dy, int64_t lddy, const float* agg, con
  * it including the two atom-embedding table gradients.  Same kernels and order as the per-layer calls
  * (bit-identical results).  Activations are caller-owned and contiguous:
  *   h0 [n,dim]; acts [num_layer][3][n][dim] = (agg, z, y) per layer; hid [num_layer][n][2dim];
- *   stats [num_layer][2][dim] = (batch mean, 1/std).  The output is acts[num_layer-1][2].
+ *   stats [num_layer][4][dim] = (batch mean, 1/std, scale a, shift b).  The output is acts[num_layer-1][2];
+ *   the y slot of earlier layers is only written when the BatchNorm output has to be materialised
+ *   (dropout, dim > 320, PGNN_FUSE_BN_AGG=0) -- otherwise the next layer's aggregation applies
+ *   relu(a*z+b) on read.
  * ------------------------------------------------------------------------------------------ */
 typedef struct pgnn_gin_layer {
   const float *emb1, *emb2;           /* edge_embedding1 [6,dim], edge_embedding2 [3,dim]   (model.py:32-33) */

@@ -31,6 +31,7 @@ PROTOTYPES = {
     "pgnn_group_workspace_bytes": (_sz, [_i64, _i64]),
     "pgnn_group_by_key": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
     "pgnn_chem_aggregate_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
+    "pgnn_chem_aggregate_bn_fwd": (_i, [_p, _i64, _p, _i, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
     "pgnn_neighbor_sum": (_i, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
     "pgnn_rowfeat_matmul_fwd": (_i, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i, _p]),
     "pgnn_rowfeat_matmul_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64]),
@@ -41,6 +42,7 @@ PROTOTYPES = {
     "pgnn_segment_broadcast": (_i, [_p, _i64, _p, _p, _i, _p, _i64, _i64, _i64, _p]),
     "pgnn_bn_workspace_bytes": (_sz, [_i64, _i64]),
     "pgnn_bn_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _f, _f, _i, _i, _p, _i64, _p, _p, _f, _u64, _i64, _i64, _p, _sz, _p]),
+    "pgnn_bn_stats_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _i64, _i64, _p, _sz, _p]),
     "pgnn_bn_bwd": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i, _i, _p, _i64, _p, _p, _f, _u64, _i64, _i64, _p, _sz,
                          _p]),
     "pgnn_mean_l2norm_fwd": (_i, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _p]),

@@ -341,12 +341,16 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 // NROW = ceil(8*gs/64) row-DMA instructions per step when known at compile time (their per-lane
 // byte offsets are then hoisted into registers: the loader issues a step with ~2 instructions per
 // KiB); NROW = 0 selects a generic run-time loop for other feature widths.
-template <bool TABLE, int P, int NROW>
+// PRE: the rows of x are pre-activations z of the previous layer's BatchNorm; every row read from LDS (or
+// from memory on the slow path) becomes relu?(a*z + b) with the SAME fmaf/fmaxf expression k_bn_apply
+// uses, so the previous layer's output is never materialised and the sums are bit-identical to
+// aggregating the materialised tensor.
+template <bool TABLE, int P, int NROW, bool PRE>
 __global__ void __launch_bounds__(704)
 k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ ptr,
                 const int32_t* __restrict__ nbr, const uint8_t* __restrict__ code,
                 const float* __restrict__ emb1, const float* __restrict__ emb2, float* __restrict__ out,
-                int64_t ldo, int n, int dim, int npb) {
+                int64_t ldo, int n, int dim, int npb, const float* __restrict__ pre_coef, int pre_relu) {
 #pragma clang fp contract(off)
   constexpr int NREG = P + 3, NBUF = P + 1;
   extern __shared__ __align__(16) float smem[];
@@ -434,6 +438,20 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
   // -------------------------------------------------------------------- consumer waves
   const int g = t / gs, c4 = t - g * gs;
   const bool active = g < kDmaG;
+  float4 pa = f4_zero(), pb = f4_zero();
+  if (PRE && active) {
+    pa = reinterpret_cast<const float4*>(pre_coef)[c4];
+    pb = reinterpret_cast<const float4*>(pre_coef + dim)[c4];
+  }
+  auto act = [&](float4 v) {
+    if (PRE) {
+      v = make_float4(fmaf(pa.x, v.x, pb.x), fmaf(pa.y, v.y, pb.y), fmaf(pa.z, v.z, pb.z), fmaf(pa.w, v.w, pb.w));
+      if (pre_relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+    }
+    return v;
+  };
   if (TABLE) {
     for (int q = t; q < kNumCodes * dim; q += cthreads) {
       const int c = q / dim, d = q - c * dim;
@@ -463,7 +481,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
     const int* idxB = idxL + (s % NBUF) * kDmaEdges;
     const int* codeB = codeL + (s % NBUF) * kDmaEdges;
     // the node's own row (self loop) does not depend on the edge list: fetch it first
-    float4 self = ring[slot_of(i) * gs + c4];
+    float4 self = act(ring[slot_of(i) * gs + c4]);
     if (TABLE) self = f4_add(self, T4[kSelfLoopCode * gs + c4]);
     float4 acc = f4_zero();
     // edges gathered per batch.  Measured on the roofline batch: 2 -> 225-234 us, 1 -> 240, 3/4 -> 245;
@@ -493,7 +511,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
         for (int j = 0; j < CH; ++j) {
           if (p + j < end) {
             const int sj = nbr[p + j];
-            float4 m = x4[(int64_t)sj * ldx4 + c4];
+            float4 m = act(x4[(int64_t)sj * ldx4 + c4]);
             if (TABLE) m = f4_add(m, T4[(int)code[p + j] * gs + c4]);
             acc = f4_add(acc, m);
           }
@@ -510,7 +528,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
           if (p + j < end) {
-            float4 m = v[j];
+            float4 m = act(v[j]);
             if (TABLE) m = f4_add(m, tv[j]);
             acc = f4_add(acc, m);
           }
@@ -522,10 +540,10 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
   }
 }
 
-template <bool TABLE, int P, int NROW>
+template <bool TABLE, int P, int NROW, bool PRE = false>
 int launch_aggregate_dma_p(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* nbr, const uint8_t* code,
                            const float* emb1, const float* emb2, float* out, int64_t ldo, int64_t n, int64_t dim,
-                           hipStream_t st) {
+                           hipStream_t st, const float* pre_coef = nullptr, int pre_relu = 0) {
   const int gs = (int)(dim / 4);
   const int cthreads = (int)align_up((size_t)kDmaG * gs, kWave);
   const int threads = cthreads + kWave;
@@ -538,10 +556,21 @@ int launch_aggregate_dma_p(const float* x, int64_t ldx, const int32_t* ptr, cons
   npb = ceil_div(npb, kDmaG) * kDmaG;
   if (npb > kDmaMaxNodes) npb = kDmaMaxNodes;
   const int grid = (int)ceil_div(n, npb);
-  allow_big_lds((const void*)k_aggregate_dma<TABLE, P, NROW>, lds);
-  hipLaunchKernelGGL((k_aggregate_dma<TABLE, P, NROW>), dim3(grid), dim3(threads), lds, st, x, ldx, ptr, nbr, code,
-                     emb1, emb2, out, ldo, (int)n, (int)dim, (int)npb);
+  allow_big_lds((const void*)k_aggregate_dma<TABLE, P, NROW, PRE>, lds);
+  hipLaunchKernelGGL((k_aggregate_dma<TABLE, P, NROW, PRE>), dim3(grid), dim3(threads), lds, st, x, ldx, ptr, nbr, code,
+                     emb1, emb2, out, ldo, (int)n, (int)dim, (int)npb, pre_coef, pre_relu);
   return check_launch("aggregate_dma");
+}
+
+// BatchNorm(+ReLU)-on-read variant: D = 300 gets the tuned instantiation, every other width the generic one
+int launch_aggregate_dma_pre(const float* z, int64_t ldz, const float* coef, int relu, const int32_t* ptr,
+                             const int32_t* nbr, const uint8_t* code, const float* emb1, const float* emb2, float* out,
+                             int64_t ldo, int64_t n, int64_t dim, hipStream_t st) {
+  const int nrow = (int)ceil_div(kDmaG * (dim / 4), kWave);
+  const bool small_ld = ldz * 4 * kDmaG < (1ll << 31);
+  if (nrow == 10 && small_ld)
+    return launch_aggregate_dma_p<true, 2, 10, true>(z, ldz, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, coef, relu);
+  return launch_aggregate_dma_p<true, 2, 0, true>(z, ldz, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, coef, relu);
 }
 
 template <bool TABLE>
@@ -949,6 +978,16 @@ int pgnn_chem_aggregate_fwd(const float* x, int64_t ldx, const int32_t* in_ptr, 
   hipStream_t st = (hipStream_t)stream;
   if (dinv) return launch_aggregate<true, true>(x, ldx, in_ptr, in_src, in_code, emb1, emb2, dinv, out, ldo, n, dim, st);
   return launch_aggregate<true, false>(x, ldx, in_ptr, in_src, in_code, emb1, emb2, dinv, out, ldo, n, dim, st);
+}
+
+int pgnn_chem_aggregate_bn_fwd(const float* z, int64_t ldz, const float* coef, int relu, const int32_t* in_ptr,
+                               const int32_t* in_src, const uint8_t* in_code, const float* emb1, const float* emb2,
+                               float* out, int64_t ldo, int64_t n, int64_t dim, pgnn_stream stream) {
+  if (int rc = check_dim(dim)) return rc;
+  PGNN_REQUIRE(n > 0 && ldz % 4 == 0 && ldo % 4 == 0 && coef, "bad aggregate_bn arguments");
+  PGNN_REQUIRE(dim <= 320, "aggregate_bn: feature width above 320 is not supported (materialise BatchNorm's output instead)");
+  return launch_aggregate_dma_pre(z, ldz, coef, relu, in_ptr, in_src, in_code, emb1, emb2, out, ldo, n, dim,
+                                  (hipStream_t)stream);
 }
 
 // diagnostics: plain float4 grid-stride copy -- the streaming ceiling the aggregation is measured against

@@ -304,6 +304,29 @@ int pgnn_bn_fwd(const float* x, int64_t ldx, const float* gamma, const float* be
   return check_launch("bn_fwd");
 }
 
+int pgnn_bn_stats_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, float momentum, float eps, int training, float* save_mean,
+                      float* save_invstd, float* coef, int64_t n, int64_t dim, void* ws, size_t ws_bytes,
+                      pgnn_stream stream) {
+  if (int rc = check_args(n, dim)) return rc;
+  PGNN_REQUIRE(ldx % 4 == 0 && coef, "batchnorm: leading dimension must be a multiple of 4, coef must be given");
+  PGNN_REQUIRE(training || (running_mean && running_var), "batchnorm eval needs running statistics");
+  if (ws_bytes < pgnn_bn_workspace_bytes(n, dim)) {
+    set_error("batchnorm workspace too small");
+    return PGNN_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  Carver cv(ws);
+  const int nblk = stat_blocks(n);
+  float* partial = cv.take<float>((size_t)nblk * 2 * dim);
+  if (training)
+    hipLaunchKernelGGL(k_bn_stats_partial, dim3(nblk), dim3(stat_threads(dim)), (size_t)8 * dim * sizeof(float), st, x,
+                       ldx, (int)n, (int)(dim / 4), partial);
+  hipLaunchKernelGGL(k_bn_stats_final, dim3((int)ceil_div(dim, 16)), dim3(256), 0, st, partial, nblk, x, gamma, beta,
+                     running_mean, running_var, momentum, eps, training, (int)n, (int)dim, save_mean, save_invstd, coef);
+  return check_launch("bn_stats_fwd");
+}
+
 int pgnn_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                 const float* beta, const float* save_mean, const float* save_invstd, int training, int relu,
                 float* dx, int64_t lddx, float* dgamma, float* dbeta, float drop_p, uint64_t drop_seed, int64_t n,

@@ -176,17 +176,40 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
   int rc;
   if ((rc = pgnn_embed_fwd(x_idx, 2, xemb1, rows1, xemb2, rows2, h0, dim, n, dim, status, stream))) return rc;
   const size_t nd = (size_t)n * dim;
-  const float* h = h0;
+  // Between two layers the BatchNorm(+ReLU) output is not written: the next layer's aggregation applies
+  // relu(a*z + b) on read (pgnn_chem_aggregate_bn_fwd).  Needs the statistics only; dropout, wide
+  // features and PGNN_FUSE_BN_AGG=0 take the materialising route.
+  const char* fv = getenv("PGNN_FUSE_BN_AGG");
+  const bool fuse = drop_p == 0.f && dim <= 320 && !(fv && atoi(fv) == 0);
   for (int l = 0; l < num_layer; ++l) {
     const pgnn_gin_layer& p = layers[l];
-    float* a = acts + (size_t)l * 3 * nd;
-    if ((rc = pgnn_chem_gin_layer_fwd(h, dim, in_ptr, in_src, in_code, p.emb1, p.emb2, p.w1, p.b1, p.w2, p.b2, p.gamma,
-                                      p.beta, p.running_mean, p.running_var, p.momentum, p.eps, training,
-                                      l != num_layer - 1, a, hid + (size_t)l * 2 * nd, a + nd, a + 2 * nd,
-                                      stats + (size_t)l * 2 * dim, stats + (size_t)l * 2 * dim + dim, drop_p,
-                                      drop_seed + (uint64_t)l, n, dim, ws, ws_bytes, stream)))
-      return rc;
-    h = a + 2 * nd;
+    float* a = acts + (size_t)l * 3 * nd;  // agg, z, y
+    float* agg = a;
+    float* z = a + nd;
+    float* y = a + 2 * nd;
+    float* hd = hid + (size_t)l * 2 * nd;
+    float* st = stats + (size_t)l * 4 * dim;  // mean, invstd, a, b
+    const bool last = l == num_layer - 1;
+    if (l == 0) {
+      rc = pgnn_chem_aggregate_fwd(h0, dim, in_ptr, in_src, in_code, p.emb1, p.emb2, nullptr, agg, dim, n, dim, stream);
+    } else if (fuse) {
+      const float* zprev = acts + (size_t)(l - 1) * 3 * nd + nd;
+      rc = pgnn_chem_aggregate_bn_fwd(zprev, dim, stats + (size_t)(l - 1) * 4 * dim + 2 * dim, 1, in_ptr, in_src, in_code,
+                                      p.emb1, p.emb2, agg, dim, n, dim, stream);
+    } else {
+      const float* yprev = acts + (size_t)(l - 1) * 3 * nd + 2 * nd;
+      rc = pgnn_chem_aggregate_fwd(yprev, dim, in_ptr, in_src, in_code, p.emb1, p.emb2, nullptr, agg, dim, n, dim, stream);
+    }
+    if (rc) return rc;
+    if ((rc = pgnn_linear_fwd(agg, dim, p.w1, p.b1, hd, 2 * dim, n, dim, 2 * dim, 1, stream))) return rc;
+    if ((rc = pgnn_linear_fwd(hd, 2 * dim, p.w2, p.b2, z, dim, n, 2 * dim, dim, 0, stream))) return rc;
+    if (fuse && !last)
+      rc = pgnn_bn_stats_fwd(z, dim, p.gamma, p.beta, p.running_mean, p.running_var, p.momentum, p.eps, training, st,
+                             st + dim, st + 2 * dim, n, dim, ws, ws_bytes, stream);
+    else
+      rc = pgnn_bn_fwd(z, dim, p.gamma, p.beta, p.running_mean, p.running_var, p.momentum, p.eps, training, !last, y, dim,
+                       st, st + dim, drop_p, drop_seed + (uint64_t)l, n, dim, ws, ws_bytes, stream);
+    if (rc) return rc;
   }
   return PGNN_OK;
 }
@@ -254,7 +277,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     const float* agg = a;
     const float* z = a + nd;
     const float* hd = hid + (size_t)l * 2 * nd;
-    const float* mean = stats + (size_t)l * 2 * dim;
+    const float* mean = stats + (size_t)l * 4 * dim;
     // buffer set b was last read by the side stream two layers ago
     if (sd && l + 2 <= num_layer - 1) PGNN_HIP(hipStreamWaitEvent(main, sd->lag[b], 0));
     if ((rc = pgnn_bn_bwd(g, ldg, z, dim, p.gamma, p.beta, mean, mean + dim, training, l != num_layer - 1, dz[b], dim,

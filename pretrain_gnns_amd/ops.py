@@ -652,7 +652,7 @@ class ChemGINStack(Function):
         h0 = torch.empty(n, dim, dtype=torch.float32, device=dev)
         acts = torch.empty(L, 3, n, dim, dtype=torch.float32, device=dev)
         hid = torch.empty(L, n, 2 * dim, dtype=torch.float32, device=dev)
-        stats = torch.empty(L, 2, dim, dtype=torch.float32, device=dev)
+        stats = torch.empty(L, 4, dim, dtype=torch.float32, device=dev)  # mean, 1/std, scale, shift
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         layers = (_lib.GinLayer * L)()
         for l in range(L):

@@ -430,3 +430,38 @@ def test_mean_l2norm_fwd_bwd(n, dim):
         ok[3] = False
         assert torch.isfinite(t.grad[3]).all()
     torch.testing.assert_close(t.grad.cpu()[ok], t_ref.grad[ok], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("dim,relu", [(300, 1), (300, 0), (64, 1), (128, 1), (320, 1)])
+def test_aggregate_with_batchnorm_on_read_is_bit_identical(dim, relu):
+    """pgnn_chem_aggregate_bn_fwd(z, coef) == pgnn_chem_aggregate_fwd(relu?(coef0*z + coef1)): the
+    BatchNorm(+ReLU) between two GIN layers applied while gathering, never materialised."""
+    from pretrain_gnns_amd import ops
+    b = synthetic.chem_plain_batch(96, seed=dim).to(DEV)
+    n = b.x.size(0)
+    g = ops.build_chem_graph(b.edge_index, b.edge_attr, n)
+    torch.manual_seed(dim + relu)
+    z = torch.randn(n, dim, device=DEV) * 1.5 + 0.2
+    gamma, beta = torch.rand(dim, device=DEV) + 0.5, torch.randn(dim, device=DEV) * 0.2
+    e1, e2 = torch.randn(6, dim, device=DEV), torch.randn(3, dim, device=DEV)
+    lib, sp = ops.load(), ops.stream_ptr()
+    ws = torch.empty(int(lib.pgnn_bn_workspace_bytes(n, dim)), dtype=torch.uint8, device=DEV)
+    y = torch.empty(n, dim, device=DEV)
+    mean, invstd = torch.empty(dim, device=DEV), torch.empty(dim, device=DEV)
+    ops.check(lib.pgnn_bn_fwd(z.data_ptr(), dim, gamma.data_ptr(), beta.data_ptr(), None, None, 0.1, 1e-5, 1, relu,
+                              y.data_ptr(), dim, mean.data_ptr(), invstd.data_ptr(), 0.0, 0, n, dim, ws.data_ptr(),
+                              ws.numel(), sp), "bn")
+    want = torch.empty(n, dim, device=DEV)
+    ops.check(lib.pgnn_chem_aggregate_fwd(y.data_ptr(), dim, g.in_ptr.data_ptr(), g.in_src.data_ptr(), g.in_code.data_ptr(),
+                                          e1.data_ptr(), e2.data_ptr(), None, want.data_ptr(), dim, n, dim, sp), "agg")
+    coef = torch.empty(2, dim, device=DEV)
+    mean2, invstd2 = torch.empty(dim, device=DEV), torch.empty(dim, device=DEV)
+    ops.check(lib.pgnn_bn_stats_fwd(z.data_ptr(), dim, gamma.data_ptr(), beta.data_ptr(), None, None, 0.1, 1e-5, 1,
+                                    mean2.data_ptr(), invstd2.data_ptr(), coef.data_ptr(), n, dim, ws.data_ptr(),
+                                    ws.numel(), sp), "stats")
+    got = torch.empty(n, dim, device=DEV)
+    ops.check(lib.pgnn_chem_aggregate_bn_fwd(z.data_ptr(), dim, coef.data_ptr(), relu, g.in_ptr.data_ptr(),
+                                             g.in_src.data_ptr(), g.in_code.data_ptr(), e1.data_ptr(), e2.data_ptr(),
+                                             got.data_ptr(), dim, n, dim, sp), "agg_bn")
+    assert torch.equal(mean, mean2) and torch.equal(invstd, invstd2)
+    assert torch.equal(got, want)
