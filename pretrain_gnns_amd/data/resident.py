@@ -81,23 +81,28 @@ class ResidentDataset:
         return cls(data.x, data.edge_index, data.edge_attr, slices["x"], slices["edge_attr"], device)
 
     # ------------------------------------------------------------------ batching
-    def _ids(self, graph_ids):
+    def _ids(self, graph_ids, ids_device=None):
         ids_host = np.asarray(graph_ids, dtype=np.int64).reshape(-1)
         if ids_host.size == 0:
             raise ValueError("empty batch")
         if ids_host.min() < 0 or ids_host.max() >= self.num_graphs:
             raise IndexError("graph id out of range")
-        return ids_host, torch.from_numpy(ids_host).to(self.device, non_blocking=True)
+        if ids_device is None:
+            ids_device = torch.from_numpy(ids_host).to(self.device, non_blocking=True)
+        elif ids_device.numel() != ids_host.size or ids_device.dtype != torch.int64 or not ids_device.is_contiguous():
+            raise ValueError("ids_device must be the int64 device copy of graph_ids")
+        return ids_host, ids_device
 
     def collate(self, graph_ids, mask_rate=0.0, seed=0, mask_edge=False, masked_atom_indices=None,
-                masked_edge_idx=None, mask_target=None):
+                masked_edge_idx=None, mask_target=None, ids_device=None):
         """BatchMasking.from_data_list over ``graph_ids``, plus the masking transform when ``mask_rate`` > 0:
         ``mask_target`` "atom" = chem MaskAtom (default for integer node features; ``mask_edge`` adds its
         bond masking), "edge" = bio MaskEdge (default for float features).  Explicit
         ``masked_atom_indices`` / ``masked_edge_idx`` (batch positions; the reference's debugging hook)
-        replace the random draw."""
+        replace the random draw.  ``ids_device``: the same ids already on the GPU (ResidentLoader uploads a
+        whole epoch's permutation once instead of one small copy per step)."""
         lib, sp, dev = load(), stream_ptr(), self.device
-        ids_host, ids = self._ids(graph_ids)
+        ids_host, ids = self._ids(graph_ids, ids_device)
         b = ids_host.size
         n, e = int(self._nodes[ids_host].sum()), int(self._edges[ids_host].sum())
         if mask_target is None:
@@ -223,6 +228,12 @@ class ResidentLoader:
     def __iter__(self):
         epoch = self.epoch
         self.epoch += 1
-        for step, ids in enumerate(self.batch_ids(epoch)):
+        batches = self.batch_ids(epoch)
+        if not batches:
+            return
+        flat = torch.from_numpy(np.concatenate(batches)).to(self.ds.device)  # one upload per epoch
+        off = 0
+        for step, ids in enumerate(batches):
             yield self.ds.collate(ids, mask_rate=self.mask_rate, seed=(self.seed * 1000003 + epoch) * 1000003 + step,
-                                  mask_edge=self.mask_edge)
+                                  mask_edge=self.mask_edge, ids_device=flat[off:off + ids.size])
+            off += ids.size
