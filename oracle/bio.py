@@ -104,6 +104,36 @@ class GraphSAGEConv(_InputLayerMixin, nn.Module):
         return F.normalize(out, p=2, dim=-1)
 
 
+class GATConv(_InputLayerMixin, nn.Module):
+    """bio/model.py:117-181."""
+
+    def __init__(self, emb_dim, heads=2, negative_slope=0.2, aggr="add", input_layer=False):
+        super().__init__()
+        self.aggr, self.emb_dim, self.heads, self.negative_slope = aggr, emb_dim, heads, negative_slope
+        self.weight_linear = nn.Linear(emb_dim, heads * emb_dim)
+        self.att = nn.Parameter(torch.Tensor(1, heads, 2 * emb_dim))
+        self.bias = nn.Parameter(torch.Tensor(emb_dim))
+        self.edge_encoder = nn.Linear(NUM_EDGE_FEATURES, heads * emb_dim)
+        self.input_layer = input_layer
+        if input_layer:
+            self.input_node_embeddings = nn.Embedding(2, emb_dim)
+            nn.init.xavier_uniform_(self.input_node_embeddings.weight.data)
+        pyg.glorot_(self.att)
+        self.bias.data.zero_()
+
+    def forward(self, x, edge_index, edge_attr):
+        n = x.size(0)
+        ei, ea = _with_self_loops(edge_index, edge_attr, n)
+        ee = self.edge_encoder(ea).view(-1, self.heads, self.emb_dim)
+        x = self._maybe_embed_input(x)
+        xh = self.weight_linear(x).view(-1, self.heads, self.emb_dim)
+        x_i, x_j = xh[ei[0]], xh[ei[1]] + ee
+        alpha = (torch.cat([x_i, x_j], dim=-1) * self.att).sum(dim=-1)
+        alpha = pyg.softmax(F.leaky_relu(alpha, self.negative_slope), ei[0], n)
+        out = pyg.scatter_add(x_j * alpha.view(-1, self.heads, 1), ei[0], n)
+        return out.mean(dim=1) + self.bias
+
+
 class GNN(nn.Module):
     """bio/model.py:227-290 (JK last / sum)."""
 
@@ -112,7 +142,7 @@ class GNN(nn.Module):
         self.num_layer, self.drop_ratio, self.JK = num_layer, drop_ratio, JK
         if num_layer < 2:
             raise ValueError("Number of GNN layers must be greater than 1.")
-        conv = {"gin": GINConv, "gcn": GCNConv, "graphsage": GraphSAGEConv}[gnn_type]
+        conv = {"gin": GINConv, "gcn": GCNConv, "graphsage": GraphSAGEConv, "gat": GATConv}[gnn_type]
         self.gnns = nn.ModuleList([conv(emb_dim, input_layer=(layer == 0)) for layer in range(num_layer)])
 
     def forward(self, x, edge_index, edge_attr):
@@ -131,7 +161,7 @@ class GNN(nn.Module):
 
 
 class GNN_graphpred(nn.Module):
-    """bio/model.py:293-347 (sum / mean / max pooling only)."""
+    """bio/model.py:293-347."""
 
     def __init__(self, num_layer, emb_dim, num_tasks, JK="last", drop_ratio=0, graph_pooling="mean", gnn_type="gin"):
         super().__init__()
@@ -141,9 +171,12 @@ class GNN_graphpred(nn.Module):
             raise ValueError("Number of GNN layers must be greater than 1.")
         self.gnn = GNN(num_layer, emb_dim, JK, drop_ratio, gnn_type=gnn_type)
         pools = {"sum": pyg.global_add_pool, "mean": pyg.global_mean_pool, "max": pyg.global_max_pool}
-        if graph_pooling not in pools:
+        if graph_pooling in pools:
+            self.pool = pools[graph_pooling]
+        elif graph_pooling == "attention":  # :331-332
+            self.pool = pyg.GlobalAttention(gate_nn=nn.Linear(emb_dim, 1))
+        else:
             raise ValueError("Invalid graph pooling type.")
-        self.pool = pools[graph_pooling]
         self.graph_pred_linear = nn.Linear(2 * emb_dim, num_tasks)
 
     def from_pretrained(self, model_file):

@@ -109,6 +109,34 @@ class GraphSAGEConv(_BondEmbedding, nn.Module):
         return F.normalize(out, p=2, dim=-1)  # update, :201-202
 
 
+class GATConv(nn.Module):
+    """chem/model.py:107-162: 2-head attention over (W x_j + b + e_ij) incl. the self loop, heads averaged."""
+
+    def __init__(self, emb_dim, heads=2, negative_slope=0.2, aggr="add"):
+        super().__init__()
+        self.aggr, self.emb_dim, self.heads, self.negative_slope = aggr, emb_dim, heads, negative_slope
+        self.weight_linear = nn.Linear(emb_dim, heads * emb_dim)
+        self.att = nn.Parameter(torch.Tensor(1, heads, 2 * emb_dim))
+        self.bias = nn.Parameter(torch.Tensor(emb_dim))
+        self.edge_embedding1 = nn.Embedding(NUM_BOND_TYPE, heads * emb_dim)
+        self.edge_embedding2 = nn.Embedding(NUM_BOND_DIRECTION, heads * emb_dim)
+        nn.init.xavier_uniform_(self.edge_embedding1.weight.data)
+        nn.init.xavier_uniform_(self.edge_embedding2.weight.data)
+        pyg.glorot_(self.att)
+        self.bias.data.zero_()
+
+    def forward(self, x, edge_index, edge_attr):
+        n = x.size(0)
+        ei, ea = _with_self_loops(edge_index, edge_attr, n)
+        ee = (self.edge_embedding1(ea[:, 0]) + self.edge_embedding2(ea[:, 1])).view(-1, self.heads, self.emb_dim)
+        xh = self.weight_linear(x).view(-1, self.heads, self.emb_dim)
+        x_i, x_j = xh[ei[0]], xh[ei[1]] + ee  # :147-150
+        alpha = (torch.cat([x_i, x_j], dim=-1) * self.att).sum(dim=-1)
+        alpha = pyg.softmax(F.leaky_relu(alpha, self.negative_slope), ei[0], n)
+        out = pyg.scatter_add(x_j * alpha.view(-1, self.heads, 1), ei[0], n)
+        return out.mean(dim=1) + self.bias  # update, :158-162
+
+
 class GNN(nn.Module):
     """chem/model.py:206-290."""
 
@@ -121,7 +149,7 @@ class GNN(nn.Module):
         self.x_embedding2 = nn.Embedding(NUM_CHIRALITY_TAG, emb_dim)
         nn.init.xavier_uniform_(self.x_embedding1.weight.data)
         nn.init.xavier_uniform_(self.x_embedding2.weight.data)
-        conv = {"gin": GINConv, "gcn": GCNConv, "graphsage": GraphSAGEConv}[gnn_type]
+        conv = {"gin": GINConv, "gcn": GCNConv, "graphsage": GraphSAGEConv, "gat": GATConv}[gnn_type]
         self.gnns = nn.ModuleList([conv(emb_dim) for _ in range(num_layer)])
         self.batch_norms = nn.ModuleList([nn.BatchNorm1d(emb_dim) for _ in range(num_layer)])
 
@@ -154,7 +182,7 @@ class GNN(nn.Module):
 
 
 class GNN_graphpred(nn.Module):
-    """chem/model.py:293-369 (sum / mean / max pooling only)."""
+    """chem/model.py:293-369."""
 
     def __init__(self, num_layer, emb_dim, num_tasks, JK="last", drop_ratio=0, graph_pooling="mean", gnn_type="gin"):
         super().__init__()
@@ -164,11 +192,18 @@ class GNN_graphpred(nn.Module):
             raise ValueError("Number of GNN layers must be greater than 1.")
         self.gnn = GNN(num_layer, emb_dim, JK, drop_ratio, gnn_type=gnn_type)
         pools = {"sum": pyg.global_add_pool, "mean": pyg.global_mean_pool, "max": pyg.global_max_pool}
-        if graph_pooling not in pools:
-            raise ValueError("Invalid graph pooling type.")
-        self.pool = pools[graph_pooling]
         width = (num_layer + 1) * emb_dim if JK == "concat" else emb_dim
-        self.graph_pred_linear = nn.Linear(width, num_tasks)
+        self.mult = 1
+        if graph_pooling in pools:
+            self.pool = pools[graph_pooling]
+        elif graph_pooling == "attention":  # :329-333
+            self.pool = pyg.GlobalAttention(gate_nn=nn.Linear(width, 1))
+        elif graph_pooling[:-1] == "set2set":  # :334-339, :344-345
+            self.pool = pyg.Set2Set(width, int(graph_pooling[-1]))
+            self.mult = 2
+        else:
+            raise ValueError("Invalid graph pooling type.")
+        self.graph_pred_linear = nn.Linear(self.mult * width, num_tasks)
 
     def from_pretrained(self, model_file):
         self.gnn.load_state_dict(torch.load(model_file, map_location="cpu"))

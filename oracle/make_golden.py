@@ -34,7 +34,7 @@ def _fixture(kind, ckpt, model, batch):
     model.train()
     out_train = model(batch.x, batch.edge_index, batch.edge_attr)
     out_train.square().mean().backward()
-    first = next(n for n, _ in model.named_parameters() if n.endswith("linear.weight"))
+    first = next(n for n, _ in model.named_parameters() if n.endswith("linear.weight"))  # also GAT's weight_linear
     grad = dict(model.named_parameters())[first].grad.clone()
     return {
         "kind": kind, "checkpoint": ckpt, "state_dict": {k: v.clone() for k, v in sd.items()},
@@ -58,6 +58,12 @@ def main():
     fx = _fixture("bio", "bio/model_architecture/graphsage_masking.pth", obio.GNN(5, 300, gnn_type="graphsage"),
                   synthetic.bio_masking_batch(3, seed=14))
     torch.save(fx, os.path.join(OUT, "bio_graphsage_masking.pt"))
+    fx = _fixture("chem", "chem/model_architecture/gat_contextpred.pth", ochem.GNN(5, 300, gnn_type="gat"),
+                  synthetic.chem_plain_batch(6, seed=15))
+    torch.save(fx, os.path.join(OUT, "chem_gat_contextpred.pt"))
+    fx = _fixture("bio", "bio/model_architecture/gat_masking.pth", obio.GNN(5, 300, gnn_type="gat"),
+                  synthetic.bio_masking_batch(3, seed=16))
+    torch.save(fx, os.path.join(OUT, "bio_gat_masking.pt"))
     # vocabulary / layout constants the reference fixes (chem/model.py:9-13,43; chem/util.py:212-213)
     torch.save({"num_atom_type": 120, "num_chirality_tag": 3, "num_bond_type": 6, "num_bond_direction": 3,
                 "self_loop_bond_type": 4, "atom_mask_token": 119, "bond_mask_token": 5,

@@ -48,6 +48,59 @@ def propagate_mean(edge_index, x_j_source, per_edge_term, combine, num_nodes):
     return scatter_mean(msg, edge_index[0], num_nodes)
 
 
+def softmax(src, index, num_nodes):
+    """torch_geometric.utils.softmax of 1.0.3 (chem/model.py:155): per index group, subtract the group
+    max, exponentiate, divide by the group sum + 1e-16."""
+    shape = (num_nodes,) + tuple(src.shape[1:])
+    mx = torch.full(shape, float("-inf"), dtype=src.dtype, device=src.device)
+    mx = mx.scatter_reduce(0, index.view(-1, *([1] * (src.dim() - 1))).expand_as(src), src, reduce="amax", include_self=True)
+    out = (src - mx[index]).exp()
+    return out / (scatter_add(out, index, num_nodes)[index] + 1e-16)
+
+
+def glorot_(tensor):
+    """torch_geometric.nn.inits.glorot: U(-a, a), a = sqrt(6 / (size(-2) + size(-1)))."""
+    a = (6.0 / (tensor.size(-2) + tensor.size(-1))) ** 0.5
+    return tensor.data.uniform_(-a, a)
+
+
+class GlobalAttention(torch.nn.Module):
+    """torch_geometric.nn.GlobalAttention(gate_nn) of 1.0.3 (chem/model.py:329-333): softmax of the gate
+    over the nodes of a graph, then the gate-weighted sum."""
+
+    def __init__(self, gate_nn):
+        super().__init__()
+        self.gate_nn = gate_nn
+
+    def forward(self, x, batch, size=None):
+        size = int(batch.max().item()) + 1 if size is None else size
+        gate = softmax(self.gate_nn(x).view(-1, 1), batch, size)
+        return scatter_add(gate * x, batch, size)
+
+
+class Set2Set(torch.nn.Module):
+    """torch_geometric.nn.Set2Set(in_channels, processing_steps) of 1.0.3 (chem/model.py:334-339)."""
+
+    def __init__(self, in_channels, processing_steps, num_layers=1):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, 2 * in_channels
+        self.processing_steps, self.num_layers = processing_steps, num_layers
+        self.lstm = torch.nn.LSTM(self.out_channels, self.in_channels, num_layers)
+
+    def forward(self, x, batch):
+        size = int(batch.max().item()) + 1
+        h = (x.new_zeros((self.num_layers, size, self.in_channels)), x.new_zeros((self.num_layers, size, self.in_channels)))
+        q_star = x.new_zeros(size, self.out_channels)
+        for _ in range(self.processing_steps):
+            q, h = self.lstm(q_star.unsqueeze(0), h)
+            q = q.view(size, self.in_channels)
+            e = (x * q[batch]).sum(dim=-1, keepdim=True)
+            a = softmax(e, batch, size)
+            r = scatter_add(a * x, batch, size)
+            q_star = torch.cat([q, r], dim=-1)
+        return q_star
+
+
 def global_add_pool(x, batch, size=None):
     size = int(batch.max().item()) + 1 if size is None else size
     return scatter_add(x, batch, size)

@@ -1,0 +1,80 @@
+"""Attention-flavoured parts of the class surface: GAT message passing, GlobalAttention
+and Set2Set pooling.
+
+These are NOT on the north-star hot path (GIN/GCN message passing) and carry no performance claim: the
+dense projections run on the library's MFMA GEMM, the per-edge softmax / weighted scatter is a plain
+composition of torch GPU ops (gathers, ``scatter_reduce``, ``index_add_`` -- atomic, hence reproducible
+only to rounding), exactly the shape of computation the reference performs through torch_geometric.
+They exist so that every ``gnn_type`` / ``graph_pooling`` value of the reference's ``GNN`` /
+``GNN_graphpred`` constructs, loads the shipped ``gat_*.pth`` checkpoints and trains on the GPU.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def segment_softmax(src, index, num_segments):
+    """torch_geometric.utils.softmax (1.0.3): per segment subtract the max, exp, divide by sum + 1e-16."""
+    idx = index.view(-1, *([1] * (src.dim() - 1))).expand_as(src)
+    mx = torch.full((num_segments,) + tuple(src.shape[1:]), float("-inf"), dtype=src.dtype, device=src.device)
+    mx = mx.scatter_reduce(0, idx, src, reduce="amax", include_self=True)
+    out = (src - mx[index]).exp()
+    den = torch.zeros((num_segments,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device).index_add_(0, index, out)
+    return out / (den[index] + 1e-16)
+
+
+def glorot_(tensor):
+    a = (6.0 / (tensor.size(-2) + tensor.size(-1))) ** 0.5
+    return tensor.data.uniform_(-a, a)
+
+
+def gat_propagate(xh, edge_index, edge_emb, self_emb, att, bias, heads, negative_slope):
+    """message / softmax / aggregate / update of GATConv (chem/model.py:147-162, bio/model.py:165-180).
+
+    xh [N, heads*D] projected node features; edge_emb [E, heads*D] per-edge embedding; self_emb
+    [heads*D] the self-loop embedding; returns [N, D]."""
+    n, d = xh.size(0), xh.size(1) // heads
+    loop = torch.arange(n, device=xh.device, dtype=edge_index.dtype)
+    dst = torch.cat([edge_index[0], loop])
+    src = torch.cat([edge_index[1], loop])
+    ee = torch.cat([edge_emb, self_emb.unsqueeze(0).expand(n, -1)], dim=0).view(-1, heads, d)
+    xh = xh.view(n, heads, d)
+    x_j = xh[src] + ee
+    alpha = (xh[dst] * att[:, :, :d]).sum(-1) + (x_j * att[:, :, d:]).sum(-1)
+    alpha = segment_softmax(F.leaky_relu(alpha, negative_slope), dst, n)
+    out = torch.zeros(n, heads, d, dtype=xh.dtype, device=xh.device).index_add_(0, dst, x_j * alpha.unsqueeze(-1))
+    return out.mean(dim=1) + bias
+
+
+class GlobalAttention(torch.nn.Module):
+    """torch_geometric.nn.GlobalAttention(gate_nn) as used by chem/model.py:329-333."""
+
+    def __init__(self, gate_nn):
+        super().__init__()
+        self.gate_nn = gate_nn
+
+    def forward(self, x, batch, size=None):
+        size = int(batch.max().item()) + 1 if size is None else size
+        gate = segment_softmax(self.gate_nn(x).view(-1, 1), batch, size)
+        return torch.zeros(size, x.size(1), dtype=x.dtype, device=x.device).index_add_(0, batch, gate * x)
+
+
+class Set2Set(torch.nn.Module):
+    """torch_geometric.nn.Set2Set(in_channels, processing_steps) as used by chem/model.py:334-339."""
+
+    def __init__(self, in_channels, processing_steps, num_layers=1):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, 2 * in_channels
+        self.processing_steps, self.num_layers = processing_steps, num_layers
+        self.lstm = torch.nn.LSTM(self.out_channels, self.in_channels, num_layers)
+
+    def forward(self, x, batch):
+        size = int(batch.max().item()) + 1
+        h = (x.new_zeros((self.num_layers, size, self.in_channels)), x.new_zeros((self.num_layers, size, self.in_channels)))
+        q_star = x.new_zeros(size, self.out_channels)
+        for _ in range(self.processing_steps):
+            q, h = self.lstm(q_star.unsqueeze(0), h)
+            q = q.view(size, self.in_channels)
+            a = segment_softmax((x * q[batch]).sum(dim=-1, keepdim=True), batch, size)
+            r = torch.zeros(size, self.in_channels, dtype=x.dtype, device=x.device).index_add_(0, batch, a * x)
+            q_star = torch.cat([q, r], dim=-1)
+        return q_star

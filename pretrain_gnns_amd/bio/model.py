@@ -11,7 +11,7 @@ node feature from a 2-row table.  GPU tensors only; the CPU restatement lives in
 import torch
 import torch.nn.functional as F
 
-from pretrain_gnns_amd import ops
+from pretrain_gnns_amd import attention, ops
 
 
 def _edge_and_input(module, emb_dim, input_layer):
@@ -89,9 +89,39 @@ class GraphSAGEConv(torch.nn.Module):
         return ops.MeanL2Normalize.apply(total, graph)
 
 
+class GATConv(torch.nn.Module):
+    """bio/model.py:117-181; see chem GATConv for what runs where."""
+
+    def __init__(self, emb_dim, heads=2, negative_slope=0.2, aggr="add", input_layer=False):
+        super().__init__()
+        if aggr != "add":
+            raise NotImplementedError("only aggr='add' is implemented")
+        self.aggr, self.emb_dim, self.heads, self.negative_slope = aggr, emb_dim, heads, negative_slope
+        self.weight_linear = torch.nn.Linear(emb_dim, heads * emb_dim)
+        self.att = torch.nn.Parameter(torch.Tensor(1, heads, 2 * emb_dim))
+        self.bias = torch.nn.Parameter(torch.Tensor(emb_dim))
+        self.edge_encoder = torch.nn.Linear(9, heads * emb_dim)
+        self.input_layer = input_layer
+        if input_layer:
+            self.input_node_embeddings = torch.nn.Embedding(2, emb_dim)
+            torch.nn.init.xavier_uniform_(self.input_node_embeddings.weight.data)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        attention.glorot_(self.att)
+        self.bias.data.zero_()
+
+    def forward(self, x, edge_index, edge_attr, graph=None):
+        x = _embed_input(self, x)
+        xh = ops.linear(x, self.weight_linear)
+        ee = self.edge_encoder(edge_attr.to(torch.float32))
+        self_emb = self.edge_encoder.weight[:, 7] + self.edge_encoder.bias  # self-loop attr = one-hot index 7
+        return attention.gat_propagate(xh, edge_index, ee, self_emb, self.att, self.bias, self.heads, self.negative_slope)
+
+
 class GNN(torch.nn.Module):
     """bio/model.py:227-290: ``num_layer`` convs with ReLU between them (no outer BatchNorm);
-    JK in last|sum; gnn_type in gin|gcn|graphsage on the HIP path."""
+    JK in last|sum; gnn_type in gin|gcn|graphsage (HIP kernels) | gat (GEMM + torch GPU ops)."""
 
     def __init__(self, num_layer, emb_dim, JK="last", drop_ratio=0, gnn_type="gin"):
         super().__init__()
@@ -111,9 +141,10 @@ class GNN(torch.nn.Module):
                 self.gnns.append(GCNConv(emb_dim, input_layer=input_layer))
             elif gnn_type == "graphsage":
                 self.gnns.append(GraphSAGEConv(emb_dim, input_layer=input_layer))
+            elif gnn_type == "gat":
+                self.gnns.append(GATConv(emb_dim, input_layer=input_layer))
             else:
-                raise NotImplementedError(
-                    "gnn_type=%r: only 'gin', 'gcn' and 'graphsage' are implemented on the MI355X path" % (gnn_type,))
+                raise ValueError("unknown gnn_type %r" % (gnn_type,))
 
     def forward(self, x, edge_index, edge_attr):
         graph = ops.build_bio_graph(edge_index, edge_attr, x.size(0), gcn=(self.gnn_type == "gcn"))
@@ -172,7 +203,7 @@ class GNN_graphpred(torch.nn.Module):
         elif graph_pooling == "max":
             self.pool = global_max_pool
         elif graph_pooling == "attention":
-            raise NotImplementedError("graph_pooling='attention' is not implemented on the MI355X hot path")
+            self.pool = attention.GlobalAttention(gate_nn=torch.nn.Linear(emb_dim, 1))
         else:
             raise ValueError("Invalid graph pooling type.")
 

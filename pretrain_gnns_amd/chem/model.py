@@ -15,7 +15,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from pretrain_gnns_amd import ops
+from pretrain_gnns_amd import attention, ops
 
 num_atom_type = 120  # including the extra mask token (chem/model.py:9)
 num_chirality_tag = 3
@@ -92,11 +92,40 @@ class GraphSAGEConv(torch.nn.Module):
         return ops.MeanL2Normalize.apply(total, graph)
 
 
+class GATConv(torch.nn.Module):
+    """2-head graph attention (chem/model.py:107-162).  Off the north-star hot path: the projection is the
+    library's MFMA GEMM, the edge softmax / weighted scatter a torch-on-GPU composition (attention.py)."""
+
+    def __init__(self, emb_dim, heads=2, negative_slope=0.2, aggr="add"):
+        super().__init__()
+        if aggr != "add":
+            raise NotImplementedError("only aggr='add' is implemented")
+        self.aggr, self.emb_dim, self.heads, self.negative_slope = aggr, emb_dim, heads, negative_slope
+        self.weight_linear = torch.nn.Linear(emb_dim, heads * emb_dim)
+        self.att = torch.nn.Parameter(torch.Tensor(1, heads, 2 * emb_dim))
+        self.bias = torch.nn.Parameter(torch.Tensor(emb_dim))
+        self.edge_embedding1 = torch.nn.Embedding(num_bond_type, heads * emb_dim)
+        self.edge_embedding2 = torch.nn.Embedding(num_bond_direction, heads * emb_dim)
+        torch.nn.init.xavier_uniform_(self.edge_embedding1.weight.data)
+        torch.nn.init.xavier_uniform_(self.edge_embedding2.weight.data)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        attention.glorot_(self.att)
+        self.bias.data.zero_()
+
+    def forward(self, x, edge_index, edge_attr, graph=None):
+        xh = ops.linear(x, self.weight_linear)
+        ee = self.edge_embedding1(edge_attr[:, 0]) + self.edge_embedding2(edge_attr[:, 1])
+        self_emb = self.edge_embedding1.weight[4] + self.edge_embedding2.weight[0]  # self-loop bond [4, 0]
+        return attention.gat_propagate(xh, edge_index, ee, self_emb, self.att, self.bias, self.heads, self.negative_slope)
+
+
 class GNN(torch.nn.Module):
     """Node-embedding network: atom embedding, ``num_layer`` x (conv, BatchNorm, ReLU, dropout).
 
     Args / output as the reference (chem/model.py:206-221): JK in last|concat|max|sum,
-    gnn_type in gin|gcn|graphsage (gat is not on the HIP path).
+    gnn_type in gin|gcn|graphsage|gat (gat: GEMM on the library, attention as torch GPU ops).
     """
 
     def __init__(self, num_layer, emb_dim, JK="last", drop_ratio=0, gnn_type="gin"):
@@ -121,9 +150,10 @@ class GNN(torch.nn.Module):
                 self.gnns.append(GCNConv(emb_dim))
             elif gnn_type == "graphsage":
                 self.gnns.append(GraphSAGEConv(emb_dim))
+            elif gnn_type == "gat":
+                self.gnns.append(GATConv(emb_dim))
             else:
-                raise NotImplementedError(
-                    "gnn_type=%r: only 'gin', 'gcn' and 'graphsage' are implemented on the MI355X path" % (gnn_type,))
+                raise ValueError("unknown gnn_type %r" % (gnn_type,))
 
         self.batch_norms = torch.nn.ModuleList(torch.nn.BatchNorm1d(emb_dim) for _ in range(num_layer))
 
@@ -194,7 +224,7 @@ def global_max_pool(x, batch, size=None):
 class GNN_graphpred(torch.nn.Module):
     """Graph-level head: GNN -> pooling -> Linear (chem/model.py:293-369).
 
-    graph_pooling in sum|mean|max (attention / set2set are outside the hot path).
+    graph_pooling in sum|mean|max (HIP segment kernels) | attention | set2set<k> (torch GPU ops, attention.py).
     """
 
     def __init__(self, num_layer, emb_dim, num_tasks, JK="last", drop_ratio=0, graph_pooling="mean", gnn_type="gin"):
@@ -215,12 +245,16 @@ class GNN_graphpred(torch.nn.Module):
             self.pool = global_mean_pool
         elif graph_pooling == "max":
             self.pool = global_max_pool
-        elif graph_pooling == "attention" or graph_pooling[:-1] == "set2set":
-            raise NotImplementedError("graph_pooling=%r is not implemented on the MI355X hot path" % (graph_pooling,))
+        elif graph_pooling == "attention":
+            width = (self.num_layer + 1) * emb_dim if self.JK == "concat" else emb_dim
+            self.pool = attention.GlobalAttention(gate_nn=torch.nn.Linear(width, 1))
+        elif graph_pooling[:-1] == "set2set":
+            width = (self.num_layer + 1) * emb_dim if self.JK == "concat" else emb_dim
+            self.pool = attention.Set2Set(width, int(graph_pooling[-1]))
         else:
             raise ValueError("Invalid graph pooling type.")
 
-        self.mult = 1
+        self.mult = 2 if graph_pooling[:-1] == "set2set" else 1
         if self.JK == "concat":
             self.graph_pred_linear = torch.nn.Linear(self.mult * (self.num_layer + 1) * self.emb_dim, self.num_tasks)
         else:

@@ -20,7 +20,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 @pytest.mark.parametrize("name,cls", [("chem_gcn_contextpred", ochem.GNN), ("bio_gcn_masking", obio.GNN),
-                                      ("chem_graphsage_contextpred", ochem.GNN), ("bio_graphsage_masking", obio.GNN)])
+                                      ("chem_graphsage_contextpred", ochem.GNN), ("bio_graphsage_masking", obio.GNN),
+                                      ("chem_gat_contextpred", ochem.GNN), ("bio_gat_masking", obio.GNN)])
 def test_oracle_reproduces_golden_checkpoint_outputs(name, cls):
     fx = torch.load(os.path.join(GOLDEN, name + ".pt"), map_location="cpu")
     m = cls(5, 300, gnn_type=name.split("_")[1])

@@ -67,7 +67,7 @@ def _grads_close(ref, hip, batch_args, weight, l2_tol=2e-2):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("gnn_type", ["gin", "gcn", "graphsage"])
+@pytest.mark.parametrize("gnn_type", ["gin", "gcn", "graphsage", "gat"])
 @pytest.mark.parametrize("graphs", [1, 32])
 def test_chem_gnn_forward_backward(gnn_type, graphs):
     hchem, _ = _hip()
@@ -113,7 +113,7 @@ def test_chem_jk_modes(jk):
                                ref(b.x, b.edge_index, b.edge_attr).detach(), **TOL)
 
 
-@pytest.mark.parametrize("pool", ["mean", "sum", "max"])
+@pytest.mark.parametrize("pool", ["mean", "sum", "max", "attention", "set2set2"])
 def test_chem_graphpred(pool):
     hchem, _ = _hip()
     ref, hip = _pair(ochem.GNN_graphpred, hchem.GNN_graphpred, 5, 300, 12, graph_pooling=pool)
@@ -127,7 +127,7 @@ def test_chem_graphpred(pool):
     torch.testing.assert_close(hip(d).detach().cpu(), ref(b).detach(), **TOL)
 
 
-@pytest.mark.parametrize("gnn_type", ["gin", "gcn", "graphsage"])
+@pytest.mark.parametrize("gnn_type", ["gin", "gcn", "graphsage", "gat"])
 def test_bio_gnn_forward_backward(gnn_type):
     _, hbio = _hip()
     ref, hip = _pair(obio.GNN, hbio.GNN, 5, 300, gnn_type=gnn_type)
@@ -141,9 +141,10 @@ def test_bio_gnn_forward_backward(gnn_type):
     _grads_close(ref, hip, (b.x.double(), b.edge_index, b.edge_attr.double()), w)
 
 
-def test_bio_graphpred():
+@pytest.mark.parametrize("pool", ["mean", "attention"])
+def test_bio_graphpred(pool):
     _, hbio = _hip()
-    ref, hip = _pair(obio.GNN_graphpred, hbio.GNN_graphpred, 5, 300, 40)
+    ref, hip = _pair(obio.GNN_graphpred, hbio.GNN_graphpred, 5, 300, 40, graph_pooling=pool)
     b = synthetic.bio_masking_batch(8, seed=2)
     d = b.clone().to(DEV)
     torch.testing.assert_close(hip(d).detach().cpu(), ref(b).detach(), **TOL)
@@ -317,7 +318,7 @@ def test_chem_finetune_with_dropout_runs_and_regularises():
 
 
 @pytest.mark.parametrize("name", ["chem_gcn_contextpred", "bio_gcn_masking", "chem_graphsage_contextpred",
-                                  "bio_graphsage_masking"])
+                                  "bio_graphsage_masking", "chem_gat_contextpred", "bio_gat_masking"])
 def test_golden_checkpoint_parity(name):
     """real shipped GCN / GraphSAGE weights + BN running stats: strict load into the HIP classes, eval- and
     train-mode embeddings and one gradient must match the fixture (oracle on the reference blob)."""
