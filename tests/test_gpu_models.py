@@ -41,7 +41,7 @@ def _grads_close(ref, hip, batch_args, weight, l2_tol=2e-2):
     A pre-activation within rounding distance of zero lands on different sides in two fp32
     implementations; one flipped unit perturbs the gradients of everything upstream by ~1e-3
     (dense, because weight gradients sum over all nodes).  Measured on the MI355X host with
-    tools/debug_layers.py: torch-CPU fp32 vs fp64 deviates by 1e-3..5e-2 (max-norm) on the very
+    tests/tools/debug_layers.py: torch-CPU fp32 vs fp64 deviates by 1e-3..5e-2 (max-norm) on the very
     batch where this stack sits at 1e-6.  Hence the model-level bar is a relative L2 error of
     ``l2_tol`` per parameter (real kernel bugs are O(10%) and the op-level tests in
     test_gpu_ops.py hold each kernel to 1e-5); analytically-zero gradients (biases feeding a
