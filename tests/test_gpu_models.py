@@ -429,6 +429,23 @@ def test_single_tiny_graph_and_eval_mode():
         torch.testing.assert_close(hip(x.to(DEV), ei.to(DEV), ea.to(DEV)).cpu(), ref(x, ei, ea), **TOL)
 
 
+@pytest.mark.parametrize("gnn_type", ["gin", "gcn", "graphsage"])
+def test_batch_without_any_edge(gnn_type):
+    """empty edge set (a batch of single-atom molecules): only the self loops exist; forward, backward and
+    the pooling head must behave like the oracle"""
+    hchem, _ = _hip()
+    ref, hip = _pair(ochem.GNN_graphpred, hchem.GNN_graphpred, 3, 300, 5, gnn_type=gnn_type, seed=4)
+    x = torch.tensor([[5, 0], [7, 1], [6, 0], [5, 2]])
+    ei = torch.zeros(2, 0, dtype=torch.int64)
+    ea = torch.zeros(0, 2, dtype=torch.int64)
+    batch = torch.tensor([0, 1, 2, 3])
+    out_ref = ref(x, ei, ea, batch)
+    out_hip = hip(x.to(DEV), ei.to(DEV), ea.to(DEV), batch.to(DEV))
+    torch.testing.assert_close(out_hip.detach().cpu(), out_ref.detach(), rtol=1e-3, atol=1e-3)  # BatchNorm over 4 rows
+    out_hip.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in hip.parameters() if p.grad is not None)
+
+
 def test_class_surface_errors():
     hchem, hbio = _hip()
     with pytest.raises(ValueError):
