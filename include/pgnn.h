@@ -321,6 +321,37 @@ int pgnn_mask_edges_apply(const int64_t* masked_edge_idx, int64_t num_masked, fl
                           int64_t attr_cols, int64_t num_edges, float* mask_edge_label, int32_t* status,
                           pgnn_stream stream);
 
+/* ExtractSubstructureContextPair (chem/util.py:96-149) + BatchSubstructContext.from_data_list
+ * (chem/batch.py:141-210) over the resident dataset, for the graphs of one batch (node_off / edge_off from
+ * pgnn_batch_offsets with mask_unit 0).  Per graph: BFS distances from a root atom (roots[g], graph-local,
+ * or drawn from (seed, graph id) when roots == NULL); substructure = atoms within k hops; context = atoms
+ * with l1 < dist <= l2; overlap = both.  Graphs whose context or overlap is empty are dropped (batch.py:169).
+ *   plan : dist / sub_rank / ctx_rank [N], esub_rank / ectx_rank [E] (rank inside the induced sub-graph or
+ *          -1), counts [B][6] = (n_sub, e_sub, n_ctx, e_ctx, n_overlap, kept), root_out [B], and
+ *          offsets [6][B+1] = exclusive sums of the count columns over the batch (offsets[c][B] = totals,
+ *          the only values the host has to read back to size the outputs).
+ *   fill : the two induced, renumbered, concatenated graphs (atoms ascending, bonds in original order),
+ *          center_substruct_idx [kept], overlap_context_substruct_idx / batch_overlapped_context
+ *          [total overlap], overlapped_context_size [kept]. */
+int pgnn_substruct_context_plan(const int64_t* graph_ids, int64_t num_graphs, int64_t dataset_graphs,
+                                const int64_t* node_slice, const int64_t* edge_slice, const int64_t* node_off,
+                                const int64_t* edge_off, const int64_t* edge_index_all, int64_t edges_all,
+                                const int64_t* roots, uint64_t seed, int k, int l1, int l2, int32_t* dist,
+                                int32_t* sub_rank, int32_t* ctx_rank, int32_t* esub_rank, int32_t* ectx_rank,
+                                int64_t* counts, int64_t* root_out, int64_t* offsets, pgnn_stream stream);
+int pgnn_substruct_context_fill(const int64_t* graph_ids, int64_t num_graphs, int64_t dataset_graphs,
+                                const int64_t* node_slice, const int64_t* edge_slice, const int64_t* node_off,
+                                const int64_t* edge_off, const int64_t* offsets, const int64_t* counts,
+                                const int64_t* root, const int32_t* sub_rank, const int32_t* ctx_rank,
+                                const int32_t* esub_rank, const int32_t* ectx_rank, const int64_t* x_all,
+                                int64_t x_cols, const int64_t* edge_index_all, int64_t edges_all,
+                                const int64_t* edge_attr_all, int64_t attr_cols, int64_t num_nodes,
+                                int64_t num_edges, int64_t* x_substruct, int64_t* edge_index_substruct,
+                                int64_t* edge_attr_substruct, int64_t* x_context, int64_t* edge_index_context,
+                                int64_t* edge_attr_context, int64_t* center_substruct_idx,
+                                int64_t* overlap_context_substruct_idx, int64_t* batch_overlapped_context,
+                                int64_t* overlapped_context_size, pgnn_stream stream);
+
 /* diagnostics: plain float4 grid-stride copy (the HBM streaming ceiling bench.py quotes next to the
  * aggregation kernel).  Not part of the hot path. */
 int pgnn_debug_stream_copy(const float* src, float* dst, int64_t n_floats, int64_t blocks, pgnn_stream stream);

@@ -67,6 +67,10 @@ PROTOTYPES = {
     "pgnn_mask_select": (_i, [_p, _i64, _p, _i, _p, _i64, _u64, _p, _p]),
     "pgnn_mask_edges_apply": (_i, [_p, _i64, _p, _i64, _i64, _p, _p, _p]),
     "pgnn_mask_atoms_apply": (_i, [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _p]),
+    "pgnn_substruct_context_plan": (_i, [_p, _i64, _i64, _p, _p, _p, _p, _p, _i64, _p, _u64, _i, _i, _i, _p, _p, _p, _p,
+                                         _p, _p, _p, _p, _p]),
+    "pgnn_substruct_context_fill": (_i, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _i64,
+                                         _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "pgnn_debug_stream_copy": (_i, [_p, _p, _i64, _i64, _p]),
 }
 

@@ -271,3 +271,263 @@ int pgnn_mask_atoms_apply(const int64_t* masked_atom_indices, int64_t num_masked
 }
 
 }  // extern "C"
+
+// =================================================================================================
+// ExtractSubstructureContextPair (chem/util.py:96-149) + BatchSubstructContext (chem/batch.py:141-210)
+// for a list of graph ids, on the resident dataset.  Per graph: BFS distances from a root atom;
+// substructure = atoms within k hops, context = atoms with l1 < dist <= l2, overlap = both.  Induced
+// sub-graphs keep atoms in ascending order and bonds in their original order (what G.subgraph +
+// reset_idxes give for the nodes; the host restatement in data/synthetic.py uses the same bond order).
+// Graphs whose context or overlap is empty are dropped, as the reference's collate does (batch.py:169).
+// One wave per graph: molecules have tens of atoms; larger graphs just loop the wave.
+// =================================================================================================
+namespace {
+
+constexpr int kCtxCols = 6;  // per-graph counts: n_sub, e_sub, n_ctx, e_ctx, n_overlap, kept
+
+// The lanes of one wave exchange per-atom values through global memory (graphs may not fit in LDS):
+// agent-scope atomic accesses go to L2, so a value stored by one lane is what another lane loads after
+// the fence -- no reliance on the CU's L1 for data written by a neighbouring lane.
+__device__ __forceinline__ int ld_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_i32(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent"); }
+
+__device__ __forceinline__ int wave_excl_rank(bool flag, int lane, int* total) {
+  const uint64_t m = __ballot(flag);
+  *total = __popcll(m);
+  return __popcll(m & ((1ull << lane) - 1ull));
+}
+
+__global__ void __launch_bounds__(256) k_ctx_plan(const int64_t* __restrict__ ids, int64_t B, int64_t G,
+                                                  const int64_t* __restrict__ node_slice,
+                                                  const int64_t* __restrict__ edge_slice,
+                                                  const int64_t* __restrict__ node_off, const int64_t* __restrict__ edge_off,
+                                                  const int64_t* __restrict__ ei_all, int64_t e_all,
+                                                  const int64_t* __restrict__ roots, uint64_t seed, int k, int l1, int l2,
+                                                  int32_t* __restrict__ dist, int32_t* __restrict__ sub_rank,
+                                                  int32_t* __restrict__ ctx_rank, int32_t* __restrict__ esub_rank,
+                                                  int32_t* __restrict__ ectx_rank, int64_t* __restrict__ counts,
+                                                  int64_t* __restrict__ root_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t g = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (g >= B) return;
+  const int64_t id = min(max(ids[g], (int64_t)0), G - 1);
+  const int64_t n0 = node_off[g], n = node_off[g + 1] - n0;
+  const int64_t e0 = edge_off[g], e = edge_off[g + 1] - e0;
+  const int64_t es = edge_slice[id];
+  int64_t root = roots ? roots[g] : (n > 0 ? (int64_t)(atom_key(graph_stream(seed, id), 0x5bd1e995) % (uint64_t)n) : 0);
+  root = min(max(root, (int64_t)0), max(n - 1, (int64_t)0));
+  if (lane == 0) root_out[g] = root;
+  for (int64_t a = lane; a < n; a += 64) st_i32(&dist[n0 + a], a == root ? 0 : -1);
+  // level-synchronous BFS by edge relaxation; writers of one level all store the same value
+  const int depth = max(k, l2);
+  for (int level = 0; level < depth; ++level) {
+    wave_fence();
+    bool grew = false;
+    for (int64_t q = lane; q < e; q += 64) {
+      const int64_t u = ei_all[es + q], v = ei_all[e_all + es + q];  // graph-local ids
+      if (ld_i32(&dist[n0 + u]) == level && ld_i32(&dist[n0 + v]) < 0) {
+        st_i32(&dist[n0 + v], level + 1);
+        grew = true;
+      }
+    }
+    if (!__any(grew)) break;
+  }
+  wave_fence();
+  // ranks of the kept atoms / bonds (stable, by wave ballots), and the five counts
+  int n_sub = 0, n_ctx = 0, n_ov = 0;
+  for (int64_t b0 = 0; b0 < n; b0 += 64) {
+    const int64_t a = b0 + lane;
+    const int d = a < n ? ld_i32(&dist[n0 + a]) : -1;
+    const bool s = d >= 0 && d <= k, c = d > l1 && d <= l2;
+    int ts, tc, to;
+    const int rs = wave_excl_rank(s, lane, &ts), rc = wave_excl_rank(c, lane, &tc);
+    (void)wave_excl_rank(s && c, lane, &to);
+    if (a < n) {
+      st_i32(&sub_rank[n0 + a], s ? n_sub + rs : -1);
+      st_i32(&ctx_rank[n0 + a], c ? n_ctx + rc : -1);
+    }
+    n_sub += ts; n_ctx += tc; n_ov += to;
+  }
+  wave_fence();
+  int e_sub = 0, e_ctx = 0;
+  for (int64_t b0 = 0; b0 < e; b0 += 64) {
+    const int64_t q = b0 + lane;
+    bool s = false, c = false;
+    if (q < e) {
+      const int64_t u = ei_all[es + q], v = ei_all[e_all + es + q];
+      s = ld_i32(&sub_rank[n0 + u]) >= 0 && ld_i32(&sub_rank[n0 + v]) >= 0;
+      c = ld_i32(&ctx_rank[n0 + u]) >= 0 && ld_i32(&ctx_rank[n0 + v]) >= 0;
+    }
+    int ts, tc;
+    const int rs = wave_excl_rank(s, lane, &ts), rc = wave_excl_rank(c, lane, &tc);
+    if (q < e) {
+      esub_rank[e0 + q] = s ? e_sub + rs : -1;
+      ectx_rank[e0 + q] = c ? e_ctx + rc : -1;
+    }
+    e_sub += ts; e_ctx += tc;
+  }
+  if (lane == 0) {
+    const bool keep = n_ctx > 0 && n_ov > 0;
+    int64_t* c = counts + g * kCtxCols;
+    c[0] = keep ? n_sub : 0; c[1] = keep ? e_sub : 0; c[2] = keep ? n_ctx : 0; c[3] = keep ? e_ctx : 0;
+    c[4] = keep ? n_ov : 0; c[5] = keep ? 1 : 0;
+  }
+}
+
+// exclusive scans of the six count columns over the batch's graphs; offs is [6][B+1], totals = offs[c][B]
+__global__ void __launch_bounds__(1024) k_ctx_offsets(const int64_t* __restrict__ counts, int64_t B, int64_t* __restrict__ offs) {
+  __shared__ int64_t sh[kCtxCols][1024];
+  __shared__ int64_t carry[kCtxCols];
+  const int t = threadIdx.x;
+  if (t < kCtxCols) carry[t] = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < B; base += 1024) {
+    const int64_t i = base + t;
+    int64_t v[kCtxCols];
+#pragma unroll
+    for (int c = 0; c < kCtxCols; ++c) {
+      v[c] = i < B ? counts[i * kCtxCols + c] : 0;
+      sh[c][t] = v[c];
+    }
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      int64_t a[kCtxCols];
+#pragma unroll
+      for (int c = 0; c < kCtxCols; ++c) a[c] = t >= d ? sh[c][t - d] : 0;
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < kCtxCols; ++c) sh[c][t] += a[c];
+      __syncthreads();
+    }
+    if (i < B) {
+#pragma unroll
+      for (int c = 0; c < kCtxCols; ++c) offs[c * (B + 1) + i] = carry[c] + sh[c][t] - v[c];
+    }
+    __syncthreads();
+    if (t < kCtxCols) carry[t] += sh[t][1023];
+    __syncthreads();
+  }
+  if (t < kCtxCols) offs[t * (B + 1) + B] = carry[t];
+}
+
+__global__ void __launch_bounds__(kBlock) k_ctx_fill_nodes(
+    const int64_t* __restrict__ ids, int64_t B, int64_t G, const int64_t* __restrict__ node_slice,
+    const int64_t* __restrict__ node_off, const int64_t* __restrict__ offs, const int64_t* __restrict__ counts,
+    const int64_t* __restrict__ root, const int32_t* __restrict__ sub_rank, const int32_t* __restrict__ ctx_rank,
+    const int64_t* __restrict__ x_all, int x_cols, int64_t* __restrict__ x_sub, int64_t* __restrict__ x_ctx,
+    int64_t* __restrict__ center_idx, int64_t* __restrict__ overlap_idx, int64_t* __restrict__ overlap_batch,
+    int64_t* __restrict__ overlap_size) {
+  const int64_t n = node_off[B];
+  const int64_t* o_nsub = offs;
+  const int64_t* o_nctx = offs + 2 * (B + 1);
+  const int64_t* o_nov = offs + 4 * (B + 1);
+  const int64_t* o_keep = offs + 5 * (B + 1);
+  for (int64_t p = blockIdx.x * (int64_t)kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
+    const int64_t g = find_graph(node_off, B, p);
+    if (!counts[g * kCtxCols + 5]) continue;
+    const int64_t id = min(max(ids[g], (int64_t)0), G - 1);
+    const int64_t a = p - node_off[g], src = node_slice[id] + a;
+    const int rs = sub_rank[p], rc = ctx_rank[p];
+    if (rs >= 0) {
+      for (int c = 0; c < x_cols; ++c) x_sub[(o_nsub[g] + rs) * x_cols + c] = x_all[src * x_cols + c];
+      if (a == root[g]) center_idx[o_keep[g]] = o_nsub[g] + rs;
+    }
+    if (rc >= 0) {
+      for (int c = 0; c < x_cols; ++c) x_ctx[(o_nctx[g] + rc) * x_cols + c] = x_all[src * x_cols + c];
+    }
+    if (a == 0) overlap_size[o_keep[g]] = counts[g * kCtxCols + 4];
+  }
+  // overlap lists: one thread per graph walks its atoms in order (overlaps are a handful of atoms)
+  for (int64_t g = blockIdx.x * (int64_t)kBlock + threadIdx.x; g < B; g += (int64_t)gridDim.x * kBlock) {
+    if (!counts[g * kCtxCols + 5]) continue;
+    int64_t w = o_nov[g];
+    for (int64_t p = node_off[g]; p < node_off[g + 1]; ++p)
+      if (sub_rank[p] >= 0 && ctx_rank[p] >= 0) {
+        overlap_idx[w] = o_nctx[g] + ctx_rank[p];
+        overlap_batch[w] = o_keep[g];
+        ++w;
+      }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_ctx_fill_edges(
+    const int64_t* __restrict__ ids, int64_t B, int64_t G, const int64_t* __restrict__ edge_slice,
+    const int64_t* __restrict__ node_off, const int64_t* __restrict__ edge_off, const int64_t* __restrict__ offs,
+    const int64_t* __restrict__ counts, const int32_t* __restrict__ sub_rank, const int32_t* __restrict__ ctx_rank,
+    const int32_t* __restrict__ esub_rank, const int32_t* __restrict__ ectx_rank, const int64_t* __restrict__ ei_all,
+    int64_t e_all, const int64_t* __restrict__ attr_all, int attr_cols, int64_t* __restrict__ ei_sub, int64_t* __restrict__ ea_sub,
+    int64_t* __restrict__ ei_ctx, int64_t* __restrict__ ea_ctx) {
+  const int64_t e = edge_off[B];
+  const int64_t* o_nsub = offs;
+  const int64_t* o_esub = offs + 1 * (B + 1);
+  const int64_t* o_nctx = offs + 2 * (B + 1);
+  const int64_t* o_ectx = offs + 3 * (B + 1);
+  const int64_t tot_esub = o_esub[B], tot_ectx = o_ectx[B];
+  for (int64_t q = blockIdx.x * (int64_t)kBlock + threadIdx.x; q < e; q += (int64_t)gridDim.x * kBlock) {
+    const int64_t g = find_graph(edge_off, B, q);
+    if (!counts[g * kCtxCols + 5]) continue;
+    const int64_t id = min(max(ids[g], (int64_t)0), G - 1);
+    const int64_t src = edge_slice[id] + (q - edge_off[g]);
+    const int64_t u = node_off[g] + ei_all[src], v = node_off[g] + ei_all[e_all + src];
+    const int rs = esub_rank[q], rc = ectx_rank[q];
+    if (rs >= 0) {
+      const int64_t w = o_esub[g] + rs;
+      ei_sub[w] = o_nsub[g] + sub_rank[u];
+      ei_sub[tot_esub + w] = o_nsub[g] + sub_rank[v];
+      for (int c = 0; c < attr_cols; ++c) ea_sub[w * attr_cols + c] = attr_all[src * attr_cols + c];
+    }
+    if (rc >= 0) {
+      const int64_t w = o_ectx[g] + rc;
+      ei_ctx[w] = o_nctx[g] + ctx_rank[u];
+      ei_ctx[tot_ectx + w] = o_nctx[g] + ctx_rank[v];
+      for (int c = 0; c < attr_cols; ++c) ea_ctx[w * attr_cols + c] = attr_all[src * attr_cols + c];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pgnn_substruct_context_plan(const int64_t* graph_ids, int64_t num_graphs, int64_t dataset_graphs,
+                                const int64_t* node_slice, const int64_t* edge_slice, const int64_t* node_off,
+                                const int64_t* edge_off, const int64_t* edge_index_all, int64_t edges_all,
+                                const int64_t* roots, uint64_t seed, int k, int l1, int l2, int32_t* dist,
+                                int32_t* sub_rank, int32_t* ctx_rank, int32_t* esub_rank, int32_t* ectx_rank,
+                                int64_t* counts, int64_t* root_out, int64_t* offsets, pgnn_stream stream) {
+  PGNN_REQUIRE(num_graphs > 0 && k >= 0 && l1 >= 0 && l2 >= l1, "bad substruct_context_plan arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_ctx_plan, dim3((int)ceil_div(num_graphs, 4)), dim3(256), 0, st, graph_ids, num_graphs, dataset_graphs,
+                     node_slice, edge_slice, node_off, edge_off, edge_index_all, edges_all, roots, seed, k, l1, l2, dist,
+                     sub_rank, ctx_rank, esub_rank, ectx_rank, counts, root_out);
+  hipLaunchKernelGGL(k_ctx_offsets, dim3(1), dim3(1024), 0, st, counts, num_graphs, offsets);
+  return check_launch("substruct_context_plan");
+}
+
+int pgnn_substruct_context_fill(const int64_t* graph_ids, int64_t num_graphs, int64_t dataset_graphs,
+                                const int64_t* node_slice, const int64_t* edge_slice, const int64_t* node_off,
+                                const int64_t* edge_off, const int64_t* offsets, const int64_t* counts,
+                                const int64_t* root, const int32_t* sub_rank, const int32_t* ctx_rank,
+                                const int32_t* esub_rank, const int32_t* ectx_rank, const int64_t* x_all, int64_t x_cols,
+                                const int64_t* edge_index_all, int64_t edges_all, const int64_t* edge_attr_all,
+                                int64_t attr_cols, int64_t num_nodes, int64_t num_edges, int64_t* x_substruct,
+                                int64_t* edge_index_substruct, int64_t* edge_attr_substruct, int64_t* x_context,
+                                int64_t* edge_index_context, int64_t* edge_attr_context, int64_t* center_substruct_idx,
+                                int64_t* overlap_context_substruct_idx, int64_t* batch_overlapped_context,
+                                int64_t* overlapped_context_size, pgnn_stream stream) {
+  PGNN_REQUIRE(num_graphs > 0 && x_cols > 0 && attr_cols > 0, "bad substruct_context_fill arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_ctx_fill_nodes, dim3(grid_for(std::max(num_nodes, num_graphs))), dim3(kBlock), 0, st, graph_ids,
+                     num_graphs, dataset_graphs, node_slice, node_off, offsets, counts, root, sub_rank, ctx_rank, x_all,
+                     (int)x_cols, x_substruct, x_context, center_substruct_idx, overlap_context_substruct_idx,
+                     batch_overlapped_context, overlapped_context_size);
+  if (num_edges > 0)
+    hipLaunchKernelGGL(k_ctx_fill_edges, dim3(grid_for(num_edges)), dim3(kBlock), 0, st, graph_ids, num_graphs,
+                       dataset_graphs, edge_slice, node_off, edge_off, offsets, counts, sub_rank, ctx_rank, esub_rank,
+                       ectx_rank, edge_index_all, edges_all, edge_attr_all, (int)attr_cols, edge_index_substruct,
+                       edge_attr_substruct, edge_index_context, edge_attr_context);
+  return check_launch("substruct_context_fill");
+}
+
+}  // extern "C"

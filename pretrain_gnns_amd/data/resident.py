@@ -168,6 +168,65 @@ class ResidentDataset:
                   "pgnn_mask_edges_apply")
         return out
 
+    def collate_substruct_context(self, graph_ids, k=5, l1=4, l2=7, seed=0, roots=None, ids_device=None):
+        """ExtractSubstructureContextPair(k, l1, l2) (chem/util.py:96-149) on every graph of the batch, then
+        BatchSubstructContext.from_data_list (chem/batch.py:141-210), all on the device.  ``roots``
+        (graph-local atom per graph; the reference's ``root_idx`` debugging hook) replaces the random root.
+        One host sync: the five totals that size the outputs (sub-graph sizes are data dependent)."""
+        if self.x.dtype != torch.int64 or self.edge_attr.dtype != torch.int64:
+            raise _lib.PgnnError("substructure/context extraction is defined for the chem datasets")
+        lib, sp, dev = load(), stream_ptr(), self.device
+        ids_host, ids = self._ids(graph_ids, ids_device)
+        b = ids_host.size
+        n, e = int(self._nodes[ids_host].sum()), int(self._edges[ids_host].sum())
+        offs = torch.empty(3, b + 1, dtype=torch.int64, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        check(lib.pgnn_batch_offsets(ids.data_ptr(), b, self.num_graphs, self.node_slice.data_ptr(),
+                                     self.edge_slice.data_ptr(), 0.0, 0, offs[0].data_ptr(), offs[1].data_ptr(),
+                                     offs[2].data_ptr(), n, e, 0, status.data_ptr(), sp), "pgnn_batch_offsets")
+        inode = torch.empty(3, max(n, 1), dtype=torch.int32, device=dev)   # dist, sub_rank, ctx_rank
+        iedge = torch.empty(2, max(e, 1), dtype=torch.int32, device=dev)   # esub_rank, ectx_rank
+        counts = torch.empty(b, 6, dtype=torch.int64, device=dev)
+        root_out = torch.empty(b, dtype=torch.int64, device=dev)
+        coffs = torch.empty(6, b + 1, dtype=torch.int64, device=dev)
+        roots_dev = None
+        if roots is not None:
+            roots_dev = torch.as_tensor(roots, dtype=torch.int64).to(dev).contiguous()
+            if roots_dev.numel() != b:
+                raise ValueError("one root per graph")
+        check(lib.pgnn_substruct_context_plan(
+            ids.data_ptr(), b, self.num_graphs, self.node_slice.data_ptr(), self.edge_slice.data_ptr(), offs[0].data_ptr(),
+            offs[1].data_ptr(), self.edge_index.data_ptr(), self.edge_index.size(1),
+            roots_dev.data_ptr() if roots_dev is not None else None, int(seed) & 0xFFFFFFFFFFFFFFFF, int(k), int(l1), int(l2),
+            inode[0].data_ptr(), inode[1].data_ptr(), inode[2].data_ptr(), iedge[0].data_ptr(), iedge[1].data_ptr(),
+            counts.data_ptr(), root_out.data_ptr(), coffs.data_ptr(), sp), "pgnn_substruct_context_plan")
+        n_sub, e_sub, n_ctx, e_ctx, n_ov, kept = [int(v) for v in coffs[:, b].tolist()]  # the one sync
+        cx, ca = self.x.size(1), self.edge_attr.size(1)
+        out = Data()
+        out.x_substruct = torch.empty(n_sub, cx, dtype=torch.int64, device=dev)
+        out.edge_index_substruct = torch.empty(2, e_sub, dtype=torch.int64, device=dev)
+        out.edge_attr_substruct = torch.empty(e_sub, ca, dtype=torch.int64, device=dev)
+        out.x_context = torch.empty(n_ctx, cx, dtype=torch.int64, device=dev)
+        out.edge_index_context = torch.empty(2, e_ctx, dtype=torch.int64, device=dev)
+        out.edge_attr_context = torch.empty(e_ctx, ca, dtype=torch.int64, device=dev)
+        out.center_substruct_idx = torch.empty(kept, dtype=torch.int64, device=dev)
+        out.overlap_context_substruct_idx = torch.empty(n_ov, dtype=torch.int64, device=dev)
+        out.batch_overlapped_context = torch.empty(n_ov, dtype=torch.int64, device=dev)
+        out.overlapped_context_size = torch.empty(kept, dtype=torch.int64, device=dev)
+        if kept:
+            check(lib.pgnn_substruct_context_fill(
+                ids.data_ptr(), b, self.num_graphs, self.node_slice.data_ptr(), self.edge_slice.data_ptr(),
+                offs[0].data_ptr(), offs[1].data_ptr(), coffs.data_ptr(), counts.data_ptr(), root_out.data_ptr(),
+                inode[1].data_ptr(), inode[2].data_ptr(), iedge[0].data_ptr(), iedge[1].data_ptr(), self.x.data_ptr(), cx,
+                self.edge_index.data_ptr(), self.edge_index.size(1), self.edge_attr.data_ptr(), ca, n, e,
+                out.x_substruct.data_ptr(), out.edge_index_substruct.data_ptr(), out.edge_attr_substruct.data_ptr(),
+                out.x_context.data_ptr(), out.edge_index_context.data_ptr(), out.edge_attr_context.data_ptr(),
+                out.center_substruct_idx.data_ptr(), out.overlap_context_substruct_idx.data_ptr(),
+                out.batch_overlapped_context.data_ptr(), out.overlapped_context_size.data_ptr(), sp),
+                "pgnn_substruct_context_fill")
+        out._num_graphs, out._status, out._roots = kept, status, root_out
+        return out
+
     def check(self, batch):
         """raise if any kernel of ``collate`` flagged an inconsistency (one device sync)"""
         bits = int(batch._status.item())
@@ -197,7 +256,10 @@ class ResidentLoader:
     semantics), the device builds the batch.  ``drop_last`` as torch's DataLoader."""
 
     def __init__(self, dataset, batch_size, shuffle=True, seed=0, mask_rate=0.0, mask_edge=False, rank=0,
-                 world_size=1, drop_last=False):
+                 world_size=1, drop_last=False, substruct_context=None):
+        """``substruct_context=(k, l1, l2)`` switches the per-batch transform from masking to
+        ExtractSubstructureContextPair + BatchSubstructContext (chem/pretrain_contextpred.py:145-152)."""
+        self.substruct_context = substruct_context
         self.ds, self.batch_size, self.shuffle, self.seed = dataset, int(batch_size), shuffle, int(seed)
         self.mask_rate, self.mask_edge, self.rank, self.world = float(mask_rate), bool(mask_edge), int(rank), int(world_size)
         self.drop_last = drop_last
@@ -234,6 +296,11 @@ class ResidentLoader:
         flat = torch.from_numpy(np.concatenate(batches)).to(self.ds.device)  # one upload per epoch
         off = 0
         for step, ids in enumerate(batches):
-            yield self.ds.collate(ids, mask_rate=self.mask_rate, seed=(self.seed * 1000003 + epoch) * 1000003 + step,
-                                  mask_edge=self.mask_edge, ids_device=flat[off:off + ids.size])
+            seed = (self.seed * 1000003 + epoch) * 1000003 + step
+            if self.substruct_context is not None:
+                k, l1, l2 = self.substruct_context
+                yield self.ds.collate_substruct_context(ids, k=k, l1=l1, l2=l2, seed=seed, ids_device=flat[off:off + ids.size])
+            else:
+                yield self.ds.collate(ids, mask_rate=self.mask_rate, seed=seed, mask_edge=self.mask_edge,
+                                      ids_device=flat[off:off + ids.size])
             off += ids.size

@@ -228,3 +228,66 @@ def test_loader_epoch_covers_dataset_once():
         assert batch.masked_atom_indices.numel() == batch.mask_node_label.size(0) > 0
     assert batches == len(loader) == 5
     assert seen_nodes == sum(g.x.size(0) for g in graphs)
+
+
+CTX_KEYS = ("x_substruct", "edge_index_substruct", "edge_attr_substruct", "x_context", "edge_index_context",
+            "edge_attr_context", "center_substruct_idx", "overlap_context_substruct_idx", "batch_overlapped_context",
+            "overlapped_context_size")
+
+
+@pytest.mark.parametrize("k,l1,l2", [(5, 4, 7), (3, 2, 5), (1, 0, 1), (4, 1, 3)])
+def test_substruct_context_matches_host_extraction(k, l1, l2):
+    """ExtractSubstructureContextPair + BatchSubstructContext on the device == the host restatement
+    (data/synthetic.py) applied per graph with the same roots, then collated -- every field, bit for bit,
+    including which graphs are dropped for lack of a context / overlap (chem/batch.py:169)."""
+    graphs = _chem_graphs(40, seed=11)
+    lone = Data(x=torch.tensor([[5, 0]]), edge_index=torch.zeros(2, 0, dtype=torch.int64),
+                edge_attr=torch.zeros(0, 2, dtype=torch.int64))
+    graphs.insert(7, lone)  # an isolated atom: no context, must be dropped
+    rng = np.random.default_rng(12)
+    ids = rng.permutation(len(graphs))[:33]
+    roots = [int(rng.integers(0, graphs[i].x.size(0))) for i in ids]
+    want = synthetic.collate_substruct_context(
+        [synthetic.extract_substruct_context(graphs[i], rng, k=k, l1=l1, l2=l2, root=r) for i, r in zip(ids, roots)])
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    out = ds.collate_substruct_context(ids, k=k, l1=l1, l2=l2, roots=roots)
+    ds.check(out)
+    _same(out, want, CTX_KEYS)
+
+
+def test_substruct_context_all_graphs_dropped():
+    """k < l1: substructure and context rings cannot overlap, every graph is dropped -> empty batch"""
+    ds = resident.ResidentDataset.from_graphs(_chem_graphs(9, seed=14), DEV)
+    out = ds.collate_substruct_context(np.arange(9), k=2, l1=3, l2=4, seed=1)
+    ds.check(out)
+    assert out.num_graphs == 0
+    assert all(getattr(out, key).numel() == 0 for key in CTX_KEYS)
+    assert out.edge_index_substruct.shape == (2, 0) and out.x_context.shape == (0, 2)
+
+
+def test_substruct_context_random_roots_and_training_step():
+    """random roots: reproducible per (seed, graph), valid (inside the graph), and the batch drives the
+    context-prediction train step"""
+    from pretrain_gnns_amd import train
+    from pretrain_gnns_amd.chem import model as hmodel
+    graphs = _chem_graphs(64, seed=13)
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    ids = np.arange(64)
+    a = ds.collate_substruct_context(ids, seed=3)
+    b = ds.collate_substruct_context(ids, seed=3)
+    c = ds.collate_substruct_context(ids, seed=4)
+    assert torch.equal(a._roots, b._roots) and not torch.equal(a._roots, c._roots)
+    sizes = torch.tensor([g.x.size(0) for g in graphs])
+    assert bool(((a._roots.cpu() >= 0) & (a._roots.cpu() < sizes)).all())
+    for key in CTX_KEYS:
+        assert torch.equal(getattr(a, key), getattr(b, key)), key
+    # same roots on the host give the same batch
+    rng = np.random.default_rng(0)
+    want = synthetic.collate_substruct_context(
+        [synthetic.extract_substruct_context(g, rng, root=int(r)) for g, r in zip(graphs, a._roots.cpu())])
+    _same(a, want, CTX_KEYS)
+    torch.manual_seed(0)
+    ms, mc = hmodel.GNN(5, 300).to(DEV), hmodel.GNN(3, 300).to(DEV)
+    os_, oc = torch.optim.Adam(ms.parameters(), lr=1e-3), torch.optim.Adam(mc.parameters(), lr=1e-3)
+    loss, acc = train.chem_contextpred_step(ms, mc, os_, oc, a)
+    assert loss == loss and 0.0 <= acc <= 1.0
