@@ -167,3 +167,50 @@ def chem_masking_epoch(model_list, optimizer_list, loader, mask_edge=False, devi
         acc_node_accum += acc_node
         acc_edge_accum += acc_edge
     return loss_accum / step, acc_node_accum / step, acc_edge_accum / step
+
+
+def chem_edgepred_step(model, optimizer, batch):
+    """chem/pretrain_edgepred.py:32-46 (loop body of train()): dot-product scores of the bonded pairs (one
+    direction of every bond) against sampled non-bonded pairs, BCE-with-logits in float32."""
+    node_emb = model(batch.x, batch.edge_index, batch.edge_attr)
+    positive_score = torch.sum(node_emb[batch.edge_index[0, ::2]] * node_emb[batch.edge_index[1, ::2]], dim=1)
+    negative_score = torch.sum(node_emb[batch.negative_edge_index[0]] * node_emb[batch.negative_edge_index[1]], dim=1)
+    optimizer.zero_grad()
+    loss = (F.binary_cross_entropy_with_logits(positive_score, torch.ones_like(positive_score))
+            + F.binary_cross_entropy_with_logits(negative_score, torch.zeros_like(negative_score)))
+    loss.backward()
+    optimizer.step()
+    acc = (torch.sum(positive_score > 0) + torch.sum(negative_score < 0)).to(torch.float32) / float(2 * len(positive_score))
+    return float(loss.detach().cpu().item()), float(acc.detach().cpu().item())
+
+
+class Discriminator(torch.nn.Module):
+    """chem/pretrain_deepgraphinfomax.py:30-42: bilinear score x^T W s; W ~ U(-1/sqrt(D), 1/sqrt(D))."""
+
+    def __init__(self, hidden_dim):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.Tensor(hidden_dim, hidden_dim))
+        bound = 1.0 / (hidden_dim ** 0.5)
+        self.weight.data.uniform_(-bound, bound)
+
+    def forward(self, x, summary):
+        return torch.sum(x * torch.matmul(summary, self.weight), dim=1)
+
+
+def chem_infomax_step(gnn, discriminator, optimizer, batch, pool=pyg.global_mean_pool):
+    """chem/pretrain_deepgraphinfomax.py:61-84 (loop body of train()): node embeddings scored against the
+    sigmoid of their own graph's mean-pooled summary (positive) and of the next graph's (negative)."""
+    node_emb = gnn(batch.x, batch.edge_index, batch.edge_attr)
+    summary_emb = torch.sigmoid(pool(node_emb, batch.batch))
+    positive_expanded = summary_emb[batch.batch]
+    shifted = summary_emb[cycle_index(len(summary_emb), 1).to(summary_emb.device)]
+    negative_expanded = shifted[batch.batch]
+    positive_score = discriminator(node_emb, positive_expanded)
+    negative_score = discriminator(node_emb, negative_expanded)
+    optimizer.zero_grad()
+    loss = (F.binary_cross_entropy_with_logits(positive_score, torch.ones_like(positive_score))
+            + F.binary_cross_entropy_with_logits(negative_score, torch.zeros_like(negative_score)))
+    loss.backward()
+    optimizer.step()
+    acc = (torch.sum(positive_score > 0) + torch.sum(negative_score < 0)).to(torch.float32) / float(2 * len(positive_score))
+    return float(loss.detach().cpu().item()), float(acc.detach().cpu().item())

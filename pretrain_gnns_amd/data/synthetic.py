@@ -172,7 +172,7 @@ def mask_edges(data, rng, mask_rate=0.15):
 
 
 # ----------------------------------------------------------------------------- collate
-_NODE_OFFSET_KEYS = ("edge_index", "masked_atom_indices", "center_node_idx")
+_NODE_OFFSET_KEYS = ("edge_index", "masked_atom_indices", "center_node_idx", "negative_edge_index")
 _EDGE_OFFSET_KEYS = ("connected_edge_indices", "masked_edge_idx")
 
 
@@ -196,7 +196,7 @@ def collate(graphs):
         edge_off += g.edge_index.size(1)
     out = Data()
     for k in keys:
-        setattr(out, k, torch.cat(cols[k], dim=-1 if k == "edge_index" else 0))
+        setattr(out, k, torch.cat(cols[k], dim=-1 if k in ("edge_index", "negative_edge_index") else 0))
     out.batch = torch.cat(batch_vec)
     return out.contiguous()
 
@@ -256,6 +256,32 @@ def chem_finetune_batch(num_graphs, num_tasks=12, seed=0, missing=0.2):
         g.y = torch.from_numpy(y.astype(np.int64))
         graphs.append(g)
     return collate(graphs)
+
+
+def negative_edges(data, rng):
+    """NegativeEdge (chem/util.py:22-44): up to E/2 distinct directed non-bonded, non-loop atom pairs drawn
+    from 5*E uniform candidates, in draw order."""
+    data = data.clone()
+    n, e = data.x.size(0), data.edge_index.size(1)
+    have = set(zip(data.edge_index[0].tolist(), data.edge_index[1].tolist()))
+    cand = rng.integers(0, n, size=(2, 5 * e))
+    picked, seen = [], set()
+    for i in range(5 * e):
+        u, v = int(cand[0, i]), int(cand[1, i])
+        if u != v and (u, v) not in have and (u, v) not in seen:
+            seen.add((u, v))
+            picked.append(i)
+        if len(picked) == e // 2:
+            break
+    data.negative_edge_index = torch.from_numpy(cand[:, picked].astype(np.int64)).reshape(2, -1)
+    return data
+
+
+def chem_edgepred_batch(num_graphs, seed=0):
+    """BatchAE layout (chem/batch.py:58-121): plain graphs + per-graph negative pairs shifted by the node cumsum."""
+    rng = np.random.default_rng(seed)
+    out = collate([negative_edges(zinc_like_graph(rng), rng) for _ in range(num_graphs)])
+    return out
 
 
 def chem_contextpred_batch(num_graphs, seed=0, num_layer=5, csize=3):

@@ -212,3 +212,64 @@ def chem_eval(model, batches):
             is_valid = y_true[:, i] ** 2 > 0
             roc_list.append(_roc_auc((y_true[is_valid, i] + 1) / 2, y_scores[is_valid, i]))
     return sum(roc_list) / len(roc_list)
+
+
+def chem_edgepred_step(model, optimizer, batch):
+    """One iteration of chem/pretrain_edgepred.py:32-46: dot-product scores of the bonded atom pairs (one
+    direction per bond) against the batch's sampled non-bonded pairs, BCE-with-logits (float32)."""
+    node_emb = model(batch.x, batch.edge_index, batch.edge_attr)
+    positive_score = torch.sum(node_emb[batch.edge_index[0, ::2]] * node_emb[batch.edge_index[1, ::2]], dim=1)
+    negative_score = torch.sum(node_emb[batch.negative_edge_index[0]] * node_emb[batch.negative_edge_index[1]], dim=1)
+    optimizer.zero_grad()
+    loss = (F.binary_cross_entropy_with_logits(positive_score, torch.ones_like(positive_score))
+            + F.binary_cross_entropy_with_logits(negative_score, torch.zeros_like(negative_score)))
+    loss.backward()
+    optimizer.step()
+    acc = (torch.sum(positive_score > 0) + torch.sum(negative_score < 0)).to(torch.float32) / float(2 * len(positive_score))
+    out = torch.stack([loss.detach(), acc]).cpu().tolist()
+    return out[0], out[1]
+
+
+class Discriminator(torch.nn.Module):
+    """Bilinear node-vs-summary score of chem/pretrain_deepgraphinfomax.py:30-42 (same parameter name, same
+    U(-1/sqrt(D), 1/sqrt(D)) initialisation as torch_geometric's ``uniform``)."""
+
+    def __init__(self, hidden_dim):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.Tensor(hidden_dim, hidden_dim))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        bound = 1.0 / (self.weight.size(0) ** 0.5)
+        self.weight.data.uniform_(-bound, bound)
+
+    def forward(self, x, summary):
+        return torch.sum(x * torch.matmul(summary, self.weight), dim=1)
+
+
+class Infomax(torch.nn.Module):
+    """chem/pretrain_deepgraphinfomax.py:44-50: holder of the GNN, the discriminator and the mean pooling."""
+
+    def __init__(self, gnn, discriminator):
+        super().__init__()
+        self.gnn, self.discriminator = gnn, discriminator
+        self.loss = torch.nn.BCEWithLogitsLoss()
+        self.pool = ops.global_mean_pool
+
+
+def chem_infomax_step(model, optimizer, batch):
+    """One iteration of chem/pretrain_deepgraphinfomax.py:61-84 on an ``Infomax`` model."""
+    node_emb = model.gnn(batch.x, batch.edge_index, batch.edge_attr)
+    summary_emb = torch.sigmoid(model.pool(node_emb, batch.batch))
+    positive_expanded = summary_emb[batch.batch]
+    shifted = summary_emb[cycle_index(len(summary_emb), 1).to(summary_emb.device)]
+    negative_expanded = shifted[batch.batch]
+    positive_score = model.discriminator(node_emb, positive_expanded)
+    negative_score = model.discriminator(node_emb, negative_expanded)
+    optimizer.zero_grad()
+    loss = model.loss(positive_score, torch.ones_like(positive_score)) + model.loss(negative_score, torch.zeros_like(negative_score))
+    loss.backward()
+    optimizer.step()
+    acc = (torch.sum(positive_score > 0) + torch.sum(negative_score < 0)).to(torch.float32) / float(2 * len(positive_score))
+    out = torch.stack([loss.detach(), acc]).cpu().tolist()
+    return out[0], out[1]

@@ -236,6 +236,36 @@ def test_chem_contextpred_train_steps():
         assert abs(ar - ah) <= 0.05
 
 
+def test_chem_edgepred_and_infomax_train_steps():
+    """the two remaining pre-training objectives of the reference (chem/pretrain_edgepred.py:32-46,
+    chem/pretrain_deepgraphinfomax.py:61-84) driven through both stacks"""
+    from pretrain_gnns_amd import train as ptrain
+    hchem, _ = _hip()
+    ref, hip = _pair(ochem.GNN, hchem.GNN, 5, 300, seed=31)
+    o_r, o_h = _opt(ref)[0], _opt(hip)[0]
+    for step in range(3):
+        b = synthetic.chem_edgepred_batch(32, seed=90 + step)
+        assert b.negative_edge_index.size(1) > 0 and int(b.negative_edge_index.max()) < b.x.size(0)
+        lr, ar = steps.chem_edgepred_step(ref, o_r, b)
+        lh, ah = ptrain.chem_edgepred_step(hip, o_h, b.clone().to(DEV))
+        assert abs(lr - lh) < (1e-4 if step == 0 else 3e-2) * max(1.0, abs(lr)), (step, lr, lh)
+        assert abs(ar - ah) <= 0.02
+    ref, hip = _pair(ochem.GNN, hchem.GNN, 5, 300, seed=32)
+    torch.manual_seed(33)
+    d_ref = steps.Discriminator(300)
+    d_hip = ptrain.Discriminator(300)
+    d_hip.load_state_dict(d_ref.state_dict())
+    model = ptrain.Infomax(hip, d_hip.to(DEV))
+    o_r = torch.optim.Adam(list(ref.parameters()) + list(d_ref.parameters()), lr=1e-3)
+    o_h = torch.optim.Adam(model.parameters(), lr=1e-3)
+    for step in range(3):
+        b = synthetic.chem_plain_batch(32, seed=95 + step)
+        lr, ar = steps.chem_infomax_step(ref, d_ref, o_r, b)
+        lh, ah = ptrain.chem_infomax_step(model, o_h, b.clone().to(DEV))
+        assert abs(lr - lh) < (1e-4 if step == 0 else 3e-2) * max(1.0, abs(lr)), (step, lr, lh)
+        assert abs(ar - ah) <= 0.02
+
+
 def test_bio_masking_train_steps():
     _, hbio = _hip()
     ref, hip = _pair(obio.GNN, hbio.GNN, 5, 300)
