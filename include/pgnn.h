@@ -277,6 +277,25 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
                             uint64_t drop_seed, int64_t n, int64_t dim, void* ws, size_t ws_bytes,
                             pgnn_stream stream);
 
+/* The same one-call network for the "Linear, then aggregate" convolutions: kind 1 = GCNConv
+ * (chem/model.py:58-104, needs dinv), kind 2 = GraphSAGEConv (chem/model.py:165-202, needs norms).
+ * acts [num_layer][4][n][dim] = (lin, sum [GraphSAGE], z, y); norms [num_layer][n] (GraphSAGE);
+ * stats [num_layer][4][dim].  pgnn_gin_layer: w1/b1 (+dw1/db1) hold the Linear, w2/b2 are unused.
+ * Output = acts[num_layer-1][3]. */
+size_t pgnn_chem_lin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t rows1, int64_t rows2);
+int pgnn_chem_lin_stack_fwd(int kind, const int64_t* x_idx, const float* xemb1, int64_t rows1, const float* xemb2,
+                            int64_t rows2, const int32_t* in_ptr, const int32_t* in_src, const uint8_t* in_code,
+                            const float* dinv, const pgnn_gin_layer* layers, int num_layer, int training,
+                            float* h0, float* acts, float* norms, float* stats, int32_t* status, float drop_p,
+                            uint64_t drop_seed, int64_t n, int64_t dim, void* ws, size_t ws_bytes,
+                            pgnn_stream stream);
+int pgnn_chem_lin_stack_bwd(int kind, const float* dy, int64_t lddy, const int64_t* x_idx, int64_t rows1,
+                            int64_t rows2, const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_dst,
+                            const float* dinv, const float* cfeat, const pgnn_gin_layer* layers, int num_layer,
+                            int training, const float* h0, const float* acts, const float* norms,
+                            const float* stats, float* dxemb1, float* dxemb2, float drop_p, uint64_t drop_seed,
+                            int64_t n, int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * Device-side batching over a dataset resident in HBM.  The dataset is kept in
  * the concatenated (data, slices) form InMemoryDataset stores (chem/loader.py MoleculeDataset,

@@ -61,6 +61,11 @@ PROTOTYPES = {
                                      _i64, _i64, _p, _sz, _p]),
     "pgnn_chem_gin_stack_bwd": (_i, [_p, _i64, _p, _i64, _i64, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _f, _u64,
                                      _i64, _i64, _p, _sz, _p]),
+    "pgnn_chem_lin_stack_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "pgnn_chem_lin_stack_fwd": (_i, [_i, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _f, _u64,
+                                     _i64, _i64, _p, _sz, _p]),
+    "pgnn_chem_lin_stack_bwd": (_i, [_i, _p, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p,
+                                     _f, _u64, _i64, _i64, _p, _sz, _p]),
     "pgnn_batch_offsets": (_i, [_p, _i64, _i64, _p, _p, ctypes.c_double, _i, _p, _p, _p, _i64, _i64, _i64, _p, _p]),
     "pgnn_collate_graphs": (_i, [_p, _i64, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _p,
                                  _p, _p]),

@@ -306,4 +306,148 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   return PGNN_OK;
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * The same one-call network for the "linear, then aggregate" convolutions of chem/model.py:
+ *   kind 1 = GCNConv  (:58-104)  : lin = h W^T + b ; z = sum_e dinv_i dinv_j (lin_j + e_ij)   (self loop incl.)
+ *   kind 2 = GraphSAGE (:165-202): lin = h W^T + b ; s = sum_e (lin_j + e_ij) ; z = normalize(s / count)
+ * followed by BatchNorm (+ReLU except after the last layer, + optional fused dropout), JK = "last".
+ * acts [L][4][n][dim] = (lin, sum (GraphSAGE only), z, y); norms [L][n] (GraphSAGE only);
+ * stats [L][4][dim] as for the GIN stack.  The per-layer struct uses w1/b1 (+ dw1/db1) for the Linear.
+ * --------------------------------------------------------------------------------------------- */
+size_t pgnn_chem_lin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t rows1, int64_t rows2) {
+  return pgnn_chem_gin_stack_workspace_bytes(n, dim, rows1, rows2);
+}
+
+int pgnn_chem_lin_stack_fwd(int kind, const int64_t* x_idx, const float* xemb1, int64_t rows1, const float* xemb2,
+                            int64_t rows2, const int32_t* in_ptr, const int32_t* in_src, const uint8_t* in_code,
+                            const float* dinv, const pgnn_gin_layer* layers, int num_layer, int training, float* h0,
+                            float* acts, float* norms, float* stats, int32_t* status, float drop_p, uint64_t drop_seed,
+                            int64_t n, int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream) {
+  if (num_layer < 1 || !layers || (kind != 1 && kind != 2) || (kind == 1 && !dinv) || (kind == 2 && !norms)) {
+    set_error("chem_lin_stack_fwd: bad arguments");
+    return PGNN_ERR_ARG;
+  }
+  if (ws_bytes < op_ws_bytes(n, dim)) {
+    set_error("chem_lin_stack_fwd workspace too small");
+    return PGNN_ERR_WORKSPACE;
+  }
+  int rc;
+  if ((rc = pgnn_embed_fwd(x_idx, 2, xemb1, rows1, xemb2, rows2, h0, dim, n, dim, status, stream))) return rc;
+  const size_t nd = (size_t)n * dim;
+  const float* h = h0;
+  for (int l = 0; l < num_layer; ++l) {
+    const pgnn_gin_layer& p = layers[l];
+    float* a = acts + (size_t)l * 4 * nd;
+    float *lin = a, *sum = a + nd, *z = a + 2 * nd, *y = a + 3 * nd;
+    float* st = stats + (size_t)l * 4 * dim;
+    if ((rc = pgnn_linear_fwd(h, dim, p.w1, p.b1, lin, dim, n, dim, dim, 0, stream))) return rc;
+    if (kind == 1) {
+      if ((rc = pgnn_chem_aggregate_fwd(lin, dim, in_ptr, in_src, in_code, p.emb1, p.emb2, dinv, z, dim, n, dim, stream))) return rc;
+    } else {
+      if ((rc = pgnn_chem_aggregate_fwd(lin, dim, in_ptr, in_src, in_code, p.emb1, p.emb2, nullptr, sum, dim, n, dim, stream))) return rc;
+      if ((rc = pgnn_mean_l2norm_fwd(sum, dim, in_ptr, z, dim, norms + (size_t)l * n, n, dim, stream))) return rc;
+    }
+    if ((rc = pgnn_bn_fwd(z, dim, p.gamma, p.beta, p.running_mean, p.running_var, p.momentum, p.eps, training,
+                          l != num_layer - 1, y, dim, st, st + dim, drop_p, drop_seed + (uint64_t)l, n, dim, ws, ws_bytes,
+                          stream))) return rc;
+    h = y;
+  }
+  return PGNN_OK;
+}
+
+int pgnn_chem_lin_stack_bwd(int kind, const float* dy, int64_t lddy, const int64_t* x_idx, int64_t rows1, int64_t rows2,
+                            const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_dst, const float* dinv,
+                            const float* cfeat, const pgnn_gin_layer* layers, int num_layer, int training,
+                            const float* h0, const float* acts, const float* norms, const float* stats, float* dxemb1,
+                            float* dxemb2, float drop_p, uint64_t drop_seed, int64_t n, int64_t dim, void* ws,
+                            size_t ws_bytes, pgnn_stream stream) {
+  if (num_layer < 1 || !layers || (kind != 1 && kind != 2) || (kind == 1 && !dinv) || (kind == 2 && !norms)) {
+    set_error("chem_lin_stack_bwd: bad arguments");
+    return PGNN_ERR_ARG;
+  }
+  if (ws_bytes < pgnn_chem_lin_stack_workspace_bytes(n, dim, rows1, rows2)) {
+    set_error("chem_lin_stack_bwd workspace too small");
+    return PGNN_ERR_WORKSPACE;
+  }
+  const size_t nd = (size_t)n * dim;
+  Carver cv(ws);
+  const size_t opb = op_ws_bytes(n, dim);
+  char* op = cv.take<char>(opb);
+  char* op2 = cv.take<char>(opb);
+  // per parity: dz (BatchNorm input gradient), dsum (GraphSAGE only), dlin, dx -- the GIN stack's buffer budget
+  float *dz[2], *dsum[2], *dlin[2], *dxb[2];
+  for (int p = 0; p < 2; ++p) {
+    dz[p] = cv.take<float>(nd);
+    dsum[p] = cv.take<float>(nd);
+    dlin[p] = cv.take<float>(nd);
+    (void)cv.take<float>(nd);  // keeps the carve identical to the GIN stack (dhid is 2 nd there)
+    dxb[p] = cv.take<float>(nd);
+  }
+  int32_t* gptr[2];
+  int32_t* gperm[2];
+  for (int c = 0; c < 2; ++c) {
+    gptr[c] = cv.take<int32_t>((size_t)std::max(rows1, rows2) + 1);
+    gperm[c] = cv.take<int32_t>((size_t)n);
+  }
+  int32_t* gstatus = cv.take<int32_t>(64);
+  const size_t grp_b = stack_group_ws(n, rows1, rows2);
+  char* grp_ws = cv.take<char>(grp_b);
+  const size_t seg_b = stack_segsum_ws(n, dim, rows1, rows2);
+  char* seg_ws = cv.take<char>(seg_b);
+
+  hipStream_t main = (hipStream_t)stream;
+  Side* sd = (use_side_stream() && n <= kSideMaxRows) ? side_for_current_device() : nullptr;
+  hipStream_t aux = sd ? sd->stream : main;
+  char* aux_ws = sd ? op2 : op;
+  int rc;
+  if (sd) {
+    PGNN_HIP(hipEventRecord(sd->fork[0], main));
+    PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[0], 0));
+  }
+  const int64_t rows[2] = {rows1, rows2};
+  float* dxemb[2] = {dxemb1, dxemb2};
+  PGNN_HIP(hipMemsetAsync(gstatus, 0, sizeof(int32_t), aux));
+  for (int c = 0; c < 2; ++c)
+    if (dxemb[c] && (rc = pgnn_group_by_key(x_idx + c, 2, n, rows[c], gptr[c], gperm[c], gstatus, grp_ws, grp_b, aux)))
+      return rc;
+
+  const float* g = dy;
+  int64_t ldg = lddy;
+  for (int l = num_layer - 1; l >= 0; --l) {
+    const pgnn_gin_layer& p = layers[l];
+    const int b = l & 1;
+    const float* a = acts + (size_t)l * 4 * nd;  // lin, sum, z, y
+    const float* z = a + 2 * nd;
+    const float* hin = l == 0 ? h0 : acts + (size_t)(l - 1) * 4 * nd + 3 * nd;
+    const float* mean = stats + (size_t)l * 4 * dim;
+    if (sd && l + 2 <= num_layer - 1) PGNN_HIP(hipStreamWaitEvent(main, sd->lag[b], 0));
+    if ((rc = pgnn_bn_bwd(g, ldg, z, dim, p.gamma, p.beta, mean, mean + dim, training, l != num_layer - 1, dz[b], dim,
+                          p.dgamma, p.dbeta, drop_p, drop_seed + (uint64_t)l, n, dim, op, opb, main))) return rc;
+    const float* dagg = dz[b];  // gradient of the aggregation's output
+    if (kind == 2) {
+      if ((rc = pgnn_mean_l2norm_bwd(dz[b], dim, z, dim, norms + (size_t)l * n, in_ptr, dsum[b], dim, n, dim, main))) return rc;
+      dagg = dsum[b];
+    }
+    if ((rc = pgnn_neighbor_sum(dagg, dim, out_ptr, out_dst, kind == 1 ? dinv : nullptr, dlin[b], dim, n, dim, main))) return rc;
+    if (sd) {
+      PGNN_HIP(hipEventRecord(sd->fork[1], main));
+      PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[1], 0));
+    }
+    if ((rc = pgnn_linear_bwd_weight(dlin[b], dim, hin, dim, p.dw1, p.db1, n, dim, dim, aux_ws, opb, aux))) return rc;
+    if ((rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg, dim, p.demb, dim, n, dim, aux_ws, opb, aux))) return rc;
+    if (sd) PGNN_HIP(hipEventRecord(sd->lag[b], aux));
+    if ((rc = pgnn_linear_bwd_data(dlin[b], dim, p.w1, nullptr, 0, dxb[b], dim, n, dim, dim, main))) return rc;
+    g = dxb[b];
+    ldg = dim;
+  }
+  if (sd) {
+    PGNN_HIP(hipEventRecord(sd->join, aux));
+    PGNN_HIP(hipStreamWaitEvent(main, sd->join, 0));
+  }
+  for (int c = 0; c < 2; ++c)
+    if (dxemb[c] && (rc = pgnn_segment_sum(g, dim, gptr[c], gperm[c], n, rows[c], 0, dxemb[c], dim, dim, seg_ws, seg_b, main)))
+      return rc;
+  return PGNN_OK;
+}
+
 }  // extern "C"

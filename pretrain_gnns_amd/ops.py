@@ -752,3 +752,128 @@ def chem_gin_stack(x_idx, graph, x_embedding1, x_embedding2, convs, bns, drop_p=
         torch._foreach_add_(counters, 1)  # num_batches_tracked of every layer in one launch
     return ChemGINStack.apply(x_idx, graph, (training, meta, drop_p, dropout_seed() if drop_p > 0 else 0),
                               x_embedding1.weight, x_embedding2.weight, *flat)
+
+
+# ------------------------------------------------------------------------------------ whole chem GCN / GraphSAGE network
+_lin_layouts = {}
+
+
+def _lin_grad_layout(L, dim, rows1, rows2):
+    key = (L, dim, rows1, rows2)
+    lay = _lin_layouts.get(key)
+    if lay is None:
+        sizes, shapes, byte_off = [rows1 * dim, rows2 * dim], [(rows1, dim), (rows2, dim)], []
+        per = [(6 * dim, (6, dim)), (3 * dim, (3, dim)), (dim * dim, (dim, dim)), (dim, None), (dim, None), (dim, None)]
+        for _ in range(L):
+            o, starts = sum(sizes) * 4, []
+            for sz, _shp in per:
+                starts.append(o)
+                o += sz * 4
+            byte_off.append([starts[0]] + starts[2:])  # demb (emb1+emb2 adjacent), dw, db, dgamma, dbeta
+            sizes += [sz for sz, _ in per]
+            shapes += [shp for _, shp in per]
+        byte_off.append([0, rows1 * dim * 4])
+        lay = _lin_layouts[key] = (sizes, shapes, byte_off)
+    return lay
+
+
+class ChemLinStack(Function):
+    """Atom embedding + every (GCNConv | GraphSAGEConv, BatchNorm, ReLU, dropout) layer of chem/model.py as ONE
+    library call per direction (pgnn_chem_lin_stack_fwd / _bwd, kind 1 = GCN, 2 = GraphSAGE).  Same kernels and
+    order as the per-layer path (bit-identical); JK="last".  Flat inputs: x_idx, graph, meta, xemb1, xemb2, then
+    6 tensors per layer (emb1, emb2, w, b, gamma, beta)."""
+
+    PER_LAYER = 6
+
+    @staticmethod
+    def forward(ctx, x_idx, graph, meta, xemb1, xemb2, *params):
+        require_cuda(x_idx, xemb1, xemb2, *params)
+        if x_idx.dtype != torch.int64 or x_idx.dim() != 2 or x_idx.size(1) != 2:
+            raise _lib.PgnnError("chem node features must be int64 [N, 2]")
+        x_idx = x_idx.contiguous()
+        kind, training, bns, drop_p, drop_seed = meta
+        L = len(params) // ChemLinStack.PER_LAYER
+        n, dim = x_idx.size(0), xemb1.size(1)
+        if training and n <= 1:
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s" % ((n, dim),))
+        if (kind == 1) != bool(graph.gcn):
+            raise _lib.PgnnError("graph structure was built for the other convolution type")
+        dev = x_idx.device
+        xemb1, xemb2 = _f32c(xemb1), _f32c(xemb2)
+        params = [_f32c(t) for t in params]
+        h0 = torch.empty(n, dim, dtype=torch.float32, device=dev)
+        acts = torch.empty(L, 4, n, dim, dtype=torch.float32, device=dev)  # lin, sum, z, y
+        norms = torch.empty(L, n, dtype=torch.float32, device=dev) if kind == 2 else None
+        stats = torch.empty(L, 4, dim, dtype=torch.float32, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        layers = (_lib.GinLayer * L)()
+        for l in range(L):
+            s, p = layers[l], params[l * 6:l * 6 + 6]
+            (s.emb1, s.emb2, s.w1, s.b1, s.gamma, s.beta) = [t.data_ptr() for t in p]
+            rm, rv, momentum, eps = bns[l]
+            s.running_mean = rm.data_ptr() if rm is not None else None
+            s.running_var = rv.data_ptr() if rv is not None else None
+            s.momentum, s.eps = momentum, eps
+        ws = _workspace(_ws_bytes("pgnn_chem_gin_layer_workspace_bytes", n, dim), dev)
+        check(load().pgnn_chem_lin_stack_fwd(
+            kind, x_idx.data_ptr(), xemb1.data_ptr(), xemb1.size(0), xemb2.data_ptr(), xemb2.size(0),
+            graph.in_ptr.data_ptr(), graph.in_src.data_ptr(), graph.in_code.data_ptr(),
+            graph.dinv.data_ptr() if kind == 1 else None, layers, L, int(training), h0.data_ptr(), acts.data_ptr(),
+            norms.data_ptr() if norms is not None else None, stats.data_ptr(), status.data_ptr(), float(drop_p),
+            int(drop_seed), n, dim, ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_chem_lin_stack_fwd")
+        if _CHECK_INDICES and int(status.item()):
+            raise IndexError("embedding index out of range")
+        saved = [h0, acts, stats] + ([norms] if norms is not None else []) + params
+        ctx.save_for_backward(*saved)
+        ctx.kind, ctx.x_idx, ctx.graph, ctx.training, ctx.layers = kind, x_idx, graph, bool(training), layers
+        ctx.rows, ctx.drop = (xemb1.size(0), xemb2.size(0)), (float(drop_p), int(drop_seed))
+        return acts[L - 1, 3]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        saved = ctx.saved_tensors
+        h0, acts, stats = saved[0], saved[1], saved[2]
+        norms = saved[3] if ctx.kind == 2 else None
+        L, _, n, dim = acts.shape
+        dy = _rows2d(dy)
+        dev = dy.device
+        rows1, rows2 = ctx.rows
+        sizes, shapes, byte_off = _lin_grad_layout(L, dim, rows1, rows2)
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        base = flat.data_ptr()
+        layers = ctx.layers
+        for l in range(L):
+            s, o = layers[l], byte_off[l]
+            s.demb, s.dw1, s.db1, s.dgamma, s.dbeta = [base + b for b in o]
+        dx1, dx2 = base + byte_off[L][0], base + byte_off[L][1]
+        ws = _workspace(_ws_bytes("pgnn_chem_lin_stack_workspace_bytes", n, dim, rows1, rows2), dev)
+        g = ctx.graph
+        check(load().pgnn_chem_lin_stack_bwd(
+            ctx.kind, dy.data_ptr(), dy.stride(0), ctx.x_idx.data_ptr(), rows1, rows2, g.in_ptr.data_ptr(),
+            g.out_ptr.data_ptr(), g.out_dst.data_ptr(), g.dinv.data_ptr() if ctx.kind == 1 else None, g.cfeat.data_ptr(),
+            layers, L, int(ctx.training), h0.data_ptr(), acts.data_ptr(), norms.data_ptr() if norms is not None else None,
+            stats.data_ptr(), dx1 if ctx.needs_input_grad[3] else None, dx2 if ctx.needs_input_grad[4] else None,
+            ctx.drop[0], ctx.drop[1], n, dim, ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_chem_lin_stack_bwd")
+        pieces = flat.split_with_sizes(sizes)
+        return (None, None, None) + tuple(t if shp is None else t.view(shp) for t, shp in zip(pieces, shapes))
+
+
+def chem_lin_stack(kind, x_idx, graph, x_embedding1, x_embedding2, convs, bns, drop_p=0.0):
+    """GCN (kind 1) / GraphSAGE (kind 2) network through the one-call path; see ``chem_gin_stack``."""
+    training = bns[0].training or bns[0].running_mean is None
+    meta, flat, counters = [], [], []
+    for conv, bn in zip(convs, bns):
+        momentum = 0.0 if bn.momentum is None else bn.momentum
+        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            counters.append(bn.num_batches_tracked)
+            if bn.momentum is None:
+                momentum = 1.0 / float(bn.num_batches_tracked + 1)
+        meta.append((bn.running_mean if bn.track_running_stats else None,
+                     bn.running_var if bn.track_running_stats else None, float(momentum), float(bn.eps)))
+        flat += [conv.edge_embedding1.weight, conv.edge_embedding2.weight, conv.linear.weight, conv.linear.bias,
+                 bn.weight, bn.bias]
+    if counters:
+        torch._foreach_add_(counters, 1)
+    return ChemLinStack.apply(x_idx, graph, (kind, training, meta, drop_p, dropout_seed() if drop_p > 0 else 0),
+                              x_embedding1.weight, x_embedding2.weight, *flat)

@@ -415,6 +415,33 @@ def test_one_call_network_equals_per_layer_path(graphs, layers, training, monkey
         assert torch.equal(res[0][2][k], res[1][2][k]), k
 
 
+@pytest.mark.parametrize("gnn_type", ["gcn", "graphsage"])
+@pytest.mark.parametrize("graphs,layers,training,drop", [(48, 5, True, 0.0), (3, 2, True, 0.0), (48, 3, False, 0.0), (400, 4, True, 0.0)])
+def test_one_call_gcn_and_graphsage_equal_per_layer_path(gnn_type, graphs, layers, training, drop, monkeypatch):
+    """pgnn_chem_lin_stack_fwd/_bwd must be BIT-identical to the per-layer GCN / GraphSAGE calls"""
+    import copy
+    hchem, _ = _hip()
+    _, a = _pair(ochem.GNN, hchem.GNN, layers, 300, seed=6, gnn_type=gnn_type)
+    b = copy.deepcopy(a)
+    a.train(training), b.train(training)
+    d = synthetic.chem_masking_batch(graphs, seed=7).to(DEV)
+    w = torch.randn(d.x.size(0), 300, device=DEV)
+    res = []
+    for m, flag in ((a, True), (b, False)):
+        monkeypatch.setattr(hchem, "_STACK_CALL", flag)
+        for _ in range(2):
+            m.zero_grad()
+            out = m(d.x, d.edge_index, d.edge_attr)
+            (out * w).sum().backward()
+        res.append((out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                    {k: v.clone() for k, v in m.named_buffers()}))
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
+
+
 def test_large_batch_properties():
     """BASELINE full size (2048 graphs): size-independent checks instead of a slow oracle run --
     linearity of the aggregation in x and agreement of the aggregation with a torch index_add on GPU."""
