@@ -260,7 +260,8 @@ typedef struct pgnn_gin_layer {
   float *demb /* [9,dim]: rows 0..5 d emb1, 6..8 d emb2 */, *dw1, *db1, *dw2, *db2, *dgamma, *dbeta;
 } pgnn_gin_layer;
 
-size_t pgnn_chem_gin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t rows1, int64_t rows2);
+size_t pgnn_chem_gin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t rows1, int64_t rows2,
+                                           int64_t num_layer);
 int pgnn_chem_gin_stack_fwd(const int64_t* x_idx /* [n,2] atom type, chirality */, const float* xemb1,
                             int64_t rows1, const float* xemb2, int64_t rows2, const int32_t* in_ptr,
                             const int32_t* in_src, const uint8_t* in_code, const pgnn_gin_layer* layers,

@@ -56,7 +56,7 @@ PROTOTYPES = {
                                      _p, _p, _p, _p, _p, _p, _f, _u64, _i64, _i64, _p, _sz, _p]),
     "pgnn_chem_gin_layer_bwd": (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i,
                                      _p, _p, _p, _p, _p, _p, _p, _p, _f, _u64, _i64, _i64, _p, _sz, _p]),
-    "pgnn_chem_gin_stack_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "pgnn_chem_gin_stack_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64]),
     "pgnn_chem_gin_stack_fwd": (_i, [_p, _p, _i64, _p, _i64, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _f, _u64,
                                      _i64, _i64, _p, _sz, _p]),
     "pgnn_chem_gin_stack_bwd": (_i, [_p, _i64, _p, _i64, _i64, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _f, _u64,

@@ -152,10 +152,13 @@ inline size_t stack_segsum_ws(int64_t n, int64_t dim, int64_t rows1, int64_t row
 }
 }  // namespace
 
-size_t pgnn_chem_gin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t rows1, int64_t rows2) {
+size_t pgnn_chem_gin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t rows1, int64_t rows2, int64_t num_layer) {
   const size_t nd = align_up((size_t)n * dim * 4, 256);
-  // 2 x op scratch + 2 x (dz, dagg, dx: nd each; dhid: 2 nd) + group-by-key of the two atom columns
-  return 2 * op_ws_bytes(n, dim) + 2 * 5 * nd + 2 * align_up((size_t)n * 4, 256) +
+  // 2 x op scratch + S x (dz, dagg, dx: nd each; dhid: 2 nd) + group-by-key of the two atom columns.
+  // S = 2 (ping-pong by layer parity); room for one set per layer is reserved while the side stream may be
+  // used so that PGNN_STACK_PER_LAYER_BUFFERS=1 (an A/B knob) needs no other sizing.
+  const size_t sets = n <= kSideMaxRows ? (size_t)std::max<int64_t>(num_layer, 2) : 2;
+  return 2 * op_ws_bytes(n, dim) + sets * 5 * nd + 2 * align_up((size_t)n * 4, 256) +
          2 * align_up((size_t)(std::max(rows1, rows2) + 1) * 4, 256) + 256 + stack_group_ws(n, rows1, rows2) +
          stack_segsum_ws(n, dim, rows1, rows2) + 256;
 }
@@ -223,7 +226,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     set_error("chem_gin_stack_bwd: no layers");
     return PGNN_ERR_ARG;
   }
-  if (ws_bytes < pgnn_chem_gin_stack_workspace_bytes(n, dim, rows1, rows2)) {
+  if (ws_bytes < pgnn_chem_gin_stack_workspace_bytes(n, dim, rows1, rows2, num_layer)) {
     set_error("chem_gin_stack_bwd workspace too small");
     return PGNN_ERR_WORKSPACE;
   }
@@ -232,8 +235,10 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   const size_t opb = op_ws_bytes(n, dim);
   char* op = cv.take<char>(opb);
   char* op2 = cv.take<char>(opb);
-  float *dz[2], *dhid[2], *dagg[2], *dxb[2];
-  for (int p = 0; p < 2; ++p) {
+  constexpr int kMaxSets = 64;
+  const int sets = n <= kSideMaxRows ? std::min(std::max(num_layer, 2), kMaxSets) : 2;
+  float *dz[kMaxSets], *dhid[kMaxSets], *dagg[kMaxSets], *dxb[kMaxSets];
+  for (int p = 0; p < sets; ++p) {
     dz[p] = cv.take<float>(nd);
     dhid[p] = cv.take<float>(2 * nd);
     dagg[p] = cv.take<float>(nd);
@@ -252,7 +257,11 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   char* seg_ws = cv.take<char>(seg_b);
 
   hipStream_t main = (hipStream_t)stream;
-  Side* sd = (use_side_stream() && n <= kSideMaxRows) ? side_for_current_device() : nullptr;
+  Side* sd = (use_side_stream() && n <= kSideMaxRows && num_layer <= kMaxSets) ? side_for_current_device() : nullptr;
+  // One buffer set per layer would save the lag events (8 event calls per step), but the ping-pong pair stays
+  // resident in the 256 MB Infinity Cache and wins on the GPU side: 1.80 vs 1.85 ms per replayed step (measured).
+  const char* pl = getenv("PGNN_STACK_PER_LAYER_BUFFERS");
+  const bool per_layer = sd && pl && atoi(pl) != 0;
   hipStream_t aux = sd ? sd->stream : main;
   char* aux_ws = sd ? op2 : op;
   int rc;
@@ -272,14 +281,13 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   int64_t ldg = lddy;
   for (int l = num_layer - 1; l >= 0; --l) {
     const pgnn_gin_layer& p = layers[l];
-    const int b = l & 1;
+    const int b = per_layer ? l : (l & 1);  // own buffer set per layer, or ping-pong guarded by lag events
+    if (sd && !per_layer && l + 2 <= num_layer - 1) PGNN_HIP(hipStreamWaitEvent(main, sd->lag[b], 0));
     const float* a = acts + (size_t)l * 3 * nd;  // agg, z, y
     const float* agg = a;
     const float* z = a + nd;
     const float* hd = hid + (size_t)l * 2 * nd;
     const float* mean = stats + (size_t)l * 4 * dim;
-    // buffer set b was last read by the side stream two layers ago
-    if (sd && l + 2 <= num_layer - 1) PGNN_HIP(hipStreamWaitEvent(main, sd->lag[b], 0));
     if ((rc = pgnn_bn_bwd(g, ldg, z, dim, p.gamma, p.beta, mean, mean + dim, training, l != num_layer - 1, dz[b], dim,
                           p.dgamma, p.dbeta, drop_p, drop_seed + (uint64_t)l, n, dim, op, opb, main))) return rc;
     if ((rc = pgnn_linear_bwd_data(dz[b], dim, p.w2, hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main))) return rc;
@@ -291,7 +299,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     if ((rc = pgnn_linear_bwd_weight(dz[b], dim, hd, 2 * dim, p.dw2, p.db2, n, 2 * dim, dim, aux_ws, opb, aux))) return rc;
     if ((rc = pgnn_linear_bwd_weight(dhid[b], 2 * dim, agg, dim, p.dw1, p.db1, n, dim, 2 * dim, aux_ws, opb, aux))) return rc;
     if ((rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, aux_ws, opb, aux))) return rc;
-    if (sd) PGNN_HIP(hipEventRecord(sd->lag[b], aux));
+    if (sd && !per_layer) PGNN_HIP(hipEventRecord(sd->lag[b], aux));
     if ((rc = pgnn_neighbor_sum(dagg[b], dim, out_ptr, out_dst, nullptr, dxb[b], dim, n, dim, main))) return rc;
     g = dxb[b];
     ldg = dim;
@@ -315,7 +323,10 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
  * stats [L][4][dim] as for the GIN stack.  The per-layer struct uses w1/b1 (+ dw1/db1) for the Linear.
  * --------------------------------------------------------------------------------------------- */
 size_t pgnn_chem_lin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t rows1, int64_t rows2) {
-  return pgnn_chem_gin_stack_workspace_bytes(n, dim, rows1, rows2);
+  const size_t nd = align_up((size_t)n * dim * 4, 256);
+  return op_ws_bytes(n, dim) + 2 * 4 * nd + 2 * align_up((size_t)n * 4, 256) +
+         2 * align_up((size_t)(std::max(rows1, rows2) + 1) * 4, 256) + 256 + stack_group_ws(n, rows1, rows2) +
+         stack_segsum_ws(n, dim, rows1, rows2) + 256;
 }
 
 int pgnn_chem_lin_stack_fwd(int kind, const int64_t* x_idx, const float* xemb1, int64_t rows1, const float* xemb2,
@@ -369,18 +380,18 @@ int pgnn_chem_lin_stack_bwd(int kind, const float* dy, int64_t lddy, const int64
     set_error("chem_lin_stack_bwd workspace too small");
     return PGNN_ERR_WORKSPACE;
   }
+  // Everything on the caller's stream: with a third of the GIN stack's MFMA work per layer this path is
+  // bound by the host's launch rate at the reference's batch size, and the ~20 event calls a forked
+  // backward needs cost more (0.15 ms) than the overlap returns (measured: 1.49 vs 1.57 ms per GCN step).
   const size_t nd = (size_t)n * dim;
   Carver cv(ws);
   const size_t opb = op_ws_bytes(n, dim);
   char* op = cv.take<char>(opb);
-  char* op2 = cv.take<char>(opb);
-  // per parity: dz (BatchNorm input gradient), dsum (GraphSAGE only), dlin, dx -- the GIN stack's buffer budget
   float *dz[2], *dsum[2], *dlin[2], *dxb[2];
   for (int p = 0; p < 2; ++p) {
     dz[p] = cv.take<float>(nd);
     dsum[p] = cv.take<float>(nd);
     dlin[p] = cv.take<float>(nd);
-    (void)cv.take<float>(nd);  // keeps the carve identical to the GIN stack (dhid is 2 nd there)
     dxb[p] = cv.take<float>(nd);
   }
   int32_t* gptr[2];
@@ -396,19 +407,12 @@ int pgnn_chem_lin_stack_bwd(int kind, const float* dy, int64_t lddy, const int64
   char* seg_ws = cv.take<char>(seg_b);
 
   hipStream_t main = (hipStream_t)stream;
-  Side* sd = (use_side_stream() && n <= kSideMaxRows) ? side_for_current_device() : nullptr;
-  hipStream_t aux = sd ? sd->stream : main;
-  char* aux_ws = sd ? op2 : op;
   int rc;
-  if (sd) {
-    PGNN_HIP(hipEventRecord(sd->fork[0], main));
-    PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[0], 0));
-  }
   const int64_t rows[2] = {rows1, rows2};
   float* dxemb[2] = {dxemb1, dxemb2};
-  PGNN_HIP(hipMemsetAsync(gstatus, 0, sizeof(int32_t), aux));
+  PGNN_HIP(hipMemsetAsync(gstatus, 0, sizeof(int32_t), main));
   for (int c = 0; c < 2; ++c)
-    if (dxemb[c] && (rc = pgnn_group_by_key(x_idx + c, 2, n, rows[c], gptr[c], gperm[c], gstatus, grp_ws, grp_b, aux)))
+    if (dxemb[c] && (rc = pgnn_group_by_key(x_idx + c, 2, n, rows[c], gptr[c], gperm[c], gstatus, grp_ws, grp_b, main)))
       return rc;
 
   const float* g = dy;
@@ -420,7 +424,6 @@ int pgnn_chem_lin_stack_bwd(int kind, const float* dy, int64_t lddy, const int64
     const float* z = a + 2 * nd;
     const float* hin = l == 0 ? h0 : acts + (size_t)(l - 1) * 4 * nd + 3 * nd;
     const float* mean = stats + (size_t)l * 4 * dim;
-    if (sd && l + 2 <= num_layer - 1) PGNN_HIP(hipStreamWaitEvent(main, sd->lag[b], 0));
     if ((rc = pgnn_bn_bwd(g, ldg, z, dim, p.gamma, p.beta, mean, mean + dim, training, l != num_layer - 1, dz[b], dim,
                           p.dgamma, p.dbeta, drop_p, drop_seed + (uint64_t)l, n, dim, op, opb, main))) return rc;
     const float* dagg = dz[b];  // gradient of the aggregation's output
@@ -429,20 +432,11 @@ int pgnn_chem_lin_stack_bwd(int kind, const float* dy, int64_t lddy, const int64
       dagg = dsum[b];
     }
     if ((rc = pgnn_neighbor_sum(dagg, dim, out_ptr, out_dst, kind == 1 ? dinv : nullptr, dlin[b], dim, n, dim, main))) return rc;
-    if (sd) {
-      PGNN_HIP(hipEventRecord(sd->fork[1], main));
-      PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[1], 0));
-    }
-    if ((rc = pgnn_linear_bwd_weight(dlin[b], dim, hin, dim, p.dw1, p.db1, n, dim, dim, aux_ws, opb, aux))) return rc;
-    if ((rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg, dim, p.demb, dim, n, dim, aux_ws, opb, aux))) return rc;
-    if (sd) PGNN_HIP(hipEventRecord(sd->lag[b], aux));
     if ((rc = pgnn_linear_bwd_data(dlin[b], dim, p.w1, nullptr, 0, dxb[b], dim, n, dim, dim, main))) return rc;
+    if ((rc = pgnn_linear_bwd_weight(dlin[b], dim, hin, dim, p.dw1, p.db1, n, dim, dim, op, opb, main))) return rc;
+    if ((rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg, dim, p.demb, dim, n, dim, op, opb, main))) return rc;
     g = dxb[b];
     ldg = dim;
-  }
-  if (sd) {
-    PGNN_HIP(hipEventRecord(sd->join, aux));
-    PGNN_HIP(hipStreamWaitEvent(main, sd->join, 0));
   }
   for (int c = 0; c < 2; ++c)
     if (dxemb[c] && (rc = pgnn_segment_sum(g, dim, gptr[c], gperm[c], n, rows[c], 0, dxemb[c], dim, dim, seg_ws, seg_b, main)))

@@ -692,7 +692,7 @@ class ChemGINStack(Function):
             s, o = layers[l], byte_off[l]
             s.demb, s.dw1, s.db1, s.dw2, s.db2, s.dgamma, s.dbeta = [base + b for b in o]
         dx1, dx2 = base + byte_off[L][0], base + byte_off[L][1]
-        ws = _workspace(_ws_bytes("pgnn_chem_gin_stack_workspace_bytes", n, dim, rows1, rows2), dev)
+        ws = _workspace(_ws_bytes("pgnn_chem_gin_stack_workspace_bytes", n, dim, rows1, rows2, L), dev)
         g = ctx.graph
         check(load().pgnn_chem_gin_stack_bwd(
             dy.data_ptr(), dy.stride(0), ctx.x_idx.data_ptr(), rows1, rows2, g.out_ptr.data_ptr(), g.out_dst.data_ptr(),

@@ -8,7 +8,7 @@ from pretrain_gnns_amd.data import synthetic
 dev = "cuda"
 batch = synthetic.chem_masking_batch(256, seed=7).to(dev)
 torch.manual_seed(0)
-mods = [hmodel.GNN(5, 300).to(dev), torch.nn.Linear(300, 119).to(dev), torch.nn.Linear(300, 4).to(dev)]
+mods = [hmodel.GNN(5, 300, gnn_type=(sys.argv[1] if len(sys.argv) > 1 else "gin")).to(dev), torch.nn.Linear(300, 119).to(dev), torch.nn.Linear(300, 4).to(dev)]
 opts = [torch.optim.Adam(m.parameters(), lr=1e-3, fused=True) for m in mods]
 for _ in range(10):
     steps.chem_masking_step(mods, opts, batch)
