@@ -44,6 +44,10 @@ inline bool use_side_stream() {
   const char* v = getenv("PGNN_SIDE_STREAM");
   return !v || atoi(v) != 0;
 }
+inline bool per_layer_buffers() {
+  const char* v = getenv("PGNN_STACK_PER_LAYER_BUFFERS");
+  return v && atoi(v) != 0;
+}
 inline size_t op_ws_bytes(int64_t n, int64_t d) {
   size_t m = pgnn_bn_workspace_bytes(n, d);
   m = std::max(m, pgnn_bn_workspace_bytes(n, 2 * d));
@@ -155,9 +159,8 @@ inline size_t stack_segsum_ws(int64_t n, int64_t dim, int64_t rows1, int64_t row
 size_t pgnn_chem_gin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t rows1, int64_t rows2, int64_t num_layer) {
   const size_t nd = align_up((size_t)n * dim * 4, 256);
   // 2 x op scratch + S x (dz, dagg, dx: nd each; dhid: 2 nd) + group-by-key of the two atom columns.
-  // S = 2 (ping-pong by layer parity); room for one set per layer is reserved while the side stream may be
-  // used so that PGNN_STACK_PER_LAYER_BUFFERS=1 (an A/B knob) needs no other sizing.
-  const size_t sets = n <= kSideMaxRows ? (size_t)std::max<int64_t>(num_layer, 2) : 2;
+  // S = 2 (ping-pong by layer parity), or one set per layer under the PGNN_STACK_PER_LAYER_BUFFERS=1 A/B knob.
+  const size_t sets = (per_layer_buffers() && n <= kSideMaxRows) ? (size_t)std::max<int64_t>(num_layer, 2) : 2;
   return 2 * op_ws_bytes(n, dim) + sets * 5 * nd + 2 * align_up((size_t)n * 4, 256) +
          2 * align_up((size_t)(std::max(rows1, rows2) + 1) * 4, 256) + 256 + stack_group_ws(n, rows1, rows2) +
          stack_segsum_ws(n, dim, rows1, rows2) + 256;
@@ -236,7 +239,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   char* op = cv.take<char>(opb);
   char* op2 = cv.take<char>(opb);
   constexpr int kMaxSets = 64;
-  const int sets = n <= kSideMaxRows ? std::min(std::max(num_layer, 2), kMaxSets) : 2;
+  const int sets = (per_layer_buffers() && n <= kSideMaxRows) ? std::min(std::max(num_layer, 2), kMaxSets) : 2;
   float *dz[kMaxSets], *dhid[kMaxSets], *dagg[kMaxSets], *dxb[kMaxSets];
   for (int p = 0; p < sets; ++p) {
     dz[p] = cv.take<float>(nd);
@@ -260,8 +263,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   Side* sd = (use_side_stream() && n <= kSideMaxRows && num_layer <= kMaxSets) ? side_for_current_device() : nullptr;
   // One buffer set per layer would save the lag events (8 event calls per step), but the ping-pong pair stays
   // resident in the 256 MB Infinity Cache and wins on the GPU side: 1.80 vs 1.85 ms per replayed step (measured).
-  const char* pl = getenv("PGNN_STACK_PER_LAYER_BUFFERS");
-  const bool per_layer = sd && pl && atoi(pl) != 0;
+  const bool per_layer = sd && per_layer_buffers();
   hipStream_t aux = sd ? sd->stream : main;
   char* aux_ws = sd ? op2 : op;
   int rc;
