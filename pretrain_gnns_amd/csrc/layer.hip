@@ -267,16 +267,13 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   hipStream_t aux = sd ? sd->stream : main;
   char* aux_ws = sd ? op2 : op;
   int rc;
-  // the atom-type / chirality groupings only depend on x_idx: first thing on the side stream
-  if (sd) {
-    PGNN_HIP(hipEventRecord(sd->fork[0], main));
-    PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[0], 0));
-  }
+  // Every event record / wait costs ~7 us of host time, so forks are spent only where they buy overlap:
+  // the atom-type / chirality groupings (three tiny kernels) stay on the caller's stream.
   const int64_t rows[2] = {rows1, rows2};
   float* dxemb[2] = {dxemb1, dxemb2};
-  PGNN_HIP(hipMemsetAsync(gstatus, 0, sizeof(int32_t), aux));
+  PGNN_HIP(hipMemsetAsync(gstatus, 0, sizeof(int32_t), main));
   for (int c = 0; c < 2; ++c)
-    if (dxemb[c] && (rc = pgnn_group_by_key(x_idx + c, 2, n, rows[c], gptr[c], gperm[c], gstatus, grp_ws, grp_b, aux)))
+    if (dxemb[c] && (rc = pgnn_group_by_key(x_idx + c, 2, n, rows[c], gptr[c], gperm[c], gstatus, grp_ws, grp_b, main)))
       return rc;
 
   const float* g = dy;
@@ -301,7 +298,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     if ((rc = pgnn_linear_bwd_weight(dz[b], dim, hd, 2 * dim, p.dw2, p.db2, n, 2 * dim, dim, aux_ws, opb, aux))) return rc;
     if ((rc = pgnn_linear_bwd_weight(dhid[b], 2 * dim, agg, dim, p.dw1, p.db1, n, dim, 2 * dim, aux_ws, opb, aux))) return rc;
     if ((rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, aux_ws, opb, aux))) return rc;
-    if (sd && !per_layer) PGNN_HIP(hipEventRecord(sd->lag[b], aux));
+    if (sd && !per_layer && l >= 2) PGNN_HIP(hipEventRecord(sd->lag[b], aux));  // awaited by layer l-2 only
     if ((rc = pgnn_neighbor_sum(dagg[b], dim, out_ptr, out_dst, nullptr, dxb[b], dim, n, dim, main))) return rc;
     g = dxb[b];
     ldg = dim;
