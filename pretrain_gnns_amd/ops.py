@@ -629,8 +629,8 @@ def chem_gin_layer(x, conv, bn, graph, relu, drop_p=0.0):
 class ChemGINStack(Function):
     """Atom embedding + every (GINConv, BatchNorm, ReLU) layer of chem/model.py:258-277 as ONE library
     call per direction (pgnn_chem_gin_stack_fwd / _bwd).  Bit-identical to the per-layer path; valid
-    for JK="last" without dropout (the pre-training configuration), which is when ``GNN.forward``
-    selects it.  Flat inputs: x_idx, graph, meta, xemb1, xemb2, then 9 tensors per layer
+    for JK="last" (the pre-training and fine-tuning configurations; dropout is fused), which is when
+    ``GNN.forward`` selects it.  Flat inputs: x_idx, graph, meta, xemb1, xemb2, then 8 tensors per layer
     (emb1, emb2, w1, b1, w2, b2, gamma, beta) -- see ``chem_gin_stack``."""
 
     PER_LAYER = 8
