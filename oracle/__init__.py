@@ -13,8 +13,9 @@ PyG-1.0.3 primitives it uses are restated in ``oracle/pyg_semantics.py``.
 
 PARITY PINNING.  The reference has no test that pins ``GNN.forward`` numerically
 (SURVEY.md §4, §8c): **parity unpinned** at the arithmetic level.  What *is* pinned:
-  * the state-dict key/shape contract and real GCN weights + BN running statistics
-    through the shipped ``chem|bio/model_architecture/gcn_*.pth`` checkpoints, which the
-    oracle strict-loads (``oracle/make_golden.py`` -> ``tests/golden/*.pt``);
+  * the state-dict key/shape contract and real GCN / GraphSAGE / GAT weights + BN running statistics
+    through the shipped ``chem|bio/model_architecture/{gcn,graphsage,gat}_*.pth`` checkpoints, which
+    the oracle strict-loads (``oracle/make_golden.py`` -> ``tests/golden/*.pt``; the GIN blobs are
+    absent from the reference repository);
   * the edge-ordering / masking contracts of ``chem/util.py:212-213,229-241``.
 """
