@@ -23,7 +23,6 @@ void set_error(const char* fmt, ...) {
 namespace {
 
 constexpr int kScanItems = 1024;  // per block: 256 threads x 4
-constexpr int kSmallSeg = 16;
 
 struct GroupJob {
   const int64_t* key;
@@ -166,23 +165,30 @@ __global__ void k_fill(GroupJobs jobs, int64_t n_items, int64_t n_keys) {
 
 // The atomic fill is order-nondeterministic; ranking the (unique) item ids inside each segment
 // restores the original order => stable grouping, bitwise-reproducible downstream sums.
-__global__ void __launch_bounds__(256) k_sort_segments(GroupJobs jobs, int64_t n_keys) {
+// One thread per ITEM slot: its rank is the number of smaller ids in its segment (l loads, balanced over
+// the grid whatever the degree distribution -- a thread per segment costs l^2 for its slowest lane, 91 us
+// on a PPI batch).  Segments longer than kRankMax are ranked by whole waves instead (thread index = key).
+constexpr int kRankMax = 512;
+__global__ void __launch_bounds__(256) k_sort_segments(GroupJobs jobs, int64_t n_items, int64_t n_keys) {
   const GroupJob& job = jobs.j[blockIdx.y];
-  const int64_t seg = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  int beg = 0, len = 0;
-  if (seg < n_keys) {
-    beg = job.ptr[seg];
-    len = job.ptr[seg + 1] - beg;
-  }
-  if (len <= kSmallSeg) {
-    for (int a = 0; a < len; ++a) {
-      const int v = job.tmp[beg + a];
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t < n_items) {
+    const int v = job.tmp[t];
+    int64_t k = job.key[(int64_t)v * job.stride];
+    if (k < 0 || k >= n_keys) k = 0;
+    const int beg = job.ptr[k], len = job.ptr[k + 1] - beg;
+    if (len <= kRankMax) {
       int rank = 0;
       for (int b = 0; b < len; ++b) rank += job.tmp[beg + b] < v;
       job.perm[beg + rank] = v;
     }
   }
-  unsigned long long m = __ballot(len > kSmallSeg);
+  int beg = 0, len = 0;
+  if (t < n_keys) {
+    beg = job.ptr[t];
+    len = job.ptr[t + 1] - beg;
+  }
+  unsigned long long m = __ballot(len > kRankMax);
   const int lane = lane_id();
   while (m) {
     const int src = __ffsll((long long)m) - 1;
@@ -304,8 +310,8 @@ int run_group(GroupJobs jobs, int njobs, int64_t n_items, int64_t n_keys, int32_
   launch_scan(jobs, njobs, n, st);
   if (n_items > 0) {
     hipLaunchKernelGGL(k_fill, dim3(gi, njobs), dim3(256), 0, st, jobs, n_items, n_keys);
-    hipLaunchKernelGGL(k_sort_segments, dim3((int)ceil_div(n_keys, 256), njobs), dim3(256), 0, st,
-                       jobs, n_keys);
+    hipLaunchKernelGGL(k_sort_segments, dim3((int)ceil_div(std::max(n_keys, n_items), 256), njobs), dim3(256), 0, st,
+                       jobs, n_items, n_keys);
   }
   return check_launch("group_by_key");
 }
