@@ -124,12 +124,16 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
       const bool kmajor = isA ? A_KMAJOR : B_KMAJOR;
       const int rows = isA ? BM : BN;
       if (kmajor) {
-        const int row = idx >> 2, kq = idx & 3;
+        // XOR swizzle of the four 16-byte k-chunks of a row (chunk kq of row r lives at kq ^ ((-(r>>2))&3)):
+        // the 16 lanes of every ds_read_b128 group then hit 16 distinct 16-byte bank groups (conflict-free)
+        const int row = idx >> 2, kq = (idx & 3) ^ ((-(row >> 2)) & 3);
         rowok[j] = r0 + row < rmax;
         kofs[j] = sub * BK + 4 * kq;
         src[j] = base + (int64_t)(r0 + row) * ld + kbeg + kofs[j];
         kstride[j] = BK * KS;
       } else {
+        // (rotating k-rows 4..7 / 12..15 by 16 columns makes these ds_read_b32 fragments conflict-free as well,
+        // but measured 2 % slower on backward-data: the extra index arithmetic costs more than the conflicts)
         const int kr = idx / (rows / 4), rq = idx % (rows / 4);
         rowok[j] = r0 + 4 * rq < rmax;
         ones[j] = ONES && !isA && r0 + 4 * rq == rmax;
@@ -174,7 +178,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
     for (int i = 0; i < MI; ++i) {
       const int m = wm0 + i * 16 + fr;
       if (A_KMAJOR) {
-        a[i] = *reinterpret_cast<const f32x4*>(At + m * BK + fk * 4);
+        a[i] = *reinterpret_cast<const f32x4*>(At + m * BK + ((fk ^ ((-(fr >> 2)) & 3)) * 4));
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[i][r] = At[(fk * 4 + r) * BM + m];
@@ -184,7 +188,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
     for (int j = 0; j < NI; ++j) {
       const int n = wn0 + j * 16 + fr;
       if (B_KMAJOR) {
-        b[j] = *reinterpret_cast<const f32x4*>(Bt + n * BK + fk * 4);
+        b[j] = *reinterpret_cast<const f32x4*>(Bt + n * BK + ((fk ^ ((-(fr >> 2)) & 3)) * 4));
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) b[j][r] = Bt[(fk * 4 + r) * BN + n];
