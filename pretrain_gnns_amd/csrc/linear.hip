@@ -319,11 +319,15 @@ int launch_gemm(const GemmArgs& p, int nsplit, hipStream_t st) {
 // power-of-two 128.  Small M (one 256-graph batch is ~6.8k rows) is a quantisation problem -- the
 // whole product is only ~8 MFMA blocks per SIMD -- so it gets the smallest wave tiles that still
 // give every SIMD a wave; large M gets the widest tile (least re-reading of the A panel).
-enum TileCfg { T128x304 = 0, T64x160 = 1, T128x160 = 2, T128x128 = 3, T64x64 = 4, T64x160w8 = 5, T320x160 = 6, kNumCfg = 7 };
+enum TileCfg { T128x304 = 0, T64x160 = 1, T128x160 = 2, T128x128 = 3, T64x64 = 4, T64x160w8 = 5, T320x160 = 6, T256x304 = 7, kNumCfg = 8 };
 struct CfgInfo { int bm, bn, wave_blocks; };
 static const CfgInfo kCfg[kNumCfg] = {{128, 304, 38}, {64, 160, 10}, {128, 160, 20}, {128, 128, 16}, {64, 64, 4},
-                                      {64, 160, 5}, {320, 160, 25}};
+                                      {64, 160, 5}, {320, 160, 25}, {256, 304, 38}};
 
+inline int env_int_linear(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
 inline int env_cfg() {
   const char* v = getenv("PGNN_GEMM_CFG");
   return v ? atoi(v) : -1;
@@ -339,11 +343,15 @@ inline int env_cfg() {
 inline TileCfg pick_cfg(int64_t m, int64_t n, int kind) {
   const int forced = env_cfg();
   if (forced >= 0 && forced < kNumCfg) return (TileCfg)forced;
+  // A 256x304 tile (8 waves x 32x304; 1.3 % instead of 6.7 % padding on N = 300 / 600) is 5-8 % faster in the
+  // isolated micro-benchmark at M = 262144 (forward 92 -> 97-103 TFLOP/s) but makes the 16384-graph train step
+  // 3 % SLOWER (55.9 vs 54.1 ms, measured A/B in one process) -- opt-in only.
+  if (m >= 65536 && env_int_linear("PGNN_GEMM_WIDE", 0)) return T256x304;
   double best = 1e30;
   int arg = T64x64;
   for (int c = 0; c < kNumCfg; ++c) {
     if (c == T128x304 && (kind == 0 || m < 32768)) continue;
-    if (c == T128x160 || c == T64x160 || c == T320x160) continue;  // 8-wave 64x160 beats the 4-wave one everywhere measured
+    if (c == T128x160 || c == T64x160 || c == T320x160 || c == T256x304) continue;  // 8-wave 64x160 beats the 4-wave one everywhere measured
     const int64_t tiles = ceil_div(m, kCfg[c].bm) * ceil_div(n, kCfg[c].bn);
     const int64_t per_simd = ceil_div(tiles * 4, 4 * kNumCU);             // waves each SIMD must run
     const double t = (double)per_simd * (kCfg[c].wave_blocks + 5.0);     // + fixed per-tile overhead
@@ -361,6 +369,7 @@ int launch_cfg(TileCfg c, const GemmArgs& p, int nsplit, hipStream_t st) {
     case T128x128: return launch_gemm<128, 128, 2, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
     case T64x160w8: return launch_gemm<64, 160, 4, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
     case T320x160: return launch_gemm<320, 160, 4, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
+    case T256x304: return launch_gemm<256, 304, 8, 1, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
     default: return launch_gemm<64, 64, 2, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
   }
 }
