@@ -503,6 +503,41 @@ def test_batch_without_any_edge(gnn_type):
     assert all(torch.isfinite(p.grad).all() for p in hip.parameters() if p.grad is not None)
 
 
+@pytest.mark.parametrize("emb_dim", [64, 128, 256, 304, 512])
+@pytest.mark.parametrize("gnn_type", ["gin", "gcn", "graphsage"])
+def test_other_embedding_widths(emb_dim, gnn_type):
+    """the reference's --emb_dim is free: every kernel family must work off 300 (generic DMA instantiation,
+    the wide-row fallback above 320, other tile counts in the GEMMs), forward and backward, through the
+    one-call path"""
+    hchem, _ = _hip()
+    ref, hip = _pair(ochem.GNN, hchem.GNN, 3, emb_dim, seed=emb_dim, gnn_type=gnn_type)
+    b = synthetic.chem_plain_batch(24, seed=emb_dim)
+    d = b.clone().to(DEV)
+    out_ref = ref(b.x, b.edge_index, b.edge_attr)
+    out_hip = hip(d.x, d.edge_index, d.edge_attr)
+    torch.testing.assert_close(out_hip.detach().cpu(), out_ref.detach(), **TOL)
+    w = torch.randn_like(out_ref)
+    (out_hip * w.to(DEV)).sum().backward()
+    _grads_close(ref, hip, (b.x, b.edge_index, b.edge_attr), w)
+    ref.eval(), hip.eval()
+    with torch.no_grad():
+        torch.testing.assert_close(hip(d.x, d.edge_index, d.edge_attr).cpu(), ref(b.x, b.edge_index, b.edge_attr), **TOL)
+
+
+@pytest.mark.parametrize("num_layer", [2, 7])
+def test_other_depths(num_layer):
+    hchem, _ = _hip()
+    ref, hip = _pair(ochem.GNN, hchem.GNN, num_layer, 300, seed=num_layer)
+    b = synthetic.chem_plain_batch(16, seed=num_layer)
+    d = b.clone().to(DEV)
+    out_ref = ref(b.x, b.edge_index, b.edge_attr)
+    out_hip = hip(d.x, d.edge_index, d.edge_attr)
+    torch.testing.assert_close(out_hip.detach().cpu(), out_ref.detach(), rtol=3e-4, atol=3e-4)
+    w = torch.randn_like(out_ref)
+    (out_hip * w.to(DEV)).sum().backward()
+    _grads_close(ref, hip, (b.x, b.edge_index, b.edge_attr), w)
+
+
 def test_class_surface_errors():
     hchem, hbio = _hip()
     with pytest.raises(ValueError):
