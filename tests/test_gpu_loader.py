@@ -291,3 +291,24 @@ def test_substruct_context_random_roots_and_training_step():
     os_, oc = torch.optim.Adam(ms.parameters(), lr=1e-3), torch.optim.Adam(mc.parameters(), lr=1e-3)
     loss, acc = train.chem_contextpred_step(ms, mc, os_, oc, a)
     assert loss == loss and 0.0 <= acc <= 1.0
+
+
+def test_bio_resident_loader_drives_the_masking_step():
+    """PPI-shaped dataset resident in HBM -> device MaskEdge batches -> bio masking train step"""
+    from pretrain_gnns_amd import train
+    from pretrain_gnns_amd.bio import model as hbio
+    rng = np.random.default_rng(21)
+    graphs = [synthetic.ppi_like_graph(rng) for _ in range(24)]
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    loader = resident.ResidentLoader(ds, batch_size=8, shuffle=True, seed=2, mask_rate=0.15)
+    torch.manual_seed(0)
+    mods = [hbio.GNN(3, 300).to(DEV), torch.nn.Linear(300, 7).to(DEV)]
+    opts = [torch.optim.Adam(m.parameters(), lr=1e-3) for m in mods]
+    losses = []
+    for batch in loader:
+        ds.check(batch)
+        assert batch.masked_edge_idx.numel() == batch.mask_edge_label.size(0) > 0
+        loss, acc = train.bio_masking_step(mods, opts, batch)
+        losses.append(loss)
+        assert loss == loss and 0.0 <= acc <= 1.0
+    assert len(losses) == 3

@@ -524,6 +524,21 @@ def test_other_embedding_widths(emb_dim, gnn_type):
         torch.testing.assert_close(hip(d.x, d.edge_index, d.edge_attr).cpu(), ref(b.x, b.edge_index, b.edge_attr), **TOL)
 
 
+@pytest.mark.parametrize("emb_dim", [64, 256])
+@pytest.mark.parametrize("gnn_type", ["gin", "gcn", "graphsage"])
+def test_bio_other_embedding_widths(emb_dim, gnn_type):
+    _, hbio = _hip()
+    ref, hip = _pair(obio.GNN, hbio.GNN, 3, emb_dim, seed=emb_dim, gnn_type=gnn_type)
+    b = synthetic.bio_masking_batch(6, seed=emb_dim)
+    d = b.clone().to(DEV)
+    out_ref = ref(b.x, b.edge_index, b.edge_attr)
+    out_hip = hip(d.x, d.edge_index, d.edge_attr)
+    torch.testing.assert_close(out_hip.detach().cpu(), out_ref.detach(), **TOL)
+    w = torch.randn_like(out_ref)
+    (out_hip * w.to(DEV)).sum().backward()
+    _grads_close(ref, hip, (b.x.double(), b.edge_index, b.edge_attr.double()), w)
+
+
 @pytest.mark.parametrize("num_layer", [2, 7])
 def test_other_depths(num_layer):
     hchem, _ = _hip()
