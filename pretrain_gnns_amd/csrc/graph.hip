@@ -321,9 +321,10 @@ size_t group_ws_bytes(int64_t n_keys, int64_t n_items) {
          align_up((size_t)ceil_div(n_keys + 1, kScanItems) * 4, 256);
 }
 
-__global__ void k_dinv(const int32_t* __restrict__ in_ptr, float* __restrict__ dinv, int64_t n) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < n) dinv[i] = 1.0f / sqrtf((float)(in_ptr[i + 1] - in_ptr[i] + 1));
+// (in-degree + 1)^-1/2, straight from the CSR row pointer: the payload kernels evaluate it for the node and for
+// each neighbour instead of waiting for a separate pass over the nodes
+__device__ __forceinline__ float dinv_of(const int32_t* __restrict__ in_ptr, int64_t i) {
+  return 1.0f / sqrtf((float)(in_ptr[i + 1] - in_ptr[i] + 1));
 }
 
 __global__ void __launch_bounds__(256)
@@ -331,11 +332,12 @@ k_chem_payload(const int64_t* __restrict__ ei, const int64_t* __restrict__ ea, i
                int gcn, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ perm_in,
                int32_t* __restrict__ in_src, uint8_t* __restrict__ in_code,
                const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ perm_out,
-               int32_t* __restrict__ out_dst, const float* __restrict__ dinv,
+               int32_t* __restrict__ out_dst, float* __restrict__ dinv,
                float* __restrict__ cfeat, int32_t* status) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= N) return;
-  const float di = dinv[i];
+  const float di = dinv_of(in_ptr, i);
+  dinv[i] = di;
   float c[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) c[t] = 0.f;
@@ -351,7 +353,7 @@ k_chem_payload(const int64_t* __restrict__ ei, const int64_t* __restrict__ ea, i
     }
     in_src[p] = (int32_t)s;
     in_code[p] = (uint8_t)(a0 * 3 + a1);
-    const float w = gcn ? di * dinv[s] : 1.0f;
+    const float w = gcn ? di * dinv_of(in_ptr, s) : 1.0f;
 #pragma unroll
     for (int t = 0; t < 6; ++t) c[t] += (a0 == t) ? w : 0.f;
 #pragma unroll
@@ -374,10 +376,11 @@ k_bio_payload(const int64_t* __restrict__ ei, const float* __restrict__ ea, int6
               int gcn, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ perm_in,
               int32_t* __restrict__ in_src, const int32_t* __restrict__ out_ptr,
               const int32_t* __restrict__ perm_out, int32_t* __restrict__ out_dst,
-              const float* __restrict__ dinv, float* __restrict__ cfeat) {
+              float* __restrict__ dinv, float* __restrict__ cfeat) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= N) return;
-  const float di = dinv[i];
+  const float di = dinv_of(in_ptr, i);
+  dinv[i] = di;
   float c[10];
 #pragma unroll
   for (int t = 0; t < 10; ++t) c[t] = 0.f;
@@ -386,7 +389,7 @@ k_bio_payload(const int64_t* __restrict__ ei, const float* __restrict__ ea, int6
     int64_t s = ei[E + e];
     if (s < 0 || s >= N) s = 0;
     in_src[p] = (int32_t)s;
-    const float w = gcn ? di * dinv[s] : 1.0f;
+    const float w = gcn ? di * dinv_of(in_ptr, s) : 1.0f;
     const float* a = ea + (int64_t)e * 9;
 #pragma unroll
     for (int t = 0; t < 9; ++t) c[t] += w * a[t];
@@ -460,7 +463,6 @@ int pgnn_chem_graph_build(const int64_t* ei, const int64_t* ea, int64_t E, int64
   rc = run_group(g.jobs, 2, E, N, status, st);
   if (rc) return rc;
   const int nbk = (int)ceil_div(N, 256);
-  hipLaunchKernelGGL(k_dinv, dim3(nbk), dim3(256), 0, st, in_ptr, dinv, N);
   hipLaunchKernelGGL(k_chem_payload, dim3(nbk), dim3(256), 0, st, ei, ea, E, N, gcn, in_ptr,
                      g.perm_in, in_src, in_code, out_ptr, g.perm_out, out_dst, dinv, cfeat, status);
   return check_launch("chem_graph_build");
@@ -479,7 +481,6 @@ int pgnn_bio_graph_build(const int64_t* ei, const float* ea, int64_t E, int64_t 
   rc = run_group(g.jobs, 2, E, N, status, st);
   if (rc) return rc;
   const int nbk = (int)ceil_div(N, 256);
-  hipLaunchKernelGGL(k_dinv, dim3(nbk), dim3(256), 0, st, in_ptr, dinv, N);
   hipLaunchKernelGGL(k_bio_payload, dim3(nbk), dim3(256), 0, st, ei, ea, E, N, gcn, in_ptr,
                      g.perm_in, in_src, out_ptr, g.perm_out, out_dst, dinv, cfeat);
   return check_launch("bio_graph_build");
