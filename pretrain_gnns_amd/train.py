@@ -77,7 +77,8 @@ class GraphedChemMaskingStep:
     captured like torch's own kernels).  Valid only while the batch keeps its shape -- node / edge /
     masked-atom counts are baked into the captured launches -- so it serves fixed-shape replay
     (benchmarks, bucketed/padded loaders); variable-shape training uses ``chem_masking_step``.
-    Optimizers must be built with ``capturable=True``."""
+    Optimizers must be built with ``capturable=True``.  Host-side scalars are frozen at capture time, which
+    includes the fused-dropout seeds: use it with ``drop_ratio == 0`` only."""
 
     def __init__(self, model_list, optimizer_list, batch, mask_edge=False, warmup=3):
         self.model_list, self.optimizer_list, self.batch, self.mask_edge = model_list, optimizer_list, batch, mask_edge
