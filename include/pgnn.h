@@ -39,6 +39,9 @@ typedef void* pgnn_stream; /* hipStream_t */
 
 int pgnn_abi_version(void);
 const char* pgnn_last_error(void); /* host string, thread-local */
+/* The PGNN_* environment knobs (A/B switches) are read once per call site and cached;
+ * call this after changing one inside a running process. */
+void pgnn_reload_env(void);
 
 /* ------------------------------------------------------------------------------------------
  * Graph structure.  Replaces the per-layer add_self_loops + torch.cat of chem/model.py:39-45,

@@ -25,6 +25,7 @@ _u64 = ctypes.c_uint64
 PROTOTYPES = {
     "pgnn_abi_version": (_i, []),
     "pgnn_last_error": (ctypes.c_char_p, []),
+    "pgnn_reload_env": (None, []),
     "pgnn_graph_workspace_bytes": (_sz, [_i64, _i64]),
     "pgnn_chem_graph_build": (_i, [_p, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "pgnn_bio_graph_build": (_i, [_p, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),

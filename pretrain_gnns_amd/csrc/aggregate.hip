@@ -193,10 +193,7 @@ inline int pick_grid(int64_t n, int blocks_per_cu, int* nodes_per_chunk) {
 // ---------------------------------------------------------------------------------------------
 constexpr int kGrpBlock = 320;
 
-inline int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
+inline int env_int(const char* name, int dflt) { return env_knob(name, dflt); }
 
 template <bool TABLE, bool WEIGHT>
 __global__ void __launch_bounds__(kGrpBlock)

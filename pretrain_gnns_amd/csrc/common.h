@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/pgnn.h"
 
@@ -40,9 +41,55 @@ inline int check_launch(const char* what) {
     }                                                                     \
   } while (0)
 
-// dynamic LDS above the 64 KiB default needs an explicit opt-in (gfx950 has 160 KiB per CU)
+// dynamic LDS above the 64 KiB default needs an explicit opt-in (gfx950 has 160 KiB per CU).  The attribute
+// is sticky per function and device, so it is raised once to the largest size seen, not on every launch
+// (hipFuncSetAttribute takes the runtime's locks: microseconds that a launch-bound step does not have).
 inline void allow_big_lds(const void* func, size_t bytes) {
-  if (bytes > 64 * 1024) (void)hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (bytes <= 64 * 1024) return;
+  struct Seen { const void* f; int dev; size_t bytes; };
+  static thread_local Seen seen[64];
+  static thread_local int nseen = 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  for (int i = 0; i < nseen; ++i)
+    if (seen[i].f == func && seen[i].dev == dev) {
+      if (seen[i].bytes >= bytes) return;
+      seen[i].bytes = bytes;
+      (void)hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      return;
+    }
+  (void)hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (nseen < 64) seen[nseen++] = Seen{func, dev, bytes};
+}
+
+// A/B knobs come from the environment.  getenv walks the whole environment block (~0.3 us) and the hot path
+// consults ~140 knobs per train step, so values are cached per call site (keyed by the literal's address) and
+// only re-read after pgnn_reload_env() -- which is what a test that flips a knob mid-process calls.
+extern unsigned g_env_generation;
+inline int env_knob(const char* name, int dflt) {
+  struct Slot { const char* name; unsigned gen; bool set; int value; };
+  static thread_local Slot slots[32];
+  static thread_local int nslots = 0;
+  const unsigned gen = g_env_generation;
+  Slot* s = nullptr;
+  for (int i = 0; i < nslots && !s; ++i)
+    if (slots[i].name == name) s = &slots[i];
+  if (!s) {
+    if (nslots == 32) {  // more call sites than slots: uncached
+      const char* v = getenv(name);
+      return v ? atoi(v) : dflt;
+    }
+    s = &slots[nslots++];
+    s->name = name;
+    s->gen = gen - 1;
+  }
+  if (s->gen != gen) {
+    const char* v = getenv(name);
+    s->set = v != nullptr;
+    s->value = v ? atoi(v) : 0;
+    s->gen = gen;
+  }
+  return s->set ? s->value : dflt;  // the default belongs to the call site, not to the cache
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -20,6 +20,8 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+unsigned g_env_generation = 1;
+
 namespace {
 
 constexpr int kScanItems = 1024;  // per block: 256 threads x 4
@@ -443,6 +445,7 @@ using namespace pgnn;
 extern "C" {
 
 int pgnn_abi_version(void) { return PGNN_ABI_VERSION; }
+void pgnn_reload_env(void) { ++pgnn::g_env_generation; }
 const char* pgnn_last_error(void) { return pgnn::g_err; }
 
 size_t pgnn_graph_workspace_bytes(int64_t N, int64_t E) {

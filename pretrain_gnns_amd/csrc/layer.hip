@@ -40,14 +40,8 @@ Side* side_for_current_device() {
   }
   return &s;
 }
-inline bool use_side_stream() {
-  const char* v = getenv("PGNN_SIDE_STREAM");
-  return !v || atoi(v) != 0;
-}
-inline bool per_layer_buffers() {
-  const char* v = getenv("PGNN_STACK_PER_LAYER_BUFFERS");
-  return v && atoi(v) != 0;
-}
+inline bool use_side_stream() { return env_knob("PGNN_SIDE_STREAM", 1) != 0; }
+inline bool per_layer_buffers() { return env_knob("PGNN_STACK_PER_LAYER_BUFFERS", 0) != 0; }
 inline size_t op_ws_bytes(int64_t n, int64_t d) {
   size_t m = pgnn_bn_workspace_bytes(n, d);
   m = std::max(m, pgnn_bn_workspace_bytes(n, 2 * d));
@@ -185,8 +179,7 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
   // Between two layers the BatchNorm(+ReLU) output is not written: the next layer's aggregation applies
   // relu(a*z + b) on read (pgnn_chem_aggregate_bn_fwd).  Needs the statistics only; dropout, wide
   // features and PGNN_FUSE_BN_AGG=0 take the materialising route.
-  const char* fv = getenv("PGNN_FUSE_BN_AGG");
-  const bool fuse = drop_p == 0.f && dim <= 320 && !(fv && atoi(fv) == 0);
+  const bool fuse = drop_p == 0.f && dim <= 320 && env_knob("PGNN_FUSE_BN_AGG", 1) != 0;
   for (int l = 0; l < num_layer; ++l) {
     const pgnn_gin_layer& p = layers[l];
     float* a = acts + (size_t)l * 3 * nd;  // agg, z, y

@@ -298,10 +298,7 @@ int launch_gemm_s(const GemmArgs& p, int nsplit, hipStream_t st) {
 }
 
 constexpr int kDefaultKS = 1;
-inline int env_ks(int dflt) {
-  const char* v = getenv("PGNN_GEMM_KS");
-  return v ? atoi(v) : dflt;
-}
+inline int env_ks(int dflt) { return env_knob("PGNN_GEMM_KS", dflt); }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES = false>
 int launch_gemm(const GemmArgs& p, int nsplit, hipStream_t st) {
@@ -324,14 +321,8 @@ struct CfgInfo { int bm, bn, wave_blocks; };
 static const CfgInfo kCfg[kNumCfg] = {{128, 304, 38}, {64, 160, 10}, {128, 160, 20}, {128, 128, 16}, {64, 64, 4},
                                       {64, 160, 5}, {320, 160, 25}, {256, 304, 38}};
 
-inline int env_int_linear(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-inline int env_cfg() {
-  const char* v = getenv("PGNN_GEMM_CFG");
-  return v ? atoi(v) : -1;
-}
+inline int env_int_linear(const char* name, int dflt) { return env_knob(name, dflt); }
+inline int env_cfg() { return env_knob("PGNN_GEMM_CFG", -1); }
 
 // At M = 6747 every tiling tried (64x160 with 4 or 8 waves, 64x64, 32x160, 32x320, 128x128; 2 or 3
 // stages; 16- or 32-deep k-steps) lands at 36-42 us per product, as does rocBLAS: 2.43 GFLOP is ~24 us at

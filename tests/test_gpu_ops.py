@@ -134,7 +134,10 @@ def test_aggregate_variants_agree_bitwise(monkeypatch):
     outs = []
     for v in ("0", "1", "3"):
         monkeypatch.setenv("PGNN_AGG_VARIANT", v)
+        ops.load().pgnn_reload_env()  # knobs are cached per call site
         outs.append(ops.ChemAggregate.apply(x, e1, e2, g).clone())
+    monkeypatch.delenv("PGNN_AGG_VARIANT")
+    ops.load().pgnn_reload_env()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 

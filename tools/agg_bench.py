@@ -40,4 +40,4 @@ for blocks in (1024, 2048, 4096, 8192, 16384):
 ref = torch.zeros_like(x)
 if os.environ.get("CHECK"):
     agg(); a = out.clone()
-    os.environ["PGNN_AGG_VARIANT"] = "0"; agg(); print("   variants bit-equal:", torch.equal(a, out))
+    os.environ["PGNN_AGG_VARIANT"] = "0"; lib.pgnn_reload_env(); agg(); print("   variants bit-equal:", torch.equal(a, out))
