@@ -173,12 +173,12 @@ class GNN(torch.nn.Module):
         drop_p = float(self.drop_ratio) if (self.training and self.drop_ratio > 0) else 0.0
         if fused and self.JK == "last" and _STACK_CALL and drop_p < 1.0:
             # the pre-training / fine-tuning configuration: the whole network is one library call per direction
-            return ops.chem_gin_stack(x, graph, self.x_embedding1, self.x_embedding2, self.gnns, self.batch_norms,
+            return ops.chem_gin_stack(self, x, graph, self.x_embedding1, self.x_embedding2, self.gnns, self.batch_norms,
                                       drop_p)
         lin_kind = {GCNConv: 1, GraphSAGEConv: 2}.get(type(self.gnns[0]), 0)
         if (lin_kind and self.JK == "last" and _STACK_CALL and drop_p < 1.0 and self.batch_norms[0].affine
                 and self.gnns[0].linear.bias is not None):
-            return ops.chem_lin_stack(lin_kind, x, graph, self.x_embedding1, self.x_embedding2, self.gnns,
+            return ops.chem_lin_stack(self, lin_kind, x, graph, self.x_embedding1, self.x_embedding2, self.gnns,
                                       self.batch_norms, drop_p)
         h = ops.Embed.apply(x, self.x_embedding1.weight, self.x_embedding2.weight)
 

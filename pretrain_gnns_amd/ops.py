@@ -5,6 +5,7 @@ Every function here launches hand-written gfx950 kernels through the C ABI on
 nothing else.  Inputs must live on the GPU: there is deliberately no CPU / eager fallback.
 """
 import os
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -626,6 +627,39 @@ def chem_gin_layer(x, conv, bn, graph, relu, drop_p=0.0):
 
 
 # ------------------------------------------------------------------------------------ whole chem GIN network
+class StackPlan:
+    """Per-model cache of the validated, filled ``pgnn_gin_layer`` array of a one-call network.  Parameter
+    storage is stable across steps (optimizers update in place), so the array is rebuilt only when a data
+    pointer, a BatchNorm buffer or a momentum changes -- otherwise a step pays one tuple comparison instead
+    of ~100 checks and ctypes field writes.  Keyed on data pointers, hence exact."""
+
+    def __init__(self):
+        self.key = None
+        self.array = None
+
+    def layers(self, per_layer, tensors, bns, fields):
+        key = tuple(t.data_ptr() for t in tensors) + tuple(
+            (rm.data_ptr() if rm is not None else 0, rv.data_ptr() if rv is not None else 0, mom, eps)
+            for rm, rv, mom, eps in bns)
+        if key != self.key:
+            require_cuda(*tensors)
+            for t in tensors:
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    raise _lib.PgnnError("model parameters must be contiguous float32 tensors")
+            L = (len(tensors) - 2) // per_layer
+            arr = (_lib.GinLayer * L)()
+            for l in range(L):
+                s_, p = arr[l], tensors[2 + l * per_layer:2 + (l + 1) * per_layer]
+                for name, t in zip(fields, p):
+                    setattr(s_, name, t.data_ptr())
+                rm, rv, momentum, eps = bns[l]
+                s_.running_mean = rm.data_ptr() if rm is not None else None
+                s_.running_var = rv.data_ptr() if rv is not None else None
+                s_.momentum, s_.eps = momentum, eps
+            self.array, self.key = arr, key
+        return self.array
+
+
 class ChemGINStack(Function):
     """Atom embedding + every (GINConv, BatchNorm, ReLU) layer of chem/model.py:258-277 as ONE library
     call per direction (pgnn_chem_gin_stack_fwd / _bwd).  Bit-identical to the per-layer path; valid
@@ -637,31 +671,22 @@ class ChemGINStack(Function):
 
     @staticmethod
     def forward(ctx, x_idx, graph, meta, xemb1, xemb2, *params):
-        require_cuda(x_idx, xemb1, xemb2, *params)
-        if x_idx.dtype != torch.int64 or x_idx.dim() != 2 or x_idx.size(1) != 2:
-            raise _lib.PgnnError("chem node features must be int64 [N, 2]")
+        if not x_idx.is_cuda or x_idx.dtype != torch.int64 or x_idx.dim() != 2 or x_idx.size(1) != 2:
+            raise _lib.PgnnError("chem node features must be a CUDA int64 [N, 2] tensor")
         x_idx = x_idx.contiguous()
-        training, bns, drop_p, drop_seed = meta
+        training, bns, drop_p, drop_seed, plan = meta
         L = len(params) // ChemGINStack.PER_LAYER
         n, dim = x_idx.size(0), xemb1.size(1)
         if training and n <= 1:
             raise ValueError("Expected more than 1 value per channel when training, got input size %s" % ((n, dim),))
         dev = x_idx.device
-        xemb1, xemb2 = _f32c(xemb1), _f32c(xemb2)
-        params = [_f32c(t) for t in params]
+        layers = plan.layers(8, (xemb1, xemb2) + params, bns,
+                             ("emb1", "emb2", "w1", "b1", "w2", "b2", "gamma", "beta"))
         h0 = torch.empty(n, dim, dtype=torch.float32, device=dev)
         acts = torch.empty(L, 3, n, dim, dtype=torch.float32, device=dev)
         hid = torch.empty(L, n, 2 * dim, dtype=torch.float32, device=dev)
         stats = torch.empty(L, 4, dim, dtype=torch.float32, device=dev)  # mean, 1/std, scale, shift
         status = torch.zeros(1, dtype=torch.int32, device=dev)
-        layers = (_lib.GinLayer * L)()
-        for l in range(L):
-            s, p = layers[l], params[l * 8:l * 8 + 8]
-            (s.emb1, s.emb2, s.w1, s.b1, s.w2, s.b2, s.gamma, s.beta) = [t.data_ptr() for t in p]
-            rm, rv, momentum, eps = bns[l]
-            s.running_mean = rm.data_ptr() if rm is not None else None
-            s.running_var = rv.data_ptr() if rv is not None else None
-            s.momentum, s.eps = momentum, eps
         ws = _workspace(_ws_bytes("pgnn_chem_gin_layer_workspace_bytes", n, dim), dev)
         check(load().pgnn_chem_gin_stack_fwd(
             x_idx.data_ptr(), xemb1.data_ptr(), xemb1.size(0), xemb2.data_ptr(), xemb2.size(0), graph.in_ptr.data_ptr(),
@@ -732,13 +757,14 @@ def _stack_grad_layout(L, dim, rows1, rows2):
     return lay
 
 
-def chem_gin_stack(x_idx, graph, x_embedding1, x_embedding2, convs, bns, drop_p=0.0):
-    """run the atom embedding and all (conv, bn) layers through the stack call; ReLU after every layer
-    but the last and (``drop_p`` > 0) dropout after every layer, as GNN.forward of the reference does."""
-    training = bns[0].training or bns[0].running_mean is None
-    meta, flat = [], []
-    counters = []
-    for conv, bn in zip(convs, bns):
+_plans = weakref.WeakKeyDictionary()  # GNN module -> StackPlan (kept off the module: ctypes arrays do not deepcopy)
+
+
+def _bn_meta(bns):
+    """(running_mean, running_var, momentum, eps) per layer + the counters to bump, as nn.BatchNorm1d.forward
+    would handle them"""
+    meta, counters = [], []
+    for bn in bns:
         momentum = 0.0 if bn.momentum is None else bn.momentum
         if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
             counters.append(bn.num_batches_tracked)
@@ -746,11 +772,23 @@ def chem_gin_stack(x_idx, graph, x_embedding1, x_embedding2, convs, bns, drop_p=
                 momentum = 1.0 / float(bn.num_batches_tracked + 1)
         meta.append((bn.running_mean if bn.track_running_stats else None,
                      bn.running_var if bn.track_running_stats else None, float(momentum), float(bn.eps)))
-        flat += [conv.edge_embedding1.weight, conv.edge_embedding2.weight, conv.mlp[0].weight, conv.mlp[0].bias,
-                 conv.mlp[2].weight, conv.mlp[2].bias, bn.weight, bn.bias]
     if counters:
         torch._foreach_add_(counters, 1)  # num_batches_tracked of every layer in one launch
-    return ChemGINStack.apply(x_idx, graph, (training, meta, drop_p, dropout_seed() if drop_p > 0 else 0),
+    return meta
+
+
+def chem_gin_stack(owner, x_idx, graph, x_embedding1, x_embedding2, convs, bns, drop_p=0.0):
+    """run the atom embedding and all (conv, bn) layers through the stack call; ReLU after every layer
+    but the last and (``drop_p`` > 0) dropout after every layer, as GNN.forward of the reference does.
+    ``owner`` (the GNN module) keys the cached StackPlan."""
+    plan = _plans.get(owner)
+    if plan is None:
+        plan = _plans[owner] = StackPlan()
+    training = bns[0].training or bns[0].running_mean is None
+    flat = [t for conv, bn in zip(convs, bns) for t in (
+        conv.edge_embedding1.weight, conv.edge_embedding2.weight, conv.mlp[0].weight, conv.mlp[0].bias,
+        conv.mlp[2].weight, conv.mlp[2].bias, bn.weight, bn.bias)]
+    return ChemGINStack.apply(x_idx, graph, (training, _bn_meta(bns), drop_p, dropout_seed() if drop_p > 0 else 0, plan),
                               x_embedding1.weight, x_embedding2.weight, *flat)
 
 
@@ -787,11 +825,10 @@ class ChemLinStack(Function):
 
     @staticmethod
     def forward(ctx, x_idx, graph, meta, xemb1, xemb2, *params):
-        require_cuda(x_idx, xemb1, xemb2, *params)
-        if x_idx.dtype != torch.int64 or x_idx.dim() != 2 or x_idx.size(1) != 2:
-            raise _lib.PgnnError("chem node features must be int64 [N, 2]")
+        if not x_idx.is_cuda or x_idx.dtype != torch.int64 or x_idx.dim() != 2 or x_idx.size(1) != 2:
+            raise _lib.PgnnError("chem node features must be a CUDA int64 [N, 2] tensor")
         x_idx = x_idx.contiguous()
-        kind, training, bns, drop_p, drop_seed = meta
+        kind, training, bns, drop_p, drop_seed, plan = meta
         L = len(params) // ChemLinStack.PER_LAYER
         n, dim = x_idx.size(0), xemb1.size(1)
         if training and n <= 1:
@@ -799,21 +836,12 @@ class ChemLinStack(Function):
         if (kind == 1) != bool(graph.gcn):
             raise _lib.PgnnError("graph structure was built for the other convolution type")
         dev = x_idx.device
-        xemb1, xemb2 = _f32c(xemb1), _f32c(xemb2)
-        params = [_f32c(t) for t in params]
+        layers = plan.layers(6, (xemb1, xemb2) + params, bns, ("emb1", "emb2", "w1", "b1", "gamma", "beta"))
         h0 = torch.empty(n, dim, dtype=torch.float32, device=dev)
         acts = torch.empty(L, 4, n, dim, dtype=torch.float32, device=dev)  # lin, sum, z, y
         norms = torch.empty(L, n, dtype=torch.float32, device=dev) if kind == 2 else None
         stats = torch.empty(L, 4, dim, dtype=torch.float32, device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
-        layers = (_lib.GinLayer * L)()
-        for l in range(L):
-            s, p = layers[l], params[l * 6:l * 6 + 6]
-            (s.emb1, s.emb2, s.w1, s.b1, s.gamma, s.beta) = [t.data_ptr() for t in p]
-            rm, rv, momentum, eps = bns[l]
-            s.running_mean = rm.data_ptr() if rm is not None else None
-            s.running_var = rv.data_ptr() if rv is not None else None
-            s.momentum, s.eps = momentum, eps
         ws = _workspace(_ws_bytes("pgnn_chem_gin_layer_workspace_bytes", n, dim), dev)
         check(load().pgnn_chem_lin_stack_fwd(
             kind, x_idx.data_ptr(), xemb1.data_ptr(), xemb1.size(0), xemb2.data_ptr(), xemb2.size(0),
@@ -823,7 +851,7 @@ class ChemLinStack(Function):
             int(drop_seed), n, dim, ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_chem_lin_stack_fwd")
         if _CHECK_INDICES and int(status.item()):
             raise IndexError("embedding index out of range")
-        saved = [h0, acts, stats] + ([norms] if norms is not None else []) + params
+        saved = [h0, acts, stats] + ([norms] if norms is not None else []) + list(params)
         ctx.save_for_backward(*saved)
         ctx.kind, ctx.x_idx, ctx.graph, ctx.training, ctx.layers = kind, x_idx, graph, bool(training), layers
         ctx.rows, ctx.drop = (xemb1.size(0), xemb2.size(0)), (float(drop_p), int(drop_seed))
@@ -859,21 +887,13 @@ class ChemLinStack(Function):
         return (None, None, None) + tuple(t if shp is None else t.view(shp) for t, shp in zip(pieces, shapes))
 
 
-def chem_lin_stack(kind, x_idx, graph, x_embedding1, x_embedding2, convs, bns, drop_p=0.0):
+def chem_lin_stack(owner, kind, x_idx, graph, x_embedding1, x_embedding2, convs, bns, drop_p=0.0):
     """GCN (kind 1) / GraphSAGE (kind 2) network through the one-call path; see ``chem_gin_stack``."""
+    plan = _plans.get(owner)
+    if plan is None:
+        plan = _plans[owner] = StackPlan()
     training = bns[0].training or bns[0].running_mean is None
-    meta, flat, counters = [], [], []
-    for conv, bn in zip(convs, bns):
-        momentum = 0.0 if bn.momentum is None else bn.momentum
-        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-            counters.append(bn.num_batches_tracked)
-            if bn.momentum is None:
-                momentum = 1.0 / float(bn.num_batches_tracked + 1)
-        meta.append((bn.running_mean if bn.track_running_stats else None,
-                     bn.running_var if bn.track_running_stats else None, float(momentum), float(bn.eps)))
-        flat += [conv.edge_embedding1.weight, conv.edge_embedding2.weight, conv.linear.weight, conv.linear.bias,
-                 bn.weight, bn.bias]
-    if counters:
-        torch._foreach_add_(counters, 1)
-    return ChemLinStack.apply(x_idx, graph, (kind, training, meta, drop_p, dropout_seed() if drop_p > 0 else 0),
+    flat = [t for conv, bn in zip(convs, bns) for t in (
+        conv.edge_embedding1.weight, conv.edge_embedding2.weight, conv.linear.weight, conv.linear.bias, bn.weight, bn.bias)]
+    return ChemLinStack.apply(x_idx, graph, (kind, training, _bn_meta(bns), drop_p, dropout_seed() if drop_p > 0 else 0, plan),
                               x_embedding1.weight, x_embedding2.weight, *flat)
