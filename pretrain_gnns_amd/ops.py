@@ -627,6 +627,33 @@ def chem_gin_layer(x, conv, bn, graph, relu, drop_p=0.0):
 
 
 # ------------------------------------------------------------------------------------ whole chem GIN network
+# Direct gradient deposit.  A custom Function with 47 tensor inputs costs ~150 us per step in torch's own
+# bookkeeping (input wrapping in apply(), 47 AccumulateGrad nodes; tools/autograd_floor.py: 306 vs 150 us), more
+# than the library spends launching the whole forward.  The one-call networks therefore take only the two atom
+# embedding tables through autograd (that keeps the output attached to the graph) and write the other parameters'
+# gradients into ``.grad`` themselves: assign when it is None, add otherwise -- what AccumulateGrad does.  What this
+# gives up: tensor hooks on those parameters and ``torch.autograd.grad(..., those parameters)`` do not see the
+# gradients (torch DDP relies on such hooks; ``parallel.AllReduceOptimizers`` does not).  PGNN_DIRECT_GRADS=0
+# routes everything through autograd again.
+_DIRECT_GRADS = os.environ.get("PGNN_DIRECT_GRADS", "1") != "0"
+
+
+def _deposit_grads(params, versions, grads):
+    acc_dst, acc_src = [], []
+    for p, v, g in zip(params, versions, grads):
+        if p._version != v:
+            raise RuntimeError("a parameter of the network was modified in place between forward and backward")
+        if not p.requires_grad:
+            continue
+        if p.grad is None:
+            p.grad = g
+        else:
+            acc_dst.append(p.grad)
+            acc_src.append(g)
+    if acc_dst:
+        torch._foreach_add_(acc_dst, acc_src)
+
+
 class StackPlan:
     """Per-model cache of the validated, filled ``pgnn_gin_layer`` array of a one-call network.  Parameter
     storage is stable across steps (optimizers update in place), so the array is rebuilt only when a data
@@ -674,7 +701,9 @@ class ChemGINStack(Function):
         if not x_idx.is_cuda or x_idx.dtype != torch.int64 or x_idx.dim() != 2 or x_idx.size(1) != 2:
             raise _lib.PgnnError("chem node features must be a CUDA int64 [N, 2] tensor")
         x_idx = x_idx.contiguous()
-        training, bns, drop_p, drop_seed, plan = meta
+        training, bns, drop_p, drop_seed, plan, direct = meta
+        if direct is not None:  # parameters travel outside autograd (see _DIRECT_GRADS)
+            params = tuple(direct)
         L = len(params) // ChemGINStack.PER_LAYER
         n, dim = x_idx.size(0), xemb1.size(1)
         if training and n <= 1:
@@ -695,7 +724,12 @@ class ChemGINStack(Function):
             ws.numel(), stream_ptr()), "pgnn_chem_gin_stack_fwd")
         if _CHECK_INDICES and int(status.item()):
             raise IndexError("embedding index out of range")
-        ctx.save_for_backward(acts, hid, stats, *params)
+        if direct is not None:
+            ctx.save_for_backward(acts, hid, stats)
+            ctx.direct, ctx.versions = params, [p._version for p in params]
+        else:
+            ctx.save_for_backward(acts, hid, stats, *params)
+            ctx.direct = None
         ctx.x_idx, ctx.graph, ctx.training, ctx.layers, ctx.rows = x_idx, graph, bool(training), layers, (xemb1.size(0), xemb2.size(0))
         ctx.drop = (float(drop_p), int(drop_seed))
         return acts[L - 1, 2]
@@ -725,7 +759,11 @@ class ChemGINStack(Function):
             dx1 if ctx.needs_input_grad[3] else None, dx2 if ctx.needs_input_grad[4] else None, ctx.drop[0], ctx.drop[1],
             n, dim, ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_chem_gin_stack_bwd")
         pieces = flat.split_with_sizes(sizes)
-        return (None, None, None) + tuple(t if shp is None else t.view(shp) for t, shp in zip(pieces, shapes))
+        grads = tuple(t if shp is None else t.view(shp) for t, shp in zip(pieces, shapes))
+        if ctx.direct is not None:
+            _deposit_grads(ctx.direct, ctx.versions, grads[2:])
+            return (None, None, None) + grads[:2]
+        return (None, None, None) + grads
 
 
 _stack_layouts = {}
@@ -788,7 +826,11 @@ def chem_gin_stack(owner, x_idx, graph, x_embedding1, x_embedding2, convs, bns, 
     flat = [t for conv, bn in zip(convs, bns) for t in (
         conv.edge_embedding1.weight, conv.edge_embedding2.weight, conv.mlp[0].weight, conv.mlp[0].bias,
         conv.mlp[2].weight, conv.mlp[2].bias, bn.weight, bn.bias)]
-    return ChemGINStack.apply(x_idx, graph, (training, _bn_meta(bns), drop_p, dropout_seed() if drop_p > 0 else 0, plan),
+    seed = dropout_seed() if drop_p > 0 else 0
+    if _DIRECT_GRADS and torch.is_grad_enabled() and x_embedding1.weight.requires_grad:
+        return ChemGINStack.apply(x_idx, graph, (training, _bn_meta(bns), drop_p, seed, plan, flat),
+                                  x_embedding1.weight, x_embedding2.weight)
+    return ChemGINStack.apply(x_idx, graph, (training, _bn_meta(bns), drop_p, seed, plan, None),
                               x_embedding1.weight, x_embedding2.weight, *flat)
 
 
@@ -828,7 +870,9 @@ class ChemLinStack(Function):
         if not x_idx.is_cuda or x_idx.dtype != torch.int64 or x_idx.dim() != 2 or x_idx.size(1) != 2:
             raise _lib.PgnnError("chem node features must be a CUDA int64 [N, 2] tensor")
         x_idx = x_idx.contiguous()
-        kind, training, bns, drop_p, drop_seed, plan = meta
+        kind, training, bns, drop_p, drop_seed, plan, direct = meta
+        if direct is not None:
+            params = tuple(direct)
         L = len(params) // ChemLinStack.PER_LAYER
         n, dim = x_idx.size(0), xemb1.size(1)
         if training and n <= 1:
@@ -851,7 +895,12 @@ class ChemLinStack(Function):
             int(drop_seed), n, dim, ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_chem_lin_stack_fwd")
         if _CHECK_INDICES and int(status.item()):
             raise IndexError("embedding index out of range")
-        saved = [h0, acts, stats] + ([norms] if norms is not None else []) + list(params)
+        saved = [h0, acts, stats] + ([norms] if norms is not None else [])
+        if direct is not None:
+            ctx.direct, ctx.versions = params, [p._version for p in params]
+        else:
+            saved += list(params)
+            ctx.direct = None
         ctx.save_for_backward(*saved)
         ctx.kind, ctx.x_idx, ctx.graph, ctx.training, ctx.layers = kind, x_idx, graph, bool(training), layers
         ctx.rows, ctx.drop = (xemb1.size(0), xemb2.size(0)), (float(drop_p), int(drop_seed))
@@ -884,7 +933,11 @@ class ChemLinStack(Function):
             stats.data_ptr(), dx1 if ctx.needs_input_grad[3] else None, dx2 if ctx.needs_input_grad[4] else None,
             ctx.drop[0], ctx.drop[1], n, dim, ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_chem_lin_stack_bwd")
         pieces = flat.split_with_sizes(sizes)
-        return (None, None, None) + tuple(t if shp is None else t.view(shp) for t, shp in zip(pieces, shapes))
+        grads = tuple(t if shp is None else t.view(shp) for t, shp in zip(pieces, shapes))
+        if ctx.direct is not None:
+            _deposit_grads(ctx.direct, ctx.versions, grads[2:])
+            return (None, None, None) + grads[:2]
+        return (None, None, None) + grads
 
 
 def chem_lin_stack(owner, kind, x_idx, graph, x_embedding1, x_embedding2, convs, bns, drop_p=0.0):
@@ -895,5 +948,9 @@ def chem_lin_stack(owner, kind, x_idx, graph, x_embedding1, x_embedding2, convs,
     training = bns[0].training or bns[0].running_mean is None
     flat = [t for conv, bn in zip(convs, bns) for t in (
         conv.edge_embedding1.weight, conv.edge_embedding2.weight, conv.linear.weight, conv.linear.bias, bn.weight, bn.bias)]
-    return ChemLinStack.apply(x_idx, graph, (kind, training, _bn_meta(bns), drop_p, dropout_seed() if drop_p > 0 else 0, plan),
+    seed = dropout_seed() if drop_p > 0 else 0
+    if _DIRECT_GRADS and torch.is_grad_enabled() and x_embedding1.weight.requires_grad:
+        return ChemLinStack.apply(x_idx, graph, (kind, training, _bn_meta(bns), drop_p, seed, plan, flat),
+                                  x_embedding1.weight, x_embedding2.weight)
+    return ChemLinStack.apply(x_idx, graph, (kind, training, _bn_meta(bns), drop_p, seed, plan, None),
                               x_embedding1.weight, x_embedding2.weight, *flat)

@@ -442,6 +442,46 @@ def test_one_call_gcn_and_graphsage_equal_per_layer_path(gnn_type, graphs, layer
         assert torch.equal(res[0][2][k], res[1][2][k]), k
 
 
+@pytest.mark.parametrize("gnn_type", ["gin", "gcn"])
+def test_direct_gradient_deposit_equals_autograd_accumulation(gnn_type, monkeypatch):
+    """the one-call networks write parameter gradients into .grad themselves (ops._DIRECT_GRADS): same bits as
+    routing them through autograd, AccumulateGrad's assign-or-add semantics, frozen parameters untouched, and
+    an in-place update between forward and backward is refused"""
+    import copy
+    from pretrain_gnns_amd import ops
+    hchem, _ = _hip()
+    _, a = _pair(ochem.GNN, hchem.GNN, 3, 300, seed=8, gnn_type=gnn_type)
+    b = copy.deepcopy(a)
+    d = synthetic.chem_masking_batch(24, seed=9).to(DEV)
+    w = torch.randn(d.x.size(0), 300, device=DEV)
+    outs = {}
+    for m, direct in ((a, True), (b, False)):
+        monkeypatch.setattr(ops, "_DIRECT_GRADS", direct)
+        out = m(d.x, d.edge_index, d.edge_attr)
+        (out * w).sum().backward()
+        outs[direct] = (out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()})
+    assert torch.equal(outs[True][0], outs[False][0])
+    for k in outs[True][1]:
+        assert torch.equal(outs[True][1][k], outs[False][1][k]), k
+    monkeypatch.setattr(ops, "_DIRECT_GRADS", True)
+    (a(d.x, d.edge_index, d.edge_attr) * w).sum().backward()  # second backward without zeroing: accumulate
+    a.eval()  # (BatchNorm batch statistics do not depend on the running buffers: same gradients both times)
+    for k, p in a.named_parameters():
+        assert torch.equal(p.grad, 2 * outs[True][1][k]), k
+    a.train()
+    a.zero_grad()
+    frozen = next(p for n_, p in a.named_parameters() if n_.endswith("gnns.1.edge_embedding1.weight"))
+    frozen.requires_grad_(False)
+    (a(d.x, d.edge_index, d.edge_attr) * w).sum().backward()
+    assert frozen.grad is None and all(p.grad is not None for p in a.parameters() if p.requires_grad)
+    frozen.requires_grad_(True)
+    out = a(d.x, d.edge_index, d.edge_attr)
+    with torch.no_grad():
+        a.batch_norms[0].weight.mul_(1.5)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        (out * w).sum().backward()
+
+
 def test_large_batch_properties():
     """BASELINE full size (2048 graphs): size-independent checks instead of a slow oracle run --
     linearity of the aggregation in x and agreement of the aggregation with a torch index_add on GPU."""
