@@ -11,6 +11,6 @@ batch = (synthetic.tile_batch(base, g // 2048) if g > 2048 else base).to(dev)
 torch.manual_seed(0)
 mods = [hmodel.GNN(5, 300).to(dev), torch.nn.Linear(300, 119).to(dev), torch.nn.Linear(300, 4).to(dev)]
 opts = [torch.optim.Adam(m.parameters(), lr=1e-3, fused=True) for m in mods]
-for _ in range(6):
+for _ in range(26):
     steps.chem_masking_step(mods, opts, batch)
 torch.cuda.synchronize()
