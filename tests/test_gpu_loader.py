@@ -312,3 +312,27 @@ def test_bio_resident_loader_drives_the_masking_step():
         losses.append(loss)
         assert loss == loss and 0.0 <= acc <= 1.0
     assert len(losses) == 3
+
+
+def test_from_inmemory_dataset_layout():
+    """the (data, slices) pair an InMemoryDataset keeps (chem/loader.py: concatenated tensors + per-key slice
+    vectors) maps one to one onto the resident dataset"""
+    graphs = _chem_graphs(11, seed=31)
+
+    class DataLike:
+        pass
+
+    data = DataLike()
+    data.x = torch.cat([g.x for g in graphs], 0)
+    data.edge_index = torch.cat([g.edge_index for g in graphs], 1)  # graph-local node ids, as InMemoryDataset stores them
+    data.edge_attr = torch.cat([g.edge_attr for g in graphs], 0)
+    ns = torch.tensor(np.cumsum([0] + [g.x.size(0) for g in graphs]))
+    es = torch.tensor(np.cumsum([0] + [g.edge_index.size(1) for g in graphs]))
+    slices = {"x": ns, "edge_index": es, "edge_attr": es}
+    ds = resident.ResidentDataset.from_inmemory(data, slices, DEV)
+    ids = [10, 0, 4, 4]
+    out = ds.collate(ids)
+    ds.check(out)
+    _same(out, synthetic.collate([graphs[i] for i in ids]))
+    with pytest.raises(ValueError):
+        resident.ResidentDataset(data.x, data.edge_index, data.edge_attr, ns[:-1], es, DEV)
