@@ -86,6 +86,16 @@ int pgnn_group_by_key(const int64_t* key, int64_t key_stride, int64_t n_items, i
                       int32_t* ptr, int32_t* perm, int32_t* status, void* ws, size_t ws_bytes,
                       pgnn_stream stream);
 
+/* The same for a PAIR of key columns in one pass: items grouped by (key_a, key_b), segment index
+ * key_a*n_b + key_b, n_a*n_b <= 1024.  With pgnn_segment_sum and pgnn_pair_fold this yields the gradients of
+ * BOTH atom embedding tables (chem/model.py:264) from one grouping and one pass over the node gradients. */
+int pgnn_group_by_key_pair(const int64_t* key_a, const int64_t* key_b, int64_t key_stride, int64_t n_items,
+                           int64_t n_a, int64_t n_b, int32_t* ptr, int32_t* perm, int32_t* status,
+                           void* ws, size_t ws_bytes, pgnn_stream stream);
+/* sums [n_a*n_b, dim] (row a*n_b + b) -> out_a[a] = sum_b, out_b[b] = sum_a, ascending order; either may be NULL */
+int pgnn_pair_fold(const float* sums, int64_t n_a, int64_t n_b, float* out_a, int64_t lda, float* out_b,
+                   int64_t ldb, int64_t dim, pgnn_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * Aggregation (the scatter_add of propagate, chem/model.py:49-52,101-104; bio/model.py:52-55).
  * ------------------------------------------------------------------------------------------ */

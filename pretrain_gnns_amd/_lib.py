@@ -31,6 +31,8 @@ PROTOTYPES = {
     "pgnn_bio_graph_build": (_i, [_p, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "pgnn_group_workspace_bytes": (_sz, [_i64, _i64]),
     "pgnn_group_by_key": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
+    "pgnn_group_by_key_pair": (_i, [_p, _p, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
+    "pgnn_pair_fold": (_i, [_p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p]),
     "pgnn_chem_aggregate_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
     "pgnn_chem_aggregate_bn_fwd": (_i, [_p, _i64, _p, _i, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
     "pgnn_neighbor_sum": (_i, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _p]),

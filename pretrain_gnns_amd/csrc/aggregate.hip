@@ -915,7 +915,7 @@ k_segsum_final2(const int32_t* __restrict__ ptr, int n_seg, int mean, float* __r
 }
 
 inline bool segsum_two_level(int64_t n_items, int64_t n_segments) {
-  return n_segments <= 256 && ceil_div(std::max<int64_t>(n_items, 1), kSegChunk) > 64;
+  return n_segments <= 1024 && ceil_div(std::max<int64_t>(n_items, 1), kSegChunk) > 64;
 }
 
 template <int R>
@@ -985,6 +985,37 @@ int pgnn_chem_aggregate_bn_fwd(const float* z, int64_t ldz, const float* coef, i
   PGNN_REQUIRE(dim <= 320, "aggregate_bn: feature width above 320 is not supported (materialise BatchNorm's output instead)");
   return launch_aggregate_dma_pre(z, ldz, coef, relu, in_ptr, in_src, in_code, emb1, emb2, out, ldo, n, dim,
                                   (hipStream_t)stream);
+}
+
+// out_a[a] = sum_b S[a*n_b + b], out_b[b] = sum_a S[a*n_b + b]  (fixed ascending order), float4 columns
+__global__ void __launch_bounds__(256) k_pair_fold(const float* __restrict__ S, int n_a, int n_b, int d4,
+                                                   float* __restrict__ out_a, int64_t lda, float* __restrict__ out_b,
+                                                   int64_t ldb) {
+  const int total = (n_a + n_b) * d4;
+  const float4* __restrict__ S4 = reinterpret_cast<const float4*>(S);
+  for (int q = blockIdx.x * 256 + threadIdx.x; q < total; q += gridDim.x * 256) {
+    const int row = q / d4, c = q - row * d4;
+    float4 acc = f4_zero();
+    if (row < n_a) {
+      for (int b = 0; b < n_b; ++b) acc = f4_add(acc, S4[(size_t)(row * n_b + b) * d4 + c]);
+      if (out_a) reinterpret_cast<float4*>(out_a + (int64_t)row * lda)[c] = acc;
+    } else {
+      const int b = row - n_a;
+      for (int a = 0; a < n_a; ++a) acc = f4_add(acc, S4[(size_t)(a * n_b + b) * d4 + c]);
+      if (out_b) reinterpret_cast<float4*>(out_b + (int64_t)b * ldb)[c] = acc;
+    }
+  }
+}
+
+int pgnn_pair_fold(const float* sums, int64_t n_a, int64_t n_b, float* out_a, int64_t lda, float* out_b, int64_t ldb,
+                   int64_t dim, pgnn_stream stream) {
+  if (int rc = check_dim(dim)) return rc;
+  PGNN_REQUIRE(n_a > 0 && n_b > 0 && lda % 4 == 0 && ldb % 4 == 0, "bad pair_fold arguments");
+  const int d4 = (int)(dim / 4);
+  const int grid = (int)std::min<int64_t>(ceil_div((n_a + n_b) * d4, 256), 1024);
+  hipLaunchKernelGGL(k_pair_fold, dim3(grid), dim3(256), 0, (hipStream_t)stream, sums, (int)n_a, (int)n_b, d4, out_a, lda,
+                     out_b, ldb);
+  return check_launch("pair_fold");
 }
 
 // diagnostics: plain float4 grid-stride copy -- the streaming ceiling the aggregation is measured against

@@ -217,19 +217,34 @@ __global__ void __launch_bounds__(256) k_sort_segments(GroupJobs jobs, int64_t n
 constexpr int kPartTile = 256;
 constexpr int kPartMaxKeys = 1024;
 
+// key of item e: key[e*stride], or the pair (key[e*stride], key2[e*stride]) flattened as a*n2 + b when a second
+// column is given (n_keys = n1*n2); out-of-range components are clamped to 0 (and counted by the histogram pass)
+__device__ __forceinline__ int part_key(const int64_t* __restrict__ key, const int64_t* __restrict__ key2, int64_t stride,
+                                        int64_t e, int n_keys, int n2, bool* bad) {
+  int64_t a = key[e * stride];
+  if (!key2) {
+    if (a < 0 || a >= n_keys) { *bad = true; a = 0; }
+    return (int)a;
+  }
+  int64_t b = key2[e * stride];
+  const int n1 = n_keys / n2;
+  if (a < 0 || a >= n1) { *bad = true; a = 0; }
+  if (b < 0 || b >= n2) { *bad = true; b = 0; }
+  return (int)(a * n2 + b);
+}
+
 __global__ void __launch_bounds__(kPartTile)
-k_part_hist(const int64_t* __restrict__ key, int64_t stride, int64_t n_items, int n_keys, int n_tiles,
-            int32_t* __restrict__ offs /*[n_keys*n_tiles + 1], element 0 reserved*/, int32_t* status) {
+k_part_hist(const int64_t* __restrict__ key, const int64_t* __restrict__ key2, int n2, int64_t stride, int64_t n_items,
+            int n_keys, int n_tiles, int32_t* __restrict__ offs /*[n_keys*n_tiles + 1], element 0 reserved*/,
+            int32_t* status) {
   extern __shared__ int lh[];
   for (int k = threadIdx.x; k < n_keys; k += kPartTile) lh[k] = 0;
   __syncthreads();
   const int64_t e = (int64_t)blockIdx.x * kPartTile + threadIdx.x;
   if (e < n_items) {
-    int64_t k = key[e * stride];
-    if (k < 0 || k >= n_keys) {
-      atomicAdd(status, 1);
-      k = 0;
-    }
+    bool bad = false;
+    const int k = part_key(key, key2, stride, e, n_keys, n2, &bad);
+    if (bad) atomicAdd(status, 1);
     atomicAdd(&lh[k], 1);
   }
   __syncthreads();
@@ -237,8 +252,9 @@ k_part_hist(const int64_t* __restrict__ key, int64_t stride, int64_t n_items, in
 }
 
 __global__ void __launch_bounds__(kPartTile)
-k_part_scatter(const int64_t* __restrict__ key, int64_t stride, int64_t n_items, int n_keys, int n_tiles,
-               const int32_t* __restrict__ offs, int32_t* __restrict__ ptr, int32_t* __restrict__ perm) {
+k_part_scatter(const int64_t* __restrict__ key, const int64_t* __restrict__ key2, int n2, int64_t stride, int64_t n_items,
+               int n_keys, int n_tiles, const int32_t* __restrict__ offs, int32_t* __restrict__ ptr,
+               int32_t* __restrict__ perm) {
   extern __shared__ int wh[];  // [4][n_keys] per-wave key counts
   for (int q = threadIdx.x; q < 4 * n_keys; q += kPartTile) wh[q] = 0;
   __syncthreads();
@@ -247,8 +263,8 @@ k_part_scatter(const int64_t* __restrict__ key, int64_t stride, int64_t n_items,
   const bool valid = e < n_items;
   int k = 0;
   if (valid) {
-    int64_t kk = key[e * stride];
-    k = (kk < 0 || kk >= n_keys) ? 0 : (int)kk;
+    bool bad = false;
+    k = part_key(key, key2, stride, e, n_keys, n2, &bad);
   }
   int rank = 0;
   unsigned long long todo = __ballot(valid);
@@ -284,20 +300,20 @@ size_t partition_ws_bytes(int64_t n_keys, int64_t n_items) {
 }
 
 int run_partition(const int64_t* key, int64_t stride, int64_t n_items, int64_t n_keys, int32_t* ptr,
-                  int32_t* perm, int32_t* status, void* ws, hipStream_t st) {
+                  int32_t* perm, int32_t* status, void* ws, hipStream_t st, const int64_t* key2 = nullptr, int n2 = 1) {
   const int n_tiles = (int)ceil_div(std::max<int64_t>(n_items, 1), kPartTile);
   const int64_t len = n_keys * n_tiles + 1;
   Carver cv(ws);
   int32_t* offs = cv.take<int32_t>((size_t)len);
   int32_t* bsum = cv.take<int32_t>((size_t)ceil_div(len, kScanItems));
   PGNN_HIP(hipMemsetAsync(offs, 0, 4, st));  // element 0; the rest is fully written by k_part_hist
-  hipLaunchKernelGGL(k_part_hist, dim3(n_tiles), dim3(kPartTile), (size_t)n_keys * 4, st, key, stride, n_items,
+  hipLaunchKernelGGL(k_part_hist, dim3(n_tiles), dim3(kPartTile), (size_t)n_keys * 4, st, key, key2, n2, stride, n_items,
                      (int)n_keys, n_tiles, offs, status);
   GroupJobs jobs;
   jobs.j[0] = GroupJob{nullptr, 1, offs, nullptr, nullptr, nullptr, bsum};
   jobs.j[1] = jobs.j[0];
   launch_scan(jobs, 1, len, st);
-  hipLaunchKernelGGL(k_part_scatter, dim3(n_tiles), dim3(kPartTile), (size_t)4 * n_keys * 4, st, key, stride,
+  hipLaunchKernelGGL(k_part_scatter, dim3(n_tiles), dim3(kPartTile), (size_t)4 * n_keys * 4, st, key, key2, n2, stride,
                      n_items, (int)n_keys, n_tiles, offs, ptr, perm);
   return check_launch("group_by_key(partition)");
 }
@@ -513,6 +529,18 @@ int pgnn_group_by_key(const int64_t* key, int64_t key_stride, int64_t n_items, i
   jobs.j[0] = GroupJob{key, key_stride, ptr, perm, cursor, tmp, bsum};
   jobs.j[1] = jobs.j[0];
   return run_group(jobs, 1, n_items, n_keys, status, st);
+}
+
+int pgnn_group_by_key_pair(const int64_t* key_a, const int64_t* key_b, int64_t key_stride, int64_t n_items,
+                           int64_t n_a, int64_t n_b, int32_t* ptr, int32_t* perm, int32_t* status, void* ws,
+                           size_t ws_bytes, pgnn_stream stream) {
+  PGNN_REQUIRE(n_a > 0 && n_b > 0 && n_items >= 0 && key_stride >= 1 && n_items < (1ll << 31), "bad group_by_key_pair sizes");
+  PGNN_REQUIRE(use_partition(n_a * n_b, n_items), "group_by_key_pair: the product of the key ranges must stay within %d", kPartMaxKeys);
+  if (ws_bytes < pgnn_group_workspace_bytes(n_a * n_b, n_items)) {
+    set_error("group_by_key_pair workspace too small");
+    return PGNN_ERR_WORKSPACE;
+  }
+  return run_partition(key_a, key_stride, n_items, n_a * n_b, ptr, perm, status, ws, (hipStream_t)stream, key_b, (int)n_b);
 }
 
 }  // extern "C"

@@ -140,13 +140,52 @@ int pgnn_chem_gin_layer_bwd(const float* dy, int64_t lddy, const float* agg, con
  * main stream from re-using a buffer set before the side stream is done with it.
  * --------------------------------------------------------------------------------------------- */
 namespace {
+// Both atom-embedding gradients come from ONE grouping by the (type, chirality) pair when the product of the
+// table sizes fits the partition kernel (120 x 3 = 360 <= 1024): one stable partition, one segment sum over the
+// node gradients, one fold -- instead of two groupings and two passes over the same gradients.
+inline bool embed_pair_path(int64_t rows1, int64_t rows2) { return rows1 > 0 && rows2 > 0 && rows1 * rows2 <= 1024; }
 inline size_t stack_group_ws(int64_t n, int64_t rows1, int64_t rows2) {
-  return align_up(std::max(pgnn_group_workspace_bytes(std::max<int64_t>(rows1, 1), n),
-                           pgnn_group_workspace_bytes(std::max<int64_t>(rows2, 1), n)), 256);
+  size_t m = std::max(pgnn_group_workspace_bytes(std::max<int64_t>(rows1, 1), n),
+                      pgnn_group_workspace_bytes(std::max<int64_t>(rows2, 1), n));
+  if (embed_pair_path(rows1, rows2)) m = std::max(m, pgnn_group_workspace_bytes(rows1 * rows2, n));
+  return align_up(m, 256);
 }
 inline size_t stack_segsum_ws(int64_t n, int64_t dim, int64_t rows1, int64_t rows2) {
-  return align_up(std::max(pgnn_segment_sum_workspace_bytes(n, std::max<int64_t>(rows1, 1), dim),
-                           pgnn_segment_sum_workspace_bytes(n, std::max<int64_t>(rows2, 1), dim)), 256);
+  size_t m = std::max(pgnn_segment_sum_workspace_bytes(n, std::max<int64_t>(rows1, 1), dim),
+                      pgnn_segment_sum_workspace_bytes(n, std::max<int64_t>(rows2, 1), dim));
+  if (embed_pair_path(rows1, rows2)) m = std::max(m, pgnn_segment_sum_workspace_bytes(n, rows1 * rows2, dim));
+  return align_up(m, 256);
+}
+inline size_t stack_keys(int64_t rows1, int64_t rows2) {
+  return (size_t)(embed_pair_path(rows1, rows2) ? rows1 * rows2 : std::max(rows1, rows2));
+}
+inline size_t stack_pair_sums(int64_t dim, int64_t rows1, int64_t rows2) {
+  return embed_pair_path(rows1, rows2) ? align_up((size_t)rows1 * rows2 * dim * 4, 256) : 0;
+}
+
+// gradients of the two atom embedding tables from the gradient g [n, dim] of their sum (chem/model.py:264)
+inline int embed_tables_bwd(const float* g, const int64_t* x_idx, int64_t n, int64_t dim, int64_t rows1, int64_t rows2,
+                            float* dxemb1, float* dxemb2, int32_t* gptr0, int32_t* gperm0, int32_t* gptr1,
+                            int32_t* gperm1, int32_t* gstatus, char* grp_ws, size_t grp_b, char* seg_ws, size_t seg_b,
+                            float* pair_sums, bool grouped, hipStream_t st) {
+  int rc;
+  if (embed_pair_path(rows1, rows2) && dxemb1 && dxemb2) {
+    if (!grouped &&
+        (rc = pgnn_group_by_key_pair(x_idx, x_idx + 1, 2, n, rows1, rows2, gptr0, gperm0, gstatus, grp_ws, grp_b, st)))
+      return rc;
+    if ((rc = pgnn_segment_sum(g, dim, gptr0, gperm0, n, rows1 * rows2, 0, pair_sums, dim, dim, seg_ws, seg_b, st))) return rc;
+    return pgnn_pair_fold(pair_sums, rows1, rows2, dxemb1, dim, dxemb2, dim, dim, st);
+  }
+  const int64_t rows[2] = {rows1, rows2};
+  float* dx[2] = {dxemb1, dxemb2};
+  int32_t* ptrs[2] = {gptr0, gptr1};
+  int32_t* perms[2] = {gperm0, gperm1};
+  for (int c = 0; c < 2; ++c) {
+    if (!dx[c]) continue;
+    if (!grouped && (rc = pgnn_group_by_key(x_idx + c, 2, n, rows[c], ptrs[c], perms[c], gstatus, grp_ws, grp_b, st))) return rc;
+    if ((rc = pgnn_segment_sum(g, dim, ptrs[c], perms[c], n, rows[c], 0, dx[c], dim, dim, seg_ws, seg_b, st))) return rc;
+  }
+  return PGNN_OK;
 }
 }  // namespace
 
@@ -156,8 +195,8 @@ size_t pgnn_chem_gin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t rows1
   // S = 2 (ping-pong by layer parity), or one set per layer under the PGNN_STACK_PER_LAYER_BUFFERS=1 A/B knob.
   const size_t sets = (per_layer_buffers() && n <= kSideMaxRows) ? (size_t)std::max<int64_t>(num_layer, 2) : 2;
   return 2 * op_ws_bytes(n, dim) + sets * 5 * nd + 2 * align_up((size_t)n * 4, 256) +
-         2 * align_up((size_t)(std::max(rows1, rows2) + 1) * 4, 256) + 256 + stack_group_ws(n, rows1, rows2) +
-         stack_segsum_ws(n, dim, rows1, rows2) + 256;
+         2 * align_up((stack_keys(rows1, rows2) + 1) * 4, 256) + 256 + stack_group_ws(n, rows1, rows2) +
+         stack_segsum_ws(n, dim, rows1, rows2) + stack_pair_sums(dim, rows1, rows2) + 256;
 }
 
 int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t rows1, const float* xemb2,
@@ -243,7 +282,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   int32_t* gptr[2];
   int32_t* gperm[2];
   for (int c = 0; c < 2; ++c) {
-    gptr[c] = cv.take<int32_t>((size_t)std::max(rows1, rows2) + 1);
+    gptr[c] = cv.take<int32_t>(stack_keys(rows1, rows2) + 1);
     gperm[c] = cv.take<int32_t>((size_t)n);
   }
   int32_t* gstatus = cv.take<int32_t>(64);
@@ -251,6 +290,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   char* grp_ws = cv.take<char>(grp_b);
   const size_t seg_b = stack_segsum_ws(n, dim, rows1, rows2);
   char* seg_ws = cv.take<char>(seg_b);
+  float* pair_sums = reinterpret_cast<float*>(cv.take<char>(stack_pair_sums(dim, rows1, rows2)));
 
   hipStream_t main = (hipStream_t)stream;
   Side* sd = (use_side_stream() && n <= kSideMaxRows && num_layer <= kMaxSets) ? side_for_current_device() : nullptr;
@@ -261,13 +301,8 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   char* aux_ws = sd ? op2 : op;
   int rc;
   // Every event record / wait costs ~7 us of host time, so forks are spent only where they buy overlap:
-  // the atom-type / chirality groupings (three tiny kernels) stay on the caller's stream.
-  const int64_t rows[2] = {rows1, rows2};
-  float* dxemb[2] = {dxemb1, dxemb2};
+  // the atom-type / chirality grouping (a few tiny kernels) stays on the caller's stream, after the layers.
   PGNN_HIP(hipMemsetAsync(gstatus, 0, sizeof(int32_t), main));
-  for (int c = 0; c < 2; ++c)
-    if (dxemb[c] && (rc = pgnn_group_by_key(x_idx + c, 2, n, rows[c], gptr[c], gperm[c], gstatus, grp_ws, grp_b, main)))
-      return rc;
 
   const float* g = dy;
   int64_t ldg = lddy;
@@ -300,10 +335,8 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     PGNN_HIP(hipEventRecord(sd->join, aux));
     PGNN_HIP(hipStreamWaitEvent(main, sd->join, 0));
   }
-  for (int c = 0; c < 2; ++c)
-    if (dxemb[c] && (rc = pgnn_segment_sum(g, dim, gptr[c], gperm[c], n, rows[c], 0, dxemb[c], dim, dim, seg_ws, seg_b, main)))
-      return rc;
-  return PGNN_OK;
+  return embed_tables_bwd(g, x_idx, n, dim, rows1, rows2, dxemb1, dxemb2, gptr[0], gperm[0], gptr[1], gperm[1], gstatus,
+                          grp_ws, grp_b, seg_ws, seg_b, pair_sums, false, main);
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -317,8 +350,8 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
 size_t pgnn_chem_lin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t rows1, int64_t rows2) {
   const size_t nd = align_up((size_t)n * dim * 4, 256);
   return op_ws_bytes(n, dim) + 2 * 4 * nd + 2 * align_up((size_t)n * 4, 256) +
-         2 * align_up((size_t)(std::max(rows1, rows2) + 1) * 4, 256) + 256 + stack_group_ws(n, rows1, rows2) +
-         stack_segsum_ws(n, dim, rows1, rows2) + 256;
+         2 * align_up((stack_keys(rows1, rows2) + 1) * 4, 256) + 256 + stack_group_ws(n, rows1, rows2) +
+         stack_segsum_ws(n, dim, rows1, rows2) + stack_pair_sums(dim, rows1, rows2) + 256;
 }
 
 int pgnn_chem_lin_stack_fwd(int kind, const int64_t* x_idx, const float* xemb1, int64_t rows1, const float* xemb2,
@@ -389,7 +422,7 @@ int pgnn_chem_lin_stack_bwd(int kind, const float* dy, int64_t lddy, const int64
   int32_t* gptr[2];
   int32_t* gperm[2];
   for (int c = 0; c < 2; ++c) {
-    gptr[c] = cv.take<int32_t>((size_t)std::max(rows1, rows2) + 1);
+    gptr[c] = cv.take<int32_t>(stack_keys(rows1, rows2) + 1);
     gperm[c] = cv.take<int32_t>((size_t)n);
   }
   int32_t* gstatus = cv.take<int32_t>(64);
@@ -397,15 +430,11 @@ int pgnn_chem_lin_stack_bwd(int kind, const float* dy, int64_t lddy, const int64
   char* grp_ws = cv.take<char>(grp_b);
   const size_t seg_b = stack_segsum_ws(n, dim, rows1, rows2);
   char* seg_ws = cv.take<char>(seg_b);
+  float* pair_sums = reinterpret_cast<float*>(cv.take<char>(stack_pair_sums(dim, rows1, rows2)));
 
   hipStream_t main = (hipStream_t)stream;
   int rc;
-  const int64_t rows[2] = {rows1, rows2};
-  float* dxemb[2] = {dxemb1, dxemb2};
   PGNN_HIP(hipMemsetAsync(gstatus, 0, sizeof(int32_t), main));
-  for (int c = 0; c < 2; ++c)
-    if (dxemb[c] && (rc = pgnn_group_by_key(x_idx + c, 2, n, rows[c], gptr[c], gperm[c], gstatus, grp_ws, grp_b, main)))
-      return rc;
 
   const float* g = dy;
   int64_t ldg = lddy;
@@ -430,10 +459,8 @@ int pgnn_chem_lin_stack_bwd(int kind, const float* dy, int64_t lddy, const int64
     g = dxb[b];
     ldg = dim;
   }
-  for (int c = 0; c < 2; ++c)
-    if (dxemb[c] && (rc = pgnn_segment_sum(g, dim, gptr[c], gperm[c], n, rows[c], 0, dxemb[c], dim, dim, seg_ws, seg_b, main)))
-      return rc;
-  return PGNN_OK;
+  return embed_tables_bwd(g, x_idx, n, dim, rows1, rows2, dxemb1, dxemb2, gptr[0], gperm[0], gptr[1], gperm[1], gstatus,
+                          grp_ws, grp_b, seg_ws, seg_b, pair_sums, false, main);
 }
 
 }  // extern "C"

@@ -410,7 +410,13 @@ def test_one_call_network_equals_per_layer_path(graphs, layers, training, monkey
                     {k: v.clone() for k, v in m.named_buffers()}))
     assert torch.equal(res[0][0], res[1][0])
     for k in res[0][1]:
-        assert torch.equal(res[0][1][k], res[1][1][k]), k
+        if k.startswith("x_embedding"):
+            # the one-call path groups the atoms once by (type, chirality) and folds; the per-layer path sums each
+            # column on its own: same values, different association order
+            scale = float(res[1][1][k].abs().max())
+            torch.testing.assert_close(res[0][1][k], res[1][1][k], rtol=1e-4, atol=1e-4 * scale)
+        else:
+            assert torch.equal(res[0][1][k], res[1][1][k]), k
     for k in res[0][2]:
         assert torch.equal(res[0][2][k], res[1][2][k]), k
 
@@ -437,7 +443,13 @@ def test_one_call_gcn_and_graphsage_equal_per_layer_path(gnn_type, graphs, layer
                     {k: v.clone() for k, v in m.named_buffers()}))
     assert torch.equal(res[0][0], res[1][0])
     for k in res[0][1]:
-        assert torch.equal(res[0][1][k], res[1][1][k]), k
+        if k.startswith("x_embedding"):
+            # the one-call path groups the atoms once by (type, chirality) and folds; the per-layer path sums each
+            # column on its own: same values, different association order
+            scale = float(res[1][1][k].abs().max())
+            torch.testing.assert_close(res[0][1][k], res[1][1][k], rtol=1e-4, atol=1e-4 * scale)
+        else:
+            assert torch.equal(res[0][1][k], res[1][1][k]), k
     for k in res[0][2]:
         assert torch.equal(res[0][2][k], res[1][2][k]), k
 

@@ -468,3 +468,38 @@ def test_aggregate_with_batchnorm_on_read_is_bit_identical(dim, relu):
                                              got.data_ptr(), dim, n, dim, sp), "agg_bn")
     assert torch.equal(mean, mean2) and torch.equal(invstd, invstd2)
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("n,na,nb,dim", [(6747, 120, 3, 300), (5, 120, 3, 300), (40000, 7, 5, 64), (1, 2, 2, 32)])
+def test_pair_grouping_and_fold(n, na, nb, dim):
+    """pgnn_group_by_key_pair + pgnn_segment_sum + pgnn_pair_fold: the gradients of two embedding tables that
+    are summed per node (chem/model.py:264) from ONE stable grouping -- against index_add on the CPU"""
+    ops = _ops()
+    lib, sp = ops.load(), ops.stream_ptr()
+    torch.manual_seed(n + na)
+    idx = torch.stack([torch.randint(0, na, (n,)), torch.randint(0, nb, (n,))], 1)
+    g = torch.randn(n, dim)
+    idx_d, g_d = idx.to(DEV), g.to(DEV)
+    keys = na * nb
+    ptr = torch.empty(keys + 1, dtype=torch.int32, device=DEV)
+    perm = torch.empty(max(n, 1), dtype=torch.int32, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ws = torch.empty(int(lib.pgnn_group_workspace_bytes(keys, n)), dtype=torch.uint8, device=DEV)
+    ops.check(lib.pgnn_group_by_key_pair(idx_d.data_ptr(), idx_d.data_ptr() + 8, 2, n, na, nb, ptr.data_ptr(), perm.data_ptr(),
+                                         status.data_ptr(), ws.data_ptr(), ws.numel(), sp), "pair")
+    combined = (idx[:, 0] * nb + idx[:, 1]).numpy()
+    want_perm = np.argsort(combined, kind="stable")
+    assert int(status.item()) == 0
+    assert np.array_equal(perm.cpu().numpy()[:n], want_perm)
+    assert np.array_equal(ptr.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(combined, minlength=keys))]))
+    sums = torch.empty(keys, dim, device=DEV)
+    ws2 = torch.empty(int(lib.pgnn_segment_sum_workspace_bytes(n, keys, dim)), dtype=torch.uint8, device=DEV)
+    ops.check(lib.pgnn_segment_sum(g_d.data_ptr(), dim, ptr.data_ptr(), perm.data_ptr(), n, keys, 0, sums.data_ptr(), dim, dim,
+                                   ws2.data_ptr(), ws2.numel(), sp), "segsum")
+    out_a, out_b = torch.empty(na, dim, device=DEV), torch.empty(nb, dim, device=DEV)
+    ops.check(lib.pgnn_pair_fold(sums.data_ptr(), na, nb, out_a.data_ptr(), dim, out_b.data_ptr(), dim, dim, sp), "fold")
+    want_a = torch.zeros(na, dim, dtype=torch.float64).index_add_(0, idx[:, 0], g.double())
+    want_b = torch.zeros(nb, dim, dtype=torch.float64).index_add_(0, idx[:, 1], g.double())
+    scale = max(1.0, float(want_b.abs().max()))
+    assert float((out_a.cpu().double() - want_a).abs().max()) <= 1e-5 * scale
+    assert float((out_b.cpu().double() - want_b).abs().max()) <= 1e-5 * scale
