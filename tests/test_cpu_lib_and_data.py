@@ -198,3 +198,21 @@ def test_resident_loader_sharding_and_mask_counts():
     assert len(dropped) == 6 and len(dropped.batch_ids()) == 6
     ns = [1, 6, 7, 13, 14, 20, 26, 27, 60, 1000]
     assert resident.mask_counts(ns, 0.15).tolist() == [int(n * 0.15 + 1) for n in ns]
+
+
+def test_direct_gradient_deposit_semantics_on_cpu():
+    """ops._deposit_grads is what replaces AccumulateGrad for the one-call networks: assign when .grad is None,
+    add otherwise, skip frozen parameters, refuse parameters changed in place since the forward"""
+    from pretrain_gnns_amd import ops
+    ps = [torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2, 2)), torch.nn.Parameter(torch.zeros(1))]
+    ps[2].requires_grad_(False)
+    versions = [p._version for p in ps]
+    g = [torch.ones(3), torch.full((2, 2), 2.0), torch.ones(1)]
+    ops._deposit_grads(ps, versions, g)
+    assert ps[0].grad is g[0] and ps[1].grad is g[1] and ps[2].grad is None
+    ops._deposit_grads(ps, versions, [torch.ones(3), torch.ones(2, 2), torch.ones(1)])
+    assert ps[0].grad.tolist() == [2.0, 2.0, 2.0] and ps[1].grad.tolist() == [[3.0, 3.0], [3.0, 3.0]]
+    with torch.no_grad():
+        ps[0].add_(1.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        ops._deposit_grads(ps, versions, g)
