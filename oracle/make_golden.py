@@ -7,17 +7,18 @@ statistics (chem/model_architecture/gcn_contextpred.pth, bio/model_architecture/
 the GIN blobs are absent from the repo).  Each fixture stores
   * the checkpoint's state dict exactly as shipped (the key/shape contract),
   * a small seeded synthetic batch,
-  * the oracle's eval-mode node embeddings on it (and train-mode embeddings + one gradient).
-The oracle strict-loads the state dict (= the drop-in key contract); the -m gpu tests then load
-the same dict into the HIP-backed classes and must reproduce the stored outputs to 1e-4.
+  * the eval-mode node embeddings (and train-mode embeddings + one gradient) that the REFERENCE'S OWN
+    `model.GNN` (unmodified /root/reference/{chem,bio}/model.py, imported through oracle/refshim)
+    computes on it after strict-loading the checkpoint.
+tests/test_cpu_oracle.py checks the oracle against them, the -m gpu tests load the same dict into the
+HIP-backed classes and must reproduce the stored outputs to 1e-4.
 /root/reference does not exist on the GPU box, hence the committed fixtures.
 """
 import os
 
 import torch
 
-from oracle import bio as obio
-from oracle import chem as ochem
+from oracle import refshim
 from pretrain_gnns_amd.data import synthetic
 
 REF = "/root/reference"
@@ -45,7 +46,9 @@ def _fixture(kind, ckpt, model, batch):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(1)
     torch.manual_seed(0)
+    ochem, obio = refshim.load("chem").model, refshim.load("bio").model  # the reference's classes
     fx = _fixture("chem", "chem/model_architecture/gcn_contextpred.pth", ochem.GNN(5, 300, gnn_type="gcn"),
                   synthetic.chem_plain_batch(6, seed=11))
     torch.save(fx, os.path.join(OUT, "chem_gcn_contextpred.pt"))

@@ -50,9 +50,11 @@ def propagate_mean(edge_index, x_j_source, per_edge_term, combine, num_nodes):
 
 def softmax(src, index, num_nodes):
     """torch_geometric.utils.softmax of 1.0.3 (chem/model.py:155): per index group, subtract the group
-    max, exponentiate, divide by the group sum + 1e-16."""
+    max, exponentiate, divide by the group sum + 1e-16.  The max comes from torch_scatter 1.1.2's
+    scatter_max, whose output is pre-filled with fill_value = 0: the shift is max(0, group max), so a group
+    whose scores are all very negative is NOT rescued from underflow (the 1e-16 then dominates)."""
     shape = (num_nodes,) + tuple(src.shape[1:])
-    mx = torch.full(shape, float("-inf"), dtype=src.dtype, device=src.device)
+    mx = torch.zeros(shape, dtype=src.dtype, device=src.device)
     mx = mx.scatter_reduce(0, index.view(-1, *([1] * (src.dim() - 1))).expand_as(src), src, reduce="amax", include_self=True)
     out = (src - mx[index]).exp()
     return out / (scatter_add(out, index, num_nodes)[index] + 1e-16)
@@ -86,6 +88,7 @@ class Set2Set(torch.nn.Module):
         self.in_channels, self.out_channels = in_channels, 2 * in_channels
         self.processing_steps, self.num_layers = processing_steps, num_layers
         self.lstm = torch.nn.LSTM(self.out_channels, self.in_channels, num_layers)
+        self.lstm.reset_parameters()  # 1.0.3's Set2Set.reset_parameters(): a second draw, kept for seeded-init parity
 
     def forward(self, x, batch):
         size = int(batch.max().item()) + 1

@@ -64,24 +64,36 @@ def cycle_index(num, shift):
     return arr
 
 
-def contextpred_logits(model_substruct, model_context, batch, neg_samples=1, pool=pyg.global_mean_pool):
-    """chem/pretrain_contextpred.py:54-67, cbow branch."""
+def contextpred_logits(model_substruct, model_context, batch, neg_samples=1, pool=pyg.global_mean_pool, mode="cbow"):
+    """chem/pretrain_contextpred.py:54-81 (= bio/pretrain_contextpred.py:49-76): cbow and skipgram branches."""
     substruct_rep = model_substruct(batch.x_substruct, batch.edge_index_substruct,
                                     batch.edge_attr_substruct)[batch.center_substruct_idx]
     overlapped_node_rep = model_context(batch.x_context, batch.edge_index_context,
                                         batch.edge_attr_context)[batch.overlap_context_substruct_idx]
-    context_rep = pool(overlapped_node_rep, batch.batch_overlapped_context)
-    neg_context_rep = torch.cat(
-        [context_rep[cycle_index(len(context_rep), i + 1).to(context_rep.device)] for i in range(neg_samples)], dim=0)
-    pred_pos = torch.sum(substruct_rep * context_rep, dim=1)
-    pred_neg = torch.sum(substruct_rep.repeat((neg_samples, 1)) * neg_context_rep, dim=1)
+    if mode == "cbow":
+        context_rep = pool(overlapped_node_rep, batch.batch_overlapped_context)
+        neg_context_rep = torch.cat(
+            [context_rep[cycle_index(len(context_rep), i + 1).to(context_rep.device)] for i in range(neg_samples)], dim=0)
+        pred_pos = torch.sum(substruct_rep * context_rep, dim=1)
+        pred_neg = torch.sum(substruct_rep.repeat((neg_samples, 1)) * neg_context_rep, dim=1)
+    elif mode == "skipgram":  # :69-81: every overlap node against its own (pos) / the next graph's (neg) centre
+        sizes = batch.overlapped_context_size
+        expanded = torch.cat([substruct_rep[i].repeat((int(sizes[i]), 1)) for i in range(len(substruct_rep))], dim=0)
+        pred_pos = torch.sum(expanded * overlapped_node_rep, dim=1)
+        shifted_all = []
+        for i in range(neg_samples):
+            shifted = substruct_rep[cycle_index(len(substruct_rep), i + 1)]
+            shifted_all.append(torch.cat([shifted[j].repeat((int(sizes[j]), 1)) for j in range(len(shifted))], dim=0))
+        pred_neg = torch.sum(torch.cat(shifted_all, dim=0) * overlapped_node_rep.repeat((neg_samples, 1)), dim=1)
+    else:
+        raise ValueError("Invalid mode!")
     return pred_pos, pred_neg
 
 
 def chem_contextpred_step(model_substruct, model_context, optimizer_substruct, optimizer_context, batch,
-                          neg_samples=1, pool=pyg.global_mean_pool):
-    """chem/pretrain_contextpred.py:51-100 (loop body of train(), mode=cbow)."""
-    pred_pos, pred_neg = contextpred_logits(model_substruct, model_context, batch, neg_samples, pool)
+                          neg_samples=1, pool=pyg.global_mean_pool, mode="cbow"):
+    """chem/pretrain_contextpred.py:51-100 and bio/pretrain_contextpred.py:46-95 (loop body of train())."""
+    pred_pos, pred_neg = contextpred_logits(model_substruct, model_context, batch, neg_samples, pool, mode)
     loss_pos = F.binary_cross_entropy_with_logits(pred_pos.double(), torch.ones_like(pred_pos).double())
     loss_neg = F.binary_cross_entropy_with_logits(pred_neg.double(), torch.zeros_like(pred_neg).double())
     optimizer_substruct.zero_grad()

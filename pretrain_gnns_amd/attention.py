@@ -13,9 +13,10 @@ import torch.nn.functional as F
 
 
 def segment_softmax(src, index, num_segments):
-    """torch_geometric.utils.softmax (1.0.3): per segment subtract the max, exp, divide by sum + 1e-16."""
+    """torch_geometric.utils.softmax (1.0.3): per segment subtract the max, exp, divide by sum + 1e-16.  The pinned
+    torch_scatter 1.1.2 pre-fills scatter_max's output with 0, i.e. the shift is max(0, segment max) -- reproduced."""
     idx = index.view(-1, *([1] * (src.dim() - 1))).expand_as(src)
-    mx = torch.full((num_segments,) + tuple(src.shape[1:]), float("-inf"), dtype=src.dtype, device=src.device)
+    mx = torch.zeros((num_segments,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
     mx = mx.scatter_reduce(0, idx, src, reduce="amax", include_self=True)
     out = (src - mx[index]).exp()
     den = torch.zeros((num_segments,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device).index_add_(0, index, out)
@@ -66,6 +67,7 @@ class Set2Set(torch.nn.Module):
         self.in_channels, self.out_channels = in_channels, 2 * in_channels
         self.processing_steps, self.num_layers = processing_steps, num_layers
         self.lstm = torch.nn.LSTM(self.out_channels, self.in_channels, num_layers)
+        self.lstm.reset_parameters()  # 1.0.3's Set2Set.reset_parameters(): a second draw, kept for seeded-init parity
 
     def forward(self, x, batch):
         size = int(batch.max().item()) + 1

@@ -59,28 +59,36 @@ def zinc_like_graph(rng):
     return Data(x=torch.from_numpy(x), edge_index=torch.from_numpy(edge_index), edge_attr=torch.from_numpy(edge_attr))
 
 
-def mask_atoms(data, rng, mask_rate=0.15, mask_edge=False):
-    """MaskAtom (chem/util.py:225-277) on a copy: k = int(n*rate + 1) distinct atoms; label = the
-    original feature row; masked rows := [119, 0]; optional bond masking := [5, 0]."""
+def mask_atoms_at(data, idx, mask_edge=False, atom_token=ATOM_MASK_TOKEN, bond_token=BOND_MASK_TOKEN):
+    """MaskAtom.__call__(data, masked_atom_indices) (chem/util.py:207-277) on a copy, for GIVEN atoms: label = the
+    original feature rows in the order of ``idx``; masked rows := [atom_token, 0]; with ``mask_edge`` the bonds
+    touching a masked atom := [bond_token, 0], their labels / indices taken from the first direction of each pair
+    (``connected_edge_indices[::2]``, :255-268)."""
     data = data.clone()
-    n = data.x.size(0)
-    idx = rng.choice(n, int(n * mask_rate + 1), replace=False).astype(np.int64)
+    idx = torch.as_tensor(idx, dtype=torch.long)
     data.mask_node_label = data.x[idx].clone()
-    data.masked_atom_indices = torch.from_numpy(idx)
-    data.x[idx] = torch.tensor([ATOM_MASK_TOKEN, 0])
+    data.masked_atom_indices = idx.clone()
+    data.x[idx] = torch.tensor([atom_token, 0])
     if mask_edge:
         ei = data.edge_index.numpy()
-        hit = np.isin(ei[0], idx) | np.isin(ei[1], idx)
+        hit = np.isin(ei[0], idx.numpy()) | np.isin(ei[1], idx.numpy())
         connected = np.nonzero(hit)[0]
         if connected.size:
             first = connected[::2]
             data.mask_edge_label = data.edge_attr[first].clone()
-            data.edge_attr[connected] = torch.tensor([BOND_MASK_TOKEN, 0])
+            data.edge_attr[connected] = torch.tensor([bond_token, 0])
             data.connected_edge_indices = torch.from_numpy(first.astype(np.int64))
         else:
             data.mask_edge_label = torch.empty((0, 2), dtype=torch.int64)
             data.connected_edge_indices = torch.empty((0,), dtype=torch.int64)
     return data
+
+
+def mask_atoms(data, rng, mask_rate=0.15, mask_edge=False):
+    """MaskAtom with its random draw (chem/util.py:225-231): k = int(n*rate + 1) distinct atoms."""
+    n = data.x.size(0)
+    idx = rng.choice(n, int(n * mask_rate + 1), replace=False).astype(np.int64)
+    return mask_atoms_at(data, idx, mask_edge)
 
 
 def _bfs_dist(n, edge_index, root):
@@ -156,18 +164,45 @@ def ppi_like_graph(rng):
                 edge_attr=torch.from_numpy(np.repeat(attr, 2, axis=0)), center_node_idx=torch.tensor([0]))
 
 
-def mask_edges(data, rng, mask_rate=0.15):
-    """MaskEdge (bio/util.py:77-102): k = int(E/2*rate + 1) undirected edges; label = original
-    attr of the first direction; both directions := [0]*8 + [1]."""
+def mask_edges_at(data, first):
+    """MaskEdge.__call__(data, masked_edge_indices) (bio/util.py:55-110) on a copy, for GIVEN first-direction edge
+    indices: label = original attr of the first direction; both directions := [0]*8 + [1]."""
     data = data.clone()
-    num_edges = data.edge_index.size(1) // 2
-    first = 2 * rng.choice(num_edges, int(num_edges * mask_rate + 1), replace=False).astype(np.int64)
-    data.masked_edge_idx = torch.from_numpy(first)
+    first = torch.as_tensor(first, dtype=torch.long)
+    data.masked_edge_idx = first.clone()
     data.mask_edge_label = data.edge_attr[first].clone()
-    both = np.concatenate([first, first + 1])
     mask_row = torch.zeros(9)
     mask_row[8] = 1
-    data.edge_attr[both] = mask_row
+    data.edge_attr[torch.cat([first, first + 1])] = mask_row
+    return data
+
+
+def mask_edges(data, rng, mask_rate=0.15):
+    """MaskEdge with its random draw (bio/util.py:77-86): k = int(E/2*rate + 1) undirected edges."""
+    num_edges = data.edge_index.size(1) // 2
+    first = 2 * rng.choice(num_edges, int(num_edges * mask_rate + 1), replace=False).astype(np.int64)
+    return mask_edges_at(data, first)
+
+
+def bio_extract_substruct_context(data, l1=1):
+    """bio ExtractSubstructureContextPair(l1, center=True) (bio/util.py:123-209): the substructure is the whole ego
+    net; the context is the sub-graph induced on the nodes MORE than l1 hops from the centre node (unreachable
+    ones included), its edge attributes rebuilt as [w1..w7, 0, 0] (bio/loader.py:56-68, 134); every context node is
+    an overlap node.  Kept nodes are numbered by node index and bonds keep their original relative order (the
+    reference takes both orders from networkx; tests compare as labelled graphs)."""
+    data = data.clone()
+    n = data.x.size(0)
+    root = int(data.center_node_idx.item())
+    dist = _bfs_dist(n, data.edge_index.numpy(), root)
+    data.x_substruct, data.edge_attr_substruct = data.x, data.edge_attr
+    data.edge_index_substruct, data.center_substruct_idx = data.edge_index, data.center_node_idx
+    ctx = np.nonzero((dist < 0) | (dist > (l1 if l1 != 0 else -1)))[0]
+    if ctx.size:
+        data.x_context, data.edge_index_context, ea, ctx_id = _induced(data, ctx)
+        ea = ea.clone()
+        ea[:, 7:] = 0
+        data.edge_attr_context = ea
+        data.overlap_context_substruct_idx = torch.arange(ctx.size)
     return data
 
 
@@ -176,9 +211,11 @@ _NODE_OFFSET_KEYS = ("edge_index", "masked_atom_indices", "center_node_idx", "ne
 _EDGE_OFFSET_KEYS = ("connected_edge_indices", "masked_edge_idx")
 
 
-def collate(graphs):
+def collate(graphs, shift_center=True):
     """BatchMasking.from_data_list (chem/batch.py:17-52, bio/batch.py:70-106): concatenate every
-    key, shifting node-index keys by the node cumsum and edge-index keys by the edge cumsum."""
+    key, shifting node-index keys by the node cumsum and edge-index keys by the edge cumsum.
+    ``center_node_idx`` is shifted by bio BatchFinetune (bio/batch.py:41) but NOT by bio BatchMasking
+    (bio/batch.py:93-96): ``shift_center=False`` gives the latter."""
     keys = sorted(set().union(*[set(g.keys) for g in graphs]))
     cols = {k: [] for k in keys}
     batch_vec, node_off, edge_off = [], 0, 0
@@ -187,7 +224,7 @@ def collate(graphs):
         batch_vec.append(torch.full((n,), i, dtype=torch.long))
         for k in g.keys:
             item = getattr(g, k)
-            if k in _NODE_OFFSET_KEYS:
+            if k in _NODE_OFFSET_KEYS and (shift_center or k != "center_node_idx"):
                 item = item + node_off
             elif k in _EDGE_OFFSET_KEYS:
                 item = item + edge_off

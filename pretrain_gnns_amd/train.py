@@ -143,17 +143,38 @@ def cycle_index(num, shift):
     return arr
 
 
-def chem_contextpred_step(model_substruct, model_context, optimizer_substruct, optimizer_context, batch, neg_samples=1):
-    """cbow mode with mean context pooling (the reference defaults)."""
+def contextpred_logits(model_substruct, model_context, batch, neg_samples=1, mode="cbow", pool=None):
+    """chem/pretrain_contextpred.py:54-81 (identical in bio/pretrain_contextpred.py:49-76): the positive and
+    negative dot-product scores.  cbow: centre embedding against the pooled overlap embeddings of its own graph /
+    of the graph `shift` places later (cycle_index).  skipgram: every overlap node against its own / the shifted
+    centre; the reference's per-graph ``.repeat`` loops are one ``repeat_interleave`` here (a pure gather: same bits)."""
+    pool = ops.global_mean_pool if pool is None else pool
     substruct_rep = model_substruct(batch.x_substruct, batch.edge_index_substruct,
                                     batch.edge_attr_substruct)[batch.center_substruct_idx]
     overlapped_node_rep = model_context(batch.x_context, batch.edge_index_context,
                                         batch.edge_attr_context)[batch.overlap_context_substruct_idx]
-    context_rep = ops.global_mean_pool(overlapped_node_rep, batch.batch_overlapped_context)
-    neg_context_rep = torch.cat([context_rep[cycle_index(len(context_rep), i + 1).to(context_rep.device)]
-                                 for i in range(neg_samples)], dim=0)
-    pred_pos = torch.sum(substruct_rep * context_rep, dim=1)
-    pred_neg = torch.sum(substruct_rep.repeat((neg_samples, 1)) * neg_context_rep, dim=1)
+    if mode == "cbow":
+        context_rep = pool(overlapped_node_rep, batch.batch_overlapped_context)
+        neg_context_rep = torch.cat([context_rep[cycle_index(len(context_rep), i + 1).to(context_rep.device)]
+                                     for i in range(neg_samples)], dim=0)
+        pred_pos = torch.sum(substruct_rep * context_rep, dim=1)
+        pred_neg = torch.sum(substruct_rep.repeat((neg_samples, 1)) * neg_context_rep, dim=1)
+    elif mode == "skipgram":
+        sizes = batch.overlapped_context_size.to(substruct_rep.device)
+        pred_pos = torch.sum(torch.repeat_interleave(substruct_rep, sizes, dim=0) * overlapped_node_rep, dim=1)
+        shifted = [torch.repeat_interleave(substruct_rep[cycle_index(len(substruct_rep), i + 1).to(substruct_rep.device)], sizes, dim=0)
+                   for i in range(neg_samples)]
+        pred_neg = torch.sum(torch.cat(shifted, dim=0) * overlapped_node_rep.repeat((neg_samples, 1)), dim=1)
+    else:
+        raise ValueError("Invalid mode!")
+    return pred_pos, pred_neg
+
+
+def chem_contextpred_step(model_substruct, model_context, optimizer_substruct, optimizer_context, batch, neg_samples=1,
+                          mode="cbow", pool=None):
+    """One iteration of chem/pretrain_contextpred.py:51-100 (bio/pretrain_contextpred.py:46-95 is the same body);
+    defaults = the reference's defaults (cbow, mean context pooling, one negative sample)."""
+    pred_pos, pred_neg = contextpred_logits(model_substruct, model_context, batch, neg_samples, mode, pool)
     loss_pos = F.binary_cross_entropy_with_logits(pred_pos.double(), torch.ones_like(pred_pos).double())
     loss_neg = F.binary_cross_entropy_with_logits(pred_neg.double(), torch.zeros_like(pred_neg).double())
     optimizer_substruct.zero_grad()
@@ -162,10 +183,12 @@ def chem_contextpred_step(model_substruct, model_context, optimizer_substruct, o
     loss.backward()
     optimizer_substruct.step()
     optimizer_context.step()
-    balanced = float(loss_pos.detach().cpu().item() + loss_neg.detach().cpu().item())
-    acc = 0.5 * (float(torch.sum(pred_pos > 0).detach().cpu().item()) / len(pred_pos)
-                 + float(torch.sum(pred_neg < 0).detach().cpu().item()) / len(pred_neg))
-    return balanced, acc
+    vals = torch.stack([loss_pos.detach(), loss_neg.detach(), torch.sum(pred_pos > 0).double() / len(pred_pos),
+                        torch.sum(pred_neg < 0).double() / len(pred_neg)]).cpu().tolist()
+    return vals[0] + vals[1], 0.5 * (vals[2] + vals[3])
+
+
+bio_contextpred_step = chem_contextpred_step  # bio/pretrain_contextpred.py:39-102: same loop body, bio GNN classes
 
 
 def chem_finetune_step(model, optimizer, batch):

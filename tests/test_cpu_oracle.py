@@ -1,10 +1,10 @@
 """CPU (-m "not gpu"): the oracle against everything the reference pins for the hot path.
 
-SURVEY.md §8c: the reference has no numerical test of GNN.forward ("parity unpinned" at the
-arithmetic level).  What it does pin -- and what is checked here -- is (i) the shipped GCN
-checkpoints (state-dict contract + real weights and BatchNorm running statistics), through the
-committed fixtures of oracle/make_golden.py, (ii) the vocabulary constants, (iii) the edge-order and
-masking contracts documented in chem/util.py:212-241 and the disabled asserts of chem/util.py:365-419.
+The arithmetic is pinned against the reference's own code in tests/test_cpu_reference.py (fixtures written
+by the unmodified /root/reference sources through oracle/refshim).  Here: (i) the shipped GCN / GraphSAGE /
+GAT checkpoints (state-dict contract + real weights and BatchNorm running statistics) -- the stored outputs
+are those of the REFERENCE model class on them (oracle/make_golden.py), (ii) the vocabulary constants,
+(iii) hand-computed small cases of the PyG-1.0.3 semantics.
 """
 import os
 
@@ -31,10 +31,10 @@ def test_oracle_reproduces_golden_checkpoint_outputs(name, cls):
     m.eval()
     with torch.no_grad():
         out = m(b["x"], b["edge_index"], b["edge_attr"])
-    torch.testing.assert_close(out, fx["out_eval"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(out, fx["out_eval"], rtol=1e-4, atol=1e-4)  # fixture = the reference model, one thread
     m.train()
     out = m(b["x"], b["edge_index"], b["edge_attr"])
-    torch.testing.assert_close(out.detach(), fx["out_train"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(out.detach(), fx["out_train"], rtol=1e-4, atol=1e-4)
 
 
 def test_checkpoint_key_contract():
