@@ -389,6 +389,11 @@ int pgnn_substruct_context_fill(const int64_t* graph_ids, int64_t num_graphs, in
  * aggregation kernel).  Not part of the hot path. */
 int pgnn_debug_stream_copy(const float* src, float* dst, int64_t n_floats, int64_t blocks, pgnn_stream stream);
 
+/* diagnostics: device buffer [blocks][8] of uint64 that the instrumented aggregation kernel (PGNN_DMA_POL=8) fills
+ * with shader-cycle totals per block: {loader vmcnt wait, loader barrier, loader issue, consumer barrier, consumer
+ * work, block total, steps, 0}.  NULL detaches.  Not part of the hot path. */
+int pgnn_debug_aggregate_profile(uint64_t* buffer, int64_t blocks);
+
 #ifdef __cplusplus
 }
 #endif

@@ -342,14 +342,27 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 // from memory on the slow path) becomes relu?(a*z + b) with the SAME fmaf/fmaxf expression k_bn_apply
 // uses, so the previous layer's output is never materialised and the sums are bit-identical to
 // aggregating the materialised tensor.
-template <bool TABLE, int P, int NROW, bool PRE>
+// POL (cache / scheduling policy, A/B-measured through PGNN_DMA_POL; 0 = none):
+//   bit 0: row DMAs carry the non-temporal hint (every row of x is read once per block)
+//   bit 1: result rows are stored non-temporally (written once, never re-read by this kernel)
+//   bit 2: the loader wave runs at s_setprio 3
+//   bit 3: instrumentation -- lane 0 of the loader and thread 0 accumulate s_memtime deltas of their phases into
+//          prof[block][8] = {loader vmcnt wait, loader barrier, loader issue, consumer barrier, consumer work,
+//          block total, steps, 0} (pgnn_debug_aggregate_profile)
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+template <bool TABLE, int P, int NROW, bool PRE, int POL>
 __global__ void __launch_bounds__(704)
 k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ ptr,
                 const int32_t* __restrict__ nbr, const uint8_t* __restrict__ code,
                 const float* __restrict__ emb1, const float* __restrict__ emb2, float* __restrict__ out,
-                int64_t ldo, int n, int dim, int npb, const float* __restrict__ pre_coef, int pre_relu) {
+                int64_t ldo, int n, int dim, int npb, const float* __restrict__ pre_coef, int pre_relu,
+                unsigned long long* __restrict__ prof) {
 #pragma clang fp contract(off)
   constexpr int NREG = P + 3, NBUF = P + 1;
+  constexpr int AUX = (POL & 1) ? 2 : 0;
+  constexpr bool PROF = (POL & 8) != 0;
+  unsigned long long t_begin = 0;
+  if (PROF) t_begin = __builtin_readcyclecounter();
   extern __shared__ __align__(16) float smem[];
   const int gs = dim >> 2;
   const int row_f4 = kDmaG * gs;  // float4 per ring region
@@ -371,6 +384,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
 
   if (t >= cthreads) {
     // ------------------------------------------------------------------ loader wave
+    if (POL & 4) __builtin_amdgcn_s_setprio(3);
     const int lane = t - cthreads;
     const int ne = ptr[n];  // total edge count (clamps the staged-edge reads at the array end)
     const int nrow = (row_f4 + kWave - 1) / kWave;
@@ -397,14 +411,14 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
 #pragma unroll
         for (int k = 0; k < NR; ++k)  // only the last instruction of a step can be partial
           if (k + 1 < NR || val[k])
-            __builtin_amdgcn_global_load_lds(PGNN_GPTR(base + off[k]), PGNN_LPTR(dst0 + k * kWave), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(PGNN_GPTR(base + off[k]), PGNN_LPTR(dst0 + k * kWave), 16, 0, AUX);
         return;
       }
       int g = g_lane, c4 = c_lane;
       for (int k = 0; k < nrow; ++k) {
         if (k * kWave + lane < row_f4) {
           const int r = min(max(r0 + g, 0), n - 1);  // out-of-range rows: harmless duplicates, never read
-          __builtin_amdgcn_global_load_lds(PGNN_GPTR(x4 + (int64_t)r * ldx4 + c4), PGNN_LPTR(dst0 + k * kWave), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds(PGNN_GPTR(x4 + (int64_t)r * ldx4 + c4), PGNN_LPTR(dst0 + k * kWave), 16, 0, AUX);
         }
         c4 += kWave;
         while (c4 >= gs) { c4 -= gs; ++g; }
@@ -422,13 +436,28 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
     for (int q = 0; q < P; ++q) issue_edges(q, ptr[min(n0 + q * kDmaG, n1)]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // prologue: T, ptrL (consumers) and the first window (loader) are in LDS
+    unsigned long long c_wait = 0, c_bar = 0, c_issue = 0;
     for (int s = 0; s < nsteps; ++s) {
+      unsigned long long t0 = 0, t1 = 0, t2 = 0;
+      if (PROF) t0 = __builtin_readcyclecounter();
       wait_vmcnt(min(s, P - 1) * K);  // everything issued >= P steps ago (rows <= s+1, edges(s)) has landed
+      if (PROF) t1 = __builtin_readcyclecounter();
       __syncthreads();                // B(s)
+      if (PROF) t2 = __builtin_readcyclecounter();
       issue_rows(s + 1 + P);
       issue_edges(s + P, ptrL[min((s + P) * kDmaG, cnt)]);
+      if (PROF) {
+        c_wait += t1 - t0;
+        c_bar += t2 - t1;
+        c_issue += __builtin_readcyclecounter() - t2;
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the block's LDS allocation
+    if (PROF && prof && lane == 0) {
+      unsigned long long* pr = prof + (size_t)blockIdx.x * 8;
+      pr[0] = c_wait; pr[1] = c_bar; pr[2] = c_issue;
+      pr[5] = __builtin_readcyclecounter() - t_begin; pr[6] = (unsigned long long)nsteps;
+    }
     return;
   }
 
@@ -462,8 +491,18 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
   // after a barrier is only: edge indices -> rows -> adds -> store
   int nb_e0 = ptrL[0], nb_beg = 0, nb_end = 0;
   if (active && g < cnt) { nb_beg = ptrL[g]; nb_end = ptrL[g + 1]; }
+  unsigned long long c_cbar = 0, c_work = 0, t_prev = 0;
+  if (PROF) t_prev = __builtin_readcyclecounter();
   for (int s = 0; s < nsteps; ++s) {
-    __syncthreads();  // B(s)
+    if (PROF) {
+      const unsigned long long tb = __builtin_readcyclecounter();
+      c_work += tb - t_prev;
+      __syncthreads();  // B(s)
+      t_prev = __builtin_readcyclecounter();
+      c_cbar += t_prev - tb;
+    } else {
+      __syncthreads();  // B(s)
+    }
     const int li = s * kDmaG + g;
     const int e0 = nb_e0, beg = nb_beg, end = nb_end;
     {
@@ -533,11 +572,23 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
       }
     }
     acc = f4_add(acc, self);
-    reinterpret_cast<float4*>(out)[(int64_t)i * ldo4 + c4] = acc;
+    if (POL & 2) {
+      v4f_t o = {acc.x, acc.y, acc.z, acc.w};
+      __builtin_nontemporal_store(o, reinterpret_cast<v4f_t*>(out) + ((int64_t)i * ldo4 + c4));
+    } else {
+      reinterpret_cast<float4*>(out)[(int64_t)i * ldo4 + c4] = acc;
+    }
+  }
+  if (PROF && prof && t == 0) {
+    unsigned long long* pr = prof + (size_t)blockIdx.x * 8;
+    pr[3] = c_cbar; pr[4] = c_work;
   }
 }
 
-template <bool TABLE, int P, int NROW, bool PRE = false>
+unsigned long long* g_agg_prof = nullptr;  // set by pgnn_debug_aggregate_profile
+int64_t g_agg_prof_blocks = 0;
+
+template <bool TABLE, int P, int NROW, bool PRE = false, int POL = 0>
 int launch_aggregate_dma_p(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* nbr, const uint8_t* code,
                            const float* emb1, const float* emb2, float* out, int64_t ldo, int64_t n, int64_t dim,
                            hipStream_t st, const float* pre_coef = nullptr, int pre_relu = 0) {
@@ -553,9 +604,10 @@ int launch_aggregate_dma_p(const float* x, int64_t ldx, const int32_t* ptr, cons
   npb = ceil_div(npb, kDmaG) * kDmaG;
   if (npb > kDmaMaxNodes) npb = kDmaMaxNodes;
   const int grid = (int)ceil_div(n, npb);
-  allow_big_lds((const void*)k_aggregate_dma<TABLE, P, NROW, PRE>, lds);
-  hipLaunchKernelGGL((k_aggregate_dma<TABLE, P, NROW, PRE>), dim3(grid), dim3(threads), lds, st, x, ldx, ptr, nbr, code,
-                     emb1, emb2, out, ldo, (int)n, (int)dim, (int)npb, pre_coef, pre_relu);
+  unsigned long long* prof = ((POL & 8) && g_agg_prof_blocks >= grid) ? g_agg_prof : nullptr;
+  allow_big_lds((const void*)k_aggregate_dma<TABLE, P, NROW, PRE, POL>, lds);
+  hipLaunchKernelGGL((k_aggregate_dma<TABLE, P, NROW, PRE, POL>), dim3(grid), dim3(threads), lds, st, x, ldx, ptr, nbr, code,
+                     emb1, emb2, out, ldo, (int)n, (int)dim, (int)npb, pre_coef, pre_relu, prof);
   return check_launch("aggregate_dma");
 }
 
@@ -580,6 +632,17 @@ int launch_aggregate_dma(const float* x, int64_t ldx, const int32_t* ptr, const 
   if (env_int("PGNN_DMA_P", 2) == 1) return launch_aggregate_dma_p<TABLE, 1, 0>(PGNN_DMA_ARGS);
   if (!small_ld || env_int("PGNN_DMA_GENERIC", 0)) return launch_aggregate_dma_p<TABLE, 2, 0>(PGNN_DMA_ARGS);
   if (nrow == 10 && env_int("PGNN_DMA_P", 2) == 3) return launch_aggregate_dma_p<TABLE, 3, 10>(PGNN_DMA_ARGS);
+  if (nrow == 10 && TABLE) {  // policy A/B on the production instantiation only
+    switch (env_int("PGNN_DMA_POL", 0)) {
+      case 1: return launch_aggregate_dma_p<TABLE, 2, 10, false, 1>(PGNN_DMA_ARGS);
+      case 2: return launch_aggregate_dma_p<TABLE, 2, 10, false, 2>(PGNN_DMA_ARGS);
+      case 3: return launch_aggregate_dma_p<TABLE, 2, 10, false, 3>(PGNN_DMA_ARGS);
+      case 4: return launch_aggregate_dma_p<TABLE, 2, 10, false, 4>(PGNN_DMA_ARGS);
+      case 7: return launch_aggregate_dma_p<TABLE, 2, 10, false, 7>(PGNN_DMA_ARGS);
+      case 8: return launch_aggregate_dma_p<TABLE, 2, 10, false, 8>(PGNN_DMA_ARGS);
+      default: break;
+    }
+  }
   switch (nrow) {
     case 10: return launch_aggregate_dma_p<TABLE, 2, 10>(PGNN_DMA_ARGS);  // D = 300 (the reference's emb_dim)
     case 8: return launch_aggregate_dma_p<TABLE, 2, 8>(PGNN_DMA_ARGS);    // D = 256
@@ -1022,10 +1085,25 @@ int pgnn_pair_fold(const float* sums, int64_t n_a, int64_t n_b, float* out_a, in
 __global__ void __launch_bounds__(256) k_debug_copy(const float4* __restrict__ a, float4* __restrict__ b, int64_t n4) {
   for (int64_t q = blockIdx.x * (int64_t)256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) b[q] = a[q];
 }
+__global__ void __launch_bounds__(256) k_debug_copy_nt(const v4f_t* __restrict__ a, v4f_t* __restrict__ b, int64_t n4) {
+  for (int64_t q = blockIdx.x * (int64_t)256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256)
+    __builtin_nontemporal_store(__builtin_nontemporal_load(a + q), b + q);
+}
 int pgnn_debug_stream_copy(const float* src, float* dst, int64_t n_floats, int64_t blocks, pgnn_stream stream) {
+  if (blocks < 0) {  // negative block count: the same copy with non-temporal loads and stores
+    hipLaunchKernelGGL(k_debug_copy_nt, dim3((int)-blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const v4f_t*>(src), reinterpret_cast<v4f_t*>(dst), n_floats / 4);
+    return check_launch("debug_stream_copy_nt");
+  }
   hipLaunchKernelGGL(k_debug_copy, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n_floats / 4);
   return check_launch("debug_stream_copy");
+}
+
+int pgnn_debug_aggregate_profile(uint64_t* buffer, int64_t blocks) {
+  g_agg_prof = reinterpret_cast<unsigned long long*>(buffer);
+  g_agg_prof_blocks = buffer ? blocks : 0;
+  return PGNN_OK;
 }
 
 int pgnn_neighbor_sum(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* nbr,

@@ -8,6 +8,8 @@ import os
 import numpy as np
 import torch
 
+from pretrain_gnns_amd.data import synthetic
+
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 _cache = {}
 
@@ -113,3 +115,91 @@ def check_params(named, tree, what, rtol, norm_rtol=None):
         seen += 1
     assert seen > 0
     return seen
+
+
+# ----------------------------------------------------------------------------- rebuilding the reference's inputs
+def masked_batches(fx, tag, mask_edge, collate=synthetic.collate):
+    """rebuild the batches the reference's loader produced: raw graphs + the stored per-graph atom choices through
+    the HOST restatements (synthetic.mask_atoms semantics with explicit indices, synthetic.collate)"""
+    raw = raw_graphs(fx["raw"])
+    counts, local = fx[tag]["mask_counts"].tolist(), fx[tag]["mask_local"]
+    graphs, pos = [], 0
+    for g, k in zip(raw, counts):
+        d = synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr)
+        graphs.append(synthetic.mask_atoms_at(d, local[pos:pos + k], mask_edge=mask_edge))
+        pos += k
+    bs = int(fx["batch_size"])
+    return [collate(graphs[i:i + bs]) for i in range(0, len(graphs), bs)]
+
+
+def context_graphs(fx, k=5, l1=4, l2=7):
+    raw = raw_graphs(fx["raw"])
+    return [synthetic.extract_substruct_context(synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr), None, k, l1, l2,
+                                                root=int(r)) for g, r in zip(raw, fx["roots"].tolist())]
+
+
+def bfs(fx, i):
+    g = raw_graphs(fx["raw"])[i]
+    d = synthetic._bfs_dist(g.x.size(0), g.edge_index.numpy(), int(fx["roots"][i]))
+    return np.where(d < 0, 10 ** 6, d)
+
+
+def assert_same_labelled_graphs(fx, graphs, want):
+    """per graph: map both numberings back to molecule atom ids and compare node features, the edge multiset
+    (with attributes), the centre and the overlap set"""
+    used = [i for i, g in enumerate(graphs) if hasattr(g, "x_context")]
+    ns = np.cumsum([0] + [graphs[i].x_substruct.size(0) for i in used])
+    nc = np.cumsum([0] + [graphs[i].x_context.size(0) for i in used])
+    raw = raw_graphs(fx["raw"])
+    eis, eic = want["edge_index_substruct"], want["edge_index_context"]
+    for j, i in enumerate(used):
+        for part, order, off, ei_all, ea_all, x_all in (
+                ("substruct", ragged(fx["sub_order"], i), ns, eis, want["edge_attr_substruct"], want["x_substruct"]),
+                ("context", ragged(fx["ctx_order"], i), nc, eic, want["edge_attr_context"], want["x_context"])):
+            lo, hi = int(off[j]), int(off[j + 1])
+            assert hi - lo == len(order)
+            assert torch.equal(x_all[lo:hi], raw[i].x[order])  # reference numbering -> atom ids
+            sel = (ei_all[0] >= lo) & (ei_all[0] < hi)
+            ref_edges = sorted((int(order[u - lo]), int(order[v - lo]), tuple(a.tolist()))
+                               for (u, v), a in zip(ei_all[:, sel].t().tolist(), ea_all[sel]))
+            mine = graphs[i]
+            kept = np.sort(order.numpy())
+            mei = getattr(mine, "edge_index_" + part)
+            my_edges = sorted((int(kept[u]), int(kept[v]), tuple(a.tolist()))
+                              for (u, v), a in zip(mei.t().tolist(), getattr(mine, "edge_attr_" + part)))
+            assert ref_edges == my_edges, (i, part)
+
+
+def bio_batches(fx):
+    raw = raw_graphs(fx["raw"], bio=True)
+    counts, local = fx["mask_counts"].tolist(), fx["mask_local"]
+    graphs, pos = [], 0
+    for g, k in zip(raw, counts):
+        d = synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr, center_node_idx=g.center_node_idx)
+        graphs.append(synthetic.mask_edges_at(d, local[pos:pos + k]))
+        pos += k
+    bs = int(fx["batch_size"])
+    return [synthetic.collate(graphs[i:i + bs], shift_center=False) for i in range(0, len(graphs), bs)]
+
+
+def assert_same_bio_context(fx, raw, graphs, want):
+    """the context graphs as labelled graphs: reference numbering (networkx order, stored) vs node-index order"""
+    used = [i for i, g in enumerate(graphs) if hasattr(g, "x_context")]
+    nc = np.cumsum([0] + [graphs[i].x_context.size(0) for i in used])
+    ei_all, ea_all = want["edge_index_context"], want["edge_attr_context"]
+    ov = want["overlap_context_substruct_idx"]
+    assert sorted(ov.tolist()) == list(range(int(nc[-1])))  # every context node is an overlap node
+    for j, i in enumerate(used):
+        order = ragged(fx["ctx_order"], i)
+        lo, hi = int(nc[j]), int(nc[j + 1])
+        assert hi - lo == len(order)
+        sel = (ei_all[0] >= lo) & (ei_all[0] < hi)
+        ref_edges = sorted((int(order[u - lo]), int(order[v - lo]), tuple(a.tolist()))
+                           for (u, v), a in zip(ei_all[:, sel].t().tolist(), ea_all[sel]))
+        kept = np.sort(order.numpy())
+        g = graphs[i]
+        my_edges = sorted((int(kept[u]), int(kept[v]), tuple(a.tolist()))
+                          for (u, v), a in zip(g.edge_index_context.t().tolist(), g.edge_attr_context))
+        assert ref_edges == my_edges, i
+
+

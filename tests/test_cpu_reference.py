@@ -93,20 +93,6 @@ def test_oracle_forward_backward_equals_reference(name, gnn_type):
 
 
 # ============================================================================== chem masking: train() sequences
-def _masked_batches(fx, tag, mask_edge, collate=synthetic.collate):
-    """rebuild the batches the reference's loader produced: raw graphs + the stored per-graph atom choices through
-    the HOST restatements (synthetic.mask_atoms semantics with explicit indices, synthetic.collate)"""
-    raw = rf.raw_graphs(fx["raw"])
-    counts, local = fx[tag]["mask_counts"].tolist(), fx[tag]["mask_local"]
-    graphs, pos = [], 0
-    for g, k in zip(raw, counts):
-        d = synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr)
-        graphs.append(synthetic.mask_atoms_at(d, local[pos:pos + k], mask_edge=mask_edge))
-        pos += k
-    bs = int(fx["batch_size"])
-    return [collate(graphs[i:i + bs]) for i in range(0, len(graphs), bs)]
-
-
 @pytest.mark.parametrize("name,tag,gnn_type,mask_edge", [
     ("ref_chem_masking_train_b32", "gin", "gin", 0), ("ref_chem_masking_train_b32", "gin_mask_edge", "gin", 1),
     ("ref_chem_masking_train_b32", "gcn", "gcn", 0), ("ref_chem_masking_train_b256", "gin", "gin", 0)])
@@ -116,7 +102,7 @@ def test_train_mirrors_reproduce_reference_train(name, tag, gnn_type, mask_edge,
     pretrain_gnns_amd/train.py mirror -- both driven with the CPU oracle modules on the same batches"""
     fx = rf.load(name)
     want = fx[tag]
-    batches = _masked_batches(fx, tag, bool(mask_edge))
+    batches = rf.masked_batches(fx, tag, bool(mask_edge))
     models = oracle_chem_models(gnn_type)
     opts = [adam(m.parameters()) for m in models]
     if driver == "oracle_steps":
@@ -132,7 +118,7 @@ def test_train_mirrors_reproduce_reference_train(name, tag, gnn_type, mask_edge,
 def test_per_step_losses_of_reference_train():
     fx = rf.load("ref_chem_masking_train_b32")
     want = fx["gin_mask_edge"]
-    batches = _masked_batches(fx, "gin_mask_edge", True)
+    batches = rf.masked_batches(fx, "gin_mask_edge", True)
     models = oracle_chem_models("gin")
     opts = [adam(m.parameters()) for m in models]
     for m in models:
@@ -150,7 +136,7 @@ def test_host_collate_and_mask_atom_equal_reference(name, mask_edge):
     """BatchMasking.from_data_list (chem/batch.py:17-52) o MaskAtom (chem/util.py:207-277), bit-exact"""
     fx = rf.load(name)
     tag = "mask_edge%d" % mask_edge
-    got = _masked_batches({"raw": fx["raw"], tag: fx[tag], "batch_size": len(fx["raw"]["node_slices"]) - 1}, tag, bool(mask_edge))[0]
+    got = rf.masked_batches({"raw": fx["raw"], tag: fx[tag], "batch_size": len(fx["raw"]["node_slices"]) - 1}, tag, bool(mask_edge))[0]
     want = fx[tag]["batch"]
     for k, v in want.items():
         assert torch.equal(getattr(got, k), v), k
@@ -185,12 +171,6 @@ def test_spec_molecule_assertions_of_the_reference():
 
 
 # ============================================================================== context prediction
-def _context_graphs(fx, k=5, l1=4, l2=7):
-    raw = rf.raw_graphs(fx["raw"])
-    return [synthetic.extract_substruct_context(synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr), None, k, l1, l2,
-                                                root=int(r)) for g, r in zip(raw, fx["roots"].tolist())]
-
-
 @pytest.mark.parametrize("name", ["ref_chem_contextpred_b32", "ref_chem_contextpred_b256"])
 def test_host_context_transform_equals_reference(name):
     """ExtractSubstructureContextPair (chem/util.py:96-149) + BatchSubstructContext.from_data_list
@@ -199,7 +179,7 @@ def test_host_context_transform_equals_reference(name):
     graph (through the stored networkx order) otherwise"""
     fx = rf.load(name)
     bs = int(fx["batch_size"])
-    graphs = _context_graphs(fx)
+    graphs = rf.context_graphs(fx)
     got = synthetic.collate_substruct_context(graphs[:bs])
     want = fx["batches"]["0"]
     exact = all(torch.equal(getattr(got, k), v) for k, v in want.items())
@@ -211,41 +191,9 @@ def test_host_context_transform_equals_reference(name):
         assert hasattr(g, "x_context") == bool(fx["has_context"][i])
         assert hasattr(g, "overlap_context_substruct_idx") == bool(fx["has_overlap"][i])
         sub_order, ctx_order = rf.ragged(fx["sub_order"], i), rf.ragged(fx["ctx_order"], i)
-        assert sorted(sub_order.tolist()) == np.nonzero(_bfs(fx, i) <= 5)[0].tolist()
+        assert sorted(sub_order.tolist()) == np.nonzero(rf.bfs(fx, i) <= 5)[0].tolist()
     if not exact:
-        _assert_same_labelled_graphs(fx, graphs[:bs], want)
-
-
-def _bfs(fx, i):
-    g = rf.raw_graphs(fx["raw"])[i]
-    d = synthetic._bfs_dist(g.x.size(0), g.edge_index.numpy(), int(fx["roots"][i]))
-    return np.where(d < 0, 10 ** 6, d)
-
-
-def _assert_same_labelled_graphs(fx, graphs, want):
-    """per graph: map both numberings back to molecule atom ids and compare node features, the edge multiset
-    (with attributes), the centre and the overlap set"""
-    used = [i for i, g in enumerate(graphs) if hasattr(g, "x_context")]
-    ns = np.cumsum([0] + [graphs[i].x_substruct.size(0) for i in used])
-    nc = np.cumsum([0] + [graphs[i].x_context.size(0) for i in used])
-    raw = rf.raw_graphs(fx["raw"])
-    eis, eic = want["edge_index_substruct"], want["edge_index_context"]
-    for j, i in enumerate(used):
-        for part, order, off, ei_all, ea_all, x_all in (
-                ("substruct", rf.ragged(fx["sub_order"], i), ns, eis, want["edge_attr_substruct"], want["x_substruct"]),
-                ("context", rf.ragged(fx["ctx_order"], i), nc, eic, want["edge_attr_context"], want["x_context"])):
-            lo, hi = int(off[j]), int(off[j + 1])
-            assert hi - lo == len(order)
-            assert torch.equal(x_all[lo:hi], raw[i].x[order])  # reference numbering -> atom ids
-            sel = (ei_all[0] >= lo) & (ei_all[0] < hi)
-            ref_edges = sorted((int(order[u - lo]), int(order[v - lo]), tuple(a.tolist()))
-                               for (u, v), a in zip(ei_all[:, sel].t().tolist(), ea_all[sel]))
-            mine = graphs[i]
-            kept = np.sort(order.numpy())
-            mei = getattr(mine, "edge_index_" + part)
-            my_edges = sorted((int(kept[u]), int(kept[v]), tuple(a.tolist()))
-                              for (u, v), a in zip(mei.t().tolist(), getattr(mine, "edge_attr_" + part)))
-            assert ref_edges == my_edges, (i, part)
+        rf.assert_same_labelled_graphs(fx, graphs[:bs], want)
 
 
 @pytest.mark.parametrize("name,mode", [("ref_chem_contextpred_b32", "cbow"), ("ref_chem_contextpred_b32", "skipgram"),
@@ -288,7 +236,7 @@ def test_contextpred_mirrors_reproduce_reference_train(name, mode, driver):
                                    want["returned"].numpy(), rtol=1e-9)  # divides by the last step index (:102)
         rf.check_params(list(ms.named_parameters()), want["final_params_substruct"], lambda p: p, rtol=1e-6)
         rf.check_params(list(mc.named_parameters()), want["final_params_context"], lambda p: p, rtol=1e-6)
-    graphs = _context_graphs(fx)
+    graphs = rf.context_graphs(fx)
     ms, mc, os_, oc = fresh()
     l0, _ = step(ms, mc, os_, oc, synthetic.collate_substruct_context(graphs[:bs]))
     assert abs(l0 - float(want["loss_pos"][0] + want["loss_neg"][0])) <= 1e-5 * abs(l0)
@@ -325,23 +273,11 @@ def test_finetune_mirrors_reproduce_reference(pooling):
 
 
 # ============================================================================== bio
-def _bio_batches(fx):
-    raw = rf.raw_graphs(fx["raw"], bio=True)
-    counts, local = fx["mask_counts"].tolist(), fx["mask_local"]
-    graphs, pos = [], 0
-    for g, k in zip(raw, counts):
-        d = synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr, center_node_idx=g.center_node_idx)
-        graphs.append(synthetic.mask_edges_at(d, local[pos:pos + k]))
-        pos += k
-    bs = int(fx["batch_size"])
-    return [synthetic.collate(graphs[i:i + bs], shift_center=False) for i in range(0, len(graphs), bs)]
-
-
 @pytest.mark.parametrize("name,types", [("ref_bio_masking_b8", ("gin", "gcn")), ("ref_bio_masking_b256", ("gin",))])
 def test_bio_masking_equals_reference(name, types):
     """bio/model.py GNN + bio/util.py MaskEdge + bio/batch.py BatchMasking + bio/pretrain_masking.py:29-66"""
     fx = rf.load(name)
-    batches = _bio_batches(fx)
+    batches = rf.bio_batches(fx)
     b0 = batches[0]
     for k, v in fx["batch0"].items():
         assert torch.equal(getattr(b0, k), v), k  # collate + MaskEdge restatement: bit-exact
@@ -393,7 +329,7 @@ def test_bio_contextpred_equals_reference(name):
               "batch_overlapped_context"):
         assert torch.equal(getattr(got0, k), w0[k]), k
     assert got0.x_context.shape == w0["x_context"].shape and got0.edge_index_context.shape == w0["edge_index_context"].shape
-    _assert_same_bio_context(fx, raw, graphs[:bs], w0)
+    rf.assert_same_bio_context(fx, raw, graphs[:bs], w0)
     ref_batches = [rf.batch(fx["batches"][str(i)]) for i in range(nsteps)]
     for driver in ("oracle_steps", "product_mirror"):
         def fresh():
@@ -414,27 +350,6 @@ def test_bio_contextpred_equals_reference(name):
         ms, mc, os_, oc = fresh()
         l0 = step(ms, mc, os_, oc, got0)
         assert abs(l0 - float(want["loss_pos"][0] + want["loss_neg"][0])) <= 1e-5 * abs(l0)
-
-
-def _assert_same_bio_context(fx, raw, graphs, want):
-    """the context graphs as labelled graphs: reference numbering (networkx order, stored) vs node-index order"""
-    used = [i for i, g in enumerate(graphs) if hasattr(g, "x_context")]
-    nc = np.cumsum([0] + [graphs[i].x_context.size(0) for i in used])
-    ei_all, ea_all = want["edge_index_context"], want["edge_attr_context"]
-    ov = want["overlap_context_substruct_idx"]
-    assert sorted(ov.tolist()) == list(range(int(nc[-1])))  # every context node is an overlap node
-    for j, i in enumerate(used):
-        order = rf.ragged(fx["ctx_order"], i)
-        lo, hi = int(nc[j]), int(nc[j + 1])
-        assert hi - lo == len(order)
-        sel = (ei_all[0] >= lo) & (ei_all[0] < hi)
-        ref_edges = sorted((int(order[u - lo]), int(order[v - lo]), tuple(a.tolist()))
-                           for (u, v), a in zip(ei_all[:, sel].t().tolist(), ea_all[sel]))
-        kept = np.sort(order.numpy())
-        g = graphs[i]
-        my_edges = sorted((int(kept[u]), int(kept[v]), tuple(a.tolist()))
-                          for (u, v), a in zip(g.edge_index_context.t().tolist(), g.edge_attr_context))
-        assert ref_edges == my_edges, i
 
 
 # ============================================================================== live: the reference itself, here

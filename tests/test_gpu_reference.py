@@ -1,0 +1,336 @@
+"""-m gpu: the HIP path (through the C ABI of libpgnn.so) against outputs of the REFERENCE'S OWN code.
+
+tests/golden/ref_*.npz were written in the build container by the unmodified /root/reference sources
+(oracle/refshim/make_fixtures.py); /root/reference does not exist on the GPU box, the fixtures do.
+
+Bars
+  * node embeddings and masked-atom / masked-edge logits: |a-b| <= 1e-4 + 1e-4 |b| vs the reference's fp32 CPU
+    run (BASELINE.json north_star);
+  * gradients: against the reference code run in FLOAT64 (fixture key "f64"), elementwise
+    |err| <= GRAD_RTOL * (|ref| + 1e-2 max|ref tensor| + 1e-1 max|ref any|) -- two fp32 implementations differ from
+    each other by more than either differs from fp64 (a ReLU input within rounding of zero flips);
+  * integer structures built on the device: bit-exact (or, where the reference's node numbering is networkx's set
+    iteration order, equal as labelled graphs);
+  * train() trajectories: first step <= 1e-5 relative; later steps within TRAJ_RTOL -- Adam normalises away the
+    scale of near-zero gradients, the reference differs from ITSELF by 1e-4..1e-3 between 1 and 8 CPU threads.
+Every measured error is also appended to gpurun_out/parity_metrics.jsonl.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ref_fixtures as rf
+from pretrain_gnns_amd import ops
+from pretrain_gnns_amd import train as ptrain
+from pretrain_gnns_amd.data import Data, resident, synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = dict(rtol=1e-4, atol=1e-4)
+GRAD_RTOL = 2e-4
+TRAJ_RTOL = 2e-2
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def log(**kw):
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "parity_metrics.jsonl"), "a") as f:
+            f.write(json.dumps(kw) + "\n")
+    except OSError:
+        pass
+
+
+def hip_models():
+    from pretrain_gnns_amd.bio import model as hbio
+    from pretrain_gnns_amd.chem import model as hchem
+    return hchem, hbio
+
+
+def adam(params):
+    return torch.optim.Adam(params, lr=0.001, weight_decay=0)
+
+
+def max_err(t, tree):
+    t = t.detach().cpu()
+    if torch.is_tensor(tree):
+        return float((t - tree).abs().max()), tree
+    return float((t[tree["rows"]] - tree["vals"]).abs().max()), tree["vals"]
+
+
+def check_rows(t, tree, what):
+    t = t.detach().cpu()
+    if torch.is_tensor(tree):
+        torch.testing.assert_close(t, tree, **TOL)
+    else:
+        torch.testing.assert_close(t[tree["rows"]], tree["vals"], **TOL)
+        torch.testing.assert_close(t.double().sum(0), tree["colsum"], rtol=1e-4, atol=1e-4 * tree["abssum"] / t.size(0))
+    log(test=what, max_abs_err=max_err(t, tree)[0])
+
+
+def grad_errors(named, tree):
+    ref = rf.unpack_params(tree)
+    top = max(float((r["full"] if "full" in r else r["val"]).abs().max()) for r in ref.values())
+    worst = 0.0
+    for name, p in named:
+        if p.grad is None or name not in ref:
+            continue
+        r = ref[name]
+        flat = p.grad.detach().reshape(-1).cpu()
+        got, want = (flat, r["full"]) if "full" in r else (flat[r["pos"]], r["val"])
+        denom = want.abs() + 1e-2 * float(want.abs().max()) + 1e-1 * top
+        worst = max(worst, float(((got - want).abs() / denom).max()))
+    return worst
+
+
+# ============================================================================== chem masking (BASELINE configs[0], [1])
+def chem_models(gnn_type, num_layer=5):
+    hchem, _ = hip_models()
+    torch.manual_seed(0)  # the seed + construction order of oracle/refshim/make_fixtures.chem_models
+    model = hchem.GNN(num_layer, 300, JK="last", drop_ratio=0, gnn_type=gnn_type)
+    atoms, bonds = torch.nn.Linear(300, 119), torch.nn.Linear(300, 4)
+    return [model.to(DEV), atoms.to(DEV), bonds.to(DEV)]
+
+
+@pytest.mark.parametrize("name", ["ref_chem_masking_b32", "ref_chem_masking_b256"])
+@pytest.mark.parametrize("gnn_type", ["gin", "gcn"])
+def test_embeddings_logits_gradients_vs_reference(name, gnn_type):
+    fx = rf.load(name)["mask_edge0"]
+    b, want = rf.batch(fx["batch"]).to(DEV), fx[gnn_type]
+    model, atoms, _ = chem_models(gnn_type)
+    model.train()
+    h = model(b.x, b.edge_index, b.edge_attr)
+    check_rows(h, want["out_train"], "%s/%s/out_train" % (name, gnn_type))
+    logits = atoms(h[b.masked_atom_indices])
+    torch.testing.assert_close(logits.detach().cpu(), want["logits"], **TOL)
+    log(test="%s/%s/logits" % (name, gnn_type), max_abs_err=float((logits.detach().cpu() - want["logits"]).abs().max()))
+    loss = torch.nn.functional.cross_entropy(logits.double(), b.mask_node_label[:, 0])
+    assert abs(loss.item() - want["loss"]) <= 1e-5 * want["loss"]
+    assert ptrain.compute_accuracy(logits, b.mask_node_label[:, 0]) == want["acc"]
+    loss.backward()
+    named = list(model.named_parameters()) + [("head." + n, p) for n, p in atoms.named_parameters()]
+    e64, e32 = grad_errors(named, want["f64"]["grads"]), grad_errors(named, want["grads"])
+    log(test="%s/%s/grads" % (name, gnn_type), rel_err_vs_f64=e64, rel_err_vs_f32=e32)
+    rf.check_params(named, want["f64"]["grads"], lambda p: p.grad, rtol=GRAD_RTOL)
+    check_rows(h, want["f64"]["out_train"], "%s/%s/out_train_f64" % (name, gnn_type))
+    torch.testing.assert_close(model.batch_norms[4].running_mean.cpu(), want["bn_running_mean_4"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(model.batch_norms[4].running_var.cpu(), want["bn_running_var_4"], rtol=1e-4, atol=1e-6)
+    model.eval()
+    with torch.no_grad():
+        check_rows(model(b.x, b.edge_index, b.edge_attr), want["out_eval"], "%s/%s/out_eval" % (name, gnn_type))
+
+
+def device_masked_batches(fx, tag, mask_edge):
+    """the reference loader's batches rebuilt ON THE DEVICE: HBM-resident raw graphs -> pgnn_collate_graphs +
+    pgnn_mask_atoms_apply with the reference's per-graph atom choices (its masked_atom_indices debugging hook)"""
+    raw = [Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr) for g in rf.raw_graphs(fx["raw"])]
+    ds = resident.ResidentDataset.from_graphs(raw, DEV)
+    counts, local = fx[tag]["mask_counts"].tolist(), fx[tag]["mask_local"]
+    bs = int(fx["batch_size"]) if "batch_size" in fx else len(raw)
+    node_off = np.asarray(fx["raw"]["node_slices"])
+    out, pos = [], 0
+    for s in range(0, len(raw), bs):
+        ids = np.arange(s, min(s + bs, len(raw)))
+        idx = []
+        for g in ids:
+            k = counts[g]
+            idx.append(local[pos:pos + k] + int(node_off[g] - node_off[s]))
+            pos += k
+        batch = ds.collate(ids, masked_atom_indices=torch.cat(idx), mask_edge=mask_edge)
+        ds.check(batch)
+        out.append(batch)
+    return out
+
+
+@pytest.mark.parametrize("name", ["ref_chem_masking_b32", "ref_chem_masking_b256"])
+@pytest.mark.parametrize("mask_edge", [0, 1])
+def test_device_collate_and_mask_atom_equal_reference(name, mask_edge):
+    """BatchMasking.from_data_list o MaskAtom of the REFERENCE vs csrc/loader.hip, bit-exact"""
+    fx = rf.load(name)
+    tag = "mask_edge%d" % mask_edge
+    got = device_masked_batches(fx, tag, bool(mask_edge))[0]
+    for k, v in fx[tag]["batch"].items():
+        g = getattr(got, k).cpu()
+        assert g.dtype == v.dtype and torch.equal(g, v), k
+
+
+@pytest.mark.parametrize("name,tag,gnn_type,mask_edge", [
+    ("ref_chem_masking_train_b32", "gin", "gin", 0), ("ref_chem_masking_train_b32", "gin_mask_edge", "gin", 1),
+    ("ref_chem_masking_train_b32", "gcn", "gcn", 0), ("ref_chem_masking_train_b256", "gin", "gin", 0)])
+def test_train_trajectory_vs_reference_train(name, tag, gnn_type, mask_edge):
+    """the reference's train() (chem/pretrain_masking.py:34-78, its own GNN, CPU) vs the product's mirror driving the
+    HIP GNN on device-built batches"""
+    fx = rf.load(name)
+    want = fx[tag]
+    batches = device_masked_batches(fx, tag, bool(mask_edge))
+    models = chem_models(gnn_type)
+    opts = [adam(m.parameters()) for m in models]
+    for m in models:
+        m.train()
+    losses, accs = [], []
+    for b in batches:
+        l, an, ae = ptrain.chem_masking_step(models, opts, b, mask_edge=bool(mask_edge), readback="inline")
+        losses.append(l), accs.append((an, ae))
+    ref_loss = want["loss"].numpy()
+    rel = np.abs(np.array(losses) - ref_loss) / ref_loss
+    log(test="%s/%s/trajectory" % (name, tag), rel_err_per_step=rel.tolist(), acc=[a[0] for a in accs],
+        ref_acc=want["acc_terms"][:, 0].tolist())
+    assert rel[0] <= 1e-5
+    assert (rel <= TRAJ_RTOL).all(), rel
+    assert abs(accs[0][0] - float(want["acc_terms"][0, 0])) < 1e-12
+    assert np.abs(np.array([a[0] for a in accs]) - want["acc_terms"][:, 0].numpy()).max() <= 0.03
+    steps_ = len(batches)
+    np.testing.assert_allclose(sum(losses) / (steps_ - 1), float(want["returned"][0]), rtol=TRAJ_RTOL)
+
+
+# ============================================================================== context prediction (BASELINE configs[2])
+@pytest.mark.parametrize("name", ["ref_chem_contextpred_b32", "ref_chem_contextpred_b256"])
+def test_device_context_transform_vs_reference(name):
+    """ExtractSubstructureContextPair + BatchSubstructContext of the REFERENCE vs pgnn_substruct_context_plan/_fill"""
+    fx = rf.load(name)
+    bs = int(fx["batch_size"])
+    raw = [Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr) for g in rf.raw_graphs(fx["raw"])]
+    ds = resident.ResidentDataset.from_graphs(raw, DEV)
+    got = ds.collate_substruct_context(np.arange(bs), k=5, l1=4, l2=7, roots=fx["roots"][:bs])
+    ds.check(got)
+    want = fx["batches"]["0"]
+    for k in ("overlapped_context_size", "batch_overlapped_context"):
+        assert torch.equal(getattr(got, k).cpu(), want[k]), k
+    for k, v in want.items():
+        assert getattr(got, k).shape == v.shape, k
+    host = rf.context_graphs(fx)[:bs]
+    hostb = synthetic.collate_substruct_context(host)
+    for k in want:
+        assert torch.equal(getattr(got, k).cpu(), getattr(hostb, k)), k  # device == host restatement, bit-exact
+    if not all(torch.equal(getattr(hostb, k), v) for k, v in want.items()):
+        rf.assert_same_labelled_graphs(fx, host, want)  # == reference up to networkx's node numbering
+
+
+def context_models(domain="chem"):
+    hchem, hbio = hip_models()
+    mod = hchem if domain == "chem" else hbio
+    torch.manual_seed(0)
+    ms = mod.GNN(5, 300, JK="last", drop_ratio=0, gnn_type="gin")
+    mc = mod.GNN(3, 300, JK="last", drop_ratio=0, gnn_type="gin")
+    return ms.to(DEV), mc.to(DEV)
+
+
+@pytest.mark.parametrize("name,mode", [("ref_chem_contextpred_b32", "cbow"), ("ref_chem_contextpred_b32", "skipgram"),
+                                       ("ref_chem_contextpred_b256", "cbow")])
+def test_contextpred_vs_reference_train(name, mode):
+    """chem/pretrain_contextpred.py:43-102 run by the reference vs the mirror on the HIP GNNs, the reference's batches"""
+    fx = rf.load(name)
+    want = fx[mode]
+    nsteps = int(fx["steps"])
+    batches = [rf.batch(fx["batches"][str(i)]).to(DEV) for i in range(nsteps)]
+    ms, mc = context_models()
+    os_, oc = adam(ms.parameters()), adam(mc.parameters())
+    ms.train(), mc.train()
+    pos, neg = ptrain.contextpred_logits(ms, mc, batches[0], mode=mode)
+    torch.testing.assert_close(pos.detach().cpu(), want["pred_pos_step0"], **TOL)
+    torch.testing.assert_close(neg.detach().cpu(), want["pred_neg_step0"], **TOL)
+    out = [ptrain.chem_contextpred_step(ms, mc, os_, oc, b, mode=mode) for b in batches]
+    ref_loss = (want["loss_pos"] + want["loss_neg"]).numpy()
+    rel = np.abs(np.array([o[0] for o in out]) - ref_loss) / ref_loss
+    log(test="%s/%s/trajectory" % (name, mode), rel_err_per_step=rel.tolist())
+    assert rel[0] <= 1e-5 and (rel <= 5e-2).all(), rel
+
+
+# ============================================================================== fine-tuning
+@pytest.mark.parametrize("pooling", ["mean", "sum"])
+def test_finetune_vs_reference(pooling):
+    fx = rf.load("ref_chem_finetune_b32")
+    want = fx[pooling]
+    hchem, _ = hip_models()
+    graphs = [synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr, y=y)
+              for g, y in zip(rf.raw_graphs(fx["raw"]), fx["y"])]
+    batches = [synthetic.collate(graphs[i:i + 32]).to(DEV) for i in range(0, len(graphs), 32)]
+    def fresh():
+        torch.manual_seed(0)
+        m = hchem.GNN_graphpred(5, 300, 12, JK="last", drop_ratio=0, graph_pooling=pooling, gnn_type="gin").to(DEV)
+        m.train()
+        return m, adam(m.parameters())
+
+    model, _ = fresh()
+    with torch.no_grad():  # the prediction train() sees at its first step (train-mode BatchNorm)
+        pred0 = model(batches[0].x, batches[0].edge_index, batches[0].edge_attr, batches[0].batch)
+    torch.testing.assert_close(pred0.cpu(), want["pred_step0"], **TOL)
+    model, opt = fresh()
+    losses = [ptrain.chem_finetune_step(model, opt, b) for b in batches]
+    rel = np.abs(np.array(losses) - want["loss"].numpy()) / want["loss"].numpy()
+    log(test="finetune/%s" % pooling, rel_err_per_step=rel.tolist())
+    assert rel[0] <= 1e-5 and (rel <= TRAJ_RTOL).all(), rel
+    assert abs(ptrain.chem_eval(model, batches) - want["roc_auc"]) <= 0.02
+
+
+# ============================================================================== bio (BASELINE configs[4] shape)
+@pytest.mark.parametrize("name,types", [("ref_bio_masking_b8", ("gin", "gcn")), ("ref_bio_masking_b256", ("gin",))])
+def test_bio_masking_vs_reference(name, types):
+    """bio/model.py GNN, bio/util.py MaskEdge, bio/batch.py BatchMasking, bio/pretrain_masking.py:29-66"""
+    fx = rf.load(name)
+    _, hbio = hip_models()
+    raw = [Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr, center_node_idx=g.center_node_idx)
+           for g in rf.raw_graphs(fx["raw"], bio=True)]
+    ds = resident.ResidentDataset.from_graphs(raw, DEV)
+    bs = int(fx["batch_size"])
+    counts, local = fx["mask_counts"].tolist(), fx["mask_local"]
+    edge_off = np.asarray(fx["raw"]["edge_slices"])
+    batches, pos = [], 0
+    for s in range(0, len(raw), bs):
+        idx = []
+        for g in range(s, s + bs):
+            idx.append(local[pos:pos + counts[g]] + int(edge_off[g] - edge_off[s]))
+            pos += counts[g]
+        b = ds.collate(np.arange(s, s + bs), masked_edge_idx=torch.cat(idx))
+        ds.check(b)
+        batches.append(b)
+    b0 = batches[0]
+    for k in ("x", "edge_index", "edge_attr", "batch", "masked_edge_idx", "mask_edge_label"):
+        assert torch.equal(getattr(b0, k).cpu(), fx["batch0"][k]), k  # device collate + MaskEdge: bit-exact
+    for gt in types:
+        want = fx[gt]
+        torch.manual_seed(0)
+        model, head = hbio.GNN(5, 300, JK="last", drop_ratio=0, gnn_type=gt).to(DEV), torch.nn.Linear(300, 7).to(DEV)
+        model.train()
+        h = model(b0.x, b0.edge_index, b0.edge_attr)
+        check_rows(h, want["out_train"], "%s/%s/out_train" % (name, gt))
+        mei = b0.edge_index[:, b0.masked_edge_idx]
+        logits = head(h[mei[0]] + h[mei[1]])
+        check_rows(logits, want["logits"], "%s/%s/logits" % (name, gt))
+        label = torch.argmax(b0.mask_edge_label, dim=1)
+        loss = torch.nn.functional.cross_entropy(logits, label)
+        assert abs(loss.item() - want["loss"]) <= 1e-5 * want["loss"]
+        loss.backward()
+        named = list(model.named_parameters()) + [("head." + n, p) for n, p in head.named_parameters()]
+        log(test="%s/%s/grads" % (name, gt), rel_err_vs_f64=grad_errors(named, want["f64"]["grads"]),
+            rel_err_vs_f32=grad_errors(named, want["grads"]))
+        rf.check_params(named, want["f64"]["grads"], lambda p: p.grad, rtol=GRAD_RTOL)
+        torch.manual_seed(0)
+        models = [hbio.GNN(5, 300, JK="last", drop_ratio=0, gnn_type=gt).to(DEV), torch.nn.Linear(300, 7).to(DEV)]
+        opts = [adam(m.parameters()) for m in models]
+        out = [ptrain.bio_masking_step(models, opts, b) for b in batches]
+        ref_loss = want["train"]["loss"].numpy()
+        rel = np.abs(np.array([o[0] for o in out]) - ref_loss) / ref_loss
+        log(test="%s/%s/trajectory" % (name, gt), rel_err_per_step=rel.tolist())
+        assert rel[0] <= 1e-5 and (rel <= TRAJ_RTOL).all(), rel
+
+
+@pytest.mark.parametrize("name", ["ref_bio_contextpred_b8", "ref_bio_contextpred_b64"])
+def test_bio_contextpred_vs_reference(name):
+    """bio/pretrain_contextpred.py:39-102 run by the reference vs the mirror on the HIP bio GNNs, the reference's batches"""
+    fx = rf.load(name)
+    want = fx["cbow"]
+    nsteps = int(fx["steps"])
+    batches = [rf.batch(fx["batches"][str(i)]).to(DEV) for i in range(nsteps)]
+    ms, mc = context_models("bio")
+    os_, oc = adam(ms.parameters()), adam(mc.parameters())
+    pos, neg = ptrain.contextpred_logits(ms, mc, batches[0])
+    torch.testing.assert_close(pos.detach().cpu(), want["pred_pos_step0"], rtol=1e-4, atol=2e-4)
+    out = [ptrain.bio_contextpred_step(ms, mc, os_, oc, b) for b in batches]
+    ref_loss = (want["loss_pos"] + want["loss_neg"]).numpy()
+    rel = np.abs(np.array([o[0] for o in out]) - ref_loss) / ref_loss
+    log(test="%s/trajectory" % name, rel_err_per_step=rel.tolist())
+    assert rel[0] <= 1e-5 and (rel <= 5e-2).all(), rel
