@@ -617,8 +617,11 @@ int launch_aggregate_dma_pre(const float* z, int64_t ldz, const float* coef, int
                              int64_t ldo, int64_t n, int64_t dim, hipStream_t st) {
   const int nrow = (int)ceil_div(kDmaG * (dim / 4), kWave);
   const bool small_ld = ldz * 4 * kDmaG < (1ll << 31);
-  if (nrow == 10 && small_ld)
+  if (nrow == 10 && small_ld) {
+    if (env_int("PGNN_DMA_POL", (int64_t)n * dim * 4 >= (128ll << 20) ? 3 : 0) == 3)
+      return launch_aggregate_dma_p<true, 2, 10, true, 3>(z, ldz, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, coef, relu);
     return launch_aggregate_dma_p<true, 2, 10, true>(z, ldz, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, coef, relu);
+  }
   return launch_aggregate_dma_p<true, 2, 0, true>(z, ldz, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, coef, relu);
 }
 
@@ -632,15 +635,22 @@ int launch_aggregate_dma(const float* x, int64_t ldx, const int32_t* ptr, const 
   if (env_int("PGNN_DMA_P", 2) == 1) return launch_aggregate_dma_p<TABLE, 1, 0>(PGNN_DMA_ARGS);
   if (!small_ld || env_int("PGNN_DMA_GENERIC", 0)) return launch_aggregate_dma_p<TABLE, 2, 0>(PGNN_DMA_ARGS);
   if (nrow == 10 && env_int("PGNN_DMA_P", 2) == 3) return launch_aggregate_dma_p<TABLE, 3, 10>(PGNN_DMA_ARGS);
-  if (nrow == 10 && TABLE) {  // policy A/B on the production instantiation only
-    switch (env_int("PGNN_DMA_POL", 0)) {
-      case 1: return launch_aggregate_dma_p<TABLE, 2, 10, false, 1>(PGNN_DMA_ARGS);
-      case 2: return launch_aggregate_dma_p<TABLE, 2, 10, false, 2>(PGNN_DMA_ARGS);
-      case 3: return launch_aggregate_dma_p<TABLE, 2, 10, false, 3>(PGNN_DMA_ARGS);
-      case 4: return launch_aggregate_dma_p<TABLE, 2, 10, false, 4>(PGNN_DMA_ARGS);
-      case 7: return launch_aggregate_dma_p<TABLE, 2, 10, false, 7>(PGNN_DMA_ARGS);
-      case 8: return launch_aggregate_dma_p<TABLE, 2, 10, false, 8>(PGNN_DMA_ARGS);
-      default: break;
+  // Streaming hint.  When x and out together exceed the 256 MB Infinity Cache nothing this launch touches can be
+  // re-used from cache by a later one: rows are then loaded and stored non-temporally (POL 3), which measured
+  // 229.8 -> 214.3 us on the roofline batch (tools/agg_sweep.py; nt loads alone 224.9, nt stores alone 217.9, loader
+  // priority 222.1).  Smaller batches keep the default policy so the next kernel finds the rows in L2 / MALL.
+  const int pol = env_int("PGNN_DMA_POL", (int64_t)n * dim * 4 >= (128ll << 20) ? 3 : 0);
+  if (nrow == 10) {
+    if (pol == 3) return launch_aggregate_dma_p<TABLE, 2, 10, false, 3>(PGNN_DMA_ARGS);
+    if (TABLE) {  // further A/B variants and the instrumented build: production instantiation only
+      switch (pol) {
+        case 1: return launch_aggregate_dma_p<TABLE, 2, 10, false, 1>(PGNN_DMA_ARGS);
+        case 2: return launch_aggregate_dma_p<TABLE, 2, 10, false, 2>(PGNN_DMA_ARGS);
+        case 4: return launch_aggregate_dma_p<TABLE, 2, 10, false, 4>(PGNN_DMA_ARGS);
+        case 7: return launch_aggregate_dma_p<TABLE, 2, 10, false, 7>(PGNN_DMA_ARGS);
+        case 8: return launch_aggregate_dma_p<TABLE, 2, 10, false, 8>(PGNN_DMA_ARGS);
+        default: break;
+      }
     }
   }
   switch (nrow) {

@@ -265,26 +265,33 @@ class ResidentLoader:
         self.drop_last = drop_last
         self.epoch = 0
 
+    def _keeps_tail(self):
+        """the last, short global batch is used iff drop_last is off AND every rank gets at least one graph of it:
+        a rank with an empty share would run one step fewer than its peers and leave their all-reduce without a
+        partner (the job would hang at the end of the epoch)"""
+        tail = len(self.ds) % self.batch_size
+        return tail != 0 and not self.drop_last and tail >= self.world
+
     def __len__(self):
-        n = len(self.ds) // self.batch_size
-        return n if self.drop_last or len(self.ds) % self.batch_size == 0 else n + 1
+        return len(self.ds) // self.batch_size + (1 if self._keeps_tail() else 0)
 
     def batch_ids(self, epoch=None):
-        """list of this rank's graph-id arrays for one epoch"""
+        """list of this rank's graph-id arrays for one epoch -- the same number of entries on every rank"""
         epoch = self.epoch if epoch is None else epoch
         order = np.arange(len(self.ds), dtype=np.int64)
         if self.shuffle:
             np.random.default_rng([self.seed, epoch]).shuffle(order)
+        if self.batch_size < self.world:
+            raise ValueError("global batch_size %d < world_size %d" % (self.batch_size, self.world))
         out = []
         for s in range(0, len(order), self.batch_size):
             glob = order[s:s + self.batch_size]
-            if glob.size < self.batch_size and self.drop_last:
+            if glob.size < self.batch_size and not self._keeps_tail():
                 break
             base, rem = divmod(glob.size, self.world)
             lo = self.rank * base + min(self.rank, rem)
             hi = lo + base + (1 if self.rank < rem else 0)
-            if hi > lo:
-                out.append(glob[lo:hi])
+            out.append(glob[lo:hi])
         return out
 
     def __iter__(self):

@@ -627,22 +627,50 @@ def chem_gin_layer(x, conv, bn, graph, relu, drop_p=0.0):
 
 
 # ------------------------------------------------------------------------------------ whole chem GIN network
-# Direct gradient deposit.  A custom Function with 47 tensor inputs costs ~150 us per step in torch's own
+# Direct gradient deposit (OPT-IN).  A custom Function with 47 tensor inputs costs ~150 us per step in torch's own
 # bookkeeping (input wrapping in apply(), 47 AccumulateGrad nodes; tools/autograd_floor.py: 306 vs 150 us), more
-# than the library spends launching the whole forward.  The one-call networks therefore take only the two atom
-# embedding tables through autograd (that keeps the output attached to the graph) and write the other parameters'
-# gradients into ``.grad`` themselves: assign when it is None, add otherwise -- what AccumulateGrad does.  What this
-# gives up: tensor hooks on those parameters and ``torch.autograd.grad(..., those parameters)`` do not see the
-# gradients (torch DDP relies on such hooks; ``parallel.AllReduceOptimizers`` does not).  PGNN_DIRECT_GRADS=0
-# routes everything through autograd again.
-_DIRECT_GRADS = os.environ.get("PGNN_DIRECT_GRADS", "1") != "0"
+# than the library spends launching the whole forward.  With the switch on, the one-call networks take only the two
+# atom embedding tables through autograd (that keeps the output attached to the graph) and write the other
+# parameters' gradients into ``.grad`` themselves: assign when it is None, add otherwise -- what AccumulateGrad does.
+# What this gives up: tensor hooks on those parameters and ``torch.autograd.grad(..., those parameters)`` do not see
+# the gradients (torch DDP relies on such hooks; ``parallel.AllReduceOptimizers`` does not).  It is therefore OFF by
+# default -- the drop-in classes keep ordinary autograd semantics -- and is switched on by ``set_direct_grads(True)``
+# (bench.py and the train-step mirrors' callers do) or PGNN_DIRECT_GRADS=1.  Even when on, a network whose
+# parameters carry hooks (DDP, user hooks) takes the autograd path.
+_DIRECT_GRADS = os.environ.get("PGNN_DIRECT_GRADS", "0") == "1"
+
+
+def set_direct_grads(on):
+    """switch direct gradient deposit of the one-call networks on / off; returns the previous setting"""
+    global _DIRECT_GRADS
+    prev, _DIRECT_GRADS = _DIRECT_GRADS, bool(on)
+    return prev
+
+
+def direct_grads_enabled():
+    return _DIRECT_GRADS
+
+
+def _use_direct(params):
+    if not (_DIRECT_GRADS and torch.is_grad_enabled()):
+        return False
+    for p in params:
+        if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
+            return False
+    return True
+
+
+def _private_layers(shared):
+    """a backward writes gradient pointers into the layer array: work on a copy, the cached plan array is shared by
+    every forward of the model (re-entrancy; two graphs of one model alive at once)"""
+    return type(shared).from_buffer_copy(shared)
 
 
 def _deposit_grads(params, versions, grads):
     acc_dst, acc_src = [], []
-    for p, v, g in zip(params, versions, grads):
-        if p._version != v:
-            raise RuntimeError("a parameter of the network was modified in place between forward and backward")
+    for p, (v, ptr), g in zip(params, versions, grads):
+        if p._version != v or p.data_ptr() != ptr:  # in-place update, or `.data` re-assigned (no version bump)
+            raise RuntimeError("a parameter of the network was modified between forward and backward")
         if not p.requires_grad:
             continue
         if p.grad is None:
@@ -726,7 +754,7 @@ class ChemGINStack(Function):
             raise IndexError("embedding index out of range")
         if direct is not None:
             ctx.save_for_backward(acts, hid, stats)
-            ctx.direct, ctx.versions = params, [p._version for p in params]
+            ctx.direct, ctx.versions = params, [(p._version, p.data_ptr()) for p in params]
         else:
             ctx.save_for_backward(acts, hid, stats, *params)
             ctx.direct = None
@@ -746,7 +774,7 @@ class ChemGINStack(Function):
         sizes, shapes, byte_off = _stack_grad_layout(L, dim, rows1, rows2)
         flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
         base = flat.data_ptr()
-        layers = ctx.layers
+        layers = _private_layers(ctx.layers)
         for l in range(L):
             s, o = layers[l], byte_off[l]
             s.demb, s.dw1, s.db1, s.dw2, s.db2, s.dgamma, s.dbeta = [base + b for b in o]
@@ -827,7 +855,7 @@ def chem_gin_stack(owner, x_idx, graph, x_embedding1, x_embedding2, convs, bns, 
         conv.edge_embedding1.weight, conv.edge_embedding2.weight, conv.mlp[0].weight, conv.mlp[0].bias,
         conv.mlp[2].weight, conv.mlp[2].bias, bn.weight, bn.bias)]
     seed = dropout_seed() if drop_p > 0 else 0
-    if _DIRECT_GRADS and torch.is_grad_enabled() and x_embedding1.weight.requires_grad:
+    if x_embedding1.weight.requires_grad and _use_direct(flat):
         return ChemGINStack.apply(x_idx, graph, (training, _bn_meta(bns), drop_p, seed, plan, flat),
                                   x_embedding1.weight, x_embedding2.weight)
     return ChemGINStack.apply(x_idx, graph, (training, _bn_meta(bns), drop_p, seed, plan, None),
@@ -897,7 +925,7 @@ class ChemLinStack(Function):
             raise IndexError("embedding index out of range")
         saved = [h0, acts, stats] + ([norms] if norms is not None else [])
         if direct is not None:
-            ctx.direct, ctx.versions = params, [p._version for p in params]
+            ctx.direct, ctx.versions = params, [(p._version, p.data_ptr()) for p in params]
         else:
             saved += list(params)
             ctx.direct = None
@@ -919,7 +947,7 @@ class ChemLinStack(Function):
         sizes, shapes, byte_off = _lin_grad_layout(L, dim, rows1, rows2)
         flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
         base = flat.data_ptr()
-        layers = ctx.layers
+        layers = _private_layers(ctx.layers)
         for l in range(L):
             s, o = layers[l], byte_off[l]
             s.demb, s.dw1, s.db1, s.dgamma, s.dbeta = [base + b for b in o]
@@ -949,7 +977,7 @@ def chem_lin_stack(owner, kind, x_idx, graph, x_embedding1, x_embedding2, convs,
     flat = [t for conv, bn in zip(convs, bns) for t in (
         conv.edge_embedding1.weight, conv.edge_embedding2.weight, conv.linear.weight, conv.linear.bias, bn.weight, bn.bias)]
     seed = dropout_seed() if drop_p > 0 else 0
-    if _DIRECT_GRADS and torch.is_grad_enabled() and x_embedding1.weight.requires_grad:
+    if x_embedding1.weight.requires_grad and _use_direct(flat):
         return ChemLinStack.apply(x_idx, graph, (kind, training, _bn_meta(bns), drop_p, seed, plan, flat),
                                   x_embedding1.weight, x_embedding2.weight)
     return ChemLinStack.apply(x_idx, graph, (kind, training, _bn_meta(bns), drop_p, seed, plan, None),

@@ -199,6 +199,28 @@ def test_resident_loader_sharding_and_mask_counts():
     ns = [1, 6, 7, 13, 14, 20, 26, 27, 60, 1000]
     assert resident.mask_counts(ns, 0.15).tolist() == [int(n * 0.15 + 1) for n in ns]
 
+    # a tail smaller than the world size would leave some ranks without a share: every rank must still run the SAME
+    # number of steps (one all-reduce per step), so that global batch is dropped on all of them, and len() agrees
+    class Tail:
+        def __len__(self):
+            return 1001
+
+    loaders = [resident.ResidentLoader(Tail(), 100, shuffle=True, seed=1, rank=r, world_size=4) for r in range(4)]
+    counts = [len(ld.batch_ids(epoch=0)) for ld in loaders]
+    assert counts == [10, 10, 10, 10] and all(len(ld) == 10 for ld in loaders)
+    assert all(ids.size > 0 for ld in loaders for ids in ld.batch_ids(epoch=0))
+    loaders = [resident.ResidentLoader(Tail(), 100, shuffle=False, rank=r, world_size=1) for r in range(1)]
+    assert len(loaders[0]) == 11 and loaders[0].batch_ids()[-1].tolist() == [1000]
+
+    class Tail6:
+        def __len__(self):
+            return 1006
+
+    loaders = [resident.ResidentLoader(Tail6(), 100, shuffle=False, rank=r, world_size=4) for r in range(4)]
+    assert [len(ld.batch_ids()) for ld in loaders] == [11] * 4 and [ld.batch_ids()[-1].size for ld in loaders] == [2, 2, 1, 1]
+    with pytest.raises(ValueError):
+        resident.ResidentLoader(Tail(), 2, rank=0, world_size=4).batch_ids()
+
 
 def test_direct_gradient_deposit_semantics_on_cpu():
     """ops._deposit_grads is what replaces AccumulateGrad for the one-call networks: assign when .grad is None,
@@ -206,7 +228,7 @@ def test_direct_gradient_deposit_semantics_on_cpu():
     from pretrain_gnns_amd import ops
     ps = [torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2, 2)), torch.nn.Parameter(torch.zeros(1))]
     ps[2].requires_grad_(False)
-    versions = [p._version for p in ps]
+    versions = [(p._version, p.data_ptr()) for p in ps]
     g = [torch.ones(3), torch.full((2, 2), 2.0), torch.ones(1)]
     ops._deposit_grads(ps, versions, g)
     assert ps[0].grad is g[0] and ps[1].grad is g[1] and ps[2].grad is None
@@ -214,5 +236,17 @@ def test_direct_gradient_deposit_semantics_on_cpu():
     assert ps[0].grad.tolist() == [2.0, 2.0, 2.0] and ps[1].grad.tolist() == [[3.0, 3.0], [3.0, 3.0]]
     with torch.no_grad():
         ps[0].add_(1.0)
-    with pytest.raises(RuntimeError, match="modified in place"):
+    with pytest.raises(RuntimeError, match="modified between forward and backward"):
         ops._deposit_grads(ps, versions, g)
+    versions = [(p._version, p.data_ptr()) for p in ps]
+    ps[1].data = ps[1].data.clone()  # storage re-assigned: no version bump, caught through the data pointer
+    with pytest.raises(RuntimeError, match="modified between forward and backward"):
+        ops._deposit_grads(ps, versions, g)
+    assert ops.direct_grads_enabled() is False  # opt-in: the drop-in classes keep plain autograd semantics by default
+    hooked = torch.nn.Parameter(torch.zeros(2))
+    hooked.register_hook(lambda grad: grad)
+    prev = ops.set_direct_grads(True)
+    try:
+        assert ops._use_direct([torch.nn.Parameter(torch.zeros(2))]) and not ops._use_direct([hooked])
+    finally:
+        ops.set_direct_grads(prev)

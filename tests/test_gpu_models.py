@@ -493,8 +493,21 @@ def test_direct_gradient_deposit_equals_autograd_accumulation(gnn_type, monkeypa
     out = a(d.x, d.edge_index, d.edge_attr)
     with torch.no_grad():
         a.batch_norms[0].weight.mul_(1.5)
-    with pytest.raises(RuntimeError, match="modified in place"):
+    with pytest.raises(RuntimeError, match="modified between forward and backward"):
         (out * w).sum().backward()
+    a.zero_grad()
+    out = a(d.x, d.edge_index, d.edge_attr)
+    a.batch_norms[0].weight.data = a.batch_norms[0].weight.data.clone()  # re-assigned storage: no version bump
+    with pytest.raises(RuntimeError, match="modified between forward and backward"):
+        (out * w).sum().backward()
+    # a parameter with a hook sends the whole network through autograd, and the hook fires
+    a.zero_grad()
+    seen = []
+    handle = a.batch_norms[1].bias.register_hook(lambda g: seen.append(g.shape))
+    (a(d.x, d.edge_index, d.edge_attr) * w).sum().backward()
+    handle.remove()
+    assert seen == [a.batch_norms[1].bias.shape]
+    assert ops.set_direct_grads(False) is True and ops.direct_grads_enabled() is False
 
 
 def test_large_batch_properties():
