@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-hipgraph", action="store_true")
     ap.add_argument("--no-loader", action="store_true", help="skip the device-side loader leg")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the context-prediction (BASELINE configs[2]) and bio masking (configs[4]) legs")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the two roofline kernels (for `rocprofv3 --kernel-trace --stats`: the profile then "
                          "holds exactly the launches `roofline.achieved` is computed from)")
@@ -240,6 +242,163 @@ def roofline_mlp(dev, rows):
             "rows": rows}
 
 
+def host_cpu_model():
+    """the `model name` line of /proc/cpuinfo (BASELINE.md asks for the CPU next to the core count)"""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_sample(step_fn, edges, seconds, max_steps=200):
+    step_fn()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step_fn()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds or n >= max_steps:
+            return edges * n / el, n, el
+
+
+def contextpred_leg(dev, args, steps_n, with_cpu):
+    """BASELINE configs[2]: chem/pretrain_contextpred.py train step (cbow, mean context pooling, 1 negative) at
+    batch_size 256 on one GPU -- 5-layer substructure GNN + 3-layer context GNN, negative-sampling dot-product loss,
+    two Adam -- with the transform IN the timed loop: every step extracts the substructure / context pair of 256 new
+    molecules on the device (ExtractSubstructureContextPair(5, 4, 7) + BatchSubstructContext, csrc/loader.hip).
+    edges = directed edges of the 256 source molecules per step (the unit of the headline metric) next to the edges the
+    two GNNs actually traverse."""
+    import numpy as np
+    from pretrain_gnns_amd import train as steps
+    from pretrain_gnns_amd.chem import model as hmodel
+    from pretrain_gnns_amd.data import resident, synthetic
+
+    rng = np.random.default_rng(4321)
+    graphs = [synthetic.zinc_like_graph(rng) for _ in range(4096)]
+    ds = resident.ResidentDataset.from_graphs(graphs, dev)
+    loader = resident.ResidentLoader(ds, args.graphs_per_gpu, shuffle=True, seed=2, drop_last=True, substruct_context=(5, 4, 7))
+    torch.manual_seed(0)
+    ms_, mc_ = hmodel.GNN(5, 300, gnn_type="gin").to(dev), hmodel.GNN(3, 300, gnn_type="gin").to(dev)
+    os_, oc_ = [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0, fused=True) for m in (ms_, mc_)]
+    ms_.train(), mc_.train()
+    mol_edges = ds._edges  # directed edges per source molecule (host copy of the slice differences)
+    src_edges = gnn_edges = done = 0
+    t0 = None
+    while done < steps_n + 5:
+        for ids, batch in zip(loader.batch_ids(loader.epoch), loader):
+            if done == 5:
+                torch.cuda.synchronize()
+                t0, src_edges, gnn_edges = time.perf_counter(), 0, 0
+            loss, acc = steps.chem_contextpred_step(ms_, mc_, os_, oc_, batch)
+            src_edges += int(mol_edges[ids].sum())
+            gnn_edges += batch.edge_index_substruct.size(1) + batch.edge_index_context.size(1)
+            done += 1
+            if done >= steps_n + 5:
+                break
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": "chem/pretrain_contextpred.py train step (cbow, mean pooling, 1 negative), substructure GNN 5 layers + context "
+                       "GNN 3 layers, emb_dim 300, batch_size %d, device-side ExtractSubstructureContextPair(5,4,7) in the loop "
+                       "(BASELINE configs[2])" % args.graphs_per_gpu,
+           "ms_per_step": round(dt / steps_n * 1e3, 4), "edges_per_s": round(src_edges / dt, 1),
+           "gnn_edges_per_s": round(gnn_edges / dt, 1), "graphs_per_s": round(args.graphs_per_gpu * steps_n / dt, 1),
+           "last_loss": round(float(loss), 5),
+           "roofline": "same aggregation kernel as the headline (`roofline`): the substructure / context batches are chem graphs"}
+    if with_cpu:
+        from oracle import chem as ochem
+        from oracle import steps as osteps
+        cores = usable_cores()
+        torch.set_num_threads(cores)
+        hb = synthetic.chem_contextpred_batch(args.graphs_per_gpu, seed=0)
+        torch.manual_seed(0)
+        a, b = ochem.GNN(5, 300), ochem.GNN(3, 300)
+        oa, ob = torch.optim.Adam(a.parameters(), lr=1e-3), torch.optim.Adam(b.parameters(), lr=1e-3)
+        rng0 = np.random.default_rng(0)  # chem_contextpred_batch(seed=0) draws its molecules from this same stream
+        e_src = int(round(float(np.mean(mol_edges)) * args.graphs_per_gpu))
+        rate, n, el = _cpu_sample(lambda: osteps.chem_contextpred_step(a, b, oa, ob, hb), e_src, max(2.0, args.cpu_seconds / 3))
+        out["cpu_baseline"] = {"value": round(rate, 1), "unit": "edges/s", "cores": cores, "cpu": host_cpu_model(), "kind": "port",
+                               "sample": "%d context-prediction train steps of the torch-CPU oracle on one %d-molecule batch "
+                                         "(host-built transform outside the timed region), %.1f s" % (n, args.graphs_per_gpu, el)}
+    return out
+
+
+def bio_leg(dev, args, steps_n, with_cpu):
+    """BASELINE configs[4] shape on one GPU: bio/pretrain_masking.py train step, 5-layer bio GIN (9-dim edge attributes,
+    E' ~ 19 N), 256 PPI-ego-shaped graphs per GPU, device-side collate + MaskEdge in the loop; and the bio aggregation
+    (neighbour sum + edge-feature product = one GINConv message/aggregate) alone on a batch that exceeds the Infinity
+    Cache, against SURVEY 8d's algorithmic bytes 3604 N + 40 E."""
+    import numpy as np
+    from pretrain_gnns_amd import ops
+    from pretrain_gnns_amd import train as steps
+    from pretrain_gnns_amd.bio import model as hbio
+    from pretrain_gnns_amd.data import resident, synthetic
+
+    rng = np.random.default_rng(99)
+    graphs = [synthetic.ppi_like_graph(rng) for _ in range(1024)]
+    ds = resident.ResidentDataset.from_graphs(graphs, dev)
+    loader = resident.ResidentLoader(ds, args.graphs_per_gpu, shuffle=True, seed=3, mask_rate=0.15, drop_last=True)
+    torch.manual_seed(0)
+    mods = [hbio.GNN(5, 300, gnn_type="gin").to(dev), torch.nn.Linear(300, 7).to(dev)]
+    opts = [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0, fused=True) for m in mods]
+    for m in mods:
+        m.train()
+    edges = done = 0
+    t0 = None
+    while done < steps_n + 3:
+        for batch in loader:
+            if done == 3:
+                torch.cuda.synchronize()
+                t0, edges = time.perf_counter(), 0
+            loss, acc = steps.bio_masking_step(mods, opts, batch)
+            edges += batch.edge_index.size(1)
+            done += 1
+            if done >= steps_n + 3:
+                break
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": "bio/pretrain_masking.py train step, 5-layer bio GIN emb_dim=300, batch_size %d PPI-ego-shaped graphs per GPU, "
+                       "device-side collate + MaskEdge in the loop (BASELINE configs[4] shape)" % args.graphs_per_gpu,
+           "ms_per_step": round(dt / steps_n * 1e3, 4), "edges_per_s": round(edges / dt, 1),
+           "edges_per_step": int(edges / steps_n), "last_loss": round(float(loss), 5)}
+    # aggregation alone at a cache-exceeding batch: x [N,300] -> [N,600] = [sum_j x_j + x_i | sum_e enc(e) + enc(loop)]
+    big = ds.collate(np.arange(4096) % len(graphs))
+    n, e = big.x.size(0), big.edge_index.size(1)
+    graph = ops.build_bio_graph(big.edge_index, big.edge_attr, n, gcn=False)
+    x = torch.randn(n, 300, device=dev)
+    enc_w, enc_b = torch.randn(300, 9, device=dev), torch.randn(300, device=dev)
+
+    def launch():
+        with torch.no_grad():
+            ops.BioAggregate.apply(x, enc_w, enc_b, graph)
+
+    ms, per, iters = steady_state_ms(launch, iters=30)
+    alg = 3604.0 * n + 40.0 * e
+    gbs = alg / (ms * 1e-3) / 1e9
+    out["roofline"] = {"bound": "hbm", "kernel": "bio GINConv aggregate = pgnn_neighbor_sum + pgnn_rowfeat_matmul_fwd", "achieved": round(gbs, 1),
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                       "ms_per_launch": round(ms, 4), "ms_per_launch_std": round(float(per.std()), 4),
+                       "algorithmic_bytes_per_launch": int(alg), "nodes": n, "edges": e,
+                       "note": "3604 N + 40 E (SURVEY 8d) counts the fp32 [E,9] attributes a layer would read; this implementation reads "
+                               "them once per batch (per-node feature sums), so a layer moves 3600 N + 4 E + 40 N bytes"}
+    if with_cpu:
+        from oracle import bio as obio
+        from oracle import steps as osteps
+        cores = usable_cores()
+        torch.set_num_threads(cores)
+        hb = synthetic.bio_masking_batch(64, seed=0)
+        torch.manual_seed(0)
+        om = [obio.GNN(5, 300), torch.nn.Linear(300, 7)]
+        oo = [torch.optim.Adam(m.parameters(), lr=1e-3) for m in om]
+        rate, k, el = _cpu_sample(lambda: osteps.bio_masking_step(om, oo, hb), hb.edge_index.size(1), max(2.0, args.cpu_seconds / 3), 50)
+        out["cpu_baseline"] = {"value": round(rate, 1), "unit": "edges/s", "cores": cores, "cpu": host_cpu_model(), "kind": "port",
+                               "sample": "%d bio masking train steps of the torch-CPU oracle on one 64-graph batch (%d edges), %.1f s"
+                                         % (k, hb.edge_index.size(1), el)}
+    return out
+
+
 def usable_cores():
     """host cores this process may really use: min(affinity, cgroup cpu quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -338,7 +497,7 @@ def cpu_baseline(graphs, seconds):
         r, n2, _, el2 = _cpu_rate(g, t, seconds / 4)
         also[name] = {"edges_per_s": round(r, 1), "steps": n2, "seconds": round(el2, 1)}
     torch.set_num_threads(cores)
-    return {"value": round(rate, 1), "unit": "edges/s", "cores": cores, "kind": "port",
+    return {"value": round(rate, 1), "unit": "edges/s", "cores": cores, "cpu": host_cpu_model(), "kind": "port",
             "sample": "%d train steps (fwd+bwd+3xAdam) of the torch-CPU oracle on one %d-graph batch (%d edges), %.1f s"
                       % (n, graphs, e, el), "also": also}
 
@@ -395,6 +554,7 @@ def main():
     elapsed = time.perf_counter() - t0
     gc.enable()
 
+    comm = parallel.comm_report(opts) if dist.is_initialized() else {"initialized": False, "world": 1}
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     etot = torch.tensor([float(edges_local)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -416,6 +576,7 @@ def main():
                        "parallelism": "dp%d" % world, "last_loss": round(float(loss), 5),
                        "adam": "foreach" if args.foreach_adam else "fused", "metrics_readback": args.readback,
                        "direct_grads": True},
+            "comm": comm,
         }
         if world == 1:
             res["forward_only"] = forward_only(dev, mods, batch, max(args.steps, 20))
@@ -428,6 +589,9 @@ def main():
         if not args.no_roofline:
             res["roofline"] = roofline_aggregation(dev, args.roofline_graphs)
             res["roofline_mlp"] = roofline_mlp(dev, 262144)
+        if world == 1 and not args.no_extra_configs:
+            res["contextpred"] = contextpred_leg(dev, args, max(args.steps // 2, 20), not args.no_cpu_baseline)
+            res["bio_masking"] = bio_leg(dev, args, max(args.steps // 5, 10), not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.graphs_per_gpu, args.cpu_seconds)
         print(json.dumps(res), flush=True)

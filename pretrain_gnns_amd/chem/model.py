@@ -168,7 +168,8 @@ class GNN(torch.nn.Module):
 
         # one structure build for all layers, forward and backward
         graph = ops.build_chem_graph(edge_index, edge_attr, x.size(0), gcn=(self.gnn_type == "gcn"))
-        fused = self.gnn_type == "gin" and type(self.gnns[0]) is GINConv and self.batch_norms[0].affine
+        exact_bn = getattr(self.batch_norms[0], "pgnn_exact", False)  # parallel.use_exact_batchnorm: per-layer path
+        fused = self.gnn_type == "gin" and type(self.gnns[0]) is GINConv and self.batch_norms[0].affine and not exact_bn
         # F.dropout of the reference (chem/model.py:271-275) is fused into the BatchNorm(+ReLU) pass
         drop_p = float(self.drop_ratio) if (self.training and self.drop_ratio > 0) else 0.0
         if fused and self.JK == "last" and _STACK_CALL and drop_p < 1.0:
@@ -177,7 +178,7 @@ class GNN(torch.nn.Module):
                                       drop_p)
         lin_kind = {GCNConv: 1, GraphSAGEConv: 2}.get(type(self.gnns[0]), 0)
         if (lin_kind and self.JK == "last" and _STACK_CALL and drop_p < 1.0 and self.batch_norms[0].affine
-                and self.gnns[0].linear.bias is not None):
+                and self.gnns[0].linear.bias is not None and not exact_bn):
             return ops.chem_lin_stack(self, lin_kind, x, graph, self.x_embedding1, self.x_embedding2, self.gnns,
                                       self.batch_norms, drop_p)
         h = ops.Embed.apply(x, self.x_embedding1.weight, self.x_embedding2.weight)

@@ -450,6 +450,9 @@ def dropout_seed():
 def batch_norm(x, bn, relu, drop_p=0.0):
     """apply a torch.nn.BatchNorm1d module's parameters/buffers with the HIP kernels; ``drop_p`` > 0
     fuses the inverted dropout that follows it in GNN.forward."""
+    if getattr(bn, "pgnn_exact", False):  # parallel.ExactBatchNorm1d: statistics all-reduced over the DP ranks
+        y = bn(x, relu=relu)
+        return torch.nn.functional.dropout(y, drop_p, training=True) if drop_p > 0 else y
     training = bn.training or bn.running_mean is None
     momentum = 0.0 if bn.momentum is None else bn.momentum
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:

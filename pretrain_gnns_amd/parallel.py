@@ -6,7 +6,10 @@ the path shards with no data-path exchange: every rank (one process per GPU) col
 graphs, runs forward/backward locally, and the only collective is ONE sum-all-reduce per step of
 a single flat fp32 bucket holding every gradient (GNN 7.43 MB + heads; RCCL over xGMI picks
 direct reduce-scatter/all-gather on the fully connected 8-GPU node), followed by identical Adam
-updates on every rank.  BatchNorm statistics stay per rank (standard DDP semantics).
+updates on every rank.  BatchNorm statistics stay per rank by default (standard DDP semantics);
+``use_exact_batchnorm(model)`` switches the outer BatchNorm layers to statistics all-reduced over the ranks
+(sum x, sum x^2: two more tiny collectives per layer and direction), which together with
+``weight_fn = local_M / global_M`` makes the N-rank step EXACTLY the single-process step on the global batch.
 
 The layer is model-agnostic (any nn.Module, any torch.distributed backend), which is how the
 world_size-2 ``gloo`` tests on CPU cover it.
@@ -113,6 +116,115 @@ class _Wrapped:
 
     def __getattr__(self, name):
         return getattr(self.opt, name)
+
+
+class _ExactBN(torch.autograd.Function):
+    """y = relu?((x - mean) * invstd * gamma + beta) with mean / biased variance over the rows of ALL ranks."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu, stats_out):
+        n_local = x.size(0)
+        xd = x.double()
+        packed = torch.cat([xd.sum(0), (xd * xd).sum(0), xd.new_tensor([float(n_local)])])
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+        d = x.size(1)
+        n = float(packed[-1].item())
+        mean = packed[:d] / n
+        var = (packed[d:2 * d] / n - mean * mean).clamp_(min=0.0)
+        invstd = (var + eps).rsqrt()
+        xhat = ((xd - mean) * invstd).to(x.dtype)
+        y = xhat * gamma + beta
+        if relu:
+            y = torch.relu(y)
+        stats_out.append((mean.to(x.dtype), var.to(x.dtype), n))
+        ctx.save_for_backward(xhat, gamma, invstd.to(x.dtype), y if relu else x.new_empty(0))
+        ctx.relu, ctx.n = bool(relu), n
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xhat, gamma, invstd, y = ctx.saved_tensors
+        if ctx.relu:
+            dy = dy * (y > 0).to(dy.dtype)
+        dyd, xh = dy.double(), xhat.double()
+        s_dy, s_dyx = dyd.sum(0), (dyd * xh).sum(0)
+        dgamma, dbeta = s_dyx.to(dy.dtype), s_dy.to(dy.dtype)  # local parts: the gradient bucket sums them over ranks
+        packed = torch.cat([s_dy, s_dyx])
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+        d = dy.size(1)
+        g_dy, g_dyx = packed[:d] / ctx.n, packed[d:] / ctx.n
+        dx = ((dyd - g_dy - xh * g_dyx) * (gamma.double() * invstd.double())).to(dy.dtype)
+        return dx, dgamma, dbeta, None, None, None
+
+
+class ExactBatchNorm1d(torch.nn.BatchNorm1d):
+    """BatchNorm1d whose training-mode statistics span the rows of every data-parallel rank (SURVEY 8e "exact
+    mode").  Same parameters, buffers and state-dict keys as ``torch.nn.BatchNorm1d``; eval mode is the ordinary
+    running-statistics form.  Off the tuned path: the reductions are torch GPU ops and the GNN takes its per-layer
+    route (no one-call network) while such modules are installed.
+
+    Loss weighting: with shared statistics the backward of one rank's rows carries terms of every rank's loss, so a
+    per-rank loss share (local_M / global_M for the masked-atom mean) must multiply the LOSS before ``backward()``
+    and the bucket must then plainly sum (``AllReduceOptimizers(..., weight_fn=lambda: 1.0)``); scaling finished
+    gradients (``weight_fn`` = the share) is exact only with per-rank statistics."""
+
+    pgnn_exact = True
+
+    def forward(self, x, relu=False):
+        if not (self.training or self.running_mean is None):
+            y = torch.nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, False, 0.0, self.eps)
+            return torch.relu(y) if relu else y
+        stats = []
+        y = _ExactBN.apply(x, self.weight, self.bias, self.eps, relu, stats)
+        if self.track_running_stats and self.running_mean is not None:
+            mean, var, n = stats[0]
+            self.num_batches_tracked.add_(1)
+            m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+            with torch.no_grad():
+                self.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                self.running_var.mul_(1 - m).add_(var * (n / max(n - 1.0, 1.0)), alpha=m)
+        return y
+
+
+def use_exact_batchnorm(module):
+    """replace every ``torch.nn.BatchNorm1d`` below ``module`` by an ``ExactBatchNorm1d`` that shares its parameter
+    and buffer tensors (optimizers built before or after keep working; state dicts are unchanged)"""
+    for name, child in list(module.named_children()):
+        if type(child) is torch.nn.BatchNorm1d:
+            new = ExactBatchNorm1d(child.num_features, eps=child.eps, momentum=child.momentum, affine=child.affine,
+                                   track_running_stats=child.track_running_stats)
+            new._parameters, new._buffers, new.training = child._parameters, child._buffers, child.training
+            setattr(module, name, new)
+        else:
+            use_exact_batchnorm(child)
+    return module
+
+
+def comm_report(optimizers, iters=10):
+    """what the collective of a step costs here: backend, world size, bucket size and the HIP-event time of one
+    flat-bucket all-reduce (bench.py prints this so that a scaling run shows RCCL really saw N ranks)"""
+    if not dist.is_initialized():
+        return {"initialized": False, "world": 1}
+    bucket = optimizers.bucket if isinstance(optimizers, AllReduceOptimizers) else None
+    out = {"initialized": True, "backend": dist.get_backend(), "world": dist.get_world_size(), "rank": dist.get_rank(),
+           "bucket_bytes": bucket.nbytes if bucket is not None else None}
+    if bucket is not None and bucket.flat.is_cuda:
+        for _ in range(3):
+            dist.all_reduce(bucket.flat)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        s.record()
+        for _ in range(iters):
+            dist.all_reduce(bucket.flat)
+        e.record()
+        torch.cuda.synchronize()
+        out["allreduce_us"] = round(s.elapsed_time(e) / iters * 1e3, 1)
+        if out["world"] > 1:  # ring / direct all-reduce moves 2 (W-1)/W of the bucket per rank
+            out["allreduce_busbw_GBps"] = round(2.0 * (out["world"] - 1) / out["world"] * bucket.nbytes / (out["allreduce_us"] * 1e-6) / 1e9, 1)
+        bucket.flat.zero_()
+    return out
 
 
 def init_from_env(backend=None):

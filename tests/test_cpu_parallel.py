@@ -97,6 +97,64 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     assert r0["bucket_bytes"] == 4 * n_params  # ONE flat fp32 bucket holds every gradient
 
 
+def _exact_worker(rank, world, port, out_dir):
+    """training-mode BatchNorm: exact statistics + loss weights local_M / global_M == the single-process step"""
+    import numpy as np
+    from oracle import chem as ochem
+    from pretrain_gnns_amd.data import synthetic
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    parallel.init_from_env(backend="gloo")
+    torch.manual_seed(3)
+    model, head = ochem.GNN(3, 32), torch.nn.Linear(32, 119)
+    ref_model, ref_head = ochem.GNN(3, 32), torch.nn.Linear(32, 119)
+    ref_model.load_state_dict(model.state_dict())
+    ref_head.load_state_dict(head.state_dict())
+    parallel.use_exact_batchnorm(model)
+    assert list(model.state_dict()) == list(ref_model.state_dict())
+    rng = np.random.default_rng(11)
+    graphs = [synthetic.mask_atoms(synthetic.zinc_like_graph(rng), rng) for _ in range(7)]
+    local = synthetic.collate([graphs[i] for i in parallel.shard_graphs(len(graphs), rank, world)])
+    whole = synthetic.collate(graphs)
+    m_local, m_global = local.masked_atom_indices.numel(), whole.masked_atom_indices.numel()
+    opts = [torch.optim.SGD(model.parameters(), lr=0.1), torch.optim.SGD(head.parameters(), lr=0.1)]
+    # with statistics shared across ranks the backward of one rank's rows carries terms of EVERY rank's loss, so the
+    # share local_M / global_M must multiply the loss itself (not the finished gradient): the bucket then plainly sums
+    dp = parallel.AllReduceOptimizers(opts, weight_fn=lambda: 1.0)
+    model.train(), ref_model.train()
+
+    def mean_loss(m, h, b):
+        rep = m(b.x, b.edge_index, b.edge_attr)
+        return F.cross_entropy(h(rep[b.masked_atom_indices]).double(), b.mask_node_label[:, 0])
+
+    for o in dp:
+        o.zero_grad()
+    (mean_loss(model, head, local) * (m_local / m_global)).backward()
+    dp._before_step()  # the all-reduce only: keep the gradients for the comparison
+    mean_loss(ref_model, ref_head, whole).backward()
+    torch.save({"grads": [p.grad.clone() for p in list(model.parameters()) + list(head.parameters())],
+                "ref_grads": [p.grad.clone() for p in list(ref_model.parameters()) + list(ref_head.parameters())],
+                "running_mean": model.batch_norms[0].running_mean.clone(), "ref_running_mean": ref_model.batch_norms[0].running_mean.clone(),
+                "running_var": model.batch_norms[2].running_var.clone(), "ref_running_var": ref_model.batch_norms[2].running_var.clone()},
+               os.path.join(out_dir, "exact%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_exact_batchnorm_and_loss_weights_reproduce_the_single_process_step(tmp_path):
+    port = _free_port()
+    mp.spawn(_exact_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        d = torch.load(tmp_path / ("exact%d.pt" % r))
+        scale = max(float(g.abs().max()) for g in d["ref_grads"])
+        for g, ref in zip(d["grads"], d["ref_grads"]):
+            assert float((g - ref).abs().max()) <= 2e-5 * scale
+        torch.testing.assert_close(d["running_mean"], d["ref_running_mean"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(d["running_var"], d["ref_running_var"], rtol=1e-5, atol=1e-6)
+
+
 def test_shard_graphs_partition():
     for n, w in [(9, 2), (256, 8), (5, 8), (2048, 8)]:
         parts = [list(parallel.shard_graphs(n, r, w)) for r in range(w)]

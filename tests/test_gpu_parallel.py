@@ -1,0 +1,145 @@
+"""-m gpu: the data-parallel path of the HIP stack with world_size 2 on ONE GPU.
+
+Two processes share cuda:0 (gloo backend -- RCCL refuses two ranks on one device; the layer under test is
+backend-agnostic and the 8-GPU RCCL run is the driver's) and run the real thing: HIP `GNN` + head,
+`parallel.AllReduceOptimizers`, direct gradient deposit ON (the path bench.py uses), `ResidentLoader(rank, world_size)`
+device-side batches.  Checked:
+  (i)   ranks start identical (broadcast) and stay bit-identical over several Adam steps;
+  (ii)  eval-mode BatchNorm: the summed gradient of the two shards == the single-process gradient of the whole batch;
+  (iii) weight_fn = local_M / global_M reproduces the gradient of the global masked-atom MEAN loss;
+  (iv)  training-mode BatchNorm with `use_exact_batchnorm`: the two-rank step == the single-process step;
+  (v)   both ranks run the same number of loader steps on a dataset whose tail is smaller than the world size.
+"""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    import numpy as np
+    import torch.distributed as dist
+    import torch.nn.functional as F
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", PGNN_DP_BACKEND="gloo")
+    from pretrain_gnns_amd import ops, parallel
+    from pretrain_gnns_amd import train as ptrain
+    from pretrain_gnns_amd.chem import model as hchem
+    from pretrain_gnns_amd.data import resident, synthetic
+
+    r, local, w = parallel.init_from_env()
+    assert (r, w, dist.get_backend()) == (rank, world, "gloo")
+    dev = torch.device("cuda", local)
+    ops.set_direct_grads(True)
+    res = {}
+
+    rng = np.random.default_rng(5)
+    graphs = [synthetic.zinc_like_graph(rng) for _ in range(65)]  # 65 = 4 x 16 + a tail of 1 < world size
+    ds = resident.ResidentDataset.from_graphs(graphs, dev)
+
+    # ---- (i) + (v): training steps through the loader, ranks must stay bit-identical
+    torch.manual_seed(100 + rank)  # deliberately different initial weights per rank
+    mods = [hchem.GNN(5, 300).to(dev), torch.nn.Linear(300, 119).to(dev), torch.nn.Linear(300, 4).to(dev)]
+    parallel.broadcast_parameters(mods)
+    opts = parallel.AllReduceOptimizers([torch.optim.Adam(m.parameters(), lr=1e-3, fused=True) for m in mods])
+    loader = resident.ResidentLoader(ds, 16, shuffle=True, seed=9, mask_rate=0.15, rank=rank, world_size=world)
+    res["len_loader"] = len(loader)
+    for m in mods:
+        m.train()
+    steps_run, losses = 0, []
+    for _ in range(2):
+        for batch in loader:
+            losses.append(ptrain.chem_masking_step(mods, list(opts), batch)[0])
+            steps_run += 1
+    res["steps_run"], res["losses"] = steps_run, losses
+    res["params"] = [p.detach().cpu().clone() for m in mods for p in m.parameters()]
+    res["bucket_bytes"] = opts.bucket.nbytes
+    res["comm"] = parallel.comm_report(opts, iters=3)
+
+    # ---- (ii) + (iii): gradients of the two shards vs the whole batch, eval-mode BatchNorm
+    whole_ids = np.arange(24)
+    mine = np.asarray(list(parallel.shard_graphs(24, rank, world)))
+    whole = ds.collate(whole_ids, mask_rate=0.15, seed=77)
+    # the same masked atoms on the shard: take them from the whole batch (mask draws depend on batch position otherwise)
+    node_off = whole._node_off.cpu().numpy()
+    lo, hi = int(node_off[mine[0]]), int(node_off[mine[-1] + 1])
+    sel = (whole.masked_atom_indices >= lo) & (whole.masked_atom_indices < hi)
+    local_b = ds.collate(mine, masked_atom_indices=(whole.masked_atom_indices[sel] - lo))
+    assert torch.equal(local_b.mask_node_label, whole.mask_node_label[sel])
+    torch.manual_seed(7)
+    model, head = hchem.GNN(5, 300).to(dev), torch.nn.Linear(300, 119).to(dev)
+    parallel.broadcast_parameters([model, head])
+    model.eval()
+
+    def loss_of(m, h, b, reduction):
+        rep = m(b.x, b.edge_index, b.edge_attr)
+        return F.cross_entropy(h(rep[b.masked_atom_indices]).double(), b.mask_node_label[:, 0], reduction=reduction)
+
+    params = list(model.parameters()) + list(head.parameters())
+
+    def grads_after(weight_fn, reduction, scale=1.0):
+        dp = parallel.AllReduceOptimizers([torch.optim.SGD(params, lr=0.0)], weight_fn=weight_fn)
+        for o in dp:
+            o.zero_grad()
+        (loss_of(model, head, local_b, reduction) * scale).backward()
+        dp._before_step()
+        return [p.grad.detach().cpu().clone() for p in params]
+
+    def single(reduction, train=False):
+        for p in params:
+            p.grad = None
+        model.train(train)
+        loss_of(model, head, whole, reduction).backward()
+        g = [p.grad.detach().cpu().clone() for p in params]
+        model.eval()
+        return g
+
+    res["sum_dp"], res["sum_single"] = grads_after(lambda: 1.0, "sum"), single("sum")
+    m_local, m_global = int(sel.sum().item()), whole.masked_atom_indices.numel()
+    res["mean_dp"], res["mean_single"] = grads_after(lambda: m_local / m_global, "mean"), single("mean")
+
+    # ---- (iv): training-mode BatchNorm, exact statistics; weights on the loss, plain sum in the bucket
+    bn_state = [(bn.running_mean.clone(), bn.running_var.clone(), bn.num_batches_tracked.clone()) for bn in model.batch_norms]
+    res["exact_single"] = single("mean", train=True)
+    for bn, (rm, rv, nb) in zip(model.batch_norms, bn_state):
+        bn.running_mean.copy_(rm), bn.running_var.copy_(rv), bn.num_batches_tracked.copy_(nb)
+    parallel.use_exact_batchnorm(model)
+    model.train()
+    res["exact_dp"] = grads_after(lambda: 1.0, "mean", scale=m_local / m_global)
+    torch.save(res, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    # (v) same number of steps on both ranks although 65 % 16 == 1 < world size; (i) identical parameters throughout
+    assert r0["steps_run"] == r1["steps_run"] == 2 * r0["len_loader"] == 8
+    assert r0["comm"]["world"] == 2 and r0["comm"]["backend"] == "gloo" and r0["comm"]["bucket_bytes"] == r0["bucket_bytes"]
+    n_params = sum(p.numel() for p in r0["params"])
+    assert r0["bucket_bytes"] == 4 * n_params  # ONE flat fp32 bucket
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)
+    assert r0["losses"] != r1["losses"]  # ... while every rank really trained on its own shard
+    # (ii) summed gradients == whole-batch gradient; (iii) weighted == gradient of the global mean; (iv) exact BatchNorm
+    for key_dp, key_single, tol in (("sum_dp", "sum_single", 2e-5), ("mean_dp", "mean_single", 2e-5), ("exact_dp", "exact_single", 3e-3)):
+        for r in (r0, r1):
+            scale = max(float(g.abs().max()) for g in r[key_single])
+            for g, ref in zip(r[key_dp], r[key_single]):
+                assert float((g - ref).abs().max()) <= tol * scale, (key_dp, float((g - ref).abs().max()), scale)
