@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PGNN_ABI_VERSION 2
+#define PGNN_ABI_VERSION 3
 
 #define PGNN_OK 0
 #define PGNN_ERR_ARG 1
@@ -376,14 +376,22 @@ int pgnn_substruct_context_fill(const int64_t* graph_ids, int64_t num_graphs, in
                                 const int64_t* node_slice, const int64_t* edge_slice, const int64_t* node_off,
                                 const int64_t* edge_off, const int64_t* offsets, const int64_t* counts,
                                 const int64_t* root, const int32_t* sub_rank, const int32_t* ctx_rank,
-                                const int32_t* esub_rank, const int32_t* ectx_rank, const int64_t* x_all,
-                                int64_t x_cols, const int64_t* edge_index_all, int64_t edges_all,
-                                const int64_t* edge_attr_all, int64_t attr_cols, int64_t num_nodes,
-                                int64_t num_edges, int64_t* x_substruct, int64_t* edge_index_substruct,
-                                int64_t* edge_attr_substruct, int64_t* x_context, int64_t* edge_index_context,
-                                int64_t* edge_attr_context, int64_t* center_substruct_idx,
-                                int64_t* overlap_context_substruct_idx, int64_t* batch_overlapped_context,
-                                int64_t* overlapped_context_size, pgnn_stream stream);
+                                const int32_t* esub_rank, const int32_t* ectx_rank, const void* x_all,
+                                int64_t x_row_bytes, const int64_t* edge_index_all, int64_t edges_all,
+                                const void* edge_attr_all, int64_t attr_row_bytes,
+                                int64_t context_attr_zero_from_byte, int64_t num_nodes, int64_t num_edges,
+                                void* x_substruct, int64_t* edge_index_substruct, void* edge_attr_substruct,
+                                void* x_context, int64_t* edge_index_context, void* edge_attr_context,
+                                int64_t* center_substruct_idx, int64_t* overlap_context_substruct_idx,
+                                int64_t* batch_overlapped_context, int64_t* overlapped_context_size,
+                                pgnn_stream stream);
+/* The same two calls serve the bio transform, ExtractSubstructureContextPair(l1, center=True) (bio/util.py:123-209) +
+ * bio BatchSubstructContext (bio/batch.py:127-232): pass k = -1 (the substructure is the WHOLE ego net, unreachable
+ * nodes included), l2 = -1 (the context is every node farther than l1 hops from the root, unreachable nodes
+ * included), roots = center_node_idx, and context_attr_zero_from_byte = 28 (the context graph is rebuilt from the
+ * w1..w7 flags only: the self-loop and mask columns of its [E,9] float attributes read 0, bio/loader.py:56-60,134).
+ * Feature rows (int64 [N,2] / [E,2] for chem, float [N,1] / [E,9] for bio) are copied as 32-bit words:
+ * x_row_bytes / attr_row_bytes must be multiples of 4; context_attr_zero_from_byte < 0 copies whole rows. */
 
 /* diagnostics: plain float4 grid-stride copy (the HBM streaming ceiling bench.py quotes next to the
  * aggregation kernel).  Not part of the hot path. */

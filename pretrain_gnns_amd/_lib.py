@@ -78,12 +78,12 @@ PROTOTYPES = {
     "pgnn_substruct_context_plan": (_i, [_p, _i64, _i64, _p, _p, _p, _p, _p, _i64, _p, _u64, _i, _i, _i, _p, _p, _p, _p,
                                          _p, _p, _p, _p, _p]),
     "pgnn_substruct_context_fill": (_i, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _i64,
-                                         _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+                                         _p, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "pgnn_debug_stream_copy": (_i, [_p, _p, _i64, _i64, _p]),
     "pgnn_debug_aggregate_profile": (_i, [_p, _i64]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class GinLayer(ctypes.Structure):

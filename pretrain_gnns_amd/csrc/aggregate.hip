@@ -61,8 +61,8 @@ __device__ __forceinline__ void row_zero(Row<R>& r) {
 // persistent-wave node range: wave w of the (XCD-remapped) grid owns chunks w, w+W, ...
 struct WaveSched {
   int wave, nwaves, lane;
-  __device__ __forceinline__ WaveSched() {
-    const int b = xcd_remap(blockIdx.x, gridDim.x);
+  __device__ __forceinline__ explicit WaveSched(int nxcd) {
+    const int b = xcd_remap(blockIdx.x, gridDim.x, nxcd);
     wave = b * kWavesPerBlock + (threadIdx.x >> 6);
     nwaves = gridDim.x * kWavesPerBlock;
     lane = lane_id();
@@ -110,7 +110,7 @@ k_aggregate(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict_
             const int32_t* __restrict__ nbr, const uint8_t* __restrict__ code,
             const float* __restrict__ emb1, const float* __restrict__ emb2,
             const float* __restrict__ dinv, float* __restrict__ out, int64_t ldo, int n, int dim,
-            int nodes_per_chunk) {
+            int nodes_per_chunk, int nxcd) {
 #pragma clang fp contract(off)
   extern __shared__ __align__(16) float T[];  // [18][dim] when TABLE
   if (TABLE) {
@@ -120,7 +120,7 @@ k_aggregate(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict_
     }
     __syncthreads();
   }
-  const WaveSched ws;
+  const WaveSched ws(nxcd);
   const int lane = ws.lane, d4 = dim >> 2;
   const int nchunks = (n + nodes_per_chunk - 1) / nodes_per_chunk;
   for (int chunk = ws.wave; chunk < nchunks; chunk += ws.nwaves) {
@@ -174,12 +174,12 @@ k_aggregate(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict_
 
 inline int pick_grid(int64_t n, int blocks_per_cu, int* nodes_per_chunk) {
   // spread small inputs over many waves, give big inputs 16-node chunks
-  const int64_t max_waves = (int64_t)kNumCU * blocks_per_cu * kWavesPerBlock;
+  const int64_t max_waves = (int64_t)num_cu() * blocks_per_cu * kWavesPerBlock;
   int64_t npc = ceil_div(n, max_waves);
   npc = std::min<int64_t>(std::max<int64_t>(npc, 1), 16);
   *nodes_per_chunk = (int)npc;
   const int64_t chunks = ceil_div(n, npc);
-  const int64_t blocks = std::min<int64_t>(ceil_div(chunks, kWavesPerBlock), (int64_t)kNumCU * blocks_per_cu);
+  const int64_t blocks = std::min<int64_t>(ceil_div(chunks, kWavesPerBlock), (int64_t)num_cu() * blocks_per_cu);
   return (int)std::max<int64_t>(blocks, 1);
 }
 
@@ -201,7 +201,7 @@ k_aggregate_grp(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
                 const int32_t* __restrict__ nbr, const uint8_t* __restrict__ code,
                 const float* __restrict__ emb1, const float* __restrict__ emb2,
                 const float* __restrict__ dinv, float* __restrict__ out, int64_t ldo, int n, int dim,
-                int groups, int nodes_per_block, int front) {
+                int groups, int nodes_per_block, int front, int nxcd) {
 #pragma clang fp contract(off)
   extern __shared__ __align__(16) float T[];  // [18][dim] when TABLE
   if (TABLE) {
@@ -220,13 +220,13 @@ k_aggregate_grp(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
   // step), so neighbour rows are shared through that XCD's L2 while HBM sees 8 sequential streams.
   int i_first, i_end, i_step;
   if (front) {
-    const int xcd = blockIdx.x % kNumXCD, j = blockIdx.x / kNumXCD, nbx = gridDim.x / kNumXCD;
-    const int slab = ((n + kNumXCD - 1) / kNumXCD + groups - 1) / groups * groups;
+    const int xcd = blockIdx.x % nxcd, j = blockIdx.x / nxcd, nbx = gridDim.x / nxcd;
+    const int slab = ((n + nxcd - 1) / nxcd + groups - 1) / groups * groups;
     i_first = xcd * slab + j * groups + g;
     i_end = min(n, (xcd + 1) * slab);
     i_step = nbx * groups;
   } else {
-    const int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = xcd_remap(blockIdx.x, gridDim.x, nxcd);
     i_first = b * nodes_per_block + g;
     i_end = min(n, b * nodes_per_block + nodes_per_block);
     i_step = groups;
@@ -288,15 +288,16 @@ int launch_aggregate_grp(const float* x, int64_t ldx, const int32_t* ptr, const 
   const int groups = kGrpBlock / gs;
   const size_t lds = TABLE ? (size_t)kNumCodes * dim * sizeof(float) : 0;
   const int bpc = env_int("PGNN_AGG_BLOCKS_PER_CU", TABLE ? 6 : 6);
-  const int64_t max_blocks = (int64_t)kNumCU * bpc;
+  const int64_t max_blocks = (int64_t)num_cu() * bpc;
   int64_t npb = std::max<int64_t>(ceil_div(n, max_blocks), groups);
   npb = ceil_div(npb, groups) * groups;
   int grid = (int)ceil_div(n, npb);
   const int front = env_int("PGNN_AGG_FRONT", 1);
-  if (front) grid = (int)std::max<int64_t>(kNumXCD, std::min<int64_t>(max_blocks, ceil_div(ceil_div(n, groups), kNumXCD) * kNumXCD) / kNumXCD * kNumXCD);
+  const int nx = num_xcd();
+  if (front) grid = (int)std::max<int64_t>(nx, std::min<int64_t>(max_blocks, ceil_div(ceil_div(n, groups), nx) * nx) / nx * nx);
   allow_big_lds((const void*)k_aggregate_grp<TABLE, WEIGHT>, lds);
   hipLaunchKernelGGL((k_aggregate_grp<TABLE, WEIGHT>), dim3(grid), dim3(kGrpBlock), lds, st, x, ldx, ptr, nbr, code,
-                     emb1, emb2, dinv, out, ldo, (int)n, (int)dim, groups, (int)npb, front);
+                     emb1, emb2, dinv, out, ldo, (int)n, (int)dim, groups, (int)npb, front, nx);
   return check_launch("aggregate_grp");
 }
 
@@ -598,7 +599,7 @@ int launch_aggregate_dma_p(const float* x, int64_t ldx, const int32_t* ptr, cons
   const size_t lds = (size_t)(TABLE ? kNumCodes * dim : 0) * 4 + (size_t)(P + 3) * kDmaG * dim * 4 +
                      (size_t)(kDmaMaxNodes + 4) * 4 + (size_t)2 * (P + 1) * kDmaEdges * 4 + 64;
   const int resident = (int)std::max<size_t>(1, (160 * 1024) / lds);
-  const int64_t target_blocks = (int64_t)kNumCU * std::min(resident, env_int("PGNN_DMA_BPC", 2));
+  const int64_t target_blocks = (int64_t)num_cu() * std::min(resident, env_int("PGNN_DMA_BPC", 2));
   int64_t npb = ceil_div(n, target_blocks);
   npb = std::min<int64_t>(std::max<int64_t>(npb, 4 * kDmaG), kDmaMaxNodes);
   npb = ceil_div(npb, kDmaG) * kDmaG;
@@ -680,7 +681,7 @@ int launch_aggregate(const float* x, int64_t ldx, const int32_t* ptr, const int3
 #define PGNN_LAUNCH_AGG(RR)                                                                         \
   allow_big_lds((const void*)k_aggregate<RR, TABLE, WEIGHT>, lds);                                  \
   hipLaunchKernelGGL((k_aggregate<RR, TABLE, WEIGHT>), dim3(grid), dim3(kBlock), lds, st, x, ldx,  \
-                     ptr, nbr, code, emb1, emb2, dinv, out, ldo, (int)n, (int)dim, npc)
+                     ptr, nbr, code, emb1, emb2, dinv, out, ldo, (int)n, (int)dim, npc, num_xcd())
   switch (R) {
     case 1: PGNN_LAUNCH_AGG(1); break;
     case 2: PGNN_LAUNCH_AGG(2); break;
@@ -698,11 +699,11 @@ int launch_aggregate(const float* x, int64_t ldx, const int32_t* ptr, const int3
 template <int R>
 __global__ void __launch_bounds__(kBlock)
 k_rowfeat_fwd(const float* __restrict__ cfeat, int kc, const float* __restrict__ table, int64_t ldt,
-              float* __restrict__ out, int64_t ldo, int n, int dim, int accumulate) {
+              float* __restrict__ out, int64_t ldo, int n, int dim, int accumulate, int nxcd) {
   extern __shared__ __align__(16) float T[];  // [kc][dim]
   for (int q = threadIdx.x; q < kc * dim; q += kBlock) T[q] = table[(q / dim) * ldt + (q % dim)];
   __syncthreads();
-  const WaveSched ws;
+  const WaveSched ws(nxcd);
   const int lane = ws.lane, d4 = dim >> 2;
   for (int i = ws.wave; i < n; i += ws.nwaves) {
     const float myc = lane < kc ? cfeat[(int64_t)i * kc + lane] : 0.f;
@@ -781,7 +782,7 @@ k_rowfeat_bwd_final(const float* __restrict__ partial, int nblocks, int kc, int 
 }
 
 inline int rowfeat_bwd_blocks(int64_t n) {
-  return (int)std::min<int64_t>(std::max<int64_t>(ceil_div(n, 64), 1), 2 * kNumCU);
+  return (int)std::min<int64_t>(std::max<int64_t>(ceil_div(n, 64), 1), 2 * num_cu());
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -791,9 +792,9 @@ template <int R>
 __global__ void __launch_bounds__(kBlock)
 k_embed_fwd(const int64_t* __restrict__ idx, int64_t stride, const float* __restrict__ t1, int rows1,
             const float* __restrict__ t2, int rows2, float* __restrict__ out, int64_t ldo, int n,
-            int dim, int32_t* status) {
+            int dim, int32_t* status, int nxcd) {
 #pragma clang fp contract(off)
-  const WaveSched ws;
+  const WaveSched ws(nxcd);
   const int lane = ws.lane, d4 = dim >> 2;
   for (int i = ws.wave; i < n; i += ws.nwaves) {
     int64_t a = idx[(int64_t)i * stride];
@@ -995,8 +996,8 @@ template <int R>
 __global__ void __launch_bounds__(kBlock)
 k_segment_broadcast(const float* __restrict__ g, int64_t ldg, const int64_t* __restrict__ key,
                     const int32_t* __restrict__ ptr, int mean, float* __restrict__ gx, int64_t ldgx,
-                    int n, int dim) {
-  const WaveSched ws;
+                    int n, int dim, int nxcd) {
+  const WaveSched ws(nxcd);
   const int lane = ws.lane, d4 = dim >> 2;
   for (int i = ws.wave; i < n; i += ws.nwaves) {
     const int64_t s = key[i];
@@ -1012,7 +1013,7 @@ k_segment_broadcast(const float* __restrict__ g, int64_t ldg, const int64_t* __r
 }
 
 inline int stream_grid(int64_t n_rows) {
-  return (int)std::min<int64_t>(std::max<int64_t>(ceil_div(n_rows, kWavesPerBlock), 1), (int64_t)kNumCU * 8);
+  return (int)std::min<int64_t>(std::max<int64_t>(ceil_div(n_rows, kWavesPerBlock), 1), (int64_t)num_cu() * 8);
 }
 
 #define PGNN_DISPATCH_R(R_, CALL)                                                     \
@@ -1135,7 +1136,7 @@ int pgnn_rowfeat_matmul_fwd(const float* cfeat, int64_t kc, const float* table, 
   const int grid = stream_grid(n);
   PGNN_DISPATCH_R(R, hipLaunchKernelGGL((k_rowfeat_fwd<RR>), dim3(grid), dim3(kBlock), lds,
                                         (hipStream_t)stream, cfeat, (int)kc, table, ldt, out, ldo,
-                                        (int)n, (int)dim, accumulate));
+                                        (int)n, (int)dim, accumulate, num_xcd()));
   return check_launch("rowfeat_matmul_fwd");
 }
 
@@ -1186,7 +1187,7 @@ int pgnn_embed_fwd(const int64_t* idx, int64_t idx_stride, const float* table1, 
   const int grid = stream_grid(n);
   PGNN_DISPATCH_R(R, hipLaunchKernelGGL((k_embed_fwd<RR>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
                                         idx, idx_stride, table1, (int)rows1, table2, (int)rows2, out, ldo,
-                                        (int)n, (int)dim, status));
+                                        (int)n, (int)dim, status, num_xcd()));
   return check_launch("embed_fwd");
 }
 
@@ -1238,7 +1239,7 @@ int pgnn_segment_broadcast(const float* g, int64_t ldg, const int64_t* key, cons
   const int grid = stream_grid(n_items);
   PGNN_DISPATCH_R(R, hipLaunchKernelGGL((k_segment_broadcast<RR>), dim3(grid), dim3(kBlock), 0,
                                         (hipStream_t)stream, g, ldg, key, ptr, mean, gx, ldgx, (int)n_items,
-                                        (int)dim));
+                                        (int)dim, num_xcd()));
   return check_launch("segment_broadcast");
 }
 

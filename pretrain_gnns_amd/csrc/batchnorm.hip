@@ -298,7 +298,7 @@ int pgnn_bn_fwd(const float* x, int64_t ldx, const float* gamma, const float* be
   hipLaunchKernelGGL(k_bn_stats_final, dim3((int)ceil_div(dim, 16)), dim3(256), 0, st, partial, nblk, x, gamma,
                      beta, running_mean, running_var, momentum, eps, training, (int)n, (int)dim, save_mean,
                      save_invstd, coef);
-  const int grid = (int)std::min<int64_t>(ceil_div(n, 4), (int64_t)kNumCU * 16);
+  const int grid = (int)std::min<int64_t>(ceil_div(n, 4), (int64_t)num_cu() * 16);
   hipLaunchKernelGGL(k_bn_apply, dim3(grid), dim3(stat_threads(dim)), 0, st, x, ldx, coef, relu, y, ldy, (int)n, d4,
                      make_drop(drop_p, drop_seed));
   return check_launch("bn_fwd");
@@ -349,7 +349,7 @@ int pgnn_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, cons
                      lddy, x, ldx, gamma, beta, save_mean, save_invstd, coef, relu, (int)n, d4, partial, drop);
   hipLaunchKernelGGL(k_bn_bwd_final, dim3((int)ceil_div(dim, 16)), dim3(256), 0, st, partial, nblk, training, (int)n, (int)dim, gamma,
                      coef, dgamma, dbeta);
-  const int grid = (int)std::min<int64_t>(ceil_div(n, 4), (int64_t)kNumCU * 16);
+  const int grid = (int)std::min<int64_t>(ceil_div(n, 4), (int64_t)num_cu() * 16);
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid), dim3(stat_threads(dim)), 0, st, dy, lddy, x, ldx, coef, relu, dx, lddx,
                      (int)n, d4, drop);
   return check_launch("bn_bwd");

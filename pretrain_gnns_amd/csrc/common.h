@@ -10,8 +10,15 @@
 namespace pgnn {
 
 constexpr int kWave = 64;         // CDNA wavefront
-constexpr int kNumCU = 256;       // MI355X
-constexpr int kNumXCD = 8;
+
+// Compute units and XCDs of the CURRENT device, queried once per device (hipDeviceProp_t.multiProcessorCount; an
+// MI355X in SPX mode reports 256 CUs = 8 XCDs x 32, a CPX partition 32 CUs = 1 XCD).  The XCD count is not an API
+// field: gfx950 XCDs carry 32 active CUs each.  Used for grid sizing and for the XCD-aware block remap; both are
+// speed heuristics -- any value gives correct results.
+struct DeviceInfo { int num_cu, num_xcd; };
+DeviceInfo device_info();
+inline int num_cu() { return device_info().num_cu; }
+inline int num_xcd() { return device_info().num_xcd; }
 
 void set_error(const char* fmt, ...);
 
@@ -47,7 +54,8 @@ inline int check_launch(const char* what) {
 inline void allow_big_lds(const void* func, size_t bytes) {
   if (bytes <= 64 * 1024) return;
   struct Seen { const void* f; int dev; size_t bytes; };
-  static thread_local Seen seen[64];
+  constexpr int kSlots = 256;
+  static thread_local Seen seen[kSlots];
   static thread_local int nseen = 0;
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -59,7 +67,13 @@ inline void allow_big_lds(const void* func, size_t bytes) {
       return;
     }
   (void)hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (nseen < 64) seen[nseen++] = Seen{func, dev, bytes};
+  if (nseen < kSlots) {
+    seen[nseen++] = Seen{func, dev, bytes};
+  } else {
+    static thread_local bool warned = false;  // still correct (the attribute is set on every launch), just slower
+    if (!warned) fprintf(stderr, "pgnn: allow_big_lds cache full (%d kernels): hipFuncSetAttribute now runs per launch\n", kSlots);
+    warned = true;
+  }
 }
 
 // A/B knobs come from the environment.  getenv walks the whole environment block (~0.3 us) and the hot path
@@ -68,14 +82,18 @@ inline void allow_big_lds(const void* func, size_t bytes) {
 extern unsigned g_env_generation;
 inline int env_knob(const char* name, int dflt) {
   struct Slot { const char* name; unsigned gen; bool set; int value; };
-  static thread_local Slot slots[32];
+  constexpr int kSlots = 128;
+  static thread_local Slot slots[kSlots];
   static thread_local int nslots = 0;
   const unsigned gen = g_env_generation;
   Slot* s = nullptr;
   for (int i = 0; i < nslots && !s; ++i)
     if (slots[i].name == name) s = &slots[i];
   if (!s) {
-    if (nslots == 32) {  // more call sites than slots: uncached
+    if (nslots == kSlots) {  // more call sites than slots: uncached (correct, ~0.3 us slower per query) -- say so once
+      static thread_local bool warned = false;
+      if (!warned) fprintf(stderr, "pgnn: env_knob cache full (%d call sites): '%s' is read with getenv on every call\n", kSlots, name);
+      warned = true;
       const char* v = getenv(name);
       return v ? atoi(v) : dflt;
     }
@@ -109,10 +127,10 @@ struct Carver {
 };
 
 // XCD-aware block remap: consecutive logical blocks land on the same XCD (same L2) instead of
-// being dealt round-robin over the 8 XCDs.  Bijective for any grid size.
-__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
-  const int q = nblocks / kNumXCD, r = nblocks % kNumXCD;
-  const int xcd = bid % kNumXCD, slot = bid / kNumXCD;
+// being dealt round-robin over the `nxcd` XCDs (host: num_xcd()).  Bijective for any grid size and any nxcd >= 1.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks, int nxcd) {
+  const int q = nblocks / nxcd, r = nblocks % nxcd;
+  const int xcd = bid % nxcd, slot = bid / nxcd;
   const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return start + slot;
 }

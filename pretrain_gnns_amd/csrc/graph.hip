@@ -22,6 +22,25 @@ void set_error(const char* fmt, ...) {
 
 unsigned g_env_generation = 1;
 
+DeviceInfo device_info() {
+  constexpr int kMaxDev = 64;
+  static DeviceInfo cache[kMaxDev];  // zero-initialised; a benign race re-queries the same values
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= kMaxDev) dev = 0;
+  if (cache[dev].num_cu == 0) {
+    hipDeviceProp_t prop;
+    int cu = 256;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cu = prop.multiProcessorCount;
+    int xcd = cu / 32;
+    if (xcd < 1) xcd = 1;
+    if (xcd > 8) xcd = 8;
+    cache[dev].num_xcd = xcd;
+    cache[dev].num_cu = cu;
+  }
+  return cache[dev];
+}
+
 namespace {
 
 constexpr int kScanItems = 1024;  // per block: 256 threads x 4

@@ -40,6 +40,7 @@ struct GemmArgs {
   int kchunk;          // split-K: k range per blockIdx.y
   int64_t split_stride;  // split-K: floats between partial C matrices
   float* colsum;       // ONES: receives sum_k Aop(m,k) (one value per m), same split stride
+  int nxcd;            // XCDs of the device (block -> tile remap)
 };
 
 enum { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_MASK = 2 };
@@ -98,7 +99,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
   extern __shared__ __align__(16) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_n = (p.N + (ONES ? 4 : 0) + BN - 1) / BN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = xcd_remap(blockIdx.x, gridDim.x, p.nxcd);
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
   const int kbeg = blockIdx.y * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
@@ -344,7 +345,7 @@ inline TileCfg pick_cfg(int64_t m, int64_t n, int kind) {
     if (c == T128x304 && (kind == 0 || m < 32768)) continue;
     if (c == T128x160 || c == T64x160 || c == T320x160 || c == T256x304) continue;  // 8-wave 64x160 beats the 4-wave one everywhere measured
     const int64_t tiles = ceil_div(m, kCfg[c].bm) * ceil_div(n, kCfg[c].bn);
-    const int64_t per_simd = ceil_div(tiles * 4, 4 * kNumCU);             // waves each SIMD must run
+    const int64_t per_simd = ceil_div(tiles * 4, 4 * num_cu());             // waves each SIMD must run
     const double t = (double)per_simd * (kCfg[c].wave_blocks + 5.0);     // + fixed per-tile overhead
     if (t < best) { best = t; arg = c; }
   }
@@ -370,7 +371,7 @@ constexpr int kWgtBK = 16;
 // split count for dW = dy^T x: every SIMD should get ~2 waves, each split at least 4 k-tiles deep
 inline int weight_splits(int64_t m, int64_t k, int64_t n, int bm, int bn) {
   const int64_t tiles = ceil_div(n, bm) * ceil_div(k, bn);
-  int64_t s = ceil_div(2 * kNumCU, tiles);
+  int64_t s = ceil_div(2 * num_cu(), tiles);
   s = std::min<int64_t>(s, std::max<int64_t>(m / (4 * kWgtBK), 1));
   return (int)std::max<int64_t>(std::min<int64_t>(s, 256), 1);
 }
@@ -398,6 +399,7 @@ int pgnn_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bi
   PGNN_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0,
                "linear_fwd: K, N and the leading dimensions must be multiples of 4");
   GemmArgs p{};
+  p.nxcd = num_xcd();
   p.A = x; p.lda = ldx; p.B = w; p.ldb = k; p.C = y; p.ldc = ldy;
   p.M = (int)m; p.N = (int)n; p.K = (int)k; p.bias = bias; p.relu = relu; p.kchunk = (int)k; p.split_stride = 0;
   return launch_cfg<true, true, EPI_BIAS>(pick_cfg(m, n, 0), p, 1, (hipStream_t)stream);
@@ -408,6 +410,7 @@ int pgnn_linear_bwd_data(const float* dy, int64_t lddy, const float* w, const fl
   PGNN_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0 && lddy % 4 == 0,
                "linear_bwd_data: K, N and lddy must be multiples of 4");
   GemmArgs p{};
+  p.nxcd = num_xcd();
   // C = dx [m, k] ; reduction over n ; A = dy (n contiguous) ; B(kcol, nn) = w[nn*k + kcol]
   p.A = dy; p.lda = lddy; p.B = w; p.ldb = k; p.C = dx; p.ldc = lddx;
   p.M = (int)m; p.N = (int)k; p.K = (int)n; p.mask = relu_out; p.ldmask = ldr; p.kchunk = (int)n; p.split_stride = 0;
@@ -435,6 +438,7 @@ int pgnn_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_
   const int nsplit = weight_splits(m, k, n, kCfg[cfg].bm, kCfg[cfg].bn);
   float* partial = cv.take<float>((size_t)nsplit * (n * k + n));
   GemmArgs p{};
+  p.nxcd = num_xcd();
   // C = dW [n, k] ; reduction over rows m ; A(nout, r) = dy[r*lddy + nout] ; B(kcol, r) = x[r*ldx + kcol]
   // db[nout] = sum_r dy[r, nout] rides along as the "ones column" of B.
   p.A = dy; p.lda = lddy; p.B = x; p.ldb = ldx;

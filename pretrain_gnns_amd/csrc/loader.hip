@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(kBlock) k_mask_apply(const int64_t* __restrict
   }
 }
 
-inline int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, kBlock), 8 * kNumCU)); }
+inline int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, kBlock), 8 * num_cu())); }
 
 }  // namespace
 
@@ -319,8 +319,11 @@ __global__ void __launch_bounds__(256) k_ctx_plan(const int64_t* __restrict__ id
   root = min(max(root, (int64_t)0), max(n - 1, (int64_t)0));
   if (lane == 0) root_out[g] = root;
   for (int64_t a = lane; a < n; a += 64) st_i32(&dist[n0 + a], a == root ? 0 : -1);
-  // level-synchronous BFS by edge relaxation; writers of one level all store the same value
-  const int depth = max(k, l2);
+  // level-synchronous BFS by edge relaxation; writers of one level all store the same value.  The bio transform
+  // (k < 0: substructure = the whole graph; l2 < 0: context = everything farther than l1, unreachable nodes included)
+  // only has to know which nodes lie within l1 hops.
+  const bool whole = k < 0, open_end = l2 < 0;
+  const int depth = open_end ? (whole ? l1 : max(k, l1)) : max(k, l2);
   for (int level = 0; level < depth; ++level) {
     wave_fence();
     bool grew = false;
@@ -339,7 +342,8 @@ __global__ void __launch_bounds__(256) k_ctx_plan(const int64_t* __restrict__ id
   for (int64_t b0 = 0; b0 < n; b0 += 64) {
     const int64_t a = b0 + lane;
     const int d = a < n ? ld_i32(&dist[n0 + a]) : -1;
-    const bool s = d >= 0 && d <= k, c = d > l1 && d <= l2;
+    const bool s = a < n && (whole || (d >= 0 && d <= k));
+    const bool c = a < n && (open_end ? (d < 0 || d > l1) : (d > l1 && d <= l2));
     int ts, tc, to;
     const int rs = wave_excl_rank(s, lane, &ts), rc = wave_excl_rank(c, lane, &tc);
     (void)wave_excl_rank(s && c, lane, &to);
@@ -415,7 +419,7 @@ __global__ void __launch_bounds__(kBlock) k_ctx_fill_nodes(
     const int64_t* __restrict__ ids, int64_t B, int64_t G, const int64_t* __restrict__ node_slice,
     const int64_t* __restrict__ node_off, const int64_t* __restrict__ offs, const int64_t* __restrict__ counts,
     const int64_t* __restrict__ root, const int32_t* __restrict__ sub_rank, const int32_t* __restrict__ ctx_rank,
-    const int64_t* __restrict__ x_all, int x_cols, int64_t* __restrict__ x_sub, int64_t* __restrict__ x_ctx,
+    const int32_t* __restrict__ x_all, int x_cols, int32_t* __restrict__ x_sub, int32_t* __restrict__ x_ctx,
     int64_t* __restrict__ center_idx, int64_t* __restrict__ overlap_idx, int64_t* __restrict__ overlap_batch,
     int64_t* __restrict__ overlap_size) {
   const int64_t n = node_off[B];
@@ -456,8 +460,8 @@ __global__ void __launch_bounds__(kBlock) k_ctx_fill_edges(
     const int64_t* __restrict__ node_off, const int64_t* __restrict__ edge_off, const int64_t* __restrict__ offs,
     const int64_t* __restrict__ counts, const int32_t* __restrict__ sub_rank, const int32_t* __restrict__ ctx_rank,
     const int32_t* __restrict__ esub_rank, const int32_t* __restrict__ ectx_rank, const int64_t* __restrict__ ei_all,
-    int64_t e_all, const int64_t* __restrict__ attr_all, int attr_cols, int64_t* __restrict__ ei_sub, int64_t* __restrict__ ea_sub,
-    int64_t* __restrict__ ei_ctx, int64_t* __restrict__ ea_ctx) {
+    int64_t e_all, const int32_t* __restrict__ attr_all, int attr_cols, int64_t* __restrict__ ei_sub, int32_t* __restrict__ ea_sub,
+    int64_t* __restrict__ ei_ctx, int32_t* __restrict__ ea_ctx, int ctx_zero_from) {
   const int64_t e = edge_off[B];
   const int64_t* o_nsub = offs;
   const int64_t* o_esub = offs + 1 * (B + 1);
@@ -481,7 +485,7 @@ __global__ void __launch_bounds__(kBlock) k_ctx_fill_edges(
       const int64_t w = o_ectx[g] + rc;
       ei_ctx[w] = o_nctx[g] + ctx_rank[u];
       ei_ctx[tot_ectx + w] = o_nctx[g] + ctx_rank[v];
-      for (int c = 0; c < attr_cols; ++c) ea_ctx[w * attr_cols + c] = attr_all[src * attr_cols + c];
+      for (int c = 0; c < attr_cols; ++c) ea_ctx[w * attr_cols + c] = c >= ctx_zero_from ? 0 : attr_all[src * attr_cols + c];
     }
   }
 }
@@ -496,7 +500,8 @@ int pgnn_substruct_context_plan(const int64_t* graph_ids, int64_t num_graphs, in
                                 const int64_t* roots, uint64_t seed, int k, int l1, int l2, int32_t* dist,
                                 int32_t* sub_rank, int32_t* ctx_rank, int32_t* esub_rank, int32_t* ectx_rank,
                                 int64_t* counts, int64_t* root_out, int64_t* offsets, pgnn_stream stream) {
-  PGNN_REQUIRE(num_graphs > 0 && k >= 0 && l1 >= 0 && l2 >= l1, "bad substruct_context_plan arguments");
+  PGNN_REQUIRE(num_graphs > 0 && l1 >= 0 && (k >= 0 || k == -1) && (l2 >= l1 || l2 == -1),
+               "bad substruct_context_plan arguments");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_ctx_plan, dim3((int)ceil_div(num_graphs, 4)), dim3(256), 0, st, graph_ids, num_graphs, dataset_graphs,
                      node_slice, edge_slice, node_off, edge_off, edge_index_all, edges_all, roots, seed, k, l1, l2, dist,
@@ -509,24 +514,31 @@ int pgnn_substruct_context_fill(const int64_t* graph_ids, int64_t num_graphs, in
                                 const int64_t* node_slice, const int64_t* edge_slice, const int64_t* node_off,
                                 const int64_t* edge_off, const int64_t* offsets, const int64_t* counts,
                                 const int64_t* root, const int32_t* sub_rank, const int32_t* ctx_rank,
-                                const int32_t* esub_rank, const int32_t* ectx_rank, const int64_t* x_all, int64_t x_cols,
-                                const int64_t* edge_index_all, int64_t edges_all, const int64_t* edge_attr_all,
-                                int64_t attr_cols, int64_t num_nodes, int64_t num_edges, int64_t* x_substruct,
-                                int64_t* edge_index_substruct, int64_t* edge_attr_substruct, int64_t* x_context,
-                                int64_t* edge_index_context, int64_t* edge_attr_context, int64_t* center_substruct_idx,
+                                const int32_t* esub_rank, const int32_t* ectx_rank, const void* x_all, int64_t x_row_bytes,
+                                const int64_t* edge_index_all, int64_t edges_all, const void* edge_attr_all,
+                                int64_t attr_row_bytes, int64_t context_attr_zero_from_byte, int64_t num_nodes,
+                                int64_t num_edges, void* x_substruct, int64_t* edge_index_substruct,
+                                void* edge_attr_substruct, void* x_context, int64_t* edge_index_context,
+                                void* edge_attr_context, int64_t* center_substruct_idx,
                                 int64_t* overlap_context_substruct_idx, int64_t* batch_overlapped_context,
                                 int64_t* overlapped_context_size, pgnn_stream stream) {
-  PGNN_REQUIRE(num_graphs > 0 && x_cols > 0 && attr_cols > 0, "bad substruct_context_fill arguments");
+  PGNN_REQUIRE(num_graphs > 0 && x_row_bytes > 0 && attr_row_bytes > 0 && x_row_bytes % 4 == 0 && attr_row_bytes % 4 == 0 &&
+                   (context_attr_zero_from_byte < 0 || context_attr_zero_from_byte % 4 == 0),
+               "bad substruct_context_fill arguments (feature rows are copied as 32-bit words)");
   hipStream_t st = (hipStream_t)stream;
+  const int xw = (int)(x_row_bytes / 4), aw = (int)(attr_row_bytes / 4);
+  const int zero_from = context_attr_zero_from_byte < 0 ? aw : (int)(context_attr_zero_from_byte / 4);
   hipLaunchKernelGGL(k_ctx_fill_nodes, dim3(grid_for(std::max(num_nodes, num_graphs))), dim3(kBlock), 0, st, graph_ids,
-                     num_graphs, dataset_graphs, node_slice, node_off, offsets, counts, root, sub_rank, ctx_rank, x_all,
-                     (int)x_cols, x_substruct, x_context, center_substruct_idx, overlap_context_substruct_idx,
+                     num_graphs, dataset_graphs, node_slice, node_off, offsets, counts, root, sub_rank, ctx_rank,
+                     static_cast<const int32_t*>(x_all), xw, static_cast<int32_t*>(x_substruct),
+                     static_cast<int32_t*>(x_context), center_substruct_idx, overlap_context_substruct_idx,
                      batch_overlapped_context, overlapped_context_size);
   if (num_edges > 0)
     hipLaunchKernelGGL(k_ctx_fill_edges, dim3(grid_for(num_edges)), dim3(kBlock), 0, st, graph_ids, num_graphs,
                        dataset_graphs, edge_slice, node_off, edge_off, offsets, counts, sub_rank, ctx_rank, esub_rank,
-                       ectx_rank, edge_index_all, edges_all, edge_attr_all, (int)attr_cols, edge_index_substruct,
-                       edge_attr_substruct, edge_index_context, edge_attr_context);
+                       ectx_rank, edge_index_all, edges_all, static_cast<const int32_t*>(edge_attr_all), aw,
+                       edge_index_substruct, static_cast<int32_t*>(edge_attr_substruct), edge_index_context,
+                       static_cast<int32_t*>(edge_attr_context), zero_from);
   return check_launch("substruct_context_fill");
 }
 

@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(kBlock) k_mean_l2norm_bwd(const float* __restr
   }
 }
 
-inline int rows_grid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, kBlock / 64), 16 * kNumCU)); }
+inline int rows_grid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, kBlock / 64), 16 * num_cu())); }
 
 }  // namespace
 

@@ -41,7 +41,7 @@ class ResidentDataset:
     ``slices['edge_attr']``.
     """
 
-    def __init__(self, x, edge_index, edge_attr, node_slice, edge_slice, device="cuda"):
+    def __init__(self, x, edge_index, edge_attr, node_slice, edge_slice, device="cuda", center_node_idx=None):
         node_slice = torch.as_tensor(node_slice, dtype=torch.int64).cpu()
         edge_slice = torch.as_tensor(edge_slice, dtype=torch.int64).cpu()
         if node_slice.numel() != edge_slice.numel() or node_slice.numel() < 2:
@@ -62,6 +62,10 @@ class ResidentDataset:
         self._nodes = np.diff(node_slice.numpy())
         self._edges = np.diff(edge_slice.numpy())
         self.num_graphs = int(self._nodes.size)
+        # bio ego nets: the graph-local index of every graph's centre node (bio/loader.py:50-51), host copy
+        self._center = None if center_node_idx is None else np.asarray(torch.as_tensor(center_node_idx).cpu(), dtype=np.int64).reshape(-1)
+        if self._center is not None and self._center.size != self.num_graphs:
+            raise ValueError("center_node_idx must hold one entry per graph")
 
     def __len__(self):
         return self.num_graphs
@@ -71,14 +75,18 @@ class ResidentDataset:
         """from a list of per-graph ``Data`` objects (x, edge_index, edge_attr)"""
         ns = np.cumsum([0] + [g.x.size(0) for g in graphs])
         es = np.cumsum([0] + [g.edge_index.size(1) for g in graphs])
+        center = None
+        if all(getattr(g, "center_node_idx", None) is not None for g in graphs):
+            center = torch.cat([g.center_node_idx.view(-1)[:1] for g in graphs])
         return cls(torch.cat([g.x for g in graphs], 0), torch.cat([g.edge_index for g in graphs], 1),
-                   torch.cat([g.edge_attr for g in graphs], 0), ns, es, device)
+                   torch.cat([g.edge_attr for g in graphs], 0), ns, es, device, center_node_idx=center)
 
     @classmethod
     def from_inmemory(cls, data, slices, device="cuda"):
         """from the ``(data, slices)`` pair of a torch_geometric InMemoryDataset processed file
         (what ``torch.load(processed_paths[0])`` returns in chem/loader.py / bio/loader.py)"""
-        return cls(data.x, data.edge_index, data.edge_attr, slices["x"], slices["edge_attr"], device)
+        return cls(data.x, data.edge_index, data.edge_attr, slices["x"], slices["edge_attr"], device,
+                   center_node_idx=getattr(data, "center_node_idx", None))
 
     # ------------------------------------------------------------------ batching
     def _ids(self, graph_ids, ids_device=None):
@@ -169,12 +177,26 @@ class ResidentDataset:
         return out
 
     def collate_substruct_context(self, graph_ids, k=5, l1=4, l2=7, seed=0, roots=None, ids_device=None):
-        """ExtractSubstructureContextPair(k, l1, l2) (chem/util.py:96-149) on every graph of the batch, then
-        BatchSubstructContext.from_data_list (chem/batch.py:141-210), all on the device.  ``roots``
-        (graph-local atom per graph; the reference's ``root_idx`` debugging hook) replaces the random root.
-        One host sync: the five totals that size the outputs (sub-graph sizes are data dependent)."""
-        if self.x.dtype != torch.int64 or self.edge_attr.dtype != torch.int64:
-            raise _lib.PgnnError("substructure/context extraction is defined for the chem datasets")
+        """ExtractSubstructureContextPair + BatchSubstructContext.from_data_list on the device.
+        chem (integer features): ExtractSubstructureContextPair(k, l1, l2) (chem/util.py:96-149, chem/batch.py:141-210);
+        ``roots`` (graph-local atom per graph; the reference's ``root_idx`` debugging hook) replaces the random root.
+        bio (float features): ExtractSubstructureContextPair(l1, center=True) (bio/util.py:123-209, bio/batch.py:127-232):
+        the substructure is the whole ego net, the context every node farther than ``l1`` hops from the centre node;
+        ``k`` / ``l2`` are ignored, the roots are the dataset's ``center_node_idx``.
+        One host sync: the totals that size the outputs (sub-graph sizes are data dependent)."""
+        bio = self.x.dtype == torch.float32
+        if bio:
+            if self.edge_attr.dtype != torch.float32 or self.edge_attr.size(1) != 9:
+                raise _lib.PgnnError("bio substructure/context extraction needs float32 [E, 9] edge attributes")
+            if roots is None:
+                if self._center is None:
+                    raise _lib.PgnnError("bio substructure/context extraction needs the dataset's center_node_idx")
+                roots = self._center[np.asarray(graph_ids, dtype=np.int64).reshape(-1)]
+            k, l2, zero_from = -1, -1, 7 * 4
+        else:
+            if self.x.dtype != torch.int64 or self.edge_attr.dtype != torch.int64:
+                raise _lib.PgnnError("substructure/context extraction is defined for the chem (int64) and bio (float32) datasets")
+            zero_from = -1
         lib, sp, dev = load(), stream_ptr(), self.device
         ids_host, ids = self._ids(graph_ids, ids_device)
         b = ids_host.size
@@ -203,12 +225,12 @@ class ResidentDataset:
         n_sub, e_sub, n_ctx, e_ctx, n_ov, kept = [int(v) for v in coffs[:, b].tolist()]  # the one sync
         cx, ca = self.x.size(1), self.edge_attr.size(1)
         out = Data()
-        out.x_substruct = torch.empty(n_sub, cx, dtype=torch.int64, device=dev)
+        out.x_substruct = torch.empty(n_sub, cx, dtype=self.x.dtype, device=dev)
         out.edge_index_substruct = torch.empty(2, e_sub, dtype=torch.int64, device=dev)
-        out.edge_attr_substruct = torch.empty(e_sub, ca, dtype=torch.int64, device=dev)
-        out.x_context = torch.empty(n_ctx, cx, dtype=torch.int64, device=dev)
+        out.edge_attr_substruct = torch.empty(e_sub, ca, dtype=self.edge_attr.dtype, device=dev)
+        out.x_context = torch.empty(n_ctx, cx, dtype=self.x.dtype, device=dev)
         out.edge_index_context = torch.empty(2, e_ctx, dtype=torch.int64, device=dev)
-        out.edge_attr_context = torch.empty(e_ctx, ca, dtype=torch.int64, device=dev)
+        out.edge_attr_context = torch.empty(e_ctx, ca, dtype=self.edge_attr.dtype, device=dev)
         out.center_substruct_idx = torch.empty(kept, dtype=torch.int64, device=dev)
         out.overlap_context_substruct_idx = torch.empty(n_ov, dtype=torch.int64, device=dev)
         out.batch_overlapped_context = torch.empty(n_ov, dtype=torch.int64, device=dev)
@@ -217,8 +239,9 @@ class ResidentDataset:
             check(lib.pgnn_substruct_context_fill(
                 ids.data_ptr(), b, self.num_graphs, self.node_slice.data_ptr(), self.edge_slice.data_ptr(),
                 offs[0].data_ptr(), offs[1].data_ptr(), coffs.data_ptr(), counts.data_ptr(), root_out.data_ptr(),
-                inode[1].data_ptr(), inode[2].data_ptr(), iedge[0].data_ptr(), iedge[1].data_ptr(), self.x.data_ptr(), cx,
-                self.edge_index.data_ptr(), self.edge_index.size(1), self.edge_attr.data_ptr(), ca, n, e,
+                inode[1].data_ptr(), inode[2].data_ptr(), iedge[0].data_ptr(), iedge[1].data_ptr(), self.x.data_ptr(),
+                cx * self.x.element_size(), self.edge_index.data_ptr(), self.edge_index.size(1), self.edge_attr.data_ptr(),
+                ca * self.edge_attr.element_size(), zero_from, n, e,
                 out.x_substruct.data_ptr(), out.edge_index_substruct.data_ptr(), out.edge_attr_substruct.data_ptr(),
                 out.x_context.data_ptr(), out.edge_index_context.data_ptr(), out.edge_attr_context.data_ptr(),
                 out.center_substruct_idx.data_ptr(), out.overlap_context_substruct_idx.data_ptr(),
