@@ -351,13 +351,16 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 //          prof[block][8] = {loader vmcnt wait, loader barrier, loader issue, consumer barrier, consumer work,
 //          block total, steps, 0} (pgnn_debug_aggregate_profile)
 typedef float v4f_t __attribute__((ext_vector_type(4)));
-template <bool TABLE, int P, int NROW, bool PRE, int POL>
+// WEIGHT: GCN symmetric normaliser w_e = dinv[i] * dinv[src_e], w_ii = dinv[i]^2 (chem/model.py:73-82,104).  dinv of the
+// block's rows and of the 8-row halo either side sits in LDS (every source inside the ring window is covered), the
+// products are formed exactly as k_aggregate_grp forms them: the two kernels are bit-identical.
+template <bool TABLE, int P, int NROW, bool PRE, int POL, bool WEIGHT>
 __global__ void __launch_bounds__(704)
 k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ ptr,
                 const int32_t* __restrict__ nbr, const uint8_t* __restrict__ code,
                 const float* __restrict__ emb1, const float* __restrict__ emb2, float* __restrict__ out,
                 int64_t ldo, int n, int dim, int npb, const float* __restrict__ pre_coef, int pre_relu,
-                unsigned long long* __restrict__ prof) {
+                unsigned long long* __restrict__ prof, const float* __restrict__ dinv) {
 #pragma clang fp contract(off)
   constexpr int NREG = P + 3, NBUF = P + 1;
   constexpr int AUX = (POL & 1) ? 2 : 0;
@@ -372,6 +375,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
   int* ptrL = reinterpret_cast<int*>(ring + NREG * row_f4);                          // [npb+1]
   int* idxL = ptrL + (kDmaMaxNodes + 4);                                             // [NBUF][64]
   int* codeL = idxL + NBUF * kDmaEdges;                                              // [NBUF][64] (byte DMA lands as dwords)
+  float* dinvL = reinterpret_cast<float*>(codeL + NBUF * kDmaEdges);                 // [8 (nsteps + 2)] rows n0-8 .. (WEIGHT)
   const float4* __restrict__ T4 = reinterpret_cast<const float4*>(T);
   const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
   const int64_t ldx4 = ldx >> 2, ldo4 = ldo >> 2;
@@ -486,6 +490,11 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
     }
   }
   for (int q = t; q <= cnt; q += cthreads) ptrL[q] = ptr[n0 + q];
+  if (WEIGHT)
+    for (int q = t; q < (nsteps + 2) * kDmaG; q += cthreads) {  // the ring window of the last step ends at n0 + 8 nsteps + 8
+      const int r = n0 - kDmaG + q;
+      dinvL[q] = (r >= 0 && r < n) ? dinv[r] : 0.f;
+    }
   __syncthreads();  // prologue
 
   // per-step row pointers are read one step ahead (they sit in LDS for the whole block), so the chain
@@ -520,6 +529,11 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
     // the node's own row (self loop) does not depend on the edge list: fetch it first
     float4 self = act(ring[slot_of(i) * gs + c4]);
     if (TABLE) self = f4_add(self, T4[kSelfLoopCode * gs + c4]);
+    float di = 1.f;
+    if (WEIGHT) {
+      di = dinvL[li + kDmaG];
+      self = f4_scale(self, di * di);
+    }
     float4 acc = f4_zero();
     // edges gathered per batch.  Measured on the roofline batch: 2 -> 225-234 us, 1 -> 240, 3/4 -> 245;
     // keeping the common bond-table rows in registers (select chain) was a loss (320-360 us).
@@ -550,6 +564,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
             const int sj = nbr[p + j];
             float4 m = act(x4[(int64_t)sj * ldx4 + c4]);
             if (TABLE) m = f4_add(m, T4[(int)code[p + j] * gs + c4]);
+            if (WEIGHT) m = f4_scale(m, di * dinv[sj]);
             acc = f4_add(acc, m);
           }
         }
@@ -567,6 +582,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
           if (p + j < end) {
             float4 m = act(v[j]);
             if (TABLE) m = f4_add(m, tv[j]);
+            if (WEIGHT) m = f4_scale(m, di * dinvL[sidx[j] - n0 + kDmaG]);
             acc = f4_add(acc, m);
           }
         }
@@ -589,15 +605,16 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
 unsigned long long* g_agg_prof = nullptr;  // set by pgnn_debug_aggregate_profile
 int64_t g_agg_prof_blocks = 0;
 
-template <bool TABLE, int P, int NROW, bool PRE = false, int POL = 0>
+template <bool TABLE, int P, int NROW, bool PRE = false, int POL = 0, bool WEIGHT = false>
 int launch_aggregate_dma_p(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* nbr, const uint8_t* code,
                            const float* emb1, const float* emb2, float* out, int64_t ldo, int64_t n, int64_t dim,
-                           hipStream_t st, const float* pre_coef = nullptr, int pre_relu = 0) {
+                           hipStream_t st, const float* pre_coef = nullptr, int pre_relu = 0, const float* dinv = nullptr) {
   const int gs = (int)(dim / 4);
   const int cthreads = (int)align_up((size_t)kDmaG * gs, kWave);
   const int threads = cthreads + kWave;
   const size_t lds = (size_t)(TABLE ? kNumCodes * dim : 0) * 4 + (size_t)(P + 3) * kDmaG * dim * 4 +
-                     (size_t)(kDmaMaxNodes + 4) * 4 + (size_t)2 * (P + 1) * kDmaEdges * 4 + 64;
+                     (size_t)(kDmaMaxNodes + 4) * 4 + (size_t)2 * (P + 1) * kDmaEdges * 4 +
+                     (WEIGHT ? (size_t)(kDmaMaxNodes + 3 * kDmaG) * 4 : 0) + 64;
   const int resident = (int)std::max<size_t>(1, (160 * 1024) / lds);
   const int64_t target_blocks = (int64_t)num_cu() * std::min(resident, env_int("PGNN_DMA_BPC", 2));
   int64_t npb = ceil_div(n, target_blocks);
@@ -606,9 +623,9 @@ int launch_aggregate_dma_p(const float* x, int64_t ldx, const int32_t* ptr, cons
   if (npb > kDmaMaxNodes) npb = kDmaMaxNodes;
   const int grid = (int)ceil_div(n, npb);
   unsigned long long* prof = ((POL & 8) && g_agg_prof_blocks >= grid) ? g_agg_prof : nullptr;
-  allow_big_lds((const void*)k_aggregate_dma<TABLE, P, NROW, PRE, POL>, lds);
-  hipLaunchKernelGGL((k_aggregate_dma<TABLE, P, NROW, PRE, POL>), dim3(grid), dim3(threads), lds, st, x, ldx, ptr, nbr, code,
-                     emb1, emb2, out, ldo, (int)n, (int)dim, (int)npb, pre_coef, pre_relu, prof);
+  allow_big_lds((const void*)k_aggregate_dma<TABLE, P, NROW, PRE, POL, WEIGHT>, lds);
+  hipLaunchKernelGGL((k_aggregate_dma<TABLE, P, NROW, PRE, POL, WEIGHT>), dim3(grid), dim3(threads), lds, st, x, ldx, ptr, nbr,
+                     code, emb1, emb2, out, ldo, (int)n, (int)dim, (int)npb, pre_coef, pre_relu, prof, dinv);
   return check_launch("aggregate_dma");
 }
 
@@ -665,11 +682,28 @@ int launch_aggregate_dma(const float* x, int64_t ldx, const int32_t* ptr, const 
 #undef PGNN_DMA_ARGS
 }
 
+// GCN-weighted aggregation on the loader/consumer kernel (D = 300 gets the tuned row-DMA instantiation)
+template <bool TABLE>
+int launch_aggregate_dma_weighted(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* nbr, const uint8_t* code,
+                                  const float* emb1, const float* emb2, const float* dinv, float* out, int64_t ldo,
+                                  int64_t n, int64_t dim, hipStream_t st) {
+  const int nrow = (int)ceil_div(kDmaG * (dim / 4), kWave);
+  const bool small_ld = ldx * 4 * kDmaG < (1ll << 31);
+  const bool nt = env_int("PGNN_DMA_POL", (int64_t)n * dim * 4 >= (128ll << 20) ? 3 : 0) == 3;
+  if (nrow == 10 && small_ld) {
+    if (nt) return launch_aggregate_dma_p<TABLE, 2, 10, false, 3, true>(x, ldx, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, nullptr, 0, dinv);
+    return launch_aggregate_dma_p<TABLE, 2, 10, false, 0, true>(x, ldx, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, nullptr, 0, dinv);
+  }
+  return launch_aggregate_dma_p<TABLE, 2, 0, false, 0, true>(x, ldx, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, nullptr, 0, dinv);
+}
+
 template <bool TABLE, bool WEIGHT>
 int launch_aggregate(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* nbr,
                      const uint8_t* code, const float* emb1, const float* emb2, const float* dinv,
                      float* out, int64_t ldo, int64_t n, int64_t dim, hipStream_t st) {
-  const int variant = env_int("PGNN_AGG_VARIANT", dim <= 320 ? (WEIGHT ? 1 : 3) : 1);
+  const int variant = env_int("PGNN_AGG_VARIANT", dim <= 320 ? 3 : 1);
+  if (variant == 3 && dim <= 320 && WEIGHT)
+    return launch_aggregate_dma_weighted<TABLE>(x, ldx, ptr, nbr, code, emb1, emb2, dinv, out, ldo, n, dim, st);
   if (variant == 3 && dim <= 320 && !WEIGHT)
     return launch_aggregate_dma<TABLE>(x, ldx, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st);
   if (variant >= 1)

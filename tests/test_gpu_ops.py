@@ -141,6 +141,41 @@ def test_aggregate_variants_agree_bitwise(monkeypatch):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("shape", ["molecules", "random", "hub"])
+def test_gcn_weighted_aggregate_variants_agree_bitwise(shape, monkeypatch):
+    """GCN's dinv[i]*dinv[src] weights (chem/model.py:73-82,104) on the loader/consumer DMA kernel (dinv of the block
+    + halo staged in LDS) == the group-per-node and wave-per-node kernels, forward and transposed (backward) CSR;
+    "random" sends most edges down the out-of-window slow path, "hub" overflows the 64 staged edge slots"""
+    ops = _ops()
+    if shape == "molecules":
+        b = synthetic.chem_masking_batch(200, seed=4).to(DEV)
+        ei, ea, n = b.edge_index, b.edge_attr, b.x.size(0)
+    else:
+        n = 3000
+        ei, ea = _rand_graph(n, 9000, seed=12, paired=False)
+        if shape == "hub":
+            ei[0, :700] = 1234
+        ei, ea = ei.to(DEV), ea.to(DEV)
+    g = ops.build_chem_graph(ei, ea, n, gcn=True)
+    torch.manual_seed(1)
+    x = torch.randn(n, 300, device=DEV)
+    e1, e2 = torch.randn(6, 300, device=DEV), torch.randn(3, 300, device=DEV)
+    lib, sp = ops.load(), ops.stream_ptr()
+    outs = []
+    for v in ("0", "1", "3"):
+        monkeypatch.setenv("PGNN_AGG_VARIANT", v)
+        lib.pgnn_reload_env()
+        fwd = ops.ChemAggregate.apply(x, e1, e2, g).clone()
+        bwd = torch.empty_like(x)
+        ops.check(lib.pgnn_neighbor_sum(x.data_ptr(), 300, g.out_ptr.data_ptr(), g.out_dst.data_ptr(), g.dinv.data_ptr(),
+                                        bwd.data_ptr(), 300, n, 300, sp), "neighbor_sum")
+        outs.append((fwd, bwd))
+    monkeypatch.delenv("PGNN_AGG_VARIANT")
+    lib.pgnn_reload_env()
+    for f, b_ in outs[1:]:
+        assert torch.equal(outs[0][0], f) and torch.equal(outs[0][1], b_)
+
+
 def test_chem_aggregate_backward_and_gcn():
     ops = _ops()
     n, dim = 500, 300
