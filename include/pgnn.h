@@ -393,6 +393,45 @@ int pgnn_substruct_context_fill(const int64_t* graph_ids, int64_t num_graphs, in
  * Feature rows (int64 [N,2] / [E,2] for chem, float [N,1] / [E,9] for bio) are copied as 32-bit words:
  * x_row_bytes / attr_row_bytes must be multiples of 4; context_attr_zero_from_byte < 0 copies whole rows. */
 
+/* ------------------------------------------------------------------------------------------
+ * Attention layers (off the north-star path, native and deterministic): csrc/attention.hip.
+ * ------------------------------------------------------------------------------------------ */
+
+/* 2-head GATConv message / edge soft-max / aggregate / update of chem/model.py:133-162 on the CSR of the graph build:
+ *   xh [N, 2*dim]      weight_linear(x), heads side by side (chem/model.py:144)
+ *   emb1 [6, 2*dim], emb2 [3, 2*dim], ctab [18, 2] = (emb1[t] + emb2[d]) . att[h, dim:2dim]  (host-side, parameter space)
+ *   att [2, 2*dim]     the reference's `att` parameter [1, heads, 2*emb_dim]; bias [dim]
+ *   scores [N, 4], z / alpha [E + N, 2] (slot p of node i at p + i, self loop at in_ptr[i+1] + i), cfa [2, N, 9]: saved
+ *   for the backward; out [N, dim].
+ * The soft-max follows torch_geometric 1.0.3 on torch_scatter 1.1.2 (shift = max(0, segment max), + 1e-16).
+ * (edge_emb / cslot: per-slot edge terms instead of the bond tables -- the bio form; pass NULL with the chem tables.) */
+int pgnn_gat_fwd(const float* xh, int64_t ldx, const int32_t* in_ptr, const int32_t* in_src, const uint8_t* in_code,
+                 const float* emb1, const float* emb2, const float* edge_emb, const float* ctab, const float* cslot,
+                 const float* att, const float* bias, float negative_slope, float* scores, float* z, float* alpha, float* cfa,
+                 float* out, int64_t ldo, int64_t num_nodes, int64_t dim, pgnn_stream stream);
+/* backward: dalpha [E + N, 2] scratch (receives dz), dsd [2, N, 2] = per head (sum dz over the in-segment, sum dz over the
+ * out-edges + self), czf [2, N, 9] = dz per bond type / direction, wout [E, 2] scratch, dxh [N, 2*dim].  The parameter
+ * gradients follow from these with pgnn_rowfeat_matmul_bwd (kc = 2: att; kc = 9: bond tables) -- see ops.GATAggregate. */
+int pgnn_gat_bwd(const float* g, int64_t ldg, const float* xh, int64_t ldx, const int32_t* in_ptr, const int32_t* in_src,
+                 const uint8_t* in_code, const int32_t* out_ptr, const int32_t* out_dst, const float* emb1, const float* emb2,
+                 const float* edge_emb, const float* att, float negative_slope, const float* z, const float* alpha,
+                 float* dalpha, float* dsd, float* czf, float* wout, float* dxh, int64_t ldd, int64_t num_nodes, int64_t dim,
+                 pgnn_stream stream);
+
+/* soft-max over segments (torch_geometric.utils.softmax 1.0.3): items perm[ptr[s] .. ptr[s+1]) (perm NULL = identity),
+ * z / alpha [items, heads].  GlobalAttention gate and Set2Set attention (chem/model.py:329-339). */
+int pgnn_segment_softmax_fwd(const float* z, const int32_t* ptr, const int32_t* perm, float* alpha, int64_t num_segments,
+                             int64_t heads, pgnn_stream stream);
+int pgnn_segment_softmax_bwd(const float* alpha, const float* dalpha, const int32_t* ptr, const int32_t* perm, float* dz,
+                             int64_t num_segments, int64_t heads, pgnn_stream stream);
+
+/* global_max_pool (chem/model.py:327-328): column-wise max over the items of a segment (empty segment -> 0) and the item
+ * that attains it (arg [segments, dim], first maximum); backward routes g[key[i]] to the arg items. */
+int pgnn_segment_max_fwd(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* perm, float* out, int64_t ldo,
+                         int32_t* arg, int64_t num_segments, int64_t dim, pgnn_stream stream);
+int pgnn_segment_max_bwd(const float* g, int64_t ldg, const int64_t* key, const int32_t* arg, float* dx, int64_t ldd,
+                         int64_t num_segments, int64_t num_items, int64_t dim, pgnn_stream stream);
+
 /* diagnostics: plain float4 grid-stride copy (the HBM streaming ceiling bench.py quotes next to the
  * aggregation kernel).  Not part of the hot path. */
 int pgnn_debug_stream_copy(const float* src, float* dst, int64_t n_floats, int64_t blocks, pgnn_stream stream);

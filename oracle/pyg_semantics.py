@@ -117,6 +117,9 @@ def global_mean_pool(x, batch, size=None):
 
 
 def global_max_pool(x, batch, size=None):
+    """scatter_('max') of torch_geometric 1.0.3: filled with -1e38, the fill value replaced by 0 afterwards (a graph
+    without nodes pools to 0)."""
     size = int(batch.max().item()) + 1 if size is None else size
-    out = torch.full((size, x.size(1)), float("-inf"), dtype=x.dtype, device=x.device)
-    return out.scatter_reduce(0, batch.unsqueeze(-1).expand_as(x), x, reduce="amax", include_self=True)
+    out = torch.full((size, x.size(1)), -1e38, dtype=x.dtype, device=x.device)
+    out = out.scatter_reduce(0, batch.unsqueeze(-1).expand_as(x), x, reduce="amax", include_self=True)
+    return torch.where(out == -1e38, torch.zeros_like(out), out)

@@ -79,6 +79,13 @@ PROTOTYPES = {
                                          _p, _p, _p, _p, _p]),
     "pgnn_substruct_context_fill": (_i, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _i64,
                                          _p, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "pgnn_gat_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
+    "pgnn_gat_bwd": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _i64, _i64,
+                          _i64, _p]),
+    "pgnn_segment_softmax_fwd": (_i, [_p, _p, _p, _p, _i64, _i64, _p]),
+    "pgnn_segment_softmax_bwd": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _p]),
+    "pgnn_segment_max_fwd": (_i, [_p, _i64, _p, _p, _p, _i64, _p, _i64, _i64, _p]),
+    "pgnn_segment_max_bwd": (_i, [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _p]),
     "pgnn_debug_stream_copy": (_i, [_p, _p, _i64, _i64, _p]),
     "pgnn_debug_aggregate_profile": (_i, [_p, _i64]),
 }

@@ -1,20 +1,22 @@
-"""Attention-flavoured parts of the class surface: GAT message passing, GlobalAttention
-and Set2Set pooling.
+"""Attention-flavoured parts of the class surface: GATConv message passing, GlobalAttention and
+Set2Set pooling.  Not on the north-star hot path (GIN / GCN), but native since round 2:
 
-These are NOT on the north-star hot path (GIN/GCN message passing) and carry no performance claim: the
-dense projections run on the library's MFMA GEMM, the per-edge softmax / weighted scatter is a plain
-composition of torch GPU ops (gathers, ``scatter_reduce``, ``index_add_`` -- atomic, hence reproducible
-only to rounding), exactly the shape of computation the reference performs through torch_geometric.
-They exist so that every ``gnn_type`` / ``graph_pooling`` value of the reference's ``GNN`` /
-``GNN_graphpred`` constructs, loads the shipped ``gat_*.pth`` checkpoints and trains on the GPU.
+* chem GATConv runs on csrc/attention.hip (``ops.GATAggregate``: CSR edge soft-max + weighted aggregate, two heads,
+  deterministic); the bio GATConv -- whose edge term is a dense ``Linear(9, 2D)`` of per-edge float attributes --
+  keeps the composition of torch GPU ops below (``gat_propagate``), like the reference's own torch_geometric path;
+* GlobalAttention / Set2Set take their soft-max from ``ops.segment_softmax`` (pgnn_segment_softmax_*) and their
+  weighted sums from the deterministic segment-sum kernel (``ops.global_add_pool``).
 """
 import torch
 import torch.nn.functional as F
 
+from . import ops
+
 
 def segment_softmax(src, index, num_segments):
     """torch_geometric.utils.softmax (1.0.3): per segment subtract the max, exp, divide by sum + 1e-16.  The pinned
-    torch_scatter 1.1.2 pre-fills scatter_max's output with 0, i.e. the shift is max(0, segment max) -- reproduced."""
+    torch_scatter 1.1.2 pre-fills scatter_max's output with 0, i.e. the shift is max(0, segment max) -- reproduced.
+    (torch-op form, used by the bio GATConv only.)"""
     idx = index.view(-1, *([1] * (src.dim() - 1))).expand_as(src)
     mx = torch.zeros((num_segments,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
     mx = mx.scatter_reduce(0, idx, src, reduce="amax", include_self=True)
@@ -47,7 +49,8 @@ def gat_propagate(xh, edge_index, edge_emb, self_emb, att, bias, heads, negative
 
 
 class GlobalAttention(torch.nn.Module):
-    """torch_geometric.nn.GlobalAttention(gate_nn) as used by chem/model.py:329-333."""
+    """torch_geometric.nn.GlobalAttention(gate_nn) as used by chem/model.py:329-333: soft-max of the gate over the nodes
+    of a graph (HIP segment soft-max), then the gate-weighted sum (HIP segment sum)."""
 
     def __init__(self, gate_nn):
         super().__init__()
@@ -55,8 +58,8 @@ class GlobalAttention(torch.nn.Module):
 
     def forward(self, x, batch, size=None):
         size = int(batch.max().item()) + 1 if size is None else size
-        gate = segment_softmax(self.gate_nn(x).view(-1, 1), batch, size)
-        return torch.zeros(size, x.size(1), dtype=x.dtype, device=x.device).index_add_(0, batch, gate * x)
+        gate = ops.segment_softmax(self.gate_nn(x).view(-1, 1), batch, size)
+        return ops.global_add_pool(gate * x, batch, size)
 
 
 class Set2Set(torch.nn.Module):
@@ -76,7 +79,7 @@ class Set2Set(torch.nn.Module):
         for _ in range(self.processing_steps):
             q, h = self.lstm(q_star.unsqueeze(0), h)
             q = q.view(size, self.in_channels)
-            a = segment_softmax((x * q[batch]).sum(dim=-1, keepdim=True), batch, size)
-            r = torch.zeros(size, self.in_channels, dtype=x.dtype, device=x.device).index_add_(0, batch, a * x)
+            a = ops.segment_softmax((x * q[batch]).sum(dim=-1, keepdim=True), batch, size)
+            r = ops.global_add_pool(a * x, batch, size)
             q_star = torch.cat([q, r], dim=-1)
         return q_star

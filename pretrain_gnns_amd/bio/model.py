@@ -176,9 +176,7 @@ def global_mean_pool(x, batch, size=None):
 
 
 def global_max_pool(x, batch, size=None):
-    size = int(batch.max().item()) + 1 if size is None else size
-    out = torch.full((size, x.size(1)), float("-inf"), dtype=x.dtype, device=x.device)
-    return out.scatter_reduce(0, batch.unsqueeze(-1).expand_as(x), x, reduce="amax", include_self=True)
+    return ops.global_max_pool(x, batch, size)
 
 
 class GNN_graphpred(torch.nn.Module):

@@ -93,8 +93,8 @@ class GraphSAGEConv(torch.nn.Module):
 
 
 class GATConv(torch.nn.Module):
-    """2-head graph attention (chem/model.py:107-162).  Off the north-star hot path: the projection is the
-    library's MFMA GEMM, the edge softmax / weighted scatter a torch-on-GPU composition (attention.py)."""
+    """2-head graph attention (chem/model.py:107-162).  Off the north-star hot path; the projection is the library's
+    MFMA GEMM, message / edge soft-max / aggregate / update run on csrc/attention.hip (``ops.GATAggregate``)."""
 
     def __init__(self, emb_dim, heads=2, negative_slope=0.2, aggr="add"):
         super().__init__()
@@ -116,7 +116,12 @@ class GATConv(torch.nn.Module):
 
     def forward(self, x, edge_index, edge_attr, graph=None):
         xh = ops.linear(x, self.weight_linear)
-        ee = self.edge_embedding1(edge_attr[:, 0]) + self.edge_embedding2(edge_attr[:, 1])
+        if self.heads == 2:
+            if graph is None:
+                graph = ops.build_chem_graph(edge_index, edge_attr, x.size(0))
+            return ops.GATAggregate.apply(xh, self.att, self.bias, self.edge_embedding1.weight, self.edge_embedding2.weight,
+                                          graph, self.negative_slope)
+        ee = self.edge_embedding1(edge_attr[:, 0]) + self.edge_embedding2(edge_attr[:, 1])  # other head counts: torch composition
         self_emb = self.edge_embedding1.weight[4] + self.edge_embedding2.weight[0]  # self-loop bond [4, 0]
         return attention.gat_propagate(xh, edge_index, ee, self_emb, self.att, self.bias, self.heads, self.negative_slope)
 
@@ -221,16 +226,13 @@ def global_mean_pool(x, batch, size=None):
 
 
 def global_max_pool(x, batch, size=None):
-    """not on the hot path: plain torch scatter-max on the GPU."""
-    size = int(batch.max().item()) + 1 if size is None else size
-    out = torch.full((size, x.size(1)), float("-inf"), dtype=x.dtype, device=x.device)
-    return out.scatter_reduce(0, batch.unsqueeze(-1).expand_as(x), x, reduce="amax", include_self=True)
+    return ops.global_max_pool(x, batch, size)
 
 
 class GNN_graphpred(torch.nn.Module):
     """Graph-level head: GNN -> pooling -> Linear (chem/model.py:293-369).
 
-    graph_pooling in sum|mean|max (HIP segment kernels) | attention | set2set<k> (torch GPU ops, attention.py).
+    graph_pooling in sum|mean|max | attention | set2set<k>: all on the HIP segment kernels (sum / soft-max / max).
     """
 
     def __init__(self, num_layer, emb_dim, num_tasks, JK="last", drop_ratio=0, graph_pooling="mean", gnn_type="gin"):

@@ -1182,7 +1182,7 @@ int pgnn_rowfeat_matmul_bwd(const float* cfeat, int64_t kc, const float* g, int6
                             int64_t ldgt, int64_t n, int64_t dim, void* ws, size_t ws_bytes,
                             pgnn_stream stream) {
   if (int rc = check_dim(dim)) return rc;
-  PGNN_REQUIRE(n > 0 && (kc == 9 || kc == 10) && ldg % 4 == 0, "rowfeat_matmul_bwd supports kc in {9,10}");
+  PGNN_REQUIRE(n > 0 && (kc == 2 || kc == 9 || kc == 10) && ldg % 4 == 0, "rowfeat_matmul_bwd supports kc in {2,9,10}");
   if (ws_bytes < pgnn_rowfeat_matmul_bwd_workspace_bytes(n, kc, dim)) {
     set_error("rowfeat_matmul_bwd workspace too small");
     return PGNN_ERR_WORKSPACE;
@@ -1196,7 +1196,12 @@ int pgnn_rowfeat_matmul_bwd(const float* cfeat, int64_t kc, const float* g, int6
     set_error("rowfeat_matmul_bwd: feature width %lld too large for the LDS reduction", (long long)dim);
     return PGNN_ERR_ARG;
   }
-  if (kc == 9) {
+  if (kc == 2) {
+    PGNN_DISPATCH_R(R, {
+      allow_big_lds((const void*)k_rowfeat_bwd_partial<RR, 2>, lds);
+      hipLaunchKernelGGL((k_rowfeat_bwd_partial<RR, 2>), dim3(nb), dim3(kBlock), lds, st, cfeat, g, ldg, partial, (int)n, (int)dim);
+    });
+  } else if (kc == 9) {
     PGNN_DISPATCH_R(R, {
       allow_big_lds((const void*)k_rowfeat_bwd_partial<RR, 9>, lds);
       hipLaunchKernelGGL((k_rowfeat_bwd_partial<RR, 9>), dim3(nb), dim3(kBlock), lds, st, cfeat, g, ldg, partial, (int)n, (int)dim);

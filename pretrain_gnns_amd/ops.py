@@ -397,6 +397,154 @@ def global_mean_pool(x, batch, size=None):
     return SegmentPool.apply(x, batch, size, True)
 
 
+# ------------------------------------------------------------------------------------ attention layers (csrc/attention.hip)
+class GATAggregate(Function):
+    """message / edge soft-max / aggregate / update of the 2-head chem GATConv (chem/model.py:133-162) on the CSR of
+    the graph build: xh [N, 2D] = weight_linear(x) -> out [N, D].  Parameters: att [1, 2, 2D], bias [D], emb1 [6, 2D],
+    emb2 [3, 2D].  All sums sequential in a fixed order: bitwise reproducible (the torch-op composition it replaces
+    used atomic index_add_)."""
+
+    @staticmethod
+    def forward(ctx, xh, att, bias, emb1, emb2, graph, negative_slope):
+        require_cuda(xh, att, bias, emb1, emb2)
+        xh = _rows2d(xh)
+        n, hd = xh.shape
+        heads, d = 2, hd // 2
+        if att.shape != (1, heads, 2 * d) or emb1.shape != (6, hd) or emb2.shape != (3, hd) or graph.kind != "chem" or n != graph.n:
+            raise _lib.PgnnError("GAT: shape mismatch (2 heads, chem graph)")
+        dev = xh.device
+        att2 = _f32c(att.view(heads, 2 * d))
+        e1, e2, b = _f32c(emb1), _f32c(emb2), _f32c(bias)
+        # parameter-space precomputation: the bond term of the logits, ctab[c, h] = (emb1[c // 3] + emb2[c % 3])[h] . att_j[h]
+        table = (e1.view(6, 1, heads, d) + e2.view(1, 3, heads, d)).view(18, heads, d)
+        ctab = (table * att2[:, d:].unsqueeze(0)).sum(-1).contiguous()
+        slots = graph.e + n
+        scores = torch.empty(n, 2 * heads, dtype=torch.float32, device=dev)
+        z = torch.empty(slots, heads, dtype=torch.float32, device=dev)
+        alpha = torch.empty(slots, heads, dtype=torch.float32, device=dev)
+        cfa = torch.empty(heads, n, 9, dtype=torch.float32, device=dev)
+        out = torch.empty(n, d, dtype=torch.float32, device=dev)
+        check(load().pgnn_gat_fwd(xh.data_ptr(), xh.stride(0), graph.in_ptr.data_ptr(), graph.in_src.data_ptr(),
+                                  graph.in_code.data_ptr(), e1.data_ptr(), e2.data_ptr(), None, ctab.data_ptr(), None,
+                                  att2.data_ptr(), b.data_ptr(), float(negative_slope), scores.data_ptr(), z.data_ptr(),
+                                  alpha.data_ptr(), cfa.data_ptr(), out.data_ptr(), d, n, d, stream_ptr()), "pgnn_gat_fwd")
+        ctx.save_for_backward(xh, att2, e1, e2, z, alpha, cfa)
+        ctx.graph, ctx.slope = graph, float(negative_slope)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        xh, att2, e1, e2, z, alpha, cfa = ctx.saved_tensors
+        graph = ctx.graph
+        g = _rows2d(g)
+        n, hd = xh.shape
+        heads, d = 2, hd // 2
+        dev = g.device
+        dalpha = torch.empty_like(alpha)
+        dsd = torch.empty(heads, n, 2, dtype=torch.float32, device=dev)
+        czf = torch.empty(heads, n, 9, dtype=torch.float32, device=dev)
+        wout = torch.empty(max(graph.e, 1), heads, dtype=torch.float32, device=dev)
+        dxh = torch.empty(n, hd, dtype=torch.float32, device=dev)
+        check(load().pgnn_gat_bwd(g.data_ptr(), g.stride(0), xh.data_ptr(), xh.stride(0), graph.in_ptr.data_ptr(),
+                                  graph.in_src.data_ptr(), graph.in_code.data_ptr(), graph.out_ptr.data_ptr(),
+                                  graph.out_dst.data_ptr(), e1.data_ptr(), e2.data_ptr(), None, att2.data_ptr(), ctx.slope,
+                                  z.data_ptr(), alpha.data_ptr(), dalpha.data_ptr(), dsd.data_ptr(), czf.data_ptr(),
+                                  wout.data_ptr(), dxh.data_ptr(), hd, n, d, stream_ptr()), "pgnn_gat_bwd")
+        demb = torch.empty(9, hd, dtype=torch.float32, device=dev)  # rows 0..5 = d emb1, 6..8 = d emb2
+        datt = torch.empty(heads, 2 * d, dtype=torch.float32, device=dev)
+        e9 = torch.cat([e1, e2], dim=0)
+        lib, sp = load(), stream_ptr()
+        for h in range(heads):
+            cols = slice(h * d, (h + 1) * d)
+            ws = _workspace(_ws_bytes("pgnn_rowfeat_matmul_bwd_workspace_bytes", n, 9, d), dev)
+            # message path: dE[t] = sum_i cfa[h, i, t] * g[i]   (cfa already carries the 1/heads of the head mean)
+            check(lib.pgnn_rowfeat_matmul_bwd(cfa[h].data_ptr(), 9, g.data_ptr(), g.stride(0), demb[:, cols].data_ptr(), hd, n, d,
+                                              ws.data_ptr(), ws.numel(), sp), "pgnn_rowfeat_matmul_bwd")
+            # logits path through the bond term: sum of dz per type / direction
+            s9 = czf[h].sum(0)
+            demb[:, cols] += s9.unsqueeze(1) * att2[h, d:].unsqueeze(0)
+            # d att: [dst term; src term] = dsd[h]^T . xh[:, head h]
+            xh_h = xh[:, cols]
+            gt = torch.empty(2, d, dtype=torch.float32, device=dev)
+            check(lib.pgnn_rowfeat_matmul_bwd(dsd[h].data_ptr(), 2, xh_h.data_ptr(), xh.stride(0), gt.data_ptr(), d, n, d,
+                                              ws.data_ptr(), ws.numel(), sp), "pgnn_rowfeat_matmul_bwd")
+            datt[h, :d] = gt[0]
+            datt[h, d:] = gt[1] + (s9.unsqueeze(1) * e9[:, cols]).sum(0)
+        return dxh, datt.view(1, heads, 2 * d), g.sum(0), demb[:6], demb[6:], None, None
+
+
+def _segments(batch, size):
+    """(ptr, perm) of the items grouped by their int64 segment key (group_by_key: stable, any order of `batch`)"""
+    return group_by_key(batch.contiguous(), size)
+
+
+class SegmentSoftmax(Function):
+    """torch_geometric.utils.softmax (1.0.3) over the segments given by (ptr, perm); z [items] or [items, heads]."""
+
+    @staticmethod
+    def forward(ctx, z, ptr, perm, size):
+        require_cuda(z)
+        shape = z.shape
+        z2 = _f32c(z.reshape(shape[0], -1))
+        alpha = torch.empty_like(z2)
+        check(load().pgnn_segment_softmax_fwd(z2.data_ptr(), ptr.data_ptr(), perm.data_ptr(), alpha.data_ptr(), size, z2.size(1),
+                                              stream_ptr()), "pgnn_segment_softmax_fwd")
+        ctx.save_for_backward(alpha)
+        ctx.ptr, ctx.perm, ctx.size, ctx.shape = ptr, perm, size, shape
+        return alpha.view(shape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (alpha,) = ctx.saved_tensors
+        g2 = _f32c(g.reshape(alpha.shape))
+        dz = torch.empty_like(alpha)
+        check(load().pgnn_segment_softmax_bwd(alpha.data_ptr(), g2.data_ptr(), ctx.ptr.data_ptr(), ctx.perm.data_ptr(),
+                                              dz.data_ptr(), ctx.size, alpha.size(1), stream_ptr()), "pgnn_segment_softmax_bwd")
+        return dz.view(ctx.shape), None, None, None
+
+
+def segment_softmax(z, batch, size):
+    ptr, perm = _segments(batch, size)
+    return SegmentSoftmax.apply(z, ptr, perm, size)
+
+
+class SegmentMax(Function):
+    """global_max_pool (chem/model.py:327-328; torch_geometric 1.0.3 scatter_('max'): empty graph -> 0)."""
+
+    @staticmethod
+    def forward(ctx, x, batch, size):
+        require_cuda(x, batch)
+        x = _rows2d(x)
+        n, dim = x.shape
+        if dim % 4:
+            raise _lib.PgnnError("global_max_pool: feature width must be a multiple of 4")
+        batch = batch.contiguous()
+        ptr, perm = _segments(batch, size)
+        out = torch.empty(size, dim, dtype=torch.float32, device=x.device)
+        arg = torch.empty(size, dim, dtype=torch.int32, device=x.device)
+        check(load().pgnn_segment_max_fwd(x.data_ptr(), x.stride(0), ptr.data_ptr(), perm.data_ptr(), out.data_ptr(), dim,
+                                          arg.data_ptr(), size, dim, stream_ptr()), "pgnn_segment_max_fwd")
+        ctx.batch, ctx.arg, ctx.n = batch, arg, n
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g = _rows2d(g)
+        size, dim = g.shape
+        dx = torch.empty(ctx.n, dim, dtype=torch.float32, device=g.device)
+        check(load().pgnn_segment_max_bwd(g.data_ptr(), g.stride(0), ctx.batch.data_ptr(), ctx.arg.data_ptr(), dx.data_ptr(), dim,
+                                          size, ctx.n, dim, stream_ptr()), "pgnn_segment_max_bwd")
+        return dx, None, None
+
+
+def global_max_pool(x, batch, size=None):
+    size = int(batch.max().item()) + 1 if size is None else size
+    return SegmentMax.apply(x, batch, size)
+
+
 # ------------------------------------------------------------------------------------ batch norm
 class BatchNormReLU(Function):
     """BatchNorm1d (+ optional fused ReLU); chem/model.py:269-275, bio/model.py:24."""

@@ -538,3 +538,88 @@ def test_pair_grouping_and_fold(n, na, nb, dim):
     scale = max(1.0, float(want_b.abs().max()))
     assert float((out_a.cpu().double() - want_a).abs().max()) <= 1e-5 * scale
     assert float((out_b.cpu().double() - want_b).abs().max()) <= 1e-5 * scale
+
+
+# ------------------------------------------------------------------------------------------ attention kernels (csrc/attention.hip)
+@pytest.mark.parametrize("shape", ["molecules", "parallel_bonds", "isolated"])
+def test_gat_aggregate_fwd_bwd(shape):
+    """2-head chem GATConv on the CSR kernels vs the oracle's torch composition (chem/model.py:133-162): output and
+    every gradient (projected features, att, bias, both bond tables).  "parallel_bonds" repeats edges (the transposed
+    pass must pair the r-th copy with the r-th copy), "isolated" has nodes whose only message is the self loop."""
+    ops = _ops()
+    dim = 300
+    if shape == "molecules":
+        b = synthetic.chem_masking_batch(12, seed=3)
+        ei, ea, n = b.edge_index, b.edge_attr, b.x.size(0)
+    elif shape == "parallel_bonds":
+        n = 40
+        ei, ea = _rand_graph(n, 120, seed=5, paired=False)
+        ei = torch.cat([ei, ei[:, :30], ei[:, 10:20]], dim=1)
+        ea = torch.cat([ea, (ea[:30] + 1) % 3, ea[10:20]], dim=0)
+    else:
+        n = 30
+        ei, ea = _rand_graph(12, 30, seed=7, paired=False)  # nodes 12..29 have no edges
+    torch.manual_seed(4)
+    conv = ochem.GATConv(dim)
+    conv.bias.data.normal_(0, 0.1)
+    x = torch.randn(n, dim, requires_grad=True)
+    want = conv(x, ei, ea)
+    gout = torch.randn(n, dim)
+    want.backward(gout)
+    g = ops.build_chem_graph(ei.to(DEV), ea.to(DEV), n)
+    xh = torch.nn.functional.linear(x.detach(), conv.weight_linear.weight.detach(), conv.weight_linear.bias.detach()).to(DEV).requires_grad_(True)
+    p = {k: getattr(conv, k).detach().to(DEV).requires_grad_(True) for k in ("att", "bias")}
+    e1 = conv.edge_embedding1.weight.detach().to(DEV).requires_grad_(True)
+    e2 = conv.edge_embedding2.weight.detach().to(DEV).requires_grad_(True)
+    got = ops.GATAggregate.apply(xh, p["att"], p["bias"], e1, e2, g, conv.negative_slope)
+    got.backward(gout.to(DEV))
+    torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-4, atol=1e-5)
+    # reference gradient w.r.t. the projected features: through the oracle with xh as the leaf
+    xh_ref = xh.detach().cpu().clone().requires_grad_(True)
+    conv.zero_grad()
+
+    class _Id(torch.nn.Module):
+        def forward(self, t):
+            return t
+
+    lin, conv.weight_linear = conv.weight_linear, _Id()
+    conv(xh_ref, ei, ea).backward(gout)
+    conv.weight_linear = lin
+    torch.testing.assert_close(xh.grad.cpu(), xh_ref.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(p["att"].grad.cpu(), conv.att.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(p["bias"].grad.cpu(), conv.bias.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(e1.grad.cpu(), conv.edge_embedding1.weight.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(e2.grad.cpu(), conv.edge_embedding2.weight.grad, rtol=1e-4, atol=1e-4)
+    # bitwise reproducible (the torch composition it replaced used atomic adds)
+    again = ops.GATAggregate.apply(xh.detach(), p["att"].detach(), p["bias"].detach(), e1.detach(), e2.detach(), g, conv.negative_slope)
+    assert torch.equal(again, got.detach())
+
+
+@pytest.mark.parametrize("sorted_batch", [True, False])
+def test_segment_softmax_and_max_pool(sorted_batch):
+    """pgnn_segment_softmax_* / pgnn_segment_max_* vs the PyG-1.0.3 semantics of the oracle: shift max(0, .), +1e-16,
+    empty graph -> 0 for the max pool, any order of the batch vector, heads"""
+    ops = _ops()
+    torch.manual_seed(9)
+    n, size = 500, 17  # graph 16 stays empty
+    batch = torch.randint(0, 16, (n,))
+    if sorted_batch:
+        batch = batch.sort().values
+    z = (torch.randn(n, 2) * 4 - 3).requires_grad_(True)  # many all-negative segments: the 0-floor of the shift matters
+    want = pyg.softmax(z, batch, size)
+    w = torch.randn(n, 2)
+    (want * w).sum().backward()
+    zd = z.detach().to(DEV).requires_grad_(True)
+    got = ops.segment_softmax(zd, batch.to(DEV), size)
+    (got * w.to(DEV)).sum().backward()
+    torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(zd.grad.cpu(), z.grad, rtol=1e-4, atol=1e-6)
+    x = torch.randn(n, 300, requires_grad=True)
+    want = pyg.global_max_pool(x, batch, size)
+    gw = torch.randn(size, 300)
+    (want * gw).sum().backward()
+    xd = x.detach().to(DEV).requires_grad_(True)
+    got = ops.global_max_pool(xd, batch.to(DEV), size)
+    (got * gw.to(DEV)).sum().backward()
+    assert torch.equal(got.detach().cpu(), want.detach()) and float(got[16].abs().max()) == 0.0
+    assert torch.equal(xd.grad.cpu(), x.grad)
