@@ -148,14 +148,14 @@ def roofline_aggregation(dev, graphs):
 
 def pmc_traffic(n, e):
     """HBM bytes per launch of the aggregation kernel from the committed rocprofv3 PMC pass
-    (profiles/r01/agg_pmc_traffic.json: FETCH_SIZE x2 (gfx950 half-count) + WRITE_SIZE, separate --pmc
+    (profiles/r02/agg_pmc_traffic.json: FETCH_SIZE x2 (gfx950 half-count) + WRITE_SIZE, separate --pmc
     run of tools/agg_bench.py on this same batch).  Counters cannot be read from inside this process, so
     the figure is only quoted when the recorded batch shape matches; otherwise null."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "agg_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02", "agg_pmc_traffic.json")
     try:
         rec = json.load(open(path))
         if rec["nodes"] == n and rec["edges"] == e:
-            return int(rec["hbm_bytes_per_launch"]), "profiles/r01/agg_pmc_traffic.json"
+            return int(rec["hbm_bytes_per_launch"]), "profiles/r02/agg_pmc_traffic.json"
     except (OSError, KeyError, ValueError):
         pass
     return None, None
