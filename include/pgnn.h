@@ -394,6 +394,20 @@ int pgnn_substruct_context_fill(const int64_t* graph_ids, int64_t num_graphs, in
  * x_row_bytes / attr_row_bytes must be multiples of 4; context_attr_zero_from_byte < 0 copies whole rows. */
 
 /* ------------------------------------------------------------------------------------------
+ * Graph-resident aggregation for batches of small dense graphs (bio ego nets; csrc/tile.hip).
+ * ------------------------------------------------------------------------------------------ */
+
+/* closed node intervals of the batch (no edge crosses an interval boundary; for a block-diagonal batch: the graphs):
+ * tile_start [num_nodes + 1] receives T + 1 ascending boundaries (0 ... num_nodes), *num_tiles = T, both on the device. */
+size_t pgnn_graph_tiles_workspace_bytes(int64_t num_nodes);
+int pgnn_graph_tiles(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                     int64_t num_nodes, int32_t* tile_start, int32_t* num_tiles, void* ws, size_t ws_bytes, pgnn_stream stream);
+/* pgnn_neighbor_sum with the rows of every interval resident in LDS while its nodes are summed (bit-identical result). */
+int pgnn_neighbor_sum_tiled(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* nbr, const float* dinv,
+                            const int32_t* tile_start, const int32_t* num_tiles, float* out, int64_t ldo, int64_t num_nodes,
+                            int64_t dim, pgnn_stream stream);
+
+/* ------------------------------------------------------------------------------------------
  * Attention layers (off the north-star path, native and deterministic): csrc/attention.hip.
  * ------------------------------------------------------------------------------------------ */
 

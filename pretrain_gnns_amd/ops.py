@@ -15,6 +15,7 @@ from . import _lib
 from ._lib import check, load, require_cuda, stream_ptr
 
 _CHECK_INDICES = os.environ.get("PGNN_CHECK_INDICES", "0") == "1"
+_BIO_TILES = os.environ.get("PGNN_BIO_TILES", "1") != "0"  # A/B: graph-resident bio aggregation (csrc/tile.hip)
 _ws_cache = {}
 
 
@@ -65,7 +66,7 @@ class GraphStruct:
     """CSR-by-destination + CSR-by-source + per-node edge-feature sums of one batch."""
 
     __slots__ = ("kind", "gcn", "n", "e", "in_ptr", "in_src", "in_code", "out_ptr", "out_dst", "dinv", "cfeat",
-                 "status")
+                 "status", "tiles")
 
     @property
     def kc(self):
@@ -86,7 +87,7 @@ def _build_graph(kind, edge_index, edge_attr, num_nodes, gcn):
     ei = edge_index.contiguous()
     e, n = ei.size(1), int(num_nodes)
     g = GraphStruct()
-    g.kind, g.gcn, g.n, g.e = kind, bool(gcn), n, e
+    g.kind, g.gcn, g.n, g.e, g.tiles = kind, bool(gcn), n, e, None
     g.in_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
     g.out_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
     g.in_src = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
@@ -116,6 +117,14 @@ def _build_graph(kind, edge_index, edge_attr, num_nodes, gcn):
                                        g.dinv.data_ptr(), g.cfeat.data_ptr(), g.status.data_ptr(), ws.data_ptr(),
                                        ws.numel(), stream_ptr()),
               "pgnn_bio_graph_build")
+        if _BIO_TILES:  # closed node intervals (= the ego nets) for the graph-resident aggregation of csrc/tile.hip
+            tile_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+            num_tiles = torch.empty(1, dtype=torch.int32, device=dev)
+            tws = _workspace(_ws_bytes("pgnn_graph_tiles_workspace_bytes", n), dev)
+            check(lib.pgnn_graph_tiles(g.in_ptr.data_ptr(), g.in_src.data_ptr(), g.out_ptr.data_ptr(), g.out_dst.data_ptr(), n,
+                                       tile_start.data_ptr(), num_tiles.data_ptr(), tws.data_ptr(), tws.numel(), stream_ptr()),
+                  "pgnn_graph_tiles")
+            g.tiles = (tile_start, num_tiles)
     if _CHECK_INDICES:
         g.check()
     return g
@@ -147,10 +156,16 @@ def group_by_key(key, n_keys, stride=1, offset=0):
 
 
 # ------------------------------------------------------------------------------------ raw launches
-def _neighbor_sum(x, ptr, nbr, dinv, n, dim, out=None):
+def _neighbor_sum(x, ptr, nbr, dinv, n, dim, out=None, tiles=None):
     x = _rows2d(x)
     if out is None:
         out = torch.empty(n, dim, dtype=torch.float32, device=x.device)
+    if tiles is not None:
+        check(load().pgnn_neighbor_sum_tiled(x.data_ptr(), x.stride(0), ptr.data_ptr(), nbr.data_ptr(),
+                                             dinv.data_ptr() if dinv is not None else None, tiles[0].data_ptr(),
+                                             tiles[1].data_ptr(), out.data_ptr(), out.stride(0), n, dim, stream_ptr()),
+              "pgnn_neighbor_sum_tiled")
+        return out
     check(load().pgnn_neighbor_sum(x.data_ptr(), x.stride(0), ptr.data_ptr(), nbr.data_ptr(),
                                    dinv.data_ptr() if dinv is not None else None, out.data_ptr(), out.stride(0),
                                    n, dim, stream_ptr()), "pgnn_neighbor_sum")
@@ -224,11 +239,11 @@ class BioAggregate(Function):
             raise _lib.PgnnError("bio aggregate: shape mismatch")
         table = torch.cat([enc_w.t(), enc_b.unsqueeze(0)], dim=0).contiguous()  # [10, D]
         if graph.gcn:
-            out = _neighbor_sum(x, graph.in_ptr, graph.in_src, graph.dinv, n, dim)
+            out = _neighbor_sum(x, graph.in_ptr, graph.in_src, graph.dinv, n, dim, tiles=graph.tiles)
             _rowfeat_fwd(graph.cfeat, table, out, dim, True)
         else:
             out = torch.empty(n, 2 * dim, dtype=torch.float32, device=x.device)
-            _neighbor_sum(x, graph.in_ptr, graph.in_src, None, n, dim, out=out[:, :dim])
+            _neighbor_sum(x, graph.in_ptr, graph.in_src, None, n, dim, out=out[:, :dim], tiles=graph.tiles)
             _rowfeat_fwd(graph.cfeat, table, out[:, dim:], dim, False)
         ctx.graph, ctx.dim = graph, dim
         return out
@@ -242,7 +257,7 @@ class BioAggregate(Function):
         gx_part, ge_part = (g, g) if graph.gcn else (g[:, :dim], g[:, dim:])
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = _neighbor_sum(gx_part, graph.out_ptr, graph.out_dst, graph.dinv if graph.gcn else None, n, dim)
+            gx = _neighbor_sum(gx_part, graph.out_ptr, graph.out_dst, graph.dinv if graph.gcn else None, n, dim, tiles=graph.tiles)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             gt = _rowfeat_bwd(graph.cfeat, ge_part, dim)
             gw, gb = gt[:9].t(), gt[9]
@@ -261,7 +276,7 @@ class BioSumAggregate(Function):
         if n != graph.n or enc_w.shape != (dim, 9) or graph.gcn:
             raise _lib.PgnnError("bio sum aggregate: shape mismatch / graph built with GCN weights")
         table = torch.cat([enc_w.t(), enc_b.unsqueeze(0)], dim=0).contiguous()  # [10, D]
-        out = _neighbor_sum(x, graph.in_ptr, graph.in_src, None, n, dim)
+        out = _neighbor_sum(x, graph.in_ptr, graph.in_src, None, n, dim, tiles=graph.tiles)
         _rowfeat_fwd(graph.cfeat, table, out, dim, True)
         ctx.graph, ctx.dim = graph, dim
         return out
@@ -273,7 +288,7 @@ class BioSumAggregate(Function):
         g = _rows2d(g)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = _neighbor_sum(g, graph.out_ptr, graph.out_dst, None, g.size(0), dim)
+            gx = _neighbor_sum(g, graph.out_ptr, graph.out_dst, None, g.size(0), dim, tiles=graph.tiles)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             gt = _rowfeat_bwd(graph.cfeat, g, dim)
             gw, gb = gt[:9].t(), gt[9]

@@ -623,3 +623,48 @@ def test_segment_softmax_and_max_pool(sorted_batch):
     (got * gw.to(DEV)).sum().backward()
     assert torch.equal(got.detach().cpu(), want.detach()) and float(got[16].abs().max()) == 0.0
     assert torch.equal(xd.grad.cpu(), x.grad)
+
+
+@pytest.mark.parametrize("shape", ["ego_nets", "big_graphs", "one_component", "singletons"])
+@pytest.mark.parametrize("gcn", [False, True])
+def test_tiled_neighbor_sum_is_bit_identical(shape, gcn):
+    """csrc/tile.hip: closed-interval tiles from pgnn_graph_tiles + the graph-resident neighbour sum == pgnn_neighbor_sum
+    bit for bit, on both CSRs; "big_graphs" have more nodes than one 48-row chunk (cross-chunk sources take the memory
+    path), "one_component" is a single interval of 3000 nodes, "singletons" has isolated nodes (one-node intervals)"""
+    ops = _ops()
+    import numpy as np
+    if shape == "ego_nets":
+        b = synthetic.bio_masking_batch(40, seed=6)
+        ei, n = b.edge_index, b.x.size(0)
+        want_tiles = 40
+    elif shape == "big_graphs":
+        rng = np.random.default_rng(3)
+        parts, off = [], 0
+        for _ in range(12):
+            m = int(rng.integers(60, 130))
+            e = rng.integers(0, m, size=(2, 6 * m))
+            e = e[:, e[0] != e[1]]
+            ring = np.stack([np.arange(m), (np.arange(m) + 1) % m])  # keeps every graph one component
+            e = np.concatenate([e, ring], axis=1)
+            parts.append(np.concatenate([e, e[::-1]], axis=1) + off)
+            off += m
+        ei, n, want_tiles = torch.from_numpy(np.concatenate(parts, axis=1)), off, 12
+    elif shape == "one_component":
+        ei, _ = _rand_graph(3000, 20000, seed=8, paired=True)
+        chain = torch.stack([torch.arange(2999), torch.arange(1, 3000)])
+        ei, n, want_tiles = torch.cat([ei, chain, chain.flip(0)], dim=1), 3000, 1
+    else:
+        ei, n, want_tiles = torch.tensor([[2, 3, 7, 8], [3, 2, 8, 7]]), 11, 9
+    ea = torch.zeros(ei.size(1), 9)
+    ea[:, 0] = 1
+    g = ops.build_bio_graph(ei.to(DEV), ea.to(DEV), n, gcn=gcn)
+    assert g.tiles is not None and int(g.tiles[1].item()) == want_tiles
+    ts = g.tiles[0][:want_tiles + 1].cpu()
+    assert ts[0] == 0 and ts[-1] == n and bool((ts[1:] > ts[:-1]).all())
+    torch.manual_seed(2)
+    x = torch.randn(n, 300, device=DEV)
+    dinv = g.dinv if gcn else None
+    for ptr, nbr in ((g.in_ptr, g.in_src), (g.out_ptr, g.out_dst)):
+        plain = ops._neighbor_sum(x, ptr, nbr, dinv, n, 300)
+        tiled = ops._neighbor_sum(x, ptr, nbr, dinv, n, 300, tiles=g.tiles)
+        assert torch.equal(plain, tiled)
