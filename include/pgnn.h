@@ -402,10 +402,15 @@ int pgnn_substruct_context_fill(const int64_t* graph_ids, int64_t num_graphs, in
 size_t pgnn_graph_tiles_workspace_bytes(int64_t num_nodes);
 int pgnn_graph_tiles(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
                      int64_t num_nodes, int32_t* tile_start, int32_t* num_tiles, void* ws, size_t ws_bytes, pgnn_stream stream);
-/* pgnn_neighbor_sum with the rows of every interval resident in LDS while its nodes are summed (bit-identical result). */
+/* pgnn_neighbor_sum with the rows of every interval resident in LDS while its nodes are summed (bit-identical result).
+ * cfeat != NULL folds the edge-feature half of the bio message into the same pass (bio/model.py:47,55,102-114):
+ *   feat_out[i, :] (+)= cfeat[i, 0:kc] . table[0:kc, :]      -- the fmaf chain of pgnn_rowfeat_matmul_fwd;
+ * feat_out == out continues from the neighbour sum (GCN: one [N, D] result), otherwise it starts from zero in its own
+ * columns (GIN: the second half of the [N, 2D] concat message).  kc <= 10. */
 int pgnn_neighbor_sum_tiled(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* nbr, const float* dinv,
                             const int32_t* tile_start, const int32_t* num_tiles, float* out, int64_t ldo, int64_t num_nodes,
-                            int64_t dim, pgnn_stream stream);
+                            int64_t dim, const float* cfeat, int64_t kc, const float* table, int64_t ldt, float* feat_out,
+                            int64_t ld_feat_out, pgnn_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Attention layers (off the north-star path, native and deterministic): csrc/attention.hip.

@@ -20,9 +20,13 @@ using namespace pgnn;
 
 namespace {
 
-constexpr int kRows = 48;        // rows of x resident per chunk: 57.6 KB at D = 300 -> two blocks per CU
+constexpr int kRows = 112;       // rows of x resident per chunk: 134.4 KB at D = 300, one block per CU.  Smaller chunks with two
+                                 // blocks per CU were measured (48, 60 rows): the ego nets that do not fit send a batch of edges per
+                                 // wave to memory and ONE such graph sets the time of a 256-graph launch (45 us vs ~9 us for a resident one)
 constexpr int kIdxCap = 2048;    // staged neighbour indices per chunk (8 KB); the rest is read from memory
-constexpr int kThreads = 640;    // 8 groups of 75 threads at D = 300
+constexpr int kThreads = 1024;   // 13 groups of 75 threads at D = 300
+constexpr int kMaxFeat = 10;     // per-node edge-feature sums folded into the same pass (bio: 9 attribute columns + the count)
+constexpr int kBatch = 4;        // edges gathered per round (8 measured the same: 307 vs 302 us on the 4 096-graph batch)
 
 #define PGNN_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define PGNN_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -68,19 +72,27 @@ __global__ void __launch_bounds__(1024) k_tile_compact(const uint8_t* __restrict
   if (t == 0) tile_start[0] = 0;
 }
 
-template <bool WEIGHT>
+template <bool WEIGHT, int DBG = 0>  // DBG (PGNN_TILE_DEBUG, timing only): 1 = skip the gather loop, 2 = skip the row DMA
 __global__ void __launch_bounds__(kThreads) k_neighbor_sum_tile(const float* __restrict__ x, int64_t ldx,
                                                                 const int32_t* __restrict__ ptr, const int32_t* __restrict__ nbr,
                                                                 const float* __restrict__ dinv,
                                                                 const int32_t* __restrict__ tile_start,
                                                                 const int32_t* __restrict__ num_tiles, float* __restrict__ out,
-                                                                int64_t ldo, int n, int dim) {
+                                                                int64_t ldo, int n, int dim, const float* __restrict__ cfeat,
+                                                                int kc, const float* __restrict__ table, int64_t ldt,
+                                                                float* __restrict__ fout, int64_t ldf) {
 #pragma clang fp contract(off)
   extern __shared__ __align__(16) float smem[];
   const int gs = dim >> 2;
   float4* rows = reinterpret_cast<float4*>(smem);                       // [kRows][gs]
   int* idxL = reinterpret_cast<int*>(rows + kRows * gs);                // [kIdxCap]
   int* ptrL = idxL + kIdxCap;                                           // [kRows + 1]
+  float4* tabL = reinterpret_cast<float4*>(ptrL + kRows + 4);           // [kc][gs]: the edge-feature table (cfeat != NULL)
+  if (cfeat) {
+    for (int q = threadIdx.x; q < kc * gs; q += kThreads)
+      tabL[q] = reinterpret_cast<const float4*>(table + (int64_t)(q / gs) * ldt)[q % gs];
+    // (visible to every thread after the first chunk's barriers)
+  }
   const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
   const int64_t ldx4 = ldx >> 2, ldo4 = ldo >> 2;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = kThreads / 64;
@@ -94,7 +106,7 @@ __global__ void __launch_bounds__(kThreads) k_neighbor_sum_tile(const float* __r
       __syncthreads();  // previous chunk fully consumed
       // rows [c0, c1) -> LDS, 1 KiB per wave instruction
       const int total4 = cnt * gs;
-      for (int base = wave * 64; base < total4; base += nwaves * 64) {
+      for (int base = wave * 64; base < total4 && DBG != 2; base += nwaves * 64) {
         const int q = base + lane;
         if (q < total4) {
           const int r = q / gs, cc = q - r * gs;
@@ -114,15 +126,69 @@ __global__ void __launch_bounds__(kThreads) k_neighbor_sum_tile(const float* __r
           float di = 1.f;
           if (WEIGHT) di = dinv[i];
           float4 acc = f4_zero();
-          for (int p = beg; p < end; ++p) {
-            const int s = p < kIdxCap ? idxL[p] : nbr[e0 + p];
-            float4 v = (s >= c0 && s < c1) ? rows[(s - c0) * gs + c4] : x4[(int64_t)s * ldx4 + c4];
-            if (WEIGHT) v = f4_scale(v, di * dinv[s]);
-            acc = f4_add(acc, v);
+          // batches of kBatch edges: indices first, then the rows, then the adds in edge order (one edge at a time is
+          // ~250 cycles of LDS latency per edge with nothing to hide it).  A batch with a source outside the resident chunk,
+          // or beyond the staged indices, takes a WAVE-UNIFORM branch that reads everything from memory: a per-lane choice
+          // between an LDS and a global address compiles to flat loads, and per-lane global fall-backs make the compiler
+          // wait for vmcnt(0) -- i.e. for the previous node's output store -- in front of every batch (measured: 44 us
+          // per 256-graph launch either way, against 9 us for the load / store phases alone)
+          for (int p = beg; p < end && DBG != 1; p += kBatch) {
+            int s[kBatch];
+            bool slow = false;
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+              s[j] = c0;
+              if (p + j < end) {
+                if (p + j < kIdxCap) {
+                  s[j] = idxL[p + j];
+                  slow |= (s[j] < c0) | (s[j] >= c1);
+                } else {
+                  slow = true;
+                }
+              }
+            }
+            if (__any(slow)) {
+              // rare: resident rows still come from LDS (index clamped), only the lanes with a far source go to memory
+#pragma unroll
+              for (int j = 0; j < kBatch; ++j) {
+                if (p + j < end) {
+                  const int sj = p + j < kIdxCap ? s[j] : nbr[e0 + p + j];
+                  const bool far = sj < c0 || sj >= c1;
+                  float4 v = rows[(far ? li : sj - c0) * gs + c4];
+                  if (far) v = x4[(int64_t)sj * ldx4 + c4];
+                  if (WEIGHT) v = f4_scale(v, di * dinv[sj]);
+                  acc = f4_add(acc, v);
+                }
+              }
+            } else {
+              float4 v[kBatch];
+#pragma unroll
+              for (int j = 0; j < kBatch; ++j) v[j] = rows[(s[j] - c0) * gs + c4];
+#pragma unroll
+              for (int j = 0; j < kBatch; ++j) {
+                if (p + j < end) {
+                  if (WEIGHT) v[j] = f4_scale(v[j], di * dinv[s[j]]);
+                  acc = f4_add(acc, v[j]);
+                }
+              }
+            }
           }
           float4 self = rows[li * gs + c4];
           if (WEIGHT) self = f4_scale(self, di * di);
           acc = f4_add(acc, self);
+          if (cfeat) {
+            // + cfeat[i, :] . table: the edge-feature half of the bio message, the same fmaf chain as pgnn_rowfeat_matmul_fwd
+            // (continuing from the neighbour sum when fout == out: the GCN form; from zero into its own columns: GIN)
+            const bool same = fout == out;
+            float4 f = same ? acc : f4_zero();
+            for (int tt = 0; tt < kc; ++tt) {
+              const float c = cfeat[(int64_t)i * kc + tt];
+              const float4 tv = tabL[tt * gs + c4];
+              f.x = fmaf(c, tv.x, f.x); f.y = fmaf(c, tv.y, f.y); f.z = fmaf(c, tv.z, f.z); f.w = fmaf(c, tv.w, f.w);
+            }
+            if (same) acc = f;
+            else reinterpret_cast<float4*>(fout)[(int64_t)i * (ldf >> 2) + c4] = f;
+          }
           reinterpret_cast<float4*>(out)[(int64_t)i * ldo4 + c4] = acc;
         }
       }
@@ -154,22 +220,33 @@ int pgnn_graph_tiles(const int32_t* in_ptr, const int32_t* in_src, const int32_t
 
 int pgnn_neighbor_sum_tiled(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* nbr, const float* dinv,
                             const int32_t* tile_start, const int32_t* num_tiles, float* out, int64_t ldo, int64_t num_nodes,
-                            int64_t dim, pgnn_stream stream) {
+                            int64_t dim, const float* cfeat, int64_t kc, const float* table, int64_t ldt, float* feat_out,
+                            int64_t ld_feat_out, pgnn_stream stream) {
   PGNN_REQUIRE(num_nodes > 0 && dim > 0 && dim % 4 == 0 && dim / 4 <= kThreads && ldx % 4 == 0 && ldo % 4 == 0,
                "neighbor_sum_tiled: bad shape");
-  const size_t lds = (size_t)kRows * dim * sizeof(float) + (size_t)(kIdxCap + kRows + 1) * sizeof(int) + 64;
+  PGNN_REQUIRE(cfeat == nullptr || (kc > 0 && kc <= kMaxFeat && table && feat_out && ldt % 4 == 0 && ld_feat_out % 4 == 0),
+               "neighbor_sum_tiled: bad edge-feature arguments (kc <= %d)", kMaxFeat);
+  const size_t lds = (size_t)kRows * dim * sizeof(float) + (size_t)(kIdxCap + kRows + 4) * sizeof(int) +
+                     (size_t)kMaxFeat * dim * sizeof(float) + 64;
   PGNN_REQUIRE(lds <= 160 * 1024, "neighbor_sum_tiled: feature width %lld too wide for the LDS tile", (long long)dim);
-  const int blocks = (int)std::min<int64_t>(num_nodes, (int64_t)num_cu() * 2 * 4);
+  const int blocks = (int)std::min<int64_t>(num_nodes, (int64_t)num_cu() * 4);
   hipStream_t st = (hipStream_t)stream;
-  if (dinv) {
+#define PGNN_TILE_ARGS x, ldx, ptr, nbr, dinv, tile_start, num_tiles, out, ldo, (int)num_nodes, (int)dim, cfeat, (int)kc, table, ldt, feat_out, ld_feat_out
+  const int dbg = env_knob("PGNN_TILE_DEBUG", 0);
+  if (dbg == 1) {
+    allow_big_lds((const void*)k_neighbor_sum_tile<false, 1>, lds);
+    hipLaunchKernelGGL((k_neighbor_sum_tile<false, 1>), dim3(blocks), dim3(kThreads), lds, st, PGNN_TILE_ARGS);
+  } else if (dbg == 2) {
+    allow_big_lds((const void*)k_neighbor_sum_tile<false, 2>, lds);
+    hipLaunchKernelGGL((k_neighbor_sum_tile<false, 2>), dim3(blocks), dim3(kThreads), lds, st, PGNN_TILE_ARGS);
+  } else if (dinv) {
     allow_big_lds((const void*)k_neighbor_sum_tile<true>, lds);
-    hipLaunchKernelGGL(k_neighbor_sum_tile<true>, dim3(blocks), dim3(kThreads), lds, st, x, ldx, ptr, nbr, dinv, tile_start,
-                       num_tiles, out, ldo, (int)num_nodes, (int)dim);
+    hipLaunchKernelGGL(k_neighbor_sum_tile<true>, dim3(blocks), dim3(kThreads), lds, st, PGNN_TILE_ARGS);
   } else {
     allow_big_lds((const void*)k_neighbor_sum_tile<false>, lds);
-    hipLaunchKernelGGL(k_neighbor_sum_tile<false>, dim3(blocks), dim3(kThreads), lds, st, x, ldx, ptr, nbr, dinv, tile_start,
-                       num_tiles, out, ldo, (int)num_nodes, (int)dim);
+    hipLaunchKernelGGL(k_neighbor_sum_tile<false>, dim3(blocks), dim3(kThreads), lds, st, PGNN_TILE_ARGS);
   }
+#undef PGNN_TILE_ARGS
   return check_launch("neighbor_sum_tiled");
 }
 

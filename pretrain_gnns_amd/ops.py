@@ -156,16 +156,23 @@ def group_by_key(key, n_keys, stride=1, offset=0):
 
 
 # ------------------------------------------------------------------------------------ raw launches
-def _neighbor_sum(x, ptr, nbr, dinv, n, dim, out=None, tiles=None):
+def _neighbor_sum(x, ptr, nbr, dinv, n, dim, out=None, tiles=None, feat=None):
+    """out = neighbour sum of x (+ self).  ``tiles``: the graph-resident kernel of csrc/tile.hip; ``feat`` =
+    (cfeat, table, feat_out) folds ``feat_out (+)= cfeat . table`` into the same launch (tiles only)."""
     x = _rows2d(x)
     if out is None:
         out = torch.empty(n, dim, dtype=torch.float32, device=x.device)
     if tiles is not None:
+        cf, tb, fo = feat if feat is not None else (None, None, None)
         check(load().pgnn_neighbor_sum_tiled(x.data_ptr(), x.stride(0), ptr.data_ptr(), nbr.data_ptr(),
                                              dinv.data_ptr() if dinv is not None else None, tiles[0].data_ptr(),
-                                             tiles[1].data_ptr(), out.data_ptr(), out.stride(0), n, dim, stream_ptr()),
-              "pgnn_neighbor_sum_tiled")
+                                             tiles[1].data_ptr(), out.data_ptr(), out.stride(0), n, dim,
+                                             cf.data_ptr() if cf is not None else None, cf.size(1) if cf is not None else 0,
+                                             tb.data_ptr() if tb is not None else None, tb.stride(0) if tb is not None else 0,
+                                             fo.data_ptr() if fo is not None else None, fo.stride(0) if fo is not None else 0,
+                                             stream_ptr()), "pgnn_neighbor_sum_tiled")
         return out
+    assert feat is None
     check(load().pgnn_neighbor_sum(x.data_ptr(), x.stride(0), ptr.data_ptr(), nbr.data_ptr(),
                                    dinv.data_ptr() if dinv is not None else None, out.data_ptr(), out.stride(0),
                                    n, dim, stream_ptr()), "pgnn_neighbor_sum")
@@ -239,12 +246,21 @@ class BioAggregate(Function):
             raise _lib.PgnnError("bio aggregate: shape mismatch")
         table = torch.cat([enc_w.t(), enc_b.unsqueeze(0)], dim=0).contiguous()  # [10, D]
         if graph.gcn:
-            out = _neighbor_sum(x, graph.in_ptr, graph.in_src, graph.dinv, n, dim, tiles=graph.tiles)
-            _rowfeat_fwd(graph.cfeat, table, out, dim, True)
+            if graph.tiles is not None:  # neighbour sum and edge-feature product in ONE graph-resident launch
+                out = torch.empty(n, dim, dtype=torch.float32, device=x.device)
+                _neighbor_sum(x, graph.in_ptr, graph.in_src, graph.dinv, n, dim, out=out, tiles=graph.tiles,
+                              feat=(graph.cfeat, table, out))
+            else:
+                out = _neighbor_sum(x, graph.in_ptr, graph.in_src, graph.dinv, n, dim)
+                _rowfeat_fwd(graph.cfeat, table, out, dim, True)
         else:
             out = torch.empty(n, 2 * dim, dtype=torch.float32, device=x.device)
-            _neighbor_sum(x, graph.in_ptr, graph.in_src, None, n, dim, out=out[:, :dim], tiles=graph.tiles)
-            _rowfeat_fwd(graph.cfeat, table, out[:, dim:], dim, False)
+            if graph.tiles is not None:
+                _neighbor_sum(x, graph.in_ptr, graph.in_src, None, n, dim, out=out[:, :dim], tiles=graph.tiles,
+                              feat=(graph.cfeat, table, out[:, dim:]))
+            else:
+                _neighbor_sum(x, graph.in_ptr, graph.in_src, None, n, dim, out=out[:, :dim])
+                _rowfeat_fwd(graph.cfeat, table, out[:, dim:], dim, False)
         ctx.graph, ctx.dim = graph, dim
         return out
 
@@ -276,8 +292,12 @@ class BioSumAggregate(Function):
         if n != graph.n or enc_w.shape != (dim, 9) or graph.gcn:
             raise _lib.PgnnError("bio sum aggregate: shape mismatch / graph built with GCN weights")
         table = torch.cat([enc_w.t(), enc_b.unsqueeze(0)], dim=0).contiguous()  # [10, D]
-        out = _neighbor_sum(x, graph.in_ptr, graph.in_src, None, n, dim, tiles=graph.tiles)
-        _rowfeat_fwd(graph.cfeat, table, out, dim, True)
+        if graph.tiles is not None:
+            out = torch.empty(n, dim, dtype=torch.float32, device=x.device)
+            _neighbor_sum(x, graph.in_ptr, graph.in_src, None, n, dim, out=out, tiles=graph.tiles, feat=(graph.cfeat, table, out))
+        else:
+            out = _neighbor_sum(x, graph.in_ptr, graph.in_src, None, n, dim)
+            _rowfeat_fwd(graph.cfeat, table, out, dim, True)
         ctx.graph, ctx.dim = graph, dim
         return out
 

@@ -668,3 +668,26 @@ def test_tiled_neighbor_sum_is_bit_identical(shape, gcn):
         plain = ops._neighbor_sum(x, ptr, nbr, dinv, n, 300)
         tiled = ops._neighbor_sum(x, ptr, nbr, dinv, n, 300, tiles=g.tiles)
         assert torch.equal(plain, tiled)
+
+
+@pytest.mark.parametrize("gcn", [False, True])
+def test_bio_aggregate_fused_tile_path_is_bit_identical(gcn, monkeypatch):
+    """bio GINConv / GCNConv aggregate: ONE graph-resident launch (neighbour sum + edge-feature product, csrc/tile.hip)
+    == the two-launch path (pgnn_neighbor_sum + pgnn_rowfeat_matmul_fwd), forward and backward, bit for bit"""
+    ops = _ops()
+    b = synthetic.bio_masking_batch(24, seed=8).to(DEV)
+    n = b.x.size(0)
+    torch.manual_seed(3)
+    x = torch.randn(n, 300, device=DEV)
+    w, bias = torch.randn(300, 9, device=DEV), torch.randn(300, device=DEV)
+    res = []
+    for tiles in (True, False):
+        monkeypatch.setattr(ops, "_BIO_TILES", tiles)
+        g = ops.build_bio_graph(b.edge_index, b.edge_attr, n, gcn=gcn)
+        assert (g.tiles is not None) == tiles
+        xi, wi, bi = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+        out = ops.BioAggregate.apply(xi, wi, bi, g)
+        out.backward(torch.ones_like(out) * 0.5)
+        res.append((out.detach(), xi.grad, wi.grad, bi.grad))
+    for a, c in zip(*res):
+        assert torch.equal(a, c)
