@@ -815,8 +815,10 @@ k_rowfeat_bwd_final(const float* __restrict__ partial, int nblocks, int kc, int 
   if (sl == 0 && qq < kc * dim) gtable[(int64_t)(q / dim) * ldgt + (q % dim)] = (float)s;
 }
 
+// rows per block of the weighted column sums.  Measured at N = 6 747 (tools/small_kernel_bench.py): 64 rows -> 12.0 us,
+// 32 -> 10.9, 16 -> 13.4, 8 -> 20.5 (both launches together).
 inline int rowfeat_bwd_blocks(int64_t n) {
-  return (int)std::min<int64_t>(std::max<int64_t>(ceil_div(n, 64), 1), 2 * num_cu());
+  return (int)std::min<int64_t>(std::max<int64_t>(ceil_div(n, env_int("PGNN_ROWFEAT_ROWS_PER_BLOCK", 32)), 1), 4 * num_cu());
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -86,14 +86,15 @@ __global__ void k_bn_stats_final(const float* __restrict__ partial, int nblk, co
                                  float momentum, float eps, int training, int n, int dim,
                                  float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                  float* __restrict__ coef) {
-  // 256 threads = 16 columns x 16 slices
-  const int sl = threadIdx.x & 15;
-  const int c = min(blockIdx.x * 16 + (threadIdx.x >> 4), dim - 1);
-  const bool writer = sl == 0 && (blockIdx.x * 16 + (threadIdx.x >> 4)) < dim;
+  // 256 threads = 4 columns x one wave of 64 slices (16-lane slices left a [N ~ 7k, 300] layer with 19 blocks that each
+  // walked their partials in 13 dependent rounds: 8 us for a 0.5 MB reduction)
+  const int sl = threadIdx.x & 63;
+  const int c = min(blockIdx.x * 4 + (threadIdx.x >> 6), dim - 1);
+  const bool writer = sl == 0 && (blockIdx.x * 4 + (threadIdx.x >> 6)) < dim;
   float mean, invstd;
   if (training) {
-    const double s1 = slice_sum16(partial + c, (size_t)2 * dim, nblk, sl);
-    const double s2 = slice_sum16(partial + dim + c, (size_t)2 * dim, nblk, sl);
+    const double s1 = slice_sum64(partial + c, (size_t)2 * dim, nblk, sl);
+    const double s2 = slice_sum64(partial + dim + c, (size_t)2 * dim, nblk, sl);
     if (!writer) return;
     const double m1 = s1 / n;
     double var = s2 / n - m1 * m1;
@@ -193,11 +194,11 @@ __global__ void k_bn_bwd_partial(const float* __restrict__ dy, int64_t lddy, con
 __global__ void k_bn_bwd_final(const float* __restrict__ partial, int nblk, int training, int n, int dim,
                                const float* __restrict__ gamma, float* __restrict__ coef,
                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int sl = threadIdx.x & 15;
-  const int c = min(blockIdx.x * 16 + (threadIdx.x >> 4), dim - 1);
-  const bool writer = sl == 0 && (blockIdx.x * 16 + (threadIdx.x >> 4)) < dim;
-  const double s1 = slice_sum16(partial + c, (size_t)2 * dim, nblk, sl);
-  const double s2 = slice_sum16(partial + dim + c, (size_t)2 * dim, nblk, sl);
+  const int sl = threadIdx.x & 63;
+  const int c = min(blockIdx.x * 4 + (threadIdx.x >> 6), dim - 1);
+  const bool writer = sl == 0 && (blockIdx.x * 4 + (threadIdx.x >> 6)) < dim;
+  const double s1 = slice_sum64(partial + c, (size_t)2 * dim, nblk, sl);
+  const double s2 = slice_sum64(partial + dim + c, (size_t)2 * dim, nblk, sl);
   if (!writer) return;
   if (dgamma) dgamma[c] = (float)s2;
   if (dbeta) dbeta[c] = (float)s1;
@@ -248,8 +249,11 @@ __global__ void k_bn_bwd_apply(const float* __restrict__ dy, int64_t lddy, const
   }
 }
 
+// rows per block of the two partial-sum kernels.  Measured at one 256-graph batch (N = 6 747, tools/small_kernel_bench.py):
+// 32 rows -> statistics 9.6 us, backward (3 launches) 17.2 us; 16 -> 10.8 / 17.6; 8 -> 14.3 / 20.9; 4 -> 14.7 / 20.4.  Each of
+// these launches already sits at the ~5 us floor of a dependent kernel; more, smaller blocks only add partials to reduce.
 inline int stat_blocks(int64_t n) {
-  return (int)std::min<int64_t>(std::max<int64_t>(ceil_div(n, 32), 1), kMaxBlocks);
+  return (int)std::min<int64_t>(std::max<int64_t>(ceil_div(n, env_knob("PGNN_BN_ROWS_PER_BLOCK", 32)), 1), kMaxBlocks);
 }
 inline int stat_threads(int64_t dim) { return (int)align_up((size_t)dim, 64); }  // 4 row lanes x dim/4
 
@@ -295,7 +299,7 @@ int pgnn_bn_fwd(const float* x, int64_t ldx, const float* gamma, const float* be
     hipLaunchKernelGGL(k_bn_stats_partial, dim3(nblk), dim3(stat_threads(dim)), (size_t)8 * dim * sizeof(float),
                        st, x, ldx, (int)n, d4, partial);
   }
-  hipLaunchKernelGGL(k_bn_stats_final, dim3((int)ceil_div(dim, 16)), dim3(256), 0, st, partial, nblk, x, gamma,
+  hipLaunchKernelGGL(k_bn_stats_final, dim3((int)ceil_div(dim, 4)), dim3(256), 0, st, partial, nblk, x, gamma,
                      beta, running_mean, running_var, momentum, eps, training, (int)n, (int)dim, save_mean,
                      save_invstd, coef);
   const int grid = (int)std::min<int64_t>(ceil_div(n, 4), (int64_t)num_cu() * 16);
@@ -322,7 +326,7 @@ int pgnn_bn_stats_fwd(const float* x, int64_t ldx, const float* gamma, const flo
   if (training)
     hipLaunchKernelGGL(k_bn_stats_partial, dim3(nblk), dim3(stat_threads(dim)), (size_t)8 * dim * sizeof(float), st, x,
                        ldx, (int)n, (int)(dim / 4), partial);
-  hipLaunchKernelGGL(k_bn_stats_final, dim3((int)ceil_div(dim, 16)), dim3(256), 0, st, partial, nblk, x, gamma, beta,
+  hipLaunchKernelGGL(k_bn_stats_final, dim3((int)ceil_div(dim, 4)), dim3(256), 0, st, partial, nblk, x, gamma, beta,
                      running_mean, running_var, momentum, eps, training, (int)n, (int)dim, save_mean, save_invstd, coef);
   return check_launch("bn_stats_fwd");
 }
@@ -347,7 +351,7 @@ int pgnn_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, cons
   const int d4 = (int)(dim / 4);
   hipLaunchKernelGGL(k_bn_bwd_partial, dim3(nblk), dim3(stat_threads(dim)), (size_t)8 * dim * sizeof(float), st, dy,
                      lddy, x, ldx, gamma, beta, save_mean, save_invstd, coef, relu, (int)n, d4, partial, drop);
-  hipLaunchKernelGGL(k_bn_bwd_final, dim3((int)ceil_div(dim, 16)), dim3(256), 0, st, partial, nblk, training, (int)n, (int)dim, gamma,
+  hipLaunchKernelGGL(k_bn_bwd_final, dim3((int)ceil_div(dim, 4)), dim3(256), 0, st, partial, nblk, training, (int)n, (int)dim, gamma,
                      coef, dgamma, dbeta);
   const int grid = (int)std::min<int64_t>(ceil_div(n, 4), (int64_t)num_cu() * 16);
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid), dim3(stat_threads(dim)), 0, st, dy, lddy, x, ldx, coef, relu, dx, lddx,

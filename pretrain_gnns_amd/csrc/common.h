@@ -167,4 +167,23 @@ __device__ __forceinline__ double slice_sum16(const float* __restrict__ p, size_
   return a;
 }
 
+
+// The same with a whole wave per output column: lane s sums the partials b = s, s+64, ... in double (four loads in
+// flight), then a 64-lane xor butterfly.  Every lane ends with the same bits; fixed association order => deterministic.
+__device__ __forceinline__ double slice_sum64(const float* __restrict__ p, size_t stride, int count, int s) {
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int b = s;
+  for (; b + 192 < count; b += 256) {
+    a0 += (double)p[(size_t)b * stride];
+    a1 += (double)p[(size_t)(b + 64) * stride];
+    a2 += (double)p[(size_t)(b + 128) * stride];
+    a3 += (double)p[(size_t)(b + 192) * stride];
+  }
+  for (; b < count; b += 64) a0 += (double)p[(size_t)b * stride];
+  double a = (a0 + a1) + (a2 + a3);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+  return a;
+}
+
 }  // namespace pgnn
