@@ -1,16 +1,24 @@
-"""run a few train steps at a given per-GPU batch (for rocprofv3 --kernel-trace --stats)."""
-import os, sys, torch
+"""exactly `steps` eager 256-graph masking train steps and nothing else, for `rocprofv3 --kernel-trace --stats` (the
+per-step kernel mix of profiles/rNN/step_b256_kernel_stats.csv = totals / steps).
+usage: python tools/step_profile.py [graphs=256] [steps=30] [warmup=5]   (prints ms/step measured without the profiler's help)"""
+import os, sys, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import bench
 from pretrain_gnns_amd import train as steps
-from pretrain_gnns_amd.chem import model as hmodel
 from pretrain_gnns_amd.data import synthetic
-g = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-dev = "cuda"
-base = synthetic.chem_masking_batch(min(g, 2048), seed=7)
-batch = (synthetic.tile_batch(base, g // 2048) if g > 2048 else base).to(dev)
-torch.manual_seed(0)
-mods = [hmodel.GNN(5, 300).to(dev), torch.nn.Linear(300, 119).to(dev), torch.nn.Linear(300, 4).to(dev)]
-opts = [torch.optim.Adam(m.parameters(), lr=1e-3, fused=True) for m in mods]
-for _ in range(26):
+graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+warm = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+dev = torch.device("cuda", 0)
+mods = bench.make_models(dev)
+opts = [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0, fused=True) for m in mods]
+batch = synthetic.chem_masking_batch(graphs, seed=0).to(dev)
+for _ in range(warm):
     steps.chem_masking_step(mods, opts, batch)
 torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(n_steps):
+    steps.chem_masking_step(mods, opts, batch)
+torch.cuda.synchronize()
+print("graphs %d: %d steps (+%d warm-up = %d launches of every per-step kernel), %.3f ms/step" % (
+    graphs, n_steps, warm, n_steps + warm, (time.perf_counter() - t0) / n_steps * 1e3))
