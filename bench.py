@@ -161,6 +161,32 @@ def pmc_traffic(n, e):
     return None, None
 
 
+def reference_loop_leg(dev, args, batch, steps_n):
+    """the same step with the reference script's loop taken literally: torch's default (foreach, multi-kernel) Adam as
+    `optim.Adam(...)` builds it (chem/pretrain_masking.py:134-136), accuracy and loss read back where the script reads them
+    (two device->host syncs per step, :54,76), ordinary autograd for every parameter (no direct gradient deposit).
+    `value` differs from this by three declared choices: fused Adam, one readback at the end of the step, direct deposit."""
+    from pretrain_gnns_amd import ops
+    from pretrain_gnns_amd import train as steps
+
+    mods = make_models(dev)
+    prev = ops.set_direct_grads(False)
+    try:
+        opts = [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0) for m in mods]
+        for _ in range(5):
+            steps.chem_masking_step(mods, opts, batch, mask_edge=False, readback="inline")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps_n):
+            steps.chem_masking_step(mods, opts, batch, mask_edge=False, readback="inline")
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps_n
+    finally:
+        ops.set_direct_grads(prev)
+    return {"edges_per_s": round(batch.edge_index.size(1) / dt, 1), "ms_per_step": round(dt * 1e3, 4),
+            "adam": "foreach (torch default)", "metrics_readback": "inline", "direct_grads": False}
+
+
 def forward_only(dev, mods, batch, iters):
     """edges/s of the GNN forward alone (training-mode BatchNorm, no autograd tape): SURVEY 8(d)(ii)."""
     model = mods[0]
@@ -579,6 +605,7 @@ def main():
             "comm": comm,
         }
         if world == 1:
+            res["reference_loop"] = reference_loop_leg(dev, args, batch, max(args.steps // 2, 20))
             res["forward_only"] = forward_only(dev, mods, batch, max(args.steps, 20))
         if world == 1 and not args.no_loader:
             res["resident_loader"] = resident_loader_leg(dev, args, max(args.steps, 20))

@@ -84,10 +84,13 @@ __device__ __forceinline__ void gemm_wait_vmcnt(int n) {
 #undef PGNN_W
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, int KS>
+// KSS encodes the k-step depth and the ring depth: 1 / 2 = KS images per barrier with a 2-stage ring; 11 / 12 = one image per
+// barrier with a 3- / 4-stage ring (PGNN_GEMM_KS selects; measured in tools/gemm_bench.py)
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, int KSS>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
   constexpr int BK = 16;       // depth of one LDS image (= 4 MFMA k-steps)
-  constexpr int STAGES = 2;    // LDS ring; each stage holds KS images = 16*KS of k per barrier
+  constexpr int KS = KSS >= 10 ? 1 : KSS;
+  constexpr int STAGES = KSS >= 10 ? KSS - 8 : 2;    // LDS ring; each stage holds KS images = 16*KS of k per barrier
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MI = WM / 16, NI = WN / 16;
@@ -290,7 +293,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, int KS>
 int launch_gemm_s(const GemmArgs& p, int nsplit, hipStream_t st) {
-  constexpr size_t lds = (size_t)2 * KS * 16 * (BM + BN) * sizeof(float);
+  constexpr size_t lds = (size_t)(KS >= 10 ? KS - 8 : 2 * KS) * 16 * (BM + BN) * sizeof(float);
   const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N + (ONES ? 4 : 0), BN));
   allow_big_lds((const void*)k_gemm<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, KS>, lds);
   hipLaunchKernelGGL((k_gemm<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, KS>), dim3(tiles, nsplit),
@@ -308,7 +311,10 @@ int launch_gemm(const GemmArgs& p, int nsplit, hipStream_t st) {
   // faster than the plain 2-stage loop -- DMA issue, fragment reads and the barrier are *issue-time*
   // costs that both waves of a SIMD pay in lockstep in front of their MFMA burst -- so the lever is
   // fewer barriers per FLOP, i.e. a deeper k-step.
-  if (env_ks(kDefaultKS) >= 2) return launch_gemm_s<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, 2>(p, nsplit, st);
+  const int ks = env_ks(kDefaultKS);
+  if (ks == 11) return launch_gemm_s<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, 11>(p, nsplit, st);
+  if (ks == 12) return launch_gemm_s<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, 12>(p, nsplit, st);
+  if (ks >= 2) return launch_gemm_s<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, 2>(p, nsplit, st);
   return launch_gemm_s<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, 1>(p, nsplit, st);
 }
 
