@@ -416,26 +416,30 @@ int pgnn_neighbor_sum_tiled(const float* x, int64_t ldx, const int32_t* ptr, con
  * Attention layers (off the north-star path, native and deterministic): csrc/attention.hip.
  * ------------------------------------------------------------------------------------------ */
 
-/* 2-head GATConv message / edge soft-max / aggregate / update of chem/model.py:133-162 on the CSR of the graph build:
- *   xh [N, 2*dim]      weight_linear(x), heads side by side (chem/model.py:144)
- *   emb1 [6, 2*dim], emb2 [3, 2*dim], ctab [18, 2] = (emb1[t] + emb2[d]) . att[h, dim:2dim]  (host-side, parameter space)
- *   att [2, 2*dim]     the reference's `att` parameter [1, heads, 2*emb_dim]; bias [dim]
- *   scores [N, 4], z / alpha [E + N, 2] (slot p of node i at p + i, self loop at in_ptr[i+1] + i), cfa [2, N, 9]: saved
- *   for the backward; out [N, dim].
- * The soft-max follows torch_geometric 1.0.3 on torch_scatter 1.1.2 (shift = max(0, segment max), + 1e-16).
- * (edge_emb / cslot: per-slot edge terms instead of the bond tables -- the bio form; pass NULL with the chem tables.) */
+/* 2-head GATConv message / edge soft-max / aggregate / update (chem/model.py:133-162, bio/model.py:147-180) on the CSR of
+ * the graph build.  Common: xh [N, 2*dim] = weight_linear(x), heads side by side; att [2, 2*dim] (the reference's `att`
+ * parameter [1, heads, 2*emb_dim]); bias [dim]; scores [N, 4], z / alpha [E + N, 2] (slot p of node i at p + i, its self loop at
+ * in_ptr[i+1] + i) and cfa are saved for the backward; out [N, dim].  The soft-max follows torch_geometric 1.0.3 on
+ * torch_scatter 1.1.2 (shift = max(0, segment max), + 1e-16).
+ *   chem form : emb1 [6, 2*dim], emb2 [3, 2*dim], in_code, ctab [18, 2] = (emb1[t] + emb2[d]) . att[h, dim:2dim] (parameter
+ *               space, host side); cfa [2, N, 9]; slot_feat = NULL.
+ *   bio form  : emb1 = NULL; slot_feat [E, kf] = the edge attributes in CSR-slot order with a trailing constant 1 (kf = 10),
+ *               self_feat [kf] (one-hot 7 and the 1), wv [kf, 2] = Tenc_h . att[h, dim:2dim] with Tenc = [W_enc^T; b] [kf, 2*dim];
+ *               cfa [2, N, kf].  The edge_encoder output [E, 2*dim] is never formed: out lacks the term
+ *               sum_h cfa[h] . Tenc_h, which the caller adds with pgnn_rowfeat_matmul_fwd (accumulate). */
 int pgnn_gat_fwd(const float* xh, int64_t ldx, const int32_t* in_ptr, const int32_t* in_src, const uint8_t* in_code,
-                 const float* emb1, const float* emb2, const float* edge_emb, const float* ctab, const float* cslot,
-                 const float* att, const float* bias, float negative_slope, float* scores, float* z, float* alpha, float* cfa,
-                 float* out, int64_t ldo, int64_t num_nodes, int64_t dim, pgnn_stream stream);
+                 const float* emb1, const float* emb2, const float* ctab, const float* slot_feat, const float* self_feat,
+                 const float* wv, int64_t kf, const float* att, const float* bias, float negative_slope, float* scores,
+                 float* z, float* alpha, float* cfa, float* out, int64_t ldo, int64_t num_nodes, int64_t dim, pgnn_stream stream);
 /* backward: dalpha [E + N, 2] scratch (receives dz), dsd [2, N, 2] = per head (sum dz over the in-segment, sum dz over the
- * out-edges + self), czf [2, N, 9] = dz per bond type / direction, wout [E, 2] scratch, dxh [N, 2*dim].  The parameter
- * gradients follow from these with pgnn_rowfeat_matmul_bwd (kc = 2: att; kc = 9: bond tables) -- see ops.GATAggregate. */
+ * out-edges + self), czf [2, N, 9 | kf] = dz per bond type / direction (chem) or dz-weighted feature sums (bio), wout [E, 2]
+ * scratch, dxh [N, 2*dim]; tenc [kf, 2*dim] (bio).  The parameter gradients follow from these with pgnn_rowfeat_matmul_bwd
+ * (kc = 2: att; kc = 9 / 10: bond tables / encoder) -- see ops.GATAggregate / ops.BioGATAggregate. */
 int pgnn_gat_bwd(const float* g, int64_t ldg, const float* xh, int64_t ldx, const int32_t* in_ptr, const int32_t* in_src,
                  const uint8_t* in_code, const int32_t* out_ptr, const int32_t* out_dst, const float* emb1, const float* emb2,
-                 const float* edge_emb, const float* att, float negative_slope, const float* z, const float* alpha,
-                 float* dalpha, float* dsd, float* czf, float* wout, float* dxh, int64_t ldd, int64_t num_nodes, int64_t dim,
-                 pgnn_stream stream);
+                 const float* slot_feat, const float* self_feat, const float* tenc, int64_t kf, const float* att,
+                 float negative_slope, const float* z, const float* alpha, float* dalpha, float* dsd, float* czf, float* wout,
+                 float* dxh, int64_t ldd, int64_t num_nodes, int64_t dim, pgnn_stream stream);
 
 /* soft-max over segments (torch_geometric.utils.softmax 1.0.3): items perm[ptr[s] .. ptr[s+1]) (perm NULL = identity),
  * z / alpha [items, heads].  GlobalAttention gate and Set2Set attention (chem/model.py:329-339). */

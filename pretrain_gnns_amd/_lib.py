@@ -82,9 +82,10 @@ PROTOTYPES = {
     "pgnn_graph_tiles_workspace_bytes": (_sz, [_i64]),
     "pgnn_graph_tiles": (_i, [_p, _p, _p, _p, _i64, _p, _p, _p, _sz, _p]),
     "pgnn_neighbor_sum_tiled": (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p]),
-    "pgnn_gat_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
-    "pgnn_gat_bwd": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _i64, _i64,
-                          _i64, _p]),
+    "pgnn_gat_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _f, _p, _p, _p, _p, _p, _i64, _i64, _i64,
+                          _p]),
+    "pgnn_gat_bwd": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _f, _p, _p, _p, _p, _p, _p, _p,
+                          _i64, _i64, _i64, _p]),
     "pgnn_segment_softmax_fwd": (_i, [_p, _p, _p, _p, _i64, _i64, _p]),
     "pgnn_segment_softmax_bwd": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _p]),
     "pgnn_segment_max_fwd": (_i, [_p, _i64, _p, _p, _p, _i64, _p, _i64, _i64, _p]),

@@ -90,7 +90,8 @@ class GraphSAGEConv(torch.nn.Module):
 
 
 class GATConv(torch.nn.Module):
-    """bio/model.py:117-181; see chem GATConv for what runs where."""
+    """bio/model.py:117-181: weight_linear on the MFMA GEMM, then message / edge soft-max / aggregate / update as the HIP
+    kernels of csrc/attention.hip (ops.BioGATAggregate; the edge_encoder output [E, 2D] is never formed)."""
 
     def __init__(self, emb_dim, heads=2, negative_slope=0.2, aggr="add", input_layer=False):
         super().__init__()
@@ -114,6 +115,12 @@ class GATConv(torch.nn.Module):
     def forward(self, x, edge_index, edge_attr, graph=None):
         x = _embed_input(self, x)
         xh = ops.linear(x, self.weight_linear)
+        if self.heads == 2:
+            if graph is None:
+                graph = ops.build_bio_graph(edge_index, edge_attr, x.size(0))
+            feat = ops.bio_slot_features(graph, edge_index, edge_attr)
+            return ops.BioGATAggregate.apply(xh, self.att, self.bias, self.edge_encoder.weight, self.edge_encoder.bias, graph, feat,
+                                             self.negative_slope)
         ee = self.edge_encoder(edge_attr.to(torch.float32))
         self_emb = self.edge_encoder.weight[:, 7] + self.edge_encoder.bias  # self-loop attr = one-hot index 7
         return attention.gat_propagate(xh, edge_index, ee, self_emb, self.att, self.bias, self.heads, self.negative_slope)
@@ -121,7 +128,7 @@ class GATConv(torch.nn.Module):
 
 class GNN(torch.nn.Module):
     """bio/model.py:227-290: ``num_layer`` convs with ReLU between them (no outer BatchNorm);
-    JK in last|sum; gnn_type in gin|gcn|graphsage (HIP kernels) | gat (GEMM + torch GPU ops)."""
+    JK in last|sum; gnn_type in gin|gcn|graphsage|gat (HIP kernels)."""
 
     def __init__(self, num_layer, emb_dim, JK="last", drop_ratio=0, gnn_type="gin"):
         super().__init__()

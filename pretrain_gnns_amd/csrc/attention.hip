@@ -11,6 +11,12 @@
 //             torch_scatter 1.1.2, whose scatter_max output is pre-filled with 0)
 //   out[i]  = mean_h sum_e a_eh m_eh + bias
 // Logits / weights live in "extended slot" arrays [E + N, H]: slot p of node i at p + i, its self loop at in_ptr[i+1] + i.
+//
+// bio GATConv (bio/model.py:117-180): the edge term is edge_encoder(attr_e) = W_enc attr_e + b instead of a table row.  By
+// linearity nothing of size [E, 2D] is ever formed: with per-slot features f_e = [attr_e (9), 1] (CSR order) and
+// Tenc = [W_enc^T; b] ([10, H*D]),  m_eh.att_j[h] = xh[src].att_j + f_e . wv[:,h]  (wv = Tenc_h . att_j[h], parameter space),
+// sum_e a_eh m_eh = sum_e a_eh xh[src_e,h] + (sum_e a_eh f_e) . Tenc_h, and the backward's per-edge rows are rebuilt on the
+// fly from f_e and Tenc (10 x 600 floats in LDS).  The chem kernels take the same path with `code` replaced by `sfeat`.
 #include "common.h"
 
 using namespace pgnn;
@@ -22,6 +28,7 @@ constexpr int kHeads = 2;          // the reference's GATConv default, the only 
 constexpr int kCodes = 18;         // bond type (6) x direction (3)
 constexpr int kSelfCode = 4 * 3;   // self loop: type 4, direction 0
 constexpr float kSoftEps = 1e-16f;
+constexpr int kMaxKF = 10;         // per-slot feature columns of the bio form (9 attributes + the constant 1)
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -63,7 +70,8 @@ __global__ void __launch_bounds__(kBlock) k_rowdot(const float* __restrict__ xh,
 // enters the bond-embedding gradients (chem only, cfa may be NULL).
 __global__ void __launch_bounds__(kBlock) k_gat_alpha_fwd(const float* __restrict__ s, const int32_t* __restrict__ ptr,
                                                           const int32_t* __restrict__ src, const uint8_t* __restrict__ code,
-                                                          const float* __restrict__ ctab, const float* __restrict__ cslot,
+                                                          const float* __restrict__ ctab, const float* __restrict__ sfeat,
+                                                          const float* __restrict__ self_feat, const float* __restrict__ wv, int kf,
                                                           float slope, float* __restrict__ z, float* __restrict__ alpha,
                                                           float* __restrict__ cfa, int n) {
   const int64_t t = blockIdx.x * (int64_t)kBlock + threadIdx.x;
@@ -71,15 +79,20 @@ __global__ void __launch_bounds__(kBlock) k_gat_alpha_fwd(const float* __restric
   const int i = (int)(t / kHeads), h = (int)(t % kHeads);
   const int beg = ptr[i], end = ptr[i + 1];
   const float sd = s[(int64_t)i * 2 * kHeads + h];
-  auto logit = [&](int p, int j, int cd) {
-    float v = sd + s[(int64_t)j * 2 * kHeads + kHeads + h];
-    v += ctab ? ctab[cd * kHeads + h] : cslot[(int64_t)(p + i) * kHeads + h];
-    return v > 0.f ? v : v * slope;
+  float w[kMaxKF];
+  if (sfeat)
+    for (int k = 0; k < kf; ++k) w[k] = wv[k * kHeads + h];
+  auto edge_term = [&](int p) {  // the bond / attribute part of the logit
+    if (!sfeat) return ctab[(p == end ? kSelfCode : code[p]) * kHeads + h];
+    const float* f = p == end ? self_feat : sfeat + (int64_t)p * kf;
+    float c = 0.f;
+    for (int k = 0; k < kf; ++k) c = fmaf(f[k], w[k], c);
+    return c;
   };
   float mx = 0.f;  // scatter_max's fill value
   for (int p = beg; p <= end; ++p) {
-    const bool self = p == end;
-    const float v = logit(p, self ? i : src[p], self ? kSelfCode : (code ? code[p] : 0));
+    float v = sd + s[(int64_t)(p == end ? i : src[p]) * 2 * kHeads + kHeads + h] + edge_term(p);
+    v = v > 0.f ? v : v * slope;
     z[(int64_t)(p + i) * kHeads + h] = v;
     mx = fmaxf(mx, v);
   }
@@ -90,18 +103,23 @@ __global__ void __launch_bounds__(kBlock) k_gat_alpha_fwd(const float* __restric
     sum += u;
   }
   const float inv = 1.f / (sum + kSoftEps);
-  float cf[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float cf[kMaxKF];
+  const int ncf = sfeat ? kf : 9;
+  for (int k = 0; k < ncf; ++k) cf[k] = 0.f;
   for (int p = beg; p <= end; ++p) {
     const float a = alpha[(int64_t)(p + i) * kHeads + h] * inv;
     alpha[(int64_t)(p + i) * kHeads + h] = a;
-    if (cfa) {
+    const float ah = a * (1.f / kHeads);
+    if (sfeat) {
+      const float* f = p == end ? self_feat : sfeat + (int64_t)p * kf;
+      for (int k = 0; k < kf; ++k) cf[k] = fmaf(ah, f[k], cf[k]);
+    } else {
       const int cd = p == end ? kSelfCode : code[p];
-      cf[cd / 3] += a * (1.f / kHeads);
-      cf[6 + cd % 3] += a * (1.f / kHeads);
+      cf[cd / 3] += ah;
+      cf[6 + cd % 3] += ah;
     }
   }
-  if (cfa)
-    for (int k = 0; k < 9; ++k) cfa[((int64_t)h * n + i) * 9 + k] = cf[k];
+  for (int k = 0; k < ncf; ++k) cfa[((int64_t)h * n + i) * ncf + k] = cf[k];
 }
 
 // out[i, :] = mean_h sum_e a_eh (xh[src_e,h,:] + T_h[code_e,:]) + bias.  D/4 threads per node, each owning one float4
@@ -136,21 +154,24 @@ __global__ void __launch_bounds__(320) k_gat_aggregate_fwd(const float* __restri
       for (int h = 0; h < kHeads; ++h) {
         float4 m = reinterpret_cast<const float4*>(xh + j * ldx + h * d)[c4];
         if (emb1) m = f4_add(m, reinterpret_cast<const float4*>(T + (self ? kSelfCode : code[p]) * hd + h * d)[c4]);
-        else m = f4_add(m, reinterpret_cast<const float4*>(ee + (int64_t)(p + i) * hd + h * d)[c4]);
+        else if (ee) m = f4_add(m, reinterpret_cast<const float4*>(ee + (int64_t)(p + i) * hd + h * d)[c4]);
         acc[h] = f4_add(acc[h], f4_scale(m, alpha[(int64_t)(p + i) * kHeads + h]));
       }
     }
     float4 o = f4_scale(f4_add(acc[0], acc[1]), 1.f / kHeads);
-    reinterpret_cast<float4*>(out + i * ldo)[c4] = f4_add(o, b4);
+    reinterpret_cast<float4*>(out + i * ldo)[c4] = f4_add(o, b4);  // (feature form: the caller adds cfa . Tenc afterwards)
   }
 }
 
-// dalpha[slot, h] = (g[i,:] / H) . (xh[src,h,:] + T_h[code,:]): one wave per node
+// dalpha[slot, h] = (g[i,:] / H) . (xh[src,h,:] + T_h[code,:]): one wave per node.  Feature form: the edge row is rebuilt as
+// sum_k f[k] Tenc[k, h, :] from the 10 x H*D table in LDS.
 __global__ void __launch_bounds__(kBlock) k_gat_edge_dot(const float* __restrict__ g, int64_t ldg, const float* __restrict__ xh,
                                                          int64_t ldx, const int32_t* __restrict__ ptr,
                                                          const int32_t* __restrict__ src, const uint8_t* __restrict__ code,
                                                          const float* __restrict__ emb1, const float* __restrict__ emb2,
-                                                         const float* __restrict__ ee, float* __restrict__ dalpha, int n, int d) {
+                                                         const float* __restrict__ sfeat, const float* __restrict__ self_feat,
+                                                         const float* __restrict__ tenc, int kf, float* __restrict__ dalpha, int n,
+                                                         int d) {
   extern __shared__ __align__(16) float T[];
   const int hd = kHeads * d;
   if (emb1) {
@@ -159,6 +180,9 @@ __global__ void __launch_bounds__(kBlock) k_gat_edge_dot(const float* __restrict
       T[q] = emb1[(c / 3) * hd + k] + emb2[(c % 3) * hd + k];
     }
     __syncthreads();
+  } else if (sfeat) {
+    for (int q = threadIdx.x; q < kf * hd; q += blockDim.x) T[q] = tenc[q];
+    __syncthreads();
   }
   const int lane = threadIdx.x & 63, d4 = d >> 2;
   for (int64_t i = blockIdx.x * (int64_t)(kBlock / 64) + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * (kBlock / 64)) {
@@ -166,14 +190,21 @@ __global__ void __launch_bounds__(kBlock) k_gat_edge_dot(const float* __restrict
     for (int p = beg; p <= end; ++p) {
       const bool self = p == end;
       const int64_t j = self ? i : src[p];
+      const float* f = sfeat ? (self ? self_feat : sfeat + (int64_t)p * kf) : nullptr;
       float acc[kHeads] = {0.f, 0.f};
       for (int c = lane; c < d4; c += 64) {
         const float4 gv = reinterpret_cast<const float4*>(g + i * ldg)[c];
 #pragma unroll
         for (int h = 0; h < kHeads; ++h) {
           float4 m = reinterpret_cast<const float4*>(xh + j * ldx + h * d)[c];
-          if (emb1) m = f4_add(m, reinterpret_cast<const float4*>(T + (self ? kSelfCode : code[p]) * hd + h * d)[c]);
-          else m = f4_add(m, reinterpret_cast<const float4*>(ee + (int64_t)(p + i) * hd + h * d)[c]);
+          if (emb1) {
+            m = f4_add(m, reinterpret_cast<const float4*>(T + (self ? kSelfCode : code[p]) * hd + h * d)[c]);
+          } else if (sfeat) {
+            for (int k = 0; k < kf; ++k) {
+              const float4 tv = reinterpret_cast<const float4*>(T + k * hd + h * d)[c];
+              m.x = fmaf(f[k], tv.x, m.x); m.y = fmaf(f[k], tv.y, m.y); m.z = fmaf(f[k], tv.z, m.z); m.w = fmaf(f[k], tv.w, m.w);
+            }
+          }
           acc[h] += dot4(gv, m);
         }
       }
@@ -190,7 +221,8 @@ __global__ void __launch_bounds__(kBlock) k_gat_edge_dot(const float* __restrict
 // (destination term) ; czf[h][i][0:9] = sum of dz per bond type / direction (chem).  dz overwrites dalpha.
 __global__ void __launch_bounds__(kBlock) k_gat_alpha_bwd(const float* __restrict__ alpha, const float* __restrict__ z,
                                                           float* __restrict__ dalpha, const int32_t* __restrict__ ptr,
-                                                          const uint8_t* __restrict__ code, float slope,
+                                                          const uint8_t* __restrict__ code, const float* __restrict__ sfeat,
+                                                          const float* __restrict__ self_feat, int kf, float slope,
                                                           float* __restrict__ dsd, float* __restrict__ czf, int n) {
   const int64_t t = blockIdx.x * (int64_t)kBlock + threadIdx.x;
   if (t >= (int64_t)n * kHeads) return;
@@ -199,22 +231,26 @@ __global__ void __launch_bounds__(kBlock) k_gat_alpha_bwd(const float* __restric
   float dotp = 0.f;
   for (int p = beg; p <= end; ++p) dotp += alpha[(int64_t)(p + i) * kHeads + h] * dalpha[(int64_t)(p + i) * kHeads + h];
   float tot = 0.f;
-  float cf[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float cf[kMaxKF];
+  const int ncf = sfeat ? kf : 9;
+  for (int k = 0; k < ncf; ++k) cf[k] = 0.f;
   for (int p = beg; p <= end; ++p) {
     const int64_t q = (int64_t)(p + i) * kHeads + h;
     float dz = alpha[q] * (dalpha[q] - dotp);
     if (!(z[q] > 0.f)) dz *= slope;
     dalpha[q] = dz;
     tot += dz;
-    if (czf) {
+    if (sfeat) {
+      const float* f = p == end ? self_feat : sfeat + (int64_t)p * kf;
+      for (int k = 0; k < kf; ++k) cf[k] = fmaf(dz, f[k], cf[k]);
+    } else {
       const int cd = p == end ? kSelfCode : code[p];
       cf[cd / 3] += dz;
       cf[6 + cd % 3] += dz;
     }
   }
   dsd[((int64_t)h * n + i) * 2 + 0] = tot;
-  if (czf)
-    for (int k = 0; k < 9; ++k) czf[((int64_t)h * n + i) * 9 + k] = cf[k];
+  for (int k = 0; k < ncf; ++k) czf[((int64_t)h * n + i) * ncf + k] = cf[k];
 }
 
 // per SOURCE node j (CSR by source): find, for each out-edge q -> dst, the matching slot in dst's in-list (the r-th edge
@@ -361,42 +397,47 @@ __global__ void __launch_bounds__(kBlock) k_segment_max_bwd(const float* __restr
 extern "C" {
 
 int pgnn_gat_fwd(const float* xh, int64_t ldx, const int32_t* in_ptr, const int32_t* in_src, const uint8_t* in_code,
-                 const float* emb1, const float* emb2, const float* edge_emb, const float* ctab, const float* cslot,
-                 const float* att, const float* bias, float negative_slope, float* scores, float* z, float* alpha, float* cfa,
-                 float* out, int64_t ldo, int64_t num_nodes, int64_t dim, pgnn_stream stream) {
+                 const float* emb1, const float* emb2, const float* ctab, const float* slot_feat, const float* self_feat,
+                 const float* wv, int64_t kf, const float* att, const float* bias, float negative_slope, float* scores,
+                 float* z, float* alpha, float* cfa, float* out, int64_t ldo, int64_t num_nodes, int64_t dim, pgnn_stream stream) {
   PGNN_REQUIRE(num_nodes > 0 && dim > 0 && dim % 4 == 0 && dim <= 1280 && ldx % 4 == 0 && ldo % 4 == 0, "gat_fwd: bad shape");
-  PGNN_REQUIRE((emb1 != nullptr) == (ctab != nullptr) && (emb1 != nullptr) != (edge_emb != nullptr) &&
-                   (edge_emb != nullptr) == (cslot != nullptr) && (emb1 == nullptr || in_code != nullptr),
-               "gat_fwd: pass either the chem tables (emb1, emb2, ctab, in_code) or the bio per-slot terms (edge_emb, cslot)");
+  const bool chem = emb1 != nullptr;
+  PGNN_REQUIRE(chem ? (emb2 && ctab && in_code && !slot_feat) : (slot_feat && self_feat && wv && kf > 0 && kf <= kMaxKF),
+               "gat_fwd: pass either the chem tables (emb1, emb2, ctab, in_code) or the per-slot features (slot_feat, self_feat, wv, kf <= %d)",
+               kMaxKF);
   hipStream_t st = (hipStream_t)stream;
   const int n = (int)num_nodes, d = (int)dim;
   hipLaunchKernelGGL(k_rowdot, dim3(grid_rows(n, kBlock / 64)), dim3(kBlock), 0, st, xh, ldx, att, scores, n, d);
   hipLaunchKernelGGL(k_gat_alpha_fwd, dim3((int)ceil_div((int64_t)n * kHeads, kBlock)), dim3(kBlock), 0, st, scores, in_ptr, in_src,
-                     in_code, ctab, cslot, negative_slope, z, alpha, cfa, n);
+                     in_code, ctab, slot_feat, self_feat, wv, (int)kf, negative_slope, z, alpha, cfa, n);
   const int gs = d / 4, groups = std::max(1, 320 / gs);
   PGNN_REQUIRE(gs <= 320, "gat_fwd: dim too wide");
-  const size_t lds = emb1 ? (size_t)kCodes * kHeads * d * sizeof(float) : 0;
+  const size_t lds = chem ? (size_t)kCodes * kHeads * d * sizeof(float) : 0;
   allow_big_lds((const void*)k_gat_aggregate_fwd, lds);
   hipLaunchKernelGGL(k_gat_aggregate_fwd, dim3(grid_rows(n, groups)), dim3(320), lds, st, xh, ldx, in_ptr, in_src, in_code, emb1,
-                     emb2, edge_emb, alpha, bias, out, ldo, n, d, groups);
+                     emb2, (const float*)nullptr, alpha, bias, out, ldo, n, d, groups);
   return check_launch("gat_fwd");
 }
 
 int pgnn_gat_bwd(const float* g, int64_t ldg, const float* xh, int64_t ldx, const int32_t* in_ptr, const int32_t* in_src,
                  const uint8_t* in_code, const int32_t* out_ptr, const int32_t* out_dst, const float* emb1, const float* emb2,
-                 const float* edge_emb, const float* att, float negative_slope, const float* z, const float* alpha,
-                 float* dalpha, float* dsd, float* czf, float* wout, float* dxh, int64_t ldd, int64_t num_nodes, int64_t dim,
-                 pgnn_stream stream) {
+                 const float* slot_feat, const float* self_feat, const float* tenc, int64_t kf, const float* att,
+                 float negative_slope, const float* z, const float* alpha, float* dalpha, float* dsd, float* czf, float* wout,
+                 float* dxh, int64_t ldd, int64_t num_nodes, int64_t dim, pgnn_stream stream) {
   PGNN_REQUIRE(num_nodes > 0 && dim > 0 && dim % 4 == 0 && dim <= 1280 && ldx % 4 == 0 && ldg % 4 == 0 && ldd % 4 == 0,
                "gat_bwd: bad shape");
+  const bool chem = emb1 != nullptr;
+  PGNN_REQUIRE(chem ? (emb2 && in_code && !slot_feat) : (slot_feat && self_feat && tenc && kf > 0 && kf <= kMaxKF),
+               "gat_bwd: pass either the chem tables or the per-slot features");
   hipStream_t st = (hipStream_t)stream;
   const int n = (int)num_nodes, d = (int)dim;
-  const size_t lds = emb1 ? (size_t)kCodes * kHeads * d * sizeof(float) : 0;
+  const size_t lds = (size_t)(chem ? kCodes : kf) * kHeads * d * sizeof(float);
   allow_big_lds((const void*)k_gat_edge_dot, lds);
   hipLaunchKernelGGL(k_gat_edge_dot, dim3(grid_rows(n, kBlock / 64)), dim3(kBlock), lds, st, g, ldg, xh, ldx, in_ptr, in_src, in_code,
-                     emb1, emb2, edge_emb, dalpha, n, d);
+                     emb1, emb2, slot_feat, self_feat, tenc, (int)kf, dalpha, n, d);
   const int tgrid = (int)ceil_div((int64_t)n * kHeads, kBlock);
-  hipLaunchKernelGGL(k_gat_alpha_bwd, dim3(tgrid), dim3(kBlock), 0, st, alpha, z, dalpha, in_ptr, in_code, negative_slope, dsd, czf, n);
+  hipLaunchKernelGGL(k_gat_alpha_bwd, dim3(tgrid), dim3(kBlock), 0, st, alpha, z, dalpha, in_ptr, in_code, slot_feat, self_feat, (int)kf,
+                     negative_slope, dsd, czf, n);
   hipLaunchKernelGGL(k_gat_src_gather, dim3(tgrid), dim3(kBlock), 0, st, in_ptr, in_src, out_ptr, out_dst, alpha, dalpha, dsd, wout, n);
   const int gs = d / 4, groups = std::max(1, 320 / gs);
   PGNN_REQUIRE(gs <= 320, "gat_bwd: dim too wide");

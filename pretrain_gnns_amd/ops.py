@@ -66,7 +66,7 @@ class GraphStruct:
     """CSR-by-destination + CSR-by-source + per-node edge-feature sums of one batch."""
 
     __slots__ = ("kind", "gcn", "n", "e", "in_ptr", "in_src", "in_code", "out_ptr", "out_dst", "dinv", "cfeat",
-                 "status", "tiles")
+                 "status", "tiles", "slot_feat")
 
     @property
     def kc(self):
@@ -87,7 +87,7 @@ def _build_graph(kind, edge_index, edge_attr, num_nodes, gcn):
     ei = edge_index.contiguous()
     e, n = ei.size(1), int(num_nodes)
     g = GraphStruct()
-    g.kind, g.gcn, g.n, g.e, g.tiles = kind, bool(gcn), n, e, None
+    g.kind, g.gcn, g.n, g.e, g.tiles, g.slot_feat = kind, bool(gcn), n, e, None, None
     g.in_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
     g.out_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
     g.in_src = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
@@ -460,7 +460,7 @@ class GATAggregate(Function):
         cfa = torch.empty(heads, n, 9, dtype=torch.float32, device=dev)
         out = torch.empty(n, d, dtype=torch.float32, device=dev)
         check(load().pgnn_gat_fwd(xh.data_ptr(), xh.stride(0), graph.in_ptr.data_ptr(), graph.in_src.data_ptr(),
-                                  graph.in_code.data_ptr(), e1.data_ptr(), e2.data_ptr(), None, ctab.data_ptr(), None,
+                                  graph.in_code.data_ptr(), e1.data_ptr(), e2.data_ptr(), ctab.data_ptr(), None, None, None, 0,
                                   att2.data_ptr(), b.data_ptr(), float(negative_slope), scores.data_ptr(), z.data_ptr(),
                                   alpha.data_ptr(), cfa.data_ptr(), out.data_ptr(), d, n, d, stream_ptr()), "pgnn_gat_fwd")
         ctx.save_for_backward(xh, att2, e1, e2, z, alpha, cfa)
@@ -483,8 +483,8 @@ class GATAggregate(Function):
         dxh = torch.empty(n, hd, dtype=torch.float32, device=dev)
         check(load().pgnn_gat_bwd(g.data_ptr(), g.stride(0), xh.data_ptr(), xh.stride(0), graph.in_ptr.data_ptr(),
                                   graph.in_src.data_ptr(), graph.in_code.data_ptr(), graph.out_ptr.data_ptr(),
-                                  graph.out_dst.data_ptr(), e1.data_ptr(), e2.data_ptr(), None, att2.data_ptr(), ctx.slope,
-                                  z.data_ptr(), alpha.data_ptr(), dalpha.data_ptr(), dsd.data_ptr(), czf.data_ptr(),
+                                  graph.out_dst.data_ptr(), e1.data_ptr(), e2.data_ptr(), None, None, None, 0, att2.data_ptr(),
+                                  ctx.slope, z.data_ptr(), alpha.data_ptr(), dalpha.data_ptr(), dsd.data_ptr(), czf.data_ptr(),
                                   wout.data_ptr(), dxh.data_ptr(), hd, n, d, stream_ptr()), "pgnn_gat_bwd")
         demb = torch.empty(9, hd, dtype=torch.float32, device=dev)  # rows 0..5 = d emb1, 6..8 = d emb2
         datt = torch.empty(heads, 2 * d, dtype=torch.float32, device=dev)
@@ -507,6 +507,98 @@ class GATAggregate(Function):
             datt[h, :d] = gt[0]
             datt[h, d:] = gt[1] + (s9.unsqueeze(1) * e9[:, cols]).sum(0)
         return dxh, datt.view(1, heads, 2 * d), g.sum(0), demb[:6], demb[6:], None, None
+
+
+def bio_slot_features(graph, edge_index, edge_attr):
+    """[E, 10] fp32: the 9 edge attributes in CSR-slot order (the stable grouping by edge_index[0] the graph build uses)
+    followed by a constant 1 -- the bias column of edge_encoder.  Built once per batch and shared by the layers."""
+    cached = getattr(graph, "slot_feat", None)
+    if cached is None:
+        e = graph.e
+        _, perm = group_by_key(edge_index[0].contiguous(), graph.n)
+        attrs = edge_attr.to(torch.float32)[perm[:e].long()]
+        cached = torch.cat([attrs, torch.ones(e, 1, dtype=torch.float32, device=attrs.device)], dim=1).contiguous()
+        if e == 0:
+            cached = torch.zeros(1, 10, dtype=torch.float32, device=attrs.device)
+        graph.slot_feat = cached
+    return cached
+
+
+class BioGATAggregate(Function):
+    """message / edge soft-max / aggregate / update of the 2-head bio GATConv (bio/model.py:147-180): xh [N, 2D] =
+    weight_linear(x) -> out [N, D], edge term edge_encoder(attr) = W_enc attr + b_enc (self loops: attr = one-hot 7).
+    The [E, 2D] encoder output is never formed (linearity; csrc/attention.hip header).  Sums sequential in a fixed order."""
+
+    KF = 10
+
+    @staticmethod
+    def forward(ctx, xh, att, bias, enc_w, enc_b, graph, slot_feat, negative_slope):
+        require_cuda(xh, att, bias, enc_w, enc_b, slot_feat)
+        xh = _rows2d(xh)
+        n, hd = xh.shape
+        heads, d, kf = 2, hd // 2, BioGATAggregate.KF
+        if att.shape != (1, heads, 2 * d) or enc_w.shape != (hd, kf - 1) or enc_b.shape != (hd,) or graph.kind != "bio" \
+                or n != graph.n or slot_feat.shape != (max(graph.e, 1), kf):
+            raise _lib.PgnnError("bio GAT: shape mismatch (2 heads, bio graph, 9 edge attributes)")
+        dev = xh.device
+        att2 = _f32c(att.view(heads, 2 * d))
+        b = _f32c(bias)
+        tenc = torch.cat([enc_w.t(), enc_b.unsqueeze(0)], dim=0).to(torch.float32).contiguous()  # [kf, 2D]
+        wv = (tenc.view(kf, heads, d) * att2[:, d:].unsqueeze(0)).sum(-1).contiguous()  # [kf, heads]
+        self_feat = torch.zeros(kf, dtype=torch.float32, device=dev)
+        self_feat[7] = 1.0
+        self_feat[kf - 1] = 1.0
+        slots = graph.e + n
+        scores = torch.empty(n, 2 * heads, dtype=torch.float32, device=dev)
+        z = torch.empty(slots, heads, dtype=torch.float32, device=dev)
+        alpha = torch.empty(slots, heads, dtype=torch.float32, device=dev)
+        cfa = torch.empty(heads, n, kf, dtype=torch.float32, device=dev)
+        out = torch.empty(n, d, dtype=torch.float32, device=dev)
+        check(load().pgnn_gat_fwd(xh.data_ptr(), xh.stride(0), graph.in_ptr.data_ptr(), graph.in_src.data_ptr(), None, None, None,
+                                  None, slot_feat.data_ptr(), self_feat.data_ptr(), wv.data_ptr(), kf, att2.data_ptr(),
+                                  b.data_ptr(), float(negative_slope), scores.data_ptr(), z.data_ptr(), alpha.data_ptr(),
+                                  cfa.data_ptr(), out.data_ptr(), d, n, d, stream_ptr()), "pgnn_gat_fwd")
+        for h in range(heads):  # + (sum_e a_eh f_e / heads) . Tenc_h
+            _rowfeat_fwd(cfa[h], tenc[:, h * d:(h + 1) * d], out, d, accumulate=True)
+        ctx.save_for_backward(xh, att2, tenc, slot_feat, self_feat, z, alpha, cfa)
+        ctx.graph, ctx.slope = graph, float(negative_slope)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        xh, att2, tenc, slot_feat, self_feat, z, alpha, cfa = ctx.saved_tensors
+        graph = ctx.graph
+        g = _rows2d(g)
+        n, hd = xh.shape
+        heads, d, kf = 2, hd // 2, BioGATAggregate.KF
+        dev = g.device
+        dalpha = torch.empty_like(alpha)
+        dsd = torch.empty(heads, n, 2, dtype=torch.float32, device=dev)
+        czf = torch.empty(heads, n, kf, dtype=torch.float32, device=dev)
+        wout = torch.empty(max(graph.e, 1), heads, dtype=torch.float32, device=dev)
+        dxh = torch.empty(n, hd, dtype=torch.float32, device=dev)
+        check(load().pgnn_gat_bwd(g.data_ptr(), g.stride(0), xh.data_ptr(), xh.stride(0), graph.in_ptr.data_ptr(),
+                                  graph.in_src.data_ptr(), None, graph.out_ptr.data_ptr(), graph.out_dst.data_ptr(), None, None,
+                                  slot_feat.data_ptr(), self_feat.data_ptr(), tenc.data_ptr(), kf, att2.data_ptr(), ctx.slope,
+                                  z.data_ptr(), alpha.data_ptr(), dalpha.data_ptr(), dsd.data_ptr(), czf.data_ptr(),
+                                  wout.data_ptr(), dxh.data_ptr(), hd, n, d, stream_ptr()), "pgnn_gat_bwd")
+        dtenc = torch.empty(kf, hd, dtype=torch.float32, device=dev)
+        datt = torch.empty(heads, 2 * d, dtype=torch.float32, device=dev)
+        lib, sp = load(), stream_ptr()
+        for h in range(heads):
+            cols = slice(h * d, (h + 1) * d)
+            ws = _workspace(_ws_bytes("pgnn_rowfeat_matmul_bwd_workspace_bytes", n, kf, d), dev)
+            check(lib.pgnn_rowfeat_matmul_bwd(cfa[h].data_ptr(), kf, g.data_ptr(), g.stride(0), dtenc[:, cols].data_ptr(), hd, n, d,
+                                              ws.data_ptr(), ws.numel(), sp), "pgnn_rowfeat_matmul_bwd")
+            sk = czf[h].sum(0)  # logits path through the edge term
+            dtenc[:, cols] += sk.unsqueeze(1) * att2[h, d:].unsqueeze(0)
+            gt = torch.empty(2, d, dtype=torch.float32, device=dev)
+            check(lib.pgnn_rowfeat_matmul_bwd(dsd[h].data_ptr(), 2, xh[:, cols].data_ptr(), xh.stride(0), gt.data_ptr(), d, n, d,
+                                              ws.data_ptr(), ws.numel(), sp), "pgnn_rowfeat_matmul_bwd")
+            datt[h, :d] = gt[0]
+            datt[h, d:] = gt[1] + (sk.unsqueeze(1) * tenc[:, cols]).sum(0)
+        return dxh, datt.view(1, heads, 2 * d), g.sum(0), dtenc[:kf - 1].t(), dtenc[kf - 1], None, None, None
 
 
 def _segments(batch, size):

@@ -595,6 +595,55 @@ def test_gat_aggregate_fwd_bwd(shape):
     assert torch.equal(again, got.detach())
 
 
+@pytest.mark.parametrize("shape", ["ego_nets", "isolated"])
+def test_bio_gat_aggregate_fwd_bwd(shape):
+    """2-head bio GATConv on the CSR kernels (per-slot attribute form; the edge_encoder output is never formed) vs the
+    oracle's torch composition (bio/model.py:117-180): output and every gradient (projected features, att, bias, edge
+    encoder weight and bias), and the slot order of the attribute rows against the graph build's CSR"""
+    from oracle import bio as obio
+    ops = _ops()
+    dim = 300
+    b = synthetic.bio_masking_batch(5, seed=6)
+    ei, ea, n = b.edge_index, b.edge_attr.to(torch.float32), b.x.size(0)
+    if shape == "isolated":
+        keep = (ei[0] < n // 2) & (ei[1] < n // 2)  # the upper half of the nodes keeps only its self loops
+        ei, ea = ei[:, keep], ea[keep]
+    ea = ea + 0.25 * torch.rand_like(ea)  # non-binary attributes: exercises the linear (not table) form
+    torch.manual_seed(4)
+    conv = obio.GATConv(dim)
+    conv.bias.data.normal_(0, 0.1)
+
+    class _Id(torch.nn.Module):
+        def forward(self, t):
+            return t
+
+    lin, conv.weight_linear = conv.weight_linear, _Id()
+    xh_ref = torch.randn(n, 2 * dim, requires_grad=True)
+    want = conv(xh_ref, ei, ea)
+    gout = torch.randn(n, dim)
+    want.backward(gout)
+    conv.weight_linear = lin
+    g = ops.build_bio_graph(ei.to(DEV), ea.to(DEV), n)
+    feat = ops.bio_slot_features(g, ei.to(DEV), ea.to(DEV))
+    _, perm = ops.group_by_key(ei[0].to(DEV).contiguous(), n)
+    assert torch.equal(g.in_src[: g.e].long().cpu(), ei[1][perm[: g.e].long().cpu()])
+    xh = xh_ref.detach().to(DEV).requires_grad_(True)
+    att = conv.att.detach().to(DEV).requires_grad_(True)
+    bias = conv.bias.detach().to(DEV).requires_grad_(True)
+    w = conv.edge_encoder.weight.detach().to(DEV).requires_grad_(True)
+    bb = conv.edge_encoder.bias.detach().to(DEV).requires_grad_(True)
+    got = ops.BioGATAggregate.apply(xh, att, bias, w, bb, g, feat, conv.negative_slope)
+    got.backward(gout.to(DEV))
+    torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(xh.grad.cpu(), xh_ref.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(att.grad.cpu(), conv.att.grad, rtol=1e-4, atol=2e-4)
+    torch.testing.assert_close(bias.grad.cpu(), conv.bias.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(w.grad.cpu(), conv.edge_encoder.weight.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(bb.grad.cpu(), conv.edge_encoder.bias.grad, rtol=1e-4, atol=1e-3)
+    again = ops.BioGATAggregate.apply(xh.detach(), att.detach(), bias.detach(), w.detach(), bb.detach(), g, feat, conv.negative_slope)
+    assert torch.equal(again, got.detach())
+
+
 @pytest.mark.parametrize("sorted_batch", [True, False])
 def test_segment_softmax_and_max_pool(sorted_batch):
     """pgnn_segment_softmax_* / pgnn_segment_max_* vs the PyG-1.0.3 semantics of the oracle: shift max(0, .), +1e-16,
