@@ -207,7 +207,9 @@ int pgnn_mean_l2norm_bwd(const float* dy, int64_t lddy, const float* y, int64_t 
 
 /* ------------------------------------------------------------------------------------------
  * Linear layers of the GIN mlp / GCN linear (chem/model.py:29,54-55,63,99; bio/model.py:24,67,109):
- * fp32 MFMA GEMMs (v_mfma_f32_16x16x4_f32), exact fp32 accumulate.
+ * fp32 GEMMs on the matrix cores.  Forward: three-term bf16 split of every fp32 value, six v_mfma_f32_16x16x32_bf16
+ * products per k-step, fp32 accumulate -- the rounding error of an fp32 FMA chain (csrc/linear.hip; PGNN_GEMM_SPLIT=0
+ * selects the v_mfma_f32_16x16x4_f32 kernel instead).  Backward products: v_mfma_f32_16x16x4_f32, exact fp32 FMA chains.
  * ------------------------------------------------------------------------------------------ */
 
 /* y[M,N] = act(x[M,K] . W[N,K]^T + b) ; relu != 0 -> act = max(.,0) */

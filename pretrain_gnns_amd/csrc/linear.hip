@@ -18,6 +18,8 @@
 // The block->tile map is XCD-aware (tiles sharing an A row-panel run on one XCD's L2).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace pgnn {
@@ -50,6 +52,50 @@ __device__ float4 g_ones_page[1] = {{1.f, 0.f, 0.f, 0.f}};  // DMA source of the
 
 #define PGNN_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define PGNN_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// epilogue shared by the fp32-MFMA and the split-bf16 kernels (identical C/D register layout): lane holds
+// C[m = mw + 16 i + (lane & 15)][n = nw + 16 j + (lane >> 4) * 4 + 0..3] of each 16x16 block
+template <int EPI, bool ONES, int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI][NI], int mw, int nw, int lane) {
+  const int fr = lane & 15, fk = lane >> 4;
+  float* C = p.C + (int64_t)blockIdx.y * p.split_stride;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = nw + j * 16 + fk * 4;
+    if (ONES && n == p.N) {  // the ones column: per-row sums of Aop
+      float* cs = p.colsum + (int64_t)blockIdx.y * p.split_stride;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = mw + i * 16 + fr;
+        if (m < p.M) cs[m] = acc[i][j][0];
+      }
+      continue;
+    }
+    if (n >= p.N) continue;
+    float4 bv = f4_zero();
+    if (EPI == EPI_BIAS && p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = mw + i * 16 + fr;
+      if (m >= p.M) continue;
+      float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      if (EPI == EPI_BIAS) {
+        v = f4_add(v, bv);
+        if (p.relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+      }
+      if (EPI == EPI_MASK) {
+        const float4 mk = *reinterpret_cast<const float4*>(p.mask + (int64_t)m * p.ldmask + n);
+        if (!(mk.x > 0.f)) v.x = 0.f;
+        if (!(mk.y > 0.f)) v.y = 0.f;
+        if (!(mk.z > 0.f)) v.z = 0.f;
+        if (!(mk.w > 0.f)) v.w = 0.f;
+      }
+      *reinterpret_cast<float4*>(C + (int64_t)m * p.ldc + n) = v;
+    }
+  }
+}
 
 // C[m,n] = sum_k Aop(m,k) * Bop(n,k);  N and ldc must be multiples of 4 (float4 epilogue).
 //
@@ -229,45 +275,178 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
     }
   }
 
-  // epilogue: lane holds C[m = .. + (lane & 15)][n = .. + (lane >> 4) * 4 + 0..3] of each 16x16 block
-  float* C = p.C + (int64_t)blockIdx.y * p.split_stride;
-#pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int n = n0 + wn0 + j * 16 + fk * 4;
-    if (ONES && n == p.N) {  // the ones column: per-row sums of Aop
-      float* cs = p.colsum + (int64_t)blockIdx.y * p.split_stride;
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wm0 + i * 16 + fr;
-        if (m < p.M) cs[m] = acc[i][j][0];
-      }
-      continue;
-    }
-    if (n >= p.N) continue;
-    float4 bv = f4_zero();
-    if (EPI == EPI_BIAS && p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n);
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int m = m0 + wm0 + i * 16 + fr;
-      if (m >= p.M) continue;
-      float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-      if (EPI == EPI_BIAS) {
-        v = f4_add(v, bv);
-        if (p.relu) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        }
-      }
-      if (EPI == EPI_MASK) {
-        const float4 mk = *reinterpret_cast<const float4*>(p.mask + (int64_t)m * p.ldmask + n);
-        if (!(mk.x > 0.f)) v.x = 0.f;
-        if (!(mk.y > 0.f)) v.y = 0.f;
-        if (!(mk.z > 0.f)) v.z = 0.f;
-        if (!(mk.w > 0.f)) v.w = 0.f;
-      }
-      *reinterpret_cast<float4*>(C + (int64_t)m * p.ldc + n) = v;
-    }
-  }
+  gemm_epilogue<EPI, ONES, MI, NI>(p, acc, m0 + wm0, n0 + wn0, lane);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// fp32 product on the bf16 matrix cores (forward product: both operands k-contiguous).  Every fp32 operand value is
+// split EXACTLY into three bf16 terms
+//     a = a1 + a2 + a3,   a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2)      (3 x 8 = 24 significand bits)
+// and a.b is accumulated as the six products whose weight is above 2^-24 of |a.b|:
+//     a1b1 + (a1b2 + a2b1) + (a1b3 + a2b2 + a3b1)            [dropped: a2b3 + a3b2 + a3b3 <= 2^-24 |a||b| (1 + 2^-7)]
+// Each bf16 x bf16 product is exact in fp32 and v_mfma_f32_16x16x32_bf16 accumulates in fp32, so the result carries
+// the error of an fp32 FMA chain (measured against float64 in tests/test_gpu_ops.py: not larger than the fp32-MFMA
+// kernel's) at 6/16 of its matrix-core time: 6 x 16 cycles per 16x16x32 block against 8 x 32 for v_mfma_f32_16x16x4_f32.
+// (Values within a factor 2^-8 of FLT_MAX would round a1 to inf; activations / weights are nowhere near.)
+//
+// Staging goes through registers (the split is VALU work on the way in, done once per element per workgroup):
+// global float4 -> v_cvt_pk_bf16_f32 / subtract, twice -> three bf16 planes in LDS, [row][32 k] = 64-byte rows whose
+// four 16-byte chunks are XOR-swizzled by the row, so the ds_write_b64 of the staging pass and the ds_read_b128 of an
+// MFMA fragment (lane: row l&15, chunk l>>4) are both conflict-free.  Tile t+1's global loads are in flight behind tile
+// t's MFMAs; one LDS stage (two barriers per 32 of k) and 8 waves per workgroup, two workgroups per CU.
+//
+// What was measured on the way (tools/gemm_split_check.py, M = 262144 and 6747, profiles/r02/README.md):
+//  - the phases of a k-step add up instead of overlapping (skip-one-phase runs: epilogue/prologue 149 us, MFMA 293,
+//    LDS writes + barriers 73, split arithmetic 90, global loads 150 of 755 at M = 262144, K = 300, N = 600): the two
+//    resident workgroups settle into lockstep, so the kernel sits at 1.45-1.5x the fp32-MFMA kernel rather than 2.7x;
+//  - 4-wave workgroups, a two-stage LDS ring with the staging interleaved behind the MFMAs, a two-tile register ring,
+//    256x160 / 128x320 tiles, and weights pre-split (and pre-transposed) into bf16 planes by a side kernel: all slower;
+//  - the backward products (row-contiguous operands, 4x4 register transposition in front of the split): slower than the
+//    fp32 MFMA, so they keep it.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {  // round to nearest even, a in the low half
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+// (a, b) -> packed (a1,b1), (a2,b2), (a3,b3)
+__device__ __forceinline__ void split3(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = pack_bf16(a, b);
+  const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+  m = pack_bf16(ra, rb);
+  const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+  l = pack_bf16(sa, sb);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3(GemmArgs p) {
+  constexpr int BK = 32;
+  constexpr int NW = WAVES_M * WAVES_N, T = 64 * NW;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int MI = WM / 16, NI = WN / 16;
+  static_assert(WM % 16 == 0 && WN % 16 == 0 && BM % 16 == 0, "tile shape");
+  constexpr int ROWB = 64;                      // bytes per LDS row of one plane (32 bf16)
+  constexpr int PLANE = (BM + BN) * ROWB;       // A rows, then B rows
+  constexpr int U = (BM + BN) * 8;              // staging units: one float4 = 4 k of one row (unit u: row u >> 3, k-quad u & 7)
+  constexpr int NU = (U + T - 1) / T;
+
+  extern __shared__ __align__(16) unsigned char smem3[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x, p.nxcd);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int nk = (p.K + BK - 1) / BK;
+
+  // this thread's units: source pointer at k-step 0 (rows past the M / N edge read a zero page) and LDS byte offset
+  const float* src[NU];
+  int kq4[NU], off[NU];
+  bool rowok[NU];
+#pragma unroll
+  for (int j = 0; j < NU; ++j) {
+    const int u = min(tid + j * T, U - 1);  // (a clamped duplicate rewrites the same LDS bytes with the same values)
+    const int row = u >> 3, kq = u & 7;
+    const bool isA = row < BM;
+    const int g = isA ? m0 + row : n0 + row - BM;
+    rowok[j] = g < (isA ? p.M : p.N);
+    kq4[j] = 4 * kq;
+    src[j] = (isA ? p.A + (int64_t)g * p.lda : p.B + (int64_t)g * p.ldb) + 4 * kq;
+    off[j] = row * ROWB + (((kq >> 1) ^ ((-(row >> 2)) & 3)) * 16) + (kq & 1) * 8;
+  }
+  float4 r[NU];
+  auto load_tile = [&](int it) {
+    const int k0 = it * BK;
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      const float* g = (rowok[j] && k0 + kq4[j] < p.K) ? src[j] + k0 : reinterpret_cast<const float*>(g_zero_page);
+      r[j] = *reinterpret_cast<const float4*>(g);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      uint32_t h0, m0_, l0, h1, m1, l1;
+      split3(r[j].x, r[j].y, h0, m0_, l0);
+      split3(r[j].z, r[j].w, h1, m1, l1);
+      *reinterpret_cast<uint2*>(smem3 + off[j]) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(smem3 + PLANE + off[j]) = make_uint2(m0_, m1);
+      *reinterpret_cast<uint2*>(smem3 + 2 * PLANE + off[j]) = make_uint2(l0, l1);
+    }
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+  const int fr = lane & 15, fk = lane >> 4;
+  const int frag_off = fr * ROWB + ((fk ^ ((-(fr >> 2)) & 3)) * 16);  // (16-row blocks start at multiples of 16 rows: same swizzle)
+  const unsigned char* At = smem3 + wm0 * ROWB + frag_off;
+  const unsigned char* Bt = smem3 + (BM + wn0) * ROWB + frag_off;
+
+  auto compute = [&]() {
+    bf16x8 a[MI][3];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(At + q * PLANE + i * 16 * ROWB);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      bf16x8 b[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) b[q] = *reinterpret_cast<const bf16x8*>(Bt + q * PLANE + j * 16 * ROWB);
+      // smallest terms first; operands swapped (D = B x A) so a lane ends up with 4 consecutive columns of one C row
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i][2], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1], a[i][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[2], a[i][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1], a[i][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i][0], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  load_tile(0);
+  store_tile();
+  if (1 < nk) load_tile(1);
+  __syncthreads();
+  for (int t = 0; t < nk; ++t) {
+    compute();
+    __syncthreads();  // every wave is done reading the stage
+    if (t + 1 < nk) store_tile();
+    __syncthreads();
+    if (t + 2 < nk) load_tile(t + 2);
+  }
+  gemm_epilogue<EPI, false, MI, NI>(p, acc, m0 + wm0, n0 + wn0, lane);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+int launch_gemm3_s(const GemmArgs& p, hipStream_t st) {
+  constexpr size_t lds = (size_t)3 * (BM + BN) * 64;
+  const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N, BN));
+  allow_big_lds((const void*)k_gemm3<BM, BN, WAVES_M, WAVES_N, EPI>, lds);
+  hipLaunchKernelGGL((k_gemm3<BM, BN, WAVES_M, WAVES_N, EPI>), dim3(tiles, 1), dim3(64 * WAVES_M * WAVES_N), lds, st, p);
+  return check_launch("gemm3");
+}
+
+// 128x160 tiles (wave tile 32x80) when they give at least 3/4 of the CUs a workgroup, else 64x160 (16x80)
+template <int EPI>
+int launch_gemm3(const GemmArgs& p, hipStream_t st) {
+  const int forced = env_knob("PGNN_GEMM3_CFG", -1);
+  const bool big = forced >= 0 ? forced == 0 : ceil_div(p.M, 128) * ceil_div(p.N, 160) * 4 >= 3 * num_cu();
+  if (big) return launch_gemm3_s<128, 160, 4, 2, EPI>(p, st);
+  return launch_gemm3_s<64, 160, 4, 2, EPI>(p, st);
+}
+
+// forward product: 1 = split-bf16 (v_mfma_f32_16x16x32_bf16 x 6), 0 = fp32 MFMA (v_mfma_f32_16x16x4_f32)
+inline int gemm_mode() { return env_knob("PGNN_GEMM_SPLIT", 1); }
 
 // dst[i] = sum_z partial[z][i]  (fixed order), float4
 // partial matrices are [nsplit][n4a + n4b] float4: the first n4a go to dst_a (dW), the rest to dst_b (db)
@@ -408,6 +587,7 @@ int pgnn_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bi
   p.nxcd = num_xcd();
   p.A = x; p.lda = ldx; p.B = w; p.ldb = k; p.C = y; p.ldc = ldy;
   p.M = (int)m; p.N = (int)n; p.K = (int)k; p.bias = bias; p.relu = relu; p.kchunk = (int)k; p.split_stride = 0;
+  if (gemm_mode() == 1) return launch_gemm3<EPI_BIAS>(p, (hipStream_t)stream);
   return launch_cfg<true, true, EPI_BIAS>(pick_cfg(m, n, 0), p, 1, (hipStream_t)stream);
 }
 

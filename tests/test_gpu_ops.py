@@ -375,6 +375,37 @@ def test_linear_layout_asymmetric():
     assert torch.equal(got, w.t()[:40].contiguous())
 
 
+@pytest.mark.parametrize("m,k,n", [(6747, 300, 600), (6747, 600, 300), (1000, 300, 300), (77, 36, 124), (130, 4, 4), (513, 1000, 164)])
+def test_linear_fwd_split_bf16_is_as_accurate_as_the_fp32_mfma(m, k, n, monkeypatch):
+    """forward GEMM on the bf16 matrix cores (three-term split, six products; csrc/linear.hip) against float64: its
+    error is held to the fp32-MFMA kernel's (exact fp32 FMA chains) measured on the same inputs -- not a looser bar --
+    over ragged M / N edges and K that is not a multiple of the 32-deep k-step; and it is bitwise reproducible"""
+    ops = _ops()
+    lib, sp = ops.load(), ops.stream_ptr()
+    torch.manual_seed(m + k)
+    x = (torch.randn(m, k) * torch.logspace(-3, 3, k)).to(DEV)  # columns spanning six decades: the residual terms matter
+    w = (torch.randn(n, k) * 0.05).to(DEV)
+    b = torch.randn(n, device=DEV)
+    want = torch.relu(x.double() @ w.double().t() + b.double())
+    scale = (x.double().abs() @ w.double().abs().t() + b.double().abs())  # |a|.|b| bound of each entry
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PGNN_GEMM_SPLIT", mode)
+        lib.pgnn_reload_env()
+        y = torch.empty(m, n, device=DEV)
+        ops.check(lib.pgnn_linear_fwd(x.data_ptr(), k, w.data_ptr(), b.data_ptr(), y.data_ptr(), n, m, k, n, 1, sp), "fwd")
+        y2 = torch.empty(m, n, device=DEV)
+        ops.check(lib.pgnn_linear_fwd(x.data_ptr(), k, w.data_ptr(), b.data_ptr(), y2.data_ptr(), n, m, k, n, 1, sp), "fwd")
+        assert torch.equal(y, y2)
+        err = (y.double() - want).abs() / scale
+        out[mode] = (err.max().item(), err.pow(2).mean().sqrt().item())
+    monkeypatch.delenv("PGNN_GEMM_SPLIT")
+    lib.pgnn_reload_env()
+    (max32, rms32), (max3, rms3) = out["0"], out["1"]
+    assert max32 < 2e-6 and max3 < 2e-6, out                  # both: a few fp32 ulps of the |a|.|b| bound
+    assert rms3 <= 1.25 * rms32 + 1e-9 and max3 <= 2.0 * max32 + 1e-9, out
+
+
 def test_mlp2_fwd_bwd():
     ops = _ops()
     torch.manual_seed(0)
