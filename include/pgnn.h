@@ -222,6 +222,15 @@ int pgnn_linear_bwd_data(const float* dy, int64_t lddy, const float* w, const fl
                          int64_t ldr, float* dx, int64_t lddx, int64_t m, int64_t k, int64_t n,
                          pgnn_stream stream);
 
+/* The same product from pre-transposed weights wt[K,N] = W^T: both operands are then contiguous along the contracted
+ * dimension and the product runs the forward kernel (the weights of a layer stack are transposed once per backward pass
+ * with pgnn_transpose_batch, off the critical path). */
+int pgnn_linear_bwd_data_t(const float* dy, int64_t lddy, const float* wt, const float* relu_out, int64_t ldr, float* dx,
+                           int64_t lddx, int64_t m, int64_t k, int64_t n, pgnn_stream stream);
+/* dst[j][c][r] = src[j][r][c] for count <= 16 dense row-major matrices (host arrays of device pointers / sizes), one launch */
+int pgnn_transpose_batch(const float* const* src, float* const* dst, const int64_t* rows, const int64_t* cols, int64_t count,
+                         pgnn_stream stream);
+
 /* dW[N,K] = dy[M,N]^T . x[M,K] ; db[N] = column sums of dy (db may be NULL).  Split over M with a
  * deterministic second-pass reduction. */
 size_t pgnn_linear_bwd_weight_workspace_bytes(int64_t m, int64_t k, int64_t n);

@@ -41,7 +41,9 @@ Side* side_for_current_device() {
   return &s;
 }
 inline bool use_side_stream() { return env_knob("PGNN_SIDE_STREAM", 1) != 0; }
+inline bool use_transposed_weights() { return env_knob("PGNN_BWD_TRANSPOSED", 1) != 0; }
 inline bool per_layer_buffers() { return env_knob("PGNN_STACK_PER_LAYER_BUFFERS", 0) != 0; }
+constexpr int kMaxTransposed = 8;  // layers whose weights pgnn_chem_gin_stack_bwd transposes up front (one 16-job launch)
 inline size_t op_ws_bytes(int64_t n, int64_t d) {
   size_t m = pgnn_bn_workspace_bytes(n, d);
   m = std::max(m, pgnn_bn_workspace_bytes(n, 2 * d));
@@ -194,7 +196,8 @@ size_t pgnn_chem_gin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t rows1
   // 2 x op scratch + S x (dz, dagg, dx: nd each; dhid: 2 nd) + group-by-key of the two atom columns.
   // S = 2 (ping-pong by layer parity), or one set per layer under the PGNN_STACK_PER_LAYER_BUFFERS=1 A/B knob.
   const size_t sets = (per_layer_buffers() && n <= kSideMaxRows) ? (size_t)std::max<int64_t>(num_layer, 2) : 2;
-  return 2 * op_ws_bytes(n, dim) + sets * 5 * nd + 2 * align_up((size_t)n * 4, 256) +
+  const size_t wt = (size_t)std::min<int64_t>(num_layer, kMaxTransposed) * 2 * align_up((size_t)2 * dim * dim * 4, 256);  // W1^T, W2^T
+  return 2 * op_ws_bytes(n, dim) + sets * 5 * nd + wt + 2 * align_up((size_t)n * 4, 256) +
          2 * align_up((stack_keys(rows1, rows2) + 1) * 4, 256) + 256 + stack_group_ws(n, rows1, rows2) +
          stack_segsum_ws(n, dim, rows1, rows2) + stack_pair_sums(dim, rows1, rows2) + 256;
 }
@@ -279,6 +282,12 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     dagg[p] = cv.take<float>(nd);
     dxb[p] = cv.take<float>(nd);
   }
+  const int ntr = std::min(num_layer, kMaxTransposed);  // layers whose backward-data runs on transposed weights
+  float *w1t[kMaxTransposed], *w2t[kMaxTransposed];
+  for (int l = 0; l < ntr; ++l) {
+    w1t[l] = cv.take<float>((size_t)2 * dim * dim);
+    w2t[l] = cv.take<float>((size_t)2 * dim * dim);
+  }
   int32_t* gptr[2];
   int32_t* gperm[2];
   for (int c = 0; c < 2; ++c) {
@@ -303,11 +312,35 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   // Every event record / wait costs ~7 us of host time, so forks are spent only where they buy overlap:
   // the atom-type / chirality grouping (a few tiny kernels) stays on the caller's stream, after the layers.
   PGNN_HIP(hipMemsetAsync(gstatus, 0, sizeof(int32_t), main));
+  // W1^T / W2^T of the top `ntr` layers in one launch: backward-data then has both operands contiguous along the
+  // contracted dimension and runs the forward (split-bf16) kernel.  On the side stream when there is one: the first
+  // BatchNorm backward covers it.
+  if (ntr > 0 && use_transposed_weights()) {
+    const float* tsrc[2 * kMaxTransposed];
+    float* tdst[2 * kMaxTransposed];
+    int64_t trows[2 * kMaxTransposed], tcols[2 * kMaxTransposed];
+    for (int q = 0; q < ntr; ++q) {
+      const pgnn_gin_layer& p = layers[num_layer - 1 - q];
+      tsrc[2 * q] = p.w1; tdst[2 * q] = w1t[q]; trows[2 * q] = 2 * dim; tcols[2 * q] = dim;          // W1 [2d, d]
+      tsrc[2 * q + 1] = p.w2; tdst[2 * q + 1] = w2t[q]; trows[2 * q + 1] = dim; tcols[2 * q + 1] = 2 * dim;  // W2 [d, 2d]
+    }
+    if (sd) {
+      PGNN_HIP(hipEventRecord(sd->fork[0], main));
+      PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[0], 0));
+    }
+    if ((rc = pgnn_transpose_batch(tsrc, tdst, trows, tcols, 2 * ntr, aux))) return rc;
+    if (sd) {
+      PGNN_HIP(hipEventRecord(sd->fork[2], aux));
+      PGNN_HIP(hipStreamWaitEvent(main, sd->fork[2], 0));
+    }
+  }
+  const bool tr = ntr > 0 && use_transposed_weights();
 
   const float* g = dy;
   int64_t ldg = lddy;
   for (int l = num_layer - 1; l >= 0; --l) {
     const pgnn_gin_layer& p = layers[l];
+    const int q = num_layer - 1 - l;  // index into the transposed weights
     const int b = per_layer ? l : (l & 1);  // own buffer set per layer, or ping-pong guarded by lag events
     if (sd && !per_layer && l + 2 <= num_layer - 1) PGNN_HIP(hipStreamWaitEvent(main, sd->lag[b], 0));
     const float* a = acts + (size_t)l * 3 * nd;  // agg, z, y
@@ -317,8 +350,13 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     const float* mean = stats + (size_t)l * 4 * dim;
     if ((rc = pgnn_bn_bwd(g, ldg, z, dim, p.gamma, p.beta, mean, mean + dim, training, l != num_layer - 1, dz[b], dim,
                           p.dgamma, p.dbeta, drop_p, drop_seed + (uint64_t)l, n, dim, op, opb, main))) return rc;
-    if ((rc = pgnn_linear_bwd_data(dz[b], dim, p.w2, hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main))) return rc;
-    if ((rc = pgnn_linear_bwd_data(dhid[b], 2 * dim, p.w1, nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main))) return rc;
+    if (tr && q < ntr) {
+      if ((rc = pgnn_linear_bwd_data_t(dz[b], dim, w2t[q], hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main))) return rc;
+      if ((rc = pgnn_linear_bwd_data_t(dhid[b], 2 * dim, w1t[q], nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main))) return rc;
+    } else {
+      if ((rc = pgnn_linear_bwd_data(dz[b], dim, p.w2, hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main))) return rc;
+      if ((rc = pgnn_linear_bwd_data(dhid[b], 2 * dim, p.w1, nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main))) return rc;
+    }
     if (sd) {
       PGNN_HIP(hipEventRecord(sd->fork[1], main));
       PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[1], 0));

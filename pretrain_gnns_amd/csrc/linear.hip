@@ -448,6 +448,35 @@ int launch_gemm3(const GemmArgs& p, hipStream_t st) {
 // forward product: 1 = split-bf16 (v_mfma_f32_16x16x32_bf16 x 6), 0 = fp32 MFMA (v_mfma_f32_16x16x4_f32)
 inline int gemm_mode() { return env_knob("PGNN_GEMM_SPLIT", 1); }
 
+// dst_j[c][r] = src_j[r][c] for up to 16 small matrices in one launch (the weights of a layer stack, transposed once
+// per backward pass so that backward-data becomes a k-contiguous product): 32x32 tiles through LDS, blockIdx.y = job
+struct TransposeJobs {
+  const float* src[16];
+  float* dst[16];
+  int rows[16], cols[16];
+};
+__global__ void __launch_bounds__(256) k_transpose_jobs(TransposeJobs jobs) {
+  __shared__ float tile[32][33];
+  const int j = blockIdx.y, rows = jobs.rows[j], cols = jobs.cols[j];
+  const int tc = (cols + 31) / 32, tiles = ((rows + 31) / 32) * tc;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + ty + 8 * i, c = c0 + tx;
+      tile[ty + 8 * i][tx] = (r < rows && c < cols) ? jobs.src[j][(int64_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + ty + 8 * i, r = r0 + tx;
+      if (c < cols && r < rows) jobs.dst[j][(int64_t)c * rows + r] = tile[tx][ty + 8 * i];
+    }
+    __syncthreads();
+  }
+}
+
 // dst[i] = sum_z partial[z][i]  (fixed order), float4
 // partial matrices are [nsplit][n4a + n4b] float4: the first n4a go to dst_a (dW), the rest to dst_b (db)
 __global__ void __launch_bounds__(256) k_splitk_reduce(const float* __restrict__ partial, int nsplit,
@@ -603,6 +632,36 @@ int pgnn_linear_bwd_data(const float* dy, int64_t lddy, const float* w, const fl
   const TileCfg c = pick_cfg(m, k, 1);
   if (relu_out) return launch_cfg<true, false, EPI_MASK>(c, p, 1, (hipStream_t)stream);
   return launch_cfg<true, false, EPI_PLAIN>(c, p, 1, (hipStream_t)stream);
+}
+
+int pgnn_transpose_batch(const float* const* src, float* const* dst, const int64_t* rows, const int64_t* cols, int64_t count,
+                         pgnn_stream stream) {
+  PGNN_REQUIRE(count >= 0 && count <= 16, "transpose_batch: at most 16 matrices per call");
+  if (count == 0) return PGNN_OK;
+  TransposeJobs jobs{};
+  int64_t most = 1;
+  for (int j = 0; j < count; ++j) {
+    PGNN_REQUIRE(src[j] && dst[j] && rows[j] > 0 && cols[j] > 0 && rows[j] < (1 << 30) && cols[j] < (1 << 30), "transpose_batch: bad job");
+    jobs.src[j] = src[j]; jobs.dst[j] = dst[j]; jobs.rows[j] = (int)rows[j]; jobs.cols[j] = (int)cols[j];
+    most = std::max(most, ceil_div(rows[j], 32) * ceil_div(cols[j], 32));
+  }
+  hipLaunchKernelGGL(k_transpose_jobs, dim3((int)std::min<int64_t>(most, 4096), (int)count), dim3(256), 0, (hipStream_t)stream, jobs);
+  return check_launch("transpose_batch");
+}
+
+int pgnn_linear_bwd_data_t(const float* dy, int64_t lddy, const float* wt, const float* relu_out, int64_t ldr, float* dx,
+                           int64_t lddx, int64_t m, int64_t k, int64_t n, pgnn_stream stream) {
+  PGNN_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0,
+               "linear_bwd_data_t: K, N and the leading dimensions must be multiples of 4");
+  GemmArgs p{};
+  p.nxcd = num_xcd();
+  // dx[m, kcol] = sum_nn dy[m, nn] wt[kcol, nn]: the forward product with the transposed weights as its (k-contiguous) B
+  p.A = dy; p.lda = lddy; p.B = wt; p.ldb = n; p.C = dx; p.ldc = lddx;
+  p.M = (int)m; p.N = (int)k; p.K = (int)n; p.mask = relu_out; p.ldmask = ldr; p.kchunk = (int)n; p.split_stride = 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (gemm_mode() == 1) return relu_out ? launch_gemm3<EPI_MASK>(p, st) : launch_gemm3<EPI_PLAIN>(p, st);
+  const TileCfg c = pick_cfg(m, k, 0);
+  return relu_out ? launch_cfg<true, true, EPI_MASK>(c, p, 1, st) : launch_cfg<true, true, EPI_PLAIN>(c, p, 1, st);
 }
 
 size_t pgnn_linear_bwd_weight_workspace_bytes(int64_t m, int64_t k, int64_t n) {

