@@ -239,6 +239,24 @@ int pgnn_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_
                            pgnn_stream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Prediction head of the masking pre-training step, fused (chem/pretrain_masking.py:52-57; bio/pretrain_masking.py:45-56):
+ *   pred = linear_pred(node_rep[idx]) ; loss = CrossEntropyLoss()(pred.double(), label) ; correct = #(argmax(pred) == label)
+ * h [n_rows, ldh] node representations, idx [m] int64 rows to predict (must not repeat: MaskAtom samples without
+ * replacement), w [classes, dim], b [classes] or NULL, label[r * label_stride] int64 in [0, classes), classes <= 128.
+ * Outputs: logits [m, classes] fp32 (kept for the backward), *loss float64 (mean over rows), *correct int64; status += bad
+ * indices / labels.  fp32 linear algebra, float64 soft-max and loss, as in the reference; fixed summation order.
+ * Backward (gloss = d objective / d loss, float64 on the device): dnode [n_rows, ldd] is overwritten (zero outside idx),
+ * dw [classes, dim], db [classes] or NULL.  Both calls use the same workspace.
+ * ------------------------------------------------------------------------------------------ */
+size_t pgnn_masked_head_workspace_bytes(int64_t m, int64_t classes, int64_t dim);
+int pgnn_masked_head_fwd(const float* h, int64_t ldh, int64_t n_rows, const int64_t* idx, int64_t m, const float* w, const float* b,
+                         const int64_t* label, int64_t label_stride, int64_t classes, int64_t dim, float* logits, double* loss,
+                         int64_t* correct, int32_t* status, void* ws, size_t ws_bytes, pgnn_stream stream);
+int pgnn_masked_head_bwd(const float* h, int64_t ldh, int64_t n_rows, const int64_t* idx, int64_t m, const float* w,
+                         const int64_t* label, int64_t label_stride, const float* logits, const double* gloss, int64_t classes,
+                         int64_t dim, float* dnode, int64_t ldd, float* dw, float* db, void* ws, size_t ws_bytes, pgnn_stream stream);
+
+/* ------------------------------------------------------------------------------------------
  * Layer-level composition (host-side only: each call enqueues the per-op kernels above in order).
  * One chem GIN layer + its outer BatchNorm (chem/model.py:37-55,269-275):
  *   agg = aggregate(x) ; hid = relu(agg W1^T + b1) ; z = hid W2^T + b2 ; y = BN(z) [ReLU]

@@ -1,0 +1,302 @@
+// The prediction head of the masking pre-training step, fused (chem/pretrain_masking.py:52-57, bio/pretrain_masking.py):
+//     pred = linear_pred(node_rep[masked_indices]);  loss = CrossEntropyLoss()(pred.double(), label);
+//     acc  = (argmax(pred, 1) == label).sum() / len(pred)
+// The reference spends ~25 tiny launches (gather, addmm, cast, soft-max, nll, arg-max, compare, their backward twins) on a
+// few hundred rows; at 256 graphs the host cannot enqueue them as fast as the GPU retires them and the GPU idles between
+// the two halves of the GNN.  Here: one launch forward, three (+ a memset) backward.
+//
+// Arithmetic follows the reference's dtypes: logits and the linear layer's gradients in fp32, soft-max / loss / their
+// gradient in float64, the gradient cast back to fp32 where `.double()` sits in the autograd graph.  All sums run in a
+// fixed order (bitwise reproducible).
+#include "common.h"
+
+namespace pgnn {
+namespace {
+
+constexpr int kHeadThreads = 128;   // one class per thread, up to 128 classes (119 atom types, 4 bond types, ...)
+constexpr int kHeadMaxDim = 2048;
+constexpr int kHeadRows = 8;        // selected rows per block: a weight value is loaded once and used for 8 rows
+constexpr int kHeadClassGroup = 8;  // classes per block of the weight-gradient kernel
+
+// rows [8 blk, 8 blk + 8): logits[r, :] = h[idx[r], :] . W^T + b, then each row's float64 log-soft-max terms.
+// The LAST block to finish (device counter, self-resetting) folds the rows in order: loss = mean_r nll_r, correct = sum_r.
+__global__ void __launch_bounds__(kHeadThreads) k_head_fwd(const float* __restrict__ h, int64_t ldh, const int64_t* __restrict__ idx,
+                                                           int m, const float* __restrict__ w, const float* __restrict__ b,
+                                                           const int64_t* __restrict__ label, int64_t label_stride, int classes, int dim,
+                                                           int64_t n_rows, float* __restrict__ logits, double* __restrict__ row_nll,
+                                                           int* __restrict__ row_hit, double* __restrict__ loss,
+                                                           int64_t* __restrict__ correct, unsigned* __restrict__ counter,
+                                                           int* __restrict__ status) {
+  extern __shared__ __align__(16) float hrows[];  // [kHeadRows][dim]
+  __shared__ double red[kHeadThreads];
+  __shared__ int redi[kHeadThreads];
+  __shared__ bool last;
+  const int r0 = blockIdx.x * kHeadRows, c = threadIdx.x;
+  const int nr = min(kHeadRows, m - r0);
+  for (int q = c; q < kHeadRows * dim; q += kHeadThreads) {
+    const int i = q / dim, k = q - i * dim;
+    float v = 0.f;
+    if (i < nr) {
+      const int64_t node = idx[r0 + i];
+      if (node >= 0 && node < n_rows) v = h[node * ldh + k];
+      else if (k == 0) atomicAdd(status, 1);
+    }
+    hrows[q] = v;
+  }
+  __syncthreads();
+  float z[kHeadRows];
+#pragma unroll
+  for (int i = 0; i < kHeadRows; ++i) z[i] = -INFINITY;
+  if (c < classes) {
+    const float4* wr = reinterpret_cast<const float4*>(w + (int64_t)c * dim);
+    float acc[kHeadRows];
+#pragma unroll
+    for (int i = 0; i < kHeadRows; ++i) acc[i] = 0.f;
+    for (int k4 = 0; k4 < dim / 4; ++k4) {
+      const float4 wv = wr[k4];
+#pragma unroll
+      for (int i = 0; i < kHeadRows; ++i) {
+        const float4 hv = *reinterpret_cast<const float4*>(hrows + i * dim + 4 * k4);
+        acc[i] = fmaf(hv.x, wv.x, acc[i]);
+        acc[i] = fmaf(hv.y, wv.y, acc[i]);
+        acc[i] = fmaf(hv.z, wv.z, acc[i]);
+        acc[i] = fmaf(hv.w, wv.w, acc[i]);
+      }
+    }
+    const float bias = b ? b[c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < kHeadRows; ++i)
+      if (i < nr) {
+        z[i] = acc[i] + bias;
+        logits[(int64_t)(r0 + i) * classes + c] = z[i];
+      }
+  }
+  for (int i = 0; i < nr; ++i) {
+    // row maximum and its FIRST index (torch.max's tie rule), then the sum of exp in float64
+    red[c] = (double)z[i];
+    redi[c] = c;
+    __syncthreads();
+    for (int s = kHeadThreads / 2; s > 0; s >>= 1) {
+      if (c < s) {
+        const double a = red[c], o = red[c + s];
+        if (o > a || (o == a && redi[c + s] < redi[c])) {
+          red[c] = o;
+          redi[c] = redi[c + s];
+        }
+      }
+      __syncthreads();
+    }
+    const double zmax = red[0];
+    const int arg = redi[0];
+    __syncthreads();
+    red[c] = c < classes ? exp((double)z[i] - zmax) : 0.0;
+    __syncthreads();
+    for (int s = kHeadThreads / 2; s > 0; s >>= 1) {
+      if (c < s) red[c] += red[c + s];
+      __syncthreads();
+    }
+    if (c == 0) {
+      const int64_t y = label[(int64_t)(r0 + i) * label_stride];
+      const bool yok = y >= 0 && y < classes;
+      if (!yok) atomicAdd(status, 1);
+      const double zy = yok ? (double)logits[(int64_t)(r0 + i) * classes + y] : 0.0;  // written by thread y of this block, before the syncs
+      row_nll[r0 + i] = log(red[0]) + zmax - zy;
+      row_hit[r0 + i] = (yok && arg == (int)y) ? 1 : 0;
+    }
+    __syncthreads();
+  }
+  if (c == 0) {
+    __threadfence();
+    last = atomicAdd(counter, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  double s = 0.0;
+  int hits = 0;
+  for (int q = c; q < m; q += kHeadThreads) {  // per-thread strided partials, then a fixed tree: the same order every run
+    s += row_nll[q];
+    hits += row_hit[q];
+  }
+  red[c] = s;
+  redi[c] = hits;
+  __syncthreads();
+  for (int t = kHeadThreads / 2; t > 0; t >>= 1) {
+    if (c < t) {
+      red[c] += red[c + t];
+      redi[c] += redi[c + t];
+    }
+    __syncthreads();
+  }
+  if (c == 0) {
+    *loss = red[0] / (double)m;
+    *correct = redi[0];
+    *counter = 0;
+  }
+}
+
+// rows [8 blk, 8 blk + 8): dl[r, c] = float((softmax64(logits[r])[c] - [c == y]) * gloss / m), then the rows of
+// d node_rep: dnode[idx[r], :] = sum_c dl[r, c] W[c, :]   (dnode is zero elsewhere; idx must not repeat)
+__global__ void __launch_bounds__(kHeadThreads) k_head_bwd_rows(const float* __restrict__ logits, const int64_t* __restrict__ idx, int m,
+                                                                const float* __restrict__ w, const int64_t* __restrict__ label,
+                                                                int64_t label_stride, const double* __restrict__ gloss, int classes, int dim,
+                                                                int64_t n_rows, float* __restrict__ dl, float* __restrict__ dnode, int64_t ldd) {
+  __shared__ double red[kHeadThreads];
+  __shared__ float dls[kHeadRows][kHeadThreads];
+  const int r0 = blockIdx.x * kHeadRows, c = threadIdx.x;
+  const int nr = min(kHeadRows, m - r0);
+  const double g = *gloss / (double)m;
+  for (int i = 0; i < kHeadRows; ++i) {
+    float d = 0.f;
+    if (i < nr) {
+      const double z = c < classes ? (double)logits[(int64_t)(r0 + i) * classes + c] : -INFINITY;
+      red[c] = z;
+      __syncthreads();
+      for (int s = kHeadThreads / 2; s > 0; s >>= 1) {
+        if (c < s) red[c] = fmax(red[c], red[c + s]);
+        __syncthreads();
+      }
+      const double zmax = red[0];
+      __syncthreads();
+      const double e = c < classes ? exp(z - zmax) : 0.0;
+      red[c] = e;
+      __syncthreads();
+      for (int s = kHeadThreads / 2; s > 0; s >>= 1) {
+        if (c < s) red[c] += red[c + s];
+        __syncthreads();
+      }
+      if (c < classes) {
+        const int64_t y = label[(int64_t)(r0 + i) * label_stride];
+        d = (float)((e / red[0] - (c == (int)y ? 1.0 : 0.0)) * g);
+        dl[(int64_t)(r0 + i) * classes + c] = d;
+      }
+      __syncthreads();
+    }
+    dls[i][c] = d;
+  }
+  __syncthreads();
+  int64_t node[kHeadRows];
+#pragma unroll
+  for (int i = 0; i < kHeadRows; ++i) {
+    node[i] = i < nr ? idx[r0 + i] : -1;
+    if (node[i] >= n_rows) node[i] = -1;
+  }
+  for (int k = c; k < dim; k += kHeadThreads) {
+    float acc[kHeadRows];
+#pragma unroll
+    for (int i = 0; i < kHeadRows; ++i) acc[i] = 0.f;
+    for (int q = 0; q < classes; ++q) {
+      const float wv = w[(int64_t)q * dim + k];
+#pragma unroll
+      for (int i = 0; i < kHeadRows; ++i) acc[i] = fmaf(dls[i][q], wv, acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < kHeadRows; ++i)
+      if (node[i] >= 0) dnode[node[i] * ldd + k] = acc[i];
+  }
+}
+
+// block (class group g, row chunk q): partial[q][c][:] = sum_{r in chunk} dl[r, c] h[idx[r], :] for the 8 classes of the group
+// (+ the chunk's share of db); rows in order inside a chunk, chunks folded in order by k_head_fold
+__global__ void __launch_bounds__(256) k_head_bwd_weight(const float* __restrict__ dl, const float* __restrict__ h, int64_t ldh,
+                                                         const int64_t* __restrict__ idx, int m, int chunk, int classes, int dim,
+                                                         int64_t n_rows, float* __restrict__ partial) {
+  const int c0 = blockIdx.x * kHeadClassGroup, q = blockIdx.y;
+  const int rbeg = q * chunk, rend = min(m, rbeg + chunk);
+  const int ncl = min(kHeadClassGroup, classes - c0);
+  float* out = partial + (int64_t)q * classes * (dim + 1);
+  for (int k = threadIdx.x; k < dim + 1; k += blockDim.x) {  // column `dim` carries the bias gradient (h := 1)
+    float acc[kHeadClassGroup];
+#pragma unroll
+    for (int j = 0; j < kHeadClassGroup; ++j) acc[j] = 0.f;
+    for (int r = rbeg; r < rend; ++r) {
+      const int64_t node = idx[r];
+      const float hv = k == dim ? 1.f : ((node >= 0 && node < n_rows) ? h[node * ldh + k] : 0.f);
+      const float* d = dl + (int64_t)r * classes + c0;
+#pragma unroll
+      for (int j = 0; j < kHeadClassGroup; ++j)
+        if (j < ncl) acc[j] = fmaf(d[j], hv, acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kHeadClassGroup; ++j)
+      if (j < ncl) out[(int64_t)(c0 + j) * (dim + 1) + k] = acc[j];
+  }
+}
+__global__ void __launch_bounds__(256) k_head_fold(const float* __restrict__ partial, int nchunk, int classes, int dim, float* __restrict__ dw,
+                                                   float* __restrict__ db) {
+  const int64_t total = (int64_t)classes * (dim + 1);
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int q = 0; q < nchunk; ++q) acc += partial[(int64_t)q * total + t];
+    const int c = (int)(t / (dim + 1)), k = (int)(t - (int64_t)c * (dim + 1));
+    if (k < dim) dw[(int64_t)c * dim + k] = acc;
+    else if (db) db[c] = acc;
+  }
+}
+
+inline int head_chunk(int64_t m) { return (int)std::max<int64_t>(32, ceil_div(m, 128)); }  // at most 128 row chunks
+
+}  // namespace
+}  // namespace pgnn
+
+using namespace pgnn;
+
+extern "C" {
+
+size_t pgnn_masked_head_workspace_bytes(int64_t m, int64_t classes, int64_t dim) {
+  // row_nll [m] f64, row_hit [m] i32, counter, then (backward) dl [m, classes] f32 and the weight-gradient partials
+  const int64_t nchunk = ceil_div(m, head_chunk(m));
+  return align_up((size_t)m * 8, 256) + align_up((size_t)m * 4, 256) + 256 + align_up((size_t)m * classes * 4, 256) +
+         align_up((size_t)nchunk * classes * (dim + 1) * 4, 256) + 256;
+}
+
+int pgnn_masked_head_fwd(const float* h, int64_t ldh, int64_t n_rows, const int64_t* idx, int64_t m, const float* w, const float* b,
+                         const int64_t* label, int64_t label_stride, int64_t classes, int64_t dim, float* logits, double* loss,
+                         int64_t* correct, int32_t* status, void* ws, size_t ws_bytes, pgnn_stream stream) {
+  PGNN_REQUIRE(m > 0 && classes > 0 && classes <= kHeadThreads && dim > 0 && dim % 4 == 0 && dim <= kHeadMaxDim && ldh % 4 == 0,
+               "masked_head: 1..%d classes, dim and ldh multiples of 4, dim up to %d", kHeadThreads, kHeadMaxDim);
+  if (ws_bytes < pgnn_masked_head_workspace_bytes(m, classes, dim)) {
+    set_error("masked_head workspace too small");
+    return PGNN_ERR_WORKSPACE;
+  }
+  Carver cv(ws);
+  double* row_nll = cv.take<double>((size_t)m);
+  int* row_hit = cv.take<int>((size_t)m);
+  unsigned* counter = cv.take<unsigned>(64);
+  hipStream_t st = (hipStream_t)stream;
+  PGNN_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned), st));  // (the kernel leaves it at zero too; a fresh workspace may not be)
+  const size_t lds = (size_t)kHeadRows * dim * sizeof(float);
+  allow_big_lds((const void*)k_head_fwd, lds);
+  hipLaunchKernelGGL(k_head_fwd, dim3((int)ceil_div(m, kHeadRows)), dim3(kHeadThreads), lds, st, h, ldh, idx, (int)m, w, b, label,
+                     label_stride, (int)classes, (int)dim, n_rows, logits, row_nll, row_hit, loss, correct, counter, status);
+  return check_launch("masked_head_fwd");
+}
+
+int pgnn_masked_head_bwd(const float* h, int64_t ldh, int64_t n_rows, const int64_t* idx, int64_t m, const float* w,
+                         const int64_t* label, int64_t label_stride, const float* logits, const double* gloss, int64_t classes,
+                         int64_t dim, float* dnode, int64_t ldd, float* dw, float* db, void* ws, size_t ws_bytes, pgnn_stream stream) {
+  PGNN_REQUIRE(m > 0 && classes > 0 && classes <= kHeadThreads && dim > 0 && dim % 4 == 0 && dim <= kHeadMaxDim && ldd >= dim,
+               "masked_head: 1..%d classes, dim a multiple of 4 up to %d", kHeadThreads, kHeadMaxDim);
+  if (ws_bytes < pgnn_masked_head_workspace_bytes(m, classes, dim)) {
+    set_error("masked_head workspace too small");
+    return PGNN_ERR_WORKSPACE;
+  }
+  Carver cv(ws);
+  cv.take<double>((size_t)m);
+  cv.take<int>((size_t)m);
+  cv.take<unsigned>(64);
+  float* dl = cv.take<float>((size_t)m * classes);
+  const int chunk = head_chunk(m), nchunk = (int)ceil_div(m, chunk);
+  float* partial = cv.take<float>((size_t)nchunk * classes * (dim + 1));
+  hipStream_t st = (hipStream_t)stream;
+  PGNN_HIP(hipMemsetAsync(dnode, 0, (size_t)n_rows * ldd * sizeof(float), st));
+  hipLaunchKernelGGL(k_head_bwd_rows, dim3((int)ceil_div(m, kHeadRows)), dim3(kHeadThreads), 0, st, logits, idx, (int)m, w, label,
+                     label_stride, gloss, (int)classes, (int)dim, n_rows, dl, dnode, ldd);
+  hipLaunchKernelGGL(k_head_bwd_weight, dim3((int)ceil_div(classes, kHeadClassGroup), nchunk), dim3(256), 0, st, dl, h, ldh, idx, (int)m,
+                     chunk, (int)classes, (int)dim, n_rows, partial);
+  hipLaunchKernelGGL(k_head_fold, dim3((int)std::min<int64_t>(ceil_div(classes * (dim + 1), 256), 1024)), dim3(256), 0, st, partial, nchunk,
+                     (int)classes, (int)dim, dw, db);
+  return check_launch("masked_head_bwd");
+}
+
+}  // extern "C"

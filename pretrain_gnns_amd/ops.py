@@ -828,6 +828,64 @@ def linear(x, layer):
     return Linear.apply(x, layer.weight, layer.bias)
 
 
+# ------------------------------------------------------------------------------------ masking prediction head
+class MaskedHead(Function):
+    """linear_pred(node_rep[idx]) -> CrossEntropyLoss()(pred.double(), label) and the number of correct arg-maxes, in one
+    launch per direction (chem/pretrain_masking.py:52-57).  Returns (loss float64 [], correct int64 [], logits fp32 [m, C]);
+    only ``loss`` carries a gradient.  ``idx`` must not repeat (MaskAtom samples without replacement)."""
+
+    @staticmethod
+    def forward(ctx, node_rep, idx, weight, bias, label):
+        require_cuda(node_rep, idx, weight, label)
+        h = _rows2d(node_rep)
+        n, dim = h.shape
+        m, classes = idx.numel(), weight.size(0)
+        if idx.dtype != torch.int64 or label.dtype != torch.int64 or label.size(0) != m or weight.size(1) != dim or m == 0:
+            raise _lib.PgnnError("masked head: idx / label must be int64 [m], weight [classes, dim]")
+        idx = idx.contiguous()
+        w = _f32c(weight)
+        b = _f32c(bias) if bias is not None else None
+        dev = h.device
+        logits = torch.empty(m, classes, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float64, device=dev)
+        correct = torch.empty((), dtype=torch.int64, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws = torch.empty(_ws_bytes("pgnn_masked_head_workspace_bytes", m, classes, dim), dtype=torch.uint8, device=dev)
+        check(load().pgnn_masked_head_fwd(h.data_ptr(), h.stride(0), n, idx.data_ptr(), m, w.data_ptr(),
+                                          b.data_ptr() if b is not None else None, label.data_ptr(), label.stride(0), classes, dim,
+                                          logits.data_ptr(), loss.data_ptr(), correct.data_ptr(), status.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), stream_ptr()), "pgnn_masked_head_fwd")
+        if _CHECK_INDICES and int(status.item()):
+            raise IndexError("masked head: row index or label out of range")
+        ctx.save_for_backward(h, idx, w, label, logits)
+        ctx.ws, ctx.has_bias = ws, bias is not None
+        ctx.mark_non_differentiable(correct, logits)
+        return loss, correct, logits
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gloss, _gc, _gl):
+        h, idx, w, label, logits = ctx.saved_tensors
+        n, dim = h.shape
+        m, classes = logits.shape
+        dev = h.device
+        gloss = gloss.to(torch.float64).contiguous()
+        dnode = torch.empty(n, dim, dtype=torch.float32, device=dev)
+        dw = torch.empty(classes, dim, dtype=torch.float32, device=dev)
+        db = torch.empty(classes, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        check(load().pgnn_masked_head_bwd(h.data_ptr(), h.stride(0), n, idx.data_ptr(), m, w.data_ptr(), label.data_ptr(),
+                                          label.stride(0), logits.data_ptr(), gloss.data_ptr(), classes, dim, dnode.data_ptr(), dim,
+                                          dw.data_ptr(), db.data_ptr() if db is not None else None, ctx.ws.data_ptr(), ctx.ws.numel(),
+                                          stream_ptr()), "pgnn_masked_head_bwd")
+        return dnode, None, dw, db, None
+
+
+def masked_head(node_rep, idx, linear, label):
+    """(loss, correct) of ``linear(node_rep[idx])`` against ``label`` -- see MaskedHead"""
+    loss, correct, _ = MaskedHead.apply(node_rep, idx, linear.weight, linear.bias, label)
+    return loss, correct
+
+
 # ------------------------------------------------------------------------------------ fused chem GIN layer
 class ChemGINLayer(Function):
     """One chem GIN layer + its outer BatchNorm (+ReLU) as ONE library call per direction

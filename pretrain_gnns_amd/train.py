@@ -15,6 +15,12 @@ def compute_accuracy(pred, target):
     return float(torch.sum(torch.max(pred.detach(), dim=1)[1] == target).cpu().item()) / len(pred)
 
 
+def _fusable_head(linear, node_rep):
+    """plain nn.Linear on the GPU with up to 128 classes: the fused masking head of csrc/head.hip applies"""
+    return (type(linear) is torch.nn.Linear and node_rep.is_cuda and node_rep.dtype == torch.float32 and linear.out_features <= 128
+            and linear.in_features % 4 == 0 and linear.in_features <= 2048)
+
+
 def _correct(pred, target):
     """numerator of compute_accuracy, left on the device"""
     return torch.sum(torch.max(pred.detach(), dim=1)[1] == target)
@@ -29,11 +35,17 @@ def chem_masking_step(model_list, optimizer_list, batch, mask_edge=False, readba
     ``optimizer.step()``, so the GPU is not left idle mid-step waiting for Python to resume."""
     model, linear_pred_atoms, linear_pred_bonds = model_list
     node_rep = model(batch.x, batch.edge_index, batch.edge_attr)
-    pred_node = linear_pred_atoms(node_rep[batch.masked_atom_indices])
-    loss = F.cross_entropy(pred_node.double(), batch.mask_node_label[:, 0])
     inline = readback == "inline"
-    acc_node = compute_accuracy(pred_node, batch.mask_node_label[:, 0]) if inline else _correct(pred_node, batch.mask_node_label[:, 0])
-    n_node, n_edge = len(pred_node), 1
+    if not inline and _fusable_head(linear_pred_atoms, node_rep):
+        # the three statements below as one launch per direction (ops.MaskedHead: same dtypes, float64 soft-max and loss)
+        loss, acc_node = ops.masked_head(node_rep, batch.masked_atom_indices, linear_pred_atoms, batch.mask_node_label[:, 0])
+        n_node = batch.masked_atom_indices.numel()
+    else:
+        pred_node = linear_pred_atoms(node_rep[batch.masked_atom_indices])
+        loss = F.cross_entropy(pred_node.double(), batch.mask_node_label[:, 0])
+        acc_node = compute_accuracy(pred_node, batch.mask_node_label[:, 0]) if inline else _correct(pred_node, batch.mask_node_label[:, 0])
+        n_node = len(pred_node)
+    n_edge = 1
     acc_edge = 0.0 if inline else torch.zeros((), dtype=torch.long, device=loss.device)
     if mask_edge:
         masked_edge_index = batch.edge_index[:, batch.connected_edge_indices]
@@ -96,11 +108,14 @@ class GraphedChemMaskingStep:
         model, linear_pred_atoms, linear_pred_bonds = self.model_list
         b = self.batch
         node_rep = model(b.x, b.edge_index, b.edge_attr)
-        pred_node = linear_pred_atoms(node_rep[b.masked_atom_indices])
-        loss = F.cross_entropy(pred_node.double(), b.mask_node_label[:, 0])
-        acc_node = _correct(pred_node, b.mask_node_label[:, 0])
+        if _fusable_head(linear_pred_atoms, node_rep):
+            loss, acc_node = ops.masked_head(node_rep, b.masked_atom_indices, linear_pred_atoms, b.mask_node_label[:, 0])
+        else:
+            pred_node = linear_pred_atoms(node_rep[b.masked_atom_indices])
+            loss = F.cross_entropy(pred_node.double(), b.mask_node_label[:, 0])
+            acc_node = _correct(pred_node, b.mask_node_label[:, 0])
         acc_edge = torch.zeros((), dtype=torch.long, device=loss.device)
-        self.n_node, self.n_edge = len(pred_node), 1
+        self.n_node, self.n_edge = b.masked_atom_indices.numel(), 1
         if self.mask_edge:
             mei = b.edge_index[:, b.connected_edge_indices]
             pred_edge = linear_pred_bonds(node_rep[mei[0]] + node_rep[mei[1]])

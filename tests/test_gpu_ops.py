@@ -406,6 +406,45 @@ def test_linear_fwd_split_bf16_is_as_accurate_as_the_fp32_mfma(m, k, n, monkeypa
     assert rms3 <= 1.25 * rms32 + 1e-9 and max3 <= 2.0 * max32 + 1e-9, out
 
 
+@pytest.mark.parametrize("n,m,classes,dim", [(6747, 1007, 119, 300), (300, 41, 4, 300), (50, 1, 128, 64), (900, 257, 119, 2048)])
+def test_masked_head_fwd_bwd(n, m, classes, dim):
+    """pgnn_masked_head_fwd/_bwd (linear_pred + CrossEntropyLoss(pred.double()) + compute_accuracy of
+    chem/pretrain_masking.py:52-57 in one launch per direction) vs the torch composition: loss (float64), correct count
+    (first-index tie rule: two classes share a weight row), gradients of node_rep (zero outside the masked rows), weight, bias"""
+    ops = _ops()
+    torch.manual_seed(n + m)
+    h = torch.randn(n, dim, requires_grad=True)
+    lin = torch.nn.Linear(dim, classes)
+    if classes >= 4:
+        with torch.no_grad():  # exact ties between classes 1 and 3
+            lin.weight[3] = lin.weight[1]
+            lin.bias[3] = lin.bias[1]
+    idx = torch.randperm(n)[:m]
+    label = torch.randint(0, classes, (m, 2))
+    pred = lin(h[idx])
+    want = torch.nn.functional.cross_entropy(pred.double(), label[:, 0])
+    want_correct = int((torch.max(pred.detach(), dim=1)[1] == label[:, 0]).sum())
+    (want * 3.0).backward()
+    hd = h.detach().to(DEV).requires_grad_(True)
+    lin_d = torch.nn.Linear(dim, classes)
+    lin_d.load_state_dict(lin.state_dict())
+    lin_d = lin_d.to(DEV)
+    label_d = label.to(DEV)
+    loss, correct = ops.masked_head(hd, idx.to(DEV), lin_d, label_d[:, 0])  # a strided label column, as the train step passes it
+    assert loss.dtype == torch.float64 and abs(loss.item() - want.item()) <= 1e-6 * abs(want.item())
+    assert int(correct) == want_correct
+    (loss * 3.0).backward()
+    scale = float(h.grad.abs().max())
+    torch.testing.assert_close(hd.grad.cpu(), h.grad, rtol=1e-4, atol=1e-5 * scale)
+    rest = torch.ones(n, dtype=torch.bool)
+    rest[idx] = False
+    assert float(hd.grad.cpu()[rest].abs().max() if rest.any() else 0.0) == 0.0
+    torch.testing.assert_close(lin_d.weight.grad.cpu(), lin.weight.grad, rtol=1e-4, atol=1e-5 * float(lin.weight.grad.abs().max()))
+    torch.testing.assert_close(lin_d.bias.grad.cpu(), lin.bias.grad, rtol=1e-4, atol=1e-5 * float(lin.bias.grad.abs().max()))
+    loss2, correct2 = ops.masked_head(hd.detach(), idx.to(DEV), lin_d, label_d[:, 0])
+    assert loss2.item() == loss.item() and int(correct2) == int(correct)
+
+
 def test_mlp2_fwd_bwd():
     ops = _ops()
     torch.manual_seed(0)
