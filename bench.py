@@ -56,7 +56,8 @@ def parse():
                          "holds exactly the launches `roofline.achieved` is computed from)")
     ap.add_argument("--sweep-graphs", default="2048,16384",
                     help="extra per-GPU batch sizes reported under `large_batch` (same step, same code); '' disables")
-    ap.add_argument("--foreach-adam", action="store_true", help="torch's default multi-kernel Adam instead of fused")
+    ap.add_argument("--adam", default="pgnn", choices=["pgnn", "fused", "foreach"],
+                    help="pgnn = one launch for the three optimizers (default); fused / foreach = torch.optim.Adam variants")
     ap.add_argument("--readback", default="end", choices=["end", "inline"],
                     help="where loss/accuracy are read back to the host (inline = the reference's two syncs per step)")
     return ap.parse_args()
@@ -73,6 +74,23 @@ def make_models(dev, seed=0):
     atoms = torch.nn.Linear(300, 119).to(dev)
     bonds = torch.nn.Linear(300, 4).to(dev)
     return [model, atoms, bonds]
+
+
+def make_optimizers(mods, kind="pgnn", capturable=False):
+    """the three Adam optimizers of chem/pretrain_masking.py:134-136 (lr 1e-3, decay 0).  kind: "pgnn" = one launch for the
+    three (pretrain_gnns_amd.optim.Adam.shared: torch's update formula, device-side step count), "fused" / "foreach" =
+    torch.optim.Adam's single-kernel-per-optimizer / default multi-kernel implementations"""
+    if kind == "pgnn":
+        from pretrain_gnns_amd import optim
+        return optim.Adam.shared([m.parameters() for m in mods], lr=1e-3, weight_decay=0)
+    kw = {"fused": True} if kind == "fused" else {}
+    if capturable:
+        kw["capturable"] = True
+    return [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0, **kw) for m in mods]
+
+
+ADAM_NOTE = {"pgnn": "pretrain_gnns_amd.optim.Adam.shared: the three optimizers' update in one launch",
+             "fused": "torch.optim.Adam(fused=True)", "foreach": "torch.optim.Adam (foreach)"}
 
 
 def event_time_ms(fn, iters, warmup=3):
@@ -214,7 +232,7 @@ def resident_loader_leg(dev, args, steps_n):
     ds = resident.ResidentDataset.from_graphs(graphs, dev)
     loader = resident.ResidentLoader(ds, args.graphs_per_gpu, shuffle=True, seed=1, mask_rate=0.15, drop_last=True)
     mods = make_models(dev)
-    opts = [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0, fused=True) for m in mods]
+    opts = make_optimizers(mods)
     edges, done, t0 = 0, 0, None
     while done < steps_n + 5:
         for batch in loader:
@@ -335,7 +353,7 @@ def contextpred_leg(dev, args, steps_n, with_cpu):
     loader = resident.ResidentLoader(ds, args.graphs_per_gpu, shuffle=True, seed=2, drop_last=True, substruct_context=(5, 4, 7))
     torch.manual_seed(0)
     ms_, mc_ = hmodel.GNN(5, 300, gnn_type="gin").to(dev), hmodel.GNN(3, 300, gnn_type="gin").to(dev)
-    os_, oc_ = [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0, fused=True) for m in (ms_, mc_)]
+    os_, oc_ = make_optimizers((ms_, mc_))
     ms_.train(), mc_.train()
     mol_edges = ds._edges  # directed edges per source molecule (host copy of the slice differences)
     src_edges = gnn_edges = done = 0
@@ -395,7 +413,7 @@ def bio_leg(dev, args, steps_n, with_cpu):
     loader = resident.ResidentLoader(ds, args.graphs_per_gpu, shuffle=True, seed=3, mask_rate=0.15, drop_last=True)
     torch.manual_seed(0)
     mods = [hbio.GNN(5, 300, gnn_type="gin").to(dev), torch.nn.Linear(300, 7).to(dev)]
-    opts = [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0, fused=True) for m in mods]
+    opts = make_optimizers(mods)
     for m in mods:
         m.train()
     edges = done = 0
@@ -471,7 +489,7 @@ def hipgraph_replay(dev, args, batch):
 
     try:
         mods = make_models(dev)
-        opts = [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0, fused=True, capturable=True) for m in mods]
+        opts = make_optimizers(mods)
         g = steps.GraphedChemMaskingStep(mods, opts, batch)
         for _ in range(5):
             g()
@@ -498,8 +516,7 @@ def large_batch_sweep(dev, sizes, args):
     for g in sizes:
         batch = (synthetic.tile_batch(base, g // 2048) if g >= 2048 else synthetic.chem_masking_batch(g, seed=7)).to(dev)
         mods = make_models(dev)
-        adam_kw = {} if args.foreach_adam else {"fused": True}
-        opts = [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0, **adam_kw) for m in mods]
+        opts = make_optimizers(mods, args.adam)
         for _ in range(2):
             steps.chem_masking_step(mods, opts, batch, readback=args.readback)
         torch.cuda.synchronize()
@@ -575,10 +592,7 @@ def main():
         return
     mods = make_models(dev)
     parallel.broadcast_parameters(mods)
-    # same optimizer as chem/pretrain_masking.py:134-136 (Adam, lr 1e-3, decay 0); `fused=True` selects
-    # torch's single-kernel implementation of that same update instead of the multi-kernel foreach one
-    adam_kw = {} if args.foreach_adam else {"fused": True}
-    opts = [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0, **adam_kw) for m in mods]
+    opts = make_optimizers(mods, args.adam)
     if world > 1 or dist.is_initialized():
         opts = parallel.AllReduceOptimizers(opts)
     batch = synthetic.chem_masking_batch(args.graphs_per_gpu, seed=rank).to(dev)
@@ -627,7 +641,7 @@ def main():
                        "graphs_per_gpu": args.graphs_per_gpu, "global_batch": args.graphs_per_gpu * world,
                        "nodes_per_gpu": int(batch.x.size(0)), "edges_per_gpu": int(edges_local),
                        "parallelism": "dp%d" % world, "last_loss": round(float(loss), 5),
-                       "adam": "foreach" if args.foreach_adam else "fused", "metrics_readback": args.readback,
+                       "adam": ADAM_NOTE[args.adam], "metrics_readback": args.readback,
                        "direct_grads": True},
             "comm": comm,
         }

@@ -239,6 +239,18 @@ int pgnn_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_
                            pgnn_stream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * torch.optim.Adam's update (chem/pretrain_masking.py:134-136 builds three of them with the same hyper-parameters) over
+ * n <= pgnn_adam_max_tensors() fp32 tensors in one launch: params[j] / grads[j] device pointers (host arrays), counts[j]
+ * elements, state_offsets[j] = where tensor j's moments live in the flat exp_avg / exp_avg_sq buffers.  *step (device
+ * int64, number of updates already applied) is advanced by the call, so the call can be captured in a HIP graph.
+ * L2 weight decay is added to the gradient (Adam, not AdamW); amsgrad is not offered.
+ * ------------------------------------------------------------------------------------------ */
+int pgnn_adam_max_tensors(void);
+int pgnn_adam_step(float* const* params, const float* const* grads, const int64_t* counts, const int64_t* state_offsets, int64_t n,
+                   float* exp_avg, float* exp_avg_sq, int64_t* step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   pgnn_stream stream);
+
+/* ------------------------------------------------------------------------------------------
  * Prediction head of the masking pre-training step, fused (chem/pretrain_masking.py:52-57; bio/pretrain_masking.py:45-56):
  *   pred = linear_pred(node_rep[idx]) ; loss = CrossEntropyLoss()(pred.double(), label) ; correct = #(argmax(pred) == label)
  * h [n_rows, ldh] node representations, idx [m] int64 rows to predict (must not repeat: MaskAtom samples without

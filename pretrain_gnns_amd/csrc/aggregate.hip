@@ -882,14 +882,14 @@ k_segsum_chunks(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
   int j = 0;
   while (j < cnt) {
     const int run_end = min(cnt, seg_end - p0);  // positions [j, run_end) belong to `seg`
-    while (j < run_end) {  // four row loads in flight, added in position order
-      const int m = min(4, run_end - j);
-      Row<R> v[4];
+    while (j < run_end) {  // eight row loads in flight (a chunk is one wave: latency, not bandwidth, sets its pace), added in position order
+      const int m = min(8, run_end - j);
+      Row<R> v[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < 8; ++u)
         if (u < m) row_load<R>(v[u], x + (int64_t)bcast_i32(item, j + u) * ldx, lane, d4);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < 8; ++u)
         if (u < m) {
 #pragma unroll
           for (int r = 0; r < R; ++r) acc.v[r] = f4_add(acc.v[r], v[u].v[r]);
@@ -1097,23 +1097,37 @@ int pgnn_chem_aggregate_bn_fwd(const float* z, int64_t ldz, const float* coef, i
                                   (hipStream_t)stream);
 }
 
-// out_a[a] = sum_b S[a*n_b + b], out_b[b] = sum_a S[a*n_b + b]  (fixed ascending order), float4 columns
+// out_a[a] = sum_b S[a*n_b + b], out_b[b] = sum_a S[a*n_b + b], float4 columns.  out_a: one thread per (a, column), b ascending.
+// out_b sums over the LONG axis (120 atom types): 8 lanes per (b, column) take a = part, part + 8, ... and are folded by a
+// fixed xor tree -- the same association every run, and 15 dependent adds per lane instead of 120.
 __global__ void __launch_bounds__(256) k_pair_fold(const float* __restrict__ S, int n_a, int n_b, int d4,
                                                    float* __restrict__ out_a, int64_t lda, float* __restrict__ out_b,
                                                    int64_t ldb) {
-  const int total = (n_a + n_b) * d4;
+  const int na4 = n_a * d4, nb0 = (na4 + 7) & ~7, total = nb0 + n_b * d4 * 8;  // the 8-lane groups start on a multiple of 8
   const float4* __restrict__ S4 = reinterpret_cast<const float4*>(S);
-  for (int q = blockIdx.x * 256 + threadIdx.x; q < total; q += gridDim.x * 256) {
-    const int row = q / d4, c = q - row * d4;
-    float4 acc = f4_zero();
-    if (row < n_a) {
+  for (int q0 = blockIdx.x * 256; q0 < total; q0 += gridDim.x * 256) {  // whole blocks iterate together (shuffles below)
+    const int q = q0 + threadIdx.x;
+    if (q < na4) {
+      const int row = q / d4, c = q - row * d4;
+      float4 acc = f4_zero();
       for (int b = 0; b < n_b; ++b) acc = f4_add(acc, S4[(size_t)(row * n_b + b) * d4 + c]);
       if (out_a) reinterpret_cast<float4*>(out_a + (int64_t)row * lda)[c] = acc;
-    } else {
-      const int b = row - n_a;
-      for (int a = 0; a < n_a; ++a) acc = f4_add(acc, S4[(size_t)(a * n_b + b) * d4 + c]);
-      if (out_b) reinterpret_cast<float4*>(out_b + (int64_t)b * ldb)[c] = acc;
     }
+    const int t = q - nb0;
+    const bool live = q >= nb0 && q < total;
+    const int part = t & 7, o = live ? t >> 3 : 0;
+    const int b = o / d4, c = o - b * d4;
+    float4 acc = f4_zero();
+    if (live)
+      for (int a = part; a < n_a; a += 8) acc = f4_add(acc, S4[(size_t)(a * n_b + b) * d4 + c]);
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      acc.x += __shfl_xor(acc.x, m);
+      acc.y += __shfl_xor(acc.y, m);
+      acc.z += __shfl_xor(acc.z, m);
+      acc.w += __shfl_xor(acc.w, m);
+    }
+    if (live && part == 0 && out_b) reinterpret_cast<float4*>(out_b + (int64_t)b * ldb)[c] = acc;
   }
 }
 
@@ -1122,7 +1136,7 @@ int pgnn_pair_fold(const float* sums, int64_t n_a, int64_t n_b, float* out_a, in
   if (int rc = check_dim(dim)) return rc;
   PGNN_REQUIRE(n_a > 0 && n_b > 0 && lda % 4 == 0 && ldb % 4 == 0, "bad pair_fold arguments");
   const int d4 = (int)(dim / 4);
-  const int grid = (int)std::min<int64_t>(ceil_div((n_a + n_b) * d4, 256), 1024);
+  const int grid = (int)std::min<int64_t>(ceil_div(align_up((size_t)(n_a * d4), 8) + n_b * d4 * 8, 256), 1024);
   hipLaunchKernelGGL(k_pair_fold, dim3(grid), dim3(256), 0, (hipStream_t)stream, sums, (int)n_a, (int)n_b, d4, out_a, lda,
                      out_b, ldb);
   return check_launch("pair_fold");

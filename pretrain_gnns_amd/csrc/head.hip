@@ -15,10 +15,11 @@ namespace {
 
 constexpr int kHeadThreads = 128;   // one class per thread, up to 128 classes (119 atom types, 4 bond types, ...)
 constexpr int kHeadMaxDim = 2048;
-constexpr int kHeadRows = 8;        // selected rows per block: a weight value is loaded once and used for 8 rows
+constexpr int kHeadRows = 4;        // selected rows per block: a weight value is loaded once and used for 4 rows (8 rows: half
+                                    // the blocks, one per two CUs at 1007 rows -- slower)
 constexpr int kHeadClassGroup = 8;  // classes per block of the weight-gradient kernel
 
-// rows [8 blk, 8 blk + 8): logits[r, :] = h[idx[r], :] . W^T + b, then each row's float64 log-soft-max terms.
+// rows [4 blk, 4 blk + 4): logits[r, :] = h[idx[r], :] . W^T + b, then each row's float64 log-soft-max terms.
 // The LAST block to finish (device counter, self-resetting) folds the rows in order: loss = mean_r nll_r, correct = sum_r.
 __global__ void __launch_bounds__(kHeadThreads) k_head_fwd(const float* __restrict__ h, int64_t ldh, const int64_t* __restrict__ idx,
                                                            int m, const float* __restrict__ w, const float* __restrict__ b,
@@ -44,6 +45,8 @@ __global__ void __launch_bounds__(kHeadThreads) k_head_fwd(const float* __restri
     hrows[q] = v;
   }
   __syncthreads();
+  // (staging W through LDS in [classes][32 k] tiles to coalesce its loads measured SLOWER, 71 vs 49 us at 1007 rows: the
+  // scalar LDS reads cost more than the strided global float4 loads, which hit L1 after the first touch of a line)
   float z[kHeadRows];
 #pragma unroll
   for (int i = 0; i < kHeadRows; ++i) z[i] = -INFINITY;
@@ -52,6 +55,7 @@ __global__ void __launch_bounds__(kHeadThreads) k_head_fwd(const float* __restri
     float acc[kHeadRows];
 #pragma unroll
     for (int i = 0; i < kHeadRows; ++i) acc[i] = 0.f;
+#pragma unroll 2
     for (int k4 = 0; k4 < dim / 4; ++k4) {
       const float4 wv = wr[k4];
 #pragma unroll
@@ -135,7 +139,7 @@ __global__ void __launch_bounds__(kHeadThreads) k_head_fwd(const float* __restri
   }
 }
 
-// rows [8 blk, 8 blk + 8): dl[r, c] = float((softmax64(logits[r])[c] - [c == y]) * gloss / m), then the rows of
+// rows [4 blk, 4 blk + 4): dl[r, c] = float((softmax64(logits[r])[c] - [c == y]) * gloss / m), then the rows of
 // d node_rep: dnode[idx[r], :] = sum_c dl[r, c] W[c, :]   (dnode is zero elsewhere; idx must not repeat)
 __global__ void __launch_bounds__(kHeadThreads) k_head_bwd_rows(const float* __restrict__ logits, const int64_t* __restrict__ idx, int m,
                                                                 const float* __restrict__ w, const int64_t* __restrict__ label,
@@ -185,7 +189,8 @@ __global__ void __launch_bounds__(kHeadThreads) k_head_bwd_rows(const float* __r
     float acc[kHeadRows];
 #pragma unroll
     for (int i = 0; i < kHeadRows; ++i) acc[i] = 0.f;
-    for (int q = 0; q < classes; ++q) {
+#pragma unroll 8
+    for (int q = 0; q < classes; ++q) {  // (coalesced across the block: consecutive threads, consecutive k; eight loads in flight)
       const float wv = w[(int64_t)q * dim + k];
 #pragma unroll
       for (int i = 0; i < kHeadRows; ++i) acc[i] = fmaf(dls[i][q], wv, acc[i]);
@@ -205,21 +210,62 @@ __global__ void __launch_bounds__(256) k_head_bwd_weight(const float* __restrict
   const int rbeg = q * chunk, rend = min(m, rbeg + chunk);
   const int ncl = min(kHeadClassGroup, classes - c0);
   float* out = partial + (int64_t)q * classes * (dim + 1);
-  for (int k = threadIdx.x; k < dim + 1; k += blockDim.x) {  // column `dim` carries the bias gradient (h := 1)
-    float acc[kHeadClassGroup];
+  // the chunk's row ids and gradient values first (LDS, 64 rows at a time): the row loop below then has nothing but
+  // independent, coalesced loads of h in it and the compiler keeps several in flight
+  __shared__ int64_t nodes[64];
+  __shared__ float dls[64][kHeadClassGroup];
+  float acc[2][kHeadClassGroup];
 #pragma unroll
-    for (int j = 0; j < kHeadClassGroup; ++j) acc[j] = 0.f;
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int j = 0; j < kHeadClassGroup; ++j) acc[u][j] = 0.f;
+  for (int r0 = rbeg; r0 < rend; r0 += 64) {
+    const int nr = min(64, rend - r0);
+    __syncthreads();
+    for (int t = threadIdx.x; t < nr * (1 + kHeadClassGroup); t += blockDim.x) {
+      const int r = t / (1 + kHeadClassGroup), j = t - r * (1 + kHeadClassGroup);
+      if (j == 0) {
+        const int64_t node = idx[r0 + r];
+        nodes[r] = (node >= 0 && node < n_rows) ? node : -1;
+      } else {
+        dls[r][j - 1] = j - 1 < ncl ? dl[(int64_t)(r0 + r) * classes + c0 + j - 1] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {  // column k = threadIdx.x + 256 u; column `dim` carries the bias gradient (h := 1)
+      const int k = threadIdx.x + 256 * u;
+      if (k > dim) continue;
+#pragma unroll 4
+      for (int r = 0; r < nr; ++r) {
+        const float hv = k == dim ? 1.f : (nodes[r] >= 0 ? h[nodes[r] * ldh + k] : 0.f);
+#pragma unroll
+        for (int j = 0; j < kHeadClassGroup; ++j) acc[u][j] = fmaf(dls[r][j], hv, acc[u][j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int k = threadIdx.x + 256 * u;
+    if (k > dim) continue;
+#pragma unroll
+    for (int j = 0; j < kHeadClassGroup; ++j)
+      if (j < ncl) out[(int64_t)(c0 + j) * (dim + 1) + k] = acc[u][j];
+  }
+  for (int k = threadIdx.x + 512; k < dim + 1; k += blockDim.x) {  // dim > 511: the plain loop
+    float a2[kHeadClassGroup];
+#pragma unroll
+    for (int j = 0; j < kHeadClassGroup; ++j) a2[j] = 0.f;
     for (int r = rbeg; r < rend; ++r) {
       const int64_t node = idx[r];
       const float hv = k == dim ? 1.f : ((node >= 0 && node < n_rows) ? h[node * ldh + k] : 0.f);
-      const float* d = dl + (int64_t)r * classes + c0;
 #pragma unroll
       for (int j = 0; j < kHeadClassGroup; ++j)
-        if (j < ncl) acc[j] = fmaf(d[j], hv, acc[j]);
+        if (j < ncl) a2[j] = fmaf(dl[(int64_t)r * classes + c0 + j], hv, a2[j]);
     }
 #pragma unroll
     for (int j = 0; j < kHeadClassGroup; ++j)
-      if (j < ncl) out[(int64_t)(c0 + j) * (dim + 1) + k] = acc[j];
+      if (j < ncl) out[(int64_t)(c0 + j) * (dim + 1) + k] = a2[j];
   }
 }
 __global__ void __launch_bounds__(256) k_head_fold(const float* __restrict__ partial, int nchunk, int classes, int dim, float* __restrict__ dw,

@@ -1,0 +1,104 @@
+"""``Adam``: torch.optim.Adam's update for the optimizers of the reference's train loops, as ONE kernel launch.
+
+The reference builds one ``optim.Adam`` per module (chem/pretrain_masking.py:134-136: model, linear_pred_atoms,
+linear_pred_bonds) with the same hyper-parameters and calls ``zero_grad()`` / ``step()`` on each.  ``Adam`` here has the
+same constructor and the same two methods; ``Adam.shared([...modules...], lr=..., weight_decay=...)`` returns one handle
+per module that share a single kernel launch, so the reference's loop body runs unchanged::
+
+    optimizer_model, optimizer_linear_pred_atoms, optimizer_linear_pred_bonds = Adam.shared(
+        [model.parameters(), linear_pred_atoms.parameters(), linear_pred_bonds.parameters()], lr=args.lr, weight_decay=args.decay)
+
+The update is torch's formula in fp32 (csrc/optim.hip); the step counter lives on the device, so a step can be captured
+in a HIP graph.  Parameters without a gradient are skipped, like torch does; their moments stay untouched.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .ops import check, load, stream_ptr
+
+
+class _Core:
+    """the tensors of all handles, the flat moment buffers and the device step counter"""
+
+    def __init__(self, params, lr, betas, eps, weight_decay):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("optimizer got an empty parameter list")
+        for p in self.params:
+            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                raise _lib.PgnnError("pretrain_gnns_amd.optim.Adam: contiguous fp32 GPU parameters only")
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        dev = self.params[0].device
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + 63) // 64 * 64
+        self.offsets = offs
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.step_count = torch.zeros((), dtype=torch.int64, device=dev)
+        self.max_tensors = int(load().pgnn_adam_max_tensors())
+        self.waiting = 0  # handles that still have to call step() before the shared launch goes out
+        self.handles = 0
+
+    @torch.no_grad()
+    def launch(self):
+        live = [(p, o) for p, o in zip(self.params, self.offsets) if p.grad is not None]
+        lib, sp = load(), stream_ptr()
+        for i in range(0, len(live), self.max_tensors):
+            part = live[i:i + self.max_tensors]
+            n = len(part)
+            for p, _ in part:
+                if p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or p.grad.device != p.device:
+                    raise _lib.PgnnError("pretrain_gnns_amd.optim.Adam: gradients must be contiguous fp32 on the parameter's device")
+            P = (ctypes.c_void_p * n)(*[p.data_ptr() for p, _ in part])
+            G = (ctypes.c_void_p * n)(*[p.grad.data_ptr() for p, _ in part])
+            C = (ctypes.c_int64 * n)(*[p.numel() for p, _ in part])
+            O = (ctypes.c_int64 * n)(*[o for _, o in part])
+            last = i + self.max_tensors >= len(live)
+            # every part reads the same step count: only the last part's launch advances it
+            counter = self.step_count if last else self.step_count.clone()
+            check(lib.pgnn_adam_step(P, G, C, O, n, self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), counter.data_ptr(), self.lr,
+                                     self.betas[0], self.betas[1], self.eps, self.weight_decay, sp), "pgnn_adam_step")
+
+
+class Adam:
+    """torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0): zero_grad() and step()."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, _core=None):
+        self._own = list(params)
+        self._core = _core if _core is not None else _Core(self._own, lr, betas, eps, weight_decay)
+        self._core.handles += 1
+        self.param_groups = [{"params": self._own, "lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay}]
+
+    @classmethod
+    def shared(cls, param_lists, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+        """one handle per parameter list; the update of all of them is a single launch, issued by the LAST handle whose
+        ``step()`` is called in a round (the reference calls them back to back)"""
+        lists = [list(ps) for ps in param_lists]
+        core = _Core([p for ps in lists for p in ps], lr, betas, eps, weight_decay)
+        return [cls(ps, lr, betas, eps, weight_decay, _core=core) for ps in lists]
+
+    def zero_grad(self, set_to_none=True):
+        for p in self._own:
+            if p.grad is None:
+                continue
+            if set_to_none:
+                p.grad = None
+            else:
+                p.grad.detach_()
+                p.grad.zero_()
+
+    def step(self):
+        core = self._core
+        if core.waiting == 0:
+            core.waiting = core.handles
+        core.waiting -= 1
+        if core.waiting == 0:
+            core.launch()
+
+    @property
+    def step_count(self):
+        return self._core.step_count

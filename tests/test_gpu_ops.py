@@ -445,6 +445,37 @@ def test_masked_head_fwd_bwd(n, m, classes, dim):
     assert loss2.item() == loss.item() and int(correct2) == int(correct)
 
 
+@pytest.mark.parametrize("weight_decay", [0.0, 0.01])
+def test_adam_one_launch_matches_torch_adam(weight_decay):
+    """pretrain_gnns_amd.optim.Adam (all tensors of the three reference optimizers in one launch, device-side step count)
+    vs torch.optim.Adam: six steps with changing gradients, a parameter that never gets a gradient (skipped by both), L2
+    decay, shared handles stepped one after the other like chem/pretrain_masking.py:72-74"""
+    from pretrain_gnns_amd import optim
+    torch.manual_seed(3)
+    shapes = [(600, 300), (600,), (300, 600), (300,), (6, 300), (119, 300), (119,), (1,), (4097,)]
+    ref = [torch.randn(s, device=DEV).requires_grad_(True) for s in shapes]
+    mine = [t.detach().clone().requires_grad_(True) for t in ref]
+    groups = (slice(0, 5), slice(5, 7), slice(7, 9))
+    ro = [torch.optim.Adam(ref[g], lr=1e-3, weight_decay=weight_decay) for g in groups]
+    mo = optim.Adam.shared([mine[g] for g in groups], lr=1e-3, weight_decay=weight_decay)
+    for step in range(6):
+        for o in ro + mo:
+            o.zero_grad()
+        for i, (a, b) in enumerate(zip(ref, mine)):
+            if i == 3:
+                continue  # never receives a gradient
+            g = torch.randn(a.shape, device=DEV) * (10.0 ** (step - 3))
+            a.grad, b.grad = g.clone(), g.clone()
+        for o in ro:
+            o.step()
+        for o in mo:
+            o.step()
+        assert int(mo[0].step_count) == step + 1
+    for a, b in zip(ref, mine):
+        torch.testing.assert_close(b.detach(), a.detach(), rtol=2e-6, atol=1e-7)
+    assert torch.equal(mine[3].detach(), ref[3].detach())
+
+
 def test_mlp2_fwd_bwd():
     ops = _ops()
     torch.manual_seed(0)

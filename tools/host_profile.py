@@ -9,7 +9,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 dev = torch.device("cuda", 0)
 ops.set_direct_grads(True)
 mods = bench.make_models(dev)
-opts = [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0, fused=True) for m in mods]
+opts = bench.make_optimizers(mods)
 batch = synthetic.chem_masking_batch(256, seed=0).to(dev)
 for _ in range(20):
     steps.chem_masking_step(mods, opts, batch)

@@ -11,7 +11,7 @@ n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 warm = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 dev = torch.device("cuda", 0)
 mods = bench.make_models(dev)
-opts = [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0, fused=True) for m in mods]
+opts = bench.make_optimizers(mods)
 batch = synthetic.chem_masking_batch(graphs, seed=0).to(dev)
 for _ in range(warm):
     steps.chem_masking_step(mods, opts, batch)
