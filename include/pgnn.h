@@ -255,15 +255,17 @@ int pgnn_adam_step(float* const* params, const float* const* grads, const int64_
  *   pred = linear_pred(node_rep[idx]) ; loss = CrossEntropyLoss()(pred.double(), label) ; correct = #(argmax(pred) == label)
  * h [n_rows, ldh] node representations, idx [m] int64 rows to predict (must not repeat: MaskAtom samples without
  * replacement), w [classes, dim], b [classes] or NULL, label[r * label_stride] int64 in [0, classes), classes <= 128.
- * Outputs: logits [m, classes] fp32 (kept for the backward), *loss float64 (mean over rows), *correct int64; status += bad
- * indices / labels.  fp32 linear algebra, float64 soft-max and loss, as in the reference; fixed summation order.
+ * Outputs: logits [m, classes] fp32 (kept for the backward), *loss float64 (mean over rows), *correct int64, optionally
+ * metrics[2] = {loss, (double)correct} for a single read-back; status += bad indices / labels.  counter: one uint32 that is
+ * zero on entry and is left zero (the arrival counter of the in-kernel final fold; a persistent per-device word).  fp32 linear algebra, float64 soft-max and loss, as in the reference; fixed summation order.
  * Backward (gloss = d objective / d loss, float64 on the device): dnode [n_rows, ldd] is overwritten (zero outside idx),
  * dw [classes, dim], db [classes] or NULL.  Both calls use the same workspace.
  * ------------------------------------------------------------------------------------------ */
 size_t pgnn_masked_head_workspace_bytes(int64_t m, int64_t classes, int64_t dim);
 int pgnn_masked_head_fwd(const float* h, int64_t ldh, int64_t n_rows, const int64_t* idx, int64_t m, const float* w, const float* b,
                          const int64_t* label, int64_t label_stride, int64_t classes, int64_t dim, float* logits, double* loss,
-                         int64_t* correct, int32_t* status, void* ws, size_t ws_bytes, pgnn_stream stream);
+                         int64_t* correct, double* metrics, int32_t* status, uint32_t* counter, void* ws, size_t ws_bytes,
+                         pgnn_stream stream);
 int pgnn_masked_head_bwd(const float* h, int64_t ldh, int64_t n_rows, const int64_t* idx, int64_t m, const float* w,
                          const int64_t* label, int64_t label_stride, const float* logits, const double* gloss, int64_t classes,
                          int64_t dim, float* dnode, int64_t ldd, float* dw, float* db, void* ws, size_t ws_bytes, pgnn_stream stream);

@@ -55,7 +55,7 @@ PROTOTYPES = {
     "pgnn_adam_max_tensors": (_i, []),
     "pgnn_adam_step": (_i, [_p, _p, _p, _p, _i64, _p, _p, _p, _f, _f, _f, _f, _f, _p]),
     "pgnn_masked_head_workspace_bytes": (_sz, [_i64, _i64, _i64]),
-    "pgnn_masked_head_fwd": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
+    "pgnn_masked_head_fwd": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "pgnn_masked_head_bwd": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _i64, _p, _p, _i64, _i64, _p, _i64, _p, _p, _p, _sz, _p]),
     "pgnn_linear_bwd_data_t": (_i, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p]),
     "pgnn_transpose_batch": (_i, [_p, _p, _p, _p, _i64, _p]),

@@ -26,8 +26,8 @@ __global__ void __launch_bounds__(kHeadThreads) k_head_fwd(const float* __restri
                                                            const int64_t* __restrict__ label, int64_t label_stride, int classes, int dim,
                                                            int64_t n_rows, float* __restrict__ logits, double* __restrict__ row_nll,
                                                            int* __restrict__ row_hit, double* __restrict__ loss,
-                                                           int64_t* __restrict__ correct, unsigned* __restrict__ counter,
-                                                           int* __restrict__ status) {
+                                                           int64_t* __restrict__ correct, double* __restrict__ metrics,
+                                                           unsigned* __restrict__ counter, int* __restrict__ status) {
   extern __shared__ __align__(16) float hrows[];  // [kHeadRows][dim]
   __shared__ double red[kHeadThreads];
   __shared__ int redi[kHeadThreads];
@@ -135,6 +135,10 @@ __global__ void __launch_bounds__(kHeadThreads) k_head_fwd(const float* __restri
   if (c == 0) {
     *loss = red[0] / (double)m;
     *correct = redi[0];
+    if (metrics) {  // the two numbers the train loop reads back, side by side: one device-to-host copy
+      metrics[0] = red[0] / (double)m;
+      metrics[1] = (double)redi[0];
+    }
     *counter = 0;
   }
 }
@@ -298,7 +302,8 @@ size_t pgnn_masked_head_workspace_bytes(int64_t m, int64_t classes, int64_t dim)
 
 int pgnn_masked_head_fwd(const float* h, int64_t ldh, int64_t n_rows, const int64_t* idx, int64_t m, const float* w, const float* b,
                          const int64_t* label, int64_t label_stride, int64_t classes, int64_t dim, float* logits, double* loss,
-                         int64_t* correct, int32_t* status, void* ws, size_t ws_bytes, pgnn_stream stream) {
+                         int64_t* correct, double* metrics, int32_t* status, uint32_t* counter, void* ws, size_t ws_bytes,
+                         pgnn_stream stream) {
   PGNN_REQUIRE(m > 0 && classes > 0 && classes <= kHeadThreads && dim > 0 && dim % 4 == 0 && dim <= kHeadMaxDim && ldh % 4 == 0,
                "masked_head: 1..%d classes, dim and ldh multiples of 4, dim up to %d", kHeadThreads, kHeadMaxDim);
   if (ws_bytes < pgnn_masked_head_workspace_bytes(m, classes, dim)) {
@@ -308,13 +313,13 @@ int pgnn_masked_head_fwd(const float* h, int64_t ldh, int64_t n_rows, const int6
   Carver cv(ws);
   double* row_nll = cv.take<double>((size_t)m);
   int* row_hit = cv.take<int>((size_t)m);
-  unsigned* counter = cv.take<unsigned>(64);
+  cv.take<unsigned>(64);
+  PGNN_REQUIRE(counter != nullptr, "masked_head: counter (one zeroed uint32 that the call leaves zeroed) is required");
   hipStream_t st = (hipStream_t)stream;
-  PGNN_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned), st));  // (the kernel leaves it at zero too; a fresh workspace may not be)
   const size_t lds = (size_t)kHeadRows * dim * sizeof(float);
   allow_big_lds((const void*)k_head_fwd, lds);
   hipLaunchKernelGGL(k_head_fwd, dim3((int)ceil_div(m, kHeadRows)), dim3(kHeadThreads), lds, st, h, ldh, idx, (int)m, w, b, label,
-                     label_stride, (int)classes, (int)dim, n_rows, logits, row_nll, row_hit, loss, correct, counter, status);
+                     label_stride, (int)classes, (int)dim, n_rows, logits, row_nll, row_hit, loss, correct, metrics, counter, status);
   return check_launch("masked_head_fwd");
 }
 

@@ -829,10 +829,23 @@ def linear(x, layer):
 
 
 # ------------------------------------------------------------------------------------ masking prediction head
+_head_words = {}
+
+
+def _head_state(dev):
+    """[status, arrival counter]: two int32 words per device, zeroed once (the kernel leaves the counter at zero)"""
+    key = (dev.type, dev.index)
+    t = _head_words.get(key)
+    if t is None:
+        t = _head_words[key] = torch.zeros(2, dtype=torch.int32, device=dev)
+    return t
+
+
 class MaskedHead(Function):
     """linear_pred(node_rep[idx]) -> CrossEntropyLoss()(pred.double(), label) and the number of correct arg-maxes, in one
-    launch per direction (chem/pretrain_masking.py:52-57).  Returns (loss float64 [], correct int64 [], logits fp32 [m, C]);
-    only ``loss`` carries a gradient.  ``idx`` must not repeat (MaskAtom samples without replacement)."""
+    launch per direction (chem/pretrain_masking.py:52-57).  Returns (loss float64 [], correct int64 [], logits fp32 [m, C],
+    metrics float64 [2] = (loss, correct) for a single read-back); only ``loss`` carries a gradient.  ``idx`` must not
+    repeat (MaskAtom samples without replacement)."""
 
     @staticmethod
     def forward(ctx, node_rep, idx, weight, bias, label):
@@ -849,22 +862,24 @@ class MaskedHead(Function):
         logits = torch.empty(m, classes, dtype=torch.float32, device=dev)
         loss = torch.empty((), dtype=torch.float64, device=dev)
         correct = torch.empty((), dtype=torch.int64, device=dev)
-        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        metrics = torch.empty(2, dtype=torch.float64, device=dev)
+        words = _head_state(dev)
         ws = torch.empty(_ws_bytes("pgnn_masked_head_workspace_bytes", m, classes, dim), dtype=torch.uint8, device=dev)
         check(load().pgnn_masked_head_fwd(h.data_ptr(), h.stride(0), n, idx.data_ptr(), m, w.data_ptr(),
                                           b.data_ptr() if b is not None else None, label.data_ptr(), label.stride(0), classes, dim,
-                                          logits.data_ptr(), loss.data_ptr(), correct.data_ptr(), status.data_ptr(), ws.data_ptr(),
-                                          ws.numel(), stream_ptr()), "pgnn_masked_head_fwd")
-        if _CHECK_INDICES and int(status.item()):
+                                          logits.data_ptr(), loss.data_ptr(), correct.data_ptr(), metrics.data_ptr(), words.data_ptr(),
+                                          words.data_ptr() + 4, ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_masked_head_fwd")
+        if _CHECK_INDICES and int(words[0].item()):
+            words[0] = 0
             raise IndexError("masked head: row index or label out of range")
         ctx.save_for_backward(h, idx, w, label, logits)
         ctx.ws, ctx.has_bias = ws, bias is not None
-        ctx.mark_non_differentiable(correct, logits)
-        return loss, correct, logits
+        ctx.mark_non_differentiable(correct, logits, metrics)
+        return loss, correct, logits, metrics
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, gloss, _gc, _gl):
+    def backward(ctx, gloss, _gc, _gl, _gm):
         h, idx, w, label, logits = ctx.saved_tensors
         n, dim = h.shape
         m, classes = logits.shape
@@ -880,10 +895,11 @@ class MaskedHead(Function):
         return dnode, None, dw, db, None
 
 
-def masked_head(node_rep, idx, linear, label):
-    """(loss, correct) of ``linear(node_rep[idx])`` against ``label`` -- see MaskedHead"""
-    loss, correct, _ = MaskedHead.apply(node_rep, idx, linear.weight, linear.bias, label)
-    return loss, correct
+def masked_head(node_rep, idx, linear, label, with_metrics=False):
+    """(loss, correct) of ``linear(node_rep[idx])`` against ``label`` -- see MaskedHead; ``with_metrics`` adds the packed
+    float64 [2] tensor (loss, correct)"""
+    loss, correct, _, metrics = MaskedHead.apply(node_rep, idx, linear.weight, linear.bias, label)
+    return (loss, correct, metrics) if with_metrics else (loss, correct)
 
 
 # ------------------------------------------------------------------------------------ fused chem GIN layer

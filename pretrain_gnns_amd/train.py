@@ -36,9 +36,11 @@ def chem_masking_step(model_list, optimizer_list, batch, mask_edge=False, readba
     model, linear_pred_atoms, linear_pred_bonds = model_list
     node_rep = model(batch.x, batch.edge_index, batch.edge_attr)
     inline = readback == "inline"
+    packed = None
     if not inline and _fusable_head(linear_pred_atoms, node_rep):
         # the three statements below as one launch per direction (ops.MaskedHead: same dtypes, float64 soft-max and loss)
-        loss, acc_node = ops.masked_head(node_rep, batch.masked_atom_indices, linear_pred_atoms, batch.mask_node_label[:, 0])
+        loss, acc_node, packed = ops.masked_head(node_rep, batch.masked_atom_indices, linear_pred_atoms,
+                                                 batch.mask_node_label[:, 0], with_metrics=True)
         n_node = batch.masked_atom_indices.numel()
     else:
         pred_node = linear_pred_atoms(node_rep[batch.masked_atom_indices])
@@ -46,7 +48,7 @@ def chem_masking_step(model_list, optimizer_list, batch, mask_edge=False, readba
         acc_node = compute_accuracy(pred_node, batch.mask_node_label[:, 0]) if inline else _correct(pred_node, batch.mask_node_label[:, 0])
         n_node = len(pred_node)
     n_edge = 1
-    acc_edge = 0.0 if inline else torch.zeros((), dtype=torch.long, device=loss.device)
+    acc_edge = 0.0 if (inline or not mask_edge) else None
     if mask_edge:
         masked_edge_index = batch.edge_index[:, batch.connected_edge_indices]
         edge_rep = node_rep[masked_edge_index[0]] + node_rep[masked_edge_index[1]]
@@ -61,6 +63,11 @@ def chem_masking_step(model_list, optimizer_list, batch, mask_edge=False, readba
         opt.step()
     if inline:
         return float(loss.cpu().item()), acc_node, acc_edge
+    if packed is not None and not mask_edge:  # (loss, correct) already side by side on the device
+        vals = packed.cpu().tolist()
+        return vals[0], vals[1] / n_node, 0.0
+    if not torch.is_tensor(acc_edge):
+        acc_edge = torch.zeros((), dtype=torch.long, device=loss.device)
     vals = torch.stack([loss.detach(), acc_node.double(), acc_edge.double()]).cpu().tolist()
     return vals[0], vals[1] / n_node, vals[2] / n_edge
 
