@@ -300,7 +300,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
 //    LDS writes + barriers 73, split arithmetic 90, global loads 150 of 755 at M = 262144, K = 300, N = 600): the two
 //    resident workgroups settle into lockstep, so the kernel sits at 1.45-1.5x the fp32-MFMA kernel rather than 2.7x;
 //  - 4-wave workgroups, a two-stage LDS ring with the staging interleaved behind the MFMAs, a two-tile register ring,
-//    256x160 / 128x320 tiles, and weights pre-split (and pre-transposed) into bf16 planes by a side kernel: all slower;
+//    256x160 / 128x320 tiles, weights pre-split (and pre-transposed) into bf16 planes by a side kernel, and wave
+//    specialisation (8 loader waves that load / split / stage + 8 consumer waves that only issue MFMAs, two LDS stages,
+//    1-4 tiles of loads in flight): all slower or equal.  The K sweep (tools/gemm_ksweep.py, M = 6747, N = 608) puts a
+//    k-step at 1.5 us where its MFMAs need ~0.9, with 8.5 us fixed per launch, in the symmetric AND the specialised form;
 //  - the backward products (row-contiguous operands, 4x4 register transposition in front of the split): slower than the
 //    fp32 MFMA, so they keep it.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
