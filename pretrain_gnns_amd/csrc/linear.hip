@@ -450,6 +450,12 @@ int launch_gemm3(const GemmArgs& p, hipStream_t st) {
 
 // forward product: 1 = split-bf16 (v_mfma_f32_16x16x32_bf16 x 6), 0 = fp32 MFMA (v_mfma_f32_16x16x4_f32)
 inline int gemm_mode() { return env_knob("PGNN_GEMM_SPLIT", 1); }
+// Below ~160 tiles of 64x160 the split kernel's smallest tile leaves most CUs empty and the fp32-MFMA kernel's 64x64 tiles win
+// (M = 1000: 12.1 / 20.4 us against 16.7 / 25.0; M = 6747: 37 / 36 against 25 / 27, tools/gemm_split_check.py)
+inline bool use_split(int64_t m, int64_t n) {
+  if (gemm_mode() != 1) return false;
+  return env_knob("PGNN_GEMM3_CFG", -1) >= 0 || ceil_div(m, 64) * ceil_div(n, 160) >= env_knob("PGNN_GEMM3_MIN_TILES", 160);
+}
 
 // dst_j[c][r] = src_j[r][c] for up to 16 small matrices in one launch (the weights of a layer stack, transposed once
 // per backward pass so that backward-data becomes a k-contiguous product): 32x32 tiles through LDS, blockIdx.y = job
@@ -619,7 +625,7 @@ int pgnn_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bi
   p.nxcd = num_xcd();
   p.A = x; p.lda = ldx; p.B = w; p.ldb = k; p.C = y; p.ldc = ldy;
   p.M = (int)m; p.N = (int)n; p.K = (int)k; p.bias = bias; p.relu = relu; p.kchunk = (int)k; p.split_stride = 0;
-  if (gemm_mode() == 1) return launch_gemm3<EPI_BIAS>(p, (hipStream_t)stream);
+  if (use_split(m, n)) return launch_gemm3<EPI_BIAS>(p, (hipStream_t)stream);
   return launch_cfg<true, true, EPI_BIAS>(pick_cfg(m, n, 0), p, 1, (hipStream_t)stream);
 }
 
@@ -662,7 +668,7 @@ int pgnn_linear_bwd_data_t(const float* dy, int64_t lddy, const float* wt, const
   p.A = dy; p.lda = lddy; p.B = wt; p.ldb = n; p.C = dx; p.ldc = lddx;
   p.M = (int)m; p.N = (int)k; p.K = (int)n; p.mask = relu_out; p.ldmask = ldr; p.kchunk = (int)n; p.split_stride = 0;
   hipStream_t st = (hipStream_t)stream;
-  if (gemm_mode() == 1) return relu_out ? launch_gemm3<EPI_MASK>(p, st) : launch_gemm3<EPI_PLAIN>(p, st);
+  if (use_split(m, k)) return relu_out ? launch_gemm3<EPI_MASK>(p, st) : launch_gemm3<EPI_PLAIN>(p, st);
   const TileCfg c = pick_cfg(m, k, 0);
   return relu_out ? launch_cfg<true, true, EPI_MASK>(c, p, 1, st) : launch_cfg<true, true, EPI_PLAIN>(c, p, 1, st);
 }
