@@ -2,7 +2,7 @@
 
 Two processes share cuda:0 (gloo backend -- RCCL refuses two ranks on one device; the layer under test is
 backend-agnostic and the 8-GPU RCCL run is the driver's) and run the real thing: HIP `GNN` + head,
-`parallel.AllReduceOptimizers`, direct gradient deposit ON (the path bench.py uses), `ResidentLoader(rank, world_size)`
+`parallel.AllReduceOptimizers` over `optim.Adam.shared`, direct gradient deposit ON (the path bench.py uses), `ResidentLoader(rank, world_size)`
 device-side batches.  Checked:
   (i)   ranks start identical (broadcast) and stay bit-identical over several Adam steps;
   (ii)  eval-mode BatchNorm: the summed gradient of the two shards == the single-process gradient of the whole batch;
@@ -53,7 +53,8 @@ def _worker(rank, world, port, out_dir):
     torch.manual_seed(100 + rank)  # deliberately different initial weights per rank
     mods = [hchem.GNN(5, 300).to(dev), torch.nn.Linear(300, 119).to(dev), torch.nn.Linear(300, 4).to(dev)]
     parallel.broadcast_parameters(mods)
-    opts = parallel.AllReduceOptimizers([torch.optim.Adam(m.parameters(), lr=1e-3, fused=True) for m in mods])
+    from pretrain_gnns_amd import optim
+    opts = parallel.AllReduceOptimizers(optim.Adam.shared([m.parameters() for m in mods], lr=1e-3))  # what bench.py builds
     loader = resident.ResidentLoader(ds, 16, shuffle=True, seed=9, mask_rate=0.15, rank=rank, world_size=world)
     res["len_loader"] = len(loader)
     for m in mods:
