@@ -354,6 +354,27 @@ int pgnn_chem_lin_stack_bwd(int kind, const float* dy, int64_t lddy, const int64
                             int64_t n, int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The bio GIN network (bio/model.py:11-58, 258-290; JK = "last", no dropout) in one call per direction:
+ *   agg = [sum_j h_j + h_i | cfeat . EncT] ; pre = agg W1^T + b1 ; hid = relu(BatchNorm_2D(pre)) ; y = hid W2^T + b2,
+ *   ReLU between layers.  pgnn_gin_layer is reused: emb1 = EncT [10, dim] = [W_enc^T; b_enc] (emb2 unused), w1 [2D,2D],
+ *   b1 [2D], w2 [D,2D], b2 [D], gamma / beta / running statistics of the BatchNorm1d(2D) inside the mlp; gradients:
+ *   demb = d EncT [10, dim], the others as named.  h0 [n, ldh0] = the first layer's (embedded) input; cfeat [n, 10] and
+ *   the CSRs from pgnn_bio_graph_build; tile_start / num_tiles from pgnn_graph_tiles (NULL: untiled aggregation).
+ *   acts [num_layer][7][n][dim] = (agg: 2 slots, pre: 2, hid: 2, y: 1); stats [num_layer][2][2*dim] = (mean, 1/std);
+ *   the output is acts[num_layer-1][6].  Backward: dy = its gradient; dh0 [n, dim] may be NULL.
+ * ------------------------------------------------------------------------------------------ */
+size_t pgnn_bio_gin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t num_layer);
+int pgnn_bio_gin_stack_fwd(const float* h0, int64_t ldh0, const int32_t* in_ptr, const int32_t* in_src, const float* cfeat,
+                           const int32_t* tile_start, const int32_t* num_tiles, const pgnn_gin_layer* layers, int num_layer,
+                           int training, float* acts, float* stats, int64_t n, int64_t dim, void* ws, size_t ws_bytes,
+                           pgnn_stream stream);
+int pgnn_bio_gin_stack_bwd(const float* dy, int64_t lddy, const int32_t* out_ptr, const int32_t* out_dst, const float* cfeat,
+                           const int32_t* tile_start, const int32_t* num_tiles, const pgnn_gin_layer* layers, int num_layer,
+                           int training, const float* acts, const float* stats, float* dh0, int64_t n, int64_t dim, void* ws,
+                           size_t ws_bytes, pgnn_stream stream);
+
+
+/* ------------------------------------------------------------------------------------------
  * Device-side batching over a dataset resident in HBM.  The dataset is kept in
  * the concatenated (data, slices) form InMemoryDataset stores (chem/loader.py MoleculeDataset,
  * bio/loader.py BioDataset): x_all [sum n, *], edge_index_all [2, sum e] with graph-local node ids,

@@ -52,6 +52,9 @@ PROTOTYPES = {
     "pgnn_mean_l2norm_bwd": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _p]),
     "pgnn_linear_fwd": (_i, [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _p]),
     "pgnn_linear_bwd_data": (_i, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p]),
+    "pgnn_bio_gin_stack_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "pgnn_bio_gin_stack_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _i64, _p, _sz, _p]),
+    "pgnn_bio_gin_stack_bwd": (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _i64, _i64, _p, _sz, _p]),
     "pgnn_adam_max_tensors": (_i, []),
     "pgnn_adam_step": (_i, [_p, _p, _p, _p, _i64, _p, _p, _p, _f, _f, _f, _f, _f, _p]),
     "pgnn_masked_head_workspace_bytes": (_sz, [_i64, _i64, _i64]),

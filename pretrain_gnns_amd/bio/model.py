@@ -11,7 +11,11 @@ node feature from a 2-row table.  GPU tensors only; the CPU restatement lives in
 import torch
 import torch.nn.functional as F
 
+import os
+
 from pretrain_gnns_amd import attention, ops
+
+_STACK_CALL = os.environ.get("PGNN_STACK_CALL", "1") != "0"  # GNN.forward of a GIN / JK="last" model as one library call
 
 
 def _edge_and_input(module, emb_dim, input_layer):
@@ -155,6 +159,10 @@ class GNN(torch.nn.Module):
 
     def forward(self, x, edge_index, edge_attr):
         graph = ops.build_bio_graph(edge_index, edge_attr, x.size(0), gcn=(self.gnn_type == "gcn"))
+        if (_STACK_CALL and self.gnn_type == "gin" and self.JK == "last" and (self.drop_ratio == 0 or not self.training)
+                and not any(getattr(c.mlp[1], "pgnn_exact", False) for c in self.gnns)):
+            # the whole network as one library call per direction (ops.BioGINStack)
+            return ops.bio_gin_stack(_embed_input(self.gnns[0], x), graph, list(self.gnns))
         h_list = [x]
         for layer in range(self.num_layer):
             h = self.gnns[layer](h_list[layer], edge_index, edge_attr, graph)

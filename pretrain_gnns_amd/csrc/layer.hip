@@ -502,3 +502,190 @@ int pgnn_chem_lin_stack_bwd(int kind, const float* dy, int64_t lddy, const int64
 }
 
 }  // extern "C"
+
+/* ---------------------------------------------------------------------------------------------
+ * The bio GIN network in one call per direction (bio/model.py:11-58, 227-290, JK = "last", no dropout):
+ *   agg = [sum_j h_j + h_i | cfeat . EncT]   (graph-resident aggregation, csrc/tile.hip, both halves in one launch)
+ *   pre = agg W1^T + b1 ; hid = relu(BN_2D(pre)) ; y = hid W2^T + b2, ReLU'd between layers (fused in the product's epilogue)
+ * pgnn_gin_layer is reused: emb1 = EncT [10, dim] = [W_enc^T; b_enc] (emb2 unused), w1 [2D,2D], b1 [2D], w2 [D,2D], b2 [D],
+ * gamma / beta / running stats of the BatchNorm1d(2D) inside the mlp; gradients: demb = d EncT [10, dim], the rest as named.
+ * acts [num_layer][7][n][dim] = (agg 2, pre 2, hid 2, y 1 slots of n*dim); stats [num_layer][2][2D] = (mean, 1/std).
+ * --------------------------------------------------------------------------------------------- */
+namespace {
+__global__ void __launch_bounds__(256) k_relu_mask(float* __restrict__ g, const float* __restrict__ y, int64_t n4) {
+  for (int64_t q = blockIdx.x * (int64_t)256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
+    float4 v = reinterpret_cast<float4*>(g)[q];
+    const float4 m = reinterpret_cast<const float4*>(y)[q];
+    if (!(m.x > 0.f)) v.x = 0.f;
+    if (!(m.y > 0.f)) v.y = 0.f;
+    if (!(m.z > 0.f)) v.z = 0.f;
+    if (!(m.w > 0.f)) v.w = 0.f;
+    reinterpret_cast<float4*>(g)[q] = v;
+  }
+}
+inline size_t bio_op_ws_bytes(int64_t n, int64_t d) {
+  size_t m = pgnn_bn_workspace_bytes(n, 2 * d);
+  m = std::max(m, pgnn_linear_bwd_weight_workspace_bytes(n, 2 * d, 2 * d));
+  m = std::max(m, pgnn_linear_bwd_weight_workspace_bytes(n, 2 * d, d));
+  m = std::max(m, pgnn_rowfeat_matmul_bwd_workspace_bytes(n, 10, d));
+  return align_up(m, 256);
+}
+}  // namespace
+
+extern "C" {
+
+size_t pgnn_bio_gin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t num_layer) {
+  const size_t nd = align_up((size_t)n * dim * 4, 256);
+  // 2 x op scratch + 2 x (dhid, dpre, dagg: 2 nd each; dx: nd) + W1^T, W2^T per layer
+  const size_t wt = (size_t)std::min<int64_t>(num_layer, kMaxTransposed) * (align_up((size_t)4 * dim * dim * 4, 256) + align_up((size_t)2 * dim * dim * 4, 256));
+  return 2 * bio_op_ws_bytes(n, dim) + 2 * 7 * nd + wt + 512;
+}
+
+int pgnn_bio_gin_stack_fwd(const float* h0, int64_t ldh0, const int32_t* in_ptr, const int32_t* in_src, const float* cfeat,
+                           const int32_t* tile_start, const int32_t* num_tiles, const pgnn_gin_layer* layers, int num_layer,
+                           int training, float* acts, float* stats, int64_t n, int64_t dim, void* ws, size_t ws_bytes,
+                           pgnn_stream stream) {
+  if (num_layer < 1 || !layers || !h0 || !cfeat) {
+    set_error("bio_gin_stack_fwd: bad arguments");
+    return PGNN_ERR_ARG;
+  }
+  if (ws_bytes < bio_op_ws_bytes(n, dim)) {
+    set_error("bio_gin_stack_fwd workspace too small");
+    return PGNN_ERR_WORKSPACE;
+  }
+  const size_t nd = (size_t)n * dim;
+  const float* h = h0;
+  int64_t ldh = ldh0;
+  int rc;
+  for (int l = 0; l < num_layer; ++l) {
+    const pgnn_gin_layer& p = layers[l];
+    float* a = acts + (size_t)l * 7 * nd;
+    float *agg = a, *pre = a + 2 * nd, *hid = a + 4 * nd, *y = a + 6 * nd;
+    float* st = stats + (size_t)l * 4 * dim;  // mean [2D], invstd [2D]
+    if (tile_start && num_tiles) {
+      rc = pgnn_neighbor_sum_tiled(h, ldh, in_ptr, in_src, nullptr, tile_start, num_tiles, agg, 2 * dim, n, dim, cfeat, 10, p.emb1,
+                                   dim, agg + dim, 2 * dim, stream);
+    } else {
+      if ((rc = pgnn_neighbor_sum(h, ldh, in_ptr, in_src, nullptr, agg, 2 * dim, n, dim, stream))) return rc;
+      rc = pgnn_rowfeat_matmul_fwd(cfeat, 10, p.emb1, dim, agg + dim, 2 * dim, n, dim, 0, stream);
+    }
+    if (rc) return rc;
+    if ((rc = pgnn_linear_fwd(agg, 2 * dim, p.w1, p.b1, pre, 2 * dim, n, 2 * dim, 2 * dim, 0, stream))) return rc;
+    if ((rc = pgnn_bn_fwd(pre, 2 * dim, p.gamma, p.beta, p.running_mean, p.running_var, p.momentum, p.eps, training, 1, hid,
+                          2 * dim, st, st + 2 * dim, 0.f, 0, n, 2 * dim, ws, ws_bytes, stream))) return rc;
+    if ((rc = pgnn_linear_fwd(hid, 2 * dim, p.w2, p.b2, y, dim, n, 2 * dim, dim, l != num_layer - 1, stream))) return rc;
+    h = y;
+    ldh = dim;
+  }
+  return PGNN_OK;
+}
+
+int pgnn_bio_gin_stack_bwd(const float* dy, int64_t lddy, const int32_t* out_ptr, const int32_t* out_dst, const float* cfeat,
+                           const int32_t* tile_start, const int32_t* num_tiles, const pgnn_gin_layer* layers, int num_layer,
+                           int training, const float* acts, const float* stats, float* dh0, int64_t n, int64_t dim, void* ws,
+                           size_t ws_bytes, pgnn_stream stream) {
+  if (num_layer < 1 || !layers || !dy || !cfeat) {
+    set_error("bio_gin_stack_bwd: bad arguments");
+    return PGNN_ERR_ARG;
+  }
+  if (ws_bytes < pgnn_bio_gin_stack_workspace_bytes(n, dim, num_layer)) {
+    set_error("bio_gin_stack_bwd workspace too small");
+    return PGNN_ERR_WORKSPACE;
+  }
+  const size_t nd = (size_t)n * dim;
+  Carver cv(ws);
+  const size_t opb = bio_op_ws_bytes(n, dim);
+  char* op = cv.take<char>(opb);
+  char* op2 = cv.take<char>(opb);
+  float *dhid[2], *dpre[2], *dagg[2], *dxb[2];
+  for (int q = 0; q < 2; ++q) {
+    dhid[q] = cv.take<float>(2 * nd);
+    dpre[q] = cv.take<float>(2 * nd);
+    dagg[q] = cv.take<float>(2 * nd);
+    dxb[q] = cv.take<float>(nd);
+  }
+  const int ntr = std::min(num_layer, kMaxTransposed);
+  float *w1t[kMaxTransposed], *w2t[kMaxTransposed];
+  for (int q = 0; q < ntr; ++q) {
+    w1t[q] = cv.take<float>((size_t)4 * dim * dim);
+    w2t[q] = cv.take<float>((size_t)2 * dim * dim);
+  }
+  hipStream_t main = (hipStream_t)stream;
+  Side* sd = (use_side_stream() && n <= kSideMaxRows) ? side_for_current_device() : nullptr;
+  hipStream_t aux = sd ? sd->stream : main;
+  char* aux_ws = sd ? op2 : op;
+  int rc;
+  const bool tr = ntr > 0 && use_transposed_weights();
+  if (tr) {
+    const float* tsrc[2 * kMaxTransposed];
+    float* tdst[2 * kMaxTransposed];
+    int64_t trows[2 * kMaxTransposed], tcols[2 * kMaxTransposed];
+    for (int q = 0; q < ntr; ++q) {
+      const pgnn_gin_layer& p = layers[num_layer - 1 - q];
+      tsrc[2 * q] = p.w1; tdst[2 * q] = w1t[q]; trows[2 * q] = 2 * dim; tcols[2 * q] = 2 * dim;          // W1 [2D, 2D]
+      tsrc[2 * q + 1] = p.w2; tdst[2 * q + 1] = w2t[q]; trows[2 * q + 1] = dim; tcols[2 * q + 1] = 2 * dim;  // W2 [D, 2D]
+    }
+    if (sd) {
+      PGNN_HIP(hipEventRecord(sd->fork[0], main));
+      PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[0], 0));
+    }
+    if ((rc = pgnn_transpose_batch(tsrc, tdst, trows, tcols, 2 * ntr, aux))) return rc;
+    if (sd) {
+      PGNN_HIP(hipEventRecord(sd->fork[2], aux));
+      PGNN_HIP(hipStreamWaitEvent(main, sd->fork[2], 0));
+    }
+  }
+  const float* g = dy;
+  int64_t ldg = lddy;
+  for (int l = num_layer - 1; l >= 0; --l) {
+    const pgnn_gin_layer& p = layers[l];
+    const int q = num_layer - 1 - l, b = l & 1;
+    const float* a = acts + (size_t)l * 7 * nd;
+    const float *agg = a, *pre = a + 2 * nd, *hid = a + 4 * nd;
+    const float* st = stats + (size_t)l * 4 * dim;
+    // g = gradient of this layer's output (already masked by the ReLU that follows it, see the end of the loop body):
+    // dy for the last layer, else dxb[l & 1], written by iteration l + 1
+    if (tr && q < ntr) rc = pgnn_linear_bwd_data_t(g, ldg, w2t[q], nullptr, 0, dhid[b], 2 * dim, n, 2 * dim, dim, main);
+    else rc = pgnn_linear_bwd_data(g, ldg, p.w2, nullptr, 0, dhid[b], 2 * dim, n, 2 * dim, dim, main);
+    if (rc) return rc;
+    if ((rc = pgnn_bn_bwd(dhid[b], 2 * dim, pre, 2 * dim, p.gamma, p.beta, st, st + 2 * dim, training, 1, dpre[b], 2 * dim,
+                          p.dgamma, p.dbeta, 0.f, 0, n, 2 * dim, op, opb, main))) return rc;
+    if (tr && q < ntr) rc = pgnn_linear_bwd_data_t(dpre[b], 2 * dim, w1t[q], nullptr, 0, dagg[b], 2 * dim, n, 2 * dim, 2 * dim, main);
+    else rc = pgnn_linear_bwd_data(dpre[b], 2 * dim, p.w1, nullptr, 0, dagg[b], 2 * dim, n, 2 * dim, 2 * dim, main);
+    if (rc) return rc;
+    if (sd) {
+      PGNN_HIP(hipEventRecord(sd->fork[1], main));
+      PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[1], 0));
+    }
+    // parameter gradients (side stream when there is one): dW2 = g^T hid, dW1 = dpre^T agg, d EncT = cfeat^T dagg[:, D:]
+    if ((rc = pgnn_linear_bwd_weight(g, ldg, hid, 2 * dim, p.dw2, p.db2, n, 2 * dim, dim, aux_ws, opb, aux))) return rc;
+    if ((rc = pgnn_linear_bwd_weight(dpre[b], 2 * dim, agg, 2 * dim, p.dw1, p.db1, n, 2 * dim, 2 * dim, aux_ws, opb, aux))) return rc;
+    if ((rc = pgnn_rowfeat_matmul_bwd(cfeat, 10, dagg[b] + dim, 2 * dim, p.demb, dim, n, dim, aux_ws, opb, aux))) return rc;
+    if (sd && l >= 1) PGNN_HIP(hipEventRecord(sd->lag[b], aux));
+    if (l == 0 && !dh0) break;
+    // dx goes to the buffer set of its consumer, layer l - 1; that set (and its dx slot, which the side stream reads as the
+    // `g` of layer l + 1's dW2) was last used by layer l + 1: wait for the side stream's layer l + 1 work
+    if (sd && l + 1 <= num_layer - 1) PGNN_HIP(hipStreamWaitEvent(main, sd->lag[(l + 1) & 1], 0));
+    float* dx = l == 0 ? dh0 : dxb[(l - 1) & 1];
+    if (tile_start && num_tiles)
+      rc = pgnn_neighbor_sum_tiled(dagg[b], 2 * dim, out_ptr, out_dst, nullptr, tile_start, num_tiles, dx, dim, n, dim, nullptr, 0,
+                                   nullptr, 0, nullptr, 0, main);
+    else
+      rc = pgnn_neighbor_sum(dagg[b], 2 * dim, out_ptr, out_dst, nullptr, dx, dim, n, dim, main);
+    if (rc) return rc;
+    if (l > 0) {  // the ReLU between layer l-1 and l: y_{l-1} = relu(.) was written by the forward product's epilogue
+      const float* yprev = acts + (size_t)(l - 1) * 7 * nd + 6 * nd;
+      hipLaunchKernelGGL(k_relu_mask, dim3((int)std::min<int64_t>(ceil_div(nd / 4, 256), 4096)), dim3(256), 0, main, dx, yprev,
+                         (int64_t)(nd / 4));
+    }
+    g = dx;
+    ldg = dim;
+  }
+  if (sd) {
+    PGNN_HIP(hipEventRecord(sd->join, aux));
+    PGNN_HIP(hipStreamWaitEvent(main, sd->join, 0));
+  }
+  return check_launch("bio_gin_stack_bwd");
+}
+
+}  // extern "C"

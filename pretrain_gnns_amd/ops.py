@@ -1214,6 +1214,99 @@ def chem_gin_stack(owner, x_idx, graph, x_embedding1, x_embedding2, convs, bns, 
                               x_embedding1.weight, x_embedding2.weight, *flat)
 
 
+# ------------------------------------------------------------------------------------ whole bio GIN network
+class BioGINStack(Function):
+    """Every (GINConv, ReLU) layer of the bio GNN (bio/model.py:11-58, 258-290, JK = "last", no dropout) as ONE library call
+    per direction (pgnn_bio_gin_stack_fwd / _bwd): graph-resident concat aggregation, both products of the mlp, the
+    BatchNorm1d(2D) between them, the ReLU between layers fused into the second product's epilogue; backward with the
+    weight-gradient products on the side stream and backward-data on transposed weights.  Inputs: h0 [N, D] (layer 0's
+    embedded input), graph, meta, then 8 tensors per layer (enc_w [D,9], enc_b [D], w1 [2D,2D], b1 [2D], w2 [D,2D], b2 [D],
+    gamma [2D], beta [2D]) -- see ``bio_gin_stack``."""
+
+    PER_LAYER = 8
+
+    @staticmethod
+    def forward(ctx, h0, graph, meta, *params):
+        training, bns = meta
+        require_cuda(h0, *params)
+        h0 = _rows2d(h0)
+        n, dim = h0.shape
+        L = len(params) // BioGINStack.PER_LAYER
+        if graph.kind != "bio" or graph.gcn or n != graph.n:
+            raise _lib.PgnnError("bio GIN stack: needs the bio graph built with gcn=False for these nodes")
+        if training and n <= 1:
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s" % ((n, 2 * dim),))
+        dev = h0.device
+        for t in params:
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise _lib.PgnnError("model parameters must be contiguous float32 tensors")
+        # [W_enc^T; b_enc] of every layer in one [L, 10, D] tensor
+        tables = torch.cat([torch.stack([params[8 * l].t() for l in range(L)]),
+                            torch.stack([params[8 * l + 1] for l in range(L)]).unsqueeze(1)], dim=1).contiguous()
+        layers = (_lib.GinLayer * L)()
+        for l in range(L):
+            s_, p = layers[l], params[8 * l:8 * l + 8]
+            s_.emb1 = tables[l].data_ptr()
+            s_.w1, s_.b1, s_.w2, s_.b2, s_.gamma, s_.beta = [t.data_ptr() for t in p[2:]]
+            rm, rv, momentum, eps = bns[l]
+            s_.running_mean = rm.data_ptr() if rm is not None else None
+            s_.running_var = rv.data_ptr() if rv is not None else None
+            s_.momentum, s_.eps = momentum, eps
+        acts = torch.empty(L, 7, n, dim, dtype=torch.float32, device=dev)
+        stats = torch.empty(L, 2, 2 * dim, dtype=torch.float32, device=dev)
+        ws = _workspace(_ws_bytes("pgnn_bio_gin_stack_workspace_bytes", n, dim, L), dev)
+        tiles = graph.tiles
+        check(load().pgnn_bio_gin_stack_fwd(
+            h0.data_ptr(), h0.stride(0), graph.in_ptr.data_ptr(), graph.in_src.data_ptr(), graph.cfeat.data_ptr(),
+            tiles[0].data_ptr() if tiles is not None else None, tiles[1].data_ptr() if tiles is not None else None, layers, L,
+            int(training), acts.data_ptr(), stats.data_ptr(), n, dim, ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_bio_gin_stack_fwd")
+        ctx.save_for_backward(acts, stats, tables, *params)
+        ctx.graph, ctx.training, ctx.layers = graph, bool(training), layers
+        return acts[L - 1, 6]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        acts, stats, tables = ctx.saved_tensors[:3]
+        L, _, n, dim = acts.shape
+        dy = _rows2d(dy)
+        dev = dy.device
+        graph = ctx.graph
+        # one flat gradient buffer: per layer d EncT [10, D], dw1 [2D, 2D], db1 [2D], dw2 [D, 2D], db2 [D], dgamma [2D], dbeta [2D]
+        per = [10 * dim, 4 * dim * dim, 2 * dim, 2 * dim * dim, dim, 2 * dim, 2 * dim]
+        flat = torch.empty(L * sum(per), dtype=torch.float32, device=dev)
+        layers = _private_layers(ctx.layers)
+        views = []
+        for l in range(L):
+            pieces = flat[l * sum(per):(l + 1) * sum(per)].split_with_sizes(per)
+            s_ = layers[l]
+            s_.demb, s_.dw1, s_.db1, s_.dw2, s_.db2, s_.dgamma, s_.dbeta = [t.data_ptr() for t in pieces]
+            views.append(pieces)
+        dh0 = torch.empty(n, dim, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        ws = _workspace(_ws_bytes("pgnn_bio_gin_stack_workspace_bytes", n, dim, L), dev)
+        tiles = graph.tiles
+        check(load().pgnn_bio_gin_stack_bwd(
+            dy.data_ptr(), dy.stride(0), graph.out_ptr.data_ptr(), graph.out_dst.data_ptr(), graph.cfeat.data_ptr(),
+            tiles[0].data_ptr() if tiles is not None else None, tiles[1].data_ptr() if tiles is not None else None, layers, L,
+            int(ctx.training), acts.data_ptr(), stats.data_ptr(), dh0.data_ptr() if dh0 is not None else None, n, dim, ws.data_ptr(),
+            ws.numel(), stream_ptr()), "pgnn_bio_gin_stack_bwd")
+        grads = []
+        for l in range(L):
+            denc, dw1, db1, dw2, db2, dgam, dbet = views[l]
+            denc = denc.view(10, dim)
+            grads += [denc[:9].t(), denc[9], dw1.view(2 * dim, 2 * dim), db1, dw2.view(dim, 2 * dim), db2, dgam, dbet]
+        return (dh0, None, None) + tuple(grads)
+
+
+def bio_gin_stack(h0, graph, convs):
+    """all GINConv layers of the bio GNN (ReLU between them) through the stack call; ``h0`` = layer 0's embedded input"""
+    bns = [c.mlp[1] for c in convs]
+    training = bns[0].training or bns[0].running_mean is None
+    flat = [t for c in convs for t in (c.edge_encoder.weight, c.edge_encoder.bias, c.mlp[0].weight, c.mlp[0].bias,
+                                       c.mlp[3].weight, c.mlp[3].bias, c.mlp[1].weight, c.mlp[1].bias)]
+    return BioGINStack.apply(h0, graph, (training, _bn_meta(bns)), *flat)
+
+
 # ------------------------------------------------------------------------------------ whole chem GCN / GraphSAGE network
 _lin_layouts = {}
 

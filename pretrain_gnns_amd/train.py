@@ -142,21 +142,28 @@ class GraphedChemMaskingStep:
         return vals[0], vals[1] / self.n_node, vals[2] / self.n_edge
 
 
-def bio_masking_step(model_list, optimizer_list, batch):
+def bio_masking_step(model_list, optimizer_list, batch, readback="end"):
+    """One iteration of bio/pretrain_masking.py:29-60.  readback as in ``chem_masking_step``: "inline" syncs where the
+    reference does (accuracy between forward and backward, loss after the optimizer), "end" (default) fetches the same two
+    numbers with one transfer after ``optimizer.step()``."""
     model, linear_pred_edges = model_list
     node_rep = model(batch.x, batch.edge_index, batch.edge_attr)
     masked_edge_index = batch.edge_index[:, batch.masked_edge_idx]
     edge_rep = node_rep[masked_edge_index[0]] + node_rep[masked_edge_index[1]]
     pred_edge = linear_pred_edges(edge_rep)
     edge_label = torch.argmax(batch.mask_edge_label, dim=1)
-    acc_edge = compute_accuracy(pred_edge, edge_label)
+    inline = readback == "inline"
+    acc_edge = compute_accuracy(pred_edge, edge_label) if inline else _correct(pred_edge, edge_label)
     for opt in optimizer_list:
         opt.zero_grad()
     loss = F.cross_entropy(pred_edge, edge_label)
     loss.backward()
     for opt in optimizer_list:
         opt.step()
-    return float(loss.cpu().item()), acc_edge
+    if inline:
+        return float(loss.cpu().item()), acc_edge
+    vals = torch.stack([loss.detach().double(), acc_edge.double()]).cpu().tolist()
+    return vals[0], vals[1] / len(pred_edge)
 
 
 def cycle_index(num, shift):

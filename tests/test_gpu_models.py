@@ -141,6 +141,45 @@ def test_bio_gnn_forward_backward(gnn_type):
     _grads_close(ref, hip, (b.x.double(), b.edge_index, b.edge_attr.double()), w)
 
 
+@pytest.mark.parametrize("graphs,layers,training", [(8, 5, True), (64, 3, True), (8, 2, False)])
+def test_bio_one_call_network_equals_per_layer_path(graphs, layers, training, monkeypatch):
+    """pgnn_bio_gin_stack_fwd/_bwd (the whole bio GIN network in one call per direction: fused ReLU between layers, side
+    stream for the weight-gradient products) against the per-layer calls: outputs and BatchNorm running statistics
+    bit-identical; every gradient bit-identical with PGNN_BWD_TRANSPOSED=0 and within fp32 rounding of a different
+    summation order with backward-data on transposed weights (the default)"""
+    import copy
+    from pretrain_gnns_amd import ops
+    _, hbio = _hip()
+    _, a = _pair(obio.GNN, hbio.GNN, layers, 300, seed=4)
+    b = copy.deepcopy(a)
+    c = copy.deepcopy(a)
+    for m in (a, b, c):
+        m.train(training)
+    d = synthetic.bio_masking_batch(graphs, seed=3).to(DEV)
+    w = torch.randn(d.x.size(0), 300, device=DEV)
+
+    def run(m, stack, transposed):
+        monkeypatch.setattr(hbio, "_STACK_CALL", stack)
+        monkeypatch.setenv("PGNN_BWD_TRANSPOSED", "1" if transposed else "0")
+        ops.load().pgnn_reload_env()
+        for _ in range(2):  # twice: running statistics advance identically
+            m.zero_grad()
+            out = m(d.x, d.edge_index, d.edge_attr)
+            (out * w).sum().backward()
+        return out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}, {k: v.clone() for k, v in m.named_buffers()}
+
+    per_layer, exact, default = run(a, False, False), run(b, True, False), run(c, True, True)
+    monkeypatch.delenv("PGNN_BWD_TRANSPOSED")
+    ops.load().pgnn_reload_env()
+    assert torch.equal(per_layer[0], exact[0]) and torch.equal(per_layer[0], default[0])
+    for k in per_layer[2]:
+        assert torch.equal(per_layer[2][k], exact[2][k]) and torch.equal(per_layer[2][k], default[2][k]), k
+    top = max(float(g.abs().max()) for g in per_layer[1].values())
+    for k, g in per_layer[1].items():
+        assert torch.equal(g, exact[1][k]), k
+        assert float((g - default[1][k]).abs().max()) <= 2e-5 * float(g.abs().max()) + 1e-5 * top, k
+
+
 @pytest.mark.parametrize("pool", ["mean", "attention"])
 def test_bio_graphpred(pool):
     _, hbio = _hip()
