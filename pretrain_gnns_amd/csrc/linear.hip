@@ -322,59 +322,129 @@ __device__ __forceinline__ void split3(float a, float b, uint32_t& h, uint32_t& 
   l = pack_bf16(sa, sb);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// LDS image of one operand tile of a 32-deep k-step, one bf16 plane:
+//   k-contiguous operand  : [row][32 k], 64-byte rows, 16-byte chunks XOR-swizzled by the row; fragment = one ds_read_b128
+//   row-contiguous operand: [32 k][S columns] as the data lies in memory (no transposition on the way in: a float4 is four
+//                           columns of one k); the MFMA fragment -- 8 consecutive k of one column per lane -- comes out of
+//                           two ds_read_b64_tr_b16 (each 16-lane group hands over a 4 k x 16 column block transposed;
+//                           semantics probed in tools/probe/tr16_probe.hip).  Rows with bit 3 of k set are rotated by 16
+//                           columns and S = columns (+ 32 unless columns % 64 == 32): conflict-free for the instruction's
+//                           32-lane groups (brute-forced over its bank map, (byte / 4) % 64).
+template <int COLS>
+struct RowMajorTile {
+  static constexpr int S = (COLS % 64 == 32) ? COLS : COLS + 32;
+  static constexpr int PLANE = 32 * S * 2;  // bytes
+  __device__ static __forceinline__ int offset(int k, int col) { return (k * S + (col + 16 * ((k >> 3) & 1)) % S) * 2; }
+};
+template <int ROWS>
+struct KMajorTile {
+  static constexpr int PLANE = ROWS * 64;
+  __device__ static __forceinline__ int offset(int row, int kq) {
+    return row * 64 + (((kq >> 1) ^ ((-(row >> 2)) & 3)) * 16) + (kq & 1) * 8;
+  }
+};
+
+// One kernel, four operand-layout instantiations: forward / backward-data on transposed weights (both k-contiguous),
+// backward-data (dy k-contiguous, W row-contiguous), backward-weight (both row-contiguous, split over k = rows, optional
+// ones column for the bias gradient).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3(GemmArgs p) {
   constexpr int BK = 32;
   constexpr int NW = WAVES_M * WAVES_N, T = 64 * NW;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MI = WM / 16, NI = WN / 16;
-  static_assert(WM % 16 == 0 && WN % 16 == 0 && BM % 16 == 0, "tile shape");
-  constexpr int ROWB = 64;                      // bytes per LDS row of one plane (32 bf16)
-  constexpr int PLANE = (BM + BN) * ROWB;       // A rows, then B rows
-  constexpr int U = (BM + BN) * 8;              // staging units: one float4 = 4 k of one row (unit u: row u >> 3, k-quad u & 7)
-  constexpr int NU = (U + T - 1) / T;
+  static_assert(WM % 16 == 0 && WN % 16 == 0 && BM % 16 == 0 && BN % 16 == 0, "tile shape");
+  using TA = typename std::conditional<A_KMAJOR, KMajorTile<BM>, RowMajorTile<BM>>::type;
+  using TB = typename std::conditional<B_KMAJOR, KMajorTile<BN>, RowMajorTile<BN>>::type;
+  constexpr int PA = TA::PLANE, PB = TB::PLANE;  // bytes per plane; a stage = three A planes, then three B planes
+  constexpr int UA = BM * 8, UB = BN * 8;        // staging units (one float4 each) per operand
+  constexpr int NA = (UA + T - 1) / T, NB = (UB + T - 1) / T;
 
   extern __shared__ __align__(16) unsigned char smem3[];
+  unsigned char* const ldsA = smem3;
+  unsigned char* const ldsB = smem3 + 3 * PA;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_n = (p.N + (ONES ? 4 : 0) + BN - 1) / BN;
   const int tile = xcd_remap(blockIdx.x, gridDim.x, p.nxcd);
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-  const int nk = (p.K + BK - 1) / BK;
+  const int kbeg = blockIdx.y * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  const int nk = (kend - kbeg + BK - 1) / BK;
 
-  // this thread's units: source pointer at k-step 0 (rows past the M / N edge read a zero page) and LDS byte offset
-  const float* src[NU];
-  int kq4[NU], off[NU];
-  bool rowok[NU];
+  // ---- this thread's staging units.  k-contiguous: unit u = (row u >> 3, k-quad u & 7), source advances along k;
+  //      row-contiguous: unit u = (k u / (cols/4), column quad u % (cols/4)), source advances by 32 rows per step.
+  const float* srcA[NA];
+  const float* srcB[NB];
+  int offA[NA], offB[NB], kofA[NA], kofB[NB];
+  bool okA[NA], okB[NB], oneB[NB];
 #pragma unroll
-  for (int j = 0; j < NU; ++j) {
-    const int u = min(tid + j * T, U - 1);  // (a clamped duplicate rewrites the same LDS bytes with the same values)
-    const int row = u >> 3, kq = u & 7;
-    const bool isA = row < BM;
-    const int g = isA ? m0 + row : n0 + row - BM;
-    rowok[j] = g < (isA ? p.M : p.N);
-    kq4[j] = 4 * kq;
-    src[j] = (isA ? p.A + (int64_t)g * p.lda : p.B + (int64_t)g * p.ldb) + 4 * kq;
-    off[j] = row * ROWB + (((kq >> 1) ^ ((-(row >> 2)) & 3)) * 16) + (kq & 1) * 8;
-  }
-  float4 r[NU];
-  auto load_tile = [&](int it) {
-    const int k0 = it * BK;
-#pragma unroll
-    for (int j = 0; j < NU; ++j) {
-      const float* g = (rowok[j] && k0 + kq4[j] < p.K) ? src[j] + k0 : reinterpret_cast<const float*>(g_zero_page);
-      r[j] = *reinterpret_cast<const float4*>(g);
+  for (int j = 0; j < NA; ++j) {
+    const int u = min(tid + j * T, UA - 1);  // (a clamped duplicate rewrites the same LDS bytes with the same values)
+    if (A_KMAJOR) {
+      const int row = u >> 3, kq = u & 7;
+      okA[j] = m0 + row < p.M;
+      kofA[j] = 4 * kq;
+      srcA[j] = p.A + (int64_t)(m0 + row) * p.lda + kbeg + 4 * kq;
+      offA[j] = KMajorTile<BM>::offset(row, kq);
+    } else {
+      const int kr = u / (BM / 4), cq = u - kr * (BM / 4);
+      okA[j] = m0 + 4 * cq < p.M;
+      kofA[j] = kr;
+      srcA[j] = p.A + (int64_t)(kbeg + kr) * p.lda + m0 + 4 * cq;
+      offA[j] = RowMajorTile<BM>::offset(kr, 4 * cq);
     }
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int u = min(tid + j * T, UB - 1);
+    oneB[j] = false;
+    if (B_KMAJOR) {
+      const int row = u >> 3, kq = u & 7;
+      okB[j] = n0 + row < p.N;
+      kofB[j] = 4 * kq;
+      srcB[j] = p.B + (int64_t)(n0 + row) * p.ldb + kbeg + 4 * kq;
+      offB[j] = KMajorTile<BN>::offset(row, kq);
+    } else {
+      const int kr = u / (BN / 4), cq = u - kr * (BN / 4);
+      okB[j] = n0 + 4 * cq < p.N;
+      oneB[j] = ONES && n0 + 4 * cq == p.N;  // the ones column: C[m][N] = sum_k Aop(m, k) = the bias gradient
+      kofB[j] = kr;
+      srcB[j] = p.B + (int64_t)(kbeg + kr) * p.ldb + n0 + 4 * cq;
+      offB[j] = RowMajorTile<BN>::offset(kr, 4 * cq);
+    }
+  }
+  float4 ra[NA], rb[NB];
+  auto load_tile = [&](int it) {
+    const int k0 = kbeg + it * BK;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const bool ok = okA[j] && k0 + kofA[j] < kend;
+      const float* g = ok ? srcA[j] + (A_KMAJOR ? (int64_t)it * BK : (int64_t)it * BK * p.lda) : reinterpret_cast<const float*>(g_zero_page);
+      ra[j] = *reinterpret_cast<const float4*>(g);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const bool kok = k0 + kofB[j] < kend;
+      const float* g = (okB[j] && kok) ? srcB[j] + (B_KMAJOR ? (int64_t)it * BK : (int64_t)it * BK * p.ldb)
+                                       : reinterpret_cast<const float*>((ONES && oneB[j] && kok) ? g_ones_page : g_zero_page);
+      rb[j] = *reinterpret_cast<const float4*>(g);
+    }
+  };
+  auto store_unit = [&](const float4& v, unsigned char* base, int plane, int off) {
+    uint32_t h0, m0_, l0, h1, m1, l1;
+    split3(v.x, v.y, h0, m0_, l0);
+    split3(v.z, v.w, h1, m1, l1);
+    *reinterpret_cast<uint2*>(base + off) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(base + plane + off) = make_uint2(m0_, m1);
+    *reinterpret_cast<uint2*>(base + 2 * plane + off) = make_uint2(l0, l1);
   };
   auto store_tile = [&]() {
 #pragma unroll
-    for (int j = 0; j < NU; ++j) {
-      uint32_t h0, m0_, l0, h1, m1, l1;
-      split3(r[j].x, r[j].y, h0, m0_, l0);
-      split3(r[j].z, r[j].w, h1, m1, l1);
-      *reinterpret_cast<uint2*>(smem3 + off[j]) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(smem3 + PLANE + off[j]) = make_uint2(m0_, m1);
-      *reinterpret_cast<uint2*>(smem3 + 2 * PLANE + off[j]) = make_uint2(l0, l1);
-    }
+    for (int j = 0; j < NA; ++j) store_unit(ra[j], ldsA, PA, offA[j]);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) store_unit(rb[j], ldsB, PB, offB[j]);
   };
 
   f32x4 acc[MI][NI];
@@ -385,21 +455,38 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3(GemmArgs p) {
 
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
   const int fr = lane & 15, fk = lane >> 4;
-  const int frag_off = fr * ROWB + ((fk ^ ((-(fr >> 2)) & 3)) * 16);  // (16-row blocks start at multiples of 16 rows: same swizzle)
-  const unsigned char* At = smem3 + wm0 * ROWB + frag_off;
-  const unsigned char* Bt = smem3 + (BM + wn0) * ROWB + frag_off;
+  // fragment of the 16 tile rows / columns starting at `c0`, plane q
+  auto frag = [&](auto kmajor, auto cols_tag, const unsigned char* base, int plane, int c0, int q) -> bf16x8 {
+    constexpr int COLS = decltype(cols_tag)::value;
+    if constexpr (decltype(kmajor)::value) {
+      return *reinterpret_cast<const bf16x8*>(base + q * plane + (c0 + fr) * 64 + ((fk ^ ((-(fr >> 2)) & 3)) * 16));
+    } else {
+      // lane (i = fr, g = fk): k-blocks 2g and 2g+1 (rows 8g .. 8g+7, all with the same bit 3 = g & 1), row 4 kb + i / 4,
+      // its address = four consecutive columns of that row; the group's 16 lanes receive one column each
+      using L = RowMajorTile<COLS>;
+      const int col = (c0 + 4 * (fr & 3) + 16 * (fk & 1)) % L::S;
+      const unsigned char* a0 = base + q * plane + ((8 * fk + (fr >> 2)) * L::S + col) * 2;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * L::S * 2));
+      return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+  };
+  using KA = std::integral_constant<bool, A_KMAJOR>;
+  using KB = std::integral_constant<bool, B_KMAJOR>;
+  using CA = std::integral_constant<int, BM>;
+  using CB = std::integral_constant<int, BN>;
 
   auto compute = [&]() {
     bf16x8 a[MI][3];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(At + q * PLANE + i * 16 * ROWB);
+      for (int q = 0; q < 3; ++q) a[i][q] = frag(KA{}, CA{}, ldsA, PA, wm0 + i * 16, q);
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       bf16x8 b[3];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) b[q] = *reinterpret_cast<const bf16x8*>(Bt + q * PLANE + j * 16 * ROWB);
+      for (int q = 0; q < 3; ++q) b[q] = frag(KB{}, CB{}, ldsB, PB, wn0 + j * 16, q);
       // smallest terms first; operands swapped (D = B x A) so a lane ends up with 4 consecutive columns of one C row
 #pragma unroll
       for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i][2], acc[i][j], 0, 0, 0);
@@ -416,9 +503,11 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3(GemmArgs p) {
     }
   };
 
-  load_tile(0);
-  store_tile();
-  if (1 < nk) load_tile(1);
+  if (nk > 0) {
+    load_tile(0);
+    store_tile();
+    if (1 < nk) load_tile(1);
+  }
   __syncthreads();
   for (int t = 0; t < nk; ++t) {
     compute();
@@ -427,25 +516,28 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3(GemmArgs p) {
     __syncthreads();
     if (t + 2 < nk) load_tile(t + 2);
   }
-  gemm_epilogue<EPI, false, MI, NI>(p, acc, m0 + wm0, n0 + wn0, lane);
+  gemm_epilogue<EPI, ONES, MI, NI>(p, acc, m0 + wm0, n0 + wn0, lane);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
-int launch_gemm3_s(const GemmArgs& p, hipStream_t st) {
-  constexpr size_t lds = (size_t)3 * (BM + BN) * 64;
-  const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N, BN));
-  allow_big_lds((const void*)k_gemm3<BM, BN, WAVES_M, WAVES_N, EPI>, lds);
-  hipLaunchKernelGGL((k_gemm3<BM, BN, WAVES_M, WAVES_N, EPI>), dim3(tiles, 1), dim3(64 * WAVES_M * WAVES_N), lds, st, p);
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES>
+int launch_gemm3_s(const GemmArgs& p, int nsplit, hipStream_t st) {
+  using TA = typename std::conditional<A_KMAJOR, KMajorTile<BM>, RowMajorTile<BM>>::type;
+  using TB = typename std::conditional<B_KMAJOR, KMajorTile<BN>, RowMajorTile<BN>>::type;
+  constexpr size_t lds = (size_t)3 * (TA::PLANE + TB::PLANE);
+  const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N + (ONES ? 4 : 0), BN));
+  allow_big_lds((const void*)k_gemm3<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES>, lds);
+  hipLaunchKernelGGL((k_gemm3<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES>), dim3(tiles, nsplit),
+                     dim3(64 * WAVES_M * WAVES_N), lds, st, p);
   return check_launch("gemm3");
 }
 
 // 128x160 tiles (wave tile 32x80) when they give at least 3/4 of the CUs a workgroup, else 64x160 (16x80)
-template <int EPI>
-int launch_gemm3(const GemmArgs& p, hipStream_t st) {
+template <bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES = false>
+int launch_gemm3(const GemmArgs& p, int nsplit, hipStream_t st) {
   const int forced = env_knob("PGNN_GEMM3_CFG", -1);
-  const bool big = forced >= 0 ? forced == 0 : ceil_div(p.M, 128) * ceil_div(p.N, 160) * 4 >= 3 * num_cu();
-  if (big) return launch_gemm3_s<128, 160, 4, 2, EPI>(p, st);
-  return launch_gemm3_s<64, 160, 4, 2, EPI>(p, st);
+  const bool big = forced >= 0 ? forced == 0 : ceil_div(p.M, 128) * ceil_div(p.N, 160) * nsplit * 4 >= 3 * num_cu();
+  if (big) return launch_gemm3_s<128, 160, 4, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
+  return launch_gemm3_s<64, 160, 4, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
 }
 
 // forward product: 1 = split-bf16 (v_mfma_f32_16x16x32_bf16 x 6), 0 = fp32 MFMA (v_mfma_f32_16x16x4_f32)
@@ -625,7 +717,7 @@ int pgnn_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bi
   p.nxcd = num_xcd();
   p.A = x; p.lda = ldx; p.B = w; p.ldb = k; p.C = y; p.ldc = ldy;
   p.M = (int)m; p.N = (int)n; p.K = (int)k; p.bias = bias; p.relu = relu; p.kchunk = (int)k; p.split_stride = 0;
-  if (use_split(m, n)) return launch_gemm3<EPI_BIAS>(p, (hipStream_t)stream);
+  if (use_split(m, n)) return launch_gemm3<true, true, EPI_BIAS>(p, 1, (hipStream_t)stream);
   return launch_cfg<true, true, EPI_BIAS>(pick_cfg(m, n, 0), p, 1, (hipStream_t)stream);
 }
 
@@ -638,6 +730,12 @@ int pgnn_linear_bwd_data(const float* dy, int64_t lddy, const float* w, const fl
   // C = dx [m, k] ; reduction over n ; A = dy (n contiguous) ; B(kcol, nn) = w[nn*k + kcol]
   p.A = dy; p.lda = lddy; p.B = w; p.ldb = k; p.C = dx; p.ldc = lddx;
   p.M = (int)m; p.N = (int)k; p.K = (int)n; p.mask = relu_out; p.ldmask = ldr; p.kchunk = (int)n; p.split_stride = 0;
+  // W row-contiguous: transpose-read fragments (RowMajorTile).  28 / 27 us against 38 / 35 at 6 747 rows, 54 / 56 against
+  // 74 / 67 at 16 384; level with the fp32-MFMA kernel from 65 536 rows on (the transposed-weights form keeps its 1.4x there)
+  if (use_split(m, k) && m <= 65536 && env_knob("PGNN_GEMM3_BWD", 1)) {
+    if (relu_out) return launch_gemm3<true, false, EPI_MASK>(p, 1, (hipStream_t)stream);
+    return launch_gemm3<true, false, EPI_PLAIN>(p, 1, (hipStream_t)stream);
+  }
   const TileCfg c = pick_cfg(m, k, 1);
   if (relu_out) return launch_cfg<true, false, EPI_MASK>(c, p, 1, (hipStream_t)stream);
   return launch_cfg<true, false, EPI_PLAIN>(c, p, 1, (hipStream_t)stream);
@@ -668,14 +766,20 @@ int pgnn_linear_bwd_data_t(const float* dy, int64_t lddy, const float* wt, const
   p.A = dy; p.lda = lddy; p.B = wt; p.ldb = n; p.C = dx; p.ldc = lddx;
   p.M = (int)m; p.N = (int)k; p.K = (int)n; p.mask = relu_out; p.ldmask = ldr; p.kchunk = (int)n; p.split_stride = 0;
   hipStream_t st = (hipStream_t)stream;
-  if (use_split(m, k)) return relu_out ? launch_gemm3<EPI_MASK>(p, st) : launch_gemm3<EPI_PLAIN>(p, st);
+  if (use_split(m, k)) return relu_out ? launch_gemm3<true, true, EPI_MASK>(p, 1, st) : launch_gemm3<true, true, EPI_PLAIN>(p, 1, st);
   const TileCfg c = pick_cfg(m, k, 0);
   return relu_out ? launch_cfg<true, true, EPI_MASK>(c, p, 1, st) : launch_cfg<true, true, EPI_PLAIN>(c, p, 1, st);
 }
 
+// backward-weight on the split-bf16 kernel (both operands row-contiguous: transpose-read fragments), 64x160 tiles: 31 us
+// against 38 at 6 747 rows, 68-78 against 88-90 at 16 384; from 32 768 rows on the fp32-MFMA kernel's 320x160 tile re-reads
+// the panels a fifth as often and wins (896 us against 975 at 262 144; a 128x160 split tile: 1052-1269)
+inline bool weight_split(int64_t m) { return gemm_mode() == 1 && env_knob("PGNN_GEMM3_BWD", 1) && m >= 2048 && m < 32768; }
+
 size_t pgnn_linear_bwd_weight_workspace_bytes(int64_t m, int64_t k, int64_t n) {
   const TileCfg c = weight_cfg(m);
-  return align_up((size_t)weight_splits(m, k, n, kCfg[c].bm, kCfg[c].bn) * (n * k + n) * sizeof(float), 256) + 256;
+  const int64_t splits = std::max(weight_splits(m, k, n, kCfg[c].bm, kCfg[c].bn), weight_splits(m, k, n, 64, 160));
+  return align_up((size_t)splits * (n * k + n) * sizeof(float), 256) + 256;
 }
 
 int pgnn_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, float* db,
@@ -689,7 +793,8 @@ int pgnn_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_
   hipStream_t st = (hipStream_t)stream;
   Carver cv(ws);
   const TileCfg cfg = weight_cfg(m);
-  const int nsplit = weight_splits(m, k, n, kCfg[cfg].bm, kCfg[cfg].bn);
+  const bool split3 = weight_split(m);
+  const int nsplit = split3 ? weight_splits(m, k, n, 64, 160) : weight_splits(m, k, n, kCfg[cfg].bm, kCfg[cfg].bn);
   float* partial = cv.take<float>((size_t)nsplit * (n * k + n));
   GemmArgs p{};
   p.nxcd = num_xcd();
@@ -698,7 +803,7 @@ int pgnn_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_
   p.A = dy; p.lda = lddy; p.B = x; p.ldb = ldx;
   p.M = (int)n; p.N = (int)k; p.K = (int)m;
   int64_t chunk = ceil_div(m, nsplit);
-  chunk = ceil_div(chunk, kWgtBK) * kWgtBK;
+  chunk = split3 ? ceil_div(chunk, 32) * 32 : ceil_div(chunk, kWgtBK) * kWgtBK;  // whole k-steps of the kernel in use
   p.kchunk = (int)chunk;
   const int used = (int)ceil_div(m, chunk);
   const bool direct = used == 1;
@@ -706,8 +811,13 @@ int pgnn_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_
   p.ldc = k;
   p.split_stride = direct ? 0 : n * k + n;
   p.colsum = direct ? db : partial + n * k;
-  int rc = db ? launch_cfg<false, false, EPI_PLAIN, true>(cfg, p, used, st)
-              : launch_cfg<false, false, EPI_PLAIN, false>(cfg, p, used, st);
+  int rc;
+  if (split3)
+    rc = db ? launch_gemm3_s<64, 160, 4, 2, false, false, EPI_PLAIN, true>(p, used, st)
+            : launch_gemm3_s<64, 160, 4, 2, false, false, EPI_PLAIN, false>(p, used, st);
+  else
+    rc = db ? launch_cfg<false, false, EPI_PLAIN, true>(cfg, p, used, st)
+            : launch_cfg<false, false, EPI_PLAIN, false>(cfg, p, used, st);
   if (rc) return rc;
   if (!direct) {
     const int64_t n4a = n * k / 4, n4b = db ? n / 4 : 0;
