@@ -41,7 +41,13 @@ Side* side_for_current_device() {
   return &s;
 }
 inline bool use_side_stream() { return env_knob("PGNN_SIDE_STREAM", 1) != 0; }
-inline bool use_transposed_weights() { return env_knob("PGNN_BWD_TRANSPOSED", 1) != 0; }
+// backward-data on pre-transposed weights (both operands k-contiguous): 0 = never, 2 = always, 1 (default) = from 16 384 rows,
+// where the k-contiguous form pulls ahead of pgnn_linear_bwd_data's transpose-read form (44 / 45 us against 54 / 56 at 16 384
+// rows, 145 / 135 against 204 / 244 at 65 536); at one 256-graph batch the two are level and the extra launch is not worth it
+inline bool use_transposed_weights(int64_t n) {
+  const int v = env_knob("PGNN_BWD_TRANSPOSED", 1);
+  return v == 2 || (v == 1 && n >= 16384);
+}
 inline bool per_layer_buffers() { return env_knob("PGNN_STACK_PER_LAYER_BUFFERS", 0) != 0; }
 constexpr int kMaxTransposed = 8;  // layers whose weights pgnn_chem_gin_stack_bwd transposes up front (one 16-job launch)
 inline size_t op_ws_bytes(int64_t n, int64_t d) {
@@ -315,7 +321,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   // W1^T / W2^T of the top `ntr` layers in one launch: backward-data then has both operands contiguous along the
   // contracted dimension and runs the forward (split-bf16) kernel.  On the side stream when there is one: the first
   // BatchNorm backward covers it.
-  if (ntr > 0 && use_transposed_weights()) {
+  if (ntr > 0 && use_transposed_weights(n)) {
     const float* tsrc[2 * kMaxTransposed];
     float* tdst[2 * kMaxTransposed];
     int64_t trows[2 * kMaxTransposed], tcols[2 * kMaxTransposed];
@@ -334,7 +340,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
       PGNN_HIP(hipStreamWaitEvent(main, sd->fork[2], 0));
     }
   }
-  const bool tr = ntr > 0 && use_transposed_weights();
+  const bool tr = ntr > 0 && use_transposed_weights(n);
 
   const float* g = dy;
   int64_t ldg = lddy;
@@ -615,7 +621,7 @@ int pgnn_bio_gin_stack_bwd(const float* dy, int64_t lddy, const int32_t* out_ptr
   hipStream_t aux = sd ? sd->stream : main;
   char* aux_ws = sd ? op2 : op;
   int rc;
-  const bool tr = ntr > 0 && use_transposed_weights();
+  const bool tr = ntr > 0 && use_transposed_weights(n);
   if (tr) {
     const float* tsrc[2 * kMaxTransposed];
     float* tdst[2 * kMaxTransposed];

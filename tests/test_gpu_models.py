@@ -160,7 +160,7 @@ def test_bio_one_call_network_equals_per_layer_path(graphs, layers, training, mo
 
     def run(m, stack, transposed):
         monkeypatch.setattr(hbio, "_STACK_CALL", stack)
-        monkeypatch.setenv("PGNN_BWD_TRANSPOSED", "1" if transposed else "0")
+        monkeypatch.setenv("PGNN_BWD_TRANSPOSED", "2" if transposed else "0")
         ops.load().pgnn_reload_env()
         for _ in range(2):  # twice: running statistics advance identically
             m.zero_grad()
@@ -484,7 +484,7 @@ def test_transposed_backward_data_matches_the_fp32_mfma_backward(graphs, layers,
     d = synthetic.chem_masking_batch(graphs, seed=9).to(DEV)
     w = torch.randn(d.x.size(0), 300, device=DEV)
     grads = []
-    for flag in ("1", "0"):
+    for flag in ("2", "0"):  # 2 = transposed weights at every size (the default switches at 16 384 rows)
         monkeypatch.setenv("PGNN_BWD_TRANSPOSED", flag)
         ops.load().pgnn_reload_env()
         m.zero_grad()
@@ -545,7 +545,7 @@ def test_transposed_backward_data_matches_the_fp32_mfma_backward(graphs, layers,
     d = synthetic.chem_masking_batch(graphs, seed=9).to(DEV)
     w = torch.randn(d.x.size(0), 300, device=DEV)
     grads = []
-    for flag in ("1", "0"):
+    for flag in ("2", "0"):  # 2 = transposed weights at every size (the default switches at 16 384 rows)
         monkeypatch.setenv("PGNN_BWD_TRANSPOSED", flag)
         ops.load().pgnn_reload_env()
         m.zero_grad()
