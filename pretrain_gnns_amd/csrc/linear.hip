@@ -1,4 +1,5 @@
-// fp32 MFMA GEMMs for the GIN mlp / GCN linear (gfx950): forward, backward-data, backward-weight.
+// GEMMs for the GIN mlp / GCN linear (gfx950): forward, backward-data, backward-weight -- an fp32-MFMA kernel (k_gemm) and a
+// split-bf16 kernel (k_gemm3, further down; the default wherever it is faster, see use_split / weight_split).
 //
 // The reference reaches cuBLAS sgemm through nn.Linear (chem/model.py:29,63; bio/model.py:24,67).
 // fp32 parity (1e-4 on node embeddings after 5 BatchNorm'ed layers) rules out bf16/fp8, and gfx950
@@ -279,7 +280,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// fp32 product on the bf16 matrix cores (forward product: both operands k-contiguous).  Every fp32 operand value is
+// fp32 product on the bf16 matrix cores.  Every fp32 operand value is
 // split EXACTLY into three bf16 terms
 //     a = a1 + a2 + a3,   a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2)      (3 x 8 = 24 significand bits)
 // and a.b is accumulated as the six products whose weight is above 2^-24 of |a.b|:
@@ -304,8 +305,9 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
 //    specialisation (8 loader waves that load / split / stage + 8 consumer waves that only issue MFMAs, two LDS stages,
 //    1-4 tiles of loads in flight): all slower or equal.  The K sweep (tools/gemm_ksweep.py, M = 6747, N = 608) puts a
 //    k-step at 1.5 us where its MFMAs need ~0.9, with 8.5 us fixed per launch, in the symmetric AND the specialised form;
-//  - the backward products (row-contiguous operands, 4x4 register transposition in front of the split): slower than the
-//    fp32 MFMA, so they keep it.
+//  - row-contiguous operands with a 4x4 register transposition in front of the split: slower than the fp32 MFMA.  What
+//    replaced it -- untransposed staging + ds_read_b64_tr_b16 fragment reads, RowMajorTile below -- is faster than the fp32
+//    MFMA up to ~32 k rows (backward-weight) / ~65 k rows (backward-data).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
