@@ -773,14 +773,16 @@ int pgnn_linear_bwd_data_t(const float* dy, int64_t lddy, const float* wt, const
   return relu_out ? launch_cfg<true, true, EPI_MASK>(c, p, 1, st) : launch_cfg<true, true, EPI_PLAIN>(c, p, 1, st);
 }
 
-// backward-weight on the split-bf16 kernel (both operands row-contiguous: transpose-read fragments), 64x160 tiles: 31 us
-// against 38 at 6 747 rows, 68-78 against 88-90 at 16 384; from 32 768 rows on the fp32-MFMA kernel's 320x160 tile re-reads
-// the panels a fifth as often and wins (896 us against 975 at 262 144; a 128x160 split tile: 1052-1269)
-inline bool weight_split(int64_t m) { return gemm_mode() == 1 && env_knob("PGNN_GEMM3_BWD", 1) && m >= 2048 && m < 32768; }
+// backward-weight on the split-bf16 kernel (both operands row-contiguous: transpose-read fragments) from 2 048 rows on:
+// 64x160 tiles below kWeightBigRows (31 us against the fp32-MFMA kernel's 38 at 6 747 rows, 64 against 83 at 16 384), 320x160
+// tiles above (the activation panels are re-read a fifth as often: 584 / 570 us against 900 at 262 144 rows, where the 64x160
+// tile takes 975; the two tiles cross at ~24 k rows: 95 vs 90 us)
+constexpr int64_t kWeightBigRows = 24576;
+inline bool weight_split(int64_t m) { return gemm_mode() == 1 && env_knob("PGNN_GEMM3_BWD", 1) && m >= 2048; }
 
 size_t pgnn_linear_bwd_weight_workspace_bytes(int64_t m, int64_t k, int64_t n) {
   const TileCfg c = weight_cfg(m);
-  const int64_t splits = std::max(weight_splits(m, k, n, kCfg[c].bm, kCfg[c].bn), weight_splits(m, k, n, 64, 160));
+  const int64_t splits = std::max({weight_splits(m, k, n, kCfg[c].bm, kCfg[c].bn), weight_splits(m, k, n, 64, 160), weight_splits(m, k, n, 320, 160)});
   return align_up((size_t)splits * (n * k + n) * sizeof(float), 256) + 256;
 }
 
@@ -796,7 +798,8 @@ int pgnn_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_
   Carver cv(ws);
   const TileCfg cfg = weight_cfg(m);
   const bool split3 = weight_split(m);
-  const int nsplit = split3 ? weight_splits(m, k, n, 64, 160) : weight_splits(m, k, n, kCfg[cfg].bm, kCfg[cfg].bn);
+  const bool big3 = split3 && m >= kWeightBigRows;
+  const int nsplit = split3 ? weight_splits(m, k, n, big3 ? 320 : 64, 160) : weight_splits(m, k, n, kCfg[cfg].bm, kCfg[cfg].bn);
   float* partial = cv.take<float>((size_t)nsplit * (n * k + n));
   GemmArgs p{};
   p.nxcd = num_xcd();
@@ -814,7 +817,10 @@ int pgnn_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_
   p.split_stride = direct ? 0 : n * k + n;
   p.colsum = direct ? db : partial + n * k;
   int rc;
-  if (split3)
+  if (split3 && big3)
+    rc = db ? launch_gemm3_s<320, 160, 4, 2, false, false, EPI_PLAIN, true>(p, used, st)
+            : launch_gemm3_s<320, 160, 4, 2, false, false, EPI_PLAIN, false>(p, used, st);
+  else if (split3)
     rc = db ? launch_gemm3_s<64, 160, 4, 2, false, false, EPI_PLAIN, true>(p, used, st)
             : launch_gemm3_s<64, 160, 4, 2, false, false, EPI_PLAIN, false>(p, used, st);
   else
