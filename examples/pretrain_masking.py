@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pretrain_gnns_amd import parallel, train  # noqa: E402
+from pretrain_gnns_amd import optim, parallel, train  # noqa: E402
 from pretrain_gnns_amd.chem.model import GNN  # noqa: E402
 from pretrain_gnns_amd.data import resident, synthetic  # noqa: E402
 
@@ -54,7 +54,8 @@ def main():
     linear_pred_bonds = torch.nn.Linear(args.emb_dim, 4).to(device)
     model_list = [model, linear_pred_atoms, linear_pred_bonds]
     parallel.broadcast_parameters(model_list)
-    optimizer_list = [torch.optim.Adam(m.parameters(), lr=args.lr, fused=True) for m in model_list]
+    # the reference's three optim.Adam (chem/pretrain_masking.py:134-136): same update, one launch for all of them
+    optimizer_list = optim.Adam.shared([m.parameters() for m in model_list], lr=args.lr)
     if world > 1:
         optimizer_list = list(parallel.AllReduceOptimizers(optimizer_list))
 
