@@ -869,9 +869,12 @@ class MaskedHead(Function):
                                           b.data_ptr() if b is not None else None, label.data_ptr(), label.stride(0), classes, dim,
                                           logits.data_ptr(), loss.data_ptr(), correct.data_ptr(), metrics.data_ptr(), words.data_ptr(),
                                           words.data_ptr() + 4, ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_masked_head_fwd")
-        if _CHECK_INDICES and int(words[0].item()):
-            words[0] = 0
-            raise IndexError("masked head: row index or label out of range")
+        if _CHECK_INDICES:
+            if int(words[0].item()):
+                words[0] = 0
+                raise IndexError("masked head: row index or label out of range")
+            if torch.unique(idx).numel() != m:  # the backward writes d node_rep rows, it does not accumulate them
+                raise ValueError("masked head: repeated row index (MaskAtom samples without replacement)")
         ctx.save_for_backward(h, idx, w, label, logits)
         ctx.ws, ctx.has_bias = ws, bias is not None
         ctx.mark_non_differentiable(correct, logits, metrics)

@@ -250,3 +250,42 @@ def test_direct_gradient_deposit_semantics_on_cpu():
         assert ops._use_direct([torch.nn.Parameter(torch.zeros(2))]) and not ops._use_direct([hooked])
     finally:
         ops.set_direct_grads(prev)
+
+
+def test_adam_refuses_cpu_parameters_and_empty_lists():
+    """pretrain_gnns_amd.optim.Adam is a GPU optimizer: CPU tensors and empty parameter lists are refused up front (no
+    silent fallback to torch's implementation)"""
+    from pretrain_gnns_amd import _lib, optim
+    with pytest.raises(_lib.PgnnError):
+        optim.Adam([torch.nn.Parameter(torch.zeros(3))])
+    with pytest.raises(ValueError):
+        optim.Adam([])
+
+
+def test_shared_adam_handles_issue_one_launch_per_round(monkeypatch):
+    """Adam.shared: the handles of a round (the reference steps its three optimizers back to back) trigger exactly one
+    launch, from the last step() call; zero_grad() touches only a handle's own parameters"""
+    from pretrain_gnns_amd import optim
+
+    class FakeCore:
+        def __init__(self):
+            self.handles, self.waiting, self.launches = 0, 0, 0
+            self.step_count = 0
+
+        def launch(self):
+            self.launches += 1
+
+    core = FakeCore()
+    params = [[torch.nn.Parameter(torch.zeros(2))], [torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(1))], []]
+    handles = [optim.Adam(ps, _core=core) for ps in params]
+    assert core.handles == 3
+    for rnd in range(3):
+        for i, h in enumerate(handles):
+            h.step()
+            assert core.launches == rnd + (1 if i == 2 else 0)
+    params[0][0].grad = torch.ones(2)
+    params[1][0].grad = torch.ones(3)
+    handles[1].zero_grad()
+    assert params[1][0].grad is None and params[0][0].grad is not None
+    handles[0].zero_grad(set_to_none=False)
+    assert params[0][0].grad is not None and float(params[0][0].grad.abs().sum()) == 0.0
