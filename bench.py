@@ -16,7 +16,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      : the aggregation kernel (pgnn_chem_aggregate_fwd) on a roofline-sized batch
                   (>= 16384 graphs, working set > the 256 MB Infinity Cache), algorithmic bytes =
                   2400 N + 6 E + 4 (N+1) per launch (SURVEY.md §8d) / HIP-event time per launch, vs 8 TB/s;
-  roofline_mlp  : the fp32 MFMA GEMM that dominates the step time, vs 157.3 TFLOP/s;
+  roofline_mlp  : the forward GEMM of the mlp (split-bf16 kernel) vs its own ceiling (2500 / 6 TFLOP/s) and vs the fp32 MFMA
+                  peak 157.3 TFLOP/s, with the fp32-MFMA kernel on the same shape next to it;
   cpu_baseline  : the CPU oracle's identical train step on the host cores (rank 0, N=1 only).
 """
 import argparse
@@ -266,7 +267,7 @@ def resident_loader_leg(dev, args, steps_n):
 
 def roofline_mlp(dev, rows):
     """time the forward GEMM of the GIN mlp (first Linear 300->600 + bias + ReLU) alone: the split-bf16 kernel the
-    product path runs, and the fp32-MFMA kernel (PGNN_GEMM_SPLIT=0) the backward products still use."""
+    product path runs, and the fp32-MFMA kernel (PGNN_GEMM_SPLIT=0) that keeps the smallest shapes."""
     import os
     from pretrain_gnns_amd import ops
 
@@ -298,7 +299,7 @@ def roofline_mlp(dev, rows):
     tf32 = flops / (ms32 * 1e-3) / 1e12
     split_peak = MFMA_BF16_PEAK_TF / 6.0
     return {"bound": "mfma",
-            "kernel": "k_gemm3<128,160,4,2,EPI_BIAS> (pgnn_linear_fwd 300->600: fp32 values as three bf16 terms, six "
+            "kernel": "k_gemm3<128,160,4,2,true,true,EPI_BIAS,false> (pgnn_linear_fwd 300->600: fp32 values as three bf16 terms, six "
                       "v_mfma_f32_16x16x32_bf16 products per k-step, fp32 accumulate; error vs float64 not above the fp32-MFMA "
                       "kernel's, tests/test_gpu_ops.py)",
             "achieved": round(tf, 2), "peak": round(split_peak, 1), "unit": "TFLOP/s (fp32-equivalent)",
@@ -307,8 +308,8 @@ def roofline_mlp(dev, rows):
                          "this kernel reaches %.3f" % (MFMA_F32_PEAK_TF, tf / MFMA_F32_PEAK_TF),
             "ms_per_launch": round(ms, 4), "ms_per_launch_std": round(float(per.std()), 4), "launches_timed": iters,
             "rows": rows,
-            "fp32_mfma_kernel": {"kernel": "k_gemm<64,160,4,2,true,true,EPI_BIAS> (v_mfma_f32_16x16x4_f32; PGNN_GEMM_SPLIT=0; the "
-                                           "backward-data / backward-weight products run this template)",
+            "fp32_mfma_kernel": {"kernel": "k_gemm<64,160,4,2,true,true,EPI_BIAS> (v_mfma_f32_16x16x4_f32; PGNN_GEMM_SPLIT=0; products "
+                                           "below ~160 tiles still run this template)",
                                  "achieved": round(tf32, 2), "peak": MFMA_F32_PEAK_TF, "frac": round(tf32 / MFMA_F32_PEAK_TF, 4),
                                  "ms_per_launch": round(ms32, 4), "ms_per_launch_std": round(float(per32.std()), 4)}}
 
