@@ -449,7 +449,7 @@ def bio_leg(dev, args, steps_n, with_cpu):
     ms, per, iters = steady_state_ms(launch, iters=30)
     alg = 3604.0 * n + 40.0 * e
     gbs = alg / (ms * 1e-3) / 1e9
-    out["roofline"] = {"bound": "hbm", "kernel": "bio GINConv aggregate = pgnn_neighbor_sum + pgnn_rowfeat_matmul_fwd", "achieved": round(gbs, 1),
+    out["roofline"] = {"bound": "hbm", "kernel": "bio GINConv aggregate = k_neighbor_sum_tile (graph-resident: neighbour sum + edge-feature product in one launch, csrc/tile.hip)", "achieved": round(gbs, 1),
                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                        "ms_per_launch": round(ms, 4), "ms_per_launch_std": round(float(per.std()), 4),
                        "algorithmic_bytes_per_launch": int(alg), "nodes": n, "edges": e,

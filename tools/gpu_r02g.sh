@@ -4,10 +4,10 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r02g
 mkdir -p $O
 cd $R
-for c in -1 2; do
-PGNN_GEMM3_CFG=$c timeout 300 python tools/gemm_split_check.py 65536 262144 2>$O/err.txt | python -c "
+timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest.log 2>&1
+timeout 900 python bench.py --no-cpu-baseline --sweep-graphs "" --no-hipgraph --no-loader > $O/bench.json 2>$O/bench.err
+grep -E "passed|failed|^FAILED|^ERROR" $O/pytest.log | tail; cat $O/bench.json | python -c "
 import json,sys
-for l in sys.stdin:
-    r=json.loads(l)
-    print('cfg $c',r['M'],r['K'],r['N'],' | '.join('%s %s: %s'%(m,k,r[m][k]['us']) for m in ('fp32_mfma', 'split') for k in ('fwd','bwd_data')))"
-done
+r=json.loads(sys.stdin.read())
+print('step',r['ms_per_step'])
+print('ctx',r['contextpred']['ms_per_step'],'bio',r['bio_masking']['ms_per_step'], r['bio_masking']['edges_per_s'], r['bio_masking']['roofline'])"
