@@ -1,4 +1,4 @@
-"""where the host time of an eager 256-graph masking train step goes (cProfile over `steps` steps, GPU kept busy)
+"""cProfile view of the host side of an eager 256-graph masking train step (Python / ctypes / torch time per call; the torch.profiler view is tools/host_prof.py)
 usage: python tools/host_profile.py [steps=200]"""
 import cProfile, os, pstats, sys, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
