@@ -10,7 +10,10 @@ One "step" = the loop body of the reference train() (chem/pretrain_masking.py:47
 3 x Adam, on ONE synthetic ZINC-2M-shaped BatchMasking batch of 256 graphs per GPU (BASELINE.json
 configs[1]; weak scaling: every rank has its own 256 graphs, one flat-bucket gradient all-reduce per
 step).  Inputs are resident in HBM before the timed region.  edges = edge_index.size(1) (directed,
-self loops excluded), counted once per step.
+self loops excluded), counted once per step.  The step's loss / accuracy are summed on the device (the
+float64 additions train() does on the host) and fetched once after the K steps, inside the timed region
+(--readback epoch, what train.chem_masking_epoch does); `per_step_readback` times the same steps with a
+fetch after every optimizer step, `reference_loop` with the reference's own two syncs per step.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      : the aggregation kernel (pgnn_chem_aggregate_fwd) on a roofline-sized batch
@@ -59,8 +62,9 @@ def parse():
                     help="extra per-GPU batch sizes reported under `large_batch` (same step, same code); '' disables")
     ap.add_argument("--adam", default="pgnn", choices=["pgnn", "fused", "foreach"],
                     help="pgnn = one launch for the three optimizers (default); fused / foreach = torch.optim.Adam variants")
-    ap.add_argument("--readback", default="end", choices=["end", "inline"],
-                    help="where loss/accuracy are read back to the host (inline = the reference's two syncs per step)")
+    ap.add_argument("--readback", default="epoch", choices=["epoch", "end", "inline"],
+                    help="where loss/accuracy reach the host: epoch = summed on the device, one fetch after the timed steps (default); "
+                         "end = one fetch per step; inline = the reference's two syncs per step")
     return ap.parse_args()
 
 
@@ -90,6 +94,10 @@ def make_optimizers(mods, kind="pgnn", capturable=False):
     return [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0, **kw) for m in mods]
 
 
+READBACK_NOTE = {"epoch": "epoch: loss / accuracy sums accumulated on the device by the step itself, ONE fetch after the K timed steps "
+                          "(inside the timed region) -- what train.chem_masking_epoch does; per_step_readback has the same steps "
+                          "fetching after every step",
+                 "end": "end: one fetch after every optimizer step", "inline": "inline: the reference's two syncs per step"}
 ADAM_NOTE = {"pgnn": "pretrain_gnns_amd.optim.Adam.shared: the three optimizers' update in one launch",
              "fused": "torch.optim.Adam(fused=True)", "foreach": "torch.optim.Adam (foreach)"}
 
@@ -219,6 +227,32 @@ def forward_only(dev, mods, batch, iters):
     return {"edges_per_s": round(batch.edge_index.size(1) / (ms * 1e-3), 1), "ms_per_pass": round(ms, 4)}
 
 
+def masking_stepper(mods, opts, readback, dev, mask_edge=False):
+    """(step(batch), finish()) for a run of chem masking train steps under one read-back mode.  "epoch": the three epoch
+    sums stay on the device (train.epoch_accumulator) and finish() fetches them -- inside the timed region -- as
+    train.chem_masking_epoch does; "end" / "inline" fetch every step.  finish() returns the mean loss of the steps run."""
+    from pretrain_gnns_amd import train as steps
+
+    state = {"accum": steps.epoch_accumulator(dev) if readback == "epoch" else None, "loss": 0.0, "n": 0}
+
+    def step(batch):
+        out = steps.chem_masking_step(mods, opts, batch, mask_edge=mask_edge, readback=readback, accum=state["accum"])
+        if out is not None:
+            state["loss"] += out[0]
+            state["n"] += 1
+
+    def finish():
+        if state["accum"] is not None:
+            vals = state["accum"].cpu().tolist()
+            state["accum"].zero_()
+            return vals[0] / max(vals[3], 1.0)
+        mean = state["loss"] / max(state["n"], 1)
+        state["loss"], state["n"] = 0.0, 0
+        return mean
+
+    return step, finish
+
+
 def resident_loader_leg(dev, args, steps_n):
     """every step draws a NEW 256-graph batch from a dataset resident in HBM
     (device-side collate + MaskAtom, csrc/loader.hip) and trains on it -- the end-to-end rate with the
@@ -235,16 +269,19 @@ def resident_loader_leg(dev, args, steps_n):
     mods = make_models(dev)
     opts = make_optimizers(mods)
     edges, done, t0 = 0, 0, None
+    step, finish = masking_stepper(mods, opts, args.readback, dev)
     while done < steps_n + 5:
         for batch in loader:
             if done == 5:  # warm-up done
+                finish()
                 torch.cuda.synchronize()
                 t0, edges = time.perf_counter(), 0
-            steps.chem_masking_step(mods, opts, batch)
+            step(batch)
             edges += batch.edge_index.size(1)
             done += 1
             if done >= steps_n + 5:
                 break
+    finish()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ids = loader.batch_ids(0)[:8]
@@ -419,22 +456,28 @@ def bio_leg(dev, args, steps_n, with_cpu):
         m.train()
     edges = done = 0
     t0 = None
+    readback = "epoch" if args.readback == "epoch" else "end"
+    accum = steps.epoch_accumulator(dev) if readback == "epoch" else None
     while done < steps_n + 3:
         for batch in loader:
             if done == 3:
                 torch.cuda.synchronize()
                 t0, edges = time.perf_counter(), 0
-            loss, acc = steps.bio_masking_step(mods, opts, batch)
+            out = steps.bio_masking_step(mods, opts, batch, readback=readback, accum=accum)
+            if out is not None:
+                loss = out[0]
             edges += batch.edge_index.size(1)
             done += 1
             if done >= steps_n + 3:
                 break
+    if accum is not None:
+        loss = accum.cpu().tolist()[0] / max(done, 1)  # the epoch's one fetch, inside the timed region (mean over all steps run)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out = {"workload": "bio/pretrain_masking.py train step, 5-layer bio GIN emb_dim=300, batch_size %d PPI-ego-shaped graphs per GPU, "
                        "device-side collate + MaskEdge in the loop (BASELINE configs[4] shape)" % args.graphs_per_gpu,
            "ms_per_step": round(dt / steps_n * 1e3, 4), "edges_per_s": round(edges / dt, 1),
-           "edges_per_step": int(edges / steps_n), "last_loss": round(float(loss), 5)}
+           "edges_per_step": int(edges / steps_n), "mean_loss" if accum is not None else "last_loss": round(float(loss), 5)}
     # aggregation alone at a cache-exceeding batch: x [N,300] -> [N,600] = [sum_j x_j + x_i | sum_e enc(e) + enc(loop)]
     big = ds.collate(np.arange(4096) % len(graphs))
     n, e = big.x.size(0), big.edge_index.size(1)
@@ -518,12 +561,15 @@ def large_batch_sweep(dev, sizes, args):
         batch = (synthetic.tile_batch(base, g // 2048) if g >= 2048 else synthetic.chem_masking_batch(g, seed=7)).to(dev)
         mods = make_models(dev)
         opts = make_optimizers(mods, args.adam)
+        step, finish = masking_stepper(mods, opts, args.readback, dev)
         for _ in range(2):
-            steps.chem_masking_step(mods, opts, batch, readback=args.readback)
+            step(batch)
+        finish()
         torch.cuda.synchronize()
         t0, n = time.perf_counter(), 5
         for _ in range(n):
-            steps.chem_masking_step(mods, opts, batch, readback=args.readback)
+            step(batch)
+        finish()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         e = batch.edge_index.size(1)
@@ -599,11 +645,10 @@ def main():
     batch = synthetic.chem_masking_batch(args.graphs_per_gpu, seed=rank).to(dev)
     edges_local = batch.edge_index.size(1)
 
-    def step():
-        return steps.chem_masking_step(mods, list(opts), batch, mask_edge=False, readback=args.readback)
-
+    step, finish = masking_stepper(mods, list(opts), args.readback, dev)
     for _ in range(args.warmup):
-        step()
+        step(batch)
+    finish()
 
     def sync():
         torch.cuda.synchronize()
@@ -617,9 +662,24 @@ def main():
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()[0]
+        step(batch)
+    loss = finish()  # (readback="epoch": the one device->host fetch of the K steps, inside the timed region)
     sync()
     elapsed = time.perf_counter() - t0
+    per_step_readback = None
+    if world == 1 and args.readback == "epoch":  # the same K steps fetching (loss, correct) after every step, for comparison
+        step2, finish2 = masking_stepper(mods, list(opts), "end", dev)
+        for _ in range(5):
+            step2(batch)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step2(batch)
+        finish2()
+        sync()
+        dt2 = time.perf_counter() - t1
+        per_step_readback = {"ms_per_step": round(1e3 * dt2 / args.steps, 4), "edges_per_s": round(edges_local * args.steps / dt2, 1),
+                             "note": "readback='end': one device->host fetch after every optimizer step (round-1/early round-2 headline mode)"}
     gc.enable()
 
     comm = parallel.comm_report(opts) if dist.is_initialized() else {"initialized": False, "world": 1}
@@ -641,11 +701,13 @@ def main():
                                    % args.graphs_per_gpu,
                        "graphs_per_gpu": args.graphs_per_gpu, "global_batch": args.graphs_per_gpu * world,
                        "nodes_per_gpu": int(batch.x.size(0)), "edges_per_gpu": int(edges_local),
-                       "parallelism": "dp%d" % world, "last_loss": round(float(loss), 5),
-                       "adam": ADAM_NOTE[args.adam], "metrics_readback": args.readback,
+                       "parallelism": "dp%d" % world, "mean_loss": round(float(loss), 5),
+                       "adam": ADAM_NOTE[args.adam], "metrics_readback": READBACK_NOTE[args.readback],
                        "direct_grads": True},
             "comm": comm,
         }
+        if per_step_readback is not None:
+            res["per_step_readback"] = per_step_readback
         if world == 1:
             res["reference_loop"] = reference_loop_leg(dev, args, batch, max(args.steps // 2, 20))
             res["forward_only"] = forward_only(dev, mods, batch, max(args.steps, 20))

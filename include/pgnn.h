@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PGNN_ABI_VERSION 3
+#define PGNN_ABI_VERSION 4
 
 #define PGNN_OK 0
 #define PGNN_ERR_ARG 1
@@ -241,8 +241,9 @@ int pgnn_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_
 /* ------------------------------------------------------------------------------------------
  * torch.optim.Adam's update (chem/pretrain_masking.py:134-136 builds three of them with the same hyper-parameters) over
  * n <= pgnn_adam_max_tensors() fp32 tensors in one launch: params[j] / grads[j] device pointers (host arrays), counts[j]
- * elements, state_offsets[j] = where tensor j's moments live in the flat exp_avg / exp_avg_sq buffers.  *step (device
- * int64, number of updates already applied) is advanced by the call, so the call can be captured in a HIP graph.
+ * elements, state_offsets[j] = where tensor j's moments live in the flat exp_avg / exp_avg_sq buffers.  step = device
+ * int64[2]: step[0], the number of updates already applied, is advanced by the call (so the call can be captured in a HIP
+ * graph); step[1] is the kernel's arrival counter, zero on entry and left zero.
  * L2 weight decay is added to the gradient (Adam, not AdamW); amsgrad is not offered.
  * ------------------------------------------------------------------------------------------ */
 int pgnn_adam_max_tensors(void);
@@ -256,7 +257,10 @@ int pgnn_adam_step(float* const* params, const float* const* grads, const int64_
  * h [n_rows, ldh] node representations, idx [m] int64 rows to predict (must not repeat: MaskAtom samples without
  * replacement), w [classes, dim], b [classes] or NULL, label[r * label_stride] int64 in [0, classes), classes <= 128.
  * Outputs: logits [m, classes] fp32 (kept for the backward), *loss float64 (mean over rows), *correct int64, optionally
- * metrics[2] = {loss, (double)correct} for a single read-back; status += bad indices / labels.  counter: one uint32 that is
+ * metrics[2] = {loss, (double)correct} for a single read-back, and optionally accum[4] float64 = the running epoch sums the
+ * reference's train() keeps on the host (chem/pretrain_masking.py:72-76): accum[0] += loss, accum[1] += correct / m,
+ * accum[3] += 1 (accum[2], the bond-accuracy sum, is the caller's), so that a train loop reads back once per epoch;
+ * status += bad indices / labels.  counter: one uint32 that is
  * zero on entry and is left zero (the arrival counter of the in-kernel final fold; a persistent per-device word).  fp32 linear algebra, float64 soft-max and loss, as in the reference; fixed summation order.
  * Backward (gloss = d objective / d loss, float64 on the device): dnode [n_rows, ldd] is overwritten (zero outside idx),
  * dw [classes, dim], db [classes] or NULL.  Both calls use the same workspace.
@@ -264,8 +268,8 @@ int pgnn_adam_step(float* const* params, const float* const* grads, const int64_
 size_t pgnn_masked_head_workspace_bytes(int64_t m, int64_t classes, int64_t dim);
 int pgnn_masked_head_fwd(const float* h, int64_t ldh, int64_t n_rows, const int64_t* idx, int64_t m, const float* w, const float* b,
                          const int64_t* label, int64_t label_stride, int64_t classes, int64_t dim, float* logits, double* loss,
-                         int64_t* correct, double* metrics, int32_t* status, uint32_t* counter, void* ws, size_t ws_bytes,
-                         pgnn_stream stream);
+                         int64_t* correct, double* metrics, double* accum, int32_t* status, uint32_t* counter, void* ws,
+                         size_t ws_bytes, pgnn_stream stream);
 int pgnn_masked_head_bwd(const float* h, int64_t ldh, int64_t n_rows, const int64_t* idx, int64_t m, const float* w,
                          const int64_t* label, int64_t label_stride, const float* logits, const double* gloss, int64_t classes,
                          int64_t dim, float* dnode, int64_t ldd, float* dw, float* db, void* ws, size_t ws_bytes, pgnn_stream stream);

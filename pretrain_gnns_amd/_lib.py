@@ -58,7 +58,7 @@ PROTOTYPES = {
     "pgnn_adam_max_tensors": (_i, []),
     "pgnn_adam_step": (_i, [_p, _p, _p, _p, _i64, _p, _p, _p, _f, _f, _f, _f, _f, _p]),
     "pgnn_masked_head_workspace_bytes": (_sz, [_i64, _i64, _i64]),
-    "pgnn_masked_head_fwd": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "pgnn_masked_head_fwd": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "pgnn_masked_head_bwd": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _i64, _p, _p, _i64, _i64, _p, _i64, _p, _p, _p, _sz, _p]),
     "pgnn_linear_bwd_data_t": (_i, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p]),
     "pgnn_transpose_batch": (_i, [_p, _p, _p, _p, _i64, _p]),
@@ -104,7 +104,7 @@ PROTOTYPES = {
     "pgnn_debug_aggregate_profile": (_i, [_p, _i64]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class GinLayer(ctypes.Structure):
@@ -160,3 +160,22 @@ def require_cuda(*tensors):
             raise PgnnError(
                 "pretrain_gnns_amd runs the message-passing path on an MI355X only; got a %s tensor. "
                 "Move the model and the batch to the GPU (there is no CPU fallback)." % t.device)
+
+
+_status_pools = {}
+_STATUS_POOL_WORDS = 1024
+
+
+def status_word(dev):
+    """one zeroed int32 on ``dev`` for a call's ``status`` argument.  Handed out from a pre-zeroed pool (a fresh
+    ``torch.zeros(1)`` per call is a fill launch each: a dozen per train step); every word is used by one call only, so a
+    batch's ``GraphStruct.check()`` still reports that batch's own count."""
+    if torch.cuda.is_current_stream_capturing():  # a captured launch keeps its word for every replay: give it its own
+        return torch.zeros(1, dtype=torch.int32, device=dev)
+    key = (dev.type, dev.index)
+    pool = _status_pools.get(key)
+    if pool is None or pool[1] >= _STATUS_POOL_WORDS:  # (views keep an exhausted pool alive for as long as they are held)
+        pool = _status_pools[key] = [torch.zeros(_STATUS_POOL_WORDS, dtype=torch.int32, device=dev), 0]
+    i = pool[1]
+    pool[1] = i + 1
+    return pool[0][i:i + 1]

@@ -854,7 +854,7 @@ k_embed_fwd(const int64_t* __restrict__ idx, int64_t stride, const float* __rest
 // ---------------------------------------------------------------------------------------------
 // two-level deterministic segment sum over a grouped item list (see pgnn.h)
 // ---------------------------------------------------------------------------------------------
-constexpr int kSegChunk = 32;
+constexpr int kSegChunk = 8;   // items per wave of the first pass: the pass is latency-bound (one wave walks its rows serially), so small chunks = more waves
 
 template <int R>
 __global__ void __launch_bounds__(kBlock)

@@ -268,6 +268,7 @@ k_part_hist(const int64_t* __restrict__ key, const int64_t* __restrict__ key2, i
   }
   __syncthreads();
   for (int k = threadIdx.x; k < n_keys; k += kPartTile) offs[(size_t)k * n_tiles + blockIdx.x + 1] = lh[k];
+  if (blockIdx.x == 0 && threadIdx.x == 0) offs[0] = 0;  // the reserved element (was a 4-byte memset launch of its own)
 }
 
 __global__ void __launch_bounds__(kPartTile)
@@ -325,7 +326,6 @@ int run_partition(const int64_t* key, int64_t stride, int64_t n_items, int64_t n
   Carver cv(ws);
   int32_t* offs = cv.take<int32_t>((size_t)len);
   int32_t* bsum = cv.take<int32_t>((size_t)ceil_div(len, kScanItems));
-  PGNN_HIP(hipMemsetAsync(offs, 0, 4, st));  // element 0; the rest is fully written by k_part_hist
   hipLaunchKernelGGL(k_part_hist, dim3(n_tiles), dim3(kPartTile), (size_t)n_keys * 4, st, key, key2, n2, stride, n_items,
                      (int)n_keys, n_tiles, offs, status);
   GroupJobs jobs;
@@ -444,6 +444,17 @@ k_bio_payload(const int64_t* __restrict__ ei, const float* __restrict__ ea, int6
   }
 }
 
+// the three zero-initialised arrays of a graph build in ONE launch (three hipMemsetAsync calls are three fill kernels)
+struct ZeroJobs {
+  int32_t* p[3];
+  int64_t n[3];
+};
+__global__ void __launch_bounds__(256) k_zero_words(ZeroJobs z) {
+  int32_t* __restrict__ p = z.p[blockIdx.y];
+  const int64_t n = z.n[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0;
+}
+
 struct GraphWs {
   GroupJobs jobs;
   int32_t *perm_in, *perm_out;
@@ -464,9 +475,11 @@ int prepare_graph_jobs(const int64_t* ei, int64_t E, int64_t N, int32_t* in_ptr,
   const size_t nb = (size_t)ceil_div(N + 1, kScanItems);
   int32_t* bs_in = cv.take<int32_t>(nb);
   int32_t* bs_out = cv.take<int32_t>(nb);
-  PGNN_HIP(hipMemsetAsync(cursors, 0, 2 * (size_t)N * 4, st));
-  PGNN_HIP(hipMemsetAsync(in_ptr, 0, (size_t)(N + 1) * 4, st));
-  PGNN_HIP(hipMemsetAsync(out_ptr, 0, (size_t)(N + 1) * 4, st));
+  ZeroJobs z;
+  z.p[0] = cursors, z.n[0] = 2 * N;
+  z.p[1] = in_ptr, z.n[1] = N + 1;
+  z.p[2] = out_ptr, z.n[2] = N + 1;
+  hipLaunchKernelGGL(k_zero_words, dim3((int)std::min<int64_t>(ceil_div(2 * N, 1024), 1024), 3), dim3(256), 0, st, z);
   g.jobs.j[0] = GroupJob{ei, 1, in_ptr, g.perm_in, cursors, tmp_in, bs_in};           // by destination
   g.jobs.j[1] = GroupJob{ei + E, 1, out_ptr, g.perm_out, cursors + N, tmp_out, bs_out};  // by source
   return PGNN_OK;

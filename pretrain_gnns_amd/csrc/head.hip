@@ -18,23 +18,27 @@ constexpr int kHeadMaxDim = 2048;
 constexpr int kHeadRows = 4;        // selected rows per block: a weight value is loaded once and used for 4 rows (8 rows: half
                                     // the blocks, one per two CUs at 1007 rows -- slower)
 constexpr int kHeadClassGroup = 8;  // classes per block of the weight-gradient kernel
+constexpr int kHeadSlices = 4;      // threads per (class, row block) in the forward kernel: each walks a quarter of k (a thread's chain
+                                    // of 300 dependent FMAs per row was the kernel's critical path), partials folded in slice order
 
 // rows [4 blk, 4 blk + 4): logits[r, :] = h[idx[r], :] . W^T + b, then each row's float64 log-soft-max terms.
 // The LAST block to finish (device counter, self-resetting) folds the rows in order: loss = mean_r nll_r, correct = sum_r.
-__global__ void __launch_bounds__(kHeadThreads) k_head_fwd(const float* __restrict__ h, int64_t ldh, const int64_t* __restrict__ idx,
+__global__ void __launch_bounds__(kHeadThreads * kHeadSlices) k_head_fwd(const float* __restrict__ h, int64_t ldh, const int64_t* __restrict__ idx,
                                                            int m, const float* __restrict__ w, const float* __restrict__ b,
                                                            const int64_t* __restrict__ label, int64_t label_stride, int classes, int dim,
                                                            int64_t n_rows, float* __restrict__ logits, double* __restrict__ row_nll,
                                                            int* __restrict__ row_hit, double* __restrict__ loss,
                                                            int64_t* __restrict__ correct, double* __restrict__ metrics,
-                                                           unsigned* __restrict__ counter, int* __restrict__ status) {
+                                                           double* __restrict__ accum, unsigned* __restrict__ counter,
+                                                           int* __restrict__ status) {
   extern __shared__ __align__(16) float hrows[];  // [kHeadRows][dim]
   __shared__ double red[kHeadThreads];
   __shared__ int redi[kHeadThreads];
+  __shared__ float part[kHeadSlices][kHeadRows][kHeadThreads];
   __shared__ bool last;
-  const int r0 = blockIdx.x * kHeadRows, c = threadIdx.x;
+  const int r0 = blockIdx.x * kHeadRows, tid = threadIdx.x, c = tid & (kHeadThreads - 1), sl = tid / kHeadThreads;
   const int nr = min(kHeadRows, m - r0);
-  for (int q = c; q < kHeadRows * dim; q += kHeadThreads) {
+  for (int q = tid; q < kHeadRows * dim; q += kHeadThreads * kHeadSlices) {
     const int i = q / dim, k = q - i * dim;
     float v = 0.f;
     if (i < nr) {
@@ -47,34 +51,42 @@ __global__ void __launch_bounds__(kHeadThreads) k_head_fwd(const float* __restri
   __syncthreads();
   // (staging W through LDS in [classes][32 k] tiles to coalesce its loads measured SLOWER, 71 vs 49 us at 1007 rows: the
   // scalar LDS reads cost more than the strided global float4 loads, which hit L1 after the first touch of a line)
-  float z[kHeadRows];
-#pragma unroll
-  for (int i = 0; i < kHeadRows; ++i) z[i] = -INFINITY;
-  if (c < classes) {
-    const float4* wr = reinterpret_cast<const float4*>(w + (int64_t)c * dim);
+  {
     float acc[kHeadRows];
 #pragma unroll
     for (int i = 0; i < kHeadRows; ++i) acc[i] = 0.f;
+    if (c < classes) {
+      const float4* wr = reinterpret_cast<const float4*>(w + (int64_t)c * dim);
 #pragma unroll 2
-    for (int k4 = 0; k4 < dim / 4; ++k4) {
-      const float4 wv = wr[k4];
+      for (int k4 = sl; k4 < dim / 4; k4 += kHeadSlices) {  // slice sl takes every fourth float4 of its class row
+        const float4 wv = wr[k4];
 #pragma unroll
-      for (int i = 0; i < kHeadRows; ++i) {
-        const float4 hv = *reinterpret_cast<const float4*>(hrows + i * dim + 4 * k4);
-        acc[i] = fmaf(hv.x, wv.x, acc[i]);
-        acc[i] = fmaf(hv.y, wv.y, acc[i]);
-        acc[i] = fmaf(hv.z, wv.z, acc[i]);
-        acc[i] = fmaf(hv.w, wv.w, acc[i]);
+        for (int i = 0; i < kHeadRows; ++i) {
+          const float4 hv = *reinterpret_cast<const float4*>(hrows + i * dim + 4 * k4);
+          acc[i] = fmaf(hv.x, wv.x, acc[i]);
+          acc[i] = fmaf(hv.y, wv.y, acc[i]);
+          acc[i] = fmaf(hv.z, wv.z, acc[i]);
+          acc[i] = fmaf(hv.w, wv.w, acc[i]);
+        }
       }
     }
+#pragma unroll
+    for (int i = 0; i < kHeadRows; ++i) part[sl][i][c] = acc[i];
+  }
+  __syncthreads();
+  float z[kHeadRows];
+#pragma unroll
+  for (int i = 0; i < kHeadRows; ++i) z[i] = -INFINITY;
+  if (sl == 0 && c < classes) {
     const float bias = b ? b[c] : 0.f;
 #pragma unroll
     for (int i = 0; i < kHeadRows; ++i)
       if (i < nr) {
-        z[i] = acc[i] + bias;
+        z[i] = ((part[0][i][c] + part[1][i][c]) + (part[2][i][c] + part[3][i][c])) + bias;
         logits[(int64_t)(r0 + i) * classes + c] = z[i];
       }
   }
+  if (sl != 0) return;  // the soft-max below is the first 128 threads' (whole waves: the barriers that follow count them only)
   for (int i = 0; i < nr; ++i) {
     // row maximum and its FIRST index (torch.max's tie rule), then the sum of exp in float64
     red[c] = (double)z[i];
@@ -139,48 +151,55 @@ __global__ void __launch_bounds__(kHeadThreads) k_head_fwd(const float* __restri
       metrics[0] = red[0] / (double)m;
       metrics[1] = (double)redi[0];
     }
+    if (accum) {  // the epoch sums the reference keeps on the host (loss_accum += loss; acc_node_accum += correct / n), left on
+                  // the device so the train loop needs no per-step read-back: same float64 operations in the same order
+      accum[0] += red[0] / (double)m;
+      accum[1] += (double)redi[0] / (double)m;
+      accum[3] += 1.0;
+    }
     *counter = 0;
   }
 }
 
 // rows [4 blk, 4 blk + 4): dl[r, c] = float((softmax64(logits[r])[c] - [c == y]) * gloss / m), then the rows of
 // d node_rep: dnode[idx[r], :] = sum_c dl[r, c] W[c, :]   (dnode is zero elsewhere; idx must not repeat)
-__global__ void __launch_bounds__(kHeadThreads) k_head_bwd_rows(const float* __restrict__ logits, const int64_t* __restrict__ idx, int m,
+__global__ void __launch_bounds__(kHeadThreads * kHeadSlices) k_head_bwd_rows(const float* __restrict__ logits, const int64_t* __restrict__ idx, int m,
                                                                 const float* __restrict__ w, const int64_t* __restrict__ label,
                                                                 int64_t label_stride, const double* __restrict__ gloss, int classes, int dim,
                                                                 int64_t n_rows, float* __restrict__ dl, float* __restrict__ dnode, int64_t ldd) {
   __shared__ double red[kHeadThreads];
   __shared__ float dls[kHeadRows][kHeadThreads];
-  const int r0 = blockIdx.x * kHeadRows, c = threadIdx.x;
+  const int r0 = blockIdx.x * kHeadRows, tid = threadIdx.x, c = tid;  // the soft-max is the first 128 threads' work
+  const bool cls = tid < kHeadThreads;
   const int nr = min(kHeadRows, m - r0);
   const double g = *gloss / (double)m;
   for (int i = 0; i < kHeadRows; ++i) {
     float d = 0.f;
-    if (i < nr) {
-      const double z = c < classes ? (double)logits[(int64_t)(r0 + i) * classes + c] : -INFINITY;
-      red[c] = z;
+    if (i < nr) {  // (uniform: every thread takes the barriers)
+      const double z = (cls && c < classes) ? (double)logits[(int64_t)(r0 + i) * classes + c] : -INFINITY;
+      if (cls) red[c] = z;
       __syncthreads();
       for (int s = kHeadThreads / 2; s > 0; s >>= 1) {
-        if (c < s) red[c] = fmax(red[c], red[c + s]);
+        if (cls && c < s) red[c] = fmax(red[c], red[c + s]);
         __syncthreads();
       }
       const double zmax = red[0];
       __syncthreads();
-      const double e = c < classes ? exp(z - zmax) : 0.0;
-      red[c] = e;
+      const double e = (cls && c < classes) ? exp(z - zmax) : 0.0;
+      if (cls) red[c] = e;
       __syncthreads();
       for (int s = kHeadThreads / 2; s > 0; s >>= 1) {
-        if (c < s) red[c] += red[c + s];
+        if (cls && c < s) red[c] += red[c + s];
         __syncthreads();
       }
-      if (c < classes) {
+      if (cls && c < classes) {
         const int64_t y = label[(int64_t)(r0 + i) * label_stride];
         d = (float)((e / red[0] - (c == (int)y ? 1.0 : 0.0)) * g);
         dl[(int64_t)(r0 + i) * classes + c] = d;
       }
       __syncthreads();
     }
-    dls[i][c] = d;
+    if (cls) dls[i][c] = d;
   }
   __syncthreads();
   int64_t node[kHeadRows];
@@ -189,7 +208,7 @@ __global__ void __launch_bounds__(kHeadThreads) k_head_bwd_rows(const float* __r
     node[i] = i < nr ? idx[r0 + i] : -1;
     if (node[i] >= n_rows) node[i] = -1;
   }
-  for (int k = c; k < dim; k += kHeadThreads) {
+  for (int k = tid; k < dim; k += kHeadThreads * kHeadSlices) {  // one column per thread at dim <= 512
     float acc[kHeadRows];
 #pragma unroll
     for (int i = 0; i < kHeadRows; ++i) acc[i] = 0.f;
@@ -302,8 +321,8 @@ size_t pgnn_masked_head_workspace_bytes(int64_t m, int64_t classes, int64_t dim)
 
 int pgnn_masked_head_fwd(const float* h, int64_t ldh, int64_t n_rows, const int64_t* idx, int64_t m, const float* w, const float* b,
                          const int64_t* label, int64_t label_stride, int64_t classes, int64_t dim, float* logits, double* loss,
-                         int64_t* correct, double* metrics, int32_t* status, uint32_t* counter, void* ws, size_t ws_bytes,
-                         pgnn_stream stream) {
+                         int64_t* correct, double* metrics, double* accum, int32_t* status, uint32_t* counter, void* ws,
+                         size_t ws_bytes, pgnn_stream stream) {
   PGNN_REQUIRE(m > 0 && classes > 0 && classes <= kHeadThreads && dim > 0 && dim % 4 == 0 && dim <= kHeadMaxDim && ldh % 4 == 0,
                "masked_head: 1..%d classes, dim and ldh multiples of 4, dim up to %d", kHeadThreads, kHeadMaxDim);
   if (ws_bytes < pgnn_masked_head_workspace_bytes(m, classes, dim)) {
@@ -318,8 +337,8 @@ int pgnn_masked_head_fwd(const float* h, int64_t ldh, int64_t n_rows, const int6
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = (size_t)kHeadRows * dim * sizeof(float);
   allow_big_lds((const void*)k_head_fwd, lds);
-  hipLaunchKernelGGL(k_head_fwd, dim3((int)ceil_div(m, kHeadRows)), dim3(kHeadThreads), lds, st, h, ldh, idx, (int)m, w, b, label,
-                     label_stride, (int)classes, (int)dim, n_rows, logits, row_nll, row_hit, loss, correct, metrics, counter, status);
+  hipLaunchKernelGGL(k_head_fwd, dim3((int)ceil_div(m, kHeadRows)), dim3(kHeadThreads * kHeadSlices), lds, st, h, ldh, idx, (int)m, w, b, label,
+                     label_stride, (int)classes, (int)dim, n_rows, logits, row_nll, row_hit, loss, correct, metrics, accum, counter, status);
   return check_launch("masked_head_fwd");
 }
 
@@ -341,7 +360,7 @@ int pgnn_masked_head_bwd(const float* h, int64_t ldh, int64_t n_rows, const int6
   float* partial = cv.take<float>((size_t)nchunk * classes * (dim + 1));
   hipStream_t st = (hipStream_t)stream;
   PGNN_HIP(hipMemsetAsync(dnode, 0, (size_t)n_rows * ldd * sizeof(float), st));
-  hipLaunchKernelGGL(k_head_bwd_rows, dim3((int)ceil_div(m, kHeadRows)), dim3(kHeadThreads), 0, st, logits, idx, (int)m, w, label,
+  hipLaunchKernelGGL(k_head_bwd_rows, dim3((int)ceil_div(m, kHeadRows)), dim3(kHeadThreads * kHeadSlices), 0, st, logits, idx, (int)m, w, label,
                      label_stride, gloss, (int)classes, (int)dim, n_rows, dl, dnode, ldd);
   hipLaunchKernelGGL(k_head_bwd_weight, dim3((int)ceil_div(classes, kHeadClassGroup), nchunk), dim3(256), 0, st, dl, h, ldh, idx, (int)m,
                      chunk, (int)classes, (int)dim, n_rows, partial);

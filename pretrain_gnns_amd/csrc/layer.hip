@@ -171,6 +171,22 @@ inline size_t stack_pair_sums(int64_t dim, int64_t rows1, int64_t rows2) {
   return embed_pair_path(rows1, rows2) ? align_up((size_t)rows1 * rows2 * dim * 4, 256) : 0;
 }
 
+// the grouping step of embed_tables_bwd on its own (it depends on the atom columns only)
+inline int embed_tables_group(const int64_t* x_idx, int64_t n, int64_t rows1, int64_t rows2, const float* dxemb1, const float* dxemb2,
+                              int32_t* gptr0, int32_t* gperm0, int32_t* gptr1, int32_t* gperm1, int32_t* gstatus, char* grp_ws,
+                              size_t grp_b, hipStream_t st) {
+  if (embed_pair_path(rows1, rows2) && dxemb1 && dxemb2)
+    return pgnn_group_by_key_pair(x_idx, x_idx + 1, 2, n, rows1, rows2, gptr0, gperm0, gstatus, grp_ws, grp_b, st);
+  const int64_t rows[2] = {rows1, rows2};
+  const float* dx[2] = {dxemb1, dxemb2};
+  int32_t* ptrs[2] = {gptr0, gptr1};
+  int32_t* perms[2] = {gperm0, gperm1};
+  for (int c = 0; c < 2; ++c)
+    if (dx[c])
+      if (int rc = pgnn_group_by_key(x_idx + c, 2, n, rows[c], ptrs[c], perms[c], gstatus, grp_ws, grp_b, st)) return rc;
+  return PGNN_OK;
+}
+
 // gradients of the two atom embedding tables from the gradient g [n, dim] of their sum (chem/model.py:264)
 inline int embed_tables_bwd(const float* g, const int64_t* x_idx, int64_t n, int64_t dim, int64_t rows1, int64_t rows2,
                             float* dxemb1, float* dxemb2, int32_t* gptr0, int32_t* gperm0, int32_t* gptr1,
@@ -317,10 +333,21 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   int rc;
   // Every event record / wait costs ~7 us of host time, so forks are spent only where they buy overlap:
   // the atom-type / chirality grouping (a few tiny kernels) stays on the caller's stream, after the layers.
-  PGNN_HIP(hipMemsetAsync(gstatus, 0, sizeof(int32_t), main));
+  // (gstatus is scratch: the forward's embedding lookup validated x_idx, nobody reads the grouping's count -- no memset launch)
   // W1^T / W2^T of the top `ntr` layers in one launch: backward-data then has both operands contiguous along the
   // contracted dimension and runs the forward (split-bf16) kernel.  On the side stream when there is one: the first
   // BatchNorm backward covers it.
+  // The atom-type x chirality grouping of the embedding gradients needs nothing from the backward: it goes to the side stream
+  // first, under the first BatchNorm backward of the caller's stream (the side stream has nothing to do until that is done),
+  // instead of after the last layer, where it sat on the critical path in front of the segment sums.
+  const bool group_early = sd != nullptr;
+  if (sd) {
+    PGNN_HIP(hipEventRecord(sd->fork[0], main));  // (the workspace words it writes were the previous call's until here)
+    PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[0], 0));
+    if ((rc = embed_tables_group(x_idx, n, rows1, rows2, dxemb1, dxemb2, gptr[0], gperm[0], gptr[1], gperm[1], gstatus, grp_ws, grp_b, aux)))
+      return rc;
+  }
+  bool waited_fork2 = false;
   if (ntr > 0 && use_transposed_weights(n)) {
     const float* tsrc[2 * kMaxTransposed];
     float* tdst[2 * kMaxTransposed];
@@ -330,15 +357,14 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
       tsrc[2 * q] = p.w1; tdst[2 * q] = w1t[q]; trows[2 * q] = 2 * dim; tcols[2 * q] = dim;          // W1 [2d, d]
       tsrc[2 * q + 1] = p.w2; tdst[2 * q + 1] = w2t[q]; trows[2 * q + 1] = dim; tcols[2 * q + 1] = 2 * dim;  // W2 [d, 2d]
     }
-    if (sd) {
-      PGNN_HIP(hipEventRecord(sd->fork[0], main));
-      PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[0], 0));
-    }
-    if ((rc = pgnn_transpose_batch(tsrc, tdst, trows, tcols, 2 * ntr, aux))) return rc;
+    if ((rc = pgnn_transpose_batch(tsrc, tdst, trows, tcols, 2 * ntr, aux))) return rc;  // (aux already waits on fork[0])
     if (sd) {
       PGNN_HIP(hipEventRecord(sd->fork[2], aux));
       PGNN_HIP(hipStreamWaitEvent(main, sd->fork[2], 0));
+      waited_fork2 = true;  // ... which also covers the grouping
     }
+  } else if (sd) {
+    PGNN_HIP(hipEventRecord(sd->fork[2], aux));  // grouping done; the caller's stream waits for it after the layers
   }
   const bool tr = ntr > 0 && use_transposed_weights(n);
 
@@ -369,18 +395,27 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     }
     if ((rc = pgnn_linear_bwd_weight(dz[b], dim, hd, 2 * dim, p.dw2, p.db2, n, 2 * dim, dim, aux_ws, opb, aux))) return rc;
     if ((rc = pgnn_linear_bwd_weight(dhid[b], 2 * dim, agg, dim, p.dw1, p.db1, n, dim, 2 * dim, aux_ws, opb, aux))) return rc;
-    if ((rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, aux_ws, opb, aux))) return rc;
+    // the bottom layer's edge-table gradient stays on the caller's stream: the side stream is the longer of the two there
+    // (two weight-gradient products behind the data products), and the caller's stream only has the embedding gradients left
+    const bool demb_on_main = sd && l == 0;
+    if (!demb_on_main && (rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, aux_ws, opb, aux))) return rc;
     if (sd && !per_layer && l >= 2) PGNN_HIP(hipEventRecord(sd->lag[b], aux));  // awaited by layer l-2 only
     if ((rc = pgnn_neighbor_sum(dagg[b], dim, out_ptr, out_dst, nullptr, dxb[b], dim, n, dim, main))) return rc;
+    if (demb_on_main && (rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, op, opb, main))) return rc;
     g = dxb[b];
     ldg = dim;
   }
-  if (sd) {  // join before the embedding gradients (they need the groupings) and before returning
+  // The embedding gradients need the last aggregation only, not the side stream's weight gradients: they run beside the
+  // bottom layer's two weight-gradient products, and the join comes after them (it used to come before: ~70 us of one
+  // stream idling per 256-graph step).
+  if (sd && !waited_fork2) PGNN_HIP(hipStreamWaitEvent(main, sd->fork[2], 0));  // the grouping (finished long ago)
+  rc = embed_tables_bwd(g, x_idx, n, dim, rows1, rows2, dxemb1, dxemb2, gptr[0], gperm[0], gptr[1], gperm[1], gstatus, grp_ws,
+                        grp_b, seg_ws, seg_b, pair_sums, group_early, main);
+  if (sd) {  // join: nothing of this call is in flight on the side stream once the caller's stream passes this point
     PGNN_HIP(hipEventRecord(sd->join, aux));
     PGNN_HIP(hipStreamWaitEvent(main, sd->join, 0));
   }
-  return embed_tables_bwd(g, x_idx, n, dim, rows1, rows2, dxemb1, dxemb2, gptr[0], gperm[0], gptr[1], gperm[1], gstatus,
-                          grp_ws, grp_b, seg_ws, seg_b, pair_sums, false, main);
+  return rc;
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -478,7 +513,6 @@ int pgnn_chem_lin_stack_bwd(int kind, const float* dy, int64_t lddy, const int64
 
   hipStream_t main = (hipStream_t)stream;
   int rc;
-  PGNN_HIP(hipMemsetAsync(gstatus, 0, sizeof(int32_t), main));
 
   const float* g = dy;
   int64_t ldg = lddy;

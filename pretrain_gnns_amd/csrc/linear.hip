@@ -56,8 +56,27 @@ __device__ float4 g_ones_page[1] = {{1.f, 0.f, 0.f, 0.f}};  // DMA source of the
 
 // epilogue shared by the fp32-MFMA and the split-bf16 kernels (identical C/D register layout): lane holds
 // C[m = mw + 16 i + (lane & 15)][n = nw + 16 j + (lane >> 4) * 4 + 0..3] of each 16x16 block
-template <int EPI, bool ONES, int MI, int NI>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI][NI], int mw, int nw, int lane) {
+// the ReLU mask operand of an EPI_MASK product, fetched BEFORE the k-loop (k_gemm3): at the 256-graph batch every workgroup
+// reaches its epilogue at the same moment, and a mask load issued there is a full memory round trip in front of the stores
+template <int MI, int NI>
+__device__ __forceinline__ void gemm_prefetch_mask(const GemmArgs& p, float4 (&mk)[MI][NI], int mw, int nw, int lane) {
+  const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = nw + j * 16 + fk * 4;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      // clamped, unconditional loads (a guarded load compiles to a branch with its own s_waitcnt: five serial round trips);
+      // the epilogue never looks at the values of rows / columns beyond the edge
+      const int m = min(mw + i * 16 + fr, p.M - 1);
+      mk[i][j] = *reinterpret_cast<const float4*>(p.mask + (int64_t)m * p.ldmask + min(n, p.N - 4));
+    }
+  }
+}
+
+template <int EPI, bool ONES, int MI, int NI, int PM>
+__device__ __forceinline__ void gemm_epilogue_pre(const GemmArgs& p, f32x4 (&acc)[MI][NI], int mw, int nw, int lane,
+                                                  const float4 (&pre)[PM][NI]) {  // PM == MI: pre holds the mask values
   const int fr = lane & 15, fk = lane >> 4;
   float* C = p.C + (int64_t)blockIdx.y * p.split_stride;
 #pragma unroll
@@ -87,7 +106,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
         }
       }
       if (EPI == EPI_MASK) {
-        const float4 mk = *reinterpret_cast<const float4*>(p.mask + (int64_t)m * p.ldmask + n);
+        float4 mk;
+        if constexpr (PM == MI) mk = pre[i][j];
+        else mk = *reinterpret_cast<const float4*>(p.mask + (int64_t)m * p.ldmask + n);
         if (!(mk.x > 0.f)) v.x = 0.f;
         if (!(mk.y > 0.f)) v.y = 0.f;
         if (!(mk.z > 0.f)) v.z = 0.f;
@@ -96,6 +117,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
       *reinterpret_cast<float4*>(C + (int64_t)m * p.ldc + n) = v;
     }
   }
+}
+
+template <int EPI, bool ONES, int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI][NI], int mw, int nw, int lane) {
+  const float4 none[MI + 1][NI] = {};
+  gemm_epilogue_pre<EPI, ONES, MI, NI, MI + 1>(p, acc, mw, nw, lane, none);
 }
 
 // C[m,n] = sum_k Aop(m,k) * Bop(n,k);  N and ldc must be multiples of 4 (float4 epilogue).
@@ -510,6 +537,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3(GemmArgs p) {
     store_tile();
     if (1 < nk) load_tile(1);
   }
+  float4 mk[MI][NI];
+  if constexpr (EPI == EPI_MASK) gemm_prefetch_mask<MI, NI>(p, mk, m0 + wm0, n0 + wn0, lane);  // lands under the k-loop
   __syncthreads();
   for (int t = 0; t < nk; ++t) {
     compute();
@@ -518,7 +547,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3(GemmArgs p) {
     __syncthreads();
     if (t + 2 < nk) load_tile(t + 2);
   }
-  gemm_epilogue<EPI, ONES, MI, NI>(p, acc, m0 + wm0, n0 + wn0, lane);
+  if constexpr (EPI == EPI_MASK) gemm_epilogue_pre<EPI, ONES, MI, NI, MI>(p, acc, m0 + wm0, n0 + wn0, lane, mk);
+  else gemm_epilogue<EPI, ONES, MI, NI>(p, acc, m0 + wm0, n0 + wn0, lane);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES>

@@ -2,7 +2,7 @@
 // launch.  The reference builds three `optim.Adam` objects (chem/pretrain_masking.py:134-136) and steps them one after the
 // other; torch's fused path is one multi-tensor launch per optimizer plus ~0.3 ms of Python per step, more than a tenth
 // of the 256-graph train step.  Here the tensors of all three are one job table in the kernel arguments, the step count
-// lives on the device (so the launch can be captured in a HIP graph), and the update is the reference formula in fp32:
+// lives on the device (so the launch can be captured in a HIP graph; the last block to arrive advances it), and the update is the reference formula in fp32:
 //     g += wd p ; m += (g - m)(1 - b1) ; v = b2 v + (1 - b2) g g ; p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 #include "common.h"
 
@@ -22,8 +22,8 @@ struct AdamJobs {
 };
 
 __global__ void __launch_bounds__(256) k_adam(AdamJobs jobs, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
-                                              const int64_t* __restrict__ step, float lr, float beta1, float beta2, float eps,
-                                              float weight_decay) {
+                                              int64_t* step /*[2]: updates applied, arrival ticket*/, float lr, float beta1,
+                                              float beta2, float eps, float weight_decay) {
   // tensor of this block: the table is tiny, a linear scan by one lane is cheaper than anything clever
   __shared__ int js;
   if (threadIdx.x == 0) {
@@ -52,8 +52,18 @@ __global__ void __launch_bounds__(256) k_adam(AdamJobs jobs, float* __restrict__
     v[i] = vi;
     p[i] = pi - step_size * (mi / (sqrtf(vi) * inv_bc2_sqrt + eps));
   }
+  // every thread of every block has read step[0] before its block takes a ticket, so the holder of the last ticket may advance it
+  // (a separate one-thread launch for this cost 6 us of a 1.4 ms train step)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(step + 1);
+    if (atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1ull) {
+      step[0] += 1;
+      *ticket = 0ull;
+    }
+  }
 }
-__global__ void k_adam_tick(int64_t* step) { *step += 1; }
 
 }  // namespace
 }  // namespace pgnn
@@ -83,7 +93,6 @@ int pgnn_adam_step(float* const* params, const float* const* grads, const int64_
   jobs.n = (int)n;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, st, jobs, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay);
-  hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, st, step);
   return check_launch("adam_step");
 }
 

@@ -128,7 +128,7 @@ class ResidentDataset:
                 raise _lib.PgnnError("MaskEdge needs both directions of every edge stored adjacently")
             m = int(mask_counts(self._edges[ids_host] // 2, rate).sum())
         offs = torch.empty(3, b + 1, dtype=torch.int64, device=dev)
-        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        status = _lib.status_word(dev)
         check(lib.pgnn_batch_offsets(ids.data_ptr(), b, self.num_graphs, self.node_slice.data_ptr(),
                                      self.edge_slice.data_ptr(), rate, unit, offs[0].data_ptr(), offs[1].data_ptr(),
                                      offs[2].data_ptr(), n, e, m, status.data_ptr(), sp), "pgnn_batch_offsets")
@@ -202,7 +202,7 @@ class ResidentDataset:
         b = ids_host.size
         n, e = int(self._nodes[ids_host].sum()), int(self._edges[ids_host].sum())
         offs = torch.empty(3, b + 1, dtype=torch.int64, device=dev)
-        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        status = _lib.status_word(dev)
         check(lib.pgnn_batch_offsets(ids.data_ptr(), b, self.num_graphs, self.node_slice.data_ptr(),
                                      self.edge_slice.data_ptr(), 0.0, 0, offs[0].data_ptr(), offs[1].data_ptr(),
                                      offs[2].data_ptr(), n, e, 0, status.data_ptr(), sp), "pgnn_batch_offsets")

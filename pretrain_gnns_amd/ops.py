@@ -93,7 +93,7 @@ def _build_graph(kind, edge_index, edge_attr, num_nodes, gcn):
     g.in_src = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
     g.out_dst = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
     g.dinv = torch.empty(n, dtype=torch.float32, device=dev)
-    g.status = torch.zeros(1, dtype=torch.int32, device=dev)
+    g.status = _lib.status_word(dev)
     ws = _workspace(_ws_bytes("pgnn_graph_workspace_bytes", n, e), dev)
     if kind == "chem":
         if edge_attr.dtype != torch.int64 or edge_attr.dim() != 2 or edge_attr.size(1) != 2:
@@ -145,7 +145,7 @@ def group_by_key(key, n_keys, stride=1, offset=0):
     n_items = key.numel() // stride
     ptr = torch.empty(n_keys + 1, dtype=torch.int32, device=dev)
     perm = torch.empty(max(n_items, 1), dtype=torch.int32, device=dev)
-    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    status = _lib.status_word(dev)
     ws = _workspace(_ws_bytes("pgnn_group_workspace_bytes", n_keys, n_items), dev)
     check(load().pgnn_group_by_key(key.data_ptr() + 8 * offset, stride, n_items, n_keys, ptr.data_ptr(),
                                    perm.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()),
@@ -362,7 +362,7 @@ class Embed(Function):
         t2 = _f32c(table2) if table2 is not None else None
         dim = t1.size(1)
         out = torch.empty(n, dim, dtype=torch.float32, device=idx.device)
-        status = torch.zeros(1, dtype=torch.int32, device=idx.device)
+        status = _lib.status_word(idx.device)
         check(load().pgnn_embed_fwd(idx.data_ptr(), stride, t1.data_ptr(), t1.size(0),
                                     t2.data_ptr() if t2 is not None else None, t2.size(0) if t2 is not None else 0,
                                     out.data_ptr(), dim, n, dim, status.data_ptr(), stream_ptr()), "pgnn_embed_fwd")
@@ -848,8 +848,11 @@ class MaskedHead(Function):
     repeat (MaskAtom samples without replacement)."""
 
     @staticmethod
-    def forward(ctx, node_rep, idx, weight, bias, label):
+    def forward(ctx, node_rep, idx, weight, bias, label, accum=None):
         require_cuda(node_rep, idx, weight, label)
+        ctx.set_materialize_grads(False)  # three of the four outputs carry no gradient: no zero tensors for them in the backward
+        if accum is not None and (accum.dtype != torch.float64 or accum.numel() < 4 or not accum.is_contiguous() or accum.device != node_rep.device):
+            raise _lib.PgnnError("masked head: accum must be a contiguous float64 [4] tensor on the device of node_rep")
         h = _rows2d(node_rep)
         n, dim = h.shape
         m, classes = idx.numel(), weight.size(0)
@@ -867,8 +870,8 @@ class MaskedHead(Function):
         ws = torch.empty(_ws_bytes("pgnn_masked_head_workspace_bytes", m, classes, dim), dtype=torch.uint8, device=dev)
         check(load().pgnn_masked_head_fwd(h.data_ptr(), h.stride(0), n, idx.data_ptr(), m, w.data_ptr(),
                                           b.data_ptr() if b is not None else None, label.data_ptr(), label.stride(0), classes, dim,
-                                          logits.data_ptr(), loss.data_ptr(), correct.data_ptr(), metrics.data_ptr(), words.data_ptr(),
-                                          words.data_ptr() + 4, ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_masked_head_fwd")
+                                          logits.data_ptr(), loss.data_ptr(), correct.data_ptr(), metrics.data_ptr(),
+                                          accum.data_ptr() if accum is not None else None, words.data_ptr(), words.data_ptr() + 4, ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_masked_head_fwd")
         if _CHECK_INDICES:
             if int(words[0].item()):
                 words[0] = 0
@@ -883,6 +886,8 @@ class MaskedHead(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gloss, _gc, _gl, _gm):
+        if gloss is None:
+            return None, None, None, None, None, None
         h, idx, w, label, logits = ctx.saved_tensors
         n, dim = h.shape
         m, classes = logits.shape
@@ -895,13 +900,14 @@ class MaskedHead(Function):
                                           label.stride(0), logits.data_ptr(), gloss.data_ptr(), classes, dim, dnode.data_ptr(), dim,
                                           dw.data_ptr(), db.data_ptr() if db is not None else None, ctx.ws.data_ptr(), ctx.ws.numel(),
                                           stream_ptr()), "pgnn_masked_head_bwd")
-        return dnode, None, dw, db, None
+        return dnode, None, dw, db, None, None
 
 
-def masked_head(node_rep, idx, linear, label, with_metrics=False):
+def masked_head(node_rep, idx, linear, label, with_metrics=False, accum=None):
     """(loss, correct) of ``linear(node_rep[idx])`` against ``label`` -- see MaskedHead; ``with_metrics`` adds the packed
-    float64 [2] tensor (loss, correct)"""
-    loss, correct, _, metrics = MaskedHead.apply(node_rep, idx, linear.weight, linear.bias, label)
+    float64 [2] tensor (loss, correct); ``accum`` (float64 [4], device) receives accum[0] += loss, accum[1] += correct / m,
+    accum[3] += 1: the epoch sums of the reference's train(), kept on the device"""
+    loss, correct, _, metrics = MaskedHead.apply(node_rep, idx, linear.weight, linear.bias, label, accum)
     return (loss, correct, metrics) if with_metrics else (loss, correct)
 
 
@@ -1098,7 +1104,7 @@ class ChemGINStack(Function):
         acts = torch.empty(L, 3, n, dim, dtype=torch.float32, device=dev)
         hid = torch.empty(L, n, 2 * dim, dtype=torch.float32, device=dev)
         stats = torch.empty(L, 4, dim, dtype=torch.float32, device=dev)  # mean, 1/std, scale, shift
-        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        status = _lib.status_word(dev)
         ws = _workspace(_ws_bytes("pgnn_chem_gin_layer_workspace_bytes", n, dim), dev)
         check(load().pgnn_chem_gin_stack_fwd(
             x_idx.data_ptr(), xemb1.data_ptr(), xemb1.size(0), xemb2.data_ptr(), xemb2.size(0), graph.in_ptr.data_ptr(),
@@ -1361,7 +1367,7 @@ class ChemLinStack(Function):
         acts = torch.empty(L, 4, n, dim, dtype=torch.float32, device=dev)  # lin, sum, z, y
         norms = torch.empty(L, n, dtype=torch.float32, device=dev) if kind == 2 else None
         stats = torch.empty(L, 4, dim, dtype=torch.float32, device=dev)
-        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        status = _lib.status_word(dev)
         ws = _workspace(_ws_bytes("pgnn_chem_gin_layer_workspace_bytes", n, dim), dev)
         check(load().pgnn_chem_lin_stack_fwd(
             kind, x_idx.data_ptr(), xemb1.data_ptr(), xemb1.size(0), xemb2.data_ptr(), xemb2.size(0),

@@ -38,7 +38,8 @@ class _Core:
         self.offsets = offs
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.step_count = torch.zeros((), dtype=torch.int64, device=dev)
+        self.step_words = torch.zeros(2, dtype=torch.int64, device=dev)  # updates applied, the kernel's arrival counter
+        self.step_count = self.step_words[0]
         self.max_tensors = int(load().pgnn_adam_max_tensors())
         self.waiting = 0  # handles that still have to call step() before the shared launch goes out
         self.handles = 0
@@ -59,7 +60,7 @@ class _Core:
             O = (ctypes.c_int64 * n)(*[o for _, o in part])
             last = i + self.max_tensors >= len(live)
             # every part reads the same step count: only the last part's launch advances it
-            counter = self.step_count if last else self.step_count.clone()
+            counter = self.step_words if last else self.step_words.clone()
             check(lib.pgnn_adam_step(P, G, C, O, n, self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), counter.data_ptr(), self.lr,
                                      self.betas[0], self.betas[1], self.eps, self.weight_decay, sp), "pgnn_adam_step")
 

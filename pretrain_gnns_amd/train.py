@@ -26,21 +26,48 @@ def _correct(pred, target):
     return torch.sum(torch.max(pred.detach(), dim=1)[1] == target)
 
 
-def chem_masking_step(model_list, optimizer_list, batch, mask_edge=False, readback="end"):
+_ones = {}
+
+
+def _unit_grad(loss):
+    """d loss / d loss for ``loss.backward``: a cached float64 one per device (torch builds a new ones_like every call)"""
+    key = (loss.device.type, loss.device.index, loss.dtype)
+    t = _ones.get(key)
+    if t is None:
+        t = _ones[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    return t
+
+
+def epoch_accumulator(device):
+    """float64 [4] on ``device``: the running sums train() of chem/pretrain_masking.py:72-76 keeps on the host --
+    [sum of loss, sum of node accuracy, sum of edge accuracy, steps] -- for ``readback="epoch"``."""
+    return torch.zeros(4, dtype=torch.float64, device=device)
+
+
+def chem_masking_step(model_list, optimizer_list, batch, mask_edge=False, readback="end", accum=None):
     """One iteration of chem/pretrain_masking.py:46-76.
 
     readback="inline" reads accuracy and loss back exactly where the reference does (a device->host
     sync between forward and backward, another after the optimizer).  readback="end" (default) computes
     the same three numbers from the same tensors but fetches them with ONE transfer after
-    ``optimizer.step()``, so the GPU is not left idle mid-step waiting for Python to resume."""
+    ``optimizer.step()``, so the GPU is not left idle mid-step waiting for Python to resume.
+    readback="epoch" does not fetch at all: the step adds its three numbers to ``accum`` (an
+    ``epoch_accumulator``) on the device -- the same float64 additions, in the same order, the reference's
+    ``loss_accum += ...`` lines do on the host -- and returns None, so the host enqueues the next step while
+    this one still runs; ``chem_masking_epoch`` reads the sums back once."""
     model, linear_pred_atoms, linear_pred_bonds = model_list
     node_rep = model(batch.x, batch.edge_index, batch.edge_attr)
-    inline = readback == "inline"
+    if readback not in ("inline", "end", "epoch"):
+        raise ValueError("readback must be 'inline', 'end' or 'epoch'")
+    inline, deferred = readback == "inline", readback == "epoch"
+    if deferred and accum is None:
+        raise ValueError("readback='epoch' needs accum=epoch_accumulator(device)")
     packed = None
     if not inline and _fusable_head(linear_pred_atoms, node_rep):
         # the three statements below as one launch per direction (ops.MaskedHead: same dtypes, float64 soft-max and loss)
         loss, acc_node, packed = ops.masked_head(node_rep, batch.masked_atom_indices, linear_pred_atoms,
-                                                 batch.mask_node_label[:, 0], with_metrics=True)
+                                                 batch.mask_node_label[:, 0], with_metrics=True,
+                                                 accum=accum if deferred and not mask_edge else None)
         n_node = batch.masked_atom_indices.numel()
     else:
         pred_node = linear_pred_atoms(node_rep[batch.masked_atom_indices])
@@ -58,11 +85,18 @@ def chem_masking_step(model_list, optimizer_list, batch, mask_edge=False, readba
         acc_edge = compute_accuracy(pred_edge, batch.mask_edge_label[:, 0]) if inline else _correct(pred_edge, batch.mask_edge_label[:, 0])
     for opt in optimizer_list:
         opt.zero_grad()
-    loss.backward()
+    loss.backward(_unit_grad(loss))
     for opt in optimizer_list:
         opt.step()
     if inline:
         return float(loss.cpu().item()), acc_node, acc_edge
+    if deferred:
+        if packed is None or mask_edge:  # (the fused head added its own numbers inside its forward launch)
+            if not torch.is_tensor(acc_edge):
+                acc_edge = torch.zeros((), dtype=torch.long, device=loss.device)
+            accum += torch.stack([loss.detach().double(), acc_node.double() / n_node, acc_edge.double() / n_edge,
+                                  torch.ones((), dtype=torch.float64, device=loss.device)])
+        return None
     if packed is not None and not mask_edge:  # (loss, correct) already side by side on the device
         vals = packed.cpu().tolist()
         return vals[0], vals[1] / n_node, 0.0
@@ -72,21 +106,31 @@ def chem_masking_step(model_list, optimizer_list, batch, mask_edge=False, readba
     return vals[0], vals[1] / n_node, vals[2] / n_edge
 
 
-def chem_masking_epoch(model_list, optimizer_list, loader, mask_edge=False, device=None, readback="end"):
+def chem_masking_epoch(model_list, optimizer_list, loader, mask_edge=False, device=None, readback="epoch"):
     """train() of chem/pretrain_masking.py:37-78: one pass over ``loader`` (a ResidentLoader yields batches
     that already live on the GPU; host batches are moved with ``.to(device)``).  Returns the reference's
-    three epoch averages, which divide by the LAST step index rather than the step count (:78)."""
+    three epoch averages, which divide by the LAST step index rather than the step count (:78).
+    The function's only outputs are the epoch sums, so by default (readback="epoch") they are accumulated on
+    the device and fetched once; "end" / "inline" fetch every step and add on the host."""
     for m in model_list:
         m.train()
     loss_accum = acc_node_accum = acc_edge_accum = 0.0
     step = 0
+    accum = None
     for step, batch in enumerate(loader):
         if device is not None:
             batch = batch.to(device)
+        if readback == "epoch":
+            if accum is None:
+                accum = epoch_accumulator(batch.x.device)
+            chem_masking_step(model_list, optimizer_list, batch, mask_edge, readback, accum)
+            continue
         loss, acc_node, acc_edge = chem_masking_step(model_list, optimizer_list, batch, mask_edge, readback)
         loss_accum += loss
         acc_node_accum += acc_node
         acc_edge_accum += acc_edge
+    if accum is not None:
+        loss_accum, acc_node_accum, acc_edge_accum, _ = accum.cpu().tolist()
     return loss_accum / step, acc_node_accum / step, acc_edge_accum / step
 
 
@@ -131,7 +175,7 @@ class GraphedChemMaskingStep:
             self.n_edge = len(pred_edge)
         for opt in self.optimizer_list:
             opt.zero_grad(set_to_none=True)
-        loss.backward()
+        loss.backward(_unit_grad(loss))
         for opt in self.optimizer_list:
             opt.step()
         return torch.stack([loss.detach(), acc_node.double(), acc_edge.double()])
@@ -142,10 +186,15 @@ class GraphedChemMaskingStep:
         return vals[0], vals[1] / self.n_node, vals[2] / self.n_edge
 
 
-def bio_masking_step(model_list, optimizer_list, batch, readback="end"):
+def bio_masking_step(model_list, optimizer_list, batch, readback="end", accum=None):
     """One iteration of bio/pretrain_masking.py:29-60.  readback as in ``chem_masking_step``: "inline" syncs where the
     reference does (accuracy between forward and backward, loss after the optimizer), "end" (default) fetches the same two
-    numbers with one transfer after ``optimizer.step()``."""
+    numbers with one transfer after ``optimizer.step()``, "epoch" adds them to ``accum`` (``epoch_accumulator``: [loss sum,
+    unused, edge-accuracy sum, steps]) on the device and returns None."""
+    if readback not in ("inline", "end", "epoch"):
+        raise ValueError("readback must be 'inline', 'end' or 'epoch'")
+    if readback == "epoch" and accum is None:
+        raise ValueError("readback='epoch' needs accum=epoch_accumulator(device)")
     model, linear_pred_edges = model_list
     node_rep = model(batch.x, batch.edge_index, batch.edge_attr)
     masked_edge_index = batch.edge_index[:, batch.masked_edge_idx]
@@ -157,13 +206,41 @@ def bio_masking_step(model_list, optimizer_list, batch, readback="end"):
     for opt in optimizer_list:
         opt.zero_grad()
     loss = F.cross_entropy(pred_edge, edge_label)
-    loss.backward()
+    loss.backward(_unit_grad(loss))
     for opt in optimizer_list:
         opt.step()
     if inline:
         return float(loss.cpu().item()), acc_edge
+    if readback == "epoch":
+        zero = torch.zeros((), dtype=torch.float64, device=loss.device)
+        accum += torch.stack([loss.detach().double(), zero, acc_edge.double() / len(pred_edge), zero + 1.0])
+        return None
     vals = torch.stack([loss.detach().double(), acc_edge.double()]).cpu().tolist()
     return vals[0], vals[1] / len(pred_edge)
+
+
+def bio_masking_epoch(model_list, optimizer_list, loader, device=None, readback="epoch"):
+    """train() of bio/pretrain_masking.py:29-62: one pass over ``loader``; returns (loss_accum / step, acc_accum / step)
+    with the reference's divisor (the last step index, :62).  Sums on the device by default, as in ``chem_masking_epoch``."""
+    for m in model_list:
+        m.train()
+    loss_accum = acc_accum = 0.0
+    step = 0
+    accum = None
+    for step, batch in enumerate(loader):
+        if device is not None:
+            batch = batch.to(device)
+        if readback == "epoch":
+            if accum is None:
+                accum = epoch_accumulator(batch.x.device)
+            bio_masking_step(model_list, optimizer_list, batch, readback, accum)
+            continue
+        loss, acc = bio_masking_step(model_list, optimizer_list, batch, readback)
+        loss_accum += loss
+        acc_accum += acc
+    if accum is not None:
+        loss_accum, _, acc_accum, _ = accum.cpu().tolist()
+    return loss_accum / step, acc_accum / step
 
 
 def cycle_index(num, shift):

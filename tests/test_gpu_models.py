@@ -237,6 +237,41 @@ def test_epoch_accuracy_matches_oracle_within_a_tenth_of_a_percent():
     assert abs(ref_out[0] - hip_out[0]) <= 2e-2 * abs(ref_out[0]), (ref_out, hip_out)  # epoch loss
 
 
+@pytest.mark.parametrize("mask_edge", [False, True])
+def test_epoch_sums_on_the_device_equal_the_per_step_read_back(mask_edge):
+    """readback="epoch" (sums kept on the device, one fetch per epoch; the fused head adds its numbers inside its forward
+    launch) returns bit-for-bit what readback="end" (fetch every step, add on the host as chem/pretrain_masking.py:72-76
+    does) returns: the same float64 additions in the same order.  Batches of different sizes, so correct / n differs per step.
+    (Bit-for-bit where the step itself is deterministic, i.e. without the bond head.)"""
+    from pretrain_gnns_amd import train as ptrain
+    hchem, _ = _hip()
+    stream = [synthetic.chem_masking_batch(8 + 5 * i, seed=40 + i, mask_edge=mask_edge).to(DEV) for i in range(5)]
+    outs = []
+    for mode in ("end", "epoch"):
+        torch.manual_seed(3)
+        mods = [hchem.GNN(5, 300).to(DEV), torch.nn.Linear(300, 119).to(DEV), torch.nn.Linear(300, 4).to(DEV)]
+        outs.append(ptrain.chem_masking_epoch(mods, _opt(*mods), stream, mask_edge=mask_edge, readback=mode))
+    if mask_edge:  # torch's index backward of the bond head accumulates with atomics: two runs differ by rounding, Adam carries it on
+        assert all(abs(a - c) <= 1e-3 * max(1.0, abs(a)) for a, c in zip(*outs)), outs
+    else:
+        assert outs[0] == outs[1], outs
+    assert outs[0][0] > 0 and (outs[0][2] > 0) == mask_edge
+    with pytest.raises(ValueError):
+        ptrain.chem_masking_step(mods, _opt(*mods), stream[0], mask_edge, readback="epoch")  # no accumulator given
+
+
+def test_bio_epoch_sums_on_the_device_equal_the_per_step_read_back():
+    from pretrain_gnns_amd import train as ptrain
+    _, hbio = _hip()
+    stream = [synthetic.bio_masking_batch(4 + i, seed=60 + i).to(DEV) for i in range(4)]
+    outs = []
+    for mode in ("end", "epoch"):
+        torch.manual_seed(4)
+        mods = [hbio.GNN(5, 300).to(DEV), torch.nn.Linear(300, 7).to(DEV)]
+        outs.append(ptrain.bio_masking_epoch(mods, _opt(*mods), stream, readback=mode))
+    assert outs[0] == outs[1], outs
+
+
 def test_product_train_step_mirrors_oracle_step():
     """pretrain_gnns_amd.train (what bench.py times) == oracle.steps on the same HIP model, for both
     readback placements, including with torch's fused Adam."""
