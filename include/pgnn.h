@@ -185,6 +185,17 @@ int pgnn_bn_stats_fwd(const float* x, int64_t ldx, const float* gamma, const flo
                       float* save_mean, float* save_invstd, float* coef, int64_t num_rows, int64_t dim,
                       void* ws, size_t ws_bytes, pgnn_stream stream);
 
+/* The same statistics from what the product in front of the BatchNorm already had in registers (pgnn_linear_fwd_colstats):
+ * blocks [ceil(num_rows / 16)][2][dim] = per 16-row block and column, the column sum and the sum of squared deviations from
+ * the block's own column mean; merged pairwise in float64 with the parallel-variance formula (fixed order).  Training mode
+ * only.  pgnn_bn_apply_fwd is the normalise pass on its own: y = coef[0]*x + coef[1] (+ReLU, + fused dropout).
+ * Together they are pgnn_bn_fwd minus its read of x for the statistics (chem/model.py:269: batch_norms[layer](h)). */
+int pgnn_bn_stats_fwd_blocks(const float* blocks, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             float momentum, float eps, float* save_mean, float* save_invstd, float* coef, int64_t num_rows,
+                             int64_t dim, pgnn_stream stream);
+int pgnn_bn_apply_fwd(const float* x, int64_t ldx, const float* coef, int relu, float* y, int64_t ldy, float drop_p,
+                      uint64_t drop_seed, int64_t num_rows, int64_t dim, pgnn_stream stream);
+
 /* Backward of the above (ReLU and dropout masks are recomputed, nothing else is kept). */
 int pgnn_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                 const float* beta, const float* save_mean, const float* save_invstd, int training,
@@ -215,6 +226,13 @@ int pgnn_mean_l2norm_bwd(const float* dy, int64_t lddy, const float* y, int64_t 
 /* y[M,N] = act(x[M,K] . W[N,K]^T + b) ; relu != 0 -> act = max(.,0) */
 int pgnn_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y,
                     int64_t ldy, int64_t m, int64_t k, int64_t n, int relu, pgnn_stream stream);
+
+/* The same product, also leaving the column statistics of y that a BatchNorm behind it needs (the mlp's second Linear in front
+ * of batch_norms[layer], chem/model.py:54-55,269): colstat [ceil(m / 16)][2][n]; for the 16-row block t and column c,
+ * colstat[t][0][c] = sum_r y[r, c] and colstat[t][1][c] = sum_r (y[r, c] - mean_t,c)^2 over the block's rows, taken in the
+ * epilogue from the accumulators (pgnn_bn_stats_fwd_blocks consumes them). */
+int pgnn_linear_fwd_colstats(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy, int64_t m,
+                             int64_t k, int64_t n, int relu, float* colstat, pgnn_stream stream);
 
 /* dx[M,K] = dy[M,N] . W[N,K] ; if relu_out != NULL: dx *= (relu_out > 0)  (relu_out = the
  * activation this dx flows into, i.e. the forward output of the preceding Linear+ReLU) */

@@ -120,6 +120,55 @@ __global__ void k_bn_stats_final(const float* __restrict__ partial, int nblk, co
   coef[dim + c] = fmaf(-mean, a, beta[c]);  // same expression as the backward's recomputation
 }
 
+// The same finalize from per-16-row-block statistics (pgnn_linear_fwd_colstats: the product in front of the BatchNorm left, for
+// every block t and column c, S_t = sum of the block's rows and Q_t = sum of squared deviations from the block's own mean):
+// blocks are merged pairwise with the parallel-variance formula in double,
+//     n = nA + nB ; d = mB - mA ; m = mA + d nB / n ; M2 = M2A + M2B + d d nA nB / n,
+// lane s of the column's wave folding blocks s, s + 64, ... in order and a 64-lane butterfly on top (fixed tree; lane 0 writes).
+// No shift is needed: every deviation is taken from a mean of 16 neighbouring values.
+__global__ void k_bn_stats_final_blocks(const float* __restrict__ blocks /*[nblk][2][dim]*/, int nblk, const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, float* __restrict__ running_mean,
+                                        float* __restrict__ running_var, float momentum, float eps, int n, int dim,
+                                        float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ coef) {
+  const int sl = threadIdx.x & 63;
+  const int c = min(blockIdx.x * 4 + (threadIdx.x >> 6), dim - 1);
+  const bool writer = sl == 0 && (blockIdx.x * 4 + (threadIdx.x >> 6)) < dim;
+  double cn = 0.0, cm = 0.0, c2 = 0.0;
+  auto merge = [&](double nb, double mb, double qb) {
+    if (nb == 0.0) return;
+    const double nn = cn + nb, d = mb - cm;
+    cm += d * (nb / nn);
+    c2 += qb + d * d * (cn * nb / nn);
+    cn = nn;
+  };
+  for (int t = sl; t < nblk; t += 64) {
+    const double nb = (double)min(16, n - 16 * t);
+    merge(nb, (double)blocks[(size_t)t * 2 * dim + c] / nb, (double)blocks[(size_t)t * 2 * dim + dim + c]);
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double nb = __shfl_xor(cn, off), mb = __shfl_xor(cm, off), qb = __shfl_xor(c2, off);
+    merge(nb, mb, qb);
+  }
+  if (!writer) return;
+  double var = c2 / n;
+  if (var < 0.0) var = 0.0;
+  const float mean = (float)cm;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = n > 1 ? var * ((double)n / (double)(n - 1)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+  if (save_mean) {
+    save_mean[c] = mean;
+    save_invstd[c] = invstd;
+  }
+  const float a = invstd * gamma[c];
+  coef[c] = a;
+  coef[dim + c] = fmaf(-mean, a, beta[c]);  // same expression as the backward's recomputation
+}
+
 __global__ void k_bn_apply(const float* __restrict__ x, int64_t ldx, const float* __restrict__ coef,
                            int relu, float* __restrict__ y, int64_t ldy, int n, int d4, Drop drop) {
   const int t = threadIdx.x, c4 = t % d4, rl = t / d4, dim = d4 * 4;
@@ -329,6 +378,28 @@ int pgnn_bn_stats_fwd(const float* x, int64_t ldx, const float* gamma, const flo
   hipLaunchKernelGGL(k_bn_stats_final, dim3((int)ceil_div(dim, 4)), dim3(256), 0, st, partial, nblk, x, gamma, beta,
                      running_mean, running_var, momentum, eps, training, (int)n, (int)dim, save_mean, save_invstd, coef);
   return check_launch("bn_stats_fwd");
+}
+
+int pgnn_bn_stats_fwd_blocks(const float* blocks, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             float momentum, float eps, float* save_mean, float* save_invstd, float* coef, int64_t n, int64_t dim,
+                             pgnn_stream stream) {
+  if (int rc = check_args(n, dim)) return rc;
+  PGNN_REQUIRE(blocks && coef && n < (1ll << 31), "batchnorm: block statistics and coef must be given");
+  hipLaunchKernelGGL(k_bn_stats_final_blocks, dim3((int)ceil_div(dim, 4)), dim3(256), 0, (hipStream_t)stream, blocks,
+                     (int)ceil_div(n, 16), gamma, beta, running_mean, running_var, momentum, eps, (int)n, (int)dim, save_mean,
+                     save_invstd, coef);
+  return check_launch("bn_stats_fwd_blocks");
+}
+
+int pgnn_bn_apply_fwd(const float* x, int64_t ldx, const float* coef, int relu, float* y, int64_t ldy, float drop_p,
+                      uint64_t drop_seed, int64_t n, int64_t dim, pgnn_stream stream) {
+  if (int rc = check_args(n, dim)) return rc;
+  PGNN_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && coef, "batchnorm: leading dimensions must be multiples of 4, coef must be given");
+  PGNN_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "batchnorm: dropout probability must be in [0, 1)");
+  const int grid = (int)std::min<int64_t>(ceil_div(n, 4), (int64_t)num_cu() * 16);
+  hipLaunchKernelGGL(k_bn_apply, dim3(grid), dim3(stat_threads(dim)), 0, (hipStream_t)stream, x, ldx, coef, relu, y, ldy, (int)n,
+                     (int)(dim / 4), make_drop(drop_p, drop_seed));
+  return check_launch("bn_apply_fwd");
 }
 
 int pgnn_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,

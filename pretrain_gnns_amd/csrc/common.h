@@ -168,6 +168,16 @@ __device__ __forceinline__ double slice_sum16(const float* __restrict__ p, size_
 }
 
 
+// Sum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15); every lane of the row ends with the same bits (each step adds
+// the two halves of a commutative pair): quad xor 1, quad xor 2, mirror within 8, mirror within 16.  No LDS, four VALU ops.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
 // The same with a whole wave per output column: lane s sums the partials b = s, s+64, ... in double (four loads in
 // flight), then a 64-lane xor butterfly.  Every lane ends with the same bits; fixed association order => deterministic.
 __device__ __forceinline__ double slice_sum64(const float* __restrict__ p, size_t stride, int count, int s) {

@@ -49,6 +49,7 @@ inline bool use_transposed_weights(int64_t n) {
   return v == 2 || (v == 1 && n >= 16384);
 }
 inline bool per_layer_buffers() { return env_knob("PGNN_STACK_PER_LAYER_BUFFERS", 0) != 0; }
+constexpr int64_t kStatsInGemmMaxRows = 32768;  // pgnn_chem_gin_stack_fwd: BatchNorm statistics from the GEMM epilogue up to here
 constexpr int kMaxTransposed = 8;  // layers whose weights pgnn_chem_gin_stack_bwd transposes up front (one 16-job launch)
 inline size_t op_ws_bytes(int64_t n, int64_t d) {
   size_t m = pgnn_bn_workspace_bytes(n, d);
@@ -244,6 +245,9 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
   // relu(a*z + b) on read (pgnn_chem_aggregate_bn_fwd).  Needs the statistics only; dropout, wide
   // features and PGNN_FUSE_BN_AGG=0 take the materialising route.
   const bool fuse = drop_p == 0.f && dim <= 320 && env_knob("PGNN_FUSE_BN_AGG", 1) != 0;
+  // Training-mode statistics from the epilogue of the product in front (PGNN_BN_STATS_IN_GEMM=0: the separate partial-sum
+  // pass).  Up to kStatsInGemmMaxRows rows: beyond, the per-16-row blocks (150 B a row) cost more than the pass they replace.
+  const bool stats_in_gemm = training && n > 1 && n <= kStatsInGemmMaxRows && env_knob("PGNN_BN_STATS_IN_GEMM", 1) != 0;
   for (int l = 0; l < num_layer; ++l) {
     const pgnn_gin_layer& p = layers[l];
     float* a = acts + (size_t)l * 3 * nd;  // agg, z, y
@@ -265,6 +269,18 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
     }
     if (rc) return rc;
     if ((rc = pgnn_linear_fwd(agg, dim, p.w1, p.b1, hd, 2 * dim, n, dim, 2 * dim, 1, stream))) return rc;
+    if (stats_in_gemm) {
+      // the BatchNorm statistics of z fall out of the second product's epilogue: no pass over z for them, one launch less
+      float* blocks = static_cast<float*>(ws);  // ceil(n/16) x 2 x dim floats <= the statistics partials of op_ws_bytes
+      if ((rc = pgnn_linear_fwd_colstats(hd, 2 * dim, p.w2, p.b2, z, dim, n, 2 * dim, dim, 0, blocks, stream))) return rc;
+      if ((rc = pgnn_bn_stats_fwd_blocks(blocks, p.gamma, p.beta, p.running_mean, p.running_var, p.momentum, p.eps, st, st + dim,
+                                         st + 2 * dim, n, dim, stream)))
+        return rc;
+      if (!(fuse && !last))
+        rc = pgnn_bn_apply_fwd(z, dim, st + 2 * dim, !last, y, dim, drop_p, drop_seed + (uint64_t)l, n, dim, stream);
+      if (rc) return rc;
+      continue;
+    }
     if ((rc = pgnn_linear_fwd(hd, 2 * dim, p.w2, p.b2, z, dim, n, 2 * dim, dim, 0, stream))) return rc;
     if (fuse && !last)
       rc = pgnn_bn_stats_fwd(z, dim, p.gamma, p.beta, p.running_mean, p.running_var, p.momentum, p.eps, training, st,

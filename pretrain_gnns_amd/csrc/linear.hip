@@ -43,6 +43,8 @@ struct GemmArgs {
   int kchunk;          // split-K: k range per blockIdx.y
   int64_t split_stride;  // split-K: floats between partial C matrices
   float* colsum;       // ONES: receives sum_k Aop(m,k) (one value per m), same split stride
+  float* colstat;      // EPI_BIAS, optional: [ceil(M/16)][2][N] per 16-row block: column sums of C and sums of squared deviations
+                       // from the block's own column mean (what a BatchNorm behind this product needs; see pgnn_linear_fwd_colstats)
   int nxcd;            // XCDs of the device (block -> tile remap)
 };
 
@@ -97,14 +99,32 @@ __device__ __forceinline__ void gemm_epilogue_pre(const GemmArgs& p, f32x4 (&acc
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = mw + i * 16 + fr;
-      if (m >= p.M) continue;
       float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
       if (EPI == EPI_BIAS) {
         v = f4_add(v, bv);
         if (p.relu) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
+        if (p.colstat) {  // (uniform) the 16 lanes of a DPP row hold the 16 rows of this block for the same four columns
+          const int mb = mw + i * 16, cnt = min(16, p.M - mb);
+          if (cnt > 0) {
+            const bool ok = fr < cnt;
+            float4 s = ok ? v : f4_zero();
+            s.x = row16_sum(s.x); s.y = row16_sum(s.y); s.z = row16_sum(s.z); s.w = row16_sum(s.w);
+            const float inv = 1.f / (float)cnt;
+            float4 q;
+            q.x = ok ? v.x - s.x * inv : 0.f; q.y = ok ? v.y - s.y * inv : 0.f;
+            q.z = ok ? v.z - s.z * inv : 0.f; q.w = ok ? v.w - s.w * inv : 0.f;
+            q.x = row16_sum(q.x * q.x); q.y = row16_sum(q.y * q.y); q.z = row16_sum(q.z * q.z); q.w = row16_sum(q.w * q.w);
+            if (fr == 0) {
+              float* cs = p.colstat + (int64_t)(mb >> 4) * 2 * p.N + n;
+              *reinterpret_cast<float4*>(cs) = s;
+              *reinterpret_cast<float4*>(cs + p.N) = q;
+            }
+          }
+        }
       }
+      if (m >= p.M) continue;
       if (EPI == EPI_MASK) {
         float4 mk;
         if constexpr (PM == MI) mk = pre[i][j];
@@ -749,6 +769,19 @@ int pgnn_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bi
   p.nxcd = num_xcd();
   p.A = x; p.lda = ldx; p.B = w; p.ldb = k; p.C = y; p.ldc = ldy;
   p.M = (int)m; p.N = (int)n; p.K = (int)k; p.bias = bias; p.relu = relu; p.kchunk = (int)k; p.split_stride = 0;
+  if (use_split(m, n)) return launch_gemm3<true, true, EPI_BIAS>(p, 1, (hipStream_t)stream);
+  return launch_cfg<true, true, EPI_BIAS>(pick_cfg(m, n, 0), p, 1, (hipStream_t)stream);
+}
+
+int pgnn_linear_fwd_colstats(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy, int64_t m,
+                             int64_t k, int64_t n, int relu, float* colstat, pgnn_stream stream) {
+  PGNN_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && colstat,
+               "linear_fwd_colstats: K, N and the leading dimensions must be multiples of 4, colstat must be given");
+  GemmArgs p{};
+  p.nxcd = num_xcd();
+  p.A = x; p.lda = ldx; p.B = w; p.ldb = k; p.C = y; p.ldc = ldy;
+  p.M = (int)m; p.N = (int)n; p.K = (int)k; p.bias = bias; p.relu = relu; p.kchunk = (int)k; p.split_stride = 0;
+  p.colstat = colstat;
   if (use_split(m, n)) return launch_gemm3<true, true, EPI_BIAS>(p, 1, (hipStream_t)stream);
   return launch_cfg<true, true, EPI_BIAS>(pick_cfg(m, n, 0), p, 1, (hipStream_t)stream);
 }

@@ -42,15 +42,36 @@ __global__ void __launch_bounds__(256) k_adam(AdamJobs jobs, float* __restrict__
   const float* __restrict__ g = jobs.g[j];
   float* __restrict__ m = exp_avg + jobs.state_off[j];
   float* __restrict__ v = exp_avg_sq + jobs.state_off[j];
-  for (int i = base + threadIdx.x; i < end; i += 256) {
-    const float pi = p[i];
-    float gi = g[i];
+  auto update = [&](float pi, float gi, float& mi, float& vi) -> float {
     if (weight_decay != 0.f) gi = fmaf(weight_decay, pi, gi);
-    const float mi = fmaf(gi - m[i], 1.f - beta1, m[i]);
-    const float vi = fmaf(1.f - beta2, gi * gi, beta2 * v[i]);
-    m[i] = mi;
-    v[i] = vi;
-    p[i] = pi - step_size * (mi / (sqrtf(vi) * inv_bc2_sqrt + eps));
+    mi = fmaf(gi - mi, 1.f - beta1, mi);
+    vi = fmaf(1.f - beta2, gi * gi, beta2 * vi);
+    return pi - step_size * (mi / (sqrtf(vi) * inv_bc2_sqrt + eps));
+  };
+  // float4 when the tensor's four arrays allow it: the update is pure streaming
+  const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                     reinterpret_cast<uintptr_t>(v)) & 15) == 0 && (jobs.count[j] & 3) == 0;
+  if (vec) {
+    for (int i = base + 4 * threadIdx.x; i < end; i += 4 * 256) {
+      float4 pv = *reinterpret_cast<const float4*>(p + i);
+      const float4 gv = *reinterpret_cast<const float4*>(g + i);
+      float4 mv = *reinterpret_cast<const float4*>(m + i), vv = *reinterpret_cast<const float4*>(v + i);
+      pv.x = update(pv.x, gv.x, mv.x, vv.x);
+      pv.y = update(pv.y, gv.y, mv.y, vv.y);
+      pv.z = update(pv.z, gv.z, mv.z, vv.z);
+      pv.w = update(pv.w, gv.w, mv.w, vv.w);
+      *reinterpret_cast<float4*>(m + i) = mv;
+      *reinterpret_cast<float4*>(v + i) = vv;
+      *reinterpret_cast<float4*>(p + i) = pv;
+    }
+  } else {
+    for (int i = base + threadIdx.x; i < end; i += 256) {
+      float mi = m[i], vi = v[i];
+      const float pn = update(p[i], g[i], mi, vi);
+      m[i] = mi;
+      v[i] = vi;
+      p[i] = pn;
+    }
   }
   // every thread of every block has read step[0] before its block takes a ticket, so the holder of the last ticket may advance it
   // (a separate one-thread launch for this cost 6 us of a 1.4 ms train step)

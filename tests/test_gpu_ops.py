@@ -406,6 +406,59 @@ def test_linear_fwd_split_bf16_is_as_accurate_as_the_fp32_mfma(m, k, n, monkeypa
     assert rms3 <= 1.25 * rms32 + 1e-9 and max3 <= 2.0 * max32 + 1e-9, out
 
 
+@pytest.mark.parametrize("m,k,n", [(6747, 600, 300), (6747, 300, 600), (1000, 600, 300), (130, 300, 300), (17, 64, 32), (16, 64, 36), (1, 32, 8)])
+@pytest.mark.parametrize("offset", [0.0, 1000.0])
+def test_linear_fwd_colstats_and_batchnorm_statistics_from_blocks(m, k, n, offset):
+    """pgnn_linear_fwd_colstats: same y as pgnn_linear_fwd, bit for bit, plus per-16-row-block column sums and squared
+    deviations from the block mean (vs float64 of the y it wrote); pgnn_bn_stats_fwd_blocks: mean / invstd / running
+    statistics / affine coefficients from those blocks vs torch's batch_norm in float64 -- also with |mean| = 1000 std, where a
+    plain sum-of-squares formula would lose every digit; pgnn_bn_apply_fwd == the normalise pass.  Ragged last block, both GEMM
+    kernels (split-bf16 from 160 tiles, fp32 MFMA below)."""
+    ops = _ops()
+    lib, sp = ops.load(), ops.stream_ptr()
+    torch.manual_seed(m + n)
+    x = torch.randn(m, k, device=DEV)
+    w = (torch.randn(n, k) * 0.05).to(DEV)
+    b = (torch.randn(n) + offset).to(DEV)
+    y0 = torch.empty(m, n, device=DEV)
+    ops.check(lib.pgnn_linear_fwd(x.data_ptr(), k, w.data_ptr(), b.data_ptr(), y0.data_ptr(), n, m, k, n, 0, sp), "fwd")
+    nb = (m + 15) // 16
+    y = torch.empty(m, n, device=DEV)
+    blocks = torch.full((nb, 2, n), float("nan"), device=DEV)
+    ops.check(lib.pgnn_linear_fwd_colstats(x.data_ptr(), k, w.data_ptr(), b.data_ptr(), y.data_ptr(), n, m, k, n, 0,
+                                           blocks.data_ptr(), sp), "fwd_colstats")
+    assert torch.equal(y, y0)
+    yd = y.double().cpu()
+    pad = torch.zeros(nb * 16, n, dtype=torch.float64)
+    pad[:m] = yd
+    valid = (torch.arange(nb * 16) < m).view(nb, 16, 1)
+    cnt = valid.sum(1).double()
+    blk = pad.view(nb, 16, n)
+    s_want = blk.sum(1)
+    q_want = (((blk - s_want.unsqueeze(1) / cnt.unsqueeze(1)) ** 2) * valid).sum(1)
+    got = blocks.double().cpu()
+    assert torch.isfinite(got).all()
+    torch.testing.assert_close(got[:, 0], s_want, rtol=2e-6, atol=2e-6 * float(yd.abs().max()) * 16)
+    torch.testing.assert_close(got[:, 1], q_want, rtol=1e-4, atol=1e-4 * float(q_want.max()) + 1e-12)
+    if m < 2:
+        return
+    gamma, beta = torch.rand(n, device=DEV) + 0.5, torch.randn(n, device=DEV)
+    rm, rv = torch.randn(n, device=DEV), torch.rand(n, device=DEV) + 0.5
+    rm_w, rv_w = rm.double().cpu().clone(), rv.double().cpu().clone()
+    mean, invstd, coef = torch.empty(n, device=DEV), torch.empty(n, device=DEV), torch.empty(2, n, device=DEV)
+    ops.check(lib.pgnn_bn_stats_fwd_blocks(blocks.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1,
+                                           1e-5, mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), m, n, sp), "stats_blocks")
+    want = torch.nn.functional.batch_norm(yd, rm_w, rv_w, gamma.double().cpu(), beta.double().cpu(), True, 0.1, 1e-5)
+    mu, var = yd.mean(0), yd.var(0, unbiased=False)
+    torch.testing.assert_close(mean.double().cpu(), mu, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(invstd.double().cpu(), 1.0 / torch.sqrt(var + 1e-5), rtol=2e-5, atol=0)
+    torch.testing.assert_close(rm.double().cpu(), rm_w, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(rv.double().cpu(), rv_w, rtol=1e-4, atol=1e-6)
+    out = torch.empty(m, n, device=DEV)
+    ops.check(lib.pgnn_bn_apply_fwd(y.data_ptr(), n, coef.data_ptr(), 0, out.data_ptr(), n, 0.0, 0, m, n, sp), "apply")
+    torch.testing.assert_close(out.double().cpu(), want, rtol=1e-4, atol=1e-4 * (1.0 + offset * 0.02))
+
+
 @pytest.mark.parametrize("n,m,classes,dim", [(6747, 1007, 119, 300), (300, 41, 4, 300), (50, 1, 128, 64), (900, 257, 119, 2048)])
 def test_masked_head_fwd_bwd(n, m, classes, dim):
     """pgnn_masked_head_fwd/_bwd (linear_pred + CrossEntropyLoss(pred.double()) + compute_accuracy of
