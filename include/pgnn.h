@@ -256,6 +256,12 @@ int pgnn_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_
                            float* db, int64_t m, int64_t k, int64_t n, void* ws, size_t ws_bytes,
                            pgnn_stream stream);
 
+/* Two weight gradients over the same m rows -- the two Linears of one GIN mlp (chem/model.py:29) -- with ONE fold of their
+ * split-K partials; results identical to two pgnn_linear_bwd_weight calls.  Workspace: the sum of the two single-call sizes. */
+int pgnn_linear_bwd_weight_pair(const float* dy_a, int64_t lddy_a, const float* x_a, int64_t ldx_a, float* dw_a, float* db_a, int64_t k_a,
+                                int64_t n_a, const float* dy_b, int64_t lddy_b, const float* x_b, int64_t ldx_b, float* dw_b, float* db_b,
+                                int64_t k_b, int64_t n_b, int64_t m, void* ws, size_t ws_bytes, pgnn_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * torch.optim.Adam's update (chem/pretrain_masking.py:134-136 builds three of them with the same hyper-parameters) over
  * n <= pgnn_adam_max_tensors() fp32 tensors in one launch: params[j] / grads[j] device pointers (host arrays), counts[j]

@@ -67,6 +67,7 @@ PROTOTYPES = {
     "pgnn_transpose_batch": (_i, [_p, _p, _p, _p, _i64, _p]),
     "pgnn_linear_bwd_weight_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "pgnn_linear_bwd_weight": (_i, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),
+    "pgnn_linear_bwd_weight_pair": (_i, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _p, _sz, _p]),
     "pgnn_chem_gin_layer_workspace_bytes": (_sz, [_i64, _i64]),
     "pgnn_chem_gin_layer_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _i,
                                      _p, _p, _p, _p, _p, _p, _f, _u64, _i64, _i64, _p, _sz, _p]),

@@ -54,8 +54,7 @@ constexpr int kMaxTransposed = 8;  // layers whose weights pgnn_chem_gin_stack_b
 inline size_t op_ws_bytes(int64_t n, int64_t d) {
   size_t m = pgnn_bn_workspace_bytes(n, d);
   m = std::max(m, pgnn_bn_workspace_bytes(n, 2 * d));
-  m = std::max(m, pgnn_linear_bwd_weight_workspace_bytes(n, d, 2 * d));
-  m = std::max(m, pgnn_linear_bwd_weight_workspace_bytes(n, 2 * d, d));
+  m = std::max(m, pgnn_linear_bwd_weight_workspace_bytes(n, d, 2 * d) + pgnn_linear_bwd_weight_workspace_bytes(n, 2 * d, d));  // as a pair
   m = std::max(m, pgnn_rowfeat_matmul_bwd_workspace_bytes(n, 9, d));
   return align_up(m, 256);
 }
@@ -409,8 +408,9 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
       PGNN_HIP(hipEventRecord(sd->fork[1], main));
       PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[1], 0));
     }
-    if ((rc = pgnn_linear_bwd_weight(dz[b], dim, hd, 2 * dim, p.dw2, p.db2, n, 2 * dim, dim, aux_ws, opb, aux))) return rc;
-    if ((rc = pgnn_linear_bwd_weight(dhid[b], 2 * dim, agg, dim, p.dw1, p.db1, n, dim, 2 * dim, aux_ws, opb, aux))) return rc;
+    if ((rc = pgnn_linear_bwd_weight_pair(dz[b], dim, hd, 2 * dim, p.dw2, p.db2, 2 * dim, dim, dhid[b], 2 * dim, agg, dim, p.dw1, p.db1,
+                                          dim, 2 * dim, n, aux_ws, opb, aux)))  // both products, one fold of the split-K partials
+      return rc;
     // the bottom layer's edge-table gradient stays on the caller's stream: the side stream is the longer of the two there
     // (two weight-gradient products behind the data products), and the caller's stream only has the embedding gradients left
     const bool demb_on_main = sd && l == 0;

@@ -849,15 +849,42 @@ size_t pgnn_linear_bwd_weight_workspace_bytes(int64_t m, int64_t k, int64_t n) {
   return align_up((size_t)splits * (n * k + n) * sizeof(float), 256) + 256;
 }
 
-int pgnn_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, float* db,
-                           int64_t m, int64_t k, int64_t n, void* ws, size_t ws_bytes, pgnn_stream stream) {
-  PGNN_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0,
-               "linear_bwd_weight: K, N and leading dimensions must be multiples of 4");
-  if (ws_bytes < pgnn_linear_bwd_weight_workspace_bytes(m, k, n)) {
-    set_error("linear_bwd_weight workspace too small");
-    return PGNN_ERR_WORKSPACE;
+namespace {
+// what is left to do after the split-K product of one weight gradient: dst = sum over `used` partial matrices
+struct ReduceJob {
+  const float* partial;
+  int used;
+  int64_t stride;
+  float* dw;
+  int64_t n4a;
+  float* db;
+  int64_t n4b;
+};
+struct ReduceJobs {
+  ReduceJob j[2];
+};
+// the same fold as k_splitk_reduce for two weight gradients in one launch (blockIdx.y picks the job)
+__global__ void __launch_bounds__(256) k_splitk_reduce_jobs(ReduceJobs jobs) {
+  const ReduceJob r = jobs.j[blockIdx.y];
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < r.n4a + r.n4b; q += (int64_t)gridDim.x * blockDim.x) {
+    float4 s = reinterpret_cast<const float4*>(r.partial)[q];
+    int z = 1;
+    for (; z + 4 <= r.used; z += 4) {  // four independent loads in flight, added in split order
+      const float4 v0 = reinterpret_cast<const float4*>(r.partial + (z + 0) * r.stride)[q];
+      const float4 v1 = reinterpret_cast<const float4*>(r.partial + (z + 1) * r.stride)[q];
+      const float4 v2 = reinterpret_cast<const float4*>(r.partial + (z + 2) * r.stride)[q];
+      const float4 v3 = reinterpret_cast<const float4*>(r.partial + (z + 3) * r.stride)[q];
+      s = f4_add(f4_add(f4_add(f4_add(s, v0), v1), v2), v3);
+    }
+    for (; z < r.used; ++z) s = f4_add(s, reinterpret_cast<const float4*>(r.partial + z * r.stride)[q]);
+    if (q < r.n4a) reinterpret_cast<float4*>(r.dw)[q] = s;
+    else reinterpret_cast<float4*>(r.db)[q - r.n4a] = s;
   }
-  hipStream_t st = (hipStream_t)stream;
+}
+
+// the split-K product of dW [n, k] = dy^T x (+ db as the ones column); job.used == 1: written in place, nothing left to fold
+int weight_product(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, float* db, int64_t m, int64_t k, int64_t n,
+                   void* ws, hipStream_t st, ReduceJob& job) {
   Carver cv(ws);
   const TileCfg cfg = weight_cfg(m);
   const bool split3 = weight_split(m);
@@ -879,23 +906,59 @@ int pgnn_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_
   p.ldc = k;
   p.split_stride = direct ? 0 : n * k + n;
   p.colsum = direct ? db : partial + n * k;
-  int rc;
+  job = ReduceJob{partial, used, n * k + n, dw, n * k / 4, db, db ? n / 4 : 0};
   if (split3 && big3)
-    rc = db ? launch_gemm3_s<320, 160, 4, 2, false, false, EPI_PLAIN, true>(p, used, st)
-            : launch_gemm3_s<320, 160, 4, 2, false, false, EPI_PLAIN, false>(p, used, st);
-  else if (split3)
-    rc = db ? launch_gemm3_s<64, 160, 4, 2, false, false, EPI_PLAIN, true>(p, used, st)
-            : launch_gemm3_s<64, 160, 4, 2, false, false, EPI_PLAIN, false>(p, used, st);
-  else
-    rc = db ? launch_cfg<false, false, EPI_PLAIN, true>(cfg, p, used, st)
-            : launch_cfg<false, false, EPI_PLAIN, false>(cfg, p, used, st);
-  if (rc) return rc;
-  if (!direct) {
-    const int64_t n4a = n * k / 4, n4b = db ? n / 4 : 0;
-    hipLaunchKernelGGL(k_splitk_reduce, dim3((int)std::min<int64_t>(ceil_div(n4a + n4b, 256), 1024)), dim3(256), 0, st,
-                       partial, used, n * k + n, dw, n4a, db, n4b);
+    return db ? launch_gemm3_s<320, 160, 4, 2, false, false, EPI_PLAIN, true>(p, used, st)
+              : launch_gemm3_s<320, 160, 4, 2, false, false, EPI_PLAIN, false>(p, used, st);
+  if (split3)
+    return db ? launch_gemm3_s<64, 160, 4, 2, false, false, EPI_PLAIN, true>(p, used, st)
+              : launch_gemm3_s<64, 160, 4, 2, false, false, EPI_PLAIN, false>(p, used, st);
+  return db ? launch_cfg<false, false, EPI_PLAIN, true>(cfg, p, used, st) : launch_cfg<false, false, EPI_PLAIN, false>(cfg, p, used, st);
+}
+}  // namespace
+
+int pgnn_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, float* db,
+                           int64_t m, int64_t k, int64_t n, void* ws, size_t ws_bytes, pgnn_stream stream) {
+  PGNN_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0,
+               "linear_bwd_weight: K, N and leading dimensions must be multiples of 4");
+  if (ws_bytes < pgnn_linear_bwd_weight_workspace_bytes(m, k, n)) {
+    set_error("linear_bwd_weight workspace too small");
+    return PGNN_ERR_WORKSPACE;
   }
+  hipStream_t st = (hipStream_t)stream;
+  ReduceJob job;
+  if (int rc = weight_product(dy, lddy, x, ldx, dw, db, m, k, n, ws, st, job)) return rc;
+  if (job.used > 1)
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((int)std::min<int64_t>(ceil_div(job.n4a + job.n4b, 256), 1024)), dim3(256), 0, st,
+                       job.partial, job.used, job.stride, dw, job.n4a, db, job.n4b);
   return check_launch("linear_bwd_weight");
+}
+
+int pgnn_linear_bwd_weight_pair(const float* dy_a, int64_t lddy_a, const float* x_a, int64_t ldx_a, float* dw_a, float* db_a, int64_t k_a,
+                                int64_t n_a, const float* dy_b, int64_t lddy_b, const float* x_b, int64_t ldx_b, float* dw_b, float* db_b,
+                                int64_t k_b, int64_t n_b, int64_t m, void* ws, size_t ws_bytes, pgnn_stream stream) {
+  PGNN_REQUIRE(m > 0 && k_a > 0 && n_a > 0 && k_b > 0 && n_b > 0 && (k_a | n_a | k_b | n_b | lddy_a | ldx_a | lddy_b | ldx_b) % 4 == 0,
+               "linear_bwd_weight_pair: K, N and leading dimensions must be multiples of 4");
+  const size_t wa = pgnn_linear_bwd_weight_workspace_bytes(m, k_a, n_a), wb = pgnn_linear_bwd_weight_workspace_bytes(m, k_b, n_b);
+  if (ws_bytes < wa + wb) {
+    set_error("linear_bwd_weight_pair workspace too small");
+    return PGNN_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  ReduceJobs jobs;
+  int rc;
+  if ((rc = weight_product(dy_a, lddy_a, x_a, ldx_a, dw_a, db_a, m, k_a, n_a, ws, st, jobs.j[0]))) return rc;
+  if ((rc = weight_product(dy_b, lddy_b, x_b, ldx_b, dw_b, db_b, m, k_b, n_b, static_cast<char*>(ws) + wa, st, jobs.j[1]))) return rc;
+  if (jobs.j[0].used > 1 && jobs.j[1].used > 1) {  // both split (the same m: they split together in practice)
+    const int64_t work = std::max(jobs.j[0].n4a + jobs.j[0].n4b, jobs.j[1].n4a + jobs.j[1].n4b);
+    hipLaunchKernelGGL(k_splitk_reduce_jobs, dim3((int)std::min<int64_t>(ceil_div(work, 256), 1024), 2), dim3(256), 0, st, jobs);
+  } else {
+    for (const ReduceJob& r : jobs.j)
+      if (r.used > 1)
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((int)std::min<int64_t>(ceil_div(r.n4a + r.n4b, 256), 1024)), dim3(256), 0, st, r.partial,
+                           r.used, r.stride, r.dw, r.n4a, r.db, r.n4b);
+  }
+  return check_launch("linear_bwd_weight_pair");
 }
 
 }  // extern "C"
