@@ -143,8 +143,13 @@ class GraphedChemMaskingStep:
     Optimizers must be built with ``capturable=True``.  Host-side scalars are frozen at capture time, which
     includes the fused-dropout seeds: use it with ``drop_ratio == 0`` only."""
 
-    def __init__(self, model_list, optimizer_list, batch, mask_edge=False, warmup=3):
+    def __init__(self, model_list, optimizer_list, batch, mask_edge=False, warmup=3, readback="end"):
         self.model_list, self.optimizer_list, self.batch, self.mask_edge = model_list, optimizer_list, batch, mask_edge
+        if readback not in ("end", "epoch"):
+            raise ValueError("readback must be 'end' or 'epoch'")
+        # readback="epoch": the captured step adds its numbers to self.accum (epoch_accumulator) and a replay fetches nothing;
+        # sums() reads and clears them
+        self.accum = epoch_accumulator(batch.x.device) if readback == "epoch" else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -154,13 +159,18 @@ class GraphedChemMaskingStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = self._core()
+        if self.accum is not None:
+            torch.cuda.synchronize()
+            self.accum.zero_()  # drop what the warm-up and the capture pass added
 
     def _core(self):
         model, linear_pred_atoms, linear_pred_bonds = self.model_list
         b = self.batch
         node_rep = model(b.x, b.edge_index, b.edge_attr)
-        if _fusable_head(linear_pred_atoms, node_rep):
-            loss, acc_node = ops.masked_head(node_rep, b.masked_atom_indices, linear_pred_atoms, b.mask_node_label[:, 0])
+        fused = _fusable_head(linear_pred_atoms, node_rep)
+        if fused:
+            loss, acc_node = ops.masked_head(node_rep, b.masked_atom_indices, linear_pred_atoms, b.mask_node_label[:, 0],
+                                             accum=self.accum if not self.mask_edge else None)
         else:
             pred_node = linear_pred_atoms(node_rep[b.masked_atom_indices])
             loss = F.cross_entropy(pred_node.double(), b.mask_node_label[:, 0])
@@ -178,12 +188,23 @@ class GraphedChemMaskingStep:
         loss.backward(_unit_grad(loss))
         for opt in self.optimizer_list:
             opt.step()
-        return torch.stack([loss.detach(), acc_node.double(), acc_edge.double()])
+        out = torch.stack([loss.detach(), acc_node.double(), acc_edge.double()])
+        if self.accum is not None and (not fused or self.mask_edge):
+            self.accum += torch.stack([out[0], out[1] / self.n_node, out[2] / self.n_edge, torch.ones_like(out[0])])
+        return out
 
     def __call__(self):
         self.graph.replay()
+        if self.accum is not None:
+            return None
         vals = self.out.cpu().tolist()
         return vals[0], vals[1] / self.n_node, vals[2] / self.n_edge
+
+    def sums(self):
+        """readback="epoch": (sum of loss, sum of node accuracy, sum of edge accuracy, replays) since the last call"""
+        vals = self.accum.cpu().tolist()
+        self.accum.zero_()
+        return vals
 
 
 def bio_masking_step(model_list, optimizer_list, batch, readback="end", accum=None):

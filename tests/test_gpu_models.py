@@ -272,6 +272,38 @@ def test_bio_epoch_sums_on_the_device_equal_the_per_step_read_back():
     assert outs[0] == outs[1], outs
 
 
+@pytest.mark.parametrize("readback", ["end", "epoch"])
+def test_hip_graph_replay_of_the_masking_step_equals_eager_steps(readback):
+    """train.GraphedChemMaskingStep (the step captured once into a HIP graph: the library's launches, its side-stream fork / join,
+    the device-side Adam step count) replays to the numbers of eager steps from the same state: 3 warm-up steps + 2 replays
+    against 5 eager steps, per-step read-back and sums kept on the device"""
+    import copy
+    from pretrain_gnns_amd import optim, train as ptrain
+    hchem, _ = _hip()
+    torch.manual_seed(11)
+    mods_a = [hchem.GNN(5, 300).to(DEV), torch.nn.Linear(300, 119).to(DEV), torch.nn.Linear(300, 4).to(DEV)]
+    mods_b = copy.deepcopy(mods_a)
+    b = synthetic.chem_masking_batch(24, seed=12).to(DEV)
+    opts_a = optim.Adam.shared([m.parameters() for m in mods_a], lr=1e-3)
+    eager = [ptrain.chem_masking_step(mods_a, opts_a, b) for _ in range(5)]
+    opts_b = optim.Adam.shared([m.parameters() for m in mods_b], lr=1e-3)
+    g = ptrain.GraphedChemMaskingStep(mods_b, opts_b, b, warmup=3, readback=readback)
+    if readback == "end":
+        got = [g(), g()]
+        for want, have in zip(eager[3:], got):
+            assert abs(want[0] - have[0]) <= 1e-6 * abs(want[0]) and abs(want[1] - have[1]) <= 1e-12, (eager, got)
+    else:
+        assert g() is None and g() is None
+        sums = g.sums()
+        assert sums[3] == 2.0
+        assert abs(sums[0] - (eager[3][0] + eager[4][0])) <= 1e-6 * abs(sums[0]), (eager, sums)
+        assert abs(sums[1] - (eager[3][1] + eager[4][1])) <= 1e-12
+        assert g.sums() == [0.0, 0.0, 0.0, 0.0]
+    for pa, pb in zip(mods_a[0].parameters(), mods_b[0].parameters()):
+        torch.testing.assert_close(pa, pb, rtol=1e-5, atol=1e-6)
+    assert int(opts_b[0].step_count) == 5
+
+
 def test_product_train_step_mirrors_oracle_step():
     """pretrain_gnns_amd.train (what bench.py times) == oracle.steps on the same HIP model, for both
     readback placements, including with torch's fused Adam."""
