@@ -95,7 +95,10 @@ class Adam:
             if set_to_none:
                 p.grad = None
             else:
-                p.grad.detach_()
+                if p.grad.grad_fn is not None:
+                    p.grad.detach_()
+                else:
+                    p.grad.requires_grad_(False)  # (a gradient that is a view -- parallel.GradBucket's -- cannot be detached in place)
                 p.grad.zero_()
 
     def step(self):

@@ -41,8 +41,8 @@ def broadcast_parameters(modules, src=0):
 
 
 class GradBucket:
-    """One flat buffer for all gradients of a parameter list; ``allreduce()`` = pack -> one
-    all_reduce(SUM) -> scale -> unpack.  ``weight`` (this rank's share of the global loss
+    """One flat buffer for all gradients of a parameter list; ``allreduce()`` = pack -> scale -> one
+    all_reduce(SUM) (RCCL: one all_reduce(AVG)) -> ``p.grad`` = the bucket's views.  ``weight`` (this rank's share of the global loss
     normaliser, e.g. local_masked/global_masked) reproduces the single-process big-batch gradient
     exactly; the default 1/world_size is the usual DDP mean."""
 
@@ -65,13 +65,20 @@ class GradBucket:
             return
         world = dist.get_world_size()
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-        torch._foreach_copy_(self.views, grads)
-        self.flat.mul_(weight if weight is not None else 1.0 / world)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        for p, g in zip(self.params, grads):
-            if p.grad is None:
-                p.grad = g
-        torch._foreach_copy_(grads, self.views)  # one multi-tensor kernel back into the .grad tensors
+        src, dst = [], []
+        for v, g in zip(self.views, grads):
+            if g.data_ptr() != v.data_ptr():  # (a gradient kept from the last step already lives in the bucket)
+                src.append(g)
+                dst.append(v)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        if weight is None and dist.get_backend() == "nccl":
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)  # RCCL scales each contribution by 1/world itself: no launch for it
+        else:
+            self.flat.mul_(weight if weight is not None else 1.0 / world)
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        for p, v in zip(self.params, self.views):
+            p.grad = v  # the reduced gradients stay where they are: the optimizers read the bucket, nothing is copied back
 
 
 class AllReduceOptimizers:

@@ -298,24 +298,63 @@ def contextpred_logits(model_substruct, model_context, batch, neg_samples=1, mod
 
 
 def chem_contextpred_step(model_substruct, model_context, optimizer_substruct, optimizer_context, batch, neg_samples=1,
-                          mode="cbow", pool=None):
+                          mode="cbow", pool=None, readback="end", accum=None):
     """One iteration of chem/pretrain_contextpred.py:51-100 (bio/pretrain_contextpred.py:46-95 is the same body);
-    defaults = the reference's defaults (cbow, mean context pooling, one negative sample)."""
+    defaults = the reference's defaults (cbow, mean context pooling, one negative sample).  readback="epoch": the two numbers
+    train() adds up on the host (:99-100) are added to ``accum`` (``epoch_accumulator``: [balanced loss sum, accuracy sum, -,
+    steps]) on the device instead -- same float64 operations -- and nothing is fetched; returns None."""
+    if readback not in ("end", "epoch"):
+        raise ValueError("readback must be 'end' or 'epoch'")
+    if readback == "epoch" and accum is None:
+        raise ValueError("readback='epoch' needs accum=epoch_accumulator(device)")
     pred_pos, pred_neg = contextpred_logits(model_substruct, model_context, batch, neg_samples, mode, pool)
     loss_pos = F.binary_cross_entropy_with_logits(pred_pos.double(), torch.ones_like(pred_pos).double())
     loss_neg = F.binary_cross_entropy_with_logits(pred_neg.double(), torch.zeros_like(pred_neg).double())
     optimizer_substruct.zero_grad()
     optimizer_context.zero_grad()
     loss = loss_pos + neg_samples * loss_neg
-    loss.backward()
+    loss.backward(_unit_grad(loss))
     optimizer_substruct.step()
     optimizer_context.step()
     vals = torch.stack([loss_pos.detach(), loss_neg.detach(), torch.sum(pred_pos > 0).double() / len(pred_pos),
-                        torch.sum(pred_neg < 0).double() / len(pred_neg)]).cpu().tolist()
+                        torch.sum(pred_neg < 0).double() / len(pred_neg)])
+    if readback == "epoch":
+        one = torch.ones((), dtype=torch.float64, device=vals.device)
+        accum += torch.stack([vals[0] + vals[1], 0.5 * (vals[2] + vals[3]), one - one, one])
+        return None
+    vals = vals.cpu().tolist()
     return vals[0] + vals[1], 0.5 * (vals[2] + vals[3])
 
 
+def chem_contextpred_epoch(model_substruct, model_context, optimizer_substruct, optimizer_context, loader, neg_samples=1, mode="cbow",
+                           pool=None, device=None, readback="epoch"):
+    """train() of chem/pretrain_contextpred.py:43-102 (bio: :39-97): one pass over ``loader``; returns (balanced_loss_accum / step,
+    acc_accum / step) with the reference's divisor, the last step index.  Sums on the device by default, one fetch per epoch."""
+    model_substruct.train()
+    model_context.train()
+    loss_accum = acc_accum = 0.0
+    step = 0
+    accum = None
+    for step, batch in enumerate(loader):
+        if device is not None:
+            batch = batch.to(device)
+        if readback == "epoch":
+            if accum is None:
+                accum = epoch_accumulator(batch.x_substruct.device)
+            chem_contextpred_step(model_substruct, model_context, optimizer_substruct, optimizer_context, batch, neg_samples, mode, pool,
+                                  readback, accum)
+            continue
+        loss, acc = chem_contextpred_step(model_substruct, model_context, optimizer_substruct, optimizer_context, batch, neg_samples,
+                                          mode, pool, readback)
+        loss_accum += loss
+        acc_accum += acc
+    if accum is not None:
+        loss_accum, acc_accum, _, _ = accum.cpu().tolist()
+    return loss_accum / step, acc_accum / step
+
+
 bio_contextpred_step = chem_contextpred_step  # bio/pretrain_contextpred.py:39-102: same loop body, bio GNN classes
+bio_contextpred_epoch = chem_contextpred_epoch
 
 
 def chem_finetune_step(model, optimizer, batch):

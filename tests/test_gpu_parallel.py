@@ -144,3 +144,48 @@ def test_two_ranks_on_one_gpu(tmp_path):
             scale = max(float(g.abs().max()) for g in r[key_single])
             for g, ref in zip(r[key_dp], r[key_single]):
                 assert float((g - ref).abs().max()) <= tol * scale, (key_dp, float((g - ref).abs().max()), scale)
+
+
+def _rccl_single_rank_worker(port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", PGNN_DP_FORCE_INIT="1")
+    os.environ.pop("PGNN_DP_BACKEND", None)
+    import copy
+    import torch.distributed as dist
+    from pretrain_gnns_amd import ops, optim, parallel
+    from pretrain_gnns_amd import train as ptrain
+    from pretrain_gnns_amd.chem import model as hchem
+    from pretrain_gnns_amd.data import synthetic
+
+    parallel.init_from_env()
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    dev = torch.device("cuda", 0)
+    ops.set_direct_grads(True)
+    torch.manual_seed(3)
+    mods_a = [hchem.GNN(5, 300).to(dev), torch.nn.Linear(300, 119).to(dev), torch.nn.Linear(300, 4).to(dev)]
+    mods_b = copy.deepcopy(mods_a)
+    batches = [synthetic.chem_masking_batch(12 + i, seed=30 + i).to(dev) for i in range(3)]
+    plain = optim.Adam.shared([m.parameters() for m in mods_a], lr=1e-3)
+    dp = parallel.AllReduceOptimizers(optim.Adam.shared([m.parameters() for m in mods_b], lr=1e-3))
+    out_a = [ptrain.chem_masking_step(mods_a, plain, b) for b in batches]
+    out_b = [ptrain.chem_masking_step(mods_b, list(dp), b) for b in batches]
+    same = all(torch.equal(pa, pb) for ma, mb in zip(mods_a, mods_b) for pa, pb in zip(ma.parameters(), mb.parameters()))
+    in_bucket = all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(dp.bucket.params, dp.bucket.views))
+    torch.save({"out_a": out_a, "out_b": out_b, "same": same, "in_bucket": in_bucket, "report": parallel.comm_report(dp)}, out_path)
+    dist.destroy_process_group()
+
+
+def test_single_rank_rccl_step_equals_the_plain_step(tmp_path):
+    """the data-parallel wrapper on the RCCL backend itself (one rank: the collective runs, averages over one contribution and
+    leaves the gradients in the bucket, where the one-launch Adam reads them): parameters after three steps are bit-identical
+    to the un-wrapped optimizers', the step's numbers equal, and comm_report names the backend"""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "rccl1.pt")
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_rccl_single_rank_worker, args=(_free_port(), out))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    res = torch.load(out)
+    assert res["same"] and res["in_bucket"], res
+    assert res["out_a"] == res["out_b"]
+    assert res["report"]["backend"] == "nccl" and res["report"]["world"] == 1 and res["report"]["bucket_bytes"] > 7e6

@@ -20,12 +20,13 @@ opts = bench.make_optimizers(mods)
 for m in mods:
     m.train()
 batches = [b for b in loader]
+accum = steps.epoch_accumulator(dev)
 for b in batches[:3]:
-    steps.bio_masking_step(mods, opts, b)
+    steps.bio_masking_step(mods, opts, b, readback="epoch", accum=accum)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(n_steps):
-    steps.bio_masking_step(mods, opts, batches[i % len(batches)])
+    steps.bio_masking_step(mods, opts, batches[i % len(batches)], readback="epoch", accum=accum)
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
