@@ -630,7 +630,30 @@ def cpu_baseline(graphs, seconds):
                       % (n, graphs, e, el), "also": also}
 
 
+class _StdoutToStderr:
+    """Everything a run prints besides its ONE JSON line goes to stderr -- RCCL writes a version banner to fd 1 when the first
+    communicator is created, which would otherwise precede the line the driver parses."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def main():
+    with _StdoutToStderr():
+        line = _run()
+    if line is not None:
+        print(line, flush=True)
+
+
+def _run():
     args = parse()
     from pretrain_gnns_amd import parallel
     from pretrain_gnns_amd.data import synthetic
@@ -645,9 +668,7 @@ def main():
     torch.cuda.set_device(dev)
 
     if args.roofline_only:
-        print(json.dumps({"roofline": roofline_aggregation(dev, args.roofline_graphs),
-                          "roofline_mlp": roofline_mlp(dev, 262144)}), flush=True)
-        return
+        return json.dumps({"roofline": roofline_aggregation(dev, args.roofline_graphs), "roofline_mlp": roofline_mlp(dev, 262144)})
     mods = make_models(dev)
     parallel.broadcast_parameters(mods)
     opts = make_optimizers(mods, args.adam)
@@ -701,6 +722,7 @@ def main():
         dist.all_reduce(etot, op=dist.ReduceOp.SUM)
     elapsed, edges_total = float(tmax.item()), float(etot.item())
 
+    line = None
     if rank == 0:
         res = {
             "metric": "edges/sec through 5-layer GIN (emb_dim=300) masking pre-train step (fwd+bwd+Adam)",
@@ -736,10 +758,11 @@ def main():
             res["bio_masking"] = bio_leg(dev, args, max(args.steps // 5, 10), not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.graphs_per_gpu, args.cpu_seconds)
-        print(json.dumps(res), flush=True)
+        line = json.dumps(res)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    return line
 
 
 if __name__ == "__main__":
