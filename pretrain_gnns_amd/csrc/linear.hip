@@ -395,6 +395,9 @@ struct KMajorTile {
   }
 };
 
+// (64-deep k-steps -- two 32-deep slice images per barrier pair, PGNN_GEMM3_KS=2 of a round-2 experiment -- measured SLOWER: the
+// 256-graph step 1.313 against 1.189 ms.  With K = 300 / 600 a tile has 10 / 19 steps; halving them doubles the prologue (two
+// slices fetched and split before the first MFMA) and the registers held across the loop, which costs more than the barriers saved.)
 // One kernel, four operand-layout instantiations: forward / backward-data on transposed weights (both k-contiguous),
 // backward-data (dy k-contiguous, W row-contiguous), backward-weight (both row-contiguous, split over k = rows, optional
 // ones column for the bias gradient).
