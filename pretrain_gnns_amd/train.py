@@ -241,8 +241,9 @@ def bio_masking_step(model_list, optimizer_list, batch, readback="end", accum=No
 
 
 def bio_masking_epoch(model_list, optimizer_list, loader, device=None, readback="epoch"):
-    """train() of bio/pretrain_masking.py:29-62: one pass over ``loader``; returns (loss_accum / step, acc_accum / step)
-    with the reference's divisor (the last step index, :62).  Sums on the device by default, as in ``chem_masking_epoch``."""
+    """train() of bio/pretrain_masking.py:29-66: one pass over ``loader``; returns (loss_accum / (step + 1), acc_accum / (step + 1))
+    -- the bio script divides by the step COUNT (:66), the chem one by the last step index.  Sums on the device by default, as
+    in ``chem_masking_epoch``."""
     for m in model_list:
         m.train()
     loss_accum = acc_accum = 0.0
@@ -261,7 +262,7 @@ def bio_masking_epoch(model_list, optimizer_list, loader, device=None, readback=
         acc_accum += acc
     if accum is not None:
         loss_accum, _, acc_accum, _ = accum.cpu().tolist()
-    return loss_accum / step, acc_accum / step
+    return loss_accum / (step + 1), acc_accum / (step + 1)
 
 
 def cycle_index(num, shift):

@@ -96,10 +96,11 @@ def test_oracle_forward_backward_equals_reference(name, gnn_type):
 @pytest.mark.parametrize("name,tag,gnn_type,mask_edge", [
     ("ref_chem_masking_train_b32", "gin", "gin", 0), ("ref_chem_masking_train_b32", "gin_mask_edge", "gin", 1),
     ("ref_chem_masking_train_b32", "gcn", "gcn", 0), ("ref_chem_masking_train_b256", "gin", "gin", 0)])
-@pytest.mark.parametrize("driver", ["oracle_steps", "product_mirror"])
+@pytest.mark.parametrize("driver", ["oracle_steps", "product_mirror", "product_mirror_end", "product_mirror_epoch"])
 def test_train_mirrors_reproduce_reference_train(name, tag, gnn_type, mask_edge, driver):
     """chem/pretrain_masking.py:34-78 run by the reference itself vs (a) oracle/steps.py, (b) the product's
-    pretrain_gnns_amd/train.py mirror -- both driven with the CPU oracle modules on the same batches"""
+    pretrain_gnns_amd/train.py mirror in each of its read-back modes (where the reference reads; once per step; sums kept in
+    tensors and read once per epoch) -- all driven with the CPU oracle modules on the same batches"""
     fx = rf.load(name)
     want = fx[tag]
     batches = rf.masked_batches(fx, tag, bool(mask_edge))
@@ -108,7 +109,8 @@ def test_train_mirrors_reproduce_reference_train(name, tag, gnn_type, mask_edge,
     if driver == "oracle_steps":
         ret = steps.chem_masking_epoch(models, opts, batches, mask_edge=bool(mask_edge))
     else:
-        ret = ptrain.chem_masking_epoch(models, opts, batches, mask_edge=bool(mask_edge), readback="inline")
+        mode = {"product_mirror": "inline", "product_mirror_end": "end", "product_mirror_epoch": "epoch"}[driver]
+        ret = ptrain.chem_masking_epoch(models, opts, batches, mask_edge=bool(mask_edge), readback=mode)
     np.testing.assert_allclose(np.array(ret), want["returned"].numpy(), rtol=2e-6, atol=1e-9)
     rf.check_params(list(models[0].named_parameters()), want["final_params"], lambda p: p, rtol=2e-5)
     close(models[1].weight.detach(), want["final_head_weight"], 2e-5, 1e-6)
@@ -236,6 +238,11 @@ def test_contextpred_mirrors_reproduce_reference_train(name, mode, driver):
                                    want["returned"].numpy(), rtol=1e-9)  # divides by the last step index (:102)
         rf.check_params(list(ms.named_parameters()), want["final_params_substruct"], lambda p: p, rtol=1e-6)
         rf.check_params(list(mc.named_parameters()), want["final_params_context"], lambda p: p, rtol=1e-6)
+        if driver == "product_mirror":  # the epoch function in both read-back modes: the pair the reference's train() returns
+            for rb in ("end", "epoch"):
+                ms, mc, os_, oc = fresh()
+                ret = ptrain.chem_contextpred_epoch(ms, mc, os_, oc, ref_batches, mode=mode, pool=pyg.global_mean_pool, readback=rb)
+                np.testing.assert_allclose(np.array(ret), want["returned"].numpy(), rtol=1e-9)
     graphs = rf.context_graphs(fx)
     ms, mc, os_, oc = fresh()
     l0, _ = step(ms, mc, os_, oc, synthetic.collate_substruct_context(graphs[:bs]))
@@ -307,6 +314,11 @@ def test_bio_masking_equals_reference(name, types):
             np.testing.assert_allclose([np.mean([o[0] for o in out]), np.mean([o[1] for o in out])],
                                        want["train"]["returned"].numpy(), rtol=1e-5)  # bio divides by step + 1 (:66)
             rf.check_params(list(models[0].named_parameters()), want["train"]["final_params"], lambda p: p, rtol=5e-5)
+        for mode in ("end", "epoch"):  # the epoch function: the reference's returned pair, divisor step + 1 (:66)
+            torch.manual_seed(0)
+            models = [obio.GNN(5, 300, JK="last", drop_ratio=0, gnn_type=gt), torch.nn.Linear(300, 7)]
+            ret = ptrain.bio_masking_epoch(models, [adam(m.parameters()) for m in models], batches, readback=mode)
+            np.testing.assert_allclose(np.array(ret), want["train"]["returned"].numpy(), rtol=1e-5)
 
 
 @pytest.mark.parametrize("name", ["ref_bio_contextpred_b8", "ref_bio_contextpred_b64"])
