@@ -1,7 +1,7 @@
 """soak: many train steps over variable-shape batches from the resident loader; watches loss, memory, status."""
 import os, sys, time, torch, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-from pretrain_gnns_amd import train as steps
+from pretrain_gnns_amd import ops, optim, train as steps
 from pretrain_gnns_amd.chem import model as hmodel
 from pretrain_gnns_amd.data import resident, synthetic
 dev = "cuda"
@@ -11,7 +11,8 @@ ds = resident.ResidentDataset.from_graphs(graphs, dev)
 loader = resident.ResidentLoader(ds, 256, shuffle=True, seed=1, mask_rate=0.15, drop_last=True)
 torch.manual_seed(0)
 mods = [hmodel.GNN(5, 300).to(dev), torch.nn.Linear(300, 119).to(dev), torch.nn.Linear(300, 4).to(dev)]
-opts = [torch.optim.Adam(m.parameters(), lr=1e-3, fused=True) for m in mods]
+ops.set_direct_grads(True)
+opts = optim.Adam.shared([m.parameters() for m in mods], lr=1e-3)  # what bench.py builds
 t0 = time.perf_counter(); n = 0; edges = 0
 for epoch in range(12):
     if epoch == 1:  # epoch 0 carries module loads and allocator warm-up
