@@ -289,3 +289,27 @@ def test_shared_adam_handles_issue_one_launch_per_round(monkeypatch):
     assert params[1][0].grad is None and params[0][0].grad is not None
     handles[0].zero_grad(set_to_none=False)
     assert params[0][0].grad is not None and float(params[0][0].grad.abs().sum()) == 0.0
+
+
+def test_bench_keeps_stdout_to_its_one_json_line():
+    """bench.py's contract is ONE JSON line on stdout; whatever libraries print while it runs (RCCL writes a version banner to
+    fd 1 when its first communicator is created) is diverted to stderr by bench._StdoutToStderr, at the file-descriptor level"""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); import bench\n"
+            "with bench._StdoutToStderr():\n"
+            "    print('python-level noise'); os.write(1, b'fd-level noise\\n')\n"
+            "print('{\"the\": \"line\"}')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout == '{"the": "line"}\n'
+    assert "python-level noise" in p.stderr and "fd-level noise" in p.stderr
+
+
+def test_epoch_readback_needs_an_accumulator_and_known_modes():
+    """host-side contract of the read-back modes (the arithmetic is pinned in tests/test_cpu_reference.py)"""
+    from pretrain_gnns_amd import train as ptrain
+    acc = ptrain.epoch_accumulator("cpu")
+    assert acc.dtype == torch.float64 and acc.shape == (4,) and float(acc.abs().sum()) == 0.0
+    with pytest.raises(ValueError):
+        ptrain.GraphedChemMaskingStep.__init__(object.__new__(ptrain.GraphedChemMaskingStep), [], [], None, readback="inline")
