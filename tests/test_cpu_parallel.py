@@ -61,6 +61,17 @@ def _worker(rank, world, port, out_dir):
     for o in dp:
         o.step()
     after = [p.detach().clone() for p in list(model.parameters()) + list(head.parameters())]
+    # the reduced gradients were not copied back: p.grad IS the bucket's view
+    in_bucket = all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(dp.bucket.params, dp.bucket.views))
+    # second step without dropping the gradients: zero in place (the views), backward accumulates into the bucket directly
+    for o in dp:
+        o.zero_grad(set_to_none=False)
+    zeroed = float(dp.bucket.flat.abs().sum()) == 0.0
+    _loss(model, head, local).backward()
+    still_in_bucket = all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(dp.bucket.params, dp.bucket.views))
+    for o in dp:
+        o.step()
+    after2 = [p.detach().clone() for p in list(model.parameters()) + list(head.parameters())]
 
     # single-process reference on the whole batch, from the same (broadcast) weights
     ref_model, ref_head = ochem.GNN(3, 32), torch.nn.Linear(32, 119)
@@ -71,7 +82,7 @@ def _worker(rank, world, port, out_dir):
         p.data.copy_(b)
     ref_model.eval()
     _loss(ref_model, ref_head, whole).backward()
-    torch.save({"before": before, "after": after,
+    torch.save({"before": before, "after": after, "after2": after2, "flags": (in_bucket, zeroed, still_in_bucket),
                 "ref_grads": [p.grad if p.grad is not None else torch.zeros_like(p)
                               for p in list(ref_model.parameters()) + list(ref_head.parameters())],
                 "bucket_bytes": dp.bucket.nbytes}, os.path.join(out_dir, "rank%d.pt" % rank))
@@ -90,6 +101,11 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
         assert torch.equal(a, b)
     for a, b in zip(r0["after"], r1["after"]):
         assert torch.equal(a, b)
+    # gradients stay in the bucket; a second step on gradients zeroed in place keeps the ranks identical and moves the weights
+    assert r0["flags"] == (True, True, True) and r1["flags"] == (True, True, True)
+    for a, b in zip(r0["after2"], r1["after2"]):
+        assert torch.equal(a, b)
+    assert any(not torch.equal(a, b) for a, b in zip(r0["after"], r0["after2"]))
     # SGD step == lr * (sum over ranks of local grads) == lr * whole-batch grad
     for before, after, g in zip(r0["before"], r0["after"], r0["ref_grads"]):
         torch.testing.assert_close((before - after) / 0.1, g, rtol=2e-4, atol=2e-5)
