@@ -404,20 +404,23 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
       if ((rc = pgnn_linear_bwd_data(dz[b], dim, p.w2, hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main))) return rc;
       if ((rc = pgnn_linear_bwd_data(dhid[b], 2 * dim, p.w1, nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main))) return rc;
     }
+    if (sd) PGNN_HIP(hipEventRecord(sd->fork[1], main));
+    // the bottom layer's edge-table gradient stays on the caller's stream: the side stream is the longer of the two there
+    // (two weight-gradient products behind the data products), and the caller's stream only has the embedding gradients left
+    const bool demb_on_main = sd && l == 0;
+    // The caller's stream is the critical path: its transposed aggregation is enqueued BEFORE the side stream's five launches
+    // (it reads dagg, which they only read, and writes dx, which they never touch), so that stream is never waiting for the host.
     if (sd) {
-      PGNN_HIP(hipEventRecord(sd->fork[1], main));
+      if ((rc = pgnn_neighbor_sum(dagg[b], dim, out_ptr, out_dst, nullptr, dxb[b], dim, n, dim, main))) return rc;
+      if (demb_on_main && (rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, op, opb, main))) return rc;
       PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[1], 0));
     }
     if ((rc = pgnn_linear_bwd_weight_pair(dz[b], dim, hd, 2 * dim, p.dw2, p.db2, 2 * dim, dim, dhid[b], 2 * dim, agg, dim, p.dw1, p.db1,
                                           dim, 2 * dim, n, aux_ws, opb, aux)))  // both products, one fold of the split-K partials
       return rc;
-    // the bottom layer's edge-table gradient stays on the caller's stream: the side stream is the longer of the two there
-    // (two weight-gradient products behind the data products), and the caller's stream only has the embedding gradients left
-    const bool demb_on_main = sd && l == 0;
     if (!demb_on_main && (rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, aux_ws, opb, aux))) return rc;
     if (sd && !per_layer && l >= 2) PGNN_HIP(hipEventRecord(sd->lag[b], aux));  // awaited by layer l-2 only
-    if ((rc = pgnn_neighbor_sum(dagg[b], dim, out_ptr, out_dst, nullptr, dxb[b], dim, n, dim, main))) return rc;
-    if (demb_on_main && (rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, op, opb, main))) return rc;
+    if (!sd && (rc = pgnn_neighbor_sum(dagg[b], dim, out_ptr, out_dst, nullptr, dxb[b], dim, n, dim, main))) return rc;
     g = dxb[b];
     ldg = dim;
   }
