@@ -249,6 +249,22 @@ int pgnn_linear_bwd_data_t(const float* dy, int64_t lddy, const float* wt, const
 int pgnn_transpose_batch(const float* const* src, float* const* dst, const int64_t* rows, const int64_t* cols, int64_t count,
                          pgnn_stream stream);
 
+/* Products on PRE-SPLIT weights (round 3; nn.Linear of chem/model.py:29,54-55, forward and backward-data).  The weights of a
+ * layer stack are constant within a pass, so their three-term bf16 split (and, for the backward, their transposition) is done
+ * once per pass by pgnn_split_weights instead of by every workgroup in every k-step: planes [3][rows][ld] of bf16, ld = cols
+ * rounded up to 32, zero beyond cols (pgnn_weight_planes_bytes bytes per matrix).  transpose[j] != 0: the planes of src[j]^T.
+ * count <= 32 matrices per launch (host arrays of device pointers / sizes). */
+size_t pgnn_weight_planes_bytes(int64_t rows, int64_t cols);
+int pgnn_split_weights(const float* const* src, void* const* dst, const int64_t* rows, const int64_t* cols, const int32_t* transpose,
+                       int64_t count, pgnn_stream stream);
+/* pgnn_linear_fwd / pgnn_linear_fwd_colstats (colstat may be NULL) with wplanes = the planes of W [n, k]; bit-identical to them
+ * wherever they run the split-bf16 kernel: the activations reach LDS by DMA as fp32 and are split by the consuming wave */
+int pgnn_linear_fwd_wp(const float* x, int64_t ldx, const void* wplanes, const float* bias, float* y, int64_t ldy, int64_t m,
+                       int64_t k, int64_t n, int relu, float* colstat, pgnn_stream stream);
+/* pgnn_linear_bwd_data_t with wtplanes = the planes of W^T [k, n] */
+int pgnn_linear_bwd_data_wp(const float* dy, int64_t lddy, const void* wtplanes, const float* relu_out, int64_t ldr, float* dx,
+                            int64_t lddx, int64_t m, int64_t k, int64_t n, pgnn_stream stream);
+
 /* dW[N,K] = dy[M,N]^T . x[M,K] ; db[N] = column sums of dy (db may be NULL).  Split over M with a
  * deterministic second-pass reduction. */
 size_t pgnn_linear_bwd_weight_workspace_bytes(int64_t m, int64_t k, int64_t n);
@@ -555,6 +571,11 @@ int pgnn_debug_stream_copy(const float* src, float* dst, int64_t n_floats, int64
  * with shader-cycle totals per block: {loader vmcnt wait, loader barrier, loader issue, consumer barrier, consumer
  * work, block total, steps, 0}.  NULL detaches.  Not part of the hot path. */
 int pgnn_debug_aggregate_profile(uint64_t* buffer, int64_t blocks);
+/* Instrumented build of the pre-split-weights product (pgnn_linear_fwd_wp with ReLU; cfg as PGNN_GEMM3W_CFG 0 / 1 / 5 / 6): lane 0
+ * of every wave of the first 8 workgroups writes buffer[workgroup][wave][8] = shader-cycle totals {wait + barrier, DMA issue,
+ * A split, multiply, loop total, k-steps, 0, 0}.  Not part of the hot path. */
+int pgnn_debug_gemm3w_profile(const float* x, int64_t ldx, const void* wplanes, const float* bias, float* y, int64_t ldy, int64_t m,
+                              int64_t k, int64_t n, int cfg, uint64_t* buffer, pgnn_stream stream);
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,11 @@ PROTOTYPES = {
     "pgnn_linear_fwd_colstats": (_i, [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _p, _p]),
     "pgnn_bn_stats_fwd_blocks": (_i, [_p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i64, _i64, _p]),
     "pgnn_bn_apply_fwd": (_i, [_p, _i64, _p, _i, _p, _i64, _f, _u64, _i64, _i64, _p]),
+    "pgnn_debug_gemm3w_profile": (_i, [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _p, _p]),
+    "pgnn_weight_planes_bytes": (_sz, [_i64, _i64]),
+    "pgnn_split_weights": (_i, [_p, _p, _p, _p, _p, _i64, _p]),
+    "pgnn_linear_fwd_wp": (_i, [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _p, _p]),
+    "pgnn_linear_bwd_data_wp": (_i, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p]),
     "pgnn_linear_bwd_data": (_i, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p]),
     "pgnn_bio_gin_stack_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "pgnn_bio_gin_stack_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _i64, _p, _sz, _p]),

@@ -46,6 +46,9 @@ struct GemmArgs {
   float* colstat;      // EPI_BIAS, optional: [ceil(M/16)][2][N] per 16-row block: column sums of C and sums of squared deviations
                        // from the block's own column mean (what a BatchNorm behind this product needs; see pgnn_linear_fwd_colstats)
   int nxcd;            // XCDs of the device (block -> tile remap)
+  unsigned long long* dbg;   // k_gemm3w<DBG>: phase cycle totals
+  const unsigned short* Bp;  // k_gemm3w: B as three pre-split bf16 planes [3][rows][ldbp], zero beyond K up to ldbp
+  int64_t ldbp, bplane;      //           row pitch and plane pitch in bf16 elements
 };
 
 enum { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_MASK = 2 };
@@ -176,6 +179,12 @@ __device__ __forceinline__ void gemm_wait_vmcnt(int n) {
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 #undef PGNN_W
+}
+
+template <int N>
+__device__ __forceinline__ void gemm_wait_vmcnt_imm() {
+  static_assert(N >= 0 && N < 64, "vmcnt immediate");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // KSS encodes the k-step depth and the ring depth: 1 / 2 = KS images per barrier with a 2-stage ring; 11 / 12 = one image per
@@ -574,6 +583,370 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3(GemmArgs p) {
   else gemm_epilogue<EPI, ONES, MI, NI>(p, acc, m0 + wm0, n0 + wn0, lane);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same arithmetic with every in-loop staging instruction gone (round 3): C = A . B^T, both operands contiguous along k,
+//   A  fp32 activations, DMA'd (global_load_lds) as they lie into a [row][32 k] fp32 image (128-byte rows, 16-byte chunks
+//      XOR-swizzled by (row & 6) | (row >> 3) through the DMA's per-lane SOURCE address: both ds_read_b128 of a fragment are
+//      conflict-free over the instruction's 16-lane groups, brute-forced over the bank map) and split into its three bf16
+//      terms by the CONSUMER wave, on its 16 x 32 fragment, between the LDS read and the MFMAs (44 VALU per fragment against
+//      the 30 MFMAs = 480 matrix-pipe cycles it feeds at a 16 x 80 wave tile);
+//   B  weights, split ONCE per step into three zero-padded bf16 planes by pgnn_split_weights (k_split_jobs below) and DMA'd
+//      into the [row][32 k] bf16 images of k_gemm3 (same swizzle, same fragment reads).
+// No VGPR staging, no v_cvt / ds_write in front of a barrier: a k-step is wait(counted vmcnt) -> s_barrier -> DMA issue of step
+// t + STAGES - 1 -> fragment reads + split + MFMAs, over a 3- or 4-deep LDS ring (38 / 46 KB per stage at 64x160 / 128x160).
+// Every output element sees the same terms in the same order as in k_gemm3: the two kernels are bit-identical.
+__device__ __forceinline__ uint64_t gemm_clock() {
+  uint64_t t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+// DBG (pgnn_debug_gemm3w_profile only): lane 0 of every wave of the first 8 workgroups accumulates s_memtime deltas of its
+// phases -- wait + barrier, DMA issue, A split, multiply -- into p.dbg [8 workgroups][NW][8] = {wait, issue, split, mma, total}
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, bool PP, bool DBG = false>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_waves_per_eu(2, 2))) k_gemm3w(GemmArgs p) {
+  constexpr int BK = 32;
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int MI = WM / 16, NI = WN / 16;
+  static_assert(WM % 16 == 0 && WN % 16 == 0 && BM % 16 == 0 && BN % 16 == 0, "tile shape");
+  constexpr int A_BYTES = BM * 128, B_PLANE = BN * 64, STAGE = A_BYTES + 3 * B_PLANE;
+  constexpr int PA = BM / 8, PB = BN / 16;       // 1-KiB DMA pieces: 8 fp32 rows / 16 bf16 rows each
+  constexpr int NP = PA + 3 * PB, NJ = (NP + NW - 1) / NW;
+
+  extern __shared__ __align__(16) unsigned char smem3w[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: piece selection compiles to scalar code
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x, p.nxcd);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int nk = (p.K + BK - 1) / BK;
+
+  // ---- this wave's DMA pieces: piece d < PA = rows 8 d .. 8 d + 7 of the A image, else 16 rows of one B plane.  Every wave
+  // issues exactly NJ pieces per k-step (the counted vmcnt below is then a compile-time immediate): a wave whose last slot falls
+  // beyond NP repeats piece NP - 1 -- the same bytes to the same LDS address as its owner, harmless.
+  const unsigned char* src[NJ];  // this lane's source for the k-step about to be issued
+  int kofs[NJ];                  // A pieces: first k of this lane's chunk inside a k-step (for the K edge)
+  int dpiece[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int d = min(wave + j * NW, NP - 1);
+    dpiece[j] = d;
+    kofs[j] = 0;
+    if (d < PA) {
+      const int row = 8 * d + (lane >> 3);
+      const int c = (lane & 7) ^ (((lane >> 3) & 6) | (d & 1));  // logical 16-byte chunk stored at position lane & 7
+      kofs[j] = 4 * c;
+      src[j] = reinterpret_cast<const unsigned char*>(p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + 4 * c);
+    } else {
+      const int q = (d - PA) / PB, pb = (d - PA) % PB;
+      const int row = 16 * pb + (lane >> 2);
+      const int c = (lane & 3) ^ ((-(lane >> 4)) & 3);
+      src[j] = reinterpret_cast<const unsigned char*>(p.Bp + q * p.bplane + (int64_t)min(n0 + row, p.N - 1) * p.ldbp + 8 * c);
+    }
+  }
+
+  const unsigned char* const zero_src = reinterpret_cast<const unsigned char*>(g_zero_page);  // (its address is a scalar LOAD: once, here)
+  auto issue = [&](int stage, int it) {
+    unsigned char* st = smem3w + stage * STAGE;
+    const int k0 = it * BK;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int d = dpiece[j];
+      if (d < PA) {
+        const unsigned char* g = (k0 + kofs[j] < p.K) ? src[j] : zero_src;
+        __builtin_amdgcn_global_load_lds(PGNN_GPTR(g), PGNN_LPTR(st + d * 1024), 16, 0, 0);
+        src[j] += BK * 4;
+      } else {
+        __builtin_amdgcn_global_load_lds(PGNN_GPTR(src[j]), PGNN_LPTR(st + A_BYTES + (d - PA) * 1024), 16, 0, 0);
+        src[j] += BK * 2;
+      }
+    }
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+  const int fr = lane & 15, fk = lane >> 4;
+  const int a_off = (wm0 + fr) * 128, a_lo = (((2 * fk) ^ ((fr & 6) | (fr >> 3))) * 16), a_hi = (((2 * fk + 1) ^ ((fr & 6) | (fr >> 3))) * 16);
+  const int b_off = (wn0 + fr) * 64 + ((fk ^ ((-(fr >> 2)) & 3)) * 16);
+
+  auto aload = [&](int stage, f32x4 (&lo)[MI], f32x4 (&hi)[MI]) {  // raw fp32 A fragment: two ds_read_b128 per 16 rows
+    const unsigned char* sa = smem3w + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      lo[i] = *reinterpret_cast<const f32x4*>(sa + a_off + i * 16 * 128 + a_lo);
+      hi[i] = *reinterpret_cast<const f32x4*>(sa + a_off + i * 16 * 128 + a_hi);
+    }
+  };
+  bf16x8 b[NI][3];  // B fragments, read two column blocks ahead of their MFMAs (static indices: registers)
+  auto bload = [&](int stage, int j) {
+    const unsigned char* sb = smem3w + stage * STAGE + A_BYTES;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(sb + q * B_PLANE + b_off + j * 16 * 64);
+  };
+  // quarter c of the three-term split: k pair c of every row block -> dword c of the three planes' fragments
+  auto asplit_q = [&](int c, const f32x4 (&lo)[MI], const f32x4 (&hi)[MI], uint4 (&pl)[MI][3]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const f32x4 v = c < 2 ? lo[i] : hi[i];
+      uint32_t h, m, l;
+      split3(v[2 * (c & 1)], v[2 * (c & 1) + 1], h, m, l);
+      (&pl[i][0].x)[c] = h; (&pl[i][1].x)[c] = m; (&pl[i][2].x)[c] = l;
+    }
+  };
+  // (pure VALU code is not ordered against sched_barrier by itself: an empty volatile asm that consumes the quarter's results is)
+  auto pin_q = [&](int c, const uint4 (&pl)[MI][3]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) asm volatile("" ::"v"((&pl[i][0].x)[c]), "v"((&pl[i][1].x)[c]), "v"((&pl[i][2].x)[c]));
+  };
+  // One k-step of a wave.  tools/probe/kstep_probe.hip prices its ingredients at a 64x160 tile, two waves per SIMD, per CU and
+  // k-step: 60 MFMAs per SIMD 0.53 us (the matrix pipes saturate at ~1.85 PFLOP/s bf16: the chip clocks down under them;
+  // six dependent MFMAs on one accumulator run as fast as six independent ones), 38 DMA pieces 0.28 us (64 B per clock and CU
+  // out of L2), 136 ds_read_b128 0.11 us, the split 0.02 us -- and a k-step that reads its fragments, waits for them, splits and
+  // then multiplies pays their SUM (0.94 us: what k_gemm3 and the first version of this kernel measured).  So nothing but MFMAs
+  // may sit on a wave's critical path: column block j multiplies (6 MI MFMAs, k_gemm3's term order: bit-identical) while the B
+  // fragments of block j + 2 are read -- the last two blocks read the first two of the NEXT step, whose stage barrier t has
+  // already seen landed -- the DMAs of step t + STAGES - 1 and the raw A fragment of step t + 1 go out behind block 0, and a
+  // quarter of its split rides behind each of blocks 1-4.  sched_barrier(0) after every block pins that interleaving (left alone,
+  // hipcc hoists every read to the top of the step and sinks the split below it).  Operands swapped (D = B x A): a lane ends up
+  // with four consecutive columns of a C row.
+  static_assert(NI >= 5, "the split's quarters ride behind column blocks 1-4");
+  auto step = [&](const bf16x8 (&cur)[MI][3], bf16x8 (&nxt)[MI][3], int stage, int next_stage, bool do_issue, int issue_stage, int issue_it) {
+    f32x4 lo[MI], hi[MI];
+    uint4 pl[MI][3];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][0], cur[i][2], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][1], cur[i][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][2], cur[i][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][0], cur[i][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][1], cur[i][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][0], cur[i][0], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);  // block j's fragment registers are dead from here: block j + 2 may land in them
+      if (j + 2 < NI) bload(stage, j + 2);
+      else bload(next_stage, j + 2 - NI);
+      if (j == 0) {
+        if (do_issue) issue(issue_stage, issue_it);
+        aload(next_stage, lo, hi);
+      } else if (j <= 4) {
+        asplit_q(j - 1, lo, hi, pl);
+        pin_q(j - 1, pl);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) nxt[i][q] = __builtin_bit_cast(bf16x8, pl[i][q]);
+  };
+
+  // epilogue operands fetched BEFORE the DMAs (older than every one of them: they land first, and no ordinary load sits in the
+  // k-loop): the ReLU mask of a backward-data product, the bias of a forward one (clamped, unconditional)
+  float4 mk[EPI == EPI_MASK ? MI : 1][NI];
+  float4 bv[NI];
+  if constexpr (EPI == EPI_MASK) gemm_prefetch_mask<MI, NI>(p, mk, m0 + wm0, n0 + wn0, lane);
+  if constexpr (EPI == EPI_BIAS) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      bv[j] = f4_zero();
+      if (p.bias) bv[j] = *reinterpret_cast<const float4*>(p.bias + min(n0 + wn0 + j * 16 + fk * 4, p.N - 4));
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < STAGES - 1; ++q)
+    if (q < nk) issue(q, q);
+  uint64_t c_wait = 0, c_issue = 0, c_split = 0, c_mma = 0, c_t = 0, c_start = 0;
+  auto tick = [&](uint64_t& acc_) {
+    if constexpr (DBG) {
+      __builtin_amdgcn_sched_barrier(0);
+      const uint64_t now = gemm_clock();
+      acc_ += now - c_t;
+      c_t = now;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if constexpr (DBG) c_start = c_t = gemm_clock();
+  static_assert(STAGES >= 3, "k_gemm3w needs a 3-deep ring");
+  // barrier t: every wave's pieces of steps <= t + 1 are in LDS (step t reads the first fragments of step t + 1), and every
+  // wave is done with the buffer of step t - 1, which the DMAs of step t + STAGES - 1 refill; steps t + 2 .. t + STAGES - 2
+  // stay in flight
+  auto sync = [&](int t) {
+    const int infl = max(0, min(t + STAGES - 2, nk - 1) - (t + 1));
+    if (STAGES >= 4 && infl == STAGES - 3) gemm_wait_vmcnt_imm<(STAGES >= 4 ? STAGES - 3 : 0) * NJ>();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  bf16x8 a0[MI][3], a1[MI][3];
+  sync(0);
+  {
+    f32x4 lo[MI], hi[MI];
+    aload(0, lo, hi);
+    bload(0, 0);
+    bload(0, 1);
+    uint4 pl[MI][3];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) asplit_q(c, lo, hi, pl);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a0[i][q] = __builtin_bit_cast(bf16x8, pl[i][q]);
+  }
+  // (the first fragments of step t + 1 are read unconditionally: behind the last step that is a stale buffer, results dropped)
+  for (int it = 0; it < nk; it += 2) {
+    if (it > 0) sync(it);
+    tick(c_wait);
+    step(a0, a1, it % STAGES, (it + 1) % STAGES, it + STAGES - 1 < nk, (it + STAGES - 1) % STAGES, it + STAGES - 1);
+    if constexpr (DBG) asm volatile("" ::"v"(acc[MI - 1][NI - 1]), "v"(a1[0][2]), "v"(b[1][2]));
+    tick(c_mma);
+    if (it + 1 < nk) {
+      sync(it + 1);
+      tick(c_wait);
+      step(a1, a0, (it + 1) % STAGES, (it + 2) % STAGES, it + STAGES < nk, (it + STAGES) % STAGES, it + STAGES);
+      if constexpr (DBG) asm volatile("" ::"v"(acc[MI - 1][NI - 1]), "v"(a0[0][2]), "v"(b[1][2]));
+      tick(c_mma);
+    }
+  }
+
+  if constexpr (DBG) {
+    if (p.dbg && blockIdx.x < 8 && lane == 0) {
+      unsigned long long* o = p.dbg + ((size_t)blockIdx.x * NW + wave) * 8;
+      o[0] = c_wait; o[1] = c_issue; o[2] = c_split; o[3] = c_mma; o[4] = gemm_clock() - c_start; o[5] = nk;
+    }
+  }
+  // ---- epilogue (the C/D register layout of gemm_epilogue_pre): lane holds C[m0 + wm0 + 16 i + fr][n0 + wn0 + 16 j + 4 fk + 0..3]
+  float* C = p.C;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = n0 + wn0 + j * 16 + fk * 4;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int mb = m0 + wm0 + i * 16, m = mb + fr;
+      float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      if constexpr (EPI == EPI_BIAS) {
+        v = f4_add(v, bv[j]);
+        if (p.relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        if (p.colstat) {  // (uniform) per-16-row-block column sums and squared deviations, see gemm_epilogue_pre
+          const int cnt = min(16, p.M - mb);
+          if (cnt > 0) {
+            const bool ok = fr < cnt;
+            float4 sm = ok ? v : f4_zero();
+            sm.x = row16_sum(sm.x); sm.y = row16_sum(sm.y); sm.z = row16_sum(sm.z); sm.w = row16_sum(sm.w);
+            const float inv = 1.f / (float)cnt;
+            float4 q;
+            q.x = ok ? v.x - sm.x * inv : 0.f; q.y = ok ? v.y - sm.y * inv : 0.f;
+            q.z = ok ? v.z - sm.z * inv : 0.f; q.w = ok ? v.w - sm.w * inv : 0.f;
+            q.x = row16_sum(q.x * q.x); q.y = row16_sum(q.y * q.y); q.z = row16_sum(q.z * q.z); q.w = row16_sum(q.w * q.w);
+            if (fr == 0 && n < p.N) {
+              float* cs = p.colstat + (int64_t)(mb >> 4) * 2 * p.N + n;
+              *reinterpret_cast<float4*>(cs) = sm;
+              *reinterpret_cast<float4*>(cs + p.N) = q;
+            }
+          }
+        }
+      }
+      if constexpr (EPI == EPI_MASK) {
+        const float4 k4 = mk[i][j];
+        if (!(k4.x > 0.f)) v.x = 0.f;
+        if (!(k4.y > 0.f)) v.y = 0.f;
+        if (!(k4.z > 0.f)) v.z = 0.f;
+        if (!(k4.w > 0.f)) v.w = 0.f;
+      }
+      if (m < p.M && n < p.N) *reinterpret_cast<float4*>(C + (int64_t)m * p.ldc + n) = v;
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, bool PP = false, bool DBG = false>
+int launch_gemm3w_s(const GemmArgs& p, hipStream_t st) {
+  constexpr size_t lds = (size_t)STAGES * (BM * 128 + 3 * BN * 64);
+  static_assert(lds <= 160 * 1024, "LDS ring too deep");
+  const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N, BN));
+  allow_big_lds((const void*)k_gemm3w<BM, BN, WAVES_M, WAVES_N, STAGES, EPI, PP, DBG>, lds);
+  hipLaunchKernelGGL((k_gemm3w<BM, BN, WAVES_M, WAVES_N, STAGES, EPI, PP, DBG>), dim3(tiles), dim3(64 * WAVES_M * WAVES_N), lds, st, p);
+  return check_launch("gemm3w");
+}
+
+// tile choice as for k_gemm3: 128x160 when that still gives 3/4 of the CUs a workgroup, else 64x160.
+// PGNN_GEMM3W_CFG: 0 = 128x160 / 3 stages, 1 = 64x160 / 4 stages, 2 = 64x160 / 3 stages
+template <int EPI>
+int launch_gemm3w(const GemmArgs& p, hipStream_t st) {
+  int cfg = env_knob("PGNN_GEMM3W_CFG", -1);
+  if (cfg < 0) cfg = ceil_div(p.M, 128) * ceil_div(p.N, 160) * 4 >= 3 * num_cu() ? 0 : 1;
+  switch (cfg) {
+    case 0: return launch_gemm3w_s<128, 160, 4, 2, 3, EPI>(p, st);
+    case 2: return launch_gemm3w_s<64, 160, 4, 2, 3, EPI>(p, st);
+    default: return launch_gemm3w_s<64, 160, 4, 2, 4, EPI>(p, st);
+  }
+}
+
+// fp32 matrices -> three zero-padded bf16 planes each, optionally transposed, for up to 32 matrices in one launch
+// (the weights of a layer stack, once per forward / backward pass).  dst[q][r][c] = term q of src[r][c] (transposed:
+// of src[c][r]); rows r < rows_out, columns c < ld with zeros from cols_out on.  32 x 32 tiles through LDS, blockIdx.y = job.
+struct SplitJobs {
+  const float* src[32];
+  unsigned short* dst[32];
+  int rows[32], cols[32], ld[32];  // rows / cols of the OUTPUT planes, their row pitch
+  int transpose[32];
+};
+__global__ void __launch_bounds__(256) k_split_jobs(SplitJobs jobs) {
+  __shared__ float tile[32][33];
+  const int j = blockIdx.y, rows = jobs.rows[j], cols = jobs.cols[j], ld = jobs.ld[j];
+  const bool tr = jobs.transpose[j] != 0;
+  const float* __restrict__ src = jobs.src[j];
+  unsigned short* __restrict__ dst = jobs.dst[j];
+  const int64_t plane = (int64_t)rows * ld;
+  const int tc = (ld + 31) / 32, tiles = ((rows + 31) / 32) * tc;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // element (r, c) of the output comes from src[r][c] (pitch cols) or, transposed, from src[c][r] (pitch rows)
+      float v = 0.f;
+      if (!tr) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        if (r < rows && c < cols) v = src[(int64_t)r * cols + c];
+        tile[ty + 8 * i][tx] = v;
+      } else {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;  // coalesced along the source's contiguous dimension (r)
+        if (r < rows && c < cols) v = src[(int64_t)c * rows + r];
+        tile[tx][ty + 8 * i] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + ty + 8 * i, c = c0 + tx;
+      if (r < rows && c < ld) {
+        const float a = tile[ty + 8 * i][tx];
+        const __bf16 h = (__bf16)a;
+        const float ra = a - (float)h;
+        const __bf16 m = (__bf16)ra;
+        const __bf16 l = (__bf16)(ra - (float)m);
+        const int64_t o = (int64_t)r * ld + c;
+        dst[o] = __builtin_bit_cast(unsigned short, h);
+        dst[plane + o] = __builtin_bit_cast(unsigned short, m);
+        dst[2 * plane + o] = __builtin_bit_cast(unsigned short, l);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES>
 int launch_gemm3_s(const GemmArgs& p, int nsplit, hipStream_t st) {
   using TA = typename std::conditional<A_KMAJOR, KMajorTile<BM>, RowMajorTile<BM>>::type;
@@ -837,6 +1210,72 @@ int pgnn_linear_bwd_data_t(const float* dy, int64_t lddy, const float* wt, const
   if (use_split(m, k)) return relu_out ? launch_gemm3<true, true, EPI_MASK>(p, 1, st) : launch_gemm3<true, true, EPI_PLAIN>(p, 1, st);
   const TileCfg c = pick_cfg(m, k, 0);
   return relu_out ? launch_cfg<true, true, EPI_MASK>(c, p, 1, st) : launch_cfg<true, true, EPI_PLAIN>(c, p, 1, st);
+}
+
+// ---- products on pre-split weight planes (k_gemm3w) ----
+size_t pgnn_weight_planes_bytes(int64_t rows, int64_t cols) {
+  return align_up((size_t)3 * rows * ceil_div(cols, 32) * 32 * sizeof(unsigned short), 256);
+}
+
+int pgnn_split_weights(const float* const* src, void* const* dst, const int64_t* rows, const int64_t* cols, const int32_t* transpose,
+                       int64_t count, pgnn_stream stream) {
+  PGNN_REQUIRE(count >= 0 && count <= 32, "split_weights: at most 32 matrices per call");
+  if (count == 0) return PGNN_OK;
+  SplitJobs jobs{};
+  int64_t most = 1;
+  for (int j = 0; j < count; ++j) {
+    PGNN_REQUIRE(src[j] && dst[j] && rows[j] > 0 && cols[j] > 0 && rows[j] < (1 << 24) && cols[j] < (1 << 24), "split_weights: bad job");
+    const bool tr = transpose && transpose[j];
+    jobs.src[j] = src[j]; jobs.dst[j] = static_cast<unsigned short*>(dst[j]);
+    jobs.rows[j] = (int)(tr ? cols[j] : rows[j]); jobs.cols[j] = (int)(tr ? rows[j] : cols[j]);
+    jobs.ld[j] = (int)(ceil_div(jobs.cols[j], 32) * 32); jobs.transpose[j] = tr;
+    most = std::max(most, ceil_div(jobs.rows[j], 32) * (jobs.ld[j] / 32));
+  }
+  hipLaunchKernelGGL(k_split_jobs, dim3((int)std::min<int64_t>(most, 4096), (int)count), dim3(256), 0, (hipStream_t)stream, jobs);
+  return check_launch("split_weights");
+}
+
+int pgnn_linear_fwd_wp(const float* x, int64_t ldx, const void* wplanes, const float* bias, float* y, int64_t ldy, int64_t m, int64_t k,
+                       int64_t n, int relu, float* colstat, pgnn_stream stream) {
+  PGNN_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && wplanes,
+               "linear_fwd_wp: K, N and the leading dimensions must be multiples of 4");
+  GemmArgs p{};
+  p.nxcd = num_xcd();
+  p.A = x; p.lda = ldx; p.C = y; p.ldc = ldy;
+  p.Bp = static_cast<const unsigned short*>(wplanes); p.ldbp = ceil_div(k, 32) * 32; p.bplane = n * p.ldbp;
+  p.M = (int)m; p.N = (int)n; p.K = (int)k; p.bias = bias; p.relu = relu; p.kchunk = (int)k; p.split_stride = 0;
+  p.colstat = colstat;
+  return launch_gemm3w<EPI_BIAS>(p, (hipStream_t)stream);
+}
+
+int pgnn_debug_gemm3w_profile(const float* x, int64_t ldx, const void* wplanes, const float* bias, float* y, int64_t ldy, int64_t m,
+                              int64_t k, int64_t n, int cfg, uint64_t* buffer, pgnn_stream stream) {
+  PGNN_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0 && wplanes && buffer, "debug_gemm3w_profile: bad arguments");
+  GemmArgs p{};
+  p.nxcd = num_xcd();
+  p.A = x; p.lda = ldx; p.C = y; p.ldc = ldy;
+  p.Bp = static_cast<const unsigned short*>(wplanes); p.ldbp = ceil_div(k, 32) * 32; p.bplane = n * p.ldbp;
+  p.M = (int)m; p.N = (int)n; p.K = (int)k; p.bias = bias; p.relu = 1; p.kchunk = (int)k;
+  p.dbg = reinterpret_cast<unsigned long long*>(buffer);
+  hipStream_t st = (hipStream_t)stream;
+  switch (cfg) {
+    case 0: return launch_gemm3w_s<128, 160, 4, 2, 3, EPI_BIAS, false, true>(p, st);
+    default: return launch_gemm3w_s<64, 160, 4, 2, 4, EPI_BIAS, false, true>(p, st);
+  }
+}
+
+int pgnn_linear_bwd_data_wp(const float* dy, int64_t lddy, const void* wtplanes, const float* relu_out, int64_t ldr, float* dx,
+                            int64_t lddx, int64_t m, int64_t k, int64_t n, pgnn_stream stream) {
+  PGNN_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && wtplanes,
+               "linear_bwd_data_wp: K, N and the leading dimensions must be multiples of 4");
+  GemmArgs p{};
+  p.nxcd = num_xcd();
+  // dx[m, kcol] = sum_nn dy[m, nn] W^T[kcol, nn]: the forward product with the planes of W^T [k, n] as its B
+  p.A = dy; p.lda = lddy; p.C = dx; p.ldc = lddx;
+  p.Bp = static_cast<const unsigned short*>(wtplanes); p.ldbp = ceil_div(n, 32) * 32; p.bplane = k * p.ldbp;
+  p.M = (int)m; p.N = (int)k; p.K = (int)n; p.mask = relu_out; p.ldmask = ldr; p.kchunk = (int)n; p.split_stride = 0;
+  hipStream_t st = (hipStream_t)stream;
+  return relu_out ? launch_gemm3w<EPI_MASK>(p, st) : launch_gemm3w<EPI_PLAIN>(p, st);
 }
 
 // backward-weight on the split-bf16 kernel (both operands row-contiguous: transpose-read fragments) from 2 048 rows on:
