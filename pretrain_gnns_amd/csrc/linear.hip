@@ -624,19 +624,20 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
   // ---- this wave's DMA pieces: piece d < PA = rows 8 d .. 8 d + 7 of the A image, else 16 rows of one B plane.  Every wave
   // issues exactly NJ pieces per k-step (the counted vmcnt below is then a compile-time immediate): a wave whose last slot falls
   // beyond NP repeats piece NP - 1 -- the same bytes to the same LDS address as its owner, harmless.
-  const unsigned char* src[NJ];  // this lane's source for the k-step about to be issued
-  int kofs[NJ];                  // A pieces: first k of this lane's chunk inside a k-step (for the K edge)
+  const unsigned char* src[NJ];  // B pieces: this lane's source for the k-step about to be issued; A pieces: start of its row
+  int koff[NJ], klast[NJ];       // A pieces: byte offset of this lane's chunk in its row, and of the row's last whole chunk
   int dpiece[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int d = min(wave + j * NW, NP - 1);
     dpiece[j] = d;
-    kofs[j] = 0;
+    koff[j] = klast[j] = 0;
     if (d < PA) {
       const int row = 8 * d + (lane >> 3);
       const int c = (lane & 7) ^ (((lane >> 3) & 6) | (d & 1));  // logical 16-byte chunk stored at position lane & 7
-      kofs[j] = 4 * c;
-      src[j] = reinterpret_cast<const unsigned char*>(p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + 4 * c);
+      koff[j] = 16 * c;
+      klast[j] = 4 * (p.K - 4);
+      src[j] = reinterpret_cast<const unsigned char*>(p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda);
     } else {
       const int q = (d - PA) / PB, pb = (d - PA) % PB;
       const int row = 16 * pb + (lane >> 2);
@@ -645,22 +646,23 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
     }
   }
 
-  const unsigned char* const zero_src = reinterpret_cast<const unsigned char*>(g_zero_page);  // (its address is a scalar LOAD: once, here)
-  auto issue = [&](int stage, int it) {
+  // piece j of this wave for the next k-step to be fetched.  (Beyond K the A chunks re-read the row's last whole chunk instead
+  // of a zero page: finite values against the B planes' zero padding, no select on a 64-bit pointer and no second source -- a
+  // scalar load of its address -- in the loop.)
+  auto issue_piece = [&](int j, int stage) {
     unsigned char* st = smem3w + stage * STAGE;
-    const int k0 = it * BK;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int d = dpiece[j];
-      if (d < PA) {
-        const unsigned char* g = (k0 + kofs[j] < p.K) ? src[j] : zero_src;
-        __builtin_amdgcn_global_load_lds(PGNN_GPTR(g), PGNN_LPTR(st + d * 1024), 16, 0, 0);
-        src[j] += BK * 4;
-      } else {
-        __builtin_amdgcn_global_load_lds(PGNN_GPTR(src[j]), PGNN_LPTR(st + A_BYTES + (d - PA) * 1024), 16, 0, 0);
-        src[j] += BK * 2;
-      }
+    const int d = dpiece[j];
+    if (d < PA) {
+      __builtin_amdgcn_global_load_lds(PGNN_GPTR(src[j] + min(koff[j], klast[j])), PGNN_LPTR(st + d * 1024), 16, 0, 0);
+      koff[j] += BK * 4;
+    } else {
+      __builtin_amdgcn_global_load_lds(PGNN_GPTR(src[j]), PGNN_LPTR(st + A_BYTES + (d - PA) * 1024), 16, 0, 0);
+      src[j] += BK * 2;
     }
+  };
+  auto issue = [&](int stage, int it) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) issue_piece(j, stage);
   };
 
   f32x4 acc[MI][NI];
@@ -736,8 +738,14 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
       __builtin_amdgcn_sched_barrier(0);  // block j's fragment registers are dead from here: block j + 2 may land in them
       if (j + 2 < NI) bload(stage, j + 2);
       else bload(next_stage, j + 2 - NI);
+      // the wave's DMA pieces of step t + STAGES - 1, spread over the column blocks (all at once they hold the wave -- and,
+      // barrier-aligned, every wave of the CU -- in the vector-memory issue queue for ~370-700 cycles with the matrix pipe idle)
+      if (do_issue) {
+#pragma unroll
+        for (int q = 0; q < NJ; ++q)
+          if (q * NI / NJ == j) issue_piece(q, issue_stage);
+      }
       if (j == 0) {
-        if (do_issue) issue(issue_stage, issue_it);
         aload(next_stage, lo, hi);
       } else if (j <= 4) {
         asplit_q(j - 1, lo, hi, pl);
