@@ -624,41 +624,37 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
   // ---- this wave's DMA pieces: piece d < PA = rows 8 d .. 8 d + 7 of the A image, else 16 rows of one B plane.  Every wave
   // issues exactly NJ pieces per k-step (the counted vmcnt below is then a compile-time immediate): a wave whose last slot falls
   // beyond NP repeats piece NP - 1 -- the same bytes to the same LDS address as its owner, harmless.
-  const unsigned char* src[NJ];  // B pieces: this lane's source for the k-step about to be issued; A pieces: start of its row
-  int koff[NJ], klast[NJ];       // A pieces: byte offset of this lane's chunk in its row, and of the row's last whole chunk
-  int dpiece[NJ];
+  // One code path for both kinds (a branch on the kind is a join inside the k-step, see step()): source = start of this lane's
+  // row + min(offset of its chunk, last whole chunk of the row) -- beyond K the A chunks re-read the row's last whole chunk
+  // instead of a zero page: finite values against the B planes' zero padding, which also bounds the B offsets -- ; the offset
+  // advances by one k-step of bytes (128 for the fp32 A image, 64 for a bf16 plane); the LDS address is wave-uniform.
+  const unsigned char* src[NJ];
+  int koff[NJ], klast[NJ], kstep[NJ], ldsoff[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int d = min(wave + j * NW, NP - 1);
-    dpiece[j] = d;
-    koff[j] = klast[j] = 0;
     if (d < PA) {
       const int row = 8 * d + (lane >> 3);
       const int c = (lane & 7) ^ (((lane >> 3) & 6) | (d & 1));  // logical 16-byte chunk stored at position lane & 7
       koff[j] = 16 * c;
       klast[j] = 4 * (p.K - 4);
+      kstep[j] = BK * 4;
+      ldsoff[j] = d * 1024;
       src[j] = reinterpret_cast<const unsigned char*>(p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda);
     } else {
       const int q = (d - PA) / PB, pb = (d - PA) % PB;
       const int row = 16 * pb + (lane >> 2);
       const int c = (lane & 3) ^ ((-(lane >> 4)) & 3);
-      src[j] = reinterpret_cast<const unsigned char*>(p.Bp + q * p.bplane + (int64_t)min(n0 + row, p.N - 1) * p.ldbp + 8 * c);
+      koff[j] = 16 * c;
+      klast[j] = 2 * ((int)p.ldbp - 8);
+      kstep[j] = BK * 2;
+      ldsoff[j] = A_BYTES + (d - PA) * 1024;
+      src[j] = reinterpret_cast<const unsigned char*>(p.Bp + q * p.bplane + (int64_t)min(n0 + row, p.N - 1) * p.ldbp);
     }
   }
-
-  // piece j of this wave for the next k-step to be fetched.  (Beyond K the A chunks re-read the row's last whole chunk instead
-  // of a zero page: finite values against the B planes' zero padding, no select on a 64-bit pointer and no second source -- a
-  // scalar load of its address -- in the loop.)
   auto issue_piece = [&](int j, int stage) {
-    unsigned char* st = smem3w + stage * STAGE;
-    const int d = dpiece[j];
-    if (d < PA) {
-      __builtin_amdgcn_global_load_lds(PGNN_GPTR(src[j] + min(koff[j], klast[j])), PGNN_LPTR(st + d * 1024), 16, 0, 0);
-      koff[j] += BK * 4;
-    } else {
-      __builtin_amdgcn_global_load_lds(PGNN_GPTR(src[j]), PGNN_LPTR(st + A_BYTES + (d - PA) * 1024), 16, 0, 0);
-      src[j] += BK * 2;
-    }
+    __builtin_amdgcn_global_load_lds(PGNN_GPTR(src[j] + min(koff[j], klast[j])), PGNN_LPTR(smem3w + stage * STAGE + ldsoff[j]), 16, 0, 0);
+    koff[j] += kstep[j];
   };
   auto issue = [&](int stage, int it) {
 #pragma unroll
@@ -717,7 +713,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
   // hipcc hoists every read to the top of the step and sinks the split below it).  Operands swapped (D = B x A): a lane ends up
   // with four consecutive columns of a C row.
   static_assert(NI >= 5, "the split's quarters ride behind column blocks 1-4");
-  auto step = [&](const bf16x8 (&cur)[MI][3], bf16x8 (&nxt)[MI][3], int stage, int next_stage, bool do_issue, int issue_stage, int issue_it) {
+  auto step = [&](auto do_issue, const bf16x8 (&cur)[MI][3], bf16x8 (&nxt)[MI][3], int stage, int next_stage, int issue_stage) {
     f32x4 lo[MI], hi[MI];
     uint4 pl[MI][3];
     __builtin_amdgcn_sched_barrier(0);
@@ -736,20 +732,22 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
 #pragma unroll
       for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][0], cur[i][0], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);  // block j's fragment registers are dead from here: block j + 2 may land in them
+      // order behind the MFMAs of block j: the split quarter first (its lgkmcnt wait then covers reads issued a block ago, not
+      // the ones that follow), then the fragment reads of block j + 2, then this block's share of the wave's DMA pieces for step
+      // t + STAGES - 1 (all at once they hold the wave -- and, barrier-aligned, every wave of the CU -- in the vector-memory
+      // issue queue for ~370-700 cycles with the matrix pipe idle).  do_issue is a compile-time flag: a branch around the DMAs
+      // is a join at which hipcc's s_waitcnt pass falls back to lgkmcnt(0).
+      if (j >= 1 && j <= 4) {
+        asplit_q(j - 1, lo, hi, pl);
+        pin_q(j - 1, pl);
+      }
       if (j + 2 < NI) bload(stage, j + 2);
       else bload(next_stage, j + 2 - NI);
-      // the wave's DMA pieces of step t + STAGES - 1, spread over the column blocks (all at once they hold the wave -- and,
-      // barrier-aligned, every wave of the CU -- in the vector-memory issue queue for ~370-700 cycles with the matrix pipe idle)
-      if (do_issue) {
+      if (j == 0) aload(next_stage, lo, hi);
+      if constexpr (decltype(do_issue)::value) {
 #pragma unroll
         for (int q = 0; q < NJ; ++q)
           if (q * NI / NJ == j) issue_piece(q, issue_stage);
-      }
-      if (j == 0) {
-        aload(next_stage, lo, hi);
-      } else if (j <= 4) {
-        asplit_q(j - 1, lo, hi, pl);
-        pin_q(j - 1, pl);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -793,7 +791,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
     const int infl = max(0, min(t + STAGES - 2, nk - 1) - (t + 1));
     if (STAGES >= 4 && infl == STAGES - 3) gemm_wait_vmcnt_imm<(STAGES >= 4 ? STAGES - 3 : 0) * NJ>();
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // (the builtin, not inline asm: hipcc's own s_waitcnt pass then KNOWS that no LDS read is outstanding behind the barrier --
+    // with an asm wait it assumes the fragment reads of the previous step are still in flight and drains lgkmcnt(0), i.e. the
+    // reads it has just issued, in front of the next block's MFMAs)
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
   };
   bf16x8 a0[MI][3], a1[MI][3];
@@ -812,18 +813,47 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
       for (int q = 0; q < 3; ++q) a0[i][q] = __builtin_bit_cast(bf16x8, pl[i][q]);
   }
   // (the first fragments of step t + 1 are read unconditionally: behind the last step that is a stale buffer, results dropped)
-  for (int it = 0; it < nk; it += 2) {
+  using Yes = std::integral_constant<bool, true>;
+  using No = std::integral_constant<bool, false>;
+  // the first nk - (STAGES - 1) steps fetch a later step, the last STAGES - 1 do not: two loops, each unrolled by two over the
+  // two A-fragment register sets (one loop choosing per step makes hipcc shuffle accumulators between the variants)
+  const int n_main = max(0, nk - (STAGES - 1));
+  int it = 0;
+  auto stamp = [&]() {
+    if constexpr (DBG) asm volatile("" ::"v"(acc[MI - 1][NI - 1]), "v"(a0[0][2]), "v"(a1[0][2]), "v"(b[1][2]));
+    tick(c_mma);
+  };
+  for (; it + 2 <= n_main; it += 2) {
     if (it > 0) sync(it);
     tick(c_wait);
-    step(a0, a1, it % STAGES, (it + 1) % STAGES, it + STAGES - 1 < nk, (it + STAGES - 1) % STAGES, it + STAGES - 1);
-    if constexpr (DBG) asm volatile("" ::"v"(acc[MI - 1][NI - 1]), "v"(a1[0][2]), "v"(b[1][2]));
-    tick(c_mma);
+    step(Yes{}, a0, a1, it % STAGES, (it + 1) % STAGES, (it + STAGES - 1) % STAGES);
+    stamp();
+    sync(it + 1);
+    tick(c_wait);
+    step(Yes{}, a1, a0, (it + 1) % STAGES, (it + 2) % STAGES, (it + STAGES) % STAGES);
+    stamp();
+  }
+  if (it < n_main) {  // odd count: one more fetching step, then the sets swap back
+    if (it > 0) sync(it);
+    tick(c_wait);
+    step(Yes{}, a0, a1, it % STAGES, (it + 1) % STAGES, (it + STAGES - 1) % STAGES);
+    stamp();
+    ++it;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a0[i][q] = a1[i][q];
+  }
+  for (; it < nk; it += 2) {
+    if (it > 0) sync(it);
+    tick(c_wait);
+    step(No{}, a0, a1, it % STAGES, (it + 1) % STAGES, 0);
+    stamp();
     if (it + 1 < nk) {
       sync(it + 1);
       tick(c_wait);
-      step(a1, a0, (it + 1) % STAGES, (it + 2) % STAGES, it + STAGES < nk, (it + STAGES) % STAGES, it + STAGES);
-      if constexpr (DBG) asm volatile("" ::"v"(acc[MI - 1][NI - 1]), "v"(a0[0][2]), "v"(b[1][2]));
-      tick(c_mma);
+      step(No{}, a1, a0, (it + 1) % STAGES, (it + 2) % STAGES, 0);
+      stamp();
     }
   }
 
@@ -889,14 +919,16 @@ int launch_gemm3w_s(const GemmArgs& p, hipStream_t st) {
 }
 
 // tile choice as for k_gemm3: 128x160 when that still gives 3/4 of the CUs a workgroup, else 64x160.
-// PGNN_GEMM3W_CFG: 0 = 128x160 / 3 stages, 1 = 64x160 / 4 stages, 2 = 64x160 / 3 stages
+// PGNN_GEMM3W_CFG: 0 = 128x160 (8 x 1 waves of 16 x 160) / 3 stages, 1 = 64x160 (4 x 2 waves of 16 x 80) / 4 stages,
+// 2 = 64x160 / 3 stages, 3 = 128x160 (4 x 2 waves of 32 x 80) / 3 stages
 template <int EPI>
 int launch_gemm3w(const GemmArgs& p, hipStream_t st) {
   int cfg = env_knob("PGNN_GEMM3W_CFG", -1);
   if (cfg < 0) cfg = ceil_div(p.M, 128) * ceil_div(p.N, 160) * 4 >= 3 * num_cu() ? 0 : 1;
   switch (cfg) {
-    case 0: return launch_gemm3w_s<128, 160, 4, 2, 3, EPI>(p, st);
+    case 0: return launch_gemm3w_s<128, 160, 8, 1, 3, EPI>(p, st);
     case 2: return launch_gemm3w_s<64, 160, 4, 2, 3, EPI>(p, st);
+    case 3: return launch_gemm3w_s<128, 160, 4, 2, 3, EPI>(p, st);
     default: return launch_gemm3w_s<64, 160, 4, 2, 4, EPI>(p, st);
   }
 }
@@ -1267,7 +1299,7 @@ int pgnn_debug_gemm3w_profile(const float* x, int64_t ldx, const void* wplanes, 
   p.dbg = reinterpret_cast<unsigned long long*>(buffer);
   hipStream_t st = (hipStream_t)stream;
   switch (cfg) {
-    case 0: return launch_gemm3w_s<128, 160, 4, 2, 3, EPI_BIAS, false, true>(p, st);
+    case 0: return launch_gemm3w_s<128, 160, 8, 1, 3, EPI_BIAS, false, true>(p, st);
     default: return launch_gemm3w_s<64, 160, 4, 2, 4, EPI_BIAS, false, true>(p, st);
   }
 }
