@@ -255,6 +255,8 @@ int pgnn_transpose_batch(const float* const* src, float* const* dst, const int64
  * rounded up to 32, zero beyond cols (pgnn_weight_planes_bytes bytes per matrix).  transpose[j] != 0: the planes of src[j]^T.
  * count <= 32 matrices per launch (host arrays of device pointers / sizes). */
 size_t pgnn_weight_planes_bytes(int64_t rows, int64_t cols);
+/* 1 if a layer stack should run its [m, k] x [n, k]^T products on planes (same bits as pgnn_linear_fwd there, faster) */
+int pgnn_linear_wp_preferred(int64_t m, int64_t k, int64_t n);
 int pgnn_split_weights(const float* const* src, void* const* dst, const int64_t* rows, const int64_t* cols, const int32_t* transpose,
                        int64_t count, pgnn_stream stream);
 /* pgnn_linear_fwd / pgnn_linear_fwd_colstats (colstat may be NULL) with wplanes = the planes of W [n, k]; bit-identical to them

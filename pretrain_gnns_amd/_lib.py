@@ -56,6 +56,7 @@ PROTOTYPES = {
     "pgnn_bn_apply_fwd": (_i, [_p, _i64, _p, _i, _p, _i64, _f, _u64, _i64, _i64, _p]),
     "pgnn_debug_gemm3w_profile": (_i, [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _p, _p]),
     "pgnn_weight_planes_bytes": (_sz, [_i64, _i64]),
+    "pgnn_linear_wp_preferred": (_i, [_i64, _i64, _i64]),
     "pgnn_split_weights": (_i, [_p, _p, _p, _p, _p, _i64, _p]),
     "pgnn_linear_fwd_wp": (_i, [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _p, _p]),
     "pgnn_linear_bwd_data_wp": (_i, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p]),

@@ -49,6 +49,34 @@ inline bool use_transposed_weights(int64_t n) {
   return v == 2 || (v == 1 && n >= 16384);
 }
 inline bool per_layer_buffers() { return env_knob("PGNN_STACK_PER_LAYER_BUFFERS", 0) != 0; }
+// Products on pre-split weight planes (csrc/linear.hip, k_gemm3w): the weights of the whole stack are split (backward: transposed
+// and split) into three bf16 planes by ONE launch per pass; every forward and backward-data product then streams them by DMA.
+constexpr int kMaxPlaneLayers = 16;  // pgnn_split_weights takes 32 matrices per launch
+inline size_t mlp_planes_bytes(int64_t d_in, int64_t d_hid, int64_t d_out) {  // W1 [d_hid, d_in] + W2 [d_out, d_hid], either orientation
+  return std::max(pgnn_weight_planes_bytes(d_hid, d_in), pgnn_weight_planes_bytes(d_in, d_hid)) +
+         std::max(pgnn_weight_planes_bytes(d_out, d_hid), pgnn_weight_planes_bytes(d_hid, d_out));
+}
+inline bool mlp_wp(int64_t n, int64_t d_in, int64_t d_hid, int64_t d_out, int num_layer) {
+  return num_layer <= kMaxPlaneLayers && pgnn_linear_wp_preferred(n, d_in, d_hid) && pgnn_linear_wp_preferred(n, d_hid, d_out) &&
+         pgnn_linear_wp_preferred(n, d_out, d_hid) && pgnn_linear_wp_preferred(n, d_hid, d_in);
+}
+// planes of W1 / W2 (transpose = 0) or W1^T / W2^T (1) of every layer: p1[l], p2[l] carved from `base`
+inline int split_mlp_weights(const pgnn_gin_layer* layers, int num_layer, int64_t d_in, int64_t d_hid, int64_t d_out, int transpose,
+                             char* base, void** p1, void** p2, hipStream_t st) {
+  const float* src[2 * kMaxPlaneLayers];
+  void* dst[2 * kMaxPlaneLayers];
+  int64_t rows[2 * kMaxPlaneLayers], cols[2 * kMaxPlaneLayers];
+  int32_t tr[2 * kMaxPlaneLayers];
+  const size_t b1 = std::max(pgnn_weight_planes_bytes(d_hid, d_in), pgnn_weight_planes_bytes(d_in, d_hid));
+  const size_t per = mlp_planes_bytes(d_in, d_hid, d_out);
+  for (int l = 0; l < num_layer; ++l) {
+    p1[l] = base + (size_t)l * per;
+    p2[l] = base + (size_t)l * per + b1;
+    src[2 * l] = layers[l].w1; dst[2 * l] = p1[l]; rows[2 * l] = d_hid; cols[2 * l] = d_in; tr[2 * l] = transpose;
+    src[2 * l + 1] = layers[l].w2; dst[2 * l + 1] = p2[l]; rows[2 * l + 1] = d_out; cols[2 * l + 1] = d_hid; tr[2 * l + 1] = transpose;
+  }
+  return pgnn_split_weights(src, dst, rows, cols, tr, 2 * num_layer, st);
+}
 constexpr int64_t kStatsInGemmMaxRows = 32768;  // pgnn_chem_gin_stack_fwd: BatchNorm statistics from the GEMM epilogue up to here
 constexpr int kMaxTransposed = 8;  // layers whose weights pgnn_chem_gin_stack_bwd transposes up front (one 16-job launch)
 inline size_t op_ws_bytes(int64_t n, int64_t d) {
@@ -218,7 +246,10 @@ size_t pgnn_chem_gin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t rows1
   // 2 x op scratch + S x (dz, dagg, dx: nd each; dhid: 2 nd) + group-by-key of the two atom columns.
   // S = 2 (ping-pong by layer parity), or one set per layer under the PGNN_STACK_PER_LAYER_BUFFERS=1 A/B knob.
   const size_t sets = (per_layer_buffers() && n <= kSideMaxRows) ? (size_t)std::max<int64_t>(num_layer, 2) : 2;
-  const size_t wt = (size_t)std::min<int64_t>(num_layer, kMaxTransposed) * 2 * align_up((size_t)2 * dim * dim * 4, 256);  // W1^T, W2^T
+  // W1^T, W2^T of the transposed-weights backward, or the bf16 planes of every layer's weights (forward: W1, W2; backward: their
+  // transposes) -- whichever is larger
+  const size_t wt = std::max((size_t)std::min<int64_t>(num_layer, kMaxTransposed) * 2 * align_up((size_t)2 * dim * dim * 4, 256),
+                             (size_t)std::min<int64_t>(num_layer, kMaxPlaneLayers) * mlp_planes_bytes(dim, 2 * dim, dim));
   return 2 * op_ws_bytes(n, dim) + sets * 5 * nd + wt + 2 * align_up((size_t)n * 4, 256) +
          2 * align_up((stack_keys(rows1, rows2) + 1) * 4, 256) + 256 + stack_group_ws(n, rows1, rows2) +
          stack_segsum_ws(n, dim, rows1, rows2) + stack_pair_sums(dim, rows1, rows2) + 256;
@@ -247,6 +278,13 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
   // Training-mode statistics from the epilogue of the product in front (PGNN_BN_STATS_IN_GEMM=0: the separate partial-sum
   // pass).  Up to kStatsInGemmMaxRows rows: beyond, the per-16-row blocks (150 B a row) cost more than the pass they replace.
   const bool stats_in_gemm = training && n > 1 && n <= kStatsInGemmMaxRows && env_knob("PGNN_BN_STATS_IN_GEMM", 1) != 0;
+  // both products of every layer on pre-split weight planes when the caller's workspace has room for them behind the op scratch
+  // (pgnn_chem_gin_stack_workspace_bytes does; the per-layer size of older callers does not: they keep the in-kernel split)
+  const size_t opb = op_ws_bytes(n, dim);
+  void *wp1[kMaxPlaneLayers], *wp2[kMaxPlaneLayers];
+  const bool wp = mlp_wp(n, dim, 2 * dim, dim, num_layer) && ws_bytes >= opb + (size_t)num_layer * mlp_planes_bytes(dim, 2 * dim, dim);
+  if (wp && (rc = split_mlp_weights(layers, num_layer, dim, 2 * dim, dim, 0, static_cast<char*>(ws) + opb, wp1, wp2, (hipStream_t)stream)))
+    return rc;
   for (int l = 0; l < num_layer; ++l) {
     const pgnn_gin_layer& p = layers[l];
     float* a = acts + (size_t)l * 3 * nd;  // agg, z, y
@@ -267,11 +305,15 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
       rc = pgnn_chem_aggregate_fwd(yprev, dim, in_ptr, in_src, in_code, p.emb1, p.emb2, nullptr, agg, dim, n, dim, stream);
     }
     if (rc) return rc;
-    if ((rc = pgnn_linear_fwd(agg, dim, p.w1, p.b1, hd, 2 * dim, n, dim, 2 * dim, 1, stream))) return rc;
+    if (wp) rc = pgnn_linear_fwd_wp(agg, dim, wp1[l], p.b1, hd, 2 * dim, n, dim, 2 * dim, 1, nullptr, stream);
+    else rc = pgnn_linear_fwd(agg, dim, p.w1, p.b1, hd, 2 * dim, n, dim, 2 * dim, 1, stream);
+    if (rc) return rc;
     if (stats_in_gemm) {
       // the BatchNorm statistics of z fall out of the second product's epilogue: no pass over z for them, one launch less
       float* blocks = static_cast<float*>(ws);  // ceil(n/16) x 2 x dim floats <= the statistics partials of op_ws_bytes
-      if ((rc = pgnn_linear_fwd_colstats(hd, 2 * dim, p.w2, p.b2, z, dim, n, 2 * dim, dim, 0, blocks, stream))) return rc;
+      if (wp) rc = pgnn_linear_fwd_wp(hd, 2 * dim, wp2[l], p.b2, z, dim, n, 2 * dim, dim, 0, blocks, stream);
+      else rc = pgnn_linear_fwd_colstats(hd, 2 * dim, p.w2, p.b2, z, dim, n, 2 * dim, dim, 0, blocks, stream);
+      if (rc) return rc;
       if ((rc = pgnn_bn_stats_fwd_blocks(blocks, p.gamma, p.beta, p.running_mean, p.running_var, p.momentum, p.eps, st, st + dim,
                                          st + 2 * dim, n, dim, stream)))
         return rc;
@@ -280,13 +322,15 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
       if (rc) return rc;
       continue;
     }
-    if ((rc = pgnn_linear_fwd(hd, 2 * dim, p.w2, p.b2, z, dim, n, 2 * dim, dim, 0, stream))) return rc;
+    if (wp) rc = pgnn_linear_fwd_wp(hd, 2 * dim, wp2[l], p.b2, z, dim, n, 2 * dim, dim, 0, nullptr, stream);
+    else rc = pgnn_linear_fwd(hd, 2 * dim, p.w2, p.b2, z, dim, n, 2 * dim, dim, 0, stream);
+    if (rc) return rc;
     if (fuse && !last)
       rc = pgnn_bn_stats_fwd(z, dim, p.gamma, p.beta, p.running_mean, p.running_var, p.momentum, p.eps, training, st,
-                             st + dim, st + 2 * dim, n, dim, ws, ws_bytes, stream);
+                             st + dim, st + 2 * dim, n, dim, ws, opb, stream);
     else
       rc = pgnn_bn_fwd(z, dim, p.gamma, p.beta, p.running_mean, p.running_var, p.momentum, p.eps, training, !last, y, dim,
-                       st, st + dim, drop_p, drop_seed + (uint64_t)l, n, dim, ws, ws_bytes, stream);
+                       st, st + dim, drop_p, drop_seed + (uint64_t)l, n, dim, ws, opb, stream);
     if (rc) return rc;
   }
   return PGNN_OK;
@@ -319,11 +363,21 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     dagg[p] = cv.take<float>(nd);
     dxb[p] = cv.take<float>(nd);
   }
-  const int ntr = std::min(num_layer, kMaxTransposed);  // layers whose backward-data runs on transposed weights
+  // backward-data on the planes of W^T (every layer; one split launch up front), else on transposed fp32 weights from 16 384 rows
+  const bool wp = mlp_wp(n, dim, 2 * dim, dim, num_layer);
+  void *wp1[kMaxPlaneLayers], *wp2[kMaxPlaneLayers];  // planes of W1^T [dim, 2 dim], W2^T [2 dim, dim]
+  const int ntr = wp ? 0 : std::min(num_layer, kMaxTransposed);  // layers whose backward-data runs on transposed fp32 weights
   float *w1t[kMaxTransposed], *w2t[kMaxTransposed];
-  for (int l = 0; l < ntr; ++l) {
-    w1t[l] = cv.take<float>((size_t)2 * dim * dim);
-    w2t[l] = cv.take<float>((size_t)2 * dim * dim);
+  char* plane_base = cv.base + cv.used;  // one region, sized for the larger of the two uses (pgnn_chem_gin_stack_workspace_bytes)
+  {
+    const size_t region = std::max((size_t)std::min<int64_t>(num_layer, kMaxTransposed) * 2 * align_up((size_t)2 * dim * dim * 4, 256),
+                                   (size_t)std::min<int64_t>(num_layer, kMaxPlaneLayers) * mlp_planes_bytes(dim, 2 * dim, dim));
+    Carver tv(plane_base);
+    for (int l = 0; l < ntr; ++l) {
+      w1t[l] = tv.take<float>((size_t)2 * dim * dim);
+      w2t[l] = tv.take<float>((size_t)2 * dim * dim);
+    }
+    cv.take<char>(region);
   }
   int32_t* gptr[2];
   int32_t* gperm[2];
@@ -363,7 +417,14 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
       return rc;
   }
   bool waited_fork2 = false;
-  if (ntr > 0 && use_transposed_weights(n)) {
+  if (wp) {
+    if ((rc = split_mlp_weights(layers, num_layer, dim, 2 * dim, dim, 1, plane_base, wp1, wp2, aux))) return rc;  // (aux already waits on fork[0])
+    if (sd) {
+      PGNN_HIP(hipEventRecord(sd->fork[2], aux));
+      PGNN_HIP(hipStreamWaitEvent(main, sd->fork[2], 0));
+      waited_fork2 = true;  // ... which also covers the grouping
+    }
+  } else if (ntr > 0 && use_transposed_weights(n)) {
     const float* tsrc[2 * kMaxTransposed];
     float* tdst[2 * kMaxTransposed];
     int64_t trows[2 * kMaxTransposed], tcols[2 * kMaxTransposed];
@@ -397,7 +458,10 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     const float* mean = stats + (size_t)l * 4 * dim;
     if ((rc = pgnn_bn_bwd(g, ldg, z, dim, p.gamma, p.beta, mean, mean + dim, training, l != num_layer - 1, dz[b], dim,
                           p.dgamma, p.dbeta, drop_p, drop_seed + (uint64_t)l, n, dim, op, opb, main))) return rc;
-    if (tr && q < ntr) {
+    if (wp) {
+      if ((rc = pgnn_linear_bwd_data_wp(dz[b], dim, wp2[l], hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main))) return rc;
+      if ((rc = pgnn_linear_bwd_data_wp(dhid[b], 2 * dim, wp1[l], nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main))) return rc;
+    } else if (tr && q < ntr) {
       if ((rc = pgnn_linear_bwd_data_t(dz[b], dim, w2t[q], hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main))) return rc;
       if ((rc = pgnn_linear_bwd_data_t(dhid[b], 2 * dim, w1t[q], nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main))) return rc;
     } else {
@@ -596,7 +660,8 @@ extern "C" {
 size_t pgnn_bio_gin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t num_layer) {
   const size_t nd = align_up((size_t)n * dim * 4, 256);
   // 2 x op scratch + 2 x (dhid, dpre, dagg: 2 nd each; dx: nd) + W1^T, W2^T per layer
-  const size_t wt = (size_t)std::min<int64_t>(num_layer, kMaxTransposed) * (align_up((size_t)4 * dim * dim * 4, 256) + align_up((size_t)2 * dim * dim * 4, 256));
+  const size_t wt = std::max((size_t)std::min<int64_t>(num_layer, kMaxTransposed) * (align_up((size_t)4 * dim * dim * 4, 256) + align_up((size_t)2 * dim * dim * 4, 256)),
+                             (size_t)std::min<int64_t>(num_layer, kMaxPlaneLayers) * mlp_planes_bytes(2 * dim, 2 * dim, dim));
   return 2 * bio_op_ws_bytes(n, dim) + 2 * 7 * nd + wt + 512;
 }
 
@@ -616,6 +681,12 @@ int pgnn_bio_gin_stack_fwd(const float* h0, int64_t ldh0, const int32_t* in_ptr,
   const float* h = h0;
   int64_t ldh = ldh0;
   int rc;
+  // both products of every layer on pre-split weight planes (behind the op scratch of the workspace), as in the chem stack
+  const size_t opb = bio_op_ws_bytes(n, dim);
+  void *wp1[kMaxPlaneLayers], *wp2[kMaxPlaneLayers];
+  const bool wp = mlp_wp(n, 2 * dim, 2 * dim, dim, num_layer) && ws_bytes >= opb + (size_t)num_layer * mlp_planes_bytes(2 * dim, 2 * dim, dim);
+  if (wp && (rc = split_mlp_weights(layers, num_layer, 2 * dim, 2 * dim, dim, 0, static_cast<char*>(ws) + opb, wp1, wp2, (hipStream_t)stream)))
+    return rc;
   for (int l = 0; l < num_layer; ++l) {
     const pgnn_gin_layer& p = layers[l];
     float* a = acts + (size_t)l * 7 * nd;
@@ -629,10 +700,14 @@ int pgnn_bio_gin_stack_fwd(const float* h0, int64_t ldh0, const int32_t* in_ptr,
       rc = pgnn_rowfeat_matmul_fwd(cfeat, 10, p.emb1, dim, agg + dim, 2 * dim, n, dim, 0, stream);
     }
     if (rc) return rc;
-    if ((rc = pgnn_linear_fwd(agg, 2 * dim, p.w1, p.b1, pre, 2 * dim, n, 2 * dim, 2 * dim, 0, stream))) return rc;
+    if (wp) rc = pgnn_linear_fwd_wp(agg, 2 * dim, wp1[l], p.b1, pre, 2 * dim, n, 2 * dim, 2 * dim, 0, nullptr, stream);
+    else rc = pgnn_linear_fwd(agg, 2 * dim, p.w1, p.b1, pre, 2 * dim, n, 2 * dim, 2 * dim, 0, stream);
+    if (rc) return rc;
     if ((rc = pgnn_bn_fwd(pre, 2 * dim, p.gamma, p.beta, p.running_mean, p.running_var, p.momentum, p.eps, training, 1, hid,
-                          2 * dim, st, st + 2 * dim, 0.f, 0, n, 2 * dim, ws, ws_bytes, stream))) return rc;
-    if ((rc = pgnn_linear_fwd(hid, 2 * dim, p.w2, p.b2, y, dim, n, 2 * dim, dim, l != num_layer - 1, stream))) return rc;
+                          2 * dim, st, st + 2 * dim, 0.f, 0, n, 2 * dim, ws, opb, stream))) return rc;
+    if (wp) rc = pgnn_linear_fwd_wp(hid, 2 * dim, wp2[l], p.b2, y, dim, n, 2 * dim, dim, l != num_layer - 1, nullptr, stream);
+    else rc = pgnn_linear_fwd(hid, 2 * dim, p.w2, p.b2, y, dim, n, 2 * dim, dim, l != num_layer - 1, stream);
+    if (rc) return rc;
     h = y;
     ldh = dim;
   }
@@ -663,11 +738,20 @@ int pgnn_bio_gin_stack_bwd(const float* dy, int64_t lddy, const int32_t* out_ptr
     dagg[q] = cv.take<float>(2 * nd);
     dxb[q] = cv.take<float>(nd);
   }
-  const int ntr = std::min(num_layer, kMaxTransposed);
+  const bool wp = mlp_wp(n, 2 * dim, 2 * dim, dim, num_layer);  // backward-data on the planes of W1^T [2D, 2D], W2^T [2D, D]
+  void *wp1[kMaxPlaneLayers], *wp2[kMaxPlaneLayers];
+  const int ntr = wp ? 0 : std::min(num_layer, kMaxTransposed);
   float *w1t[kMaxTransposed], *w2t[kMaxTransposed];
-  for (int q = 0; q < ntr; ++q) {
-    w1t[q] = cv.take<float>((size_t)4 * dim * dim);
-    w2t[q] = cv.take<float>((size_t)2 * dim * dim);
+  char* plane_base = cv.base + cv.used;
+  {
+    const size_t region = std::max((size_t)std::min<int64_t>(num_layer, kMaxTransposed) * (align_up((size_t)4 * dim * dim * 4, 256) + align_up((size_t)2 * dim * dim * 4, 256)),
+                                   (size_t)std::min<int64_t>(num_layer, kMaxPlaneLayers) * mlp_planes_bytes(2 * dim, 2 * dim, dim));
+    Carver tv(plane_base);
+    for (int q = 0; q < ntr; ++q) {
+      w1t[q] = tv.take<float>((size_t)4 * dim * dim);
+      w2t[q] = tv.take<float>((size_t)2 * dim * dim);
+    }
+    cv.take<char>(region);
   }
   hipStream_t main = (hipStream_t)stream;
   Side* sd = (use_side_stream() && n <= kSideMaxRows) ? side_for_current_device() : nullptr;
@@ -675,7 +759,17 @@ int pgnn_bio_gin_stack_bwd(const float* dy, int64_t lddy, const int32_t* out_ptr
   char* aux_ws = sd ? op2 : op;
   int rc;
   const bool tr = ntr > 0 && use_transposed_weights(n);
-  if (tr) {
+  if (wp) {
+    if (sd) {
+      PGNN_HIP(hipEventRecord(sd->fork[0], main));
+      PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[0], 0));
+    }
+    if ((rc = split_mlp_weights(layers, num_layer, 2 * dim, 2 * dim, dim, 1, plane_base, wp1, wp2, aux))) return rc;
+    if (sd) {
+      PGNN_HIP(hipEventRecord(sd->fork[2], aux));
+      PGNN_HIP(hipStreamWaitEvent(main, sd->fork[2], 0));
+    }
+  } else if (tr) {
     const float* tsrc[2 * kMaxTransposed];
     float* tdst[2 * kMaxTransposed];
     int64_t trows[2 * kMaxTransposed], tcols[2 * kMaxTransposed];
@@ -704,12 +798,14 @@ int pgnn_bio_gin_stack_bwd(const float* dy, int64_t lddy, const int32_t* out_ptr
     const float* st = stats + (size_t)l * 4 * dim;
     // g = gradient of this layer's output (already masked by the ReLU that follows it, see the end of the loop body):
     // dy for the last layer, else dxb[l & 1], written by iteration l + 1
-    if (tr && q < ntr) rc = pgnn_linear_bwd_data_t(g, ldg, w2t[q], nullptr, 0, dhid[b], 2 * dim, n, 2 * dim, dim, main);
+    if (wp) rc = pgnn_linear_bwd_data_wp(g, ldg, wp2[l], nullptr, 0, dhid[b], 2 * dim, n, 2 * dim, dim, main);
+    else if (tr && q < ntr) rc = pgnn_linear_bwd_data_t(g, ldg, w2t[q], nullptr, 0, dhid[b], 2 * dim, n, 2 * dim, dim, main);
     else rc = pgnn_linear_bwd_data(g, ldg, p.w2, nullptr, 0, dhid[b], 2 * dim, n, 2 * dim, dim, main);
     if (rc) return rc;
     if ((rc = pgnn_bn_bwd(dhid[b], 2 * dim, pre, 2 * dim, p.gamma, p.beta, st, st + 2 * dim, training, 1, dpre[b], 2 * dim,
                           p.dgamma, p.dbeta, 0.f, 0, n, 2 * dim, op, opb, main))) return rc;
-    if (tr && q < ntr) rc = pgnn_linear_bwd_data_t(dpre[b], 2 * dim, w1t[q], nullptr, 0, dagg[b], 2 * dim, n, 2 * dim, 2 * dim, main);
+    if (wp) rc = pgnn_linear_bwd_data_wp(dpre[b], 2 * dim, wp1[l], nullptr, 0, dagg[b], 2 * dim, n, 2 * dim, 2 * dim, main);
+    else if (tr && q < ntr) rc = pgnn_linear_bwd_data_t(dpre[b], 2 * dim, w1t[q], nullptr, 0, dagg[b], 2 * dim, n, 2 * dim, 2 * dim, main);
     else rc = pgnn_linear_bwd_data(dpre[b], 2 * dim, p.w1, nullptr, 0, dagg[b], 2 * dim, n, 2 * dim, 2 * dim, main);
     if (rc) return rc;
     if (sd) {

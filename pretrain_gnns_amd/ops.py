@@ -1105,7 +1105,8 @@ class ChemGINStack(Function):
         hid = torch.empty(L, n, 2 * dim, dtype=torch.float32, device=dev)
         stats = torch.empty(L, 4, dim, dtype=torch.float32, device=dev)  # mean, 1/std, scale, shift
         status = _lib.status_word(dev)
-        ws = _workspace(_ws_bytes("pgnn_chem_gin_layer_workspace_bytes", n, dim), dev)
+        # (the stack size, not the per-layer one: room for the bf16 planes of every layer's weights behind the op scratch)
+        ws = _workspace(_ws_bytes("pgnn_chem_gin_stack_workspace_bytes", n, dim, xemb1.size(0), xemb2.size(0), L), dev)
         check(load().pgnn_chem_gin_stack_fwd(
             x_idx.data_ptr(), xemb1.data_ptr(), xemb1.size(0), xemb2.data_ptr(), xemb2.size(0), graph.in_ptr.data_ptr(),
             graph.in_src.data_ptr(), graph.in_code.data_ptr(), layers, L, int(training), h0.data_ptr(), acts.data_ptr(),
