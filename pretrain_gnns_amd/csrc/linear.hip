@@ -1257,11 +1257,14 @@ size_t pgnn_weight_planes_bytes(int64_t rows, int64_t cols) {
   return align_up((size_t)3 * rows * ceil_div(cols, 32) * 32 * sizeof(unsigned short), 256);
 }
 
-// 1 where the products of a layer stack should run on pre-split planes: wherever pgnn_linear_fwd would pick the split-bf16
-// kernel (the two are bit-identical, so a stack may switch per shape) up to 65 536 rows -- 21.9 / 18.7 us against 29.1 / 26.8 for
-// the 600 -> 300 products at 6 747 rows, 23.6 against 26.1 for 300 -> 600; level from ~65 k rows on (tools/gemm3w_bench.cpp)
+// 1 where the products of a layer stack should run on pre-split planes: from 48 tiles of 64x160 (where pgnn_linear_fwd still
+// takes the fp32-MFMA kernel's 64x64 tiles: 12.4 / 18.3 us against 20.3 / 20.6 at 2 048 rows) up to 65 536 rows -- 21.9 / 18.7 us
+// against the split-bf16 kernel's 29.1 / 26.8 for the 600 -> 300 products at 6 747 rows, 23.6 against 26.1 for 300 -> 600; level
+// from ~65 k rows on (tools/gemm3w_bench.cpp).  Bit-identical to pgnn_linear_fwd wherever THAT runs the split-bf16 kernel (from
+// 160 tiles; PGNN_GEMM_WP_MIN_TILES=160 restricts the planes to that range), fp32-rounding-equal to its fp32-MFMA kernel below.
 int pgnn_linear_wp_preferred(int64_t m, int64_t k, int64_t n) {
-  return env_knob("PGNN_GEMM_WP", 1) != 0 && k >= 4 && k % 4 == 0 && n % 4 == 0 && m <= 65536 && use_split(m, n);
+  if (env_knob("PGNN_GEMM_WP", 1) == 0 || gemm_mode() != 1 || k < 4 || k % 4 || n % 4 || m > 65536) return 0;
+  return ceil_div(m, 64) * ceil_div(n, 160) >= env_knob("PGNN_GEMM_WP_MIN_TILES", 48);
 }
 
 int pgnn_split_weights(const float* const* src, void* const* dst, const int64_t* rows, const int64_t* cols, const int32_t* transpose,

@@ -161,6 +161,7 @@ def test_bio_one_call_network_equals_per_layer_path(graphs, layers, training, mo
     def run(m, stack, transposed):
         monkeypatch.setattr(hbio, "_STACK_CALL", stack)
         monkeypatch.setenv("PGNN_BWD_TRANSPOSED", "2" if transposed else "0")
+        monkeypatch.setenv("PGNN_GEMM_WP_MIN_TILES", "160")  # weight planes only where the per-layer calls run the same arithmetic
         ops.load().pgnn_reload_env()
         for _ in range(2):  # twice: running statistics advance identically
             m.zero_grad()
@@ -170,6 +171,7 @@ def test_bio_one_call_network_equals_per_layer_path(graphs, layers, training, mo
 
     per_layer, exact, default = run(a, False, False), run(b, True, False), run(c, True, True)
     monkeypatch.delenv("PGNN_BWD_TRANSPOSED")
+    monkeypatch.delenv("PGNN_GEMM_WP_MIN_TILES")
     ops.load().pgnn_reload_env()
     assert torch.equal(per_layer[0], exact[0]) and torch.equal(per_layer[0], default[0])
     for k in per_layer[2]:
@@ -523,6 +525,10 @@ def test_one_call_network_equals_per_layer_path(graphs, layers, training, monkey
     hchem, _ = _hip()
     monkeypatch.setenv("PGNN_BWD_TRANSPOSED", "0")
     monkeypatch.setenv("PGNN_BN_STATS_IN_GEMM", "0")  # (the one-call forward takes the BatchNorm statistics from the GEMM epilogue)
+    # the one-call network's products run on pre-split weight planes, bit-identical to the per-layer calls wherever THOSE take the
+    # split-bf16 kernel (from 160 tiles; the 1500-graph case); below, the per-layer calls run the fp32-MFMA kernel, so the planes
+    # are held off there -- test_one_call_network_on_weight_planes_below_the_split_threshold holds that pairing to fp32 rounding
+    monkeypatch.setenv("PGNN_GEMM_WP_MIN_TILES", "160")
     ops.load().pgnn_reload_env()
     _, a = _pair(ochem.GNN, hchem.GNN, layers, 300, seed=5)
     b = copy.deepcopy(a)
@@ -551,7 +557,36 @@ def test_one_call_network_equals_per_layer_path(graphs, layers, training, monkey
         assert torch.equal(res[0][2][k], res[1][2][k]), k
     monkeypatch.delenv("PGNN_BWD_TRANSPOSED")
     monkeypatch.delenv("PGNN_BN_STATS_IN_GEMM")
+    monkeypatch.delenv("PGNN_GEMM_WP_MIN_TILES")
     ops.load().pgnn_reload_env()
+
+
+@pytest.mark.parametrize("graphs", [64, 90])
+def test_one_call_network_on_weight_planes_below_the_split_threshold(graphs, monkeypatch):
+    """between 48 and 160 tiles (~1 500 .. 2 600 rows) the one-call network multiplies on weight planes (split-bf16 arithmetic)
+    while the per-layer calls still take the fp32-MFMA kernel: equal to fp32 rounding carried through five BatchNorm'ed layers,
+    not bit for bit"""
+    import copy
+    from pretrain_gnns_amd import ops
+    hchem, _ = _hip()
+    _, a = _pair(ochem.GNN, hchem.GNN, 5, 300, seed=5)
+    b = copy.deepcopy(a)
+    a.train(), b.train()
+    d = synthetic.chem_masking_batch(graphs, seed=6).to(DEV)
+    assert int(ops.load().pgnn_linear_wp_preferred(d.x.size(0), 600, 300)) == 1
+    w = torch.randn(d.x.size(0), 300, device=DEV)
+    res = []
+    for m, flag in ((a, True), (b, False)):
+        monkeypatch.setattr(hchem, "_STACK_CALL", flag)
+        m.zero_grad()
+        out = m(d.x, d.edge_index, d.edge_attr)
+        (out * w).sum().backward()
+        res.append((out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=2e-5, atol=2e-5)
+    top = max(float(g.abs().max()) for g in res[1][1].values())
+    for k in res[0][1]:
+        scale = float(res[1][1][k].abs().max())
+        assert float((res[0][1][k] - res[1][1][k]).abs().max()) <= 1e-4 * scale + 2e-5 * top, k
 
 
 @pytest.mark.parametrize("graphs,layers", [(48, 5), (256, 5), (3, 2)])

@@ -406,6 +406,101 @@ def test_linear_fwd_split_bf16_is_as_accurate_as_the_fp32_mfma(m, k, n, monkeypa
     assert rms3 <= 1.25 * rms32 + 1e-9 and max3 <= 2.0 * max32 + 1e-9, out
 
 
+def _weight_planes(lib, sp, mats, transpose):
+    """pgnn_split_weights on a list of fp32 matrices -> list of uint16 plane tensors [3, rows, ld]"""
+    import ctypes
+    cnt = len(mats)
+    outs = []
+    for w, tr in zip(mats, transpose):
+        r, c = (w.size(1), w.size(0)) if tr else (w.size(0), w.size(1))
+        ld = (c + 31) // 32 * 32
+        assert int(lib.pgnn_weight_planes_bytes(r, c)) >= 3 * r * ld * 2
+        outs.append(torch.full((3, r, ld), 0x7fc0, dtype=torch.int16, device=DEV))  # NaN pattern: padding must be overwritten
+    arr = lambda vals, ty: (ty * cnt)(*vals)
+    ops = _ops()
+    ops.check(lib.pgnn_split_weights(arr([w.data_ptr() for w in mats], ctypes.c_void_p), arr([o.data_ptr() for o in outs], ctypes.c_void_p),
+                                     arr([w.size(0) for w in mats], ctypes.c_int64), arr([w.size(1) for w in mats], ctypes.c_int64),
+                                     arr([int(t) for t in transpose], ctypes.c_int32), cnt, sp), "split")
+    return outs
+
+
+def _bf16_planes_to_float64(planes):
+    return (planes.to(torch.int32) << 16).view(torch.float32).double()
+
+
+@pytest.mark.parametrize("rows,cols", [(600, 300), (300, 600), (7, 100), (119, 300), (33, 32)])
+def test_split_weights_planes_are_the_exact_three_term_split(rows, cols):
+    """pgnn_split_weights: the three bf16 planes of W (and of W^T) sum back to W EXACTLY (3 x 8 significand bits), each plane is
+    the round-to-nearest-even bf16 of what the planes before it left over, and the padding columns up to the 32-multiple row
+    pitch are zero (csrc/linear.hip k_split_jobs; nn.Linear weights of chem/model.py:29)"""
+    ops = _ops()
+    lib, sp = ops.load(), ops.stream_ptr()
+    torch.manual_seed(rows + cols)
+    w = (torch.randn(rows, cols) * torch.logspace(-4, 2, cols)).to(DEV)
+    plain, transposed = _weight_planes(lib, sp, [w, w], [False, True])
+    for planes, ref in ((plain, w), (transposed, w.t().contiguous())):
+        r, c = ref.shape
+        vals = _bf16_planes_to_float64(planes)
+        assert torch.equal(vals[:, :, :c].sum(0), ref.double())                      # exact
+        assert float(vals[:, :, c:].abs().max()) == 0.0 if planes.size(2) > c else True  # zero padding
+        h = ref.to(torch.bfloat16)
+        assert torch.equal(vals[0, :, :c], h.double())
+        m = (ref - h.float()).to(torch.bfloat16)
+        assert torch.equal(vals[1, :, :c], m.double())
+        l = (ref - h.float() - m.float()).to(torch.bfloat16)
+        assert torch.equal(vals[2, :, :c], l.double())
+
+
+@pytest.mark.parametrize("m,k,n", [(6747, 300, 600), (6747, 600, 300), (10194, 600, 600), (40000, 300, 600), (2051, 300, 600), (1000, 300, 300), (77, 36, 124),
+                                   (130, 4, 4), (513, 1000, 164), (129, 300, 600)])
+def test_products_on_weight_planes(m, k, n, monkeypatch):
+    """pgnn_linear_fwd_wp / pgnn_linear_bwd_data_wp (k_gemm3w: weights pre-split into bf16 planes, activations DMA'd as fp32 and
+    split by the consuming wave; chem/model.py:29,54-55 forward and backward): BIT-identical to pgnn_linear_fwd(_colstats) /
+    pgnn_linear_bwd_data wherever those run the split-bf16 kernel (forced here with PGNN_GEMM3_MIN_TILES=1), as accurate against
+    float64 as the fp32-MFMA kernel everywhere; ragged M / N edges, K not a multiple of the 32-deep k-step, every tile shape"""
+    ops = _ops()
+    lib, sp = ops.load(), ops.stream_ptr()
+    torch.manual_seed(m + k + n)
+    x = (torch.randn(m, k) * torch.logspace(-2, 2, k)).to(DEV)
+    w = (torch.randn(n, k) * 0.05).to(DEV)
+    b = torch.randn(n, device=DEV)
+    dy = (torch.randn(m, n) * 1e-3).to(DEV)
+    mask = torch.relu(torch.randn(m, k, device=DEV))
+    wp, wtp = _weight_planes(lib, sp, [w, w], [False, True])
+    nblk = (m + 15) // 16
+    monkeypatch.setenv("PGNN_GEMM3_MIN_TILES", "1")  # the reference calls on the split-bf16 kernel at every size
+    lib.pgnn_reload_env()
+    y0, y1 = torch.empty(m, n, device=DEV), torch.full((m, n), float("nan"), device=DEV)
+    c0, c1 = torch.empty(nblk, 2, n, device=DEV), torch.full((nblk, 2, n), float("nan"), device=DEV)
+    dx0, dx1 = torch.empty(m, k, device=DEV), torch.full((m, k), float("nan"), device=DEV)
+    ops.check(lib.pgnn_linear_fwd_colstats(x.data_ptr(), k, w.data_ptr(), b.data_ptr(), y0.data_ptr(), n, m, k, n, 1, c0.data_ptr(), sp), "ref fwd")
+    ops.check(lib.pgnn_linear_bwd_data(dy.data_ptr(), n, w.data_ptr(), mask.data_ptr(), k, dx0.data_ptr(), k, m, k, n, sp), "ref bwd")
+    for cfg in ("-1", "0", "1", "2", "3"):
+        if cfg == "-1":
+            monkeypatch.delenv("PGNN_GEMM3W_CFG", raising=False)
+        else:
+            monkeypatch.setenv("PGNN_GEMM3W_CFG", cfg)
+        lib.pgnn_reload_env()
+        y1.fill_(float("nan")); c1.fill_(float("nan")); dx1.fill_(float("nan"))
+        ops.check(lib.pgnn_linear_fwd_wp(x.data_ptr(), k, wp.data_ptr(), b.data_ptr(), y1.data_ptr(), n, m, k, n, 1, c1.data_ptr(), sp), "wp fwd")
+        ops.check(lib.pgnn_linear_bwd_data_wp(dy.data_ptr(), n, wtp.data_ptr(), mask.data_ptr(), k, dx1.data_ptr(), k, m, k, n, sp), "wp bwd")
+        assert torch.equal(y0, y1), cfg
+        assert torch.equal(c0, c1), cfg
+        assert torch.equal(dx0, dx1), cfg
+    monkeypatch.delenv("PGNN_GEMM3W_CFG", raising=False)
+    monkeypatch.delenv("PGNN_GEMM3_MIN_TILES")
+    lib.pgnn_reload_env()
+    # accuracy against float64, relative to the |a|.|b| bound of each entry -- the bar of the fp32-MFMA kernel's test
+    want = torch.relu(x.double() @ w.double().t() + b.double())
+    scale = x.double().abs() @ w.double().abs().t() + b.double().abs()
+    err = (y1.double() - want).abs() / scale
+    assert err.max().item() < 2e-6 and err.pow(2).mean().sqrt().item() < 3e-7
+    wantd = (dy.double() @ w.double()) * (mask > 0)
+    scaled = dy.double().abs() @ w.double().abs()
+    errd = (dx1.double() - wantd).abs() / scaled
+    assert errd.max().item() < 2e-6
+
+
 @pytest.mark.parametrize("m,k,n", [(6747, 600, 300), (6747, 300, 600), (1000, 600, 300), (130, 300, 300), (17, 64, 32), (16, 64, 36), (1, 32, 8)])
 @pytest.mark.parametrize("offset", [0.0, 1000.0])
 def test_linear_fwd_colstats_and_batchnorm_statistics_from_blocks(m, k, n, offset):
