@@ -6,8 +6,8 @@ Everything numerical or structural in these fixtures is produced by the unmodifi
 /root/reference (imported through oracle/refshim, third-party modules replaced by the stand-ins of
 pyg103.py): `model.GNN` / `GNN_graphpred` forward + backward, `batch.BatchMasking` /
 `BatchSubstructContext.from_data_list`, `util.MaskAtom` / `MaskEdge` / `ExtractSubstructureContextPair`,
-and the `train()` / `eval()` functions of pretrain_masking.py, pretrain_contextpred.py and finetune.py
-(chem and bio).  Only the RAW synthetic graphs (SURVEY.md §8d shapes) come from this repository's
+`util.NegativeEdge` / `batch.BatchAE`, bio `batch.BatchFinetune`, and the `train()` / `eval()` functions of pretrain_masking.py,
+pretrain_contextpred.py and finetune.py (chem and bio), chem pretrain_edgepred.py and pretrain_deepgraphinfomax.py.  Only the RAW synthetic graphs (SURVEY.md §8d shapes) come from this repository's
 generator; they are stored in the fixture, so the tests never regenerate them.
 
 The fixtures are what `/root/reference` leaves behind for the GPU box, where it does not exist:
@@ -483,6 +483,95 @@ def make_bio_contextpred(ref):
         save(name, fx)
 
 
+# ----------------------------------------------------------------------------- chem: edge prediction, Deep Graph Infomax
+def make_chem_edgepred(ref):
+    """chem/util.py NegativeEdge -> chem/batch.py BatchAE (chem/dataloader.py DataLoaderAE) -> chem/pretrain_edgepred.py:25-52 train()"""
+    pe = ref.pretrain_edgepred
+    raw = chem_raw(4 * 32, seed=12)
+    torch.manual_seed(13)  # NegativeEdge draws its candidates with torch.randint
+    tf = ref.util.NegativeEdge()
+    graphs = [tf(to_ref_data(ref, g)) for g in raw]
+    fx = {"raw": raw_pack(raw), "batch_size": 32, "neg": ragged([g.negative_edge_index.t().reshape(-1).tolist() for g in graphs])}
+    loader = ref.dataloader.DataLoaderAE(graphs, batch_size=32, shuffle=False, num_workers=0)
+    fx["batch0"] = batch_pack(next(iter(loader)))
+    for gt in ("gin", "gcn"):
+        torch.manual_seed(0)
+        model = ref.model.GNN(5, 300, JK="last", drop_ratio=0, gnn_type=gt)
+        opt = adam(model.parameters())
+        with Recorder(pe, "criterion") as crit:
+            ret = pe.train(argparse.Namespace(), model, torch.device("cpu"), loader, opt)
+        vals = [float(v) for v in crit.values]  # two calls per step: positive pairs, negative pairs
+        fx[gt] = {"returned": np.array(ret, dtype=np.float64), "loss": np.array([a + b for a, b in zip(vals[0::2], vals[1::2])]),
+                  "final_params": pack_params(list(model.named_parameters()), lambda p: p)}
+    save("ref_chem_edgepred_b32", fx)
+
+
+def make_chem_infomax(ref):
+    """torch_geometric DataLoader (chem/pretrain_deepgraphinfomax.py:4) -> its Infomax / Discriminator -> train() :52-90"""
+    dgi = ref.pretrain_deepgraphinfomax
+    raw = chem_raw(4 * 32, seed=14)
+    graphs = [to_ref_data(ref, g) for g in raw]
+    loader = dgi.DataLoader(graphs, batch_size=32, shuffle=False, num_workers=0)
+    torch.manual_seed(0)
+    gnn = ref.model.GNN(5, 300, JK="last", drop_ratio=0, gnn_type="gin")
+    model = dgi.Infomax(gnn, dgi.Discriminator(300))
+    disc0 = model.discriminator.weight.detach().clone()
+    opt = adam(model.parameters())
+    vals = []
+
+    class RecordingLoss(torch.nn.Module):  # `loss` is a registered child module: its stand-in has to be one too
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, *a):
+            r = self.inner(*a)
+            vals.append(float(r))
+            return r
+
+    model.loss = RecordingLoss(model.loss)  # an instance attribute: the script's source is untouched
+    ret = dgi.train(argparse.Namespace(), model, torch.device("cpu"), loader, opt)
+    fx = {"raw": raw_pack(raw), "batch_size": 32, "discriminator_init": disc0, "returned": np.array(ret, dtype=np.float64),
+          "loss": np.array([a + b for a, b in zip(vals[0::2], vals[1::2])]),
+          "final_params": pack_params(list(model.gnn.named_parameters()) + [("discriminator.weight", model.discriminator.weight)], lambda p: p)}
+    save("ref_chem_infomax_b32", fx)
+
+
+# ----------------------------------------------------------------------------- bio: fine-tuning
+def make_bio_finetune(ref):
+    """bio/batch.py BatchFinetune (bio/dataloader.py DataLoaderFinetune) -> bio/model.py GNN_graphpred :293-347 ->
+    bio/finetune.py:25-65 train() / eval()"""
+    ft = ref.finetune
+    rng = np.random.default_rng(15)
+    raw, ys = [], []
+    for _ in range(4 * 32):
+        g = synthetic.ppi_like_graph(rng)
+        ys.append((rng.random(40) < 0.3).astype(np.int64))
+        raw.append(g)
+    graphs = []
+    for g, y in zip(raw, ys):
+        d = to_ref_bio(ref, g)
+        d.go_target_downstream = torch.from_numpy(y)
+        graphs.append(d)
+    fx = {"raw": raw_pack(raw), "y": np.stack(ys), "batch_size": 32}
+    loader = ref.dataloader.DataLoaderFinetune(graphs, batch_size=32, shuffle=False, num_workers=0)
+    b0 = next(iter(loader))
+    fx["batch0"] = {"center_node_idx": b0.center_node_idx, "batch": b0.batch}
+    for pooling in ("mean", "sum"):
+        torch.manual_seed(0)
+        model = ref.model.GNN_graphpred(5, 300, 40, JK="last", drop_ratio=0, graph_pooling=pooling, gnn_type="gin")
+        opt = adam(model.parameters())
+        with Recorder(ft, "criterion") as crit:
+            ft.train(argparse.Namespace(), model, torch.device("cpu"), loader, opt)
+        roc = ft.eval(argparse.Namespace(), model, torch.device("cpu"), loader)
+        model.eval()
+        with torch.no_grad():
+            pred_eval = model(b0)
+        fx[pooling] = {"pred_step0": crit.inputs[0].float(), "loss": np.array([float(v) for v in crit.values]), "roc": np.asarray(roc, dtype=np.float64),
+                       "pred_eval_batch0": pred_eval, "final_params": pack_params(list(model.named_parameters()), lambda p: p)}
+    save("ref_bio_finetune_b32", fx)
+
+
 # ----------------------------------------------------------------------------- main
 def main():
     if not refshim.available():
@@ -493,7 +582,9 @@ def main():
     chem, bio = refshim.load("chem"), refshim.load("bio")
     jobs = [("chem_spec", make_chem_spec, chem), ("chem_masking", make_chem_masking, chem),
             ("chem_contextpred", make_chem_contextpred, chem), ("chem_finetune", make_chem_finetune, chem),
-            ("bio_masking", make_bio_masking, bio), ("bio_contextpred", make_bio_contextpred, bio)]
+            ("chem_edgepred", make_chem_edgepred, chem), ("chem_infomax", make_chem_infomax, chem),
+            ("bio_masking", make_bio_masking, bio), ("bio_contextpred", make_bio_contextpred, bio),
+            ("bio_finetune", make_bio_finetune, bio)]
     for tag, fn, ref in jobs:
         if not only or tag in only:
             fn(ref)

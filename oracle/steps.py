@@ -181,6 +181,38 @@ def chem_masking_epoch(model_list, optimizer_list, loader, mask_edge=False, devi
     return loss_accum / step, acc_node_accum / step, acc_edge_accum / step
 
 
+def bio_finetune_step(model, optimizer, batch):
+    """bio/finetune.py:25-37 (loop body of train()): bio GNN_graphpred on the whole batch object (it reads
+    center_node_idx), BCE-with-logits in float64 against go_target_downstream viewed as [graphs, tasks]."""
+    pred = model(batch)
+    y = batch.go_target_downstream.view(pred.shape).to(torch.float64)
+    optimizer.zero_grad()
+    loss = F.binary_cross_entropy_with_logits(pred.double(), y)
+    loss.backward()
+    optimizer.step()
+    return float(loss.detach().cpu().item())
+
+
+def bio_eval(model, batches):
+    """bio/finetune.py:40-65: eval-mode scores of every batch, then one ROC-AUC per task (nan where a task has a single class)."""
+    import numpy as np
+    model.eval()
+    y_true, y_scores = [], []
+    for batch in batches:
+        with torch.no_grad():
+            pred = model(batch)
+        y_true.append(batch.go_target_downstream.view(pred.shape).detach().cpu())
+        y_scores.append(pred.detach().cpu())
+    y_true, y_scores = torch.cat(y_true, dim=0).numpy(), torch.cat(y_scores, dim=0).numpy()
+    roc_list = []
+    for i in range(y_true.shape[1]):
+        if np.sum(y_true[:, i] == 1) > 0 and np.sum(y_true[:, i] == 0) > 0:
+            roc_list.append(roc_auc(y_true[:, i], y_scores[:, i]))
+        else:
+            roc_list.append(np.nan)
+    return np.array(roc_list)
+
+
 def chem_edgepred_step(model, optimizer, batch):
     """chem/pretrain_edgepred.py:32-46 (loop body of train()): dot-product scores of the bonded pairs (one
     direction of every bond) against sampled non-bonded pairs, BCE-with-logits in float32."""

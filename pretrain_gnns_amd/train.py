@@ -405,6 +405,41 @@ def chem_eval(model, batches):
     return sum(roc_list) / len(roc_list)
 
 
+def bio_finetune_step(model, optimizer, batch):
+    """One iteration of bio/finetune.py:25-37: bio ``GNN_graphpred`` on the batch object (mean / sum pooling concatenated with
+    the centre node's row, bio/model.py:338-347), float64 BCE-with-logits against ``go_target_downstream`` viewed as
+    [graphs, tasks], backward, optimizer step."""
+    pred = model(batch)
+    y = batch.go_target_downstream.view(pred.shape).to(torch.float64)
+    optimizer.zero_grad()
+    loss = F.binary_cross_entropy_with_logits(pred.double(), y)
+    loss.backward()
+    optimizer.step()
+    return float(loss.detach().cpu().item())
+
+
+def bio_eval(model, batches):
+    """bio/finetune.py:40-65: eval-mode scores for every batch, then one ROC-AUC per task (nan where a task shows a single
+    class) -- the array the reference's eval() returns."""
+    import numpy as np
+    model.eval()
+    y_true, y_scores = [], []
+    for batch in batches:
+        with torch.no_grad():
+            pred = model(batch)
+        y_true.append(batch.go_target_downstream.view(pred.shape))
+        y_scores.append(pred)
+    y_true = torch.cat(y_true, dim=0).cpu().numpy()
+    y_scores = torch.cat(y_scores, dim=0).cpu().numpy()
+    roc_list = []
+    for i in range(y_true.shape[1]):
+        if np.sum(y_true[:, i] == 1) > 0 and np.sum(y_true[:, i] == 0) > 0:
+            roc_list.append(_roc_auc(y_true[:, i], y_scores[:, i]))
+        else:
+            roc_list.append(np.nan)
+    return np.array(roc_list)
+
+
 def chem_edgepred_step(model, optimizer, batch):
     """One iteration of chem/pretrain_edgepred.py:32-46: dot-product scores of the bonded atom pairs (one
     direction per bond) against the batch's sampled non-bonded pairs, BCE-with-logits (float32)."""

@@ -203,3 +203,30 @@ def assert_same_bio_context(fx, raw, graphs, want):
         assert ref_edges == my_edges, i
 
 
+
+
+def edgepred_batches(fx):
+    """raw graphs + the reference's stored NegativeEdge draws -> BatchAE layout through the host collate"""
+    raw = raw_graphs(fx["raw"])
+    graphs = []
+    for i, g in enumerate(raw):
+        neg = ragged(fx["neg"], i).reshape(-1, 2).t().contiguous()
+        graphs.append(synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr, negative_edge_index=neg))
+    bs = int(fx["batch_size"])
+    return [synthetic.collate(graphs[i:i + bs]) for i in range(0, len(graphs), bs)]
+
+
+def plain_batches(fx):
+    raw = raw_graphs(fx["raw"])
+    graphs = [synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr) for g in raw]
+    bs = int(fx["batch_size"])
+    return [synthetic.collate(graphs[i:i + bs]) for i in range(0, len(graphs), bs)]
+
+
+def bio_finetune_batches(fx):
+    """BatchFinetune layout (bio/batch.py:4-50): centre node indices shifted by the node offset, labels concatenated"""
+    raw = raw_graphs(fx["raw"], bio=True)
+    graphs = [synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr, center_node_idx=g.center_node_idx, go_target_downstream=y)
+              for g, y in zip(raw, fx["y"])]
+    bs = int(fx["batch_size"])
+    return [synthetic.collate(graphs[i:i + bs], shift_center=True) for i in range(0, len(graphs), bs)]

@@ -279,6 +279,80 @@ def test_finetune_mirrors_reproduce_reference(pooling):
         rf.check_params(list(model.named_parameters()), want["final_params"], lambda p: p, rtol=2e-5)
 
 
+# ============================================================================== edge prediction, Deep Graph Infomax
+@pytest.mark.parametrize("gt", ["gin", "gcn"])
+def test_edgepred_mirrors_reproduce_reference(gt):
+    """chem/util.py NegativeEdge + chem/batch.py BatchAE + chem/pretrain_edgepred.py:25-52 train() run by the reference"""
+    fx = rf.load("ref_chem_edgepred_b32")
+    batches = rf.edgepred_batches(fx)
+    for k, v in fx["batch0"].items():
+        assert torch.equal(getattr(batches[0], k), v), k  # the BatchAE collate, bit for bit
+    want = fx[gt]
+    for step in (steps.chem_edgepred_step, ptrain.chem_edgepred_step):
+        torch.manual_seed(0)
+        model = ochem.GNN(5, 300, JK="last", drop_ratio=0, gnn_type=gt)
+        model.train()
+        opt = adam(model.parameters())
+        out = [step(model, opt, b) for b in batches]
+        losses, accs = np.array([o[0] for o in out]), np.array([o[1] for o in out])
+        np.testing.assert_allclose(losses, want["loss"].numpy(), rtol=2e-6)
+        # train() returns its sums divided by the LAST step index, not the step count (chem/pretrain_edgepred.py:52)
+        np.testing.assert_allclose([accs.sum() / (len(out) - 1), losses.sum() / (len(out) - 1)], want["returned"].numpy(), rtol=2e-6)
+        rf.check_params(list(model.named_parameters()), want["final_params"], lambda p: p, rtol=2e-5)
+
+
+def test_infomax_mirrors_reproduce_reference():
+    """torch_geometric DataLoader collate + chem/pretrain_deepgraphinfomax.py:30-90 (Discriminator, Infomax, train()) run by the reference"""
+    fx = rf.load("ref_chem_infomax_b32")
+    batches = rf.plain_batches(fx)
+    for driver in ("oracle_steps", "product_mirror"):
+        torch.manual_seed(0)
+        gnn = ochem.GNN(5, 300, JK="last", drop_ratio=0, gnn_type="gin")
+        disc = steps.Discriminator(300) if driver == "oracle_steps" else ptrain.Discriminator(300)
+        assert torch.equal(disc.weight.detach(), fx["discriminator_init"])  # same draw from the same generator state
+        gnn.train()
+        if driver == "oracle_steps":
+            opt = adam(list(gnn.parameters()) + list(disc.parameters()))
+            out = [steps.chem_infomax_step(gnn, disc, opt, b) for b in batches]
+        else:
+            model = ptrain.Infomax(gnn, disc)
+            model.pool = pyg.global_mean_pool  # CPU run: the HIP pooling op needs the GPU
+            opt = adam(model.parameters())
+            out = [ptrain.chem_infomax_step(model, opt, b) for b in batches]
+        losses, accs = np.array([o[0] for o in out]), np.array([o[1] for o in out])
+        np.testing.assert_allclose(losses, fx["loss"].numpy(), rtol=2e-6)
+        np.testing.assert_allclose([accs.sum() / (len(out) - 1), losses.sum() / (len(out) - 1)], fx["returned"].numpy(), rtol=2e-6)
+        named = list(gnn.named_parameters()) + [("discriminator.weight", disc.weight)]
+        rf.check_params(named, fx["final_params"], lambda p: p, rtol=2e-5)
+
+
+# ============================================================================== bio fine-tuning
+@pytest.mark.parametrize("pooling", ["mean", "sum"])
+def test_bio_finetune_mirrors_reproduce_reference(pooling):
+    """bio/batch.py BatchFinetune + bio/model.py GNN_graphpred :293-347 + bio/finetune.py:25-65 train() / eval() run by the reference"""
+    fx = rf.load("ref_bio_finetune_b32")
+    want = fx[pooling]
+    batches = rf.bio_finetune_batches(fx)
+    assert torch.equal(batches[0].center_node_idx, fx["batch0"]["center_node_idx"]) and torch.equal(batches[0].batch, fx["batch0"]["batch"])
+    for driver in ("oracle_steps", "product_mirror"):
+        torch.manual_seed(0)
+        model = obio.GNN_graphpred(5, 300, 40, JK="last", drop_ratio=0, graph_pooling=pooling, gnn_type="gin")
+        opt = adam(model.parameters())
+        model.train()
+        import copy
+        with torch.no_grad():  # (on a copy: a train-mode forward advances the BatchNorm running statistics)
+            close(copy.deepcopy(model)(batches[0]), want["pred_step0"], 1e-6, 1e-6)
+        step = steps.bio_finetune_step if driver == "oracle_steps" else ptrain.bio_finetune_step
+        losses = [step(model, opt, b) for b in batches]
+        np.testing.assert_allclose(losses, want["loss"].numpy(), rtol=2e-6)
+        evalf = steps.bio_eval if driver == "oracle_steps" else ptrain.bio_eval
+        np.testing.assert_allclose(evalf(model, batches), want["roc"].numpy(), rtol=0, atol=1e-6, equal_nan=True)
+        model.eval()
+        with torch.no_grad():
+            close(model(batches[0]), want["pred_eval_batch0"], 1e-5, 1e-5)
+        rf.check_params(list(model.named_parameters()), want["final_params"], lambda p: p, rtol=2e-5)
+
+
 # ============================================================================== bio
 @pytest.mark.parametrize("name,types", [("ref_bio_masking_b8", ("gin", "gcn")), ("ref_bio_masking_b256", ("gin",))])
 def test_bio_masking_equals_reference(name, types):
@@ -430,6 +504,50 @@ def test_oracle_equals_live_reference_graphpred(pooling):
         o = ochem.GNN_graphpred(3, 32, 5, JK=jk, drop_ratio=0, graph_pooling=pooling, gnn_type="gin")
         o.load_state_dict(r.state_dict(), strict=True)
         close(o(b.x, b.edge_index, b.edge_attr, b.batch), r(b.x, b.edge_index, b.edge_attr, b.batch), 1e-5, 1e-6)
+
+
+@live
+@pytest.mark.parametrize("pooling", ["sum", "mean", "max", "attention"])
+def test_oracle_equals_live_reference_graphpred_bio(pooling):
+    """bio/model.py:293-347: cat[pool(h), h[center_node_idx]] -> Linear(2 D, tasks), on a BatchFinetune-layout batch"""
+    ref = refshim.load("bio")
+    rng = np.random.default_rng(29)
+    graphs = []
+    for _ in range(12):
+        g = synthetic.ppi_like_graph(rng)
+        graphs.append(synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr, center_node_idx=g.center_node_idx))
+    b = synthetic.collate(graphs, shift_center=True)
+    for jk in ("last",):
+        torch.manual_seed(6)
+        r = ref.model.GNN_graphpred(3, 32, 7, JK=jk, drop_ratio=0, graph_pooling=pooling, gnn_type="gin")
+        torch.manual_seed(6)
+        o = obio.GNN_graphpred(3, 32, 7, JK=jk, drop_ratio=0, graph_pooling=pooling, gnn_type="gin")
+        assert list(o.state_dict()) == list(r.state_dict())
+        assert all(torch.equal(a, c) for a, c in zip(o.state_dict().values(), r.state_dict().values()))  # same seeded construction
+        r.train(), o.train()
+        got, want = o(b), r(b)
+        assert torch.equal(got, want)
+        if pooling == "max":  # (the scatter_max stand-ins fill in place: forward only)
+            continue
+        got.square().sum().backward()
+        want.square().sum().backward()
+        for (n, pa), (_, pb) in zip(o.named_parameters(), r.named_parameters()):
+            if pb.grad is not None:
+                close(pa.grad, pb.grad, 1e-5, 1e-6)
+
+
+@live
+def test_new_fixtures_are_what_the_live_reference_produces(tmp_path, monkeypatch):
+    """regenerate the edge-prediction and bio fine-tuning fixtures with the reference's code and compare with the committed ones"""
+    from oracle.refshim import make_fixtures as mf
+    monkeypatch.setattr(mf, "OUT", str(tmp_path))
+    mf.make_chem_edgepred(refshim.load("chem"))
+    mf.make_bio_finetune(refshim.load("bio"))
+    for name in ("ref_chem_edgepred_b32", "ref_bio_finetune_b32"):
+        with np.load(os.path.join(str(tmp_path), name + ".npz")) as new, np.load(os.path.join(rf.GOLDEN, name + ".npz")) as old:
+            assert sorted(new.files) == sorted(old.files)
+            for k in new.files:
+                np.testing.assert_array_equal(new[k], old[k], err_msg=name + ":" + k)
 
 
 @live
