@@ -235,7 +235,7 @@ def make_chem_masking(ref):
                     fx[tag][gt] = chem_forward_backward(ref, batch, gt, full)
         save(name, fx)
 
-    # train() sequences: 5 x 32 graphs (gin, gin + bond masking, gcn) and 4 x 256 graphs (gin)
+    # train() sequences: 5 x 32 graphs (gin, gin + bond masking, gcn) and 10 x 256 graphs (gin)
     raw = chem_raw(5 * 32, seed=2)
     fx = {"raw": raw_pack(raw), "batch_size": 32}
     for tag, gt, me in (("gin", "gin", 0), ("gin_mask_edge", "gin", 1), ("gcn", "gcn", 0)):
@@ -244,9 +244,9 @@ def make_chem_masking(ref):
         fx[tag]["mask_counts"] = np.array([g.masked_atom_indices.numel() for g in graphs])
         fx[tag]["mask_local"] = torch.cat([g.masked_atom_indices for g in graphs])
     save("ref_chem_masking_train_b32", fx)
-    raw = chem_raw(4 * 256, seed=4)
+    raw = chem_raw(10 * 256, seed=4)  # ten steps: the +-0.1 % epoch-accuracy bar of BASELINE.json is checked on this run
     graphs = chem_masked_graphs(ref, raw, seed=5, mask_edge=0)
-    fx = {"raw": raw_pack(raw), "batch_size": 256, "gin": chem_train_sequence(ref, graphs, 256, "gin", 0, steps=4)}
+    fx = {"raw": raw_pack(raw), "batch_size": 256, "gin": chem_train_sequence(ref, graphs, 256, "gin", 0, steps=10)}
     fx["gin"]["mask_counts"] = np.array([g.masked_atom_indices.numel() for g in graphs])
     fx["gin"]["mask_local"] = torch.cat([g.masked_atom_indices for g in graphs])
     save("ref_chem_masking_train_b256", fx)

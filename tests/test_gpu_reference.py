@@ -78,8 +78,11 @@ def check_rows(t, tree, what, tree64=None):
             want, got, slack = tree[rows64], g64, (tree[rows64] - w64).abs()
         log(test=what + "/vs_f64", max_abs_err=float(e64.max()), ref32_vs_ref64=float(slack.max()))
     err = (got - want).abs()
-    log(test=what, max_abs_err=float(err.max()))
+    needed = err > 1e-4 + 1e-4 * want.abs()  # elements that pass only through the |ref32 - ref64| slack
+    frac = float(needed.float().mean())
+    log(test=what, max_abs_err=float(err.max()), fraction_needing_f64_slack=frac, elements=int(err.numel()))
     assert bool((err <= 1e-4 + 1e-4 * want.abs() + slack).all()), "%s: max %.3e" % (what, float(err.max()))
+    assert frac < 0.01, "%s: %.3f %% of the elements are outside the literal 1e-4 bar" % (what, 100 * frac)
     if not torch.is_tensor(tree):  # whole-tensor guard for the rows that are not stored: column means
         n = t.size(0)
         dm = (t.detach().cpu().double().sum(0) - tree["colsum"]).abs() / n
@@ -246,6 +249,30 @@ def test_train_trajectory_vs_reference_train(name, tag, gnn_type, mask_edge):
     np.testing.assert_allclose(sum(losses) / (steps_ - 1), float(want["returned"][0]), rtol=TRAJ_RTOL)
 
 
+def test_epoch_accuracy_vs_reference_train_in_the_benchmarked_mode():
+    """BASELINE.json: 'masked-atom-prediction accuracy on the reference's own eval matching CPU within +-0.1 %'.  The reference's
+    train() (chem/pretrain_masking.py:34-78) over TEN 256-molecule batches returns (loss_accum / step, acc_accum / step); the same
+    epoch through train.chem_masking_epoch in the mode bench.py times -- the one-launch optim.Adam.shared for the three
+    optimizers, the fused head, loss / accuracy summed on the device and fetched once (readback="epoch"), gradients deposited
+    directly -- must return the same accuracy within 0.001 absolute and the same loss within TRAJ_RTOL"""
+    from pretrain_gnns_amd import optim as poptim
+    fx = rf.load("ref_chem_masking_train_b256")
+    want = fx["gin"]
+    batches = device_masked_batches(fx, "gin", False)
+    assert len(batches) >= 10
+    models = chem_models("gin")
+    opts = poptim.Adam.shared([m.parameters() for m in models], lr=1e-3, weight_decay=0)
+    was = ops.set_direct_grads(True)
+    try:
+        ret = ptrain.chem_masking_epoch(models, opts, batches, mask_edge=False, device=torch.device(DEV), readback="epoch")
+    finally:
+        ops.set_direct_grads(was)
+    ref_loss, ref_acc = float(want["returned"][0]), float(want["returned"][1])
+    log(test="epoch_accuracy_b256x10", loss=ret[0], ref_loss=ref_loss, acc=ret[1], ref_acc=ref_acc, abs_acc_diff=abs(ret[1] - ref_acc))
+    assert abs(ret[0] - ref_loss) <= TRAJ_RTOL * ref_loss
+    assert abs(ret[1] - ref_acc) <= 1e-3, (ret[1], ref_acc)
+
+
 # ============================================================================== context prediction (BASELINE configs[2])
 @pytest.mark.parametrize("name", ["ref_chem_contextpred_b32", "ref_chem_contextpred_b256"])
 def test_device_context_transform_vs_reference(name):
@@ -330,6 +357,81 @@ def test_finetune_vs_reference(pooling):
     log(test="finetune/%s" % pooling, rel_err_per_step=rel.tolist())
     assert rel[0] <= 1e-5 and (rel <= TRAJ_RTOL).all(), rel
     assert abs(ptrain.chem_eval(model, batches) - want["roc_auc"]) <= 0.02
+
+
+# ============================================================================== edge prediction, Deep Graph Infomax
+def _traj(losses, want, what):
+    rel = np.abs(np.array(losses) - want) / np.abs(want)
+    log(test=what, rel_err_per_step=rel.tolist())
+    assert rel[0] <= 1e-5 and (rel <= TRAJ_RTOL).all(), (what, rel)
+
+
+@pytest.mark.parametrize("gt", ["gin", "gcn"])
+def test_edgepred_vs_reference(gt):
+    """chem/pretrain_edgepred.py:25-52 train() run by the reference (NegativeEdge draws and BatchAE collate from the fixture)"""
+    fx = rf.load("ref_chem_edgepred_b32")
+    hchem, _ = hip_models()
+    batches = [b.to(DEV) for b in rf.edgepred_batches(fx)]
+    torch.manual_seed(0)
+    model = hchem.GNN(5, 300, JK="last", drop_ratio=0, gnn_type=gt).to(DEV)
+    model.train()
+    opt = adam(model.parameters())
+    out = [ptrain.chem_edgepred_step(model, opt, b) for b in batches]
+    want = fx[gt]
+    _traj([o[0] for o in out], want["loss"].numpy(), "edgepred/%s" % gt)
+    ret = np.array([sum(o[1] for o in out) / (len(out) - 1), sum(o[0] for o in out) / (len(out) - 1)])  # divided by the last step index
+    assert abs(ret[0] - float(want["returned"][0])) <= 0.03 and abs(ret[1] - float(want["returned"][1])) <= TRAJ_RTOL * float(want["returned"][1])
+    rf.check_params(list(model.named_parameters()), want["final_params"], lambda p: p, rtol=5e-2)
+
+
+def test_infomax_vs_reference():
+    """chem/pretrain_deepgraphinfomax.py:30-90 (Discriminator, Infomax, train()) run by the reference"""
+    fx = rf.load("ref_chem_infomax_b32")
+    hchem, _ = hip_models()
+    batches = [b.to(DEV) for b in rf.plain_batches(fx)]
+    torch.manual_seed(0)
+    gnn = hchem.GNN(5, 300, JK="last", drop_ratio=0, gnn_type="gin")
+    disc = ptrain.Discriminator(300)
+    assert torch.equal(disc.weight.detach(), fx["discriminator_init"])
+    model = ptrain.Infomax(gnn, disc).to(DEV)
+    model.train()
+    opt = adam(model.parameters())
+    out = [ptrain.chem_infomax_step(model, opt, b) for b in batches]
+    _traj([o[0] for o in out], fx["loss"].numpy(), "infomax")
+    assert abs(sum(o[1] for o in out) / (len(out) - 1) - float(fx["returned"][0])) <= 0.03
+
+
+# ============================================================================== bio fine-tuning
+@pytest.mark.parametrize("pooling", ["mean", "sum"])
+def test_bio_finetune_vs_reference(pooling):
+    """bio/model.py GNN_graphpred :293-347 + bio/finetune.py:25-65 train() / eval() run by the reference on BatchFinetune batches"""
+    fx = rf.load("ref_bio_finetune_b32")
+    want = fx[pooling]
+    _, hbio = hip_models()
+    batches = [b.to(DEV) for b in rf.bio_finetune_batches(fx)]
+
+    def fresh():
+        torch.manual_seed(0)
+        m = hbio.GNN_graphpred(5, 300, 40, JK="last", drop_ratio=0, graph_pooling=pooling, gnn_type="gin").to(DEV)
+        m.train()
+        return m, adam(m.parameters())
+
+    model, _ = fresh()
+    with torch.no_grad():
+        pred0 = model(batches[0])
+    scale = float(want["pred_step0"].abs().max())
+    err = float((pred0.cpu() - want["pred_step0"]).abs().max())
+    log(test="bio_finetune/%s/pred_step0" % pooling, max_abs_err=err, scale=scale)
+    # sum pooling adds ~40 node rows (each within 1e-4) in front of the linear head: relative to the largest prediction
+    assert err <= 1e-4 + (1e-4 if pooling == "mean" else 5e-4) * scale
+    model, opt = fresh()
+    losses = [ptrain.bio_finetune_step(model, opt, b) for b in batches]
+    _traj(losses, want["loss"].numpy(), "bio_finetune/%s" % pooling)
+    roc, ref = ptrain.bio_eval(model, batches), want["roc"].numpy()
+    assert np.array_equal(np.isnan(roc), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    log(test="bio_finetune/%s/roc" % pooling, max_abs_diff=float(np.abs(roc[ok] - ref[ok]).max()), mean_abs_diff=float(np.abs(roc[ok] - ref[ok]).mean()))
+    assert abs(float(np.mean(roc[ok])) - float(np.mean(ref[ok]))) <= 0.02 and float(np.abs(roc[ok] - ref[ok]).max()) <= 0.1
 
 
 # ============================================================================== bio (BASELINE configs[4] shape)
