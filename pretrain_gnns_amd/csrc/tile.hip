@@ -238,7 +238,14 @@ int pgnn_neighbor_sum_tiled(const float* x, int64_t ldx, const int32_t* ptr, con
                "neighbor_sum_tiled: bad edge-feature arguments (kc <= %d)", kMaxFeat);
   const size_t lds = (size_t)kRows * dim * sizeof(float) + (size_t)(kIdxCap + kRows + 4) * sizeof(int) +
                      (size_t)kMaxFeat * dim * sizeof(float) + (size_t)kRows * kMaxFeat * sizeof(float) + 64;
-  PGNN_REQUIRE(lds <= 160 * 1024, "neighbor_sum_tiled: feature width %lld too wide for the LDS tile", (long long)dim);
+  if (lds > 160 * 1024) {
+    // the 112-row tile of a wider feature matrix (dim > 308) does not fit the LDS: the row-streaming kernel + the edge-feature
+    // product as a launch of its own -- the path this entry replaced, same sums in the same order (a bio GNN with
+    // --emb_dim 512 used to fail here)
+    if (int rc = pgnn_neighbor_sum(x, ldx, ptr, nbr, dinv, out, ldo, num_nodes, dim, stream)) return rc;
+    if (cfeat) return pgnn_rowfeat_matmul_fwd(cfeat, kc, table, ldt, feat_out, ld_feat_out, num_nodes, dim, feat_out == out ? 1 : 0, stream);
+    return PGNN_OK;
+  }
   const int blocks = (int)std::min<int64_t>(num_nodes, (int64_t)num_cu() * 4);
   hipStream_t st = (hipStream_t)stream;
 #define PGNN_TILE_ARGS x, ldx, ptr, nbr, dinv, tile_start, num_tiles, out, ldo, (int)num_nodes, (int)dim, cfeat, (int)kc, table, ldt, feat_out, ld_feat_out

@@ -851,9 +851,11 @@ def test_other_embedding_widths(emb_dim, gnn_type):
         torch.testing.assert_close(hip(d.x, d.edge_index, d.edge_attr).cpu(), ref(b.x, b.edge_index, b.edge_attr), **TOL)
 
 
-@pytest.mark.parametrize("emb_dim", [64, 256])
+@pytest.mark.parametrize("emb_dim", [64, 256, 312, 512])
 @pytest.mark.parametrize("gnn_type", ["gin", "gcn", "graphsage"])
 def test_bio_other_embedding_widths(emb_dim, gnn_type):
+    """(312 and 512: wider than the 112-row LDS tile of the graph-resident aggregation holds -- pgnn_neighbor_sum_tiled falls
+    back to the row-streaming kernel there)"""
     _, hbio = _hip()
     ref, hip = _pair(obio.GNN, hbio.GNN, 3, emb_dim, seed=emb_dim, gnn_type=gnn_type)
     b = synthetic.bio_masking_batch(6, seed=emb_dim)
