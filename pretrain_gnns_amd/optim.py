@@ -10,6 +10,16 @@ per module that share a single kernel launch, so the reference's loop body runs 
 
 The update is torch's formula in fp32 (csrc/optim.hip); the step counter lives on the device, so a step can be captured
 in a HIP graph.  Parameters without a gradient are skipped, like torch does; their moments stay untouched.
+
+Limits, enforced rather than silent:
+  * ONE step counter serves every parameter, where torch keeps ``state['step']`` per parameter and starts it at that
+    parameter's first gradient.  A parameter that never gets a gradient (the bond head without --mask_edge) is simply skipped,
+    which is torch's behaviour; a parameter whose FIRST gradient shows up after other parameters have already been stepped
+    would get torch's bias correction for the wrong t, so ``launch()`` raises for it.
+  * lr / betas / eps / weight_decay are read from ``param_groups[0]`` of the handles at every launch (an LR scheduler or a manual
+    ``param_groups[0]['lr'] = x`` takes effect); the handles of one ``Adam.shared`` share a launch and must agree on them.
+  * every handle of ``Adam.shared`` must call ``step()`` in every round: stepping a handle twice, or calling ``zero_grad()``
+    while a round is incomplete, raises (the update of ALL handles would silently never be issued otherwise).
 """
 import ctypes
 
@@ -44,10 +54,35 @@ class _Core:
         self.waiting = 0  # handles that still have to call step() before the shared launch goes out
         self._tables, self._table_key = [], None
         self.handles = 0
+        self.owners = []       # the Adam handles (their param_groups carry the hyper-parameters)
+        self.stepped = set()   # ids of the handles that have stepped in the current round
+        self.launches = 0
+        self._seen = set()     # ids of the parameters that took part in the first launch
+
+    def hyper(self):
+        """(lr, beta1, beta2, eps, weight_decay) as the handles' param_groups say NOW"""
+        vals = None
+        for h in self.owners:
+            g = h.param_groups[0]
+            v = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]))
+            if vals is None:
+                vals = v
+            elif v != vals:
+                raise _lib.PgnnError("pretrain_gnns_amd.optim.Adam.shared: the handles share ONE launch and must agree on lr / betas / eps / "
+                                     "weight_decay (%r vs %r); use separate Adam instances for different hyper-parameters" % (vals, v))
+        return vals if vals is not None else (self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay)
 
     @torch.no_grad()
     def launch(self):
         live = [(p, o) for p, o in zip(self.params, self.offsets) if p.grad is not None]
+        ids = {id(p) for p, _ in live}
+        if self.launches == 0:
+            self._seen = ids
+        elif not ids <= self._seen:
+            raise _lib.PgnnError("pretrain_gnns_amd.optim.Adam: a parameter received its first gradient after %d updates of the others; the "
+                                 "single device-side step count cannot give it torch's per-parameter bias correction" % self.launches)
+        self.launches += 1
+        lr, b1, b2, eps, wd = self.hyper()
         # the job tables (ctypes arrays of pointers / counts / offsets) are rebuilt only when a pointer moved: with the caching
         # allocator the gradients come back at the same addresses step after step, and building the tables was ~0.1 ms a step
         key = tuple([p.data_ptr() for p, _ in live] + [p.grad.data_ptr() for p, _ in live])
@@ -67,8 +102,8 @@ class _Core:
         for i, (P, G, C, O, n) in enumerate(self._tables):
             # every part reads the same step count: only the last part's launch advances it
             counter = self.step_words if i == len(self._tables) - 1 else self.step_words.clone()
-            check(lib.pgnn_adam_step(P, G, C, O, n, self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), counter.data_ptr(), self.lr,
-                                     self.betas[0], self.betas[1], self.eps, self.weight_decay, sp), "pgnn_adam_step")
+            check(lib.pgnn_adam_step(P, G, C, O, n, self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), counter.data_ptr(), lr,
+                                     b1, b2, eps, wd, sp), "pgnn_adam_step")
 
 
 class Adam:
@@ -78,6 +113,7 @@ class Adam:
         self._own = list(params)
         self._core = _core if _core is not None else _Core(self._own, lr, betas, eps, weight_decay)
         self._core.handles += 1
+        self._core.owners.append(self)
         self.param_groups = [{"params": self._own, "lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay}]
 
     @classmethod
@@ -89,6 +125,9 @@ class Adam:
         return [cls(ps, lr, betas, eps, weight_decay, _core=core) for ps in lists]
 
     def zero_grad(self, set_to_none=True):
+        if self._core.waiting != 0:
+            raise _lib.PgnnError("pretrain_gnns_amd.optim.Adam.shared: zero_grad() with %d of %d handles not stepped -- the shared update "
+                                 "has NOT been issued; every handle must call step() each round" % (self._core.waiting, self._core.handles))
         for p in self._own:
             if p.grad is None:
                 continue
@@ -105,6 +144,11 @@ class Adam:
         core = self._core
         if core.waiting == 0:
             core.waiting = core.handles
+            core.stepped.clear()
+        if id(self) in core.stepped:
+            raise _lib.PgnnError("pretrain_gnns_amd.optim.Adam.shared: this handle stepped twice before the others stepped once; every "
+                                 "handle must call step() each round (the update is one launch for all of them)")
+        core.stepped.add(id(self))
         core.waiting -= 1
         if core.waiting == 0:
             core.launch()

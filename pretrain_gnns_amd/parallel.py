@@ -8,8 +8,15 @@ a single flat fp32 bucket holding every gradient (GNN 7.43 MB + heads; RCCL over
 direct reduce-scatter/all-gather on the fully connected 8-GPU node), followed by identical Adam
 updates on every rank.  BatchNorm statistics stay per rank by default (standard DDP semantics);
 ``use_exact_batchnorm(model)`` switches the outer BatchNorm layers to statistics all-reduced over the ranks
-(sum x, sum x^2: two more tiny collectives per layer and direction), which together with
-``weight_fn = local_M / global_M`` makes the N-rank step EXACTLY the single-process step on the global batch.
+(sum x, sum x^2: two more tiny collectives per layer and direction).  With shared statistics one rank's rows carry gradient
+terms of EVERY rank's loss (the backward all-reduces sum dy and sum dy.xhat), so the rank's share of the global loss
+normaliser -- local_M / global_M -- must multiply its LOSS before ``backward()`` and the bucket must plainly sum
+(``weight_fn=lambda: 1.0``): that makes the N-rank step EXACTLY the single-process step on the global batch.  Scaling the
+finished gradients instead (``weight_fn = local_M / global_M``) is exact only with per-rank statistics.
+
+Aliasing contract: after the first ``allreduce()`` every ``p.grad`` IS a view of the flat bucket -- holding or detaching a
+``.grad`` aliases bucket storage, ``zero_grad(set_to_none=False)`` gradients are scaled in place by the next pack, and
+anything that writes the bucket between ``backward()`` and ``optimizer.step()`` destroys live gradients.
 
 The layer is model-agnostic (any nn.Module, any torch.distributed backend), which is how the
 world_size-2 ``gloo`` tests on CPU cover it.
@@ -218,19 +225,19 @@ def comm_report(optimizers, iters=10):
     out = {"initialized": True, "backend": dist.get_backend(), "world": dist.get_world_size(), "rank": dist.get_rank(),
            "bucket_bytes": bucket.nbytes if bucket is not None else None}
     if bucket is not None and bucket.flat.is_cuda:
+        scratch = torch.zeros_like(bucket.flat)  # same size, NOT the bucket: its gradients may be live
         for _ in range(3):
-            dist.all_reduce(bucket.flat)
+            dist.all_reduce(scratch)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         s.record()
         for _ in range(iters):
-            dist.all_reduce(bucket.flat)
+            dist.all_reduce(scratch)
         e.record()
         torch.cuda.synchronize()
         out["allreduce_us"] = round(s.elapsed_time(e) / iters * 1e3, 1)
         if out["world"] > 1:  # ring / direct all-reduce moves 2 (W-1)/W of the bucket per rank
             out["allreduce_busbw_GBps"] = round(2.0 * (out["world"] - 1) / out["world"] * bucket.nbytes / (out["allreduce_us"] * 1e-6) / 1e9, 1)
-        bucket.flat.zero_()
     return out
 
 

@@ -624,6 +624,46 @@ def test_adam_one_launch_matches_torch_adam(weight_decay):
     assert torch.equal(mine[3].detach(), ref[3].detach())
 
 
+def test_adam_limits_are_enforced_not_silent():
+    """lr read from param_groups at launch (a scheduler works); a handle stepped twice, a zero_grad() in an incomplete
+    round and a parameter whose first gradient arrives late raise instead of silently doing something else than torch"""
+    from pretrain_gnns_amd import _lib, optim
+    torch.manual_seed(4)
+    a = [torch.randn(300, 7, device=DEV).requires_grad_(True), torch.randn(9, device=DEV).requires_grad_(True)]
+    b = [t.detach().clone().requires_grad_(True) for t in a]
+    ro = torch.optim.Adam(a, lr=1e-3)
+    m1, m2 = optim.Adam.shared([[b[0]], [b[1]]], lr=1e-3)
+    for step in range(3):
+        lr = 1e-3 * (0.5 ** step)
+        for g in ro.param_groups + m1.param_groups + m2.param_groups:
+            g["lr"] = lr  # what a scheduler does
+        for x, y in zip(a, b):
+            x.grad = torch.randn_like(x)
+            y.grad = x.grad.clone()
+        ro.step(), m1.step(), m2.step()
+    for x, y in zip(a, b):
+        torch.testing.assert_close(y.detach(), x.detach(), rtol=2e-6, atol=1e-7)
+    m1.param_groups[0]["lr"] = 5e-3  # the handles of one shared launch must agree
+    b[0].grad, b[1].grad = torch.randn_like(b[0]), torch.randn_like(b[1])
+    m1.step()
+    with pytest.raises(_lib.PgnnError):
+        m2.step()
+    m1.param_groups[0]["lr"] = m2.param_groups[0]["lr"]
+    n1, n2 = optim.Adam.shared([[b[0]], [b[1]]], lr=1e-3)
+    n1.step()
+    with pytest.raises(_lib.PgnnError):
+        n1.step()      # twice before n2 stepped
+    with pytest.raises(_lib.PgnnError):
+        n2.zero_grad()  # round incomplete: the shared update has not gone out
+    p, q = torch.randn(5, device=DEV).requires_grad_(True), torch.randn(5, device=DEV).requires_grad_(True)
+    late = optim.Adam([p, q], lr=1e-3)
+    p.grad = torch.randn_like(p)
+    late.step()
+    q.grad = torch.randn_like(q)  # first gradient after one update of p
+    with pytest.raises(_lib.PgnnError):
+        late.step()
+
+
 def test_mlp2_fwd_bwd():
     ops = _ops()
     torch.manual_seed(0)
