@@ -21,6 +21,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                   2400 N + 6 E + 4 (N+1) per launch (SURVEY.md §8d) / HIP-event time per launch, vs 8 TB/s;
   roofline_mlp  : the forward GEMM of the mlp (split-bf16 kernel) vs its own ceiling (2500 / 6 TFLOP/s) and vs the fp32 MFMA
                   peak 157.3 TFLOP/s, with the fp32-MFMA kernel on the same shape next to it;
+  roofline_mlp_step : the two forward products of one mlp at the TIMED batch's row count on pre-split weight planes (what the
+                  one-call networks run there), against the same ceiling;
   cpu_baseline  : the CPU oracle's identical train step on the host cores (rank 0, N=1 only).
 """
 import argparse
@@ -351,6 +353,34 @@ def roofline_mlp(dev, rows):
                                  "ms_per_launch": round(ms32, 4), "ms_per_launch_std": round(float(per32.std()), 4)}}
 
 
+def roofline_mlp_planes(dev, rows, what):
+    """the two forward products of one GIN mlp (300->600 + ReLU, 600->300) at `rows` rows on pre-split weight planes -- what the
+    one-call networks run from ~1 500 to 65 536 rows (csrc/linear.hip k_gemm3w) -- each timed alone in the steady state, against
+    the split-bf16 ceiling (dense bf16 MFMA peak / 6 products per fp32 product)"""
+    from pretrain_gnns_amd import ops
+
+    torch.manual_seed(0)
+    x = torch.randn(rows, 300, device=dev)
+    w1, b1 = torch.randn(600, 300, device=dev) * 0.05, torch.randn(600, device=dev)
+    w2, b2 = torch.randn(300, 600, device=dev) * 0.05, torch.randn(300, device=dev)
+    p1, p2 = ops.weight_planes([w1, w2])
+    hid = torch.empty(rows, 600, device=dev)
+    z = torch.empty(rows, 300, device=dev)
+    split_peak = MFMA_BF16_PEAK_TF / 6.0
+    flops = 2.0 * rows * 300 * 600
+    out = {"bound": "mfma", "rows": rows, "what": what, "peak": round(split_peak, 1), "unit": "TFLOP/s (fp32-equivalent)",
+           "kernel": "k_gemm3w (pgnn_linear_fwd_wp: weights pre-split into three bf16 planes once per pass, activations DMA'd as fp32 "
+                     "and split by the consuming wave, six v_mfma_f32_16x16x32_bf16 per 16x16x32 block, fp32 accumulate; bit-identical "
+                     "to the split-bf16 kernel of pgnn_linear_fwd)"}
+    for tag, fn in (("300_to_600", lambda: ops.linear_fwd_wp(x, p1, b1, 600, relu=True, out=hid)),
+                    ("600_to_300", lambda: ops.linear_fwd_wp(hid, p2, b2, 300, out=z))):
+        ms, per, iters = steady_state_ms(fn, warm_s=0.05, iters=50)
+        tf = flops / (ms * 1e-3) / 1e12
+        out[tag] = {"achieved": round(tf, 2), "frac": round(tf / split_peak, 4), "ms_per_launch": round(ms, 5),
+                    "ms_per_launch_std": round(float(per.std()), 5), "launches_timed": iters}
+    return out
+
+
 def host_cpu_model():
     """the `model name` line of /proc/cpuinfo (BASELINE.md asks for the CPU next to the core count)"""
     try:
@@ -421,7 +451,9 @@ def contextpred_leg(dev, args, steps_n, with_cpu):
            "ms_per_step": round(dt / steps_n * 1e3, 4), "edges_per_s": round(src_edges / dt, 1),
            "gnn_edges_per_s": round(gnn_edges / dt, 1), "graphs_per_s": round(args.graphs_per_gpu * steps_n / dt, 1),
            "mean_loss" if accum is not None else "last_loss": round(float(loss), 5),
-           "roofline": "same aggregation kernel as the headline (`roofline`): the substructure / context batches are chem graphs"}
+           # the step's dominant kernels (profiles/r03/ctx_step_kernel_stats.csv): the forward / backward-data products of its
+           # eight GIN layers on weight planes; timed alone at the row count of this run's last substructure batch
+           "roofline": roofline_mlp_planes(dev, int(batch.x_substruct.size(0)), "substructure batch of this run's last step")}
     if with_cpu:
         from oracle import chem as ochem
         from oracle import steps as osteps
@@ -484,27 +516,7 @@ def bio_leg(dev, args, steps_n, with_cpu):
                        "device-side collate + MaskEdge in the loop (BASELINE configs[4] shape)" % args.graphs_per_gpu,
            "ms_per_step": round(dt / steps_n * 1e3, 4), "edges_per_s": round(edges / dt, 1),
            "edges_per_step": int(edges / steps_n), "mean_loss" if accum is not None else "last_loss": round(float(loss), 5)}
-    # aggregation alone at a cache-exceeding batch: x [N,300] -> [N,600] = [sum_j x_j + x_i | sum_e enc(e) + enc(loop)]
-    big = ds.collate(np.arange(4096) % len(graphs))
-    n, e = big.x.size(0), big.edge_index.size(1)
-    graph = ops.build_bio_graph(big.edge_index, big.edge_attr, n, gcn=False)
-    x = torch.randn(n, 300, device=dev)
-    enc_w, enc_b = torch.randn(300, 9, device=dev), torch.randn(300, device=dev)
-
-    def launch():
-        with torch.no_grad():
-            ops.BioAggregate.apply(x, enc_w, enc_b, graph)
-
-    ms, per, iters = steady_state_ms(launch, iters=30)
-    alg = 3604.0 * n + 40.0 * e
-    gbs = alg / (ms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic(n, e, "bio_agg_pmc_traffic.json")
-    out["roofline"] = {"bound": "hbm", "kernel": "bio GINConv aggregate = k_neighbor_sum_tile (graph-resident: neighbour sum + edge-feature product in one launch, csrc/tile.hip)", "achieved": round(gbs, 1),
-                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                       "ms_per_launch": round(ms, 4), "ms_per_launch_std": round(float(per.std()), 4),
-                       "algorithmic_bytes_per_launch": int(alg), "nodes": n, "edges": e,
-                       "note": "3604 N + 40 E (SURVEY 8d) counts the fp32 [E,9] attributes a layer would read; this implementation reads "
-                               "them once per batch (per-node feature sums), so a layer moves 3600 N + 4 E + 40 N bytes"}
+    out["roofline"] = bio_roofline(dev, ds, len(graphs))
     if with_cpu:
         from oracle import bio as obio
         from oracle import steps as osteps
@@ -519,6 +531,38 @@ def bio_leg(dev, args, steps_n, with_cpu):
                                "sample": "%d bio masking train steps of the torch-CPU oracle on one 64-graph batch (%d edges), %.1f s"
                                          % (k, hb.edge_index.size(1), el)}
     return out
+
+
+def bio_roofline(dev, ds=None, num_graphs=1024):
+    """the bio GINConv aggregate alone at a cache-exceeding batch (4 096 PPI-ego-shaped graphs): x [N,300] -> [N,600] =
+    [sum_j x_j + x_i | sum_e enc(e) + enc(loop)], against SURVEY 8d's algorithmic bytes 3604 N + 40 E"""
+    import numpy as np
+    from pretrain_gnns_amd import ops
+    from pretrain_gnns_amd.data import resident, synthetic
+
+    if ds is None:
+        rng = np.random.default_rng(99)
+        ds = resident.ResidentDataset.from_graphs([synthetic.ppi_like_graph(rng) for _ in range(num_graphs)], dev)
+    big = ds.collate(np.arange(4096) % num_graphs)
+    n, e = big.x.size(0), big.edge_index.size(1)
+    graph = ops.build_bio_graph(big.edge_index, big.edge_attr, n, gcn=False)
+    x = torch.randn(n, 300, device=dev)
+    enc_w, enc_b = torch.randn(300, 9, device=dev), torch.randn(300, device=dev)
+
+    def launch():
+        with torch.no_grad():
+            ops.BioAggregate.apply(x, enc_w, enc_b, graph)
+
+    ms, per, iters = steady_state_ms(launch, iters=30)
+    alg = 3604.0 * n + 40.0 * e
+    gbs = alg / (ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic(n, e, "bio_agg_pmc_traffic.json")
+    return {"bound": "hbm", "kernel": "bio GINConv aggregate = k_neighbor_sum_tile (graph-resident: neighbour sum + edge-feature product in one launch, csrc/tile.hip)", "achieved": round(gbs, 1),
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                       "ms_per_launch": round(ms, 4), "ms_per_launch_std": round(float(per.std()), 4),
+                       "algorithmic_bytes_per_launch": int(alg), "nodes": n, "edges": e,
+                       "note": "3604 N + 40 E (SURVEY 8d) counts the fp32 [E,9] attributes a layer would read; this implementation reads "
+                               "them once per batch (per-node feature sums), so a layer moves 3600 N + 4 E + 40 N bytes"}
 
 
 def usable_cores():
@@ -668,8 +712,11 @@ def _run():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    if args.roofline_only:
-        return json.dumps({"roofline": roofline_aggregation(dev, args.roofline_graphs), "roofline_mlp": roofline_mlp(dev, 262144)})
+    if args.roofline_only:  # exactly the launches behind every roofline object of the JSON line (profiles/rNN/roofline_only_kernel_stats.csv)
+        return json.dumps({"roofline": roofline_aggregation(dev, args.roofline_graphs), "roofline_mlp": roofline_mlp(dev, 262144),
+                           "roofline_mlp_step": roofline_mlp_planes(dev, 6747, "one 256-graph batch (BASELINE configs[1])"),
+                           "contextpred_roofline": roofline_mlp_planes(dev, 5100, "substructure batch of a 256-molecule context-prediction step"),
+                           "bio_masking_roofline": bio_roofline(dev)})
     mods = make_models(dev)
     parallel.broadcast_parameters(mods)
     opts = make_optimizers(mods, args.adam)
@@ -754,6 +801,7 @@ def _run():
         if not args.no_roofline:
             res["roofline"] = roofline_aggregation(dev, args.roofline_graphs)
             res["roofline_mlp"] = roofline_mlp(dev, 262144)
+            res["roofline_mlp_step"] = roofline_mlp_planes(dev, int(batch.x.size(0)), "the timed %d-graph batch" % args.graphs_per_gpu)
         if world == 1 and not args.no_extra_configs:
             res["contextpred"] = contextpred_leg(dev, args, max(args.steps // 2, 20), not args.no_cpu_baseline)
             res["bio_masking"] = bio_leg(dev, args, max(args.steps // 5, 10), not args.no_cpu_baseline)

@@ -1224,6 +1224,36 @@ def chem_gin_stack(owner, x_idx, graph, x_embedding1, x_embedding2, convs, bns, 
                               x_embedding1.weight, x_embedding2.weight, *flat)
 
 
+# ------------------------------------------------------------------------------------ products on pre-split weight planes
+def weight_planes(mats, transpose=None):
+    """pgnn_split_weights: the three-term bf16 split of every fp32 matrix in ``mats`` (``transpose[j]``: of its transpose), one
+    launch; returns one int16 tensor [3, rows, ld] per matrix (ld = columns rounded up to 32, zero padded) -- what
+    ``linear_fwd_wp`` / pgnn_linear_bwd_data_wp take as their weight operand"""
+    import ctypes
+    cnt = len(mats)
+    transpose = [False] * cnt if transpose is None else list(transpose)
+    outs = []
+    for w, tr in zip(mats, transpose):
+        if not w.is_cuda or w.dtype != torch.float32 or w.dim() != 2 or not w.is_contiguous():
+            raise _lib.PgnnError("weight_planes: contiguous fp32 CUDA matrices only")
+        r, c = (w.size(1), w.size(0)) if tr else (w.size(0), w.size(1))
+        outs.append(torch.empty(3, r, (c + 31) // 32 * 32, dtype=torch.int16, device=w.device))
+    arr = lambda vals, ty: (ty * cnt)(*vals)
+    check(load().pgnn_split_weights(arr([w.data_ptr() for w in mats], ctypes.c_void_p), arr([o.data_ptr() for o in outs], ctypes.c_void_p),
+                                    arr([w.size(0) for w in mats], ctypes.c_int64), arr([w.size(1) for w in mats], ctypes.c_int64),
+                                    arr([int(t) for t in transpose], ctypes.c_int32), cnt, stream_ptr()), "pgnn_split_weights")
+    return outs
+
+
+def linear_fwd_wp(x, planes, bias, n_out, relu=False, out=None):
+    """y = act(x . W^T + b) with W given as its planes (``weight_planes([W])[0]``): pgnn_linear_fwd_wp, no autograd"""
+    m, k = x.shape
+    y = out if out is not None else torch.empty(m, n_out, dtype=torch.float32, device=x.device)
+    check(load().pgnn_linear_fwd_wp(x.data_ptr(), x.stride(0), planes.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                    y.stride(0), m, k, n_out, int(relu), None, stream_ptr()), "pgnn_linear_fwd_wp")
+    return y
+
+
 # ------------------------------------------------------------------------------------ whole bio GIN network
 class BioGINStack(Function):
     """Every (GINConv, ReLU) layer of the bio GNN (bio/model.py:11-58, 258-290, JK = "last", no dropout) as ONE library call

@@ -271,6 +271,7 @@ def test_shared_adam_handles_issue_one_launch_per_round(monkeypatch):
         def __init__(self):
             self.handles, self.waiting, self.launches = 0, 0, 0
             self.step_count = 0
+            self.owners, self.stepped = [], set()
 
         def launch(self):
             self.launches += 1
@@ -289,6 +290,13 @@ def test_shared_adam_handles_issue_one_launch_per_round(monkeypatch):
     assert params[1][0].grad is None and params[0][0].grad is not None
     handles[0].zero_grad(set_to_none=False)
     assert params[0][0].grad is not None and float(params[0][0].grad.abs().sum()) == 0.0
+    # an incomplete round is an error, not a silently missing update
+    from pretrain_gnns_amd import _lib
+    handles[0].step()
+    with pytest.raises(_lib.PgnnError):
+        handles[0].step()
+    with pytest.raises(_lib.PgnnError):
+        handles[1].zero_grad()
 
 
 def test_bench_keeps_stdout_to_its_one_json_line():
