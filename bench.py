@@ -176,6 +176,44 @@ def roofline_aggregation(dev, graphs):
             "nodes": n, "edges": e}
 
 
+def aggregation_robustness(dev, graphs):
+    """informational: the same roofline launch on atom orders less local than SURVEY 8d's generator -- parent
+    of atom i uniform in [i - 8, i), and atoms relabelled at random within each molecule -- with the fraction of edges whose source
+    row lies outside the kernel's LDS window for its destination's 8-node step ([base - 8, base + 16), base = 8 floor(i / 8): those
+    take the kernel's wave-uniform path to global memory).  Same algorithmic bytes formula, same 8 TB/s denominator."""
+    import numpy as np
+    from pretrain_gnns_amd import ops
+    from pretrain_gnns_amd.data import synthetic
+
+    out = {}
+    lib, sp = ops.load(), ops.stream_ptr()
+    for tag, kw in (("survey_order", {}), ("parent_within_8", {"parent_window": 8}), ("parent_within_12", {"parent_window": 12}),
+                    ("parent_within_16", {"parent_window": 16}), ("atoms_permuted", {"permute": True})):
+        rng = np.random.default_rng(777)
+        base = synthetic.collate([synthetic.zinc_like_graph(rng, **kw) for _ in range(2048)])
+        big = synthetic.tile_batch(base, max(1, graphs // 2048)).to(dev)
+        n, e = big.x.size(0), big.edge_index.size(1)
+        dst, src = big.edge_index[0], big.edge_index[1]
+        lo = (dst // 8) * 8 - 8
+        miss = float(((src < lo) | (src >= lo + 24)).float().mean())
+        g = ops.build_chem_graph(big.edge_index, big.edge_attr, n)
+        torch.manual_seed(0)
+        x = torch.randn(n, 300, device=dev)
+        e1, e2 = torch.randn(6, 300, device=dev), torch.randn(3, 300, device=dev)
+        y = torch.empty(n, 300, device=dev)
+
+        def launch():
+            ops.check(lib.pgnn_chem_aggregate_fwd(x.data_ptr(), 300, g.in_ptr.data_ptr(), g.in_src.data_ptr(), g.in_code.data_ptr(),
+                                                  e1.data_ptr(), e2.data_ptr(), None, y.data_ptr(), 300, n, 300, sp), "aggregate")
+
+        ms, per, iters = steady_state_ms(launch, warm_s=0.05, iters=30)
+        alg = 2400.0 * n + 6.0 * e + 4.0 * (n + 1)
+        out[tag] = {"out_of_window_edge_fraction": round(miss, 4), "ms_per_launch": round(ms, 4), "ms_per_launch_std": round(float(per.std()), 4),
+                    "achieved_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "nodes": n, "edges": e}
+        del x, y, g, big
+    return out
+
+
 def pmc_traffic(n, e, name="agg_pmc_traffic.json"):
     """HBM bytes per launch of an aggregation kernel from the committed rocprofv3 PMC pass
     (profiles/r02/agg_pmc_traffic.json, bio_agg_pmc_traffic.json: FETCH_SIZE x2 (gfx950 half-count) + WRITE_SIZE, separate
@@ -802,6 +840,8 @@ def _run():
             res["roofline"] = roofline_aggregation(dev, args.roofline_graphs)
             res["roofline_mlp"] = roofline_mlp(dev, 262144)
             res["roofline_mlp_step"] = roofline_mlp_planes(dev, int(batch.x.size(0)), "the timed %d-graph batch" % args.graphs_per_gpu)
+            if world == 1:
+                res["aggregation_robustness"] = aggregation_robustness(dev, args.roofline_graphs)
         if world == 1 and not args.no_extra_configs:
             res["contextpred"] = contextpred_leg(dev, args, max(args.steps // 2, 20), not args.no_cpu_baseline)
             res["bio_masking"] = bio_leg(dev, args, max(args.steps // 5, 10), not args.no_cpu_baseline)

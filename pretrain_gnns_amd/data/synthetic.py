@@ -31,11 +31,14 @@ _BOND_DIR_P = np.array([0.97, 0.015, 0.015])
 
 
 # ----------------------------------------------------------------------------- molecules
-def zinc_like_graph(rng):
-    """One ZINC-shaped molecule: random tree + a few ring closures, max degree 5."""
+def zinc_like_graph(rng, parent_window=3, permute=False):
+    """One ZINC-shaped molecule: random tree + a few ring closures, max degree 5.  SURVEY.md 8d's generator is the default
+    (parent of atom i uniform in [i - 3, i)); ``parent_window`` widens that range and ``permute`` relabels the atoms at random --
+    atom orders less local than the survey's, for bench.py's aggregation robustness leg (an RDKit atom order, chem/loader.py:53-100,
+    is not the survey's generator)."""
     n = int(np.clip(np.rint(rng.normal(26.6, 6.0)), 6, 60))
     local = np.arange(1, n)
-    parent = local - rng.integers(1, np.minimum(local, 3) + 1)
+    parent = local - rng.integers(1, np.minimum(local, parent_window) + 1)
     bonds = [(int(p), int(c)) for p, c in zip(parent, local)]
     deg = np.bincount(np.concatenate([parent, local]), minlength=n)
     have = set(bonds)
@@ -56,6 +59,12 @@ def zinc_like_graph(rng):
     battr = np.stack([rng.choice(_BOND_TYPES, nb, p=_BOND_P), rng.choice(3, nb, p=_BOND_DIR_P)], axis=1)
     edge_attr = np.repeat(battr, 2, axis=0).astype(np.int64)
     x = np.stack([rng.choice(_ATOM_TYPES, n, p=_ATOM_P), rng.choice(3, n, p=_CHIRAL_P)], axis=1).astype(np.int64)
+    if permute:  # new label of atom a = perm[a]; both directions of a bond stay adjacent
+        perm = rng.permutation(n)
+        edge_index = perm[edge_index]
+        x_new = np.empty_like(x)
+        x_new[perm] = x
+        x = x_new
     return Data(x=torch.from_numpy(x), edge_index=torch.from_numpy(edge_index), edge_attr=torch.from_numpy(edge_attr))
 
 
