@@ -804,9 +804,18 @@ def _run():
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     etot = torch.tensor([float(edges_local)], dtype=torch.float64, device=dev)
     if world > 1:
+        per_rank = [torch.zeros_like(tmax) for _ in range(world)]
+        dist.all_gather(per_rank, tmax)  # every rank's own wall time for the K steps: a straggler shows in `comm`
+        comm["ms_per_step_by_rank"] = [round(1e3 * float(t.item()) / args.steps, 4) for t in per_rank]
+        comm["ms_per_step_min"], comm["ms_per_step_max"] = min(comm["ms_per_step_by_rank"]), max(comm["ms_per_step_by_rank"])
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(etot, op=dist.ReduceOp.SUM)
     elapsed, edges_total = float(tmax.item()), float(etot.item())
+    if world > 1:
+        # the collective part of the run is over: the process group goes away HERE, so that no rank sits in a barrier while rank 0
+        # times its single-GPU roofline launches below (ranks > 0 simply exit)
+        dist.barrier()
+        dist.destroy_process_group()
 
     line = None
     if rank == 0:
@@ -848,8 +857,7 @@ def _run():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.graphs_per_gpu, args.cpu_seconds)
         line = json.dumps(res)
-    if dist.is_initialized():
-        dist.barrier()
+    if dist.is_initialized():  # (a single-rank group, PGNN_DP_FORCE_INIT=1)
         dist.destroy_process_group()
     return line
 

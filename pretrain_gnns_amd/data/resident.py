@@ -145,7 +145,7 @@ class ResidentDataset:
                                       out.edge_index.data_ptr(), out.edge_attr.data_ptr(), out.batch.data_ptr(), sp),
               "pgnn_collate_graphs")
         out._num_graphs = b
-        out._status, out._node_off = status, offs[0]
+        out._status, out._node_off, out._edge_off = status, offs[0], offs[1]
         if unit == 0 and explicit is None:
             return out
         if explicit is not None:

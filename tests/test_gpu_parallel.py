@@ -146,6 +146,97 @@ def test_two_ranks_on_one_gpu(tmp_path):
                 assert float((g - ref).abs().max()) <= tol * scale, (key_dp, float((g - ref).abs().max()), scale)
 
 
+def _bio_worker(rank, world, port, out_dir):
+    """BASELINE configs[4]: bio masking pre-training, data parallel -- the one-call bio GIN network + the edge head through
+    AllReduceOptimizers over optim.Adam.shared, ResidentLoader(rank, world) batches with device-side MaskEdge"""
+    import numpy as np
+    import torch.distributed as dist
+    import torch.nn.functional as F
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", PGNN_DP_BACKEND="gloo")
+    from pretrain_gnns_amd import ops, optim, parallel
+    from pretrain_gnns_amd import train as ptrain
+    from pretrain_gnns_amd.bio import model as hbio
+    from pretrain_gnns_amd.data import resident, synthetic
+
+    r, local, w = parallel.init_from_env()
+    dev = torch.device("cuda", local)
+    ops.set_direct_grads(True)
+    res = {}
+    rng = np.random.default_rng(6)
+    graphs = [synthetic.ppi_like_graph(rng) for _ in range(33)]  # 33 = 2 x 16 + a tail of 1 < world size
+    ds = resident.ResidentDataset.from_graphs(graphs, dev)
+    torch.manual_seed(200 + rank)  # deliberately different initial weights per rank
+    mods = [hbio.GNN(5, 300, gnn_type="gin").to(dev), torch.nn.Linear(300, 7).to(dev)]
+    parallel.broadcast_parameters(mods)
+    opts = parallel.AllReduceOptimizers(optim.Adam.shared([m.parameters() for m in mods], lr=1e-3))
+    loader = resident.ResidentLoader(ds, 16, shuffle=True, seed=11, mask_rate=0.15, rank=rank, world_size=world)
+    for m in mods:
+        m.train()
+    losses = []
+    for _ in range(2):
+        for batch in loader:
+            losses.append(ptrain.bio_masking_step(mods, list(opts), batch)[0])
+    res["len_loader"], res["losses"] = len(loader), losses
+    res["params"] = [p.detach().cpu().clone() for m in mods for p in m.parameters()]
+    res["bucket_bytes"] = opts.bucket.nbytes
+
+    # summed shard gradients == whole-batch gradient (eval-mode BatchNorm inside the mlps: per-rank statistics would differ)
+    whole = ds.collate(np.arange(12), mask_rate=0.15, seed=5)
+    mine = np.asarray(list(parallel.shard_graphs(12, rank, world)))
+    edge_off = whole._edge_off.cpu().numpy() if hasattr(whole, "_edge_off") else None
+    torch.manual_seed(8)
+    model, head = hbio.GNN(3, 300, gnn_type="gin").to(dev), torch.nn.Linear(300, 7).to(dev)
+    parallel.broadcast_parameters([model, head])
+    model.eval()
+    params = list(model.parameters()) + list(head.parameters())
+
+    def loss_of(b):
+        h = model(b.x, b.edge_index, b.edge_attr)
+        mei = b.edge_index[:, b.masked_edge_idx]
+        return F.cross_entropy(head(h[mei[0]] + h[mei[1]]), torch.argmax(b.mask_edge_label, dim=1), reduction="sum")
+
+    if edge_off is not None:
+        lo, hi = int(edge_off[mine[0]]), int(edge_off[mine[-1] + 1])
+        sel = (whole.masked_edge_idx >= lo) & (whole.masked_edge_idx < hi)
+        local_b = ds.collate(mine, masked_edge_idx=(whole.masked_edge_idx[sel] - lo))
+        dp = parallel.AllReduceOptimizers([torch.optim.SGD(params, lr=0.0)], weight_fn=lambda: 1.0)
+        for o in dp:
+            o.zero_grad()
+        loss_of(local_b).backward()
+        dp._before_step()
+        res["sum_dp"] = [p.grad.detach().cpu().clone() for p in params]
+        for p in params:
+            p.grad = None
+        loss_of(whole).backward()
+        res["sum_single"] = [p.grad.detach().cpu().clone() for p in params]
+    torch.save(res, os.path.join(out_dir, "bio_rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_bio_masking(tmp_path):
+    """BASELINE configs[4] (bio PPI ego-net masking pre-train, DDP): two ranks on one GPU drive the HIP bio stack; ranks start
+    and stay bit-identical while training on different shards, run the same number of steps, keep ONE flat bucket, and the sum
+    of the shard gradients equals the whole-batch gradient"""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_bio_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "bio_rank0.pt"), torch.load(tmp_path / "bio_rank1.pt")
+    assert len(r0["losses"]) == len(r1["losses"]) == 2 * r0["len_loader"] and r0["len_loader"] == r1["len_loader"] == 1
+    assert r0["bucket_bytes"] == 4 * sum(p.numel() for p in r0["params"])
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)
+    assert r0["losses"] != r1["losses"]
+    if "sum_dp" in r0:
+        for r in (r0, r1):
+            scale = max(float(g.abs().max()) for g in r["sum_single"])
+            for g, ref in zip(r["sum_dp"], r["sum_single"]):
+                assert float((g - ref).abs().max()) <= 5e-5 * scale, (float((g - ref).abs().max()), scale)
+
+
 def _rccl_single_rank_worker(port, out_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", PGNN_DP_FORCE_INIT="1")
     os.environ.pop("PGNN_DP_BACKEND", None)
