@@ -217,6 +217,29 @@ int pgnn_mean_l2norm_bwd(const float* dy, int64_t lddy, const float* y, int64_t 
                          pgnn_stream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Context prediction: the negative-sampling dot-product loss (chem/pretrain_contextpred.py:54-67,86-97 and the same lines of
+ * bio/pretrain_contextpred.py; cbow mode, mean context pooling -- the reference's defaults) in two launches forward, one backward.
+ *   hs [n_sub, dim]: substructure node embeddings, center [graphs]: row of every graph's centre atom
+ *   hc [n_ctx, dim]: context node embeddings, overlap [n_overlap]: rows of the overlap nodes, seg [n_overlap]: their graph ids,
+ *                    ascending (batch_overlapped_context)
+ *   out [4] float64 = (loss_pos, loss_neg, fraction of pred_pos > 0, fraction of pred_neg < 0); loss (may be NULL) float64 =
+ *   loss_pos + neg_samples loss_neg, the quantity train() back-propagates (:89); accum (may be NULL) [4] float64:
+ *   accum[0] += loss_pos + loss_neg, accum[1] += 0.5 (fraction + fraction), accum[3] += 1 (the epoch sums of train(), :99-100).
+ *   counter: one zeroed uint32 that the call leaves zeroed; status: incremented per out-of-range index (clamped).
+ * The workspace carries the pooled context rows and the scores from forward to backward (same buffer, untouched in between).
+ * backward: grad_loss [1] float64 = d / d loss; dhs [n_sub, lddhs], dhc [n_ctx, lddhc] are written in full
+ * (zero except the centre rows / the overlap rows; neither index vector may repeat a row).
+ * ------------------------------------------------------------------------------------------ */
+size_t pgnn_contextpred_loss_workspace_bytes(int64_t graphs, int64_t dim, int64_t neg_samples);
+int pgnn_contextpred_loss_fwd(const float* hs, int64_t ldhs, int64_t n_sub, const int64_t* center, const float* hc, int64_t ldhc, int64_t n_ctx,
+                              const int64_t* overlap, const int64_t* seg, int64_t n_overlap, int64_t graphs, int64_t dim, int64_t neg_samples,
+                              double* out, double* loss, double* accum, int32_t* status, uint32_t* counter, void* ws, size_t ws_bytes,
+                              pgnn_stream stream);
+int pgnn_contextpred_loss_bwd(const float* hs, int64_t ldhs, int64_t n_sub, const int64_t* center, int64_t n_ctx, const int64_t* overlap,
+                              const int64_t* seg, int64_t n_overlap, int64_t graphs, int64_t dim, int64_t neg_samples, const double* grad_loss,
+                              float* dhs, int64_t lddhs, float* dhc, int64_t lddhc, const void* ws, size_t ws_bytes, pgnn_stream stream);
+
+/* ------------------------------------------------------------------------------------------
  * Linear layers of the GIN mlp / GCN linear (chem/model.py:29,54-55,63,99; bio/model.py:24,67,109):
  * fp32 GEMMs on the matrix cores.  Forward: three-term bf16 split of every fp32 value, six v_mfma_f32_16x16x32_bf16
  * products per k-step, fp32 accumulate -- the rounding error of an fp32 FMA chain (csrc/linear.hip; PGNN_GEMM_SPLIT=0

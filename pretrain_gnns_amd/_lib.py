@@ -55,6 +55,9 @@ PROTOTYPES = {
     "pgnn_bn_stats_fwd_blocks": (_i, [_p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i64, _i64, _p]),
     "pgnn_bn_apply_fwd": (_i, [_p, _i64, _p, _i, _p, _i64, _f, _u64, _i64, _i64, _p]),
     "pgnn_debug_gemm3w_profile": (_i, [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _p, _p]),
+    "pgnn_contextpred_loss_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "pgnn_contextpred_loss_fwd": (_i, [_p, _i64, _i64, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "pgnn_contextpred_loss_bwd": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _p, _p, _i64, _p, _i64, _p, _sz, _p]),
     "pgnn_weight_planes_bytes": (_sz, [_i64, _i64]),
     "pgnn_linear_wp_preferred": (_i, [_i64, _i64, _i64]),
     "pgnn_split_weights": (_i, [_p, _p, _p, _p, _p, _i64, _p]),

@@ -911,6 +911,61 @@ def masked_head(node_rep, idx, linear, label, with_metrics=False, accum=None):
     return (loss, correct, metrics) if with_metrics else (loss, correct)
 
 
+# ------------------------------------------------------------------------------------ context-prediction loss
+class ContextPredLoss(Function):
+    """chem/pretrain_contextpred.py:54-67,86-97 (cbow, mean context pooling) on the two networks' node embeddings, two launches:
+    returns (loss float64 [] = loss_pos + neg_samples * loss_neg -- what train() back-propagates, one launch back --,
+    vals float64 [4] = (loss_pos, loss_neg, fraction of pred_pos > 0, fraction of pred_neg < 0), no gradient).
+    ``center`` / ``overlap`` must not repeat a row."""
+
+    @staticmethod
+    def forward(ctx, hs, center, hc, overlap, seg, neg_samples, accum=None):
+        require_cuda(hs, center, hc, overlap, seg)
+        ctx.set_materialize_grads(False)
+        hs, hc = _rows2d(hs), _rows2d(hc)
+        dim, B = hs.size(1), center.numel()
+        if hc.size(1) != dim or B == 0 or overlap.numel() != seg.numel() or any(t.dtype != torch.int64 for t in (center, overlap, seg)):
+            raise _lib.PgnnError("contextpred loss: hs / hc [*, dim] fp32, center [graphs], overlap / seg [n] int64")
+        if accum is not None and (accum.dtype != torch.float64 or accum.numel() < 4 or not accum.is_contiguous() or accum.device != hs.device):
+            raise _lib.PgnnError("contextpred loss: accum must be a contiguous float64 [4] tensor on the device of the embeddings")
+        center, overlap, seg = center.contiguous(), overlap.contiguous(), seg.contiguous()
+        dev = hs.device
+        vals = torch.empty(4, dtype=torch.float64, device=dev)
+        loss = torch.empty((), dtype=torch.float64, device=dev)
+        words = _head_state(dev)
+        ws = torch.empty(_ws_bytes("pgnn_contextpred_loss_workspace_bytes", B, dim, int(neg_samples)), dtype=torch.uint8, device=dev)
+        check(load().pgnn_contextpred_loss_fwd(hs.data_ptr(), hs.stride(0), hs.size(0), center.data_ptr(), hc.data_ptr(), hc.stride(0), hc.size(0),
+                                               overlap.data_ptr(), seg.data_ptr(), overlap.numel(), B, dim, int(neg_samples), vals.data_ptr(),
+                                               loss.data_ptr(), accum.data_ptr() if accum is not None else None, words.data_ptr(),
+                                               words.data_ptr() + 4, ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_contextpred_loss_fwd")
+        if _CHECK_INDICES and int(words[0].item()):
+            words[0] = 0
+            raise IndexError("contextpred loss: row index out of range")
+        ctx.save_for_backward(hs, center, overlap, seg)
+        ctx.ws, ctx.n_ctx, ctx.neg = ws, hc.size(0), int(neg_samples)
+        ctx.mark_non_differentiable(vals)
+        return loss, vals
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gloss, _gvals):
+        if gloss is None:
+            return None, None, None, None, None, None, None
+        hs, center, overlap, seg = ctx.saved_tensors
+        dev, dim, B = hs.device, hs.size(1), center.numel()
+        gloss = gloss.to(torch.float64).contiguous()
+        dhs = torch.empty(hs.size(0), dim, dtype=torch.float32, device=dev)
+        dhc = torch.empty(ctx.n_ctx, dim, dtype=torch.float32, device=dev)
+        check(load().pgnn_contextpred_loss_bwd(hs.data_ptr(), hs.stride(0), hs.size(0), center.data_ptr(), ctx.n_ctx, overlap.data_ptr(),
+                                               seg.data_ptr(), overlap.numel(), B, dim, ctx.neg, gloss.data_ptr(), dhs.data_ptr(), dim,
+                                               dhc.data_ptr(), dim, ctx.ws.data_ptr(), ctx.ws.numel(), stream_ptr()), "pgnn_contextpred_loss_bwd")
+        return dhs, None, dhc, None, None, None, None
+
+
+def contextpred_loss(hs, center, hc, overlap, seg, neg_samples=1, accum=None):
+    return ContextPredLoss.apply(hs, center, hc, overlap, seg, neg_samples, accum)
+
+
 # ------------------------------------------------------------------------------------ fused chem GIN layer
 class ChemGINLayer(Function):
     """One chem GIN layer + its outer BatchNorm (+ReLU) as ONE library call per direction

@@ -308,6 +308,23 @@ def chem_contextpred_step(model_substruct, model_context, optimizer_substruct, o
         raise ValueError("readback must be 'end' or 'epoch'")
     if readback == "epoch" and accum is None:
         raise ValueError("readback='epoch' needs accum=epoch_accumulator(device)")
+    if mode == "cbow" and pool is None and batch.x_substruct.is_cuda and 1 <= neg_samples <= 8:
+        # the reference's defaults: the whole loss in two launches forward and one back (csrc/contextpred.hip) instead of ~50
+        # torch launches a few hundred elements long, between which the GPU idled
+        hs = model_substruct(batch.x_substruct, batch.edge_index_substruct, batch.edge_attr_substruct)
+        hc = model_context(batch.x_context, batch.edge_index_context, batch.edge_attr_context)
+        if hs.dim() == 2 and hs.size(1) % 4 == 0 and hs.size(1) <= 512:
+            loss, vals = ops.contextpred_loss(hs, batch.center_substruct_idx, hc, batch.overlap_context_substruct_idx,
+                                              batch.batch_overlapped_context, neg_samples, accum if readback == "epoch" else None)
+            optimizer_substruct.zero_grad()
+            optimizer_context.zero_grad()
+            loss.backward(_unit_grad(loss))
+            optimizer_substruct.step()
+            optimizer_context.step()
+            if readback == "epoch":
+                return None
+            v = vals.cpu().tolist()
+            return v[0] + v[1], 0.5 * (v[2] + v[3])
     pred_pos, pred_neg = contextpred_logits(model_substruct, model_context, batch, neg_samples, mode, pool)
     loss_pos = F.binary_cross_entropy_with_logits(pred_pos.double(), torch.ones_like(pred_pos).double())
     loss_neg = F.binary_cross_entropy_with_logits(pred_neg.double(), torch.zeros_like(pred_neg).double())

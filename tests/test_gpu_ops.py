@@ -624,6 +624,61 @@ def test_adam_one_launch_matches_torch_adam(weight_decay):
     assert torch.equal(mine[3].detach(), ref[3].detach())
 
 
+@pytest.mark.parametrize("graphs,neg", [(256, 1), (37, 3), (2, 1), (1, 2)])
+def test_contextpred_loss_fused_matches_the_torch_composition(graphs, neg):
+    """csrc/contextpred.hip (two launches forward, one back) against the statements of chem/pretrain_contextpred.py:54-67,86-97
+    written with torch ops in float64: pooled context rows, cycle_index negatives, both BCE means, both hit fractions, the
+    gradients of loss_pos + neg_samples * loss_neg with respect to BOTH node-embedding matrices (zero off the centre / overlap
+    rows), the epoch accumulator, bitwise reproducibility"""
+    ops = _ops()
+    from pretrain_gnns_amd import train as ptrain
+    torch.manual_seed(graphs * 10 + neg)
+    D = 300
+    sizes_s = torch.randint(5, 30, (graphs,))
+    sizes_c = torch.randint(3, 20, (graphs,))
+    ns, nc = int(sizes_s.sum()), int(sizes_c.sum())
+    hs = torch.randn(ns, D, device=DEV) * 0.3
+    hc = torch.randn(nc, D, device=DEV) * 0.3
+    off_s = torch.cumsum(sizes_s, 0) - sizes_s
+    off_c = torch.cumsum(sizes_c, 0) - sizes_c
+    center = (off_s + (torch.rand(graphs) * sizes_s).long()).to(DEV)
+    ov, seg = [], []
+    for g in range(graphs):
+        k = int(torch.randint(1, int(sizes_c[g]) + 1, (1,)))
+        ov.append(off_c[g] + torch.randperm(int(sizes_c[g]))[:k])
+        seg.append(torch.full((k,), g))
+    overlap, seg = torch.cat(ov).to(DEV), torch.cat(seg).to(DEV)
+
+    def reference(hs_, hc_):
+        s = hs_[center]
+        o = hc_[overlap]
+        ctx = torch.zeros(graphs, D, dtype=o.dtype, device=DEV).index_add_(0, seg, o) / torch.bincount(seg, minlength=graphs).clamp(min=1).to(o.dtype)[:, None]
+        negc = torch.cat([ctx[ptrain.cycle_index(graphs, i + 1).to(DEV)] for i in range(neg)], dim=0)
+        pp, pn = (s * ctx).sum(1), (s.repeat((neg, 1)) * negc).sum(1)
+        lp = torch.nn.functional.binary_cross_entropy_with_logits(pp.double(), torch.ones_like(pp).double())
+        ln = torch.nn.functional.binary_cross_entropy_with_logits(pn.double(), torch.zeros_like(pn).double())
+        return lp, ln, (pp > 0).double().mean(), (pn < 0).double().mean()
+
+    a, c = hs.double().requires_grad_(True), hc.double().requires_grad_(True)
+    lp, ln, fp, fn = reference(a, c)
+    (lp + neg * ln).backward()
+    x, y = hs.clone().requires_grad_(True), hc.clone().requires_grad_(True)
+    accum = torch.zeros(4, dtype=torch.float64, device=DEV)
+    loss, vals = ops.contextpred_loss(x, center, y, overlap, seg, neg, accum)
+    loss.backward()
+    torch.testing.assert_close(vals, torch.stack([lp, ln, fp, fn]).detach(), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(loss.detach(), (lp + neg * ln).detach(), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(accum, torch.stack([lp + ln, 0.5 * (fp + fn), torch.zeros_like(lp), torch.ones_like(lp)]).detach(), rtol=1e-6, atol=1e-7)
+    for got, want in ((x.grad, a.grad), (y.grad, c.grad)):
+        scale = float(want.abs().max())
+        assert float((got.double() - want).abs().max()) <= 2e-6 * scale
+        assert torch.equal(got == 0, want == 0) or float((got.double() - want).abs().max()) <= 1e-12 + 2e-6 * scale
+    x2, y2 = hs.clone().requires_grad_(True), hc.clone().requires_grad_(True)
+    loss2, vals2 = ops.contextpred_loss(x2, center, y2, overlap, seg, neg)
+    loss2.backward()
+    assert torch.equal(loss2, loss) and torch.equal(vals2, vals) and torch.equal(x2.grad, x.grad) and torch.equal(y2.grad, y.grad)
+
+
 def test_adam_limits_are_enforced_not_silent():
     """lr read from param_groups at launch (a scheduler works); a handle stepped twice, a zero_grad() in an incomplete
     round and a parameter whose first gradient arrives late raise instead of silently doing something else than torch"""
