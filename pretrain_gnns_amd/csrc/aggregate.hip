@@ -776,21 +776,34 @@ k_rowfeat_bwd_partial(const float* __restrict__ cfeat, const float* __restrict__
   Row<R> acc[KC];
 #pragma unroll
   for (int t = 0; t < KC; ++t) row_zero<R>(acc[t]);
-  for (int i = i0; i < i1; ++i) {
-    const float myc = lane < KC ? cfeat[(int64_t)i * KC + lane] : 0.f;
-    Row<R> gv;
-    row_load<R>(gv, g + (int64_t)i * ldg, lane, d4);
+  // four rows' loads in flight per wave (clamped, unconditional: a guarded load waits for itself), consumed in row order: the
+  // same fmaf chains as a one-row-at-a-time loop, which paid a full memory round trip per row (8 rows per wave at 6 747 rows:
+  // 18.6 us of pure latency in the 256-graph step)
+  constexpr int U = 4;
+  for (int i = i0; i < i1; i += U) {
+    float myc[U];
+    Row<R> gv[U];
 #pragma unroll
-    for (int t = 0; t < KC; ++t) {
-      const float c = __int_as_float(bcast_i32(__float_as_int(myc), t));
+    for (int u = 0; u < U; ++u) {
+      const int ii = min(i + u, i1 - 1);
+      myc[u] = lane < KC ? cfeat[(int64_t)ii * KC + lane] : 0.f;
+      row_load<R>(gv[u], g + (int64_t)ii * ldg, lane, d4);
+    }
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int ch = lane + r * kWave;
-        if (r + 1 < R || ch < d4) {
-          acc[t].v[r].x = fmaf(c, gv.v[r].x, acc[t].v[r].x);
-          acc[t].v[r].y = fmaf(c, gv.v[r].y, acc[t].v[r].y);
-          acc[t].v[r].z = fmaf(c, gv.v[r].z, acc[t].v[r].z);
-          acc[t].v[r].w = fmaf(c, gv.v[r].w, acc[t].v[r].w);
+    for (int u = 0; u < U; ++u) {
+      if (i + u >= i1) break;
+#pragma unroll
+      for (int t = 0; t < KC; ++t) {
+        const float c = __int_as_float(bcast_i32(__float_as_int(myc[u]), t));
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int ch = lane + r * kWave;
+          if (r + 1 < R || ch < d4) {
+            acc[t].v[r].x = fmaf(c, gv[u].v[r].x, acc[t].v[r].x);
+            acc[t].v[r].y = fmaf(c, gv[u].v[r].y, acc[t].v[r].y);
+            acc[t].v[r].z = fmaf(c, gv[u].v[r].z, acc[t].v[r].z);
+            acc[t].v[r].w = fmaf(c, gv[u].v[r].w, acc[t].v[r].w);
+          }
         }
       }
     }

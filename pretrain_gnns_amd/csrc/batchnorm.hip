@@ -68,11 +68,19 @@ __global__ void k_bn_stats_partial(const float* __restrict__ x, int64_t ldx, int
   float4 s1 = f4_zero(), s2 = f4_zero();
   if (rl < 4) {
     const float4 k = reinterpret_cast<const float4*>(x)[c4];  // shift = row 0
-    for (int r = r0 + rl; r < r1; r += 4) {
-      const float4 v = reinterpret_cast<const float4*>(x + (int64_t)r * ldx)[c4];
-      const float dx = v.x - k.x, dy = v.y - k.y, dz = v.z - k.z, dw = v.w - k.w;
-      s1.x += dx; s1.y += dy; s1.z += dz; s1.w += dw;
-      s2.x = fmaf(dx, dx, s2.x); s2.y = fmaf(dy, dy, s2.y); s2.z = fmaf(dz, dz, s2.z); s2.w = fmaf(dw, dw, s2.w);
+    constexpr int U = 4;  // four rows in flight per thread, summed in row order (see k_bn_bwd_partial)
+    for (int rb = r0 + rl; rb < r1; rb += 4 * U) {
+      float4 vv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) vv[u] = reinterpret_cast<const float4*>(x + (int64_t)min(rb + 4 * u, r1 - 1) * ldx)[c4];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (rb + 4 * u >= r1) break;
+        const float4 v = vv[u];
+        const float dx = v.x - k.x, dy = v.y - k.y, dz = v.z - k.z, dw = v.w - k.w;
+        s1.x += dx; s1.y += dy; s1.z += dz; s1.w += dw;
+        s2.x = fmaf(dx, dx, s2.x); s2.y = fmaf(dy, dy, s2.y); s2.z = fmaf(dz, dz, s2.z); s2.w = fmaf(dw, dw, s2.w);
+      }
     }
   }
   float* p = partial + (size_t)blockIdx.x * 2 * dim;
@@ -213,24 +221,39 @@ __global__ void k_bn_bwd_partial(const float* __restrict__ dy, int64_t lddy, con
       reinterpret_cast<float4*>(coef + 2 * dim)[c4] = mu;
       reinterpret_cast<float4*>(coef + 3 * dim)[c4] = is;
     }
-    for (int r = r0 + rl; r < r1; r += 4) {
-      const float4 v = reinterpret_cast<const float4*>(x + (int64_t)r * ldx)[c4];
-      float4 g = reinterpret_cast<const float4*>(dy + (int64_t)r * lddy)[c4];
-      if (drop.thresh) {
-        const float4 f = drop_factors(drop, r, d4, c4);
-        g.x *= f.x; g.y *= f.y; g.z *= f.z; g.w *= f.w;
+    // four of the thread's rows in flight (clamped, unconditional loads), consumed in row order: the same sums as a loop that
+    // pays a memory round trip per row (8 round trips per thread at 32 rows per block: ~16 us of latency at 6 747 rows)
+    constexpr int U = 4;
+    for (int rb = r0 + rl; rb < r1; rb += 4 * U) {
+      float4 vv[U], gg[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = min(rb + 4 * u, r1 - 1);
+        vv[u] = reinterpret_cast<const float4*>(x + (int64_t)r * ldx)[c4];
+        gg[u] = reinterpret_cast<const float4*>(dy + (int64_t)r * lddy)[c4];
       }
-      if (relu) {
-        if (!(fmaf(a.x, v.x, b.x) > 0.f)) g.x = 0.f;
-        if (!(fmaf(a.y, v.y, b.y) > 0.f)) g.y = 0.f;
-        if (!(fmaf(a.z, v.z, b.z) > 0.f)) g.z = 0.f;
-        if (!(fmaf(a.w, v.w, b.w) > 0.f)) g.w = 0.f;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = rb + 4 * u;
+        if (r >= r1) break;
+        const float4 v = vv[u];
+        float4 g = gg[u];
+        if (drop.thresh) {
+          const float4 f = drop_factors(drop, r, d4, c4);
+          g.x *= f.x; g.y *= f.y; g.z *= f.z; g.w *= f.w;
+        }
+        if (relu) {
+          if (!(fmaf(a.x, v.x, b.x) > 0.f)) g.x = 0.f;
+          if (!(fmaf(a.y, v.y, b.y) > 0.f)) g.y = 0.f;
+          if (!(fmaf(a.z, v.z, b.z) > 0.f)) g.z = 0.f;
+          if (!(fmaf(a.w, v.w, b.w) > 0.f)) g.w = 0.f;
+        }
+        s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+        s2.x = fmaf(g.x, (v.x - mu.x) * is.x, s2.x);
+        s2.y = fmaf(g.y, (v.y - mu.y) * is.y, s2.y);
+        s2.z = fmaf(g.z, (v.z - mu.z) * is.z, s2.z);
+        s2.w = fmaf(g.w, (v.w - mu.w) * is.w, s2.w);
       }
-      s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
-      s2.x = fmaf(g.x, (v.x - mu.x) * is.x, s2.x);
-      s2.y = fmaf(g.y, (v.y - mu.y) * is.y, s2.y);
-      s2.z = fmaf(g.z, (v.z - mu.z) * is.z, s2.z);
-      s2.w = fmaf(g.w, (v.w - mu.w) * is.w, s2.w);
     }
   }
   float* p = partial + (size_t)blockIdx.x * 2 * dim;
