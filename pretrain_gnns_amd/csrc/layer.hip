@@ -662,7 +662,10 @@ size_t pgnn_bio_gin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t num_la
   // 2 x op scratch + 2 x (dhid, dpre, dagg: 2 nd each; dx: nd) + W1^T, W2^T per layer
   const size_t wt = std::max((size_t)std::min<int64_t>(num_layer, kMaxTransposed) * (align_up((size_t)4 * dim * dim * 4, 256) + align_up((size_t)2 * dim * dim * 4, 256)),
                              (size_t)std::min<int64_t>(num_layer, kMaxPlaneLayers) * mlp_planes_bytes(2 * dim, 2 * dim, dim));
-  return 2 * bio_op_ws_bytes(n, dim) + 2 * 7 * nd + wt + 512;
+  // + the per-16-row column statistics of the 2D-wide pre-activation and the BatchNorm coefficients (forward, statistics from the
+  // product's epilogue)
+  const size_t blocks = align_up((size_t)ceil_div(n, 16) * 2 * 2 * dim * 4, 256) + align_up((size_t)2 * 2 * dim * 4, 256);
+  return 2 * bio_op_ws_bytes(n, dim) + 2 * 7 * nd + wt + blocks + 512;
 }
 
 int pgnn_bio_gin_stack_fwd(const float* h0, int64_t ldh0, const int32_t* in_ptr, const int32_t* in_src, const float* cfeat,
@@ -684,9 +687,17 @@ int pgnn_bio_gin_stack_fwd(const float* h0, int64_t ldh0, const int32_t* in_ptr,
   // both products of every layer on pre-split weight planes (behind the op scratch of the workspace), as in the chem stack
   const size_t opb = bio_op_ws_bytes(n, dim);
   void *wp1[kMaxPlaneLayers], *wp2[kMaxPlaneLayers];
-  const bool wp = mlp_wp(n, 2 * dim, 2 * dim, dim, num_layer) && ws_bytes >= opb + (size_t)num_layer * mlp_planes_bytes(2 * dim, 2 * dim, dim);
+  const size_t planes_b = (size_t)num_layer * mlp_planes_bytes(2 * dim, 2 * dim, dim);
+  const bool wp = mlp_wp(n, 2 * dim, 2 * dim, dim, num_layer) && ws_bytes >= opb + planes_b;
   if (wp && (rc = split_mlp_weights(layers, num_layer, 2 * dim, 2 * dim, dim, 0, static_cast<char*>(ws) + opb, wp1, wp2, (hipStream_t)stream)))
     return rc;
+  // training-mode statistics of the mlp's BatchNorm1d(2D) from the epilogue of the product that writes its input (the chem form,
+  // csrc/batchnorm.hip pgnn_bn_stats_fwd_blocks): no pass over `pre` for them, two launches less per layer
+  const size_t blocks_b = align_up((size_t)ceil_div(n, 16) * 2 * 2 * dim * 4, 256);
+  const bool stats_in_gemm = wp && training && n > 1 && n <= kStatsInGemmMaxRows && env_knob("PGNN_BN_STATS_IN_GEMM", 1) != 0 &&
+                             ws_bytes >= opb + planes_b + blocks_b + align_up((size_t)2 * 2 * dim * 4, 256);
+  float* blocks = reinterpret_cast<float*>(static_cast<char*>(ws) + opb + planes_b);
+  float* coef = reinterpret_cast<float*>(static_cast<char*>(ws) + opb + planes_b + blocks_b);
   for (int l = 0; l < num_layer; ++l) {
     const pgnn_gin_layer& p = layers[l];
     float* a = acts + (size_t)l * 7 * nd;
@@ -700,11 +711,18 @@ int pgnn_bio_gin_stack_fwd(const float* h0, int64_t ldh0, const int32_t* in_ptr,
       rc = pgnn_rowfeat_matmul_fwd(cfeat, 10, p.emb1, dim, agg + dim, 2 * dim, n, dim, 0, stream);
     }
     if (rc) return rc;
-    if (wp) rc = pgnn_linear_fwd_wp(agg, 2 * dim, wp1[l], p.b1, pre, 2 * dim, n, 2 * dim, 2 * dim, 0, nullptr, stream);
+    if (wp) rc = pgnn_linear_fwd_wp(agg, 2 * dim, wp1[l], p.b1, pre, 2 * dim, n, 2 * dim, 2 * dim, 0, stats_in_gemm ? blocks : nullptr, stream);
     else rc = pgnn_linear_fwd(agg, 2 * dim, p.w1, p.b1, pre, 2 * dim, n, 2 * dim, 2 * dim, 0, stream);
     if (rc) return rc;
-    if ((rc = pgnn_bn_fwd(pre, 2 * dim, p.gamma, p.beta, p.running_mean, p.running_var, p.momentum, p.eps, training, 1, hid,
-                          2 * dim, st, st + 2 * dim, 0.f, 0, n, 2 * dim, ws, opb, stream))) return rc;
+    if (stats_in_gemm) {
+      if ((rc = pgnn_bn_stats_fwd_blocks(blocks, p.gamma, p.beta, p.running_mean, p.running_var, p.momentum, p.eps, st, st + 2 * dim, coef, n,
+                                         2 * dim, stream))) return rc;
+      rc = pgnn_bn_apply_fwd(pre, 2 * dim, coef, 1, hid, 2 * dim, 0.f, 0, n, 2 * dim, stream);
+    } else {
+      rc = pgnn_bn_fwd(pre, 2 * dim, p.gamma, p.beta, p.running_mean, p.running_var, p.momentum, p.eps, training, 1, hid, 2 * dim, st,
+                       st + 2 * dim, 0.f, 0, n, 2 * dim, ws, opb, stream);
+    }
+    if (rc) return rc;
     if (wp) rc = pgnn_linear_fwd_wp(hid, 2 * dim, wp2[l], p.b2, y, dim, n, 2 * dim, dim, l != num_layer - 1, nullptr, stream);
     else rc = pgnn_linear_fwd(hid, 2 * dim, p.w2, p.b2, y, dim, n, 2 * dim, dim, l != num_layer - 1, stream);
     if (rc) return rc;

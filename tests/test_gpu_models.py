@@ -162,6 +162,7 @@ def test_bio_one_call_network_equals_per_layer_path(graphs, layers, training, mo
         monkeypatch.setattr(hbio, "_STACK_CALL", stack)
         monkeypatch.setenv("PGNN_BWD_TRANSPOSED", "2" if transposed else "0")
         monkeypatch.setenv("PGNN_GEMM_WP_MIN_TILES", "160")  # weight planes only where the per-layer calls run the same arithmetic
+        monkeypatch.setenv("PGNN_BN_STATS_IN_GEMM", "0")     # (the one-call forward takes the mlp's BatchNorm statistics from the GEMM epilogue)
         ops.load().pgnn_reload_env()
         for _ in range(2):  # twice: running statistics advance identically
             m.zero_grad()
@@ -172,6 +173,7 @@ def test_bio_one_call_network_equals_per_layer_path(graphs, layers, training, mo
     per_layer, exact, default = run(a, False, False), run(b, True, False), run(c, True, True)
     monkeypatch.delenv("PGNN_BWD_TRANSPOSED")
     monkeypatch.delenv("PGNN_GEMM_WP_MIN_TILES")
+    monkeypatch.delenv("PGNN_BN_STATS_IN_GEMM")
     ops.load().pgnn_reload_env()
     assert torch.equal(per_layer[0], exact[0]) and torch.equal(per_layer[0], default[0])
     for k in per_layer[2]:
@@ -180,6 +182,42 @@ def test_bio_one_call_network_equals_per_layer_path(graphs, layers, training, mo
     for k, g in per_layer[1].items():
         assert torch.equal(g, exact[1][k]), k
         assert float((g - default[1][k]).abs().max()) <= 2e-5 * float(g.abs().max()) + 1e-5 * top, k
+
+
+def test_bio_batchnorm_statistics_from_the_gemm_epilogue_match_the_separate_pass(monkeypatch):
+    """bio one-call network: the statistics of the mlp's BatchNorm1d(2D) taken from the 600 -> 600 product's epilogue (the default
+    from ~1 500 rows) against the same call with PGNN_BN_STATS_IN_GEMM=0 (a pass over the pre-activation): outputs and running
+    statistics agree to fp32 rounding carried through the layers, gradients in relative l2"""
+    import copy
+    from pretrain_gnns_amd import ops
+    _, hbio = _hip()
+    _, a = _pair(obio.GNN, hbio.GNN, 5, 300, seed=12)
+    b = copy.deepcopy(a)
+    a.train(), b.train()
+    d = synthetic.bio_masking_batch(64, seed=13).to(DEV)
+    assert int(ops.load().pgnn_linear_wp_preferred(d.x.size(0), 600, 300)) == 1
+    w = torch.randn(d.x.size(0), 300, device=DEV)
+    res = []
+    for m, flag in ((a, "1"), (b, "0")):
+        monkeypatch.setenv("PGNN_BN_STATS_IN_GEMM", flag)
+        ops.load().pgnn_reload_env()
+        for _ in range(2):
+            m.zero_grad()
+            out = m(d.x, d.edge_index, d.edge_attr)
+            (out * w).sum().backward()
+        res.append((out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}, {k: v.clone() for k, v in m.named_buffers()}))
+    monkeypatch.delenv("PGNN_BN_STATS_IN_GEMM")
+    ops.load().pgnn_reload_env()
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-4, atol=1e-4)
+    for k in res[0][2]:
+        if res[0][2][k].dtype.is_floating_point:
+            torch.testing.assert_close(res[0][2][k], res[1][2][k], rtol=1e-5, atol=1e-6)
+        else:
+            assert torch.equal(res[0][2][k], res[1][2][k]), k
+    top = max(float(g.abs().max()) for g in res[1][1].values())
+    for k in res[0][1]:
+        g0, g1 = res[0][1][k].double(), res[1][1][k].double()
+        assert float((g0 - g1).norm()) <= 1e-2 * float(g1.norm()) + 1e-4 * top, k
 
 
 @pytest.mark.parametrize("pool", ["mean", "attention"])
