@@ -918,13 +918,22 @@ int launch_gemm3w_s(const GemmArgs& p, hipStream_t st) {
   return check_launch("gemm3w");
 }
 
-// tile choice as for k_gemm3: 128x160 when that still gives 3/4 of the CUs a workgroup, else 64x160.
+// tile choice: the cheaper of 64x160 and 128x160 under a rounds x (k-steps + fixed) model, see below.
 // PGNN_GEMM3W_CFG: 0 = 128x160 (8 x 1 waves of 16 x 160) / 3 stages, 1 = 64x160 (4 x 2 waves of 16 x 80) / 4 stages,
 // 2 = 64x160 / 3 stages, 3 = 128x160 (4 x 2 waves of 32 x 80) / 3 stages
 template <int EPI>
 int launch_gemm3w(const GemmArgs& p, hipStream_t st) {
   int cfg = env_knob("PGNN_GEMM3W_CFG", -1);
-  if (cfg < 0) cfg = ceil_div(p.M, 128) * ceil_div(p.N, 160) * 4 >= 3 * num_cu() ? 0 : 1;
+  if (cfg < 0) {
+    // one workgroup per CU (LDS), so a launch runs ceil(tiles / CUs) rounds of (k-steps x step time + per-tile prologue and
+    // epilogue): 0.66 / 1.34 us per 32-deep k-step of a 64- / 128-row tile and ~3 us per tile (tools/gemm3w_bench.cpp, 2 048 rows).
+    // 6 747 x 600: 212 tiles of 128 rows in one round (16 us) beat 424 of 64 in two (19); 10 249 x 600 (bio): 644 tiles of 64 in
+    // three rounds (47 us) beat 324 of 128 in two (57, measured 57)
+    const int64_t nk = ceil_div(p.K, 32), cus = num_cu();
+    const double t64 = (double)ceil_div(ceil_div(p.M, 64) * ceil_div(p.N, 160), cus) * (0.66 * nk + 3.0);
+    const double t128 = (double)ceil_div(ceil_div(p.M, 128) * ceil_div(p.N, 160), cus) * (1.34 * nk + 3.0);
+    cfg = t128 <= t64 ? 0 : 1;
+  }
   switch (cfg) {
     case 0: return launch_gemm3w_s<128, 160, 8, 1, 3, EPI>(p, st);
     case 2: return launch_gemm3w_s<64, 160, 4, 2, 3, EPI>(p, st);
