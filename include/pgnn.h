@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PGNN_ABI_VERSION 4
+#define PGNN_ABI_VERSION 5
 
 #define PGNN_OK 0
 #define PGNN_ERR_ARG 1

@@ -117,7 +117,7 @@ PROTOTYPES = {
     "pgnn_debug_aggregate_profile": (_i, [_p, _i64]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class GinLayer(ctypes.Structure):
