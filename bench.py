@@ -145,7 +145,7 @@ def roofline_aggregation(dev, graphs):
     from pretrain_gnns_amd import ops
     from pretrain_gnns_amd.data import synthetic
 
-    base = synthetic.chem_masking_batch(2048, seed=123)
+    base = synthetic.chem_masking_batch(2048, seed=123, device=dev)
     big = synthetic.tile_batch(base, max(1, graphs // 2048)).to(dev)
     n, e = big.x.size(0), big.edge_index.size(1)
     g = ops.build_chem_graph(big.edge_index, big.edge_attr, n)
@@ -333,8 +333,9 @@ def resident_loader_leg(dev, args, steps_n):
     e.record()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    from oracle import hostdata  # (the CPU side of this comparison: the host restatement of the reference's transform + collate)
     for i in ids[:4]:
-        synthetic.collate([synthetic.mask_atoms(graphs[j], rng) for j in i]).to(dev)
+        hostdata.collate([hostdata.mask_atoms(graphs[j], rng) for j in i]).to(dev)
     torch.cuda.synchronize()
     host_ms = (time.perf_counter() - t1) / 4 * 1e3
     return {"edges_per_s": round(edges / dt, 1), "ms_per_step": round(dt / steps_n * 1e3, 4),
@@ -497,7 +498,8 @@ def contextpred_leg(dev, args, steps_n, with_cpu):
         from oracle import steps as osteps
         cores = usable_cores()
         torch.set_num_threads(cores)
-        hb = synthetic.chem_contextpred_batch(args.graphs_per_gpu, seed=0)
+        from oracle import hostdata
+        hb = hostdata.chem_contextpred_batch(args.graphs_per_gpu, seed=0)
         torch.manual_seed(0)
         a, b = ochem.GNN(5, 300), ochem.GNN(3, 300)
         oa, ob = torch.optim.Adam(a.parameters(), lr=1e-3), torch.optim.Adam(b.parameters(), lr=1e-3)
@@ -560,7 +562,8 @@ def bio_leg(dev, args, steps_n, with_cpu):
         from oracle import steps as osteps
         cores = usable_cores()
         torch.set_num_threads(cores)
-        hb = synthetic.bio_masking_batch(64, seed=0)
+        from oracle import hostdata
+        hb = hostdata.bio_masking_batch(64, seed=0)
         torch.manual_seed(0)
         om = [obio.GNN(5, 300), torch.nn.Linear(300, 7)]
         oo = [torch.optim.Adam(m.parameters(), lr=1e-3) for m in om]
@@ -650,9 +653,9 @@ def large_batch_sweep(dev, sizes, args):
     from pretrain_gnns_amd.data import synthetic
 
     out = {}
-    base = synthetic.chem_masking_batch(2048, seed=7)
+    base = synthetic.chem_masking_batch(2048, seed=7, device=dev)
     for g in sizes:
-        batch = (synthetic.tile_batch(base, g // 2048) if g >= 2048 else synthetic.chem_masking_batch(g, seed=7)).to(dev)
+        batch = (synthetic.tile_batch(base, g // 2048) if g >= 2048 else synthetic.chem_masking_batch(g, seed=7, device=dev)).to(dev)
         mods = make_models(dev)
         opts = make_optimizers(mods, args.adam)
         step, finish = masking_stepper(mods, opts, args.readback, dev)
@@ -676,12 +679,11 @@ def large_batch_sweep(dev, sizes, args):
 
 def _cpu_rate(graphs, threads, seconds):
     from oracle import chem as ochem
-    from oracle import steps
-    from pretrain_gnns_amd.data import synthetic
+    from oracle import hostdata, steps
 
     torch.set_num_threads(threads)
     torch.manual_seed(0)
-    batch = synthetic.chem_masking_batch(graphs, seed=0)
+    batch = hostdata.chem_masking_batch(graphs, seed=0)
     mods = [ochem.GNN(5, 300), torch.nn.Linear(300, 119), torch.nn.Linear(300, 4)]
     opts = [torch.optim.Adam(m.parameters(), lr=1e-3) for m in mods]
     for _ in range(2):
@@ -760,7 +762,7 @@ def _run():
     opts = make_optimizers(mods, args.adam)
     if world > 1 or dist.is_initialized():
         opts = parallel.AllReduceOptimizers(opts)
-    batch = synthetic.chem_masking_batch(args.graphs_per_gpu, seed=rank).to(dev)
+    batch = synthetic.chem_masking_batch(args.graphs_per_gpu, seed=rank, device=dev)  # collated and MaskAtom'ed on the device
     edges_local = batch.edge_index.size(1)
 
     step, finish = masking_stepper(mods, list(opts), args.readback, dev)

@@ -28,7 +28,11 @@
 extern "C" {
 #endif
 
-#define PGNN_ABI_VERSION 5
+#define PGNN_ABI_VERSION 6
+/* uint32 words behind every `counter` argument below: the arrival tickets of a launch whose last block folds the others'
+ * results (one top word + up to 32 group words: same-address atomics retire at ~50 ns each, see csrc/common.h).  Zero before
+ * the first call, left zero by every call; one buffer per device serves all calls of a stream. */
+#define PGNN_TICKET_WORDS 40
 
 #define PGNN_OK 0
 #define PGNN_ERR_ARG 1
@@ -225,7 +229,7 @@ int pgnn_mean_l2norm_bwd(const float* dy, int64_t lddy, const float* y, int64_t 
  *   out [4] float64 = (loss_pos, loss_neg, fraction of pred_pos > 0, fraction of pred_neg < 0); loss (may be NULL) float64 =
  *   loss_pos + neg_samples loss_neg, the quantity train() back-propagates (:89); accum (may be NULL) [4] float64:
  *   accum[0] += loss_pos + loss_neg, accum[1] += 0.5 (fraction + fraction), accum[3] += 1 (the epoch sums of train(), :99-100).
- *   counter: one zeroed uint32 that the call leaves zeroed; status: incremented per out-of-range index (clamped).
+ *   counter: PGNN_TICKET_WORDS zeroed uint32 that the call leaves zeroed; status: incremented per out-of-range index (clamped).
  * The workspace carries the pooled context rows and the scores from forward to backward (same buffer, untouched in between).
  * backward: grad_loss [1] float64 = d / d loss; dhs [n_sub, lddhs], dhc [n_ctx, lddhc] are written in full
  * (zero except the centre rows / the overlap rows; neither index vector may repeat a row).
@@ -307,8 +311,10 @@ int pgnn_linear_bwd_weight_pair(const float* dy_a, int64_t lddy_a, const float* 
  * torch.optim.Adam's update (chem/pretrain_masking.py:134-136 builds three of them with the same hyper-parameters) over
  * n <= pgnn_adam_max_tensors() fp32 tensors in one launch: params[j] / grads[j] device pointers (host arrays), counts[j]
  * elements, state_offsets[j] = where tensor j's moments live in the flat exp_avg / exp_avg_sq buffers.  step = device
- * int64[2]: step[0], the number of updates already applied, is advanced by the call (so the call can be captured in a HIP
- * graph); step[1] is the kernel's arrival counter, zero on entry and left zero.
+ * int64[32], zero before the first call: step[0], the number of updates already applied, is advanced by the call (so the call can
+ * be captured in a HIP graph); words 2..6 are the call's own cache of beta1^step, beta2^step (float64), the betas and the step
+ * they belong to -- a caller may overwrite step[0] (a restored checkpoint) without touching them, the call then recomputes the
+ * powers; words 8.. hold the kernel's PGNN_TICKET_WORDS arrival tickets, zero on entry and left zero.
  * L2 weight decay is added to the gradient (Adam, not AdamW); amsgrad is not offered.
  * ------------------------------------------------------------------------------------------ */
 int pgnn_adam_max_tensors(void);
@@ -325,8 +331,8 @@ int pgnn_adam_step(float* const* params, const float* const* grads, const int64_
  * metrics[2] = {loss, (double)correct} for a single read-back, and optionally accum[4] float64 = the running epoch sums the
  * reference's train() keeps on the host (chem/pretrain_masking.py:72-76): accum[0] += loss, accum[1] += correct / m,
  * accum[3] += 1 (accum[2], the bond-accuracy sum, is the caller's), so that a train loop reads back once per epoch;
- * status += bad indices / labels.  counter: one uint32 that is
- * zero on entry and is left zero (the arrival counter of the in-kernel final fold; a persistent per-device word).  fp32 linear algebra, float64 soft-max and loss, as in the reference; fixed summation order.
+ * status += bad indices / labels.  counter: PGNN_TICKET_WORDS uint32 that are
+ * zero on entry and are left zero (the arrival tickets of the in-kernel final fold; a persistent per-device buffer).  fp32 linear algebra, float64 soft-max and loss, as in the reference; fixed summation order.
  * Backward (gloss = d objective / d loss, float64 on the device): dnode [n_rows, ldd] is overwritten (zero outside idx),
  * dw [classes, dim], db [classes] or NULL.  Both calls use the same workspace.
  * ------------------------------------------------------------------------------------------ */
@@ -338,6 +344,34 @@ int pgnn_masked_head_fwd(const float* h, int64_t ldh, int64_t n_rows, const int6
 int pgnn_masked_head_bwd(const float* h, int64_t ldh, int64_t n_rows, const int64_t* idx, int64_t m, const float* w,
                          const int64_t* label, int64_t label_stride, const float* logits, const double* gloss, int64_t classes,
                          int64_t dim, float* dnode, int64_t ldd, float* dw, float* db, void* ws, size_t ws_bytes, pgnn_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Edge-prediction head of the masking pre-training steps (bio/pretrain_masking.py:45-58; chem/pretrain_masking.py:60-66):
+ *   edge_rep = node_rep[u] + node_rep[v] ; pred = linear(edge_rep) ; loss = CrossEntropyLoss()(pred, label) ;
+ *   correct = #(argmax(pred, 1) == label)
+ * h [n_nodes, ldh]; ends [2, m] int64 = the masked edges' end points (row 0: u, row 1: v -- edge_index[:, masked_idx],
+ * contiguous; a node may appear in any number of edges); w [classes, dim], b [classes] or NULL, classes 4 (chem bond types)
+ * or 7 (bio edge types).  Labels: EITHER label[r * label_stride] int64 OR onehot [m, onehot_cols] fp32 rows (pitch ld_onehot) whose
+ * first maximum is the label (the bio script's torch.argmax(mask_edge_label, 1) over the 9 edge-attribute columns; a maximum at
+ * a column >= classes counts in status, as a label out of range).  loss_float64 != 0: soft-max and loss in float64 (chem's
+ * pred.double()); 0: in fp32 (bio) -- *loss64 then holds the fp32 value widened, loss32 (optional) the fp32 value.
+ * logits [m, classes] is kept for the backward.  accum (optional float64 [4]): accum[0] += loss, accum[accum_slot] += correct / m
+ * (slot 1 or 2), accum[3] += 1 iff accum_step; metrics / status / counter as in pgnn_masked_head_fwd.
+ * The head is evaluated as P = h . w^T [n_nodes, classes], pred[r] = P[u] + P[v] + b, so nothing of size [m, dim] exists.
+ * Backward: exactly one of gloss64 / gloss32 (device scalar, d objective / d loss).  dnode [n_nodes, ldd] OVERWRITTEN with
+ * d objective / d h (S . w with S[n] = the sum of d pred over the masked edges at n, grouped in a fixed order), dw
+ * [classes, dim] = S^T . h, db [classes] or NULL.  Both calls use the same workspace and the same zeroed counter words.
+ * ------------------------------------------------------------------------------------------ */
+size_t pgnn_edge_head_workspace_bytes(int64_t n_nodes, int64_t m, int64_t classes, int64_t dim);
+int pgnn_edge_head_fwd(const float* h, int64_t ldh, int64_t n_nodes, const int64_t* ends, int64_t m, const float* w, const float* b,
+                       const int64_t* label, int64_t label_stride, const float* onehot, int64_t ld_onehot, int64_t onehot_cols,
+                       int64_t classes, int64_t dim, int loss_float64, float* logits, double* loss64, float* loss32, int64_t* correct, double* metrics,
+                       double* accum, int accum_slot, int accum_step, int32_t* status, uint32_t* counter, void* ws, size_t ws_bytes,
+                       pgnn_stream stream);
+int pgnn_edge_head_bwd(const float* h, int64_t ldh, int64_t n_nodes, const int64_t* ends, int64_t m, const float* w,
+                       const int64_t* label, int64_t label_stride, const float* onehot, int64_t ld_onehot, int64_t onehot_cols, const float* logits,
+                       const double* gloss64, const float* gloss32, int64_t classes, int64_t dim, int loss_float64, float* dnode,
+                       int64_t ldd, float* dw, float* db, uint32_t* counter, void* ws, size_t ws_bytes, pgnn_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Layer-level composition (host-side only: each call enqueues the per-op kernels above in order).

@@ -19,7 +19,7 @@ import os
 import torch
 
 from oracle import refshim
-from pretrain_gnns_amd.data import synthetic
+from oracle import hostdata
 
 REF = "/root/reference"
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
@@ -50,22 +50,22 @@ def main():
     torch.manual_seed(0)
     ochem, obio = refshim.load("chem").model, refshim.load("bio").model  # the reference's classes
     fx = _fixture("chem", "chem/model_architecture/gcn_contextpred.pth", ochem.GNN(5, 300, gnn_type="gcn"),
-                  synthetic.chem_plain_batch(6, seed=11))
+                  hostdata.chem_plain_batch(6, seed=11))
     torch.save(fx, os.path.join(OUT, "chem_gcn_contextpred.pt"))
     fx = _fixture("bio", "bio/model_architecture/gcn_masking.pth", obio.GNN(5, 300, gnn_type="gcn"),
-                  synthetic.bio_masking_batch(3, seed=12))
+                  hostdata.bio_masking_batch(3, seed=12))
     torch.save(fx, os.path.join(OUT, "bio_gcn_masking.pt"))
     fx = _fixture("chem", "chem/model_architecture/graphsage_contextpred.pth", ochem.GNN(5, 300, gnn_type="graphsage"),
-                  synthetic.chem_plain_batch(6, seed=13))
+                  hostdata.chem_plain_batch(6, seed=13))
     torch.save(fx, os.path.join(OUT, "chem_graphsage_contextpred.pt"))
     fx = _fixture("bio", "bio/model_architecture/graphsage_masking.pth", obio.GNN(5, 300, gnn_type="graphsage"),
-                  synthetic.bio_masking_batch(3, seed=14))
+                  hostdata.bio_masking_batch(3, seed=14))
     torch.save(fx, os.path.join(OUT, "bio_graphsage_masking.pt"))
     fx = _fixture("chem", "chem/model_architecture/gat_contextpred.pth", ochem.GNN(5, 300, gnn_type="gat"),
-                  synthetic.chem_plain_batch(6, seed=15))
+                  hostdata.chem_plain_batch(6, seed=15))
     torch.save(fx, os.path.join(OUT, "chem_gat_contextpred.pt"))
     fx = _fixture("bio", "bio/model_architecture/gat_masking.pth", obio.GNN(5, 300, gnn_type="gat"),
-                  synthetic.bio_masking_batch(3, seed=16))
+                  hostdata.bio_masking_batch(3, seed=16))
     torch.save(fx, os.path.join(OUT, "bio_gat_masking.pt"))
     # vocabulary / layout constants the reference fixes (chem/model.py:9-13,43; chem/util.py:212-213)
     torch.save({"num_atom_type": 120, "num_chirality_tag": 3, "num_bond_type": 6, "num_bond_direction": 3,

@@ -72,6 +72,11 @@ PROTOTYPES = {
     "pgnn_masked_head_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "pgnn_masked_head_fwd": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "pgnn_masked_head_bwd": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _i64, _p, _p, _i64, _i64, _p, _i64, _p, _p, _p, _sz, _p]),
+    "pgnn_edge_head_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "pgnn_edge_head_fwd": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p,
+                                _p, _sz, _p]),
+    "pgnn_edge_head_bwd": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i, _p, _i64, _p, _p, _p, _p, _sz,
+                                _p]),
     "pgnn_linear_bwd_data_t": (_i, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p]),
     "pgnn_transpose_batch": (_i, [_p, _p, _p, _p, _i64, _p]),
     "pgnn_linear_bwd_weight_workspace_bytes": (_sz, [_i64, _i64, _i64]),
@@ -117,7 +122,7 @@ PROTOTYPES = {
     "pgnn_debug_aggregate_profile": (_i, [_p, _i64]),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class GinLayer(ctypes.Structure):

@@ -1,9 +1,10 @@
 """Attention-flavoured parts of the class surface: GATConv message passing, GlobalAttention and
 Set2Set pooling.  Not on the north-star hot path (GIN / GCN), but native since round 2:
 
-* chem GATConv runs on csrc/attention.hip (``ops.GATAggregate``: CSR edge soft-max + weighted aggregate, two heads,
-  deterministic); the bio GATConv -- whose edge term is a dense ``Linear(9, 2D)`` of per-edge float attributes --
-  keeps the composition of torch GPU ops below (``gat_propagate``), like the reference's own torch_geometric path;
+* the chem and the bio GATConv with the reference's default two heads run on csrc/attention.hip (``ops.GATAggregate`` /
+  ``ops.BioGATAggregate``: CSR edge soft-max + weighted aggregate, deterministic; for bio the ``Linear(9, 2D)`` edge term is
+  folded into per-node feature sums, the [E, 2D] edge embedding is never formed).  ``gat_propagate`` below, a composition of
+  torch GPU ops like the reference's own torch_geometric path, is what both classes fall back to for ``heads != 2`` only;
 * GlobalAttention / Set2Set take their soft-max from ``ops.segment_softmax`` (pgnn_segment_softmax_*) and their
   weighted sums from the deterministic segment-sum kernel (``ops.global_add_pool``).
 """
@@ -16,7 +17,7 @@ from . import ops
 def segment_softmax(src, index, num_segments):
     """torch_geometric.utils.softmax (1.0.3): per segment subtract the max, exp, divide by sum + 1e-16.  The pinned
     torch_scatter 1.1.2 pre-fills scatter_max's output with 0, i.e. the shift is max(0, segment max) -- reproduced.
-    (torch-op form, used by the bio GATConv only.)"""
+    (torch-op form, used by ``gat_propagate``, the heads != 2 fallback, only.)"""
     idx = index.view(-1, *([1] * (src.dim() - 1))).expand_as(src)
     mx = torch.zeros((num_segments,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
     mx = mx.scatter_reduce(0, idx, src, reduce="amax", include_self=True)

@@ -873,23 +873,34 @@ template <int R>
 __global__ void __launch_bounds__(kBlock)
 k_segsum_chunks(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ ptr,
                 const int32_t* __restrict__ perm, int n_items, int n_seg, int mean,
-                float* __restrict__ out, int64_t ldo, float* __restrict__ partial, int dim) {
+                float* __restrict__ out, int64_t ldo, float* __restrict__ partial, int dim, int ptr_in_lds) {
   const int lane = lane_id(), d4 = dim >> 2;
   const int chunk = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  const int p0 = chunk * kSegChunk;
-  if (p0 >= n_items) return;
+  const int p0 = min(chunk * kSegChunk, max(n_items - 1, 0));  // a wave past the end still takes part in the block's table load
+  const bool idle = chunk * kSegChunk >= n_items;
   const int cnt = min(kSegChunk, n_items - p0);
   const int item = lane < cnt ? (perm ? perm[p0 + lane] : p0 + lane) : 0;
-  // segment of the chunk's first position: largest s with ptr[s] <= p0 (binary search, uniform)
+  // segment of every position of the chunk: largest s with ptr[s] <= position (with empty segments ptr repeats and the
+  // largest such s is the non-empty one).  Each lane searches for its own position, so a chunk that crosses dozens of
+  // empty segments (the pair-type segments of the atom-embedding gradient: 360 segments, ~40 populated) pays one search,
+  // not one dependent load per empty segment; a short table is searched in LDS.
+  extern __shared__ int32_t s_ptr[];
+  const int32_t* P = ptr;
+  if (ptr_in_lds) {
+    for (int q = threadIdx.x; q <= n_seg; q += kBlock) s_ptr[q] = ptr[q];
+    __syncthreads();
+    P = s_ptr;
+  }
+  const int pos = p0 + (lane < cnt ? lane : 0);
   int lo = 0, hi = n_seg;
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
-    if (ptr[mid] <= p0) lo = mid; else hi = mid;
+    if (P[mid] <= pos) lo = mid; else hi = mid;
   }
-  int seg = lo;
-  int seg_end = ptr[seg + 1];
-  while (seg_end <= p0) { ++seg; seg_end = ptr[seg + 1]; }  // skip empty segments
-  int seg_beg = ptr[seg];
+  if (idle) return;
+  const int seg_of = lo;
+  int seg = bcast_i32(seg_of, 0);
+  int seg_beg = P[seg], seg_end = P[seg + 1];
   Row<R> acc;
   row_zero<R>(acc);
   int j = 0;
@@ -921,7 +932,9 @@ k_segsum_chunks(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
     }
     row_zero<R>(acc);
     if (j < cnt) {
-      do { ++seg; seg_beg = seg_end; seg_end = ptr[seg + 1]; } while (seg_end <= seg_beg);
+      seg = bcast_i32(seg_of, j);
+      seg_beg = P[seg];
+      seg_end = P[seg + 1];
     }
   }
 }
@@ -1211,7 +1224,7 @@ int pgnn_rowfeat_matmul_bwd(const float* cfeat, int64_t kc, const float* g, int6
                             int64_t ldgt, int64_t n, int64_t dim, void* ws, size_t ws_bytes,
                             pgnn_stream stream) {
   if (int rc = check_dim(dim)) return rc;
-  PGNN_REQUIRE(n > 0 && (kc == 2 || kc == 9 || kc == 10) && ldg % 4 == 0, "rowfeat_matmul_bwd supports kc in {2,9,10}");
+  PGNN_REQUIRE(n > 0 && (kc == 2 || kc == 4 || kc == 7 || kc == 9 || kc == 10) && ldg % 4 == 0, "rowfeat_matmul_bwd supports kc in {2,4,7,9,10}");
   if (ws_bytes < pgnn_rowfeat_matmul_bwd_workspace_bytes(n, kc, dim)) {
     set_error("rowfeat_matmul_bwd workspace too small");
     return PGNN_ERR_WORKSPACE;
@@ -1229,6 +1242,16 @@ int pgnn_rowfeat_matmul_bwd(const float* cfeat, int64_t kc, const float* g, int6
     PGNN_DISPATCH_R(R, {
       allow_big_lds((const void*)k_rowfeat_bwd_partial<RR, 2>, lds);
       hipLaunchKernelGGL((k_rowfeat_bwd_partial<RR, 2>), dim3(nb), dim3(kBlock), lds, st, cfeat, g, ldg, partial, (int)n, (int)dim);
+    });
+  } else if (kc == 4) {
+    PGNN_DISPATCH_R(R, {
+      allow_big_lds((const void*)k_rowfeat_bwd_partial<RR, 4>, lds);
+      hipLaunchKernelGGL((k_rowfeat_bwd_partial<RR, 4>), dim3(nb), dim3(kBlock), lds, st, cfeat, g, ldg, partial, (int)n, (int)dim);
+    });
+  } else if (kc == 7) {
+    PGNN_DISPATCH_R(R, {
+      allow_big_lds((const void*)k_rowfeat_bwd_partial<RR, 7>, lds);
+      hipLaunchKernelGGL((k_rowfeat_bwd_partial<RR, 7>), dim3(nb), dim3(kBlock), lds, st, cfeat, g, ldg, partial, (int)n, (int)dim);
     });
   } else if (kc == 9) {
     PGNN_DISPATCH_R(R, {
@@ -1279,9 +1302,10 @@ int pgnn_segment_sum(const float* x, int64_t ldx, const int32_t* ptr, const int3
   float* partial = static_cast<float*>(ws);
   const int nchunks = (int)ceil_div(n_items, kSegChunk);
   if (nchunks > 0) {
+    const int in_lds = n_segments + 1 <= 4096;
     PGNN_DISPATCH_R(R, hipLaunchKernelGGL((k_segsum_chunks<RR>), dim3((int)ceil_div(nchunks, kWavesPerBlock)),
-                                          dim3(kBlock), 0, st, x, ldx, ptr, perm, (int)n_items, (int)n_segments,
-                                          mean, out, ldo, partial, (int)dim));
+                                          dim3(kBlock), in_lds ? (size_t)(n_segments + 1) * sizeof(int32_t) : 0, st, x, ldx, ptr,
+                                          perm, (int)n_items, (int)n_segments, mean, out, ldo, partial, (int)dim, in_lds));
   }
   if (segsum_two_level(n_items, n_segments)) {
     float* partial2 = partial + align_up((size_t)nchunks * 2 * dim * sizeof(float), 256) / sizeof(float);

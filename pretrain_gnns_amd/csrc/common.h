@@ -148,6 +148,34 @@ __device__ __forceinline__ float4 f4_scale(float4 a, float s) {
 }
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// Results one block publishes and ANOTHER block of the same launch reads: agent-scope accesses -- write-through stores, loads that
+// bypass the non-coherent caches (sc1).  The alternative, __threadfence() around the arrival ticket, is a write-back of the XCD's
+// whole L2 (buffer_wbl2 sc1) per block: ~0.4 us each and serialized per XCD -- the 1 820 blocks of the Adam launch spent 88 of
+// their 91 us in them, the 253 blocks of the masking head 12 of 27 us.
+template <typename T>
+__device__ __forceinline__ void publish(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ T fetch_published(const T* p) { return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// "The last block to finish folds everybody's partial results": called by ONE thread of every block, behind a __syncthreads()
+// that follows the block's publish() stores (every wave has then waited for its own stores); true in exactly one block, which may
+// then read every block's results with fetch_published().  No cache maintenance (see above).  Same-address device-scope atomics
+// retire at ~50 ns each, so a block first takes a ticket in one of up to 32 group words and only the last of each group takes one
+// in the top word.  words: PGNN_TICKET_WORDS uint32, zero before the launch, left zero.
+constexpr unsigned kTicketGroups = 32;
+__device__ __forceinline__ bool arrive_last(unsigned* words) {
+  const unsigned nb = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+  const unsigned G = nb < kTicketGroups ? nb : kTicketGroups, g = b % G;
+  const unsigned size = nb / G + (g < nb % G ? 1u : 0u);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt only: this thread's stores are done, nothing moves below
+  if (__hip_atomic_fetch_add(words + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != size - 1u) return false;
+  publish(words + 1 + g, 0u);
+  if (__hip_atomic_fetch_add(words, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != G - 1u) return false;
+  publish(words, 0u);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return true;
+}
+
 // Second-pass reduction helper: 16 lanes share one output column; lane s sums the partials
 // b = s, s+16, ... in double, then an xor-butterfly combines the 16 slices (every lane ends with the
 // same bits: fixed association order => deterministic).  Call with all 16 lanes of the group active.

@@ -93,23 +93,20 @@ __global__ void __launch_bounds__(kCtxThreads) k_ctx_scores(const float* __restr
       for (int k = 0; k <= neg; ++k) red[k][t] += red[k][t + h];
     __syncthreads();
   }
-  if (t <= neg) scores[(int64_t)t * B + g] = red[t][0];
-  if (t == 0) {
-    __threadfence();
-    last = atomicAdd(counter, 1u) == gridDim.x - 1;
-  }
+  if (t <= neg) publish(scores + (int64_t)t * B + g, red[t][0]);  // (read by the last block: agent-scope, see common.h)
+  __syncthreads();  // (the score stores of threads 1..neg are behind this block's arrival)
+  if (t == 0) last = arrive_last(counter);
   __syncthreads();
   if (!last) return;
-  __threadfence();
   double lp = 0.0, ln = 0.0;
   int hp = 0, hn = 0;
   for (int q = t; q < B; q += kCtxThreads) {
-    const float x = __builtin_nontemporal_load(scores + q);  // (written by other blocks: bypass this CU's L1)
+    const float x = fetch_published(scores + q);
     lp += bce_logits((double)x, 1.0);
     hp += x > 0.f ? 1 : 0;
   }
   for (int q = t; q < neg * B; q += kCtxThreads) {
-    const float x = __builtin_nontemporal_load(scores + B + q);
+    const float x = fetch_published(scores + B + q);
     ln += bce_logits((double)x, 0.0);
     hn += x < 0.f ? 1 : 0;
   }
@@ -132,7 +129,6 @@ __global__ void __launch_bounds__(kCtxThreads) k_ctx_scores(const float* __restr
       accum[1] += 0.5 * (fp + fn);
       accum[3] += 1.0;
     }
-    *counter = 0;
   }
 }
 

@@ -116,23 +116,19 @@ __global__ void __launch_bounds__(kHeadThreads * kHeadSlices) k_head_fwd(const f
       const bool yok = y >= 0 && y < classes;
       if (!yok) atomicAdd(status, 1);
       const double zy = yok ? (double)logits[(int64_t)(r0 + i) * classes + y] : 0.0;  // written by thread y of this block, before the syncs
-      row_nll[r0 + i] = log(red[0]) + zmax - zy;
-      row_hit[r0 + i] = (yok && arg == (int)y) ? 1 : 0;
+      publish(row_nll + r0 + i, log(red[0]) + zmax - zy);  // (read by the last block: agent-scope, see common.h)
+      publish(row_hit + r0 + i, (yok && arg == (int)y) ? 1 : 0);
     }
     __syncthreads();
   }
-  if (c == 0) {
-    __threadfence();
-    last = atomicAdd(counter, 1u) == gridDim.x - 1;
-  }
+  if (c == 0) last = arrive_last(counter);
   __syncthreads();
   if (!last) return;
-  __threadfence();
   double s = 0.0;
   int hits = 0;
   for (int q = c; q < m; q += kHeadThreads) {  // per-thread strided partials, then a fixed tree: the same order every run
-    s += row_nll[q];
-    hits += row_hit[q];
+    s += fetch_published(row_nll + q);
+    hits += fetch_published(row_hit + q);
   }
   red[c] = s;
   redi[c] = hits;
@@ -157,7 +153,6 @@ __global__ void __launch_bounds__(kHeadThreads * kHeadSlices) k_head_fwd(const f
       accum[1] += (double)redi[0] / (double)m;
       accum[3] += 1.0;
     }
-    *counter = 0;
   }
 }
 
@@ -333,7 +328,7 @@ int pgnn_masked_head_fwd(const float* h, int64_t ldh, int64_t n_rows, const int6
   double* row_nll = cv.take<double>((size_t)m);
   int* row_hit = cv.take<int>((size_t)m);
   cv.take<unsigned>(64);
-  PGNN_REQUIRE(counter != nullptr, "masked_head: counter (one zeroed uint32 that the call leaves zeroed) is required");
+  PGNN_REQUIRE(counter != nullptr, "masked_head: counter (PGNN_TICKET_WORDS zeroed uint32 that the call leaves zeroed) is required");
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = (size_t)kHeadRows * dim * sizeof(float);
   allow_big_lds((const void*)k_head_fwd, lds);

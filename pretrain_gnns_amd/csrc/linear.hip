@@ -938,6 +938,8 @@ int launch_gemm3w(const GemmArgs& p, hipStream_t st) {
     case 0: return launch_gemm3w_s<128, 160, 8, 1, 3, EPI>(p, st);
     case 2: return launch_gemm3w_s<64, 160, 4, 2, 3, EPI>(p, st);
     case 3: return launch_gemm3w_s<128, 160, 4, 2, 3, EPI>(p, st);
+    case 4: return launch_gemm3w_s<64, 80, 4, 1, 3, EPI>(p, st);   // 71 KB of LDS, four waves: two workgroups share a CU
+    case 5: return launch_gemm3w_s<128, 80, 8, 1, 3, EPI>(p, st);  // 94 KB: one per CU, 16 x 80 wave tiles
     default: return launch_gemm3w_s<64, 160, 4, 2, 4, EPI>(p, st);
   }
 }
@@ -1319,6 +1321,7 @@ int pgnn_debug_gemm3w_profile(const float* x, int64_t ldx, const void* wplanes, 
   hipStream_t st = (hipStream_t)stream;
   switch (cfg) {
     case 0: return launch_gemm3w_s<128, 160, 8, 1, 3, EPI_BIAS, false, true>(p, st);
+    case 4: return launch_gemm3w_s<64, 80, 4, 1, 3, EPI_BIAS, false, true>(p, st);
     default: return launch_gemm3w_s<64, 160, 4, 2, 4, EPI_BIAS, false, true>(p, st);
   }
 }

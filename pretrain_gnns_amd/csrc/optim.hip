@@ -10,7 +10,7 @@ namespace pgnn {
 namespace {
 
 constexpr int kAdamMaxTensors = 96;
-constexpr int kAdamChunk = 4096;  // elements per block
+constexpr int kAdamChunk = 1024;  // elements per block: one float4 per thread, so a block is ONE round trip to memory (four serial ones at 4096 made the launch 34 us for 1.9 M parameters)
 
 struct AdamJobs {
   float* p[kAdamMaxTensors];
@@ -22,20 +22,33 @@ struct AdamJobs {
 };
 
 __global__ void __launch_bounds__(256) k_adam(AdamJobs jobs, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
-                                              int64_t* step /*[2]: updates applied, arrival ticket*/, float lr, float beta1,
+                                              int64_t* step /*[32]: updates applied, -, cached beta powers (see below), arrival tickets from word 8*/, float lr, float beta1,
                                               float beta2, float eps, float weight_decay) {
-  // tensor of this block: the table is tiny, a linear scan by one lane is cheaper than anything clever
-  __shared__ int js;
-  if (threadIdx.x == 0) {
-    int j = 0;
-    while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.first[j + 1]) ++j;
-    js = j;
+  // tensor of this block: largest j with first[j] <= blockIdx.x (uniform bisection over the kernel arguments: 7 dependent
+  // scalar loads; the linear scan cost the blocks of the last tensors ~50)
+  int j = 0;
+  {
+    int hi = jobs.n;
+    while (hi - j > 1) {
+      const int mid = (j + hi) >> 1;
+      if (jobs.first[mid] <= (int)blockIdx.x) j = mid; else hi = mid;
+    }
   }
-  __syncthreads();
-  const int j = js;
-  const double t = (double)(*step + 1);
-  const float step_size = (float)((double)lr / (1.0 - pow((double)beta1, t)));
-  const float inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)beta2, t)));
+  // beta^t: two float64 pow() per wave were most of this launch once a block was a single round trip (93 us for 7 280 waves).  The
+  // powers of the PREVIOUS update are kept next to the step count (words 2..6: beta1^s, beta2^s, the betas they belong to, s) and
+  // advanced by one multiplication; pow() runs only when they do not match (first update, changed betas, a restored step count).
+  const int64_t s0 = *step;
+  const double* pw = reinterpret_cast<const double*>(step + 2);
+  double b1t, b2t;
+  if (s0 > 0 && step[6] == s0 && pw[2] == (double)beta1 && pw[3] == (double)beta2) {
+    b1t = pw[0] * (double)beta1;
+    b2t = pw[1] * (double)beta2;
+  } else {
+    b1t = pow((double)beta1, (double)(s0 + 1));
+    b2t = pow((double)beta2, (double)(s0 + 1));
+  }
+  const float step_size = (float)((double)lr / (1.0 - b1t));
+  const float inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - b2t));
   const int base = ((int)blockIdx.x - jobs.first[j]) * kAdamChunk;
   const int end = min(jobs.count[j], base + kAdamChunk);
   float* __restrict__ p = jobs.p[j];
@@ -73,16 +86,17 @@ __global__ void __launch_bounds__(256) k_adam(AdamJobs jobs, float* __restrict__
       p[i] = pn;
     }
   }
-  // every thread of every block has read step[0] before its block takes a ticket, so the holder of the last ticket may advance it
-  // (a separate one-thread launch for this cost 6 us of a 1.4 ms train step)
+  // every thread of every block has read step[0] and the cached powers before its block arrives, so the last block to arrive may
+  // advance them (a separate one-thread launch for this cost 6 us of a 1.4 ms train step)
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(step + 1);
-    if (atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1ull) {
-      step[0] += 1;
-      *ticket = 0ull;
-    }
+  if (threadIdx.x == 0 && arrive_last(reinterpret_cast<unsigned*>(step + 8))) {
+    double* pwo = reinterpret_cast<double*>(step + 2);
+    pwo[0] = b1t;
+    pwo[1] = b2t;
+    pwo[2] = (double)beta1;
+    pwo[3] = (double)beta2;
+    step[6] = s0 + 1;
+    step[0] = s0 + 1;
   }
 }
 

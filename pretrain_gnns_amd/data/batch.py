@@ -3,7 +3,7 @@ reference's ``Batch*`` classes (chem/batch.py:4-52,124-228; bio/batch.py:58-121)
 
 Only what the hot path and the reference ``train()`` bodies touch is provided:
 attribute access, ``keys``, ``to(device)``, ``contiguous()``, ``num_nodes`` and
-``num_graphs``.  The collate functions that fill it live in ``synthetic.py``.
+``num_graphs``.  The device-side collate that fills it is ``resident.py`` (csrc/loader.hip); the host restatement is ``oracle/hostdata.py``.
 """
 import torch
 

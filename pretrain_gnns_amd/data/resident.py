@@ -9,7 +9,7 @@ it on the GPU in the concatenated ``(data, slices)`` layout ``InMemoryDataset`` 
 ``slices``) and builds every batch with the kernels of csrc/loader.hip from a list of graph ids.
 The host keeps only the two slice vectors (to size outputs without a device sync) and the sampler.
 
-Output batches have the field layout of ``BatchMasking`` / the synthetic collate in this package
+Output batches have the field layout of the reference's ``BatchMasking`` (restated on the host in oracle/hostdata.py)
 (x, edge_index, edge_attr, batch, masked_atom_indices, mask_node_label, [connected_edge_indices,
 mask_edge_label]; bio: masked_edge_idx, mask_edge_label), so ``train.chem_masking_step`` /
 ``train.bio_masking_step`` consume them unchanged.

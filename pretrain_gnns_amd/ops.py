@@ -833,11 +833,11 @@ _head_words = {}
 
 
 def _head_state(dev):
-    """[status, arrival counter]: two int32 words per device, zeroed once (the kernel leaves the counter at zero)"""
+    """[status, -, arrival tickets (PGNN_TICKET_WORDS)]: int32 words per device, zeroed once (the kernels leave the tickets at zero)"""
     key = (dev.type, dev.index)
     t = _head_words.get(key)
     if t is None:
-        t = _head_words[key] = torch.zeros(2, dtype=torch.int32, device=dev)
+        t = _head_words[key] = torch.zeros(64, dtype=torch.int32, device=dev)
     return t
 
 
@@ -871,7 +871,7 @@ class MaskedHead(Function):
         check(load().pgnn_masked_head_fwd(h.data_ptr(), h.stride(0), n, idx.data_ptr(), m, w.data_ptr(),
                                           b.data_ptr() if b is not None else None, label.data_ptr(), label.stride(0), classes, dim,
                                           logits.data_ptr(), loss.data_ptr(), correct.data_ptr(), metrics.data_ptr(),
-                                          accum.data_ptr() if accum is not None else None, words.data_ptr(), words.data_ptr() + 4, ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_masked_head_fwd")
+                                          accum.data_ptr() if accum is not None else None, words.data_ptr(), words.data_ptr() + 8, ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_masked_head_fwd")
         if _CHECK_INDICES:
             if int(words[0].item()):
                 words[0] = 0
@@ -911,6 +911,90 @@ def masked_head(node_rep, idx, linear, label, with_metrics=False, accum=None):
     return (loss, correct, metrics) if with_metrics else (loss, correct)
 
 
+class EdgeHead(Function):
+    """linear(node_rep[u] + node_rep[v]) -> CrossEntropyLoss()(pred, label) and the number of correct arg-maxes over the masked
+    edges (bio/pretrain_masking.py:45-58; chem/pretrain_masking.py:60-66), csrc/edgehead.hip.  ``ends`` int64 [2, m] =
+    ``edge_index[:, masked_idx]``; ``label`` int64 [m] or a float [m, classes] matrix whose first row maximum is the label
+    (``torch.argmax(mask_edge_label, 1)``).  ``float64``: the loss in float64 (chem's ``pred.double()``) or fp32 (bio).
+    Returns (loss [] in that dtype, correct int64 [], logits fp32 [m, classes], metrics float64 [2] = (loss, correct)); only
+    ``loss`` carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, node_rep, ends, weight, bias, label, float64=False, accum=None, accum_slot=2, accum_step=True):
+        require_cuda(node_rep, ends, weight, label)
+        ctx.set_materialize_grads(False)
+        if accum is not None and (accum.dtype != torch.float64 or accum.numel() < 4 or not accum.is_contiguous() or accum.device != node_rep.device):
+            raise _lib.PgnnError("edge head: accum must be a contiguous float64 [4] tensor on the device of node_rep")
+        h = _rows2d(node_rep)
+        n, dim = h.shape
+        classes = weight.size(0)
+        if ends.dtype != torch.int64 or ends.dim() != 2 or ends.size(0) != 2 or ends.size(1) == 0 or weight.size(1) != dim:
+            raise _lib.PgnnError("edge head: ends must be int64 [2, m] with m > 0, weight [classes, dim]")
+        m = ends.size(1)
+        ends = ends.contiguous()
+        onehot = label.dtype != torch.int64
+        if onehot:
+            if label.dtype != torch.float32 or label.dim() != 2 or label.size(0) != m or label.size(1) < classes or label.stride(1) != 1:
+                raise _lib.PgnnError("edge head: a float label must be [m, >= classes] fp32 with contiguous rows")
+        elif label.dim() != 1 or label.size(0) != m:
+            raise _lib.PgnnError("edge head: an int64 label must be [m]")
+        w = _f32c(weight)
+        b = _f32c(bias) if bias is not None else None
+        dev = h.device
+        logits = torch.empty(m, classes, dtype=torch.float32, device=dev)
+        loss64 = torch.empty((), dtype=torch.float64, device=dev)
+        loss32 = None if float64 else torch.empty((), dtype=torch.float32, device=dev)
+        correct = torch.empty((), dtype=torch.int64, device=dev)
+        metrics = torch.empty(2, dtype=torch.float64, device=dev)
+        words = _head_state(dev)
+        ws = torch.empty(_ws_bytes("pgnn_edge_head_workspace_bytes", n, m, classes, dim), dtype=torch.uint8, device=dev)
+        check(load().pgnn_edge_head_fwd(h.data_ptr(), h.stride(0), n, ends.data_ptr(), m, w.data_ptr(), b.data_ptr() if b is not None else None,
+                                        None if onehot else label.data_ptr(), 0 if onehot else label.stride(0),
+                                        label.data_ptr() if onehot else None, label.stride(0) if onehot else 0, label.size(1) if onehot else 0,
+                                        classes, dim, 1 if float64 else 0, logits.data_ptr(), loss64.data_ptr(), loss32.data_ptr() if loss32 is not None else None,
+                                        correct.data_ptr(), metrics.data_ptr(), accum.data_ptr() if accum is not None else None, int(accum_slot),
+                                        1 if accum_step else 0, words.data_ptr(), words.data_ptr() + 8, ws.data_ptr(), ws.numel(), stream_ptr()),
+              "pgnn_edge_head_fwd")
+        if _CHECK_INDICES and int(words[0].item()):
+            words[0] = 0
+            raise IndexError("edge head: end point or label out of range")
+        ctx.save_for_backward(h, ends, w, label, logits)
+        ctx.ws, ctx.has_bias, ctx.float64 = ws, bias is not None, bool(float64)
+        loss = loss64 if float64 else loss32
+        ctx.mark_non_differentiable(correct, logits, metrics)
+        return loss, correct, logits, metrics
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gloss, _gc, _gl, _gm):
+        if gloss is None:
+            return (None,) * 9
+        h, ends, w, label, logits = ctx.saved_tensors
+        n, dim = h.shape
+        m, classes = logits.shape
+        dev = h.device
+        onehot = label.dtype != torch.int64
+        g64 = gloss.dtype == torch.float64
+        gloss = gloss.contiguous() if g64 else gloss.to(torch.float32).contiguous()
+        dnode = torch.empty(n, dim, dtype=torch.float32, device=dev)
+        dw = torch.empty(classes, dim, dtype=torch.float32, device=dev)
+        db = torch.empty(classes, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        words = _head_state(dev)
+        check(load().pgnn_edge_head_bwd(h.data_ptr(), h.stride(0), n, ends.data_ptr(), m, w.data_ptr(),
+                                        None if onehot else label.data_ptr(), 0 if onehot else label.stride(0),
+                                        label.data_ptr() if onehot else None, label.stride(0) if onehot else 0, label.size(1) if onehot else 0, logits.data_ptr(),
+                                        gloss.data_ptr() if g64 else None, None if g64 else gloss.data_ptr(), classes, dim,
+                                        1 if ctx.float64 else 0, dnode.data_ptr(), dim, dw.data_ptr(), db.data_ptr() if db is not None else None,
+                                        words.data_ptr() + 8, ctx.ws.data_ptr(), ctx.ws.numel(), stream_ptr()), "pgnn_edge_head_bwd")
+        return dnode, None, dw, db, None, None, None, None, None
+
+
+def edge_head(node_rep, ends, linear, label, float64=False, accum=None, accum_slot=2, accum_step=True):
+    """(loss, correct, metrics) of ``linear(node_rep[ends[0]] + node_rep[ends[1]])`` against ``label`` -- see EdgeHead"""
+    loss, correct, _, metrics = EdgeHead.apply(node_rep, ends, linear.weight, linear.bias, label, float64, accum, accum_slot, accum_step)
+    return loss, correct, metrics
+
+
 # ------------------------------------------------------------------------------------ context-prediction loss
 class ContextPredLoss(Function):
     """chem/pretrain_contextpred.py:54-67,86-97 (cbow, mean context pooling) on the two networks' node embeddings, two launches:
@@ -937,7 +1021,7 @@ class ContextPredLoss(Function):
         check(load().pgnn_contextpred_loss_fwd(hs.data_ptr(), hs.stride(0), hs.size(0), center.data_ptr(), hc.data_ptr(), hc.stride(0), hc.size(0),
                                                overlap.data_ptr(), seg.data_ptr(), overlap.numel(), B, dim, int(neg_samples), vals.data_ptr(),
                                                loss.data_ptr(), accum.data_ptr() if accum is not None else None, words.data_ptr(),
-                                               words.data_ptr() + 4, ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_contextpred_loss_fwd")
+                                               words.data_ptr() + 8, ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_contextpred_loss_fwd")
         if _CHECK_INDICES and int(words[0].item()):
             words[0] = 0
             raise IndexError("contextpred loss: row index out of range")

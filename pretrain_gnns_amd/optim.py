@@ -48,7 +48,7 @@ class _Core:
         self.offsets = offs
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.step_words = torch.zeros(2, dtype=torch.int64, device=dev)  # updates applied, the kernel's arrival counter
+        self.step_words = torch.zeros(32, dtype=torch.int64, device=dev)  # updates applied, the kernel's cache of beta^step, its arrival tickets
         self.step_count = self.step_words[0]
         self.max_tensors = int(load().pgnn_adam_max_tensors())
         self.waiting = 0  # handles that still have to call step() before the shared launch goes out

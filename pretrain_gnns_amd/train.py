@@ -21,6 +21,13 @@ def _fusable_head(linear, node_rep):
             and linear.in_features % 4 == 0 and linear.in_features <= 2048)
 
 
+def _fusable_edge_head(linear, node_rep, label):
+    """plain nn.Linear onto 4 (bond types) or 7 (PPI edge types) classes on the GPU: the edge head of csrc/edgehead.hip applies"""
+    return (type(linear) is torch.nn.Linear and node_rep.is_cuda and node_rep.dtype == torch.float32 and linear.out_features in (4, 7)
+            and linear.in_features % 4 == 0 and linear.in_features <= 1024 and label.numel() > 0
+            and (label.dtype == torch.int64 or (label.dtype == torch.float32 and label.dim() == 2 and label.size(1) >= linear.out_features)))
+
+
 def _correct(pred, target):
     """numerator of compute_accuracy, left on the device"""
     return torch.sum(torch.max(pred.detach(), dim=1)[1] == target)
@@ -219,6 +226,20 @@ def bio_masking_step(model_list, optimizer_list, batch, readback="end", accum=No
     model, linear_pred_edges = model_list
     node_rep = model(batch.x, batch.edge_index, batch.edge_attr)
     masked_edge_index = batch.edge_index[:, batch.masked_edge_idx]
+    if readback != "inline" and _fusable_edge_head(linear_pred_edges, node_rep, batch.mask_edge_label):
+        # the statements below as two launches forward / ten backward on [*, 7]-wide data (ops.EdgeHead: fp32 soft-max and loss as here)
+        deferred = readback == "epoch"
+        loss, correct, packed = ops.edge_head(node_rep, masked_edge_index, linear_pred_edges, batch.mask_edge_label,
+                                              accum=accum if deferred else None, accum_slot=2)
+        for opt in optimizer_list:
+            opt.zero_grad()
+        loss.backward(_unit_grad(loss))
+        for opt in optimizer_list:
+            opt.step()
+        if deferred:
+            return None
+        vals = packed.cpu().tolist()
+        return vals[0], vals[1] / masked_edge_index.size(1)
     edge_rep = node_rep[masked_edge_index[0]] + node_rep[masked_edge_index[1]]
     pred_edge = linear_pred_edges(edge_rep)
     edge_label = torch.argmax(batch.mask_edge_label, dim=1)

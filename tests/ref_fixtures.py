@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 from pretrain_gnns_amd.data import synthetic
+from oracle import hostdata
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 _cache = {}
@@ -118,15 +119,15 @@ def check_params(named, tree, what, rtol, norm_rtol=None):
 
 
 # ----------------------------------------------------------------------------- rebuilding the reference's inputs
-def masked_batches(fx, tag, mask_edge, collate=synthetic.collate):
+def masked_batches(fx, tag, mask_edge, collate=hostdata.collate):
     """rebuild the batches the reference's loader produced: raw graphs + the stored per-graph atom choices through
-    the HOST restatements (synthetic.mask_atoms semantics with explicit indices, synthetic.collate)"""
+    the HOST restatements (hostdata.mask_atoms semantics with explicit indices, hostdata.collate)"""
     raw = raw_graphs(fx["raw"])
     counts, local = fx[tag]["mask_counts"].tolist(), fx[tag]["mask_local"]
     graphs, pos = [], 0
     for g, k in zip(raw, counts):
         d = synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr)
-        graphs.append(synthetic.mask_atoms_at(d, local[pos:pos + k], mask_edge=mask_edge))
+        graphs.append(hostdata.mask_atoms_at(d, local[pos:pos + k], mask_edge=mask_edge))
         pos += k
     bs = int(fx["batch_size"])
     return [collate(graphs[i:i + bs]) for i in range(0, len(graphs), bs)]
@@ -134,13 +135,13 @@ def masked_batches(fx, tag, mask_edge, collate=synthetic.collate):
 
 def context_graphs(fx, k=5, l1=4, l2=7):
     raw = raw_graphs(fx["raw"])
-    return [synthetic.extract_substruct_context(synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr), None, k, l1, l2,
+    return [hostdata.extract_substruct_context(synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr), None, k, l1, l2,
                                                 root=int(r)) for g, r in zip(raw, fx["roots"].tolist())]
 
 
 def bfs(fx, i):
     g = raw_graphs(fx["raw"])[i]
-    d = synthetic._bfs_dist(g.x.size(0), g.edge_index.numpy(), int(fx["roots"][i]))
+    d = hostdata._bfs_dist(g.x.size(0), g.edge_index.numpy(), int(fx["roots"][i]))
     return np.where(d < 0, 10 ** 6, d)
 
 
@@ -176,10 +177,10 @@ def bio_batches(fx):
     graphs, pos = [], 0
     for g, k in zip(raw, counts):
         d = synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr, center_node_idx=g.center_node_idx)
-        graphs.append(synthetic.mask_edges_at(d, local[pos:pos + k]))
+        graphs.append(hostdata.mask_edges_at(d, local[pos:pos + k]))
         pos += k
     bs = int(fx["batch_size"])
-    return [synthetic.collate(graphs[i:i + bs], shift_center=False) for i in range(0, len(graphs), bs)]
+    return [hostdata.collate(graphs[i:i + bs], shift_center=False) for i in range(0, len(graphs), bs)]
 
 
 def assert_same_bio_context(fx, raw, graphs, want):
@@ -213,14 +214,14 @@ def edgepred_batches(fx):
         neg = ragged(fx["neg"], i).reshape(-1, 2).t().contiguous()
         graphs.append(synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr, negative_edge_index=neg))
     bs = int(fx["batch_size"])
-    return [synthetic.collate(graphs[i:i + bs]) for i in range(0, len(graphs), bs)]
+    return [hostdata.collate(graphs[i:i + bs]) for i in range(0, len(graphs), bs)]
 
 
 def plain_batches(fx):
     raw = raw_graphs(fx["raw"])
     graphs = [synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr) for g in raw]
     bs = int(fx["batch_size"])
-    return [synthetic.collate(graphs[i:i + bs]) for i in range(0, len(graphs), bs)]
+    return [hostdata.collate(graphs[i:i + bs]) for i in range(0, len(graphs), bs)]
 
 
 def bio_finetune_batches(fx):
@@ -229,4 +230,4 @@ def bio_finetune_batches(fx):
     graphs = [synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr, center_node_idx=g.center_node_idx, go_target_downstream=y)
               for g, y in zip(raw, fx["y"])]
     bs = int(fx["batch_size"])
-    return [synthetic.collate(graphs[i:i + bs], shift_center=True) for i in range(0, len(graphs), bs)]
+    return [hostdata.collate(graphs[i:i + bs], shift_center=True) for i in range(0, len(graphs), bs)]

@@ -34,6 +34,7 @@ def _worker(rank, world, port, out_dir):
     import numpy as np
     from oracle import chem as ochem
     from pretrain_gnns_amd.data import synthetic
+    from oracle import hostdata
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
@@ -47,10 +48,10 @@ def _worker(rank, world, port, out_dir):
     model.eval()
 
     rng = np.random.default_rng(7)
-    graphs = [synthetic.mask_atoms(synthetic.zinc_like_graph(rng), rng) for _ in range(9)]
+    graphs = [hostdata.mask_atoms(synthetic.zinc_like_graph(rng), rng) for _ in range(9)]
     mine = [graphs[i] for i in parallel.shard_graphs(len(graphs), rank, world)]
-    local = synthetic.collate(mine)
-    whole = synthetic.collate(graphs)
+    local = hostdata.collate(mine)
+    whole = hostdata.collate(graphs)
 
     opts = [torch.optim.SGD(model.parameters(), lr=0.1), torch.optim.SGD(head.parameters(), lr=0.1)]
     dp = parallel.AllReduceOptimizers(opts, weight_fn=lambda: 1.0)  # losses are sums -> plain sum of grads
@@ -118,6 +119,7 @@ def _exact_worker(rank, world, port, out_dir):
     import numpy as np
     from oracle import chem as ochem
     from pretrain_gnns_amd.data import synthetic
+    from oracle import hostdata
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     torch.set_num_threads(1)
@@ -130,9 +132,9 @@ def _exact_worker(rank, world, port, out_dir):
     parallel.use_exact_batchnorm(model)
     assert list(model.state_dict()) == list(ref_model.state_dict())
     rng = np.random.default_rng(11)
-    graphs = [synthetic.mask_atoms(synthetic.zinc_like_graph(rng), rng) for _ in range(7)]
-    local = synthetic.collate([graphs[i] for i in parallel.shard_graphs(len(graphs), rank, world)])
-    whole = synthetic.collate(graphs)
+    graphs = [hostdata.mask_atoms(synthetic.zinc_like_graph(rng), rng) for _ in range(7)]
+    local = hostdata.collate([graphs[i] for i in parallel.shard_graphs(len(graphs), rank, world)])
+    whole = hostdata.collate(graphs)
     m_local, m_global = local.masked_atom_indices.numel(), whole.masked_atom_indices.numel()
     opts = [torch.optim.SGD(model.parameters(), lr=0.1), torch.optim.SGD(head.parameters(), lr=0.1)]
     # with statistics shared across ranks the backward of one rank's rows carries terms of EVERY rank's loss, so the

@@ -30,6 +30,7 @@ from oracle import pyg_semantics as pyg
 from oracle import refshim, steps
 from pretrain_gnns_amd import train as ptrain
 from pretrain_gnns_amd.data import synthetic
+from oracle import hostdata
 
 live = pytest.mark.skipif(not refshim.available(), reason="reference sources not present (GPU box)")
 
@@ -157,7 +158,7 @@ def test_spec_molecule_assertions_of_the_reference():
         assert ("mask_edge_label" in d) == me
         assert (d["x"][idx] == torch.tensor([num_atom_type, 0])).all()
         assert (d["mask_node_label"] == mol["x"][idx]).all()
-        mine = synthetic.mask_atoms_at(synthetic.Data(x=mol["x"], edge_index=mol["edge_index"], edge_attr=mol["edge_attr"]),
+        mine = hostdata.mask_atoms_at(synthetic.Data(x=mol["x"], edge_index=mol["edge_index"], edge_attr=mol["edge_attr"]),
                                        torch.tensor(idx), mask_edge=me, atom_token=num_atom_type, bond_token=num_edge_type)
         for k, v in d.items():
             assert torch.equal(getattr(mine, k), v), k
@@ -182,7 +183,7 @@ def test_host_context_transform_equals_reference(name):
     fx = rf.load(name)
     bs = int(fx["batch_size"])
     graphs = rf.context_graphs(fx)
-    got = synthetic.collate_substruct_context(graphs[:bs])
+    got = hostdata.collate_substruct_context(graphs[:bs])
     want = fx["batches"]["0"]
     exact = all(torch.equal(getattr(got, k), v) for k, v in want.items())
     # sizes and the index-free parts are always identical
@@ -245,7 +246,7 @@ def test_contextpred_mirrors_reproduce_reference_train(name, mode, driver):
                 np.testing.assert_allclose(np.array(ret), want["returned"].numpy(), rtol=1e-9)
     graphs = rf.context_graphs(fx)
     ms, mc, os_, oc = fresh()
-    l0, _ = step(ms, mc, os_, oc, synthetic.collate_substruct_context(graphs[:bs]))
+    l0, _ = step(ms, mc, os_, oc, hostdata.collate_substruct_context(graphs[:bs]))
     assert abs(l0 - float(want["loss_pos"][0] + want["loss_neg"][0])) <= 1e-5 * abs(l0)
 
 
@@ -259,7 +260,7 @@ def test_finetune_mirrors_reproduce_reference(pooling):
     graphs = []
     for g, y in zip(raw, fx["y"]):
         graphs.append(synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr, y=y))
-    batches = [synthetic.collate(graphs[i:i + 32]) for i in range(0, len(graphs), 32)]
+    batches = [hostdata.collate(graphs[i:i + 32]) for i in range(0, len(graphs), 32)]
     for driver in ("oracle_steps", "product_mirror"):
         torch.manual_seed(0)
         model = ochem.GNN_graphpred(5, 300, 12, JK="last", drop_ratio=0, graph_pooling=pooling, gnn_type="gin")
@@ -403,13 +404,13 @@ def test_bio_contextpred_equals_reference(name):
     want = fx["cbow"]
     bs, nsteps = int(fx["batch_size"]), int(fx["steps"])
     raw = rf.raw_graphs(fx["raw"], bio=True)
-    graphs = [synthetic.bio_extract_substruct_context(
+    graphs = [hostdata.bio_extract_substruct_context(
         synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr, center_node_idx=g.center_node_idx), l1=1) for g in raw]
     for i, g in enumerate(graphs):
         assert hasattr(g, "x_context") == bool(fx["has_context"][i])
         if hasattr(g, "x_context"):
             assert g.x_context.size(0) == len(rf.ragged(fx["ctx_order"], i))
-    got0 = synthetic.collate_substruct_context(graphs[:bs])
+    got0 = hostdata.collate_substruct_context(graphs[:bs])
     w0 = fx["batches"]["0"]
     for k in ("x_substruct", "edge_index_substruct", "edge_attr_substruct", "center_substruct_idx", "overlapped_context_size",
               "batch_overlapped_context"):
@@ -469,7 +470,7 @@ def test_fixtures_are_what_the_live_reference_produces():
 def test_oracle_equals_live_reference_model(domain, gnn_type):
     ref = refshim.load(domain)
     omod = ochem if domain == "chem" else obio
-    b = synthetic.chem_masking_batch(24, seed=21) if domain == "chem" else synthetic.bio_masking_batch(4, seed=22)
+    b = hostdata.chem_masking_batch(24, seed=21) if domain == "chem" else hostdata.bio_masking_batch(4, seed=22)
     for jk in (("last", "concat", "max", "sum") if domain == "chem" else ("last", "sum")):
         torch.manual_seed(5)
         r = ref.model.GNN(3, 64, JK=jk, drop_ratio=0, gnn_type=gnn_type)
@@ -496,7 +497,7 @@ def test_oracle_equals_live_reference_model(domain, gnn_type):
 @pytest.mark.parametrize("pooling", ["sum", "mean", "max", "attention", "set2set2"])
 def test_oracle_equals_live_reference_graphpred(pooling):
     ref = refshim.load("chem")
-    b = synthetic.chem_finetune_batch(16, num_tasks=5, seed=23)
+    b = hostdata.chem_finetune_batch(16, num_tasks=5, seed=23)
     for jk in ("last", "concat"):
         torch.manual_seed(6)
         r = ref.model.GNN_graphpred(3, 32, 5, JK=jk, drop_ratio=0, graph_pooling=pooling, gnn_type="gin")
@@ -516,7 +517,7 @@ def test_oracle_equals_live_reference_graphpred_bio(pooling):
     for _ in range(12):
         g = synthetic.ppi_like_graph(rng)
         graphs.append(synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr, center_node_idx=g.center_node_idx))
-    b = synthetic.collate(graphs, shift_center=True)
+    b = hostdata.collate(graphs, shift_center=True)
     for jk in ("last",):
         torch.manual_seed(6)
         r = ref.model.GNN_graphpred(3, 32, 7, JK=jk, drop_ratio=0, graph_pooling=pooling, gnn_type="gin")

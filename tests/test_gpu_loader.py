@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from pretrain_gnns_amd.data import Data, resident, synthetic
+from oracle import hostdata
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -30,7 +31,7 @@ def test_collate_matches_host_collate_chem(batch_size):
     ids = np.random.default_rng(batch_size).integers(0, len(graphs), size=batch_size)  # with repeats; > 1024 ids = scan carry
     out = ds.collate(ids)
     ds.check(out)
-    _same(out, synthetic.collate([graphs[i] for i in ids]))
+    _same(out, hostdata.collate([graphs[i] for i in ids]))
     assert out.num_graphs == batch_size
 
 
@@ -41,7 +42,7 @@ def test_collate_matches_host_collate_bio():
     ids = [3, 3, 0, 11, 7]
     out = ds.collate(ids)
     ds.check(out)
-    _same(out, synthetic.collate([graphs[i] for i in ids]))
+    _same(out, hostdata.collate([graphs[i] for i in ids]))
 
 
 def test_collate_ragged_and_empty_graphs():
@@ -55,7 +56,7 @@ def test_collate_ragged_and_empty_graphs():
     for ids in ([0], [0, 0, 0], [0, 1, 2], [2, 0, 3, 0, 1], [1, 0]):
         out = ds.collate(ids)
         ds.check(out)
-        _same(out, synthetic.collate([graphs[i] for i in ids]))
+        _same(out, hostdata.collate([graphs[i] for i in ids]))
 
 
 def test_bad_graph_ids_are_refused():
@@ -144,7 +145,7 @@ def test_explicit_indices_match_host_maskatom(mask_edge):
         masked.append(d)
         picks.append(idx + off)
         off += n
-    want = synthetic.collate(masked)
+    want = hostdata.collate(masked)
     ds = resident.ResidentDataset.from_graphs(graphs, DEV)
     out = ds.collate(np.arange(16), masked_atom_indices=np.concatenate(picks), mask_edge=mask_edge)
     ds.check(out)
@@ -161,8 +162,8 @@ def test_bio_mask_edge_matches_host_and_properties():
     rng = np.random.default_rng(8)
     graphs = [synthetic.ppi_like_graph(rng) for _ in range(6)]
     ds = resident.ResidentDataset.from_graphs(graphs, DEV)
-    masked = [synthetic.mask_edges(g, rng) for g in graphs]
-    want = synthetic.collate(masked)
+    masked = [hostdata.mask_edges(g, rng) for g in graphs]
+    want = hostdata.collate(masked)
     out = ds.collate(np.arange(6), masked_edge_idx=want.masked_edge_idx)
     ds.check(out)
     _same(out, want, ("x", "edge_index", "edge_attr", "batch", "masked_edge_idx", "mask_edge_label"))
@@ -197,12 +198,12 @@ def test_resident_batch_drives_the_train_step_identically():
     """same graphs + same masked atoms => the train step sees bit-identical inputs => identical loss"""
     from pretrain_gnns_amd import train
     from pretrain_gnns_amd.chem import model as hmodel
-    host = synthetic.chem_masking_batch(32, seed=9)
+    host = hostdata.chem_masking_batch(32, seed=9)
     rng = np.random.default_rng(9)  # chem_masking_batch draws graph, mask, graph, mask, ... from this stream
     graphs = []
     for _ in range(32):
         g = synthetic.zinc_like_graph(rng)
-        synthetic.mask_atoms(g, rng)
+        hostdata.mask_atoms(g, rng)
         graphs.append(g)
     ds = resident.ResidentDataset.from_graphs(graphs, DEV)
     dev_batch = ds.collate(np.arange(32), masked_atom_indices=host.masked_atom_indices)
@@ -247,8 +248,8 @@ def test_substruct_context_matches_host_extraction(k, l1, l2):
     rng = np.random.default_rng(12)
     ids = rng.permutation(len(graphs))[:33]
     roots = [int(rng.integers(0, graphs[i].x.size(0))) for i in ids]
-    want = synthetic.collate_substruct_context(
-        [synthetic.extract_substruct_context(graphs[i], rng, k=k, l1=l1, l2=l2, root=r) for i, r in zip(ids, roots)])
+    want = hostdata.collate_substruct_context(
+        [hostdata.extract_substruct_context(graphs[i], rng, k=k, l1=l1, l2=l2, root=r) for i, r in zip(ids, roots)])
     ds = resident.ResidentDataset.from_graphs(graphs, DEV)
     out = ds.collate_substruct_context(ids, k=k, l1=l1, l2=l2, roots=roots)
     ds.check(out)
@@ -283,8 +284,8 @@ def test_substruct_context_random_roots_and_training_step():
         assert torch.equal(getattr(a, key), getattr(b, key)), key
     # same roots on the host give the same batch
     rng = np.random.default_rng(0)
-    want = synthetic.collate_substruct_context(
-        [synthetic.extract_substruct_context(g, rng, root=int(r)) for g, r in zip(graphs, a._roots.cpu())])
+    want = hostdata.collate_substruct_context(
+        [hostdata.extract_substruct_context(g, rng, root=int(r)) for g, r in zip(graphs, a._roots.cpu())])
     _same(a, want, CTX_KEYS)
     torch.manual_seed(0)
     ms, mc = hmodel.GNN(5, 300).to(DEV), hmodel.GNN(3, 300).to(DEV)
@@ -333,6 +334,6 @@ def test_from_inmemory_dataset_layout():
     ids = [10, 0, 4, 4]
     out = ds.collate(ids)
     ds.check(out)
-    _same(out, synthetic.collate([graphs[i] for i in ids]))
+    _same(out, hostdata.collate([graphs[i] for i in ids]))
     with pytest.raises(ValueError):
         resident.ResidentDataset(data.x, data.edge_index, data.edge_attr, ns[:-1], es, DEV)

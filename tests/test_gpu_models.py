@@ -14,6 +14,7 @@ from oracle import chem as ochem
 from oracle import pyg_semantics as pyg
 from oracle import steps
 from pretrain_gnns_amd.data import synthetic
+from oracle import hostdata
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -72,7 +73,7 @@ def _grads_close(ref, hip, batch_args, weight, l2_tol=2e-2):
 def test_chem_gnn_forward_backward(gnn_type, graphs):
     hchem, _ = _hip()
     ref, hip = _pair(ochem.GNN, hchem.GNN, 5, 300, gnn_type=gnn_type)
-    b = synthetic.chem_masking_batch(graphs, seed=graphs)
+    b = hostdata.chem_masking_batch(graphs, seed=graphs)
     d = b.clone().to(DEV)
     out_ref = ref(b.x, b.edge_index, b.edge_attr)
     out_hip = hip(d.x, d.edge_index, d.edge_attr)
@@ -95,7 +96,7 @@ def test_chem_masked_atom_logits_match():
     head_d = torch.nn.Linear(300, 119)
     head_d.load_state_dict(head.state_dict())
     head_d = head_d.to(DEV)
-    b = synthetic.chem_masking_batch(256, seed=0)
+    b = hostdata.chem_masking_batch(256, seed=0)
     d = b.clone().to(DEV)
     lr = head(ref(b.x, b.edge_index, b.edge_attr)[b.masked_atom_indices])
     lh = head_d(hip(d.x, d.edge_index, d.edge_attr)[d.masked_atom_indices])
@@ -107,7 +108,7 @@ def test_chem_masked_atom_logits_match():
 def test_chem_jk_modes(jk):
     hchem, _ = _hip()
     ref, hip = _pair(ochem.GNN, hchem.GNN, 3, 64, JK=jk)
-    b = synthetic.chem_plain_batch(4, seed=2)
+    b = hostdata.chem_plain_batch(4, seed=2)
     d = b.clone().to(DEV)
     torch.testing.assert_close(hip(d.x, d.edge_index, d.edge_attr).detach().cpu(),
                                ref(b.x, b.edge_index, b.edge_attr).detach(), **TOL)
@@ -117,7 +118,7 @@ def test_chem_jk_modes(jk):
 def test_chem_graphpred(pool):
     hchem, _ = _hip()
     ref, hip = _pair(ochem.GNN_graphpred, hchem.GNN_graphpred, 5, 300, 12, graph_pooling=pool)
-    b = synthetic.chem_plain_batch(16, seed=3)
+    b = hostdata.chem_plain_batch(16, seed=3)
     d = b.clone().to(DEV)
     out_ref = ref(b.x, b.edge_index, b.edge_attr, b.batch)
     out_hip = hip(d.x, d.edge_index, d.edge_attr, d.batch)
@@ -131,7 +132,7 @@ def test_chem_graphpred(pool):
 def test_bio_gnn_forward_backward(gnn_type):
     _, hbio = _hip()
     ref, hip = _pair(obio.GNN, hbio.GNN, 5, 300, gnn_type=gnn_type)
-    b = synthetic.bio_masking_batch(8, seed=1)
+    b = hostdata.bio_masking_batch(8, seed=1)
     d = b.clone().to(DEV)
     out_ref = ref(b.x, b.edge_index, b.edge_attr)
     out_hip = hip(d.x, d.edge_index, d.edge_attr)
@@ -155,7 +156,7 @@ def test_bio_one_call_network_equals_per_layer_path(graphs, layers, training, mo
     c = copy.deepcopy(a)
     for m in (a, b, c):
         m.train(training)
-    d = synthetic.bio_masking_batch(graphs, seed=3).to(DEV)
+    d = hostdata.bio_masking_batch(graphs, seed=3).to(DEV)
     w = torch.randn(d.x.size(0), 300, device=DEV)
 
     def run(m, stack, transposed):
@@ -194,7 +195,7 @@ def test_bio_batchnorm_statistics_from_the_gemm_epilogue_match_the_separate_pass
     _, a = _pair(obio.GNN, hbio.GNN, 5, 300, seed=12)
     b = copy.deepcopy(a)
     a.train(), b.train()
-    d = synthetic.bio_masking_batch(64, seed=13).to(DEV)
+    d = hostdata.bio_masking_batch(64, seed=13).to(DEV)
     assert int(ops.load().pgnn_linear_wp_preferred(d.x.size(0), 600, 300)) == 1
     w = torch.randn(d.x.size(0), 300, device=DEV)
     res = []
@@ -224,7 +225,7 @@ def test_bio_batchnorm_statistics_from_the_gemm_epilogue_match_the_separate_pass
 def test_bio_graphpred(pool):
     _, hbio = _hip()
     ref, hip = _pair(obio.GNN_graphpred, hbio.GNN_graphpred, 5, 300, 40, graph_pooling=pool)
-    b = synthetic.bio_masking_batch(8, seed=2)
+    b = hostdata.bio_masking_batch(8, seed=2)
     d = b.clone().to(DEV)
     torch.testing.assert_close(hip(d).detach().cpu(), ref(b).detach(), **TOL)
 
@@ -246,7 +247,7 @@ def test_chem_masking_train_steps(mask_edge):
     heads_d = [h.to(DEV) for h in heads_d]
     opt_r, opt_h = _opt(ref, *heads), _opt(hip, *heads_d)
     for step in range(4):
-        b = synthetic.chem_masking_batch(32, seed=100 + step, mask_edge=mask_edge)
+        b = hostdata.chem_masking_batch(32, seed=100 + step, mask_edge=mask_edge)
         lr, ar, er = steps.chem_masking_step([ref] + heads, opt_r, b, mask_edge)
         lh, ah, eh = steps.chem_masking_step([hip] + heads_d, opt_h, b.clone().to(DEV), mask_edge)
         assert abs(lr - lh) < (1e-4 if step == 0 else 2e-2) * max(1.0, abs(lr)), (step, lr, lh)
@@ -270,7 +271,7 @@ def test_epoch_accuracy_matches_oracle_within_a_tenth_of_a_percent():
     for a, b in zip(heads, heads_d):
         b.load_state_dict(a.state_dict())
     heads_d = [h.to(DEV) for h in heads_d]
-    stream = [synthetic.chem_masking_batch(256, seed=100 + i) for i in range(9)]
+    stream = [hostdata.chem_masking_batch(256, seed=100 + i) for i in range(9)]
     ref_out = steps.chem_masking_epoch([ref] + heads, _opt(ref, *heads), stream)
     hip_out = ptrain.chem_masking_epoch([hip] + heads_d, _opt(hip, *heads_d), [b.clone() for b in stream], device=DEV)
     assert abs(ref_out[1] - hip_out[1]) <= 1e-3, (ref_out, hip_out)          # epoch accuracy
@@ -285,7 +286,7 @@ def test_epoch_sums_on_the_device_equal_the_per_step_read_back(mask_edge):
     (Bit-for-bit where the step itself is deterministic, i.e. without the bond head.)"""
     from pretrain_gnns_amd import train as ptrain
     hchem, _ = _hip()
-    stream = [synthetic.chem_masking_batch(8 + 5 * i, seed=40 + i, mask_edge=mask_edge).to(DEV) for i in range(5)]
+    stream = [hostdata.chem_masking_batch(8 + 5 * i, seed=40 + i, mask_edge=mask_edge).to(DEV) for i in range(5)]
     outs = []
     for mode in ("end", "epoch"):
         torch.manual_seed(3)
@@ -303,7 +304,7 @@ def test_epoch_sums_on_the_device_equal_the_per_step_read_back(mask_edge):
 def test_contextpred_epoch_sums_on_the_device_equal_the_per_step_read_back():
     from pretrain_gnns_amd import train as ptrain
     hchem, _ = _hip()
-    stream = [synthetic.chem_contextpred_batch(6 + 3 * i, seed=70 + i).to(DEV) for i in range(4)]
+    stream = [hostdata.chem_contextpred_batch(6 + 3 * i, seed=70 + i).to(DEV) for i in range(4)]
     outs = []
     for mode in ("end", "epoch"):
         torch.manual_seed(5)
@@ -318,7 +319,7 @@ def test_contextpred_epoch_sums_on_the_device_equal_the_per_step_read_back():
 def test_bio_epoch_sums_on_the_device_equal_the_per_step_read_back():
     from pretrain_gnns_amd import train as ptrain
     _, hbio = _hip()
-    stream = [synthetic.bio_masking_batch(4 + i, seed=60 + i).to(DEV) for i in range(4)]
+    stream = [hostdata.bio_masking_batch(4 + i, seed=60 + i).to(DEV) for i in range(4)]
     outs = []
     for mode in ("end", "epoch"):
         torch.manual_seed(4)
@@ -338,7 +339,7 @@ def test_hip_graph_replay_of_the_masking_step_equals_eager_steps(readback):
     torch.manual_seed(11)
     mods_a = [hchem.GNN(5, 300).to(DEV), torch.nn.Linear(300, 119).to(DEV), torch.nn.Linear(300, 4).to(DEV)]
     mods_b = copy.deepcopy(mods_a)
-    b = synthetic.chem_masking_batch(24, seed=12).to(DEV)
+    b = hostdata.chem_masking_batch(24, seed=12).to(DEV)
     opts_a = optim.Adam.shared([m.parameters() for m in mods_a], lr=1e-3)
     eager = [ptrain.chem_masking_step(mods_a, opts_a, b) for _ in range(5)]
     opts_b = optim.Adam.shared([m.parameters() for m in mods_b], lr=1e-3)
@@ -364,7 +365,7 @@ def test_product_train_step_mirrors_oracle_step():
     readback placements, including with torch's fused Adam."""
     from pretrain_gnns_amd import train as ptrain
     hchem, _ = _hip()
-    b = synthetic.chem_masking_batch(16, seed=5, mask_edge=True).to(DEV)
+    b = hostdata.chem_masking_batch(16, seed=5, mask_edge=True).to(DEV)
     results = []
     for mode in ("oracle", "inline", "end"):
         torch.manual_seed(0)
@@ -390,7 +391,7 @@ def test_chem_contextpred_train_steps():
     o_rs, o_rc = _opt(ref_s, ref_c)
     o_hs, o_hc = _opt(hip_s, hip_c)
     for step in range(3):
-        b = synthetic.chem_contextpred_batch(32, seed=50 + step)
+        b = hostdata.chem_contextpred_batch(32, seed=50 + step)
         lr, ar = steps.chem_contextpred_step(ref_s, ref_c, o_rs, o_rc, b)
         lh, ah = steps.chem_contextpred_step(hip_s, hip_c, o_hs, o_hc, b.clone().to(DEV), pool=hchem.global_mean_pool)
         assert abs(lr - lh) < (1e-4 if step == 0 else 3e-2) * max(1.0, abs(lr)), (step, lr, lh)
@@ -405,7 +406,7 @@ def test_chem_edgepred_and_infomax_train_steps():
     ref, hip = _pair(ochem.GNN, hchem.GNN, 5, 300, seed=31)
     o_r, o_h = _opt(ref)[0], _opt(hip)[0]
     for step in range(3):
-        b = synthetic.chem_edgepred_batch(32, seed=90 + step)
+        b = hostdata.chem_edgepred_batch(32, seed=90 + step)
         assert b.negative_edge_index.size(1) > 0 and int(b.negative_edge_index.max()) < b.x.size(0)
         lr, ar = steps.chem_edgepred_step(ref, o_r, b)
         lh, ah = ptrain.chem_edgepred_step(hip, o_h, b.clone().to(DEV))
@@ -420,7 +421,7 @@ def test_chem_edgepred_and_infomax_train_steps():
     o_r = torch.optim.Adam(list(ref.parameters()) + list(d_ref.parameters()), lr=1e-3)
     o_h = torch.optim.Adam(model.parameters(), lr=1e-3)
     for step in range(3):
-        b = synthetic.chem_plain_batch(32, seed=95 + step)
+        b = hostdata.chem_plain_batch(32, seed=95 + step)
         lr, ar = steps.chem_infomax_step(ref, d_ref, o_r, b)
         lh, ah = ptrain.chem_infomax_step(model, o_h, b.clone().to(DEV))
         assert abs(lr - lh) < (1e-4 if step == 0 else 3e-2) * max(1.0, abs(lr)), (step, lr, lh)
@@ -437,7 +438,7 @@ def test_bio_masking_train_steps():
     head_d = head_d.to(DEV)
     opt_r, opt_h = _opt(ref, head), _opt(hip, head_d)
     for step in range(3):
-        b = synthetic.bio_masking_batch(8, seed=70 + step)
+        b = hostdata.bio_masking_batch(8, seed=70 + step)
         lr, ar = steps.bio_masking_step([ref, head], opt_r, b)
         lh, ah = steps.bio_masking_step([hip, head_d], opt_h, b.clone().to(DEV))
         assert abs(lr - lh) < (1e-4 if step == 0 else 3e-2) * max(1.0, abs(lr)), (step, lr, lh)
@@ -451,16 +452,16 @@ def test_chem_finetune_steps_and_eval(gnn_type):
     from pretrain_gnns_amd import train
     hchem, _ = _hip()
     ref, hip = _pair(ochem.GNN_graphpred, hchem.GNN_graphpred, 5, 300, 12, gnn_type=gnn_type, seed=11)
-    b = synthetic.chem_finetune_batch(48, num_tasks=12, seed=3)
-    bd = synthetic.chem_finetune_batch(48, num_tasks=12, seed=3).to(DEV)
+    b = hostdata.chem_finetune_batch(48, num_tasks=12, seed=3)
+    bd = hostdata.chem_finetune_batch(48, num_tasks=12, seed=3).to(DEV)
     o_ref, o_hip = torch.optim.Adam(ref.parameters(), lr=1e-3), torch.optim.Adam(hip.parameters(), lr=1e-3)
     for step in range(3):
         l_ref, l_hip = steps.chem_finetune_step(ref, o_ref, b), train.chem_finetune_step(hip, o_hip, bd)
         assert abs(l_ref - l_hip) <= (1e-4 if step == 0 else 3e-2) * max(1.0, abs(l_ref)), (step, l_ref, l_hip)
     hip.load_state_dict(ref.state_dict())  # same weights again: eval parity is then a pure forward check
-    val = synthetic.chem_finetune_batch(64, num_tasks=12, seed=4)
+    val = hostdata.chem_finetune_batch(64, num_tasks=12, seed=4)
     auc_ref = steps.chem_eval(ref, [b, val])
-    auc_hip = train.chem_eval(hip, [bd, synthetic.chem_finetune_batch(64, num_tasks=12, seed=4).to(DEV)])
+    auc_hip = train.chem_eval(hip, [bd, hostdata.chem_finetune_batch(64, num_tasks=12, seed=4).to(DEV)])
     assert abs(auc_ref - auc_hip) <= 1e-3, (auc_ref, auc_hip)  # "within +-0.1 % absolute" 
 
 
@@ -472,7 +473,7 @@ def test_dropout_is_reproducible_under_manual_seed(stack, monkeypatch):
     monkeypatch.setattr(hchem, "_STACK_CALL", stack)
     torch.manual_seed(0)
     m = hchem.GNN(3, 300, drop_ratio=0.5).to(DEV)
-    d = synthetic.chem_plain_batch(24, seed=2).to(DEV)
+    d = hostdata.chem_plain_batch(24, seed=2).to(DEV)
     runs = []
     for seed in (7, 7, 8):
         torch.manual_seed(seed)
@@ -493,7 +494,7 @@ def test_chem_finetune_with_dropout_runs_and_regularises():
     hchem, _ = _hip()
     torch.manual_seed(0)
     hip = hchem.GNN_graphpred(5, 300, 12, drop_ratio=0.5).to(DEV)
-    bd = synthetic.chem_finetune_batch(64, num_tasks=12, seed=5).to(DEV)
+    bd = hostdata.chem_finetune_batch(64, num_tasks=12, seed=5).to(DEV)
     hip.train()
     a = hip(bd.x, bd.edge_index, bd.edge_attr, bd.batch).detach()
     b = hip(bd.x, bd.edge_index, bd.edge_attr, bd.batch).detach()
@@ -540,7 +541,7 @@ def test_forward_is_bitwise_deterministic(graphs):
     the backward) and BASELINE's full 2048 (54k nodes: single-stream regime, two-level reductions)"""
     hchem, _ = _hip()
     _, hip = _pair(ochem.GNN, hchem.GNN, 5, 300)
-    d = synthetic.chem_masking_batch(graphs, seed=4).to(DEV)
+    d = hostdata.chem_masking_batch(graphs, seed=4).to(DEV)
     outs, grads = [], []
     for _ in range(3):
         hip.zero_grad()
@@ -571,7 +572,7 @@ def test_one_call_network_equals_per_layer_path(graphs, layers, training, monkey
     _, a = _pair(ochem.GNN, hchem.GNN, layers, 300, seed=5)
     b = copy.deepcopy(a)
     a.train(training), b.train(training)
-    d = synthetic.chem_masking_batch(graphs, seed=6).to(DEV)
+    d = hostdata.chem_masking_batch(graphs, seed=6).to(DEV)
     w = torch.randn(d.x.size(0), 300, device=DEV)
     res = []
     for m, flag in ((a, True), (b, False)):
@@ -610,7 +611,7 @@ def test_one_call_network_on_weight_planes_below_the_split_threshold(graphs, mon
     _, a = _pair(ochem.GNN, hchem.GNN, 5, 300, seed=5)
     b = copy.deepcopy(a)
     a.train(), b.train()
-    d = synthetic.chem_masking_batch(graphs, seed=6).to(DEV)
+    d = hostdata.chem_masking_batch(graphs, seed=6).to(DEV)
     assert int(ops.load().pgnn_linear_wp_preferred(d.x.size(0), 600, 300)) == 1
     w = torch.randn(d.x.size(0), 300, device=DEV)
     res = []
@@ -637,7 +638,7 @@ def test_batchnorm_statistics_from_the_gemm_epilogue_match_the_separate_pass(gra
     hchem, _ = _hip()
     _, a = _pair(ochem.GNN, hchem.GNN, layers, 300, seed=8)
     b = copy.deepcopy(a)
-    d = synthetic.chem_masking_batch(graphs, seed=9).to(DEV)
+    d = hostdata.chem_masking_batch(graphs, seed=9).to(DEV)
     w = torch.randn(d.x.size(0), 300, device=DEV)
     res = []
     for m, flag in ((a, "1"), (b, "0")):
@@ -676,7 +677,7 @@ def test_transposed_backward_data_matches_the_fp32_mfma_backward(graphs, layers,
     hchem, _ = _hip()
     _, m = _pair(ochem.GNN, hchem.GNN, layers, 300, seed=8)
     m.train()
-    d = synthetic.chem_masking_batch(graphs, seed=9).to(DEV)
+    d = hostdata.chem_masking_batch(graphs, seed=9).to(DEV)
     w = torch.randn(d.x.size(0), 300, device=DEV)
     grads = []
     for flag in ("2", "0"):  # 2 = transposed weights at every size (the default switches at 16 384 rows)
@@ -702,7 +703,7 @@ def test_one_call_gcn_and_graphsage_equal_per_layer_path(gnn_type, graphs, layer
     _, a = _pair(ochem.GNN, hchem.GNN, layers, 300, seed=6, gnn_type=gnn_type)
     b = copy.deepcopy(a)
     a.train(training), b.train(training)
-    d = synthetic.chem_masking_batch(graphs, seed=7).to(DEV)
+    d = hostdata.chem_masking_batch(graphs, seed=7).to(DEV)
     w = torch.randn(d.x.size(0), 300, device=DEV)
     res = []
     for m, flag in ((a, True), (b, False)):
@@ -737,7 +738,7 @@ def test_transposed_backward_data_matches_the_fp32_mfma_backward(graphs, layers,
     hchem, _ = _hip()
     _, m = _pair(ochem.GNN, hchem.GNN, layers, 300, seed=8)
     m.train()
-    d = synthetic.chem_masking_batch(graphs, seed=9).to(DEV)
+    d = hostdata.chem_masking_batch(graphs, seed=9).to(DEV)
     w = torch.randn(d.x.size(0), 300, device=DEV)
     grads = []
     for flag in ("2", "0"):  # 2 = transposed weights at every size (the default switches at 16 384 rows)
@@ -764,7 +765,7 @@ def test_direct_gradient_deposit_equals_autograd_accumulation(gnn_type, monkeypa
     hchem, _ = _hip()
     _, a = _pair(ochem.GNN, hchem.GNN, 3, 300, seed=8, gnn_type=gnn_type)
     b = copy.deepcopy(a)
-    d = synthetic.chem_masking_batch(24, seed=9).to(DEV)
+    d = hostdata.chem_masking_batch(24, seed=9).to(DEV)
     w = torch.randn(d.x.size(0), 300, device=DEV)
     outs = {}
     for m, direct in ((a, True), (b, False)):
@@ -811,7 +812,7 @@ def test_large_batch_properties():
     """BASELINE full size (2048 graphs): size-independent checks instead of a slow oracle run --
     linearity of the aggregation in x and agreement of the aggregation with a torch index_add on GPU."""
     from pretrain_gnns_amd import ops
-    b = synthetic.chem_masking_batch(2048, seed=8).to(DEV)
+    b = hostdata.chem_masking_batch(2048, seed=8).to(DEV)
     n = b.x.size(0)
     g = ops.build_chem_graph(b.edge_index, b.edge_attr, n)
     g.check()
@@ -876,7 +877,7 @@ def test_other_embedding_widths(emb_dim, gnn_type):
     one-call path"""
     hchem, _ = _hip()
     ref, hip = _pair(ochem.GNN, hchem.GNN, 3, emb_dim, seed=emb_dim, gnn_type=gnn_type)
-    b = synthetic.chem_plain_batch(24, seed=emb_dim)
+    b = hostdata.chem_plain_batch(24, seed=emb_dim)
     d = b.clone().to(DEV)
     out_ref = ref(b.x, b.edge_index, b.edge_attr)
     out_hip = hip(d.x, d.edge_index, d.edge_attr)
@@ -896,7 +897,7 @@ def test_bio_other_embedding_widths(emb_dim, gnn_type):
     back to the row-streaming kernel there)"""
     _, hbio = _hip()
     ref, hip = _pair(obio.GNN, hbio.GNN, 3, emb_dim, seed=emb_dim, gnn_type=gnn_type)
-    b = synthetic.bio_masking_batch(6, seed=emb_dim)
+    b = hostdata.bio_masking_batch(6, seed=emb_dim)
     d = b.clone().to(DEV)
     out_ref = ref(b.x, b.edge_index, b.edge_attr)
     out_hip = hip(d.x, d.edge_index, d.edge_attr)
@@ -910,7 +911,7 @@ def test_bio_other_embedding_widths(emb_dim, gnn_type):
 def test_other_depths(num_layer):
     hchem, _ = _hip()
     ref, hip = _pair(ochem.GNN, hchem.GNN, num_layer, 300, seed=num_layer)
-    b = synthetic.chem_plain_batch(16, seed=num_layer)
+    b = hostdata.chem_plain_batch(16, seed=num_layer)
     d = b.clone().to(DEV)
     out_ref = ref(b.x, b.edge_index, b.edge_attr)
     out_hip = hip(d.x, d.edge_index, d.edge_attr)

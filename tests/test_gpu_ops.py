@@ -10,7 +10,7 @@ import torch
 
 from oracle import chem as ochem
 from oracle import pyg_semantics as pyg
-from pretrain_gnns_amd.data import synthetic
+from oracle import hostdata
 
 pytestmark = pytest.mark.gpu
 
@@ -125,7 +125,7 @@ def test_chem_aggregate_tiny_and_ragged(n, e):
 def test_aggregate_variants_agree_bitwise(monkeypatch):
     """the three aggregation kernels (wave-per-node, group-per-node, loader/consumer DMA) are interchangeable"""
     ops = _ops()
-    b = synthetic.chem_masking_batch(96, seed=9).to(DEV)
+    b = hostdata.chem_masking_batch(96, seed=9).to(DEV)
     n = b.x.size(0)
     g = ops.build_chem_graph(b.edge_index, b.edge_attr, n)
     torch.manual_seed(0)
@@ -148,7 +148,7 @@ def test_gcn_weighted_aggregate_variants_agree_bitwise(shape, monkeypatch):
     "random" sends most edges down the out-of-window slow path, "hub" overflows the 64 staged edge slots"""
     ops = _ops()
     if shape == "molecules":
-        b = synthetic.chem_masking_batch(200, seed=4).to(DEV)
+        b = hostdata.chem_masking_batch(200, seed=4).to(DEV)
         ei, ea, n = b.edge_index, b.edge_attr, b.x.size(0)
     else:
         n = 3000
@@ -208,7 +208,7 @@ def test_chem_aggregate_backward_and_gcn():
 def test_bio_aggregate_fwd_bwd(gcn):
     from oracle import bio as obio
     ops = _ops()
-    b = synthetic.bio_masking_batch(6, seed=4)
+    b = hostdata.bio_masking_batch(6, seed=4)
     n, dim = b.x.size(0), 300
     torch.manual_seed(2)
     conv = (obio.GCNConv if gcn else obio.GINConv)(dim)
@@ -679,6 +679,58 @@ def test_contextpred_loss_fused_matches_the_torch_composition(graphs, neg):
     assert torch.equal(loss2, loss) and torch.equal(vals2, vals) and torch.equal(x2.grad, x.grad) and torch.equal(y2.grad, y.grad)
 
 
+@pytest.mark.parametrize("n,m,classes,f64", [(4000, 9000, 7, False), (4000, 9000, 4, True), (50, 3, 7, False), (700, 1, 4, True), (300, 5000, 7, True)])
+def test_edge_head_matches_the_torch_composition(n, m, classes, f64):
+    """csrc/edgehead.hip against the statements of bio/pretrain_masking.py:45-58 (fp32 loss, labels = argmax over the 9-column
+    multi-hot edge attributes) and chem/pretrain_masking.py:60-66 (loss on pred.double(), int64 labels) written with torch ops in
+    float64: logits, loss, hit count, the gradients w.r.t. node_rep (nodes in several masked edges, nodes in none), weight and
+    bias, the epoch accumulator, bitwise reproducibility"""
+    ops = _ops()
+    torch.manual_seed(n + m + classes)
+    D = 300
+    h = torch.randn(n, D, device=DEV) * 0.5
+    lin = torch.nn.Linear(D, classes).to(DEV)
+    ends = torch.randint(0, max(1, n // 2), (2, m), device=DEV)  # the upper half of the nodes is in no masked edge
+    if f64:
+        label = torch.randint(0, classes, (m,), device=DEV)
+        target = label
+    else:
+        label = (torch.rand(m, 9, device=DEV) < 0.3).float()
+        label[:, classes:] = 0
+        label[torch.arange(m, device=DEV), torch.randint(0, classes, (m,), device=DEV)] = 1.0  # at least one type set, often several
+        target = torch.argmax(label, dim=1)
+
+    hd = h.double().requires_grad_(True)
+    wd, bd = lin.weight.detach().double().requires_grad_(True), lin.bias.detach().double().requires_grad_(True)
+    pred = (hd[ends[0]] + hd[ends[1]]) @ wd.t() + bd
+    ref_loss = torch.nn.functional.cross_entropy(pred, target)
+    ref_loss.backward()
+    ref_hits = int((pred.argmax(1) == target).sum())
+
+    x = h.clone().requires_grad_(True)
+    accum = torch.zeros(4, dtype=torch.float64, device=DEV)
+    loss, correct, metrics = ops.edge_head(x, ends, lin, label, float64=f64, accum=accum, accum_slot=2)
+    assert loss.dtype == (torch.float64 if f64 else torch.float32)
+    loss.backward()
+    torch.testing.assert_close(loss.detach().double(), ref_loss.detach(), rtol=2e-6, atol=1e-7)
+    # (an arg-max can flip where two logits agree to fp32 rounding)
+    assert abs(int(correct) - ref_hits) <= max(1, m // 2000)
+    torch.testing.assert_close(metrics, torch.stack([loss.detach().double(), correct.double()]), rtol=0, atol=0)
+    torch.testing.assert_close(accum, torch.stack([loss.detach().double(), torch.zeros_like(ref_loss), correct.double() / m, torch.ones_like(ref_loss)]),
+                               rtol=1e-12, atol=0)
+    for got, want in ((x.grad, hd.grad), (lin.weight.grad, wd.grad), (lin.bias.grad, bd.grad)):
+        scale = float(want.abs().max())
+        assert float((got.double() - want).abs().max()) <= 5e-6 * scale, (float((got.double() - want).abs().max()), scale)
+    assert float(x.grad[max(1, n // 2):].abs().max()) == 0.0 if n >= 4 else True
+    lin2 = torch.nn.Linear(D, classes).to(DEV)
+    lin2.load_state_dict(lin.state_dict())
+    x2 = h.clone().requires_grad_(True)
+    loss2, correct2, _ = ops.edge_head(x2, ends, lin2, label, float64=f64)
+    loss2.backward()
+    assert torch.equal(loss2, loss) and torch.equal(correct2, correct) and torch.equal(x2.grad, x.grad)
+    assert torch.equal(lin2.weight.grad, lin.weight.grad) and torch.equal(lin2.bias.grad, lin.bias.grad)
+
+
 def test_adam_limits_are_enforced_not_silent():
     """lr read from param_groups at launch (a scheduler works); a handle stepped twice, a zero_grad() in an incomplete
     round and a parameter whose first gradient arrives late raise instead of silently doing something else than torch"""
@@ -819,7 +871,7 @@ def test_aggregate_with_batchnorm_on_read_is_bit_identical(dim, relu):
     """pgnn_chem_aggregate_bn_fwd(z, coef) == pgnn_chem_aggregate_fwd(relu?(coef0*z + coef1)): the
     BatchNorm(+ReLU) between two GIN layers applied while gathering, never materialised."""
     from pretrain_gnns_amd import ops
-    b = synthetic.chem_plain_batch(96, seed=dim).to(DEV)
+    b = hostdata.chem_plain_batch(96, seed=dim).to(DEV)
     n = b.x.size(0)
     g = ops.build_chem_graph(b.edge_index, b.edge_attr, n)
     torch.manual_seed(dim + relu)
@@ -893,7 +945,7 @@ def test_gat_aggregate_fwd_bwd(shape):
     ops = _ops()
     dim = 300
     if shape == "molecules":
-        b = synthetic.chem_masking_batch(12, seed=3)
+        b = hostdata.chem_masking_batch(12, seed=3)
         ei, ea, n = b.edge_index, b.edge_attr, b.x.size(0)
     elif shape == "parallel_bonds":
         n = 40
@@ -947,7 +999,7 @@ def test_bio_gat_aggregate_fwd_bwd(shape):
     from oracle import bio as obio
     ops = _ops()
     dim = 300
-    b = synthetic.bio_masking_batch(5, seed=6)
+    b = hostdata.bio_masking_batch(5, seed=6)
     ei, ea, n = b.edge_index, b.edge_attr.to(torch.float32), b.x.size(0)
     if shape == "isolated":
         keep = (ei[0] < n // 2) & (ei[1] < n // 2)  # the upper half of the nodes keeps only its self loops
@@ -1027,7 +1079,7 @@ def test_tiled_neighbor_sum_is_bit_identical(shape, gcn):
     ops = _ops()
     import numpy as np
     if shape == "ego_nets":
-        b = synthetic.bio_masking_batch(40, seed=6)
+        b = hostdata.bio_masking_batch(40, seed=6)
         ei, n = b.edge_index, b.x.size(0)
         want_tiles = 40
     elif shape == "big_graphs":
@@ -1068,7 +1120,7 @@ def test_bio_aggregate_fused_tile_path_is_bit_identical(gcn, monkeypatch):
     """bio GINConv / GCNConv aggregate: ONE graph-resident launch (neighbour sum + edge-feature product, csrc/tile.hip)
     == the two-launch path (pgnn_neighbor_sum + pgnn_rowfeat_matmul_fwd), forward and backward, bit for bit"""
     ops = _ops()
-    b = synthetic.bio_masking_batch(24, seed=8).to(DEV)
+    b = hostdata.bio_masking_batch(24, seed=8).to(DEV)
     n = b.x.size(0)
     torch.manual_seed(3)
     x = torch.randn(n, 300, device=DEV)

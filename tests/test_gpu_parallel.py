@@ -38,6 +38,7 @@ def _worker(rank, world, port, out_dir):
     from pretrain_gnns_amd import train as ptrain
     from pretrain_gnns_amd.chem import model as hchem
     from pretrain_gnns_amd.data import resident, synthetic
+    from oracle import hostdata
 
     r, local, w = parallel.init_from_env()
     assert (r, w, dist.get_backend()) == (rank, world, "gloo")
@@ -159,6 +160,7 @@ def _bio_worker(rank, world, port, out_dir):
     from pretrain_gnns_amd import train as ptrain
     from pretrain_gnns_amd.bio import model as hbio
     from pretrain_gnns_amd.data import resident, synthetic
+    from oracle import hostdata
 
     r, local, w = parallel.init_from_env()
     dev = torch.device("cuda", local)
@@ -246,6 +248,7 @@ def _rccl_single_rank_worker(port, out_path):
     from pretrain_gnns_amd import train as ptrain
     from pretrain_gnns_amd.chem import model as hchem
     from pretrain_gnns_amd.data import synthetic
+    from oracle import hostdata
 
     parallel.init_from_env()
     assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
@@ -254,7 +257,7 @@ def _rccl_single_rank_worker(port, out_path):
     torch.manual_seed(3)
     mods_a = [hchem.GNN(5, 300).to(dev), torch.nn.Linear(300, 119).to(dev), torch.nn.Linear(300, 4).to(dev)]
     mods_b = copy.deepcopy(mods_a)
-    batches = [synthetic.chem_masking_batch(12 + i, seed=30 + i).to(dev) for i in range(3)]
+    batches = [hostdata.chem_masking_batch(12 + i, seed=30 + i).to(dev) for i in range(3)]
     plain = optim.Adam.shared([m.parameters() for m in mods_a], lr=1e-3)
     dp = parallel.AllReduceOptimizers(optim.Adam.shared([m.parameters() for m in mods_b], lr=1e-3))
     out_a = [ptrain.chem_masking_step(mods_a, plain, b) for b in batches]

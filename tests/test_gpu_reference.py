@@ -26,6 +26,7 @@ import ref_fixtures as rf
 from pretrain_gnns_amd import ops
 from pretrain_gnns_amd import train as ptrain
 from pretrain_gnns_amd.data import Data, resident, synthetic
+from oracle import hostdata
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -289,7 +290,7 @@ def test_device_context_transform_vs_reference(name):
     for k, v in want.items():
         assert getattr(got, k).shape == v.shape, k
     host = rf.context_graphs(fx)[:bs]
-    hostb = synthetic.collate_substruct_context(host)
+    hostb = hostdata.collate_substruct_context(host)
     for k in want:
         assert torch.equal(getattr(got, k).cpu(), getattr(hostb, k)), k  # device == host restatement, bit-exact
     if not all(torch.equal(getattr(hostb, k), v) for k, v in want.items()):
@@ -338,7 +339,7 @@ def test_finetune_vs_reference(pooling):
     hchem, _ = hip_models()
     graphs = [synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr, y=y)
               for g, y in zip(rf.raw_graphs(fx["raw"]), fx["y"])]
-    batches = [synthetic.collate(graphs[i:i + 32]).to(DEV) for i in range(0, len(graphs), 32)]
+    batches = [hostdata.collate(graphs[i:i + 32]).to(DEV) for i in range(0, len(graphs), 32)]
     def fresh():
         torch.manual_seed(0)
         m = hchem.GNN_graphpred(5, 300, 12, JK="last", drop_ratio=0, graph_pooling=pooling, gnn_type="gin").to(DEV)
@@ -500,8 +501,8 @@ def test_bio_contextpred_vs_reference(name):
     ds = resident.ResidentDataset.from_graphs(raw, DEV)
     got = ds.collate_substruct_context(np.arange(bs), l1=1)
     ds.check(got)
-    host = [synthetic.bio_extract_substruct_context(g, l1=1) for g in raw[:bs]]
-    hostb = synthetic.collate_substruct_context(host)
+    host = [hostdata.bio_extract_substruct_context(g, l1=1) for g in raw[:bs]]
+    hostb = hostdata.collate_substruct_context(host)
     w0 = fx["batches"]["0"]
     for k in w0:
         g_, h_ = getattr(got, k).cpu(), getattr(hostb, k)

@@ -10,7 +10,7 @@ from pretrain_gnns_amd.data import synthetic
 graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 torch.manual_seed(8)
 ref = ochem.GNN(5, 300)
-d = synthetic.chem_masking_batch(graphs, seed=9)
+d = synthetic.chem_masking_batch(graphs, seed=9).to("cpu")  # (device-collated; the float64 reference runs on the host)
 w = torch.randn(d.x.size(0), 300)
 ref64 = copy.deepcopy(ref).double()
 ref64.train()
