@@ -183,14 +183,15 @@ def aggregation_robustness(dev, graphs):
     take the kernel's wave-uniform path to global memory).  Same algorithmic bytes formula, same 8 TB/s denominator."""
     import numpy as np
     from pretrain_gnns_amd import ops
-    from pretrain_gnns_amd.data import synthetic
+    from pretrain_gnns_amd.data import resident, synthetic
 
     out = {}
     lib, sp = ops.load(), ops.stream_ptr()
     for tag, kw in (("survey_order", {}), ("parent_within_8", {"parent_window": 8}), ("parent_within_12", {"parent_window": 12}),
                     ("parent_within_16", {"parent_window": 16}), ("atoms_permuted", {"permute": True})):
         rng = np.random.default_rng(777)
-        base = synthetic.collate([synthetic.zinc_like_graph(rng, **kw) for _ in range(2048)])
+        gl = [synthetic.zinc_like_graph(rng, **kw) for _ in range(2048)]
+        base = resident.ResidentDataset.from_graphs(gl, dev).collate(np.arange(len(gl)))
         big = synthetic.tile_batch(base, max(1, graphs // 2048)).to(dev)
         n, e = big.x.size(0), big.edge_index.size(1)
         dst, src = big.edge_index[0], big.edge_index[1]

@@ -120,6 +120,8 @@ __global__ void __launch_bounds__(kEdgeBlock) k_edge_ce(const float* __restrict_
   __shared__ int redi[kEdgeBlock];
   __shared__ bool last;
   const int r = blockIdx.x * kEdgeBlock + threadIdx.x;
+  double my_nll = 0.0;
+  int my_hit = 0;
   if (r < m) {
     int64_t u = ends[r], v = ends[(int64_t)m + r];
     if (u < 0 || u >= n_nodes || v < 0 || v >= n_nodes) {
@@ -151,19 +153,35 @@ __global__ void __launch_bounds__(kEdgeBlock) k_edge_ce(const float* __restrict_
       row_softmax<float>(z, classes, zmax, sum, arg);
       nll = (double)((logf(sum) + zmax) - zy);
     }
-    publish(row_nll + r, nll);  // (read by the last block: agent-scope, see common.h)
-    publish(row_hit + r, arg == y ? 1 : 0);
+    my_nll = nll;
+    my_hit = arg == y ? 1 : 0;
   }
+  // the block's rows by a fixed tree, one partial per block (read by the last block: agent-scope, see common.h), the blocks'
+  // partials by strided sums + the same tree: the same order every run
+  red[threadIdx.x] = my_nll;
+  redi[threadIdx.x] = my_hit;
   __syncthreads();
-  if (threadIdx.x == 0) last = arrive_last(counter);
+  for (int t = kEdgeBlock / 2; t > 0; t >>= 1) {
+    if ((int)threadIdx.x < t) {
+      red[threadIdx.x] += red[threadIdx.x + t];
+      redi[threadIdx.x] += redi[threadIdx.x + t];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    publish(row_nll + blockIdx.x, red[0]);
+    publish(row_hit + blockIdx.x, redi[0]);
+    last = arrive_last(counter);
+  }
   __syncthreads();
   if (!last) return;
   double s = 0.0;
   int hits = 0;
-  for (int q = threadIdx.x; q < m; q += kEdgeBlock) {
+  for (int q = threadIdx.x; q < (int)gridDim.x; q += kEdgeBlock) {
     s += fetch_published(row_nll + q);
     hits += fetch_published(row_hit + q);
   }
+  __syncthreads();
   red[threadIdx.x] = s;
   redi[threadIdx.x] = hits;
   __syncthreads();

@@ -87,6 +87,8 @@ __global__ void __launch_bounds__(kHeadThreads * kHeadSlices) k_head_fwd(const f
       }
   }
   if (sl != 0) return;  // the soft-max below is the first 128 threads' (whole waves: the barriers that follow count them only)
+  double blk_nll = 0.0;
+  int blk_hit = 0;
   for (int i = 0; i < nr; ++i) {
     // row maximum and its FIRST index (torch.max's tie rule), then the sum of exp in float64
     red[c] = (double)z[i];
@@ -116,17 +118,21 @@ __global__ void __launch_bounds__(kHeadThreads * kHeadSlices) k_head_fwd(const f
       const bool yok = y >= 0 && y < classes;
       if (!yok) atomicAdd(status, 1);
       const double zy = yok ? (double)logits[(int64_t)(r0 + i) * classes + y] : 0.0;  // written by thread y of this block, before the syncs
-      publish(row_nll + r0 + i, log(red[0]) + zmax - zy);  // (read by the last block: agent-scope, see common.h)
-      publish(row_hit + r0 + i, (yok && arg == (int)y) ? 1 : 0);
+      blk_nll += log(red[0]) + zmax - zy;  // rows of a block in order, blocks in order below: the same sums every run
+      blk_hit += (yok && arg == (int)y) ? 1 : 0;
     }
     __syncthreads();
   }
-  if (c == 0) last = arrive_last(counter);
+  if (c == 0) {  // one partial per block (read by the last block: agent-scope, see common.h)
+    publish(row_nll + blockIdx.x, blk_nll);
+    publish(row_hit + blockIdx.x, blk_hit);
+    last = arrive_last(counter);
+  }
   __syncthreads();
   if (!last) return;
   double s = 0.0;
   int hits = 0;
-  for (int q = c; q < m; q += kHeadThreads) {  // per-thread strided partials, then a fixed tree: the same order every run
+  for (int q = c; q < (int)gridDim.x; q += kHeadThreads) {  // per-thread strided partials, then a fixed tree: the same order every run
     s += fetch_published(row_nll + q);
     hits += fetch_published(row_hit + q);
   }

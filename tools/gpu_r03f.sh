@@ -1,0 +1,33 @@
+#!/bin/bash
+# round-3 GPU session F: full GPU suite after the ticket / edge-head / hostdata changes, smoke, step profiles, bench
+set +e
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r03f
+mkdir -p $O
+cd $R
+timeout 1500 python -m pytest tests -m gpu -x -q > $O/tests.txt 2>&1
+tail -n 6 $O/tests.txt
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -n 2 $O/smoke.txt
+cd /tmp && export TMPDIR=/tmp
+prof() {  # name, command...
+  local name=$1; shift
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -o $name -- "$@" > $O/$name.log 2>&1
+  cp $(find $O/prof_$name -name "*kernel_stats.csv" | head -1) $O/${name}_kernel_stats.csv
+  cp $(find $O/prof_$name -name "*kernel_trace.csv" | head -1) $O/${name}_trace.csv
+  rm -rf $O/prof_$name
+  python $R/tools/kstats.py $O/${name}_kernel_stats.csv 45 > $O/${name}_kstats.txt
+  python $R/tools/step_timeline.py $O/${name}_trace.csv > $O/${name}_timeline.txt 2>&1
+  gzip -f $O/${name}_trace.csv
+}
+prof step_b256 python $R/tools/step_profile.py 256 30 5 epoch
+prof bio_step python $R/tools/bio_step_profile.py 256 30
+prof ctx_step python $R/tools/ctx_step_profile.py 256 30
+grep -h "k_adam\|k_head_fwd\|k_edge_ce\|k_edge_dl\|k_ctx_scores" $O/*_kstats.txt
+tail -n 3 $O/step_b256.log | head -1; tail -n 3 $O/bio_step.log | head -1; tail -n 3 $O/ctx_step.log | head -1
+cd $R
+python bench.py > $O/bench.json 2> $O/bench.err
+python - <<PY
+import json
+b=json.loads(open("$O/bench.json").read().strip().splitlines()[-1])
+print({k:b[k] for k in ("value","ms_per_step")}, b.get("hipgraph_replay",{}).get("ms_per_step"), b.get("contextpred",{}).get("ms_per_step"), b.get("bio_masking",{}).get("ms_per_step"))
+PY
