@@ -1070,18 +1070,37 @@ def test_segment_softmax_and_max_pool(sorted_batch):
     assert torch.equal(xd.grad.cpu(), x.grad)
 
 
-@pytest.mark.parametrize("shape", ["ego_nets", "big_graphs", "one_component", "singletons"])
+@pytest.fixture
+def tile_kernel(request, monkeypatch):
+    """PGNN_TILE_PIPE: "0" = load / wait / gather per tile (what small batches run), "2" = loader wave + consumers with dynamic tile
+    tickets (what batches from ~128 rows per CU on run), forced at the test's sizes"""
+    monkeypatch.setenv("PGNN_TILE_PIPE", request.param)
+    _ops().load().pgnn_reload_env()
+    yield request.param
+    monkeypatch.delenv("PGNN_TILE_PIPE")
+    _ops().load().pgnn_reload_env()
+
+
+@pytest.mark.parametrize("tile_kernel", ["0", "2"], indirect=True)
+@pytest.mark.parametrize("shape", ["ego_nets", "many_ego_nets", "big_graphs", "one_component", "singletons"])
 @pytest.mark.parametrize("gcn", [False, True])
-def test_tiled_neighbor_sum_is_bit_identical(shape, gcn):
+def test_tiled_neighbor_sum_is_bit_identical(shape, gcn, tile_kernel):
     """csrc/tile.hip: closed-interval tiles from pgnn_graph_tiles + the graph-resident neighbour sum == pgnn_neighbor_sum
-    bit for bit, on both CSRs; "big_graphs" have more nodes than one 48-row chunk (cross-chunk sources take the memory
-    path), "one_component" is a single interval of 3000 nodes, "singletons" has isolated nodes (one-node intervals)"""
+    bit for bit, on both CSRs and with both tile kernels; "big_graphs" have more nodes than one chunk (cross-chunk sources take
+    the memory path, and consecutive tiles that cannot share the row ring are loaded late), "many_ego_nets" gives every CU
+    several tiles (the pipelined kernel's ring placement and ticket hand-out), "one_component" is a single interval of 3000
+    nodes, "singletons" has isolated nodes (one-node intervals)"""
     ops = _ops()
     import numpy as np
     if shape == "ego_nets":
         b = hostdata.bio_masking_batch(40, seed=6)
         ei, n = b.edge_index, b.x.size(0)
         want_tiles = 40
+    elif shape == "many_ego_nets":
+        b = hostdata.bio_masking_batch(96, seed=16)
+        reps, n1 = 12, b.x.size(0)
+        ei = torch.cat([b.edge_index + r * n1 for r in range(reps)], dim=1)
+        n, want_tiles = reps * n1, 96 * reps
     elif shape == "big_graphs":
         rng = np.random.default_rng(3)
         parts, off = [], 0
@@ -1111,12 +1130,18 @@ def test_tiled_neighbor_sum_is_bit_identical(shape, gcn):
     dinv = g.dinv if gcn else None
     for ptr, nbr in ((g.in_ptr, g.in_src), (g.out_ptr, g.out_dst)):
         plain = ops._neighbor_sum(x, ptr, nbr, dinv, n, 300)
-        tiled = ops._neighbor_sum(x, ptr, nbr, dinv, n, 300, tiles=g.tiles)
-        assert torch.equal(plain, tiled)
+        for _ in range(3 if shape == "many_ego_nets" else 1):  # (repeat: the ticket slots must come back clean)
+            tiled = ops._neighbor_sum(x, ptr, nbr, dinv, n, 300, tiles=g.tiles)
+            assert torch.equal(plain, tiled)
+    if shape == "ego_nets":  # a source matrix whose rows are NOT adjacent in memory (the backward's d agg is half of a [N, 600] buffer)
+        wide = torch.randn(n, 600, device=DEV)
+        assert torch.equal(ops._neighbor_sum(wide[:, :300], g.in_ptr, g.in_src, dinv, n, 300),
+                           ops._neighbor_sum(wide[:, :300], g.in_ptr, g.in_src, dinv, n, 300, tiles=g.tiles))
 
 
+@pytest.mark.parametrize("tile_kernel", ["0", "2"], indirect=True)
 @pytest.mark.parametrize("gcn", [False, True])
-def test_bio_aggregate_fused_tile_path_is_bit_identical(gcn, monkeypatch):
+def test_bio_aggregate_fused_tile_path_is_bit_identical(gcn, monkeypatch, tile_kernel):
     """bio GINConv / GCNConv aggregate: ONE graph-resident launch (neighbour sum + edge-feature product, csrc/tile.hip)
     == the two-launch path (pgnn_neighbor_sum + pgnn_rowfeat_matmul_fwd), forward and backward, bit for bit"""
     ops = _ops()
