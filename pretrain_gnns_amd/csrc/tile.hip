@@ -222,8 +222,8 @@ __global__ void __launch_bounds__(kThreads) k_neighbor_sum_tile(const float* __r
 //     descriptor; the other 15 waves are CONSUMERS (12 groups of 75 threads at D = 300) that gather out of LDS and store rows
 //     they never wait for.  The split is by wave, not by phase, because hipcc puts `s_waitcnt vmcnt(0)` in front of every LDS
 //     read that follows an LDS-DMA on the same path -- on a path that only consumes there is none;
-//   * rows live in one ring of kCap rows: tile j + 1 goes behind tile j if it fits there, else in front of it if tile j starts
-//     high enough, else it is loaded after tile j's gather (two large ego nets in a row: no overlap for that pair); neighbour
+//   * rows live in one buffer of kCap rows that consecutive tiles fill from opposite ends: tile j + 1 is loaded under tile j's
+//     gather whenever the two fit together, else after it (two large ego nets in a row: no overlap for that pair); neighbour
 //     ids (kIdxSlot per tile, the rest is read from memory), CSR pointers, feature sums and descriptors have two slots each;
 //   * a tile longer than kCap rows is walked in chunks of kCap rows (sources outside the chunk come from memory, as above).
 // Barrier protocol per item k (a tile or a chunk): loader [desc k written, DMAs of k landed] A_k [stage k + 1, or, if it has to
@@ -231,6 +231,7 @@ __global__ void __launch_bounds__(kThreads) k_neighbor_sum_tile(const float* __r
 // k_neighbor_sum_tile and to pgnn_neighbor_sum.
 constexpr int kCap = 104;        // 124.8 KB of rows at D = 300
 constexpr int kIdxSlot = 1280;   // a 40-node ego net has ~760 in-edges
+constexpr int kIdxPitch = kIdxSlot + 8;   // + padding a full batch may read past the staged ids
 constexpr int kPtrSlot = kCap + 8;
 constexpr int kConsumerThreads = kThreads - 64;
 
@@ -256,8 +257,8 @@ __global__ void __launch_bounds__(kThreads) k_neighbor_sum_tile_pipe(const float
   constexpr int AUX = NT ? 2 : 0;
   const int gs = dim >> 2;
   float4* rows = reinterpret_cast<float4*>(smem);                       // [kCap][gs]
-  int* idxS = reinterpret_cast<int*>(rows + kCap * gs);                 // [2][kIdxSlot]
-  int* ptrS = idxS + 2 * kIdxSlot;                                      // [2][kPtrSlot]
+  int* idxS = reinterpret_cast<int*>(rows + kCap * gs);                 // [2][kIdxPitch]
+  int* ptrS = idxS + 2 * kIdxPitch;                                     // [2][kPtrSlot]
   float* cfS = reinterpret_cast<float*>(ptrS + 2 * kPtrSlot);           // [2][kCap * kMaxFeat]
   float4* tabL = reinterpret_cast<float4*>(cfS + 2 * kCap * kMaxFeat);  // [kc][gs]
   int* desc = reinterpret_cast<int*>(tabL + kMaxFeat * gs);  // [2][8]: c0, c1, e0, ring row, valid, late-next (plain LDS accesses: the
@@ -307,7 +308,7 @@ __global__ void __launch_bounds__(kThreads) k_neighbor_sum_tile_pipe(const float
       for (int base = 0; base <= cnt; base += 64)
         if (base + lane <= cnt) __builtin_amdgcn_global_load_lds(PGNN_GPTR(ptr + c0 + base + lane), PGNN_LPTR(pd + base), 4, 0, 0);
       const int ne = min(e1 - e0, kIdxSlot);
-      int* id = idxS + slot * kIdxSlot;
+      int* id = idxS + slot * kIdxPitch;
       for (int base = 0; base < ne; base += 64)
         if (base + lane < ne) __builtin_amdgcn_global_load_lds(PGNN_GPTR(nbr + e0 + base + lane), PGNN_LPTR(id + base), 4, 0, 0);
       if (cfeat) {
@@ -360,11 +361,13 @@ __global__ void __launch_bounds__(kThreads) k_neighbor_sum_tile_pipe(const float
           ne1 = ptr[n1];
         }
       }
+      // items alternate between the two ends of the row ring (even: from row 0 up, odd: from row kCap down), so two consecutive
+      // items share it whenever their rows add up to at most kCap -- behind-or-in-front placement lost another 13 % of the pairs
+      // to fragmentation
       int noff = -1;
       if (nvalid) {
         const int cnt0 = c1 - c0, cnt1 = n1 - n0;
-        if (off + cnt0 + cnt1 <= kCap) noff = off + cnt0;
-        else if (cnt1 <= off) noff = 0;
+        if (cnt0 + cnt1 <= kCap) noff = (slot ^ 1) ? kCap - cnt1 : 0;
       }
       const bool late = nvalid && noff < 0;
       if (lane == 0) {
@@ -377,7 +380,7 @@ __global__ void __launch_bounds__(kThreads) k_neighbor_sum_tile_pipe(const float
       if (nvalid) {
         if (late) {
           tile_barrier();  // B_k: the consumers are done with item k, whose space item k + 1 needs
-          noff = 0;
+          noff = (slot ^ 1) ? kCap - (n1 - n0) : 0;
         }
         stage(n0, n1, ne0, ne1, noff, slot ^ 1);
       }
@@ -412,7 +415,7 @@ __global__ void __launch_bounds__(kThreads) k_neighbor_sum_tile_pipe(const float
     const int cnt = c1 - c0;
     const float4* rowsB = rows + off * gs;
     const int* ptrL = ptrS + slot * kPtrSlot;
-    const int* idxL = idxS + slot * kIdxSlot;
+    const int* idxL = idxS + slot * kIdxPitch;
     const float* cfL = cfS + slot * kCap * kMaxFeat;
     if (g < groups) {
       for (int li = g; li < cnt; li += groups) {
@@ -426,9 +429,12 @@ __global__ void __launch_bounds__(kThreads) k_neighbor_sum_tile_pipe(const float
           constexpr bool FULL = decltype(full_tag)::value;
           unsigned dd[kBatch];
           bool slow = p + kBatch > kIdxSlot;
+          // (a full batch reads kBatch adjacent ids from one clamped start -- two ds_read2_b32 instead of four clamped ds_read_b32;
+          // ids past the staged ones are padding the slow branch below never uses)
+          const int pb = min(p, kIdxSlot);
 #pragma unroll
           for (int j = 0; j < kBatch; ++j)
-            dd[j] = (unsigned)(idxL[min(FULL ? p + j : min(p + j, p + nv - 1), kIdxSlot - 1)] - c0);
+            dd[j] = (unsigned)(idxL[FULL ? pb + j : min(min(p + j, p + nv - 1), kIdxSlot - 1)] - c0);
 #pragma unroll
           for (int j = 0; j < kBatch; ++j) slow |= (FULL || j < nv) & (dd[j] >= (unsigned)cnt);
           if (__any(slow)) {
@@ -528,7 +534,7 @@ int pgnn_neighbor_sum_tiled(const float* x, int64_t ldx, const int32_t* ptr, con
   hipStream_t st = (hipStream_t)stream;
 #define PGNN_TILE_ARGS x, ldx, ptr, nbr, dinv, tile_start, num_tiles, out, ldo, (int)num_nodes, (int)dim, cfeat, (int)kc, table, ldt, feat_out, ld_feat_out
   const int dbg = env_knob("PGNN_TILE_DEBUG", 0);
-  const size_t lds_pipe = (size_t)kCap * dim * sizeof(float) + (size_t)(2 * kIdxSlot + 2 * kPtrSlot) * sizeof(int) +
+  const size_t lds_pipe = (size_t)kCap * dim * sizeof(float) + (size_t)(2 * kIdxPitch + 2 * kPtrSlot) * sizeof(int) +
                           (size_t)2 * kCap * kMaxFeat * sizeof(float) + (size_t)kMaxFeat * dim * sizeof(float) + 64 + 64;
   // the pipelined kernel pays for its single loader wave and its tickets when a CU gets one or two tiles (256 ego nets: 25 us
   // against 17); from ~128 rows per CU on it wins (4 096 ego nets, neighbour sum + edge-feature product: 168 us against 247).
