@@ -617,8 +617,13 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: piece selection compiles to scalar code
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x, p.nxcd);
-  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  // PP (persistent): the workgroup walks tiles q = blockIdx.x, + gridDim.x, ... and keeps its DMA ring running ACROSS them -- the
+  // last STAGES - 1 k-steps of a tile fetch the first stages of the next one, so only the first tile of a workgroup pays the
+  // pipeline fill, and no tile pays a workgroup launch / retirement (together 6.6-8 us of a 20 us tile at 41 269 x 300 x 600,
+  // where a CU holds ONE of these workgroups and nothing else overlaps them)
+  const int ntiles = tiles_n * ((p.M + BM - 1) / BM);
+  int tile = xcd_remap(blockIdx.x, gridDim.x, p.nxcd);
+  int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
   const int nk = (p.K + BK - 1) / BK;
 
   // ---- this wave's DMA pieces: piece d < PA = rows 8 d .. 8 d + 7 of the A image, else 16 rows of one B plane.  Every wave
@@ -630,28 +635,31 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
   // advances by one k-step of bytes (128 for the fp32 A image, 64 for a bf16 plane); the LDS address is wave-uniform.
   const unsigned char* src[NJ];
   int koff[NJ], klast[NJ], kstep[NJ], ldsoff[NJ];
+  auto set_pieces = [&](int pm0, int pn0) {  // the DMA sources of tile (pm0, pn0), offsets back at its first k-step
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int d = min(wave + j * NW, NP - 1);
-    if (d < PA) {
-      const int row = 8 * d + (lane >> 3);
-      const int c = (lane & 7) ^ (((lane >> 3) & 6) | (d & 1));  // logical 16-byte chunk stored at position lane & 7
-      koff[j] = 16 * c;
-      klast[j] = 4 * (p.K - 4);
-      kstep[j] = BK * 4;
-      ldsoff[j] = d * 1024;
-      src[j] = reinterpret_cast<const unsigned char*>(p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda);
-    } else {
-      const int q = (d - PA) / PB, pb = (d - PA) % PB;
-      const int row = 16 * pb + (lane >> 2);
-      const int c = (lane & 3) ^ ((-(lane >> 4)) & 3);
-      koff[j] = 16 * c;
-      klast[j] = 2 * ((int)p.ldbp - 8);
-      kstep[j] = BK * 2;
-      ldsoff[j] = A_BYTES + (d - PA) * 1024;
-      src[j] = reinterpret_cast<const unsigned char*>(p.Bp + q * p.bplane + (int64_t)min(n0 + row, p.N - 1) * p.ldbp);
+    for (int j = 0; j < NJ; ++j) {
+      const int d = min(wave + j * NW, NP - 1);
+      if (d < PA) {
+        const int row = 8 * d + (lane >> 3);
+        const int c = (lane & 7) ^ (((lane >> 3) & 6) | (d & 1));  // logical 16-byte chunk stored at position lane & 7
+        koff[j] = 16 * c;
+        klast[j] = 4 * (p.K - 4);
+        kstep[j] = BK * 4;
+        ldsoff[j] = d * 1024;
+        src[j] = reinterpret_cast<const unsigned char*>(p.A + (int64_t)min(pm0 + row, p.M - 1) * p.lda);
+      } else {
+        const int q = (d - PA) / PB, pb = (d - PA) % PB;
+        const int row = 16 * pb + (lane >> 2);
+        const int c = (lane & 3) ^ ((-(lane >> 4)) & 3);
+        koff[j] = 16 * c;
+        klast[j] = 2 * ((int)p.ldbp - 8);
+        kstep[j] = BK * 2;
+        ldsoff[j] = A_BYTES + (d - PA) * 1024;
+        src[j] = reinterpret_cast<const unsigned char*>(p.Bp + q * p.bplane + (int64_t)min(pn0 + row, p.N - 1) * p.ldbp);
+      }
     }
-  }
+  };
+  set_pieces(m0, n0);
   auto issue_piece = [&](int j, int stage) {
     __builtin_amdgcn_global_load_lds(PGNN_GPTR(src[j] + min(koff[j], klast[j])), PGNN_LPTR(smem3w + stage * STAGE + ldsoff[j]), 16, 0, 0);
     koff[j] += kstep[j];
@@ -757,18 +765,23 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
       for (int q = 0; q < 3; ++q) nxt[i][q] = __builtin_bit_cast(bf16x8, pl[i][q]);
   };
 
-  // epilogue operands fetched BEFORE the DMAs (older than every one of them: they land first, and no ordinary load sits in the
-  // k-loop): the ReLU mask of a backward-data product, the bias of a forward one (clamped, unconditional)
+  // epilogue operands: the ReLU mask of a backward-data product, the bias of a forward one (clamped, unconditional loads).  One
+  // tile per workgroup: fetched BEFORE the DMAs (older than every one of them: they land first, and no ordinary load sits in the
+  // k-loop).  Persistent: fetched in front of a tile's LAST k-step, which is straight-line code up to the epilogue, so hipcc
+  // counts the DMAs issued behind them and waits for exactly these loads.
   float4 mk[EPI == EPI_MASK ? MI : 1][NI];
   float4 bv[NI];
-  if constexpr (EPI == EPI_MASK) gemm_prefetch_mask<MI, NI>(p, mk, m0 + wm0, n0 + wn0, lane);
-  if constexpr (EPI == EPI_BIAS) {
+  auto prefetch_epi = [&]() {
+    if constexpr (EPI == EPI_MASK) gemm_prefetch_mask<MI, NI>(p, mk, m0 + wm0, n0 + wn0, lane);
+    if constexpr (EPI == EPI_BIAS) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      bv[j] = f4_zero();
-      if (p.bias) bv[j] = *reinterpret_cast<const float4*>(p.bias + min(n0 + wn0 + j * 16 + fk * 4, p.N - 4));
+      for (int j = 0; j < NI; ++j) {
+        bv[j] = f4_zero();
+        if (p.bias) bv[j] = *reinterpret_cast<const float4*>(p.bias + min(n0 + wn0 + j * 16 + fk * 4, p.N - 4));
+      }
     }
-  }
+  };
+  if constexpr (!PP) prefetch_epi();
 #pragma unroll
   for (int q = 0; q < STAGES - 1; ++q)
     if (q < nk) issue(q, q);
@@ -786,9 +799,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
   static_assert(STAGES >= 3, "k_gemm3w needs a 3-deep ring");
   // barrier t: every wave's pieces of steps <= t + 1 are in LDS (step t reads the first fragments of step t + 1), and every
   // wave is done with the buffer of step t - 1, which the DMAs of step t + STAGES - 1 refill; steps t + 2 .. t + STAGES - 2
-  // stay in flight
-  auto sync = [&](int t) {
-    const int infl = max(0, min(t + STAGES - 2, nk - 1) - (t + 1));
+  // stay in flight.  `cont`: the stream of steps continues into another tile (persistent), so the steady-state count holds to the
+  // tile's end.  (Loads and stores that are not DMAs -- the epilogue's -- only make a counted wait stricter: they are older.)
+  auto sync = [&](int t, bool cont) {
+    const int infl = cont ? STAGES - 3 : max(0, min(t + STAGES - 2, nk - 1) - (t + 1));
     if (STAGES >= 4 && infl == STAGES - 3) gemm_wait_vmcnt_imm<(STAGES >= 4 ? STAGES - 3 : 0) * NJ>();
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // (the builtin, not inline asm: hipcc's own s_waitcnt pass then KNOWS that no LDS read is outstanding behind the barrier --
@@ -798,7 +812,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
     __builtin_amdgcn_s_barrier();
   };
   bf16x8 a0[MI][3], a1[MI][3];
-  sync(0);
+  sync(0, false);
   {
     f32x4 lo[MI], hi[MI];
     aload(0, lo, hi);
@@ -815,42 +829,168 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
   // (the first fragments of step t + 1 are read unconditionally: behind the last step that is a stale buffer, results dropped)
   using Yes = std::integral_constant<bool, true>;
   using No = std::integral_constant<bool, false>;
+  auto swap_back = [&]() {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a0[i][q] = a1[i][q];
+  };
+  // ---- epilogue (the C/D register layout of gemm_epilogue_pre): lane holds C[m0 + wm0 + 16 i + fr][n0 + wn0 + 16 j + 4 fk + 0..3]
+  auto epilogue = [&]() {
+    float* C = p.C;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + wn0 + j * 16 + fk * 4;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int mb = m0 + wm0 + i * 16, m = mb + fr;
+        float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if constexpr (EPI == EPI_BIAS) {
+          v = f4_add(v, bv[j]);
+          if (p.relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          }
+          if (p.colstat) {  // (uniform) per-16-row-block column sums and squared deviations, see gemm_epilogue_pre
+            const int cnt = min(16, p.M - mb);
+            if (cnt > 0) {
+              const bool ok = fr < cnt;
+              float4 sm = ok ? v : f4_zero();
+              sm.x = row16_sum(sm.x); sm.y = row16_sum(sm.y); sm.z = row16_sum(sm.z); sm.w = row16_sum(sm.w);
+              const float inv = 1.f / (float)cnt;
+              float4 q;
+              q.x = ok ? v.x - sm.x * inv : 0.f; q.y = ok ? v.y - sm.y * inv : 0.f;
+              q.z = ok ? v.z - sm.z * inv : 0.f; q.w = ok ? v.w - sm.w * inv : 0.f;
+              q.x = row16_sum(q.x * q.x); q.y = row16_sum(q.y * q.y); q.z = row16_sum(q.z * q.z); q.w = row16_sum(q.w * q.w);
+              if (fr == 0 && n < p.N) {
+                float* cs = p.colstat + (int64_t)(mb >> 4) * 2 * p.N + n;
+                *reinterpret_cast<float4*>(cs) = sm;
+                *reinterpret_cast<float4*>(cs + p.N) = q;
+              }
+            }
+          }
+        }
+        if constexpr (EPI == EPI_MASK) {
+          const float4 k4 = mk[i][j];
+          if (!(k4.x > 0.f)) v.x = 0.f;
+          if (!(k4.y > 0.f)) v.y = 0.f;
+          if (!(k4.z > 0.f)) v.z = 0.f;
+          if (!(k4.w > 0.f)) v.w = 0.f;
+        }
+        if (m < p.M && n < p.N) *reinterpret_cast<float4*>(C + (int64_t)m * p.ldc + n) = v;
+      }
+    }
+  };
   // the first nk - (STAGES - 1) steps fetch a later step, the last STAGES - 1 do not: two loops, each unrolled by two over the
   // two A-fragment register sets (one loop choosing per step makes hipcc shuffle accumulators between the variants)
   const int n_main = max(0, nk - (STAGES - 1));
-  int it = 0;
   auto stamp = [&]() {
     if constexpr (DBG) asm volatile("" ::"v"(acc[MI - 1][NI - 1]), "v"(a0[0][2]), "v"(a1[0][2]), "v"(b[1][2]));
     tick(c_mma);
   };
+
+  if constexpr (PP) {
+    // ------------------------------------------------------------------------------------------------ persistent: a stream of tiles
+    // (launched only with nk >= STAGES.)  Ring position of a tile's step t: (sb + t) % STAGES, sb = steps of the earlier tiles.
+    int sb = 0;
+    bool first = true;
+    for (int q = blockIdx.x;;) {
+      const int qn = q + gridDim.x;
+      const int tn = (qn / gridDim.x) * gridDim.x + xcd_remap(blockIdx.x, gridDim.x, p.nxcd);  // (= qn with the block id remapped)
+      const bool has_next = tn < ntiles;
+      int it = 0;
+      auto st = [&](int t) { return (sb + t) % STAGES; };
+      for (; it + 2 <= n_main; it += 2) {
+        if (!(first && it == 0)) sync(it, true);
+        step(Yes{}, a0, a1, st(it), st(it + 1), st(it + STAGES - 1));
+        sync(it + 1, true);
+        step(Yes{}, a1, a0, st(it + 1), st(it + 2), st(it + STAGES));
+      }
+      if (it < n_main) {
+        if (!(first && it == 0)) sync(it, true);
+        step(Yes{}, a0, a1, st(it), st(it + 1), st(it + STAGES - 1));
+        ++it;
+        swap_back();
+      }
+      first = false;
+      // the last STAGES - 1 steps: their DMAs belong to the next tile (its steps 0 .. STAGES - 2), the very last one is peeled so
+      // that the epilogue's operands are fetched in straight-line code in front of it
+      if (has_next) {
+        set_pieces((tn / tiles_n) * BM, (tn % tiles_n) * BN);
+        if constexpr (STAGES == 3) {
+          sync(it, true);
+          step(Yes{}, a0, a1, st(it), st(it + 1), st(it + 2));
+          sync(it + 1, true);
+          prefetch_epi();
+          step(Yes{}, a1, a0, st(it + 1), st(it + 2), st(it + 3));
+        } else {
+          sync(it, true);
+          step(Yes{}, a0, a1, st(it), st(it + 1), st(it + 3));
+          sync(it + 1, true);
+          step(Yes{}, a1, a0, st(it + 1), st(it + 2), st(it + 4));
+          sync(it + 2, true);
+          prefetch_epi();
+          step(Yes{}, a0, a1, st(it + 2), st(it + 3), st(it + 5));
+          swap_back();
+        }
+      } else {
+        if constexpr (STAGES == 3) {
+          sync(it, false);
+          step(No{}, a0, a1, st(it), st(it + 1), 0);
+          sync(it + 1, false);
+          prefetch_epi();
+          step(No{}, a1, a0, st(it + 1), st(it + 2), 0);
+        } else {
+          sync(it, false);
+          step(No{}, a0, a1, st(it), st(it + 1), 0);
+          sync(it + 1, false);
+          step(No{}, a1, a0, st(it + 1), st(it + 2), 0);
+          sync(it + 2, false);
+          prefetch_epi();
+          step(No{}, a0, a1, st(it + 2), st(it + 3), 0);
+        }
+      }
+      epilogue();
+      if (!has_next) break;
+      // the next tile: accumulators back to zero (its fragments of step 0 are already in a0 / b[0], b[1])
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      sb = (sb + nk) % STAGES;
+      q = qn;
+      tile = tn;
+      m0 = (tile / tiles_n) * BM;
+      n0 = (tile % tiles_n) * BN;
+    }
+    return;
+  }
+
+  int it = 0;
   for (; it + 2 <= n_main; it += 2) {
-    if (it > 0) sync(it);
+    if (it > 0) sync(it, false);
     tick(c_wait);
     step(Yes{}, a0, a1, it % STAGES, (it + 1) % STAGES, (it + STAGES - 1) % STAGES);
     stamp();
-    sync(it + 1);
+    sync(it + 1, false);
     tick(c_wait);
     step(Yes{}, a1, a0, (it + 1) % STAGES, (it + 2) % STAGES, (it + STAGES) % STAGES);
     stamp();
   }
   if (it < n_main) {  // odd count: one more fetching step, then the sets swap back
-    if (it > 0) sync(it);
+    if (it > 0) sync(it, false);
     tick(c_wait);
     step(Yes{}, a0, a1, it % STAGES, (it + 1) % STAGES, (it + STAGES - 1) % STAGES);
     stamp();
     ++it;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) a0[i][q] = a1[i][q];
+    swap_back();
   }
   for (; it < nk; it += 2) {
-    if (it > 0) sync(it);
+    if (it > 0) sync(it, false);
     tick(c_wait);
     step(No{}, a0, a1, it % STAGES, (it + 1) % STAGES, 0);
     stamp();
     if (it + 1 < nk) {
-      sync(it + 1);
+      sync(it + 1, false);
       tick(c_wait);
       step(No{}, a1, a0, (it + 1) % STAGES, (it + 2) % STAGES, 0);
       stamp();
@@ -863,49 +1003,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
       o[0] = c_wait; o[1] = c_issue; o[2] = c_split; o[3] = c_mma; o[4] = gemm_clock() - c_start; o[5] = nk;
     }
   }
-  // ---- epilogue (the C/D register layout of gemm_epilogue_pre): lane holds C[m0 + wm0 + 16 i + fr][n0 + wn0 + 16 j + 4 fk + 0..3]
-  float* C = p.C;
-#pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int n = n0 + wn0 + j * 16 + fk * 4;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int mb = m0 + wm0 + i * 16, m = mb + fr;
-      float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-      if constexpr (EPI == EPI_BIAS) {
-        v = f4_add(v, bv[j]);
-        if (p.relu) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        }
-        if (p.colstat) {  // (uniform) per-16-row-block column sums and squared deviations, see gemm_epilogue_pre
-          const int cnt = min(16, p.M - mb);
-          if (cnt > 0) {
-            const bool ok = fr < cnt;
-            float4 sm = ok ? v : f4_zero();
-            sm.x = row16_sum(sm.x); sm.y = row16_sum(sm.y); sm.z = row16_sum(sm.z); sm.w = row16_sum(sm.w);
-            const float inv = 1.f / (float)cnt;
-            float4 q;
-            q.x = ok ? v.x - sm.x * inv : 0.f; q.y = ok ? v.y - sm.y * inv : 0.f;
-            q.z = ok ? v.z - sm.z * inv : 0.f; q.w = ok ? v.w - sm.w * inv : 0.f;
-            q.x = row16_sum(q.x * q.x); q.y = row16_sum(q.y * q.y); q.z = row16_sum(q.z * q.z); q.w = row16_sum(q.w * q.w);
-            if (fr == 0 && n < p.N) {
-              float* cs = p.colstat + (int64_t)(mb >> 4) * 2 * p.N + n;
-              *reinterpret_cast<float4*>(cs) = sm;
-              *reinterpret_cast<float4*>(cs + p.N) = q;
-            }
-          }
-        }
-      }
-      if constexpr (EPI == EPI_MASK) {
-        const float4 k4 = mk[i][j];
-        if (!(k4.x > 0.f)) v.x = 0.f;
-        if (!(k4.y > 0.f)) v.y = 0.f;
-        if (!(k4.z > 0.f)) v.z = 0.f;
-        if (!(k4.w > 0.f)) v.w = 0.f;
-      }
-      if (m < p.M && n < p.N) *reinterpret_cast<float4*>(C + (int64_t)m * p.ldc + n) = v;
-    }
-  }
+  epilogue();
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, bool PP = false, bool DBG = false>
@@ -913,8 +1011,16 @@ int launch_gemm3w_s(const GemmArgs& p, hipStream_t st) {
   constexpr size_t lds = (size_t)STAGES * (BM * 128 + 3 * BN * 64);
   static_assert(lds <= 160 * 1024, "LDS ring too deep");
   const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N, BN));
+  if constexpr (!PP && !DBG) {
+    // two or more tiles per CU (a CU holds one of these workgroups): persistent workgroups that prefetch across tile boundaries.
+    // Measured (tools/gemm3w_bench.cpp, 300 -> 600 / 600 -> 300 backward-data): 10 249 rows 40.7 -> 36.2 / 40.1 -> 35.4 us,
+    // 41 269 rows 122 -> 114 / 135 -> 121 us; with 1.3-1.7 tiles per CU (6 747 rows, 64-row tiles) it is level or 3 % behind
+    if (tiles >= 2 * num_cu() && ceil_div(p.K, 32) >= STAGES && env_knob("PGNN_GEMM3W_PERSIST", 1))
+      return launch_gemm3w_s<BM, BN, WAVES_M, WAVES_N, STAGES, EPI, true, false>(p, st);
+  }
+  const int grid = PP ? std::min(tiles, num_cu()) : tiles;
   allow_big_lds((const void*)k_gemm3w<BM, BN, WAVES_M, WAVES_N, STAGES, EPI, PP, DBG>, lds);
-  hipLaunchKernelGGL((k_gemm3w<BM, BN, WAVES_M, WAVES_N, STAGES, EPI, PP, DBG>), dim3(tiles), dim3(64 * WAVES_M * WAVES_N), lds, st, p);
+  hipLaunchKernelGGL((k_gemm3w<BM, BN, WAVES_M, WAVES_N, STAGES, EPI, PP, DBG>), dim3(grid), dim3(64 * WAVES_M * WAVES_N), lds, st, p);
   return check_launch("gemm3w");
 }
 
