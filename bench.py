@@ -217,16 +217,17 @@ def aggregation_robustness(dev, graphs):
 
 def pmc_traffic(n, e, name="agg_pmc_traffic.json"):
     """HBM bytes per launch of an aggregation kernel from the committed rocprofv3 PMC pass
-    (profiles/r02/agg_pmc_traffic.json, bio_agg_pmc_traffic.json: FETCH_SIZE x2 (gfx950 half-count) + WRITE_SIZE, separate
+    (profiles/r03/agg_pmc_traffic.json, bio_agg_pmc_traffic.json: FETCH_SIZE x2 (gfx950 half-count) + WRITE_SIZE, separate
     --pmc runs of tools/agg_bench.py / tools/bio_tile_pmc.py on this same batch).  Counters cannot be read from inside this
     process, so the figure is only quoted when the recorded batch shape matches; otherwise null."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02", name)
-    try:
-        rec = json.load(open(path))
-        if rec["nodes"] == n and rec["edges"] == e:
-            return int(rec["hbm_bytes_per_launch"]), "profiles/r02/" + name
-    except (OSError, KeyError, ValueError):
-        pass
+    for rnd in ("r03", "r02"):  # (the newest pass whose batch AND kernel this run reproduces)
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", rnd, name)
+        try:
+            rec = json.load(open(path))
+            if rec["nodes"] == n and rec["edges"] == e:
+                return int(rec["hbm_bytes_per_launch"]), "profiles/%s/%s" % (rnd, name)
+        except (OSError, KeyError, ValueError):
+            pass
     return None, None
 
 
@@ -599,7 +600,7 @@ def bio_roofline(dev, ds=None, num_graphs=1024):
     alg = 3604.0 * n + 40.0 * e
     gbs = alg / (ms * 1e-3) / 1e9
     traffic, traffic_src = pmc_traffic(n, e, "bio_agg_pmc_traffic.json")
-    return {"bound": "hbm", "kernel": "bio GINConv aggregate = k_neighbor_sum_tile (graph-resident: neighbour sum + edge-feature product in one launch, csrc/tile.hip)", "achieved": round(gbs, 1),
+    return {"bound": "hbm", "kernel": "bio GINConv aggregate = k_neighbor_sum_tile_pipe<false,true> (graph-resident: neighbour sum + edge-feature product in one launch; a loader wave DMAs the next ego net into LDS under the gathers of this one, tiles handed out by ticket; csrc/tile.hip)", "achieved": round(gbs, 1),
                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                        "ms_per_launch": round(ms, 4), "ms_per_launch_std": round(float(per.std()), 4),
                        "algorithmic_bytes_per_launch": int(alg), "nodes": n, "edges": e,
