@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PGNN_ABI_VERSION 6
+#define PGNN_ABI_VERSION 7
 /* uint32 words behind every `counter` argument below: the arrival tickets of a launch whose last block folds the others'
  * results (one top word + up to 32 group words: same-address atomics retire at ~50 ns each, see csrc/common.h).  Zero before
  * the first call, left zero by every call; one buffer per device serves all calls of a stream. */
@@ -417,6 +417,10 @@ typedef struct pgnn_gin_layer {
   float momentum, eps;
   /* gradients, written by the backward only */
   float *demb /* [9,dim]: rows 0..5 d emb1, 6..8 d emb2 */, *dw1, *db1, *dw2, *db2, *dgamma, *dbeta;
+  /* batch_norms[l].num_batches_tracked (device int64) or NULL: incremented by a stack FORWARD call in training mode, as
+   * nn.BatchNorm1d.forward does -- inside a launch the call makes anyway (torch's own increment of the five counters is one more
+   * launch and ~70 us of host time per train step) */
+  int64_t* num_batches_tracked;
 } pgnn_gin_layer;
 
 size_t pgnn_chem_gin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t rows1, int64_t rows2,

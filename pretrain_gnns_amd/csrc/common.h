@@ -110,6 +110,10 @@ inline int env_knob(const char* name, int dflt) {
   return s->set ? s->value : dflt;  // the default belongs to the call site, not to the cache
 }
 
+// (linear.hip) pgnn_split_weights + `nbump` device int64 counters incremented by the same launch (BatchNorm's num_batches_tracked)
+int split_weights_bump(const float* const* src, void* const* dst, const int64_t* rows, const int64_t* cols, const int32_t* transpose,
+                       int64_t count, int64_t* const* bump, int nbump, hipStream_t stream);
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -61,8 +61,9 @@ inline bool mlp_wp(int64_t n, int64_t d_in, int64_t d_hid, int64_t d_out, int nu
          pgnn_linear_wp_preferred(n, d_out, d_hid) && pgnn_linear_wp_preferred(n, d_hid, d_in);
 }
 // planes of W1 / W2 (transpose = 0) or W1^T / W2^T (1) of every layer: p1[l], p2[l] carved from `base`
+// (bump: also increment the layers' num_batches_tracked -- a training-mode forward -- in the same launch)
 inline int split_mlp_weights(const pgnn_gin_layer* layers, int num_layer, int64_t d_in, int64_t d_hid, int64_t d_out, int transpose,
-                             char* base, void** p1, void** p2, hipStream_t st) {
+                             char* base, void** p1, void** p2, hipStream_t st, bool bump = false) {
   const float* src[2 * kMaxPlaneLayers];
   void* dst[2 * kMaxPlaneLayers];
   int64_t rows[2 * kMaxPlaneLayers], cols[2 * kMaxPlaneLayers];
@@ -75,7 +76,36 @@ inline int split_mlp_weights(const pgnn_gin_layer* layers, int num_layer, int64_
     src[2 * l] = layers[l].w1; dst[2 * l] = p1[l]; rows[2 * l] = d_hid; cols[2 * l] = d_in; tr[2 * l] = transpose;
     src[2 * l + 1] = layers[l].w2; dst[2 * l + 1] = p2[l]; rows[2 * l + 1] = d_out; cols[2 * l + 1] = d_hid; tr[2 * l + 1] = transpose;
   }
-  return pgnn_split_weights(src, dst, rows, cols, tr, 2 * num_layer, st);
+  int64_t* counters[kMaxPlaneLayers];
+  int nb = 0;
+  if (bump)
+    for (int l = 0; l < num_layer; ++l)
+      if (layers[l].num_batches_tracked) counters[nb++] = layers[l].num_batches_tracked;
+  return split_weights_bump(src, dst, rows, cols, tr, 2 * num_layer, counters, nb, st);
+}
+// the same increment as a launch of its own, for the calls that split nothing (small batches on the fp32-MFMA products)
+__global__ void k_bump_counters(long long* c0, long long* c1, long long* c2, long long* c3, long long* c4, long long* c5, long long* c6,
+                                long long* c7) {
+  long long* c[8] = {c0, c1, c2, c3, c4, c5, c6, c7};
+  if (threadIdx.x < 8 && c[threadIdx.x]) *c[threadIdx.x] += 1;
+}
+inline int bump_batches_tracked(const pgnn_gin_layer* layers, int num_layer, hipStream_t st) {
+  long long* c[8];
+  int nb = 0;
+  for (int l = 0; l < num_layer; ++l) {
+    if (!layers[l].num_batches_tracked) continue;
+    c[nb++] = reinterpret_cast<long long*>(layers[l].num_batches_tracked);
+    if (nb == 8 || l == num_layer - 1) {
+      for (int q = nb; q < 8; ++q) c[q] = nullptr;
+      hipLaunchKernelGGL(k_bump_counters, dim3(1), dim3(64), 0, st, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+      nb = 0;
+    }
+  }
+  if (nb) {
+    for (int q = nb; q < 8; ++q) c[q] = nullptr;
+    hipLaunchKernelGGL(k_bump_counters, dim3(1), dim3(64), 0, st, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+  }
+  return check_launch("bump_batches_tracked");
 }
 constexpr int64_t kStatsInGemmMaxRows = 32768;  // pgnn_chem_gin_stack_fwd: BatchNorm statistics from the GEMM epilogue up to here
 constexpr int kMaxTransposed = 8;  // layers whose weights pgnn_chem_gin_stack_bwd transposes up front (one 16-job launch)
@@ -283,8 +313,10 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
   const size_t opb = op_ws_bytes(n, dim);
   void *wp1[kMaxPlaneLayers], *wp2[kMaxPlaneLayers];
   const bool wp = mlp_wp(n, dim, 2 * dim, dim, num_layer) && ws_bytes >= opb + (size_t)num_layer * mlp_planes_bytes(dim, 2 * dim, dim);
-  if (wp && (rc = split_mlp_weights(layers, num_layer, dim, 2 * dim, dim, 0, static_cast<char*>(ws) + opb, wp1, wp2, (hipStream_t)stream)))
+  if (wp && (rc = split_mlp_weights(layers, num_layer, dim, 2 * dim, dim, 0, static_cast<char*>(ws) + opb, wp1, wp2, (hipStream_t)stream,
+                                    training != 0)))
     return rc;
+  if (!wp && training && (rc = bump_batches_tracked(layers, num_layer, (hipStream_t)stream))) return rc;
   for (int l = 0; l < num_layer; ++l) {
     const pgnn_gin_layer& p = layers[l];
     float* a = acts + (size_t)l * 3 * nd;  // agg, z, y
@@ -689,8 +721,10 @@ int pgnn_bio_gin_stack_fwd(const float* h0, int64_t ldh0, const int32_t* in_ptr,
   void *wp1[kMaxPlaneLayers], *wp2[kMaxPlaneLayers];
   const size_t planes_b = (size_t)num_layer * mlp_planes_bytes(2 * dim, 2 * dim, dim);
   const bool wp = mlp_wp(n, 2 * dim, 2 * dim, dim, num_layer) && ws_bytes >= opb + planes_b;
-  if (wp && (rc = split_mlp_weights(layers, num_layer, 2 * dim, 2 * dim, dim, 0, static_cast<char*>(ws) + opb, wp1, wp2, (hipStream_t)stream)))
+  if (wp && (rc = split_mlp_weights(layers, num_layer, 2 * dim, 2 * dim, dim, 0, static_cast<char*>(ws) + opb, wp1, wp2, (hipStream_t)stream,
+                                    training != 0)))
     return rc;
+  if (!wp && training && (rc = bump_batches_tracked(layers, num_layer, (hipStream_t)stream))) return rc;
   // training-mode statistics of the mlp's BatchNorm1d(2D) from the epilogue of the product that writes its input (the chem form,
   // csrc/batchnorm.hip pgnn_bn_stats_fwd_blocks): no pass over `pre` for them, two launches less per layer
   const size_t blocks_b = align_up((size_t)ceil_div(n, 16) * 2 * 2 * dim * 4, 256);

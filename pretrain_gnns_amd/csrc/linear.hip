@@ -1058,8 +1058,11 @@ struct SplitJobs {
   unsigned short* dst[32];
   int rows[32], cols[32], ld[32];  // rows / cols of the OUTPUT planes, their row pitch
   int transpose[32];
+  long long* bump[16];  // device counters this launch increments by one (BatchNorm's num_batches_tracked), nbump of them
+  int nbump;
 };
 __global__ void __launch_bounds__(256) k_split_jobs(SplitJobs jobs) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < jobs.nbump) *jobs.bump[threadIdx.x] += 1;
   __shared__ float tile[32][33];
   const int j = blockIdx.y, rows = jobs.rows[j], cols = jobs.cols[j], ld = jobs.ld[j];
   const bool tr = jobs.transpose[j] != 0;
@@ -1386,9 +1389,17 @@ int pgnn_linear_wp_preferred(int64_t m, int64_t k, int64_t n) {
 
 int pgnn_split_weights(const float* const* src, void* const* dst, const int64_t* rows, const int64_t* cols, const int32_t* transpose,
                        int64_t count, pgnn_stream stream) {
-  PGNN_REQUIRE(count >= 0 && count <= 32, "split_weights: at most 32 matrices per call");
+  return pgnn::split_weights_bump(src, dst, rows, cols, transpose, count, nullptr, 0, (hipStream_t)stream);
+}
+}  // extern "C"
+
+int pgnn::split_weights_bump(const float* const* src, void* const* dst, const int64_t* rows, const int64_t* cols, const int32_t* transpose,
+                             int64_t count, int64_t* const* bump, int nbump, hipStream_t stream) {
+  PGNN_REQUIRE(count >= 0 && count <= 32 && nbump >= 0 && nbump <= 16, "split_weights: at most 32 matrices (and 16 counters) per call");
   if (count == 0) return PGNN_OK;
   SplitJobs jobs{};
+  for (int j = 0; j < nbump; ++j) jobs.bump[j] = reinterpret_cast<long long*>(bump[j]);
+  jobs.nbump = nbump;
   int64_t most = 1;
   for (int j = 0; j < count; ++j) {
     PGNN_REQUIRE(src[j] && dst[j] && rows[j] > 0 && cols[j] > 0 && rows[j] < (1 << 24) && cols[j] < (1 << 24), "split_weights: bad job");
@@ -1398,9 +1409,11 @@ int pgnn_split_weights(const float* const* src, void* const* dst, const int64_t*
     jobs.ld[j] = (int)(ceil_div(jobs.cols[j], 32) * 32); jobs.transpose[j] = tr;
     most = std::max(most, ceil_div(jobs.rows[j], 32) * (jobs.ld[j] / 32));
   }
-  hipLaunchKernelGGL(k_split_jobs, dim3((int)std::min<int64_t>(most, 4096), (int)count), dim3(256), 0, (hipStream_t)stream, jobs);
+  hipLaunchKernelGGL(k_split_jobs, dim3((int)std::min<int64_t>(most, 4096), (int)count), dim3(256), 0, stream, jobs);
   return check_launch("split_weights");
 }
+
+extern "C" {
 
 int pgnn_linear_fwd_wp(const float* x, int64_t ldx, const void* wplanes, const float* bias, float* y, int64_t ldy, int64_t m, int64_t k,
                        int64_t n, int relu, float* colstat, pgnn_stream stream) {

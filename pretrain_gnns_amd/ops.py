@@ -35,8 +35,8 @@ def _workspace(nbytes, device):
     """scratch for ONE C call.  Every library call finishes with its workspace before it returns
     control to the stream's next kernel (all work is enqueued in order on the current stream), so a
     single grow-only buffer per (device, stream) replaces one allocator round trip per op."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(device).cuda_stream)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, stream_ptr(idx))
     buf = _ws_pool.get(key)
     need = max(int(nbytes), 256)
     if buf is None or buf.numel() < need:
@@ -1194,8 +1194,8 @@ class StackPlan:
 
     def layers(self, per_layer, tensors, bns, fields):
         key = tuple(t.data_ptr() for t in tensors) + tuple(
-            (rm.data_ptr() if rm is not None else 0, rv.data_ptr() if rv is not None else 0, mom, eps)
-            for rm, rv, mom, eps in bns)
+            (b[0].data_ptr() if b[0] is not None else 0, b[1].data_ptr() if b[1] is not None else 0, b[2], b[3],
+             b[4].data_ptr() if len(b) > 4 and b[4] is not None else 0) for b in bns)
         if key != self.key:
             require_cuda(*tensors)
             for t in tensors:
@@ -1207,10 +1207,12 @@ class StackPlan:
                 s_, p = arr[l], tensors[2 + l * per_layer:2 + (l + 1) * per_layer]
                 for name, t in zip(fields, p):
                     setattr(s_, name, t.data_ptr())
-                rm, rv, momentum, eps = bns[l]
+                rm, rv, momentum, eps = bns[l][:4]
+                nbt = bns[l][4] if len(bns[l]) > 4 else None
                 s_.running_mean = rm.data_ptr() if rm is not None else None
                 s_.running_var = rv.data_ptr() if rv is not None else None
                 s_.momentum, s_.eps = momentum, eps
+                s_.num_batches_tracked = nbt.data_ptr() if nbt is not None else None
             self.array, self.key = arr, key
         return self.array
 
@@ -1327,18 +1329,25 @@ def _stack_grad_layout(L, dim, rows1, rows2):
 _plans = weakref.WeakKeyDictionary()  # GNN module -> StackPlan (kept off the module: ctypes arrays do not deepcopy)
 
 
-def _bn_meta(bns):
-    """(running_mean, running_var, momentum, eps) per layer + the counters to bump, as nn.BatchNorm1d.forward
-    would handle them"""
+def _bn_meta(bns, in_call=False):
+    """(running_mean, running_var, momentum, eps, counter) per layer, as nn.BatchNorm1d.forward would handle them.
+    ``num_batches_tracked`` of a training-mode forward: incremented here (one torch launch for all layers, ~70 us of host
+    time), or -- ``in_call``: the GIN stack calls -- handed to the library as the fifth entry, which increments it inside a
+    launch it makes anyway.  momentum=None (cumulative average) needs the count on the host first and stays on the torch path."""
     meta, counters = [], []
     for bn in bns:
         momentum = 0.0 if bn.momentum is None else bn.momentum
+        counter = None
         if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-            counters.append(bn.num_batches_tracked)
             if bn.momentum is None:
                 momentum = 1.0 / float(bn.num_batches_tracked + 1)
+                counters.append(bn.num_batches_tracked)
+            elif in_call and bn.num_batches_tracked.is_cuda and bn.num_batches_tracked.dtype == torch.int64:
+                counter = bn.num_batches_tracked
+            else:
+                counters.append(bn.num_batches_tracked)
         meta.append((bn.running_mean if bn.track_running_stats else None,
-                     bn.running_var if bn.track_running_stats else None, float(momentum), float(bn.eps)))
+                     bn.running_var if bn.track_running_stats else None, float(momentum), float(bn.eps), counter))
     if counters:
         torch._foreach_add_(counters, 1)  # num_batches_tracked of every layer in one launch
     return meta
@@ -1357,9 +1366,9 @@ def chem_gin_stack(owner, x_idx, graph, x_embedding1, x_embedding2, convs, bns, 
         conv.mlp[2].weight, conv.mlp[2].bias, bn.weight, bn.bias)]
     seed = dropout_seed() if drop_p > 0 else 0
     if x_embedding1.weight.requires_grad and _use_direct(flat):
-        return ChemGINStack.apply(x_idx, graph, (training, _bn_meta(bns), drop_p, seed, plan, flat),
+        return ChemGINStack.apply(x_idx, graph, (training, _bn_meta(bns, in_call=True), drop_p, seed, plan, flat),
                                   x_embedding1.weight, x_embedding2.weight)
-    return ChemGINStack.apply(x_idx, graph, (training, _bn_meta(bns), drop_p, seed, plan, None),
+    return ChemGINStack.apply(x_idx, graph, (training, _bn_meta(bns, in_call=True), drop_p, seed, plan, None),
                               x_embedding1.weight, x_embedding2.weight, *flat)
 
 
@@ -1427,10 +1436,11 @@ class BioGINStack(Function):
             s_, p = layers[l], params[8 * l:8 * l + 8]
             s_.emb1 = tables[l].data_ptr()
             s_.w1, s_.b1, s_.w2, s_.b2, s_.gamma, s_.beta = [t.data_ptr() for t in p[2:]]
-            rm, rv, momentum, eps = bns[l]
+            rm, rv, momentum, eps, nbt = bns[l]
             s_.running_mean = rm.data_ptr() if rm is not None else None
             s_.running_var = rv.data_ptr() if rv is not None else None
             s_.momentum, s_.eps = momentum, eps
+            s_.num_batches_tracked = nbt.data_ptr() if nbt is not None else None
         acts = torch.empty(L, 7, n, dim, dtype=torch.float32, device=dev)
         stats = torch.empty(L, 2, 2 * dim, dtype=torch.float32, device=dev)
         ws = _workspace(_ws_bytes("pgnn_bio_gin_stack_workspace_bytes", n, dim, L), dev)
@@ -1483,7 +1493,7 @@ def bio_gin_stack(h0, graph, convs):
     training = bns[0].training or bns[0].running_mean is None
     flat = [t for c in convs for t in (c.edge_encoder.weight, c.edge_encoder.bias, c.mlp[0].weight, c.mlp[0].bias,
                                        c.mlp[3].weight, c.mlp[3].bias, c.mlp[1].weight, c.mlp[1].bias)]
-    return BioGINStack.apply(h0, graph, (training, _bn_meta(bns)), *flat)
+    return BioGINStack.apply(h0, graph, (training, _bn_meta(bns, in_call=True)), *flat)
 
 
 # ------------------------------------------------------------------------------------ whole chem GCN / GraphSAGE network

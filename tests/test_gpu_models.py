@@ -628,6 +628,29 @@ def test_one_call_network_on_weight_planes_below_the_split_threshold(graphs, mon
         assert d <= 2e-2 * float(res[1][1][k].double().norm()) + 1e-4 * top, k
 
 
+@pytest.mark.parametrize("graphs", [4, 256])
+def test_num_batches_tracked_is_counted_inside_the_stack_call(graphs):
+    """nn.BatchNorm1d.forward adds one to num_batches_tracked per training-mode forward; the one-call GIN networks do it inside
+    a launch they make anyway (the weight-plane split at 256 graphs, a one-block launch at 4) instead of a torch launch:
+    +1 per training forward for every layer, nothing in eval mode, chem and bio"""
+    hchem, hbio = _hip()
+    torch.manual_seed(0)
+    m = hchem.GNN(5, 300, gnn_type="gin").to(DEV)
+    d = hostdata.chem_masking_batch(graphs, seed=2).to(DEV)
+    mb = hbio.GNN(3, 300, gnn_type="gin").to(DEV)
+    db = hostdata.bio_masking_batch(max(2, graphs // 8), seed=2).to(DEV)
+    for net, args, bns in ((m, (d.x, d.edge_index, d.edge_attr), list(m.batch_norms)),
+                           (mb, (db.x, db.edge_index, db.edge_attr), [c.mlp[1] for c in mb.gnns])):
+        net.train()
+        for k in range(1, 4):
+            net(*args)
+            assert [int(bn.num_batches_tracked) for bn in bns] == [k] * len(bns)
+        net.eval()
+        with torch.no_grad():
+            net(*args)
+        assert [int(bn.num_batches_tracked) for bn in bns] == [3] * len(bns)
+
+
 @pytest.mark.parametrize("graphs,layers", [(48, 5), (256, 5), (3, 2)])
 def test_batchnorm_statistics_from_the_gemm_epilogue_match_the_separate_pass(graphs, layers, monkeypatch):
     """one-call network with the training-mode BatchNorm statistics taken from the second product's epilogue (per-16-row
