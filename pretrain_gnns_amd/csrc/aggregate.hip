@@ -362,7 +362,14 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
                 int64_t ldo, int n, int dim, int npb, const float* __restrict__ pre_coef, int pre_relu,
                 unsigned long long* __restrict__ prof, const float* __restrict__ dinv) {
 #pragma clang fp contract(off)
-  constexpr int NREG = P + 3, NBUF = P + 1;
+  // POL bit 4 (PF): source rows OUTSIDE the ring window are fetched into registers ONE STEP AHEAD of their use (the step's edge
+  // slots are then staged one step earlier), instead of on the spot behind a wave-uniform branch that waits a memory round trip
+  // per batch: at 5.6 % such edges the on-the-spot path ran at 0.46 of the HBM roofline against 0.63 without any (bench.py's
+  // aggregation_robustness leg).  Two rows per node and step; a third one, or a step with more than 64 edges, still takes the branch.
+  constexpr bool PF = (POL & 16) != 0;
+  constexpr int EL = PF ? 1 : 0;  // steps by which the edge slots lead the rows
+  static_assert(!(PF && WEIGHT), "the prefetch variant does not carry the GCN normaliser of a far row");
+  constexpr int NREG = P + 3, NBUF = P + 1 + EL;
   constexpr int AUX = (POL & 1) ? 2 : 0;
   constexpr bool PROF = (POL & 8) != 0;
   unsigned long long t_begin = 0;
@@ -438,7 +445,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
     };
     if (n0 > 0) issue_rows(-1);
     for (int q = 0; q <= P; ++q) issue_rows(q);
-    for (int q = 0; q < P; ++q) issue_edges(q, ptr[min(n0 + q * kDmaG, n1)]);
+    for (int q = 0; q < P + EL; ++q) issue_edges(q, ptr[min(n0 + q * kDmaG, n1)]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // prologue: T, ptrL (consumers) and the first window (loader) are in LDS
     unsigned long long c_wait = 0, c_bar = 0, c_issue = 0;
@@ -450,7 +457,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
       __syncthreads();                // B(s)
       if (PROF) t2 = __builtin_readcyclecounter();
       issue_rows(s + 1 + P);
-      issue_edges(s + P, ptrL[min((s + P) * kDmaG, cnt)]);
+      issue_edges(s + P + EL, ptrL[min((s + P + EL) * kDmaG, cnt)]);
       if (PROF) {
         c_wait += t1 - t0;
         c_bar += t2 - t1;
@@ -503,6 +510,8 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
   if (active && g < cnt) { nb_beg = ptrL[g]; nb_end = ptrL[g + 1]; }
   unsigned long long c_cbar = 0, c_work = 0, t_prev = 0;
   if (PROF) t_prev = __builtin_readcyclecounter();
+  float4 pf0 = f4_zero(), pf1 = f4_zero();  // (PF) rows fetched for this step's node during the previous step: its first npf far
+  int npf = 0;                              // sources, in edge order (the summation below meets them in the same order)
   for (int s = 0; s < nsteps; ++s) {
     if (PROF) {
       const unsigned long long tb = __builtin_readcyclecounter();
@@ -538,19 +547,30 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
     // edges gathered per batch.  Measured on the roofline batch: 2 -> 225-234 us, 1 -> 240, 3/4 -> 245;
     // keeping the common bond-table rows in registers (select chain) was a loss (320-360 us).
     constexpr int CH = 2;
+    int nf = 0;  // (PF) far sources met so far
     for (int p = beg; p < end; p += CH) {
-      int sidx[CH], cd[CH];
+      int sidx[CH], cd[CH], psel[CH];
       bool slow = false;
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
         sidx[j] = 0;
         cd[j] = 0;
+        psel[j] = -1;
         if (p + j < end) {
           const int k = p + j - e0;
           if (k < kDmaEdges) {
             sidx[j] = idxB[k];
             if (TABLE) cd[j] = codeB[k] & 0xff;
-            slow |= (sidx[j] < win_lo) | (sidx[j] >= win_hi);
+            const bool far = (sidx[j] < win_lo) | (sidx[j] >= win_hi);
+            if (PF) {
+              if (far) {  // (rare: the whole wave skips this)
+                slow |= nf >= npf;
+                psel[j] = nf++;
+                sidx[j] = i;  // the LDS read below must stay inside the ring; its value is replaced
+              }
+            } else {
+              slow |= far;
+            }
           } else {
             slow = true;
           }
@@ -574,6 +594,9 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
         for (int j = 0; j < CH; ++j) {
           if (p + j < end) {
             v[j] = ring[slot_of(sidx[j]) * gs + c4];
+            if (PF) {
+              if (psel[j] >= 0) v[j] = psel[j] == 0 ? pf0 : pf1;
+            }
             if (TABLE) tv[j] = T4[cd[j] * gs + c4];
           }
         }
@@ -589,6 +612,29 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
       }
     }
     acc = f4_add(acc, self);
+    if (PF) {
+      // the node this thread sums in step s + 1: its first four edges' sources are already staged; fetch the (at most two)
+      // rows that the ring will not hold then.  Issued in front of this step's store: the loads are older than it, so the wait in
+      // front of their use does not include the store.
+      npf = 0;
+      if (li + kDmaG < cnt) {
+        const int* idxN = idxL + ((s + 1) % NBUF) * kDmaEdges;
+        const int nlo = max(base, 0), nhi = min(base + 3 * kDmaG, n);
+        const int pe = min(nb_end, nb_beg + 4);
+        for (int q = nb_beg; q < pe; ++q) {
+          const int k = q - nb_e0;
+          if (k < kDmaEdges) {
+            const int sj = idxN[k];
+            if ((sj < nlo) | (sj >= nhi)) {
+              if (npf == 0) pf0 = x4[(int64_t)sj * ldx4 + c4];
+              else if (npf == 1) pf1 = x4[(int64_t)sj * ldx4 + c4];
+              if (npf < 2) ++npf;
+              else break;  // (a third far source: it and whatever follows take the branch -- the counts must stay in step)
+            }
+          }
+        }
+      }
+    }
     if (POL & 2) {
       v4f_t o = {acc.x, acc.y, acc.z, acc.w};
       __builtin_nontemporal_store(o, reinterpret_cast<v4f_t*>(out) + ((int64_t)i * ldo4 + c4));
@@ -613,7 +659,7 @@ int launch_aggregate_dma_p(const float* x, int64_t ldx, const int32_t* ptr, cons
   const int cthreads = (int)align_up((size_t)kDmaG * gs, kWave);
   const int threads = cthreads + kWave;
   const size_t lds = (size_t)(TABLE ? kNumCodes * dim : 0) * 4 + (size_t)(P + 3) * kDmaG * dim * 4 +
-                     (size_t)(kDmaMaxNodes + 4) * 4 + (size_t)2 * (P + 1) * kDmaEdges * 4 +
+                     (size_t)(kDmaMaxNodes + 4) * 4 + (size_t)2 * (P + 1 + ((POL & 16) ? 1 : 0)) * kDmaEdges * 4 +
                      (WEIGHT ? (size_t)(kDmaMaxNodes + 3 * kDmaG) * 4 : 0) + 64;
   const int resident = (int)std::max<size_t>(1, (160 * 1024) / lds);
   const int64_t target_blocks = (int64_t)num_cu() * std::min(resident, env_int("PGNN_DMA_BPC", 2));
@@ -636,8 +682,12 @@ int launch_aggregate_dma_pre(const float* z, int64_t ldz, const float* coef, int
   const int nrow = (int)ceil_div(kDmaG * (dim / 4), kWave);
   const bool small_ld = ldz * 4 * kDmaG < (1ll << 31);
   if (nrow == 10 && small_ld) {
-    if (env_int("PGNN_DMA_POL", (int64_t)n * dim * 4 >= (128ll << 20) ? 3 : 0) == 3)
-      return launch_aggregate_dma_p<true, 2, 10, true, 3>(z, ldz, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, coef, relu);
+    const bool nt = env_int("PGNN_DMA_POL", (int64_t)n * dim * 4 >= (128ll << 20) ? 3 : 0) == 3;
+    if (env_int("PGNN_DMA_PF", g_far_rows_hint) != 0) {
+      if (nt) return launch_aggregate_dma_p<true, 2, 10, true, 19>(z, ldz, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, coef, relu);
+      return launch_aggregate_dma_p<true, 2, 10, true, 16>(z, ldz, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, coef, relu);
+    }
+    if (nt) return launch_aggregate_dma_p<true, 2, 10, true, 3>(z, ldz, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, coef, relu);
     return launch_aggregate_dma_p<true, 2, 10, true>(z, ldz, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, coef, relu);
   }
   return launch_aggregate_dma_p<true, 2, 0, true>(z, ldz, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, coef, relu);
@@ -658,6 +708,11 @@ int launch_aggregate_dma(const float* x, int64_t ldx, const int32_t* ptr, const 
   // 229.8 -> 214.3 us on the roofline batch (tools/agg_sweep.py; nt loads alone 224.9, nt stores alone 217.9, loader
   // priority 222.1).  Smaller batches keep the default policy so the next kernel finds the rows in L2 / MALL.
   const int pol = env_int("PGNN_DMA_POL", (int64_t)n * dim * 4 >= (128ll << 20) ? 3 : 0);
+  const bool pf = env_int("PGNN_DMA_PF", g_far_rows_hint) != 0;  // far rows fetched a step ahead (POL bit 4)
+  if (nrow == 10 && pf) {
+    if (pol == 3) return launch_aggregate_dma_p<TABLE, 2, 10, false, 19>(PGNN_DMA_ARGS);
+    if (pol == 0) return launch_aggregate_dma_p<TABLE, 2, 10, false, 16>(PGNN_DMA_ARGS);
+  }
   if (nrow == 10) {
     if (pol == 3) return launch_aggregate_dma_p<TABLE, 2, 10, false, 3>(PGNN_DMA_ARGS);
     if (TABLE) {  // further A/B variants and the instrumented build: production instantiation only

@@ -83,9 +83,23 @@ def test_graph_build_flags_bad_indices():
         g.check()
 
 
+@pytest.fixture
+def far_row_prefetch(request, monkeypatch):
+    """PGNN_DMA_PF: 0 = a source row outside the LDS window is read on the spot (wave-uniform branch), 1 = it is fetched into
+    registers one step ahead (k_aggregate_dma's POL bit 4)"""
+    monkeypatch.setenv("PGNN_DMA_PF", request.param)
+    _ops().load().pgnn_reload_env()
+    yield request.param
+    monkeypatch.delenv("PGNN_DMA_PF")
+    _ops().load().pgnn_reload_env()
+
+
+@pytest.mark.parametrize("far_row_prefetch", ["0", "1"], indirect=True)
 @pytest.mark.parametrize("dim", [300, 32, 512, 600])
 @pytest.mark.parametrize("n,e", [(64, 150), (2000, 4400), (333, 4000)])
-def test_chem_gin_aggregate_bit_exact(n, e, dim):
+def test_chem_gin_aggregate_bit_exact(n, e, dim, far_row_prefetch):
+    """(random graphs: almost every source row is outside the kernel's 24-row window -- with the prefetch variant a node's first
+    two such rows come out of registers, the rest and every edge past a step's 64 staged slots take the branch)"""
     ops = _ops()
     torch.manual_seed(n + dim)
     ei, ea = _rand_graph(n, e, seed=e)
