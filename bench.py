@@ -191,8 +191,7 @@ def aggregation_robustness(dev, graphs):
                     ("parent_within_16", {"parent_window": 16}), ("atoms_permuted", {"permute": True})):
         rng = np.random.default_rng(777)
         gl = [synthetic.zinc_like_graph(rng, **kw) for _ in range(2048)]
-        ds = resident.ResidentDataset.from_graphs(gl, dev)  # (measures its far-bond share once; every collate then tells the library
-        base = ds.collate(np.arange(len(gl)))                #  which form of the kernel to run: pgnn_hint_far_rows)
+        base = resident.ResidentDataset.from_graphs(gl, dev).collate(np.arange(len(gl)))
         big = synthetic.tile_batch(base, max(1, graphs // 2048)).to(dev)
         n, e = big.x.size(0), big.edge_index.size(1)
         dst, src = big.edge_index[0], big.edge_index[1]
@@ -211,8 +210,7 @@ def aggregation_robustness(dev, graphs):
         ms, per, iters = steady_state_ms(launch, warm_s=0.05, iters=30)
         alg = 2400.0 * n + 6.0 * e + 4.0 * (n + 1)
         out[tag] = {"out_of_window_edge_fraction": round(miss, 4), "ms_per_launch": round(ms, 4), "ms_per_launch_std": round(float(per.std()), 4),
-                    "achieved_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "nodes": n, "edges": e,
-                    "kernel_form": "far rows prefetched a step ahead" if ds._far_hint else "far rows read on the spot"}
+                    "achieved_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "nodes": n, "edges": e}
         del x, y, g, big
     return out
 

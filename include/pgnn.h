@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PGNN_ABI_VERSION 8
+#define PGNN_ABI_VERSION 7
 /* uint32 words behind every `counter` argument below: the arrival tickets of a launch whose last block folds the others'
  * results (one top word + up to 32 group words: same-address atomics retire at ~50 ns each, see csrc/common.h).  Zero before
  * the first call, left zero by every call; one buffer per device serves all calls of a stream. */
@@ -46,13 +46,6 @@ const char* pgnn_last_error(void); /* host string, thread-local */
 /* The PGNN_* environment knobs (A/B switches) are read once per call site and cached;
  * call this after changing one inside a running process. */
 void pgnn_reload_env(void);
-/* Process-wide hint for the molecule aggregation (pgnn_chem_aggregate_*, and through it the one-call networks): on != 0 = many
- * bonds join atoms more than ~8 rows apart (an atom order less local than a depth-first SMILES order), so source rows outside
- * the kernel's 24-row LDS window are fetched into registers one step ahead instead of on the spot.  Costs 14 % of the rate when
- * no such bond exists, gains 14-35 % from 5 % of them on (bench.py: aggregation_robustness).  Results are bit-identical either
- * way.  pretrain_gnns_amd.data.ResidentDataset measures its graphs once and sets it; PGNN_DMA_PF=0|1 overrides. */
-void pgnn_hint_far_rows(int on);
-
 /* ------------------------------------------------------------------------------------------
  * Graph structure.  Replaces the per-layer add_self_loops + torch.cat of chem/model.py:39-45,
  * 84-93 and bio/model.py:39-45,94-100 and the COO gather/scatter inside propagate: built ONCE

@@ -26,7 +26,6 @@ PROTOTYPES = {
     "pgnn_abi_version": (_i, []),
     "pgnn_last_error": (ctypes.c_char_p, []),
     "pgnn_reload_env": (None, []),
-    "pgnn_hint_far_rows": (None, [_i]),
     "pgnn_graph_workspace_bytes": (_sz, [_i64, _i64]),
     "pgnn_chem_graph_build": (_i, [_p, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "pgnn_bio_graph_build": (_i, [_p, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
@@ -123,7 +122,7 @@ PROTOTYPES = {
     "pgnn_debug_aggregate_profile": (_i, [_p, _i64]),
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 7
 
 
 class GinLayer(ctypes.Structure):

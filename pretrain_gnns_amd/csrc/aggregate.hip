@@ -366,6 +366,8 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
   // slots are then staged one step earlier), instead of on the spot behind a wave-uniform branch that waits a memory round trip
   // per batch: at 5.6 % such edges the on-the-spot path ran at 0.46 of the HBM roofline against 0.63 without any (bench.py's
   // aggregation_robustness leg).  Two rows per node and step; a third one, or a step with more than 64 edges, still takes the branch.
+  // The loader publishes one ballot per step (which staged sources are far), so a batch without such bonds pays a two-word LDS read
+  // per step for it and nothing else: 0.62 either way, 0.52 / 0.47 / 0.41 at 5.6 / 13 / 33 % far bonds.
   constexpr bool PF = (POL & 16) != 0;
   constexpr int EL = PF ? 1 : 0;  // steps by which the edge slots lead the rows
   static_assert(!(PF && WEIGHT), "the prefetch variant does not carry the GCN normaliser of a far row");
@@ -383,6 +385,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
   int* idxL = ptrL + (kDmaMaxNodes + 4);                                             // [NBUF][64]
   int* codeL = idxL + NBUF * kDmaEdges;                                              // [NBUF][64] (byte DMA lands as dwords)
   float* dinvL = reinterpret_cast<float*>(codeL + NBUF * kDmaEdges);                 // [8 (nsteps + 2)] rows n0-8 .. (WEIGHT)
+  int* farL = codeL + NBUF * kDmaEdges;  // (PF; never together with WEIGHT) [NBUF][2]: bit k = staged edge slot k of the step is far
   const float4* __restrict__ T4 = reinterpret_cast<const float4*>(T);
   const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
   const int64_t ldx4 = ldx >> 2, ldo4 = ldo >> 2;
@@ -453,6 +456,22 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
       unsigned long long t0 = 0, t1 = 0, t2 = 0;
       if (PROF) t0 = __builtin_readcyclecounter();
       wait_vmcnt(min(s, P - 1) * K);  // everything issued >= P steps ago (rows <= s+1, edges(s)) has landed
+      if (PF) {
+        // which of step s + 1's staged sources lie outside ITS ring window: one ballot, published before B(s), so that a consumer
+        // looks ahead only when there is something to fetch (the look-ahead cost 14 % of the rate on batches without any far bond).
+        // The slot is read with inline asm: behind a ds_read in C++ hipcc waits for vmcnt(0) on this path, i.e. for every DMA in flight.
+        const int sn = s + 1;
+        const unsigned addr = (unsigned)(unsigned long long)PGNN_LPTR(idxL + (sn % NBUF) * kDmaEdges + lane);
+        int v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+        const int b2 = n0 + sn * kDmaG;
+        const int ne_step = ptrL[min((sn + 1) * kDmaG, cnt)] - ptrL[min(sn * kDmaG, cnt)];  // (slots past it hold later steps' edges)
+        const unsigned long long m = __ballot(lane < ne_step && (v < max(b2 - kDmaG, 0) || v >= min(b2 + 2 * kDmaG, n)));
+        if (lane == 0) {
+          farL[(sn % NBUF) * 2] = (int)(unsigned)m;
+          farL[(sn % NBUF) * 2 + 1] = (int)(unsigned)(m >> 32);
+        }
+      }
       if (PROF) t1 = __builtin_readcyclecounter();
       __syncthreads();                // B(s)
       if (PROF) t2 = __builtin_readcyclecounter();
@@ -617,7 +636,8 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
       // rows that the ring will not hold then.  Issued in front of this step's store: the loads are older than it, so the wait in
       // front of their use does not include the store.
       npf = 0;
-      if (li + kDmaG < cnt) {
+      const int fm = __builtin_amdgcn_readfirstlane(farL[((s + 1) % NBUF) * 2] | farL[((s + 1) % NBUF) * 2 + 1]);
+      if (fm != 0 && li + kDmaG < cnt) {  // (uniform: nothing far among the next step's staged sources -> nothing to look for)
         const int* idxN = idxL + ((s + 1) % NBUF) * kDmaEdges;
         const int nlo = max(base, 0), nhi = min(base + 3 * kDmaG, n);
         const int pe = min(nb_end, nb_beg + 4);
@@ -683,7 +703,7 @@ int launch_aggregate_dma_pre(const float* z, int64_t ldz, const float* coef, int
   const bool small_ld = ldz * 4 * kDmaG < (1ll << 31);
   if (nrow == 10 && small_ld) {
     const bool nt = env_int("PGNN_DMA_POL", (int64_t)n * dim * 4 >= (128ll << 20) ? 3 : 0) == 3;
-    if (env_int("PGNN_DMA_PF", g_far_rows_hint) != 0) {
+    if (env_int("PGNN_DMA_PF", 1) != 0) {
       if (nt) return launch_aggregate_dma_p<true, 2, 10, true, 19>(z, ldz, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, coef, relu);
       return launch_aggregate_dma_p<true, 2, 10, true, 16>(z, ldz, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, coef, relu);
     }
@@ -708,7 +728,7 @@ int launch_aggregate_dma(const float* x, int64_t ldx, const int32_t* ptr, const 
   // 229.8 -> 214.3 us on the roofline batch (tools/agg_sweep.py; nt loads alone 224.9, nt stores alone 217.9, loader
   // priority 222.1).  Smaller batches keep the default policy so the next kernel finds the rows in L2 / MALL.
   const int pol = env_int("PGNN_DMA_POL", (int64_t)n * dim * 4 >= (128ll << 20) ? 3 : 0);
-  const bool pf = env_int("PGNN_DMA_PF", g_far_rows_hint) != 0;  // far rows fetched a step ahead (POL bit 4)
+  const bool pf = env_int("PGNN_DMA_PF", 1) != 0;  // far rows fetched a step ahead (POL bit 4; the default -- 0 = read on the spot)
   if (nrow == 10 && pf) {
     if (pol == 3) return launch_aggregate_dma_p<TABLE, 2, 10, false, 19>(PGNN_DMA_ARGS);
     if (pol == 0) return launch_aggregate_dma_p<TABLE, 2, 10, false, 16>(PGNN_DMA_ARGS);

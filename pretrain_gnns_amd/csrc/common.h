@@ -80,7 +80,6 @@ inline void allow_big_lds(const void* func, size_t bytes) {
 // consults ~140 knobs per train step, so values are cached per call site (keyed by the literal's address) and
 // only re-read after pgnn_reload_env() -- which is what a test that flips a knob mid-process calls.
 extern unsigned g_env_generation;
-extern int g_far_rows_hint;
 inline int env_knob(const char* name, int dflt) {
   struct Slot { const char* name; unsigned gen; bool set; int value; };
   constexpr int kSlots = 128;

@@ -21,7 +21,6 @@ void set_error(const char* fmt, ...) {
 }
 
 unsigned g_env_generation = 1;
-int g_far_rows_hint = 0;  // pgnn_hint_far_rows: the aggregation kernel's far-row prefetch when PGNN_DMA_PF is not set
 
 DeviceInfo device_info() {
   constexpr int kMaxDev = 64;
@@ -495,7 +494,6 @@ extern "C" {
 
 int pgnn_abi_version(void) { return PGNN_ABI_VERSION; }
 void pgnn_reload_env(void) { ++pgnn::g_env_generation; }
-void pgnn_hint_far_rows(int on) { pgnn::g_far_rows_hint = on ? 1 : 0; }
 const char* pgnn_last_error(void) { return pgnn::g_err; }
 
 size_t pgnn_graph_workspace_bytes(int64_t N, int64_t E) {

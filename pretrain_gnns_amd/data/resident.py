@@ -66,16 +66,6 @@ class ResidentDataset:
         self._center = None if center_node_idx is None else np.asarray(torch.as_tensor(center_node_idx).cpu(), dtype=np.int64).reshape(-1)
         if self._center is not None and self._center.size != self.num_graphs:
             raise ValueError("center_node_idx must hold one entry per graph")
-        # molecules: the share of bonds whose two atoms are too far apart in the atom order for the aggregation kernel's 24-row
-        # LDS window ([8 (i // 8) - 8, + 24) around destination i; graph-local ids: a batch shifts them by a common offset, the
-        # share stays).  Measured once (on the host copy handed in, at most the first million bonds); every batch then tells the
-        # library which of the kernel's two forms to run (pgnn_hint_far_rows: the prefetch form pays from ~3 % on).
-        self.far_bond_fraction = 0.0
-        if x.dtype == torch.int64 and edge_index.size(1) > 0:
-            ei = edge_index[:, :1 << 20].cpu().numpy()
-            lo = (ei[0] // 8) * 8 - 8
-            self.far_bond_fraction = float(((ei[1] < lo) | (ei[1] >= lo + 24)).mean())
-        self._far_hint = 1 if self.far_bond_fraction > 0.03 else 0
 
     def __len__(self):
         return self.num_graphs
@@ -120,8 +110,6 @@ class ResidentDataset:
         replace the random draw.  ``ids_device``: the same ids already on the GPU (ResidentLoader uploads a
         whole epoch's permutation once instead of one small copy per step)."""
         lib, sp, dev = load(), stream_ptr(), self.device
-        if self.x.dtype == torch.int64:
-            lib.pgnn_hint_far_rows(self._far_hint)
         ids_host, ids = self._ids(graph_ids, ids_device)
         b = ids_host.size
         n, e = int(self._nodes[ids_host].sum()), int(self._edges[ids_host].sum())

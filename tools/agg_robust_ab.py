@@ -6,9 +6,9 @@ import bench
 from pretrain_gnns_amd import ops
 dev = torch.device("cuda", 0)
 graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-for pf in ("0", "1", None):
-    os.environ.pop("PGNN_DMA_PF", None) if pf is None else os.environ.__setitem__("PGNN_DMA_PF", pf)
+for pf in ("0", "1"):
+    os.environ["PGNN_DMA_PF"] = pf
     ops.load().pgnn_reload_env()
     r = bench.aggregation_robustness(dev, graphs)
-    print("PGNN_DMA_PF=%s " % (pf if pf is not None else "unset (dataset hint)") + "  ".join("%s %.1f%% -> %.3f (%.1f us)" % (k, 100 * v["out_of_window_edge_fraction"], v["frac"], 1e3 * v["ms_per_launch"])
+    print("PGNN_DMA_PF=%s " % pf + "  ".join("%s %.1f%% -> %.3f (%.1f us)" % (k, 100 * v["out_of_window_edge_fraction"], v["frac"], 1e3 * v["ms_per_launch"])
                                               for k, v in r.items()), flush=True)
