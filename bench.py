@@ -165,8 +165,9 @@ def roofline_aggregation(dev, graphs):
     alg_bytes = 2400.0 * n + 6.0 * e + 4.0 * (n + 1)
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     traffic, traffic_src = pmc_traffic(n, e)
-    return {"bound": "hbm", "kernel": "k_aggregate_dma<true,2,10,false,3> (pgnn_chem_aggregate_fwd; rows loaded and stored "
-                                      "non-temporally because x + out exceed the Infinity Cache)", "achieved": round(gbs, 1),
+    return {"bound": "hbm", "kernel": "k_aggregate_dma<true,2,10,false,19> (pgnn_chem_aggregate_fwd; rows loaded and stored "
+                                      "non-temporally because x + out exceed the Infinity Cache; POL bit 4: source rows outside the LDS window "
+                                      "are fetched a step ahead -- this batch has none)", "achieved": round(gbs, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
             "traffic_source": traffic_src, "ms_per_launch": round(ms, 4), "launches_timed": iters,
             "ms_per_launch_std": round(float(per.std()), 4), "ms_per_launch_min": round(float(per.min()), 4),
