@@ -6,12 +6,18 @@
 //   pass 3: elementwise normalise (+ReLU) / gradient, float4.
 // Statistics use sums shifted by row 0 (K = x[0,:]) so that var = E[(x-K)^2] - E[x-K]^2 does not
 // cancel catastrophically when |mean| >> std.
+#include <atomic>
+
 #include "common.h"
 
 namespace pgnn {
 namespace {
 
 constexpr int kMaxBlocks = 1024;
+constexpr int kFoldGroup = 16;       // blocks per group of the in-launch fold of k_bn_bwd_partial
+constexpr int kFoldMaxGroups = 64;   // (kMaxBlocks / kFoldGroup)
+constexpr int kFoldSlots = 256;      // ticket sets; a launch draws the next one, every launch leaves its set zeroed
+__device__ unsigned g_bn_fold_tickets[kFoldSlots][kFoldMaxGroups + 8];
 
 // Inverted dropout fused into the normalise pass (F.dropout after the ReLU, chem/model.py:271-275).
 // Counter-based: the keep bits of float4 (row r, column group c4) come from one splitmix64 of
@@ -53,9 +59,9 @@ __device__ __forceinline__ void block_col_reduce2(float4 a, float4 b, int d4, fl
     reinterpret_cast<float4*>(lds + (1 * 4 + rl) * dim)[c4] = b;
   }
   __syncthreads();
-  for (int q = t; q < dim; q += blockDim.x) {
-    dst_a[q] = (lds[q] + lds[dim + q]) + (lds[2 * dim + q] + lds[3 * dim + q]);
-    dst_b[q] = (lds[4 * dim + q] + lds[5 * dim + q]) + (lds[6 * dim + q] + lds[7 * dim + q]);
+  for (int q = t; q < dim; q += blockDim.x) {  // (agent-scope stores: another block of the same launch may read them, see k_bn_bwd_partial)
+    publish(dst_a + q, (lds[q] + lds[dim + q]) + (lds[2 * dim + q] + lds[3 * dim + q]));
+    publish(dst_b + q, (lds[4 * dim + q] + lds[5 * dim + q]) + (lds[6 * dim + q] + lds[7 * dim + q]));
   }
 }
 
@@ -202,7 +208,9 @@ __global__ void k_bn_bwd_partial(const float* __restrict__ dy, int64_t lddy, con
                                  int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
                                  const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                                  float* __restrict__ coef /*out (block 0): a,b,mean,invstd*/, int relu,
-                                 int n, int d4, float* __restrict__ partial, Drop drop) {
+                                 int n, int d4, float* __restrict__ partial, Drop drop, double* __restrict__ gsum,
+                                 unsigned* __restrict__ tickets, int training, float* __restrict__ dgamma,
+                                 float* __restrict__ dbeta) {
   extern __shared__ __align__(16) float lds[];
   const int t = threadIdx.x, c4 = t % d4, rl = t / d4, dim = d4 * 4;
   const int per = (n + gridDim.x - 1) / gridDim.x;
@@ -258,6 +266,72 @@ __global__ void k_bn_bwd_partial(const float* __restrict__ dy, int64_t lddy, con
   }
   float* p = partial + (size_t)blockIdx.x * 2 * dim;
   block_col_reduce2(s1, s2, d4, lds, p, p + dim);
+  if (!tickets) return;  // (the fold is k_bn_bwd_final's: more than kFoldMaxGroups groups)
+  // ---- the fold of the partials, inside this launch (a launch of its own cost 6-8 us + a kernel boundary per layer on the
+  // backward's critical path): blocks are grouped by kFoldGroup consecutive ids; the LAST block of a group to arrive adds the
+  // group's partials in block order (float64) into gsum[group]; the last GROUP leader to arrive adds the groups in order and
+  // finishes as k_bn_bwd_final does.  Which block does the adding varies, what is added in which order does not.  Partials cross
+  // blocks as agent-scope stores / loads and relaxed tickets (common.h: no L2 write-backs).
+  __shared__ int role;
+  const int nblk = gridDim.x, ngroups = (nblk + kFoldGroup - 1) / kFoldGroup;
+  const int grp = blockIdx.x / kFoldGroup, gsize = min(kFoldGroup, nblk - grp * kFoldGroup);
+  __syncthreads();  // this block's partial row is written (agent-scope stores, block_col_reduce2)
+  if (t == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    role = __hip_atomic_fetch_add(tickets + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)gsize - 1u ? 1 : 0;
+  }
+  __syncthreads();
+  if (role == 0) return;
+  for (int q = t; q < 2 * dim; q += blockDim.x) {
+    float v[kFoldGroup];  // every load of the group in flight at once (clamped, unconditional), added in block order
+#pragma unroll
+    for (int b = 0; b < kFoldGroup; ++b) v[b] = fetch_published(partial + (size_t)(grp * kFoldGroup + min(b, gsize - 1)) * 2 * dim + q);
+    double acc = 0.0;
+#pragma unroll
+    for (int b = 0; b < kFoldGroup; ++b)
+      if (b < gsize) acc += (double)v[b];
+    publish(gsum + (size_t)grp * 2 * dim + q, acc);
+  }
+  __syncthreads();
+  if (t == 0) {
+    publish(tickets + 1 + grp, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    role = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ngroups - 1u ? 2 : 0;
+  }
+  __syncthreads();
+  if (role != 2) return;
+  if (t == 0) publish(tickets, 0u);
+  for (int c = t; c < dim; c += blockDim.x) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int g0 = 0; g0 < ngroups; g0 += 8) {  // eight groups' sums in flight at once, added in group order
+      double u1[8], u2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int gq = min(g0 + j, ngroups - 1);
+        u1[j] = fetch_published(gsum + (size_t)gq * 2 * dim + c);
+        u2[j] = fetch_published(gsum + (size_t)gq * 2 * dim + dim + c);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (g0 + j < ngroups) {
+          t1 += u1[j];
+          t2 += u2[j];
+        }
+    }
+    if (dgamma) dgamma[c] = (float)t2;
+    if (dbeta) dbeta[c] = (float)t1;
+    const float invstd = save_invstd[c];
+    const float k1 = gamma[c] * invstd;
+    float k2 = 0.f, k3 = 0.f;
+    if (training) {  // dx = k1 * (dyr - s1/n - xhat * s2/n),  xhat = (x - mean) * invstd
+      const float m1 = (float)(t1 / n), m2 = (float)(t2 / n);
+      k2 = -k1 * invstd * m2;
+      k3 = -k1 * m1;
+    }
+    coef[4 * dim + c] = k1;
+    coef[5 * dim + c] = k2;
+    coef[6 * dim + c] = k3;
+  }
 }
 
 // coef layout for backward: [a, b, mean, invstd, k1, k2, k3] each [dim]
@@ -346,7 +420,8 @@ using namespace pgnn;
 extern "C" {
 
 size_t pgnn_bn_workspace_bytes(int64_t n, int64_t dim) {
-  return align_up((size_t)stat_blocks(n) * 2 * dim * sizeof(float), 256) + align_up((size_t)7 * dim * sizeof(float), 256);
+  return align_up((size_t)stat_blocks(n) * 2 * dim * sizeof(float), 256) + align_up((size_t)7 * dim * sizeof(float), 256) +
+         align_up((size_t)kFoldMaxGroups * 2 * dim * sizeof(double), 256);
 }
 
 int pgnn_bn_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* running_mean,
@@ -443,10 +518,27 @@ int pgnn_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, cons
   float* partial = cv.take<float>((size_t)nblk * 2 * dim);
   float* coef = cv.take<float>((size_t)7 * dim);
   const int d4 = (int)(dim / 4);
+  double* gsum = cv.take<double>((size_t)kFoldMaxGroups * 2 * dim);
+  const bool fold = ceil_div(nblk, kFoldGroup) <= kFoldMaxGroups && env_knob("PGNN_BN_BWD_FOLD", 1) != 0;
+  static std::atomic<unsigned> next_slot{0};
+  unsigned* tickets = nullptr;
+  if (fold) {
+    static thread_local unsigned* base = nullptr;  // (one device per process; the lookup takes the runtime's locks)
+    static thread_local int base_dev = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!base || base_dev != dev) {
+      PGNN_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_bn_fold_tickets)));
+      base_dev = dev;
+    }
+    tickets = base + (size_t)(next_slot.fetch_add(1, std::memory_order_relaxed) % kFoldSlots) * (kFoldMaxGroups + 8);
+  }
   hipLaunchKernelGGL(k_bn_bwd_partial, dim3(nblk), dim3(stat_threads(dim)), (size_t)8 * dim * sizeof(float), st, dy,
-                     lddy, x, ldx, gamma, beta, save_mean, save_invstd, coef, relu, (int)n, d4, partial, drop);
-  hipLaunchKernelGGL(k_bn_bwd_final, dim3((int)ceil_div(dim, 4)), dim3(256), 0, st, partial, nblk, training, (int)n, (int)dim, gamma,
-                     coef, dgamma, dbeta);
+                     lddy, x, ldx, gamma, beta, save_mean, save_invstd, coef, relu, (int)n, d4, partial, drop, gsum, tickets, training,
+                     dgamma, dbeta);
+  if (!fold)
+    hipLaunchKernelGGL(k_bn_bwd_final, dim3((int)ceil_div(dim, 4)), dim3(256), 0, st, partial, nblk, training, (int)n, (int)dim, gamma,
+                       coef, dgamma, dbeta);
   const int grid = (int)std::min<int64_t>(ceil_div(n, 4), (int64_t)num_cu() * 16);
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid), dim3(stat_threads(dim)), 0, st, dy, lddy, x, ldx, coef, relu, dx, lddx,
                      (int)n, d4, drop);
