@@ -163,7 +163,7 @@ int main(int argc, char** argv) {
              ok ? "bit-equal" : "DIFFERS  ", u_f1, u_f2, u_b2, u_b1, u_chain, gf / u_f1 * 1e3, gf / u_f2 * 1e3);
     }
     set_cfg(-1);
-    if (m <= 20000) {  // in-kernel phase cycles (instrumented build), first workgroup, every wave
+    if (m <= 300000) {  // in-kernel phase cycles (instrumented build), first workgroup, every wave
       uint64_t* dbg = dev_alloc<uint64_t>(8 * 8 * 8);
       for (int cfg : {1, 0, 4}) {
         for (int which = 0; which < 2; ++which) {
