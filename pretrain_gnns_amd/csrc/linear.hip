@@ -755,7 +755,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
       if constexpr (decltype(do_issue)::value) {
 #pragma unroll
         for (int q = 0; q < NJ; ++q)
-          if (q * NI / NJ == j) issue_piece(q, issue_stage);
+          if ((NJ <= NI ? q : q * NI / NJ) == j) issue_piece(q, issue_stage);  // one piece behind each of the FIRST blocks (spread over ALL
+          // blocks their last ones had a few hundred cycles to land: 41 269 rows 114 / 105 / 121 / 92 -> 110 / 96 / 112 / 84 us; two per block: worse)
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1378,12 +1379,13 @@ size_t pgnn_weight_planes_bytes(int64_t rows, int64_t cols) {
 }
 
 // 1 where the products of a layer stack should run on pre-split planes: from 48 tiles of 64x160 (where pgnn_linear_fwd still
-// takes the fp32-MFMA kernel's 64x64 tiles: 12.4 / 18.3 us against 20.3 / 20.6 at 2 048 rows) up to 65 536 rows -- 21.9 / 18.7 us
-// against the split-bf16 kernel's 29.1 / 26.8 for the 600 -> 300 products at 6 747 rows, 23.6 against 26.1 for 300 -> 600; level
-// from ~65 k rows on (tools/gemm3w_bench.cpp).  Bit-identical to pgnn_linear_fwd wherever THAT runs the split-bf16 kernel (from
+// takes the fp32-MFMA kernel's 64x64 tiles: 12.4 / 18.3 us against 20.3 / 20.6 at 2 048 rows) on -- 21.9 / 18.7 us
+// against the split-bf16 kernel's 29.1 / 26.8 for the 600 -> 300 products at 6 747 rows, 23.6 against 26.1 for 300 -> 600; with
+// persistent workgroups and early DMA issue also at 262 144 rows (forward 696 + 576 us against 666 + 599, backward-data
+// 691 + 510 against 907 + 563: tools/gemm3w_bench.cpp; the first half of the round stopped at 65 536 rows, where it was level).  Bit-identical to pgnn_linear_fwd wherever THAT runs the split-bf16 kernel (from
 // 160 tiles; PGNN_GEMM_WP_MIN_TILES=160 restricts the planes to that range), fp32-rounding-equal to its fp32-MFMA kernel below.
 int pgnn_linear_wp_preferred(int64_t m, int64_t k, int64_t n) {
-  if (env_knob("PGNN_GEMM_WP", 1) == 0 || gemm_mode() != 1 || k < 4 || k % 4 || n % 4 || m > 65536) return 0;
+  if (env_knob("PGNN_GEMM_WP", 1) == 0 || gemm_mode() != 1 || k < 4 || k % 4 || n % 4) return 0;
   return ceil_div(m, 64) * ceil_div(n, 160) >= env_knob("PGNN_GEMM_WP_MIN_TILES", 48);
 }
 
