@@ -97,11 +97,18 @@ def chem_masking_step(model_list, optimizer_list, batch, mask_edge=False, readba
     acc_edge = 0.0 if (inline or not mask_edge) else None
     if mask_edge:
         masked_edge_index = batch.edge_index[:, batch.connected_edge_indices]
-        edge_rep = node_rep[masked_edge_index[0]] + node_rep[masked_edge_index[1]]
-        pred_edge = linear_pred_bonds(edge_rep)
-        loss = loss + F.cross_entropy(pred_edge.double(), batch.mask_edge_label[:, 0])
-        n_edge = len(pred_edge)
-        acc_edge = compute_accuracy(pred_edge, batch.mask_edge_label[:, 0]) if inline else _correct(pred_edge, batch.mask_edge_label[:, 0])
+        edge_label = batch.mask_edge_label[:, 0]
+        if not inline and masked_edge_index.size(1) > 0 and _fusable_edge_head(linear_pred_bonds, node_rep, edge_label):
+            # the bond head (:60-66) on [nodes, 4]-wide data (ops.EdgeHead: float64 soft-max and loss as `pred_edge.double()` here)
+            loss_edge, acc_edge, _ = ops.edge_head(node_rep, masked_edge_index, linear_pred_bonds, edge_label.contiguous(), float64=True)
+            loss = loss + loss_edge
+            n_edge = masked_edge_index.size(1)
+        else:
+            edge_rep = node_rep[masked_edge_index[0]] + node_rep[masked_edge_index[1]]
+            pred_edge = linear_pred_bonds(edge_rep)
+            loss = loss + F.cross_entropy(pred_edge.double(), edge_label)
+            n_edge = len(pred_edge)
+            acc_edge = compute_accuracy(pred_edge, edge_label) if inline else _correct(pred_edge, edge_label)
     for opt in optimizer_list:
         opt.zero_grad()
     _backward(loss)
