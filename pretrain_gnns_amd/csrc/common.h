@@ -76,11 +76,14 @@ inline void allow_big_lds(const void* func, size_t bytes) {
   }
 }
 
-// A/B knobs come from the environment.  getenv walks the whole environment block (~0.3 us) and the hot path
-// consults ~140 knobs per train step, so values are cached per call site (keyed by the literal's address) and
-// only re-read after pgnn_reload_env() -- which is what a test that flips a knob mid-process calls.
+// A/B knobs come from the environment.  A process without any `PGNN_*` variable -- production -- takes every default at the
+// cost of one flag test per call site.  With one set, getenv walks the whole environment block (~0.3 us) and a train step asks
+// ~140 times, so values are cached per call site (keyed by the literal's address) and only re-read after pgnn_reload_env() --
+// which is what a test that flips a knob mid-process calls.
 extern unsigned g_env_generation;
+extern bool g_env_any;  // is ANY `PGNN_*` variable set?  (scanned at load and by pgnn_reload_env)
 inline int env_knob(const char* name, int dflt) {
+  if (!g_env_any) return dflt;  // the production path: no A/B variable in the environment, no table to consult
   struct Slot { const char* name; unsigned gen; bool set; int value; };
   constexpr int kSlots = 128;
   static thread_local Slot slots[kSlots];

@@ -7,7 +7,11 @@
 // gradients into a tall-skinny reduction.  All kernels are HBM/latency-bound integer work.
 #include <stdarg.h>
 
+#include <string.h>
+
 #include "common.h"
+
+extern char** environ;
 
 namespace pgnn {
 
@@ -21,6 +25,12 @@ void set_error(const char* fmt, ...) {
 }
 
 unsigned g_env_generation = 1;
+static bool scan_env_for_knobs() {
+  for (char** e = ::environ; e && *e; ++e)
+    if (strncmp(*e, "PGNN_", 5) == 0) return true;
+  return false;
+}
+bool g_env_any = scan_env_for_knobs();
 
 DeviceInfo device_info() {
   constexpr int kMaxDev = 64;
@@ -493,7 +503,10 @@ using namespace pgnn;
 extern "C" {
 
 int pgnn_abi_version(void) { return PGNN_ABI_VERSION; }
-void pgnn_reload_env(void) { ++pgnn::g_env_generation; }
+void pgnn_reload_env(void) {
+  pgnn::g_env_any = pgnn::scan_env_for_knobs();
+  ++pgnn::g_env_generation;
+}
 const char* pgnn_last_error(void) { return pgnn::g_err; }
 
 size_t pgnn_graph_workspace_bytes(int64_t N, int64_t E) {
