@@ -735,6 +735,12 @@ class _StdoutToStderr:
 
 
 def main():
+    # a run that does not come back is worse than one that fails: after PGNN_BENCH_WATCHDOG seconds (default 900, 0 = off; a default
+    # run takes ~70 s) every thread's Python stack goes to stderr and the process exits with status 1
+    wd = float(os.environ.get("PGNN_BENCH_WATCHDOG", "900"))
+    if wd > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, exit=True)
     with _StdoutToStderr():
         line = _run()
     if line is not None:
