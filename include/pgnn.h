@@ -462,9 +462,14 @@ int pgnn_chem_lin_stack_bwd(int kind, const float* dy, int64_t lddy, const int64
 /* ------------------------------------------------------------------------------------------
  * The bio GIN network (bio/model.py:11-58, 258-290; JK = "last", no dropout) in one call per direction:
  *   agg = [sum_j h_j + h_i | cfeat . EncT] ; pre = agg W1^T + b1 ; hid = relu(BatchNorm_2D(pre)) ; y = hid W2^T + b2,
- *   ReLU between layers.  pgnn_gin_layer is reused: emb1 = EncT [10, dim] = [W_enc^T; b_enc] (emb2 unused), w1 [2D,2D],
- *   b1 [2D], w2 [D,2D], b2 [D], gamma / beta / running statistics of the BatchNorm1d(2D) inside the mlp; gradients:
- *   demb = d EncT [10, dim], the others as named.  h0 [n, ldh0] = the first layer's (embedded) input; cfeat [n, 10] and
+ *   ReLU between layers.  pgnn_gin_layer is reused: w1 [2D,2D], b1 [2D], w2 [D,2D], b2 [D], gamma / beta / running
+ *   statistics of the BatchNorm1d(2D) inside the mlp, and the edge encoder (bio/model.py:24) in one of two forms, the same
+ *   for every layer of a call:
+ *     emb2 == NULL: emb1 = EncT [10, dim] = [W_enc^T; b_enc], built by the caller; gradient demb = d EncT [10, dim];
+ *     emb2 != NULL: emb1 = edge_encoder.weight [dim, 9], emb2 = edge_encoder.bias [dim] as the module holds them (the
+ *       forward writes the tables into its workspace, in the launch that splits the weights; at most 16 layers);
+ *       gradient demb = d weight [dim, 9] followed by d bias [dim] (10 * dim floats).
+ *   The other gradients as named.  h0 [n, ldh0] = the first layer's (embedded) input; cfeat [n, 10] and
  *   the CSRs from pgnn_bio_graph_build; tile_start / num_tiles from pgnn_graph_tiles (NULL: untiled aggregation).
  *   acts [num_layer][7][n][dim] = (agg: 2 slots, pre: 2, hid: 2, y: 1); stats [num_layer][2][2*dim] = (mean, 1/std);
  *   the output is acts[num_layer-1][6].  Backward: dy = its gradient; dh0 [n, dim] may be NULL.

@@ -895,12 +895,16 @@ k_rowfeat_bwd_partial(const float* __restrict__ cfeat, const float* __restrict__
 
 __global__ void __launch_bounds__(kBlock)
 k_rowfeat_bwd_final(const float* __restrict__ partial, int nblocks, int kc, int dim,
-                    float* __restrict__ gtable, int64_t ldgt) {
+                    float* __restrict__ gtable, int64_t s_row, int64_t s_col, float* __restrict__ last_row_out) {
   const int sl = threadIdx.x & 15;
   const int qq = blockIdx.x * 16 + (threadIdx.x >> 4);
   const int q = min(qq, kc * dim - 1);
   const double s = slice_sum16(partial + q, (size_t)kc * dim, nblocks, sl);
-  if (sl == 0 && qq < kc * dim) gtable[(int64_t)(q / dim) * ldgt + (q % dim)] = (float)s;
+  if (sl == 0 && qq < kc * dim) {
+    const int r = q / dim, c = q - r * dim;
+    if (last_row_out && r == kc - 1) last_row_out[c] = (float)s;
+    else gtable[(int64_t)r * s_row + (int64_t)c * s_col] = (float)s;
+  }
 }
 
 // rows per block of the weighted column sums.  Measured at N = 6 747 (tools/small_kernel_bench.py): 64 rows -> 12.0 us,
@@ -1298,6 +1302,13 @@ size_t pgnn_rowfeat_matmul_bwd_workspace_bytes(int64_t n, int64_t kc, int64_t di
 int pgnn_rowfeat_matmul_bwd(const float* cfeat, int64_t kc, const float* g, int64_t ldg, float* gtable,
                             int64_t ldgt, int64_t n, int64_t dim, void* ws, size_t ws_bytes,
                             pgnn_stream stream) {
+  return pgnn::rowfeat_matmul_bwd_strided(cfeat, kc, g, ldg, gtable, ldgt, 1, nullptr, n, dim, ws, ws_bytes, (hipStream_t)stream);
+}
+}  // extern "C"
+
+int pgnn::rowfeat_matmul_bwd_strided(const float* cfeat, int64_t kc, const float* g, int64_t ldg, float* gtable, int64_t s_row,
+                                     int64_t s_col, float* last_row_out, int64_t n, int64_t dim, void* ws, size_t ws_bytes,
+                                     hipStream_t stream) {
   if (int rc = check_dim(dim)) return rc;
   PGNN_REQUIRE(n > 0 && (kc == 2 || kc == 4 || kc == 7 || kc == 9 || kc == 10) && ldg % 4 == 0, "rowfeat_matmul_bwd supports kc in {2,4,7,9,10}");
   if (ws_bytes < pgnn_rowfeat_matmul_bwd_workspace_bytes(n, kc, dim)) {
@@ -1340,9 +1351,11 @@ int pgnn_rowfeat_matmul_bwd(const float* cfeat, int64_t kc, const float* g, int6
     });
   }
   hipLaunchKernelGGL(k_rowfeat_bwd_final, dim3((int)ceil_div(kc * dim, 16)), dim3(kBlock), 0, st,
-                     partial, nb, (int)kc, (int)dim, gtable, ldgt);
+                     partial, nb, (int)kc, (int)dim, gtable, s_row, s_col, last_row_out);
   return check_launch("rowfeat_matmul_bwd");
 }
+
+extern "C" {
 
 int pgnn_embed_fwd(const int64_t* idx, int64_t idx_stride, const float* table1, int64_t rows1,
                    const float* table2, int64_t rows2, float* out, int64_t ldo, int64_t n, int64_t dim,

@@ -114,8 +114,21 @@ inline int env_knob(const char* name, int dflt) {
 }
 
 // (linear.hip) pgnn_split_weights + `nbump` device int64 counters incremented by the same launch (BatchNorm's num_batches_tracked)
+// ... and, for the bio stack, the [k+1, dim] edge-encoder tables [W_enc^T; b_enc] of up to 16 layers (W_enc [dim, k], b_enc [dim]):
+// the same launch writes them, instead of three torch.cat / stack launches per step
+struct EncTables {
+  const float* w[16];
+  const float* b[16];
+  float* dst[16];
+  int count, dim, k;
+};
 int split_weights_bump(const float* const* src, void* const* dst, const int64_t* rows, const int64_t* cols, const int32_t* transpose,
-                       int64_t count, int64_t* const* bump, int nbump, hipStream_t stream);
+                       int64_t count, int64_t* const* bump, int nbump, hipStream_t stream, const EncTables* tabs = nullptr);
+// (aggregate.hip) pgnn_rowfeat_matmul_bwd with a strided result: row r < kc, column c of the product goes to out[r * s_row + c * s_col],
+// except that with `last_row_out` the LAST row (the bias gradient of an edge encoder whose input carries a ones column) goes
+// there, contiguous
+int rowfeat_matmul_bwd_strided(const float* cfeat, int64_t kc, const float* g, int64_t ldg, float* out, int64_t s_row, int64_t s_col,
+                               float* last_row_out, int64_t n, int64_t dim, void* ws, size_t ws_bytes, hipStream_t stream);
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

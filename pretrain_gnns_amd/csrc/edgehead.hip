@@ -390,8 +390,8 @@ int pgnn_edge_head_bwd(const float* h, int64_t ldh, int64_t n_nodes, const int64
   const EdgeLabel L{label, label_stride, onehot, ld_onehot, (int)onehot_cols};
   hipLaunchKernelGGL(k_edge_dl, dim3((int)ceil_div(m, kEdgeBlock)), dim3(kEdgeBlock), 0, st, logits, (int)m, L, (int)classes, loss_float64,
                      gloss64, gloss32, e.dl, e.partial, db, counter);
-  // (endpoints were range-checked by the forward; the grouping's own count of bad keys lands in a scratch word)
-  PGNN_HIP(hipMemsetAsync(e.gstatus, 0, 4, st));
+  // (endpoints were range-checked by the forward; the grouping's own count of bad keys is added to a scratch word nobody reads,
+  // so nobody zeroes it either)
   if (int rc = pgnn_group_by_key(ends, 1, 2 * m, n_nodes, e.ptr, e.perm, e.gstatus, e.group_ws, e.group_bytes, stream)) return rc;
   hipLaunchKernelGGL(k_node_gsum, dim3((int)ceil_div(n_nodes * 8, kEdgeBlock)), dim3(kEdgeBlock), 0, st, e.dl, (int)m, e.ptr, e.perm,
                      (int)n_nodes, (int)classes, e.S);

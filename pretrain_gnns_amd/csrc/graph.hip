@@ -454,6 +454,61 @@ k_bio_payload(const int64_t* __restrict__ ei, const float* __restrict__ ea, int6
   }
 }
 
+// The same results from 16 lanes per node (4 nodes per wave): lane j of a group fetches edge j of a 16-edge chunk (its id, its
+// source, the normaliser) and writes in_src coalesced, then lane t < 10 owns feature column t and adds the chunk's 16 attribute
+// values -- all loaded before the first addition -- in edge order, exactly the order and the operations of k_bio_payload.
+// One thread per node walked three dependent loads per edge one edge at a time, and a protein's hub nodes (hundreds of
+// in-edges, 36-byte attribute rows at random offsets) set the kernel's time: 46 us on a 256-ego-net batch, the largest
+// launch of the build.
+__global__ void __launch_bounds__(256)
+k_bio_payload16(const int64_t* __restrict__ ei, const float* __restrict__ ea, int64_t E, int64_t N,
+                int gcn, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ perm_in,
+                int32_t* __restrict__ in_src, const int32_t* __restrict__ out_ptr,
+                const int32_t* __restrict__ perm_out, int32_t* __restrict__ out_dst,
+                float* __restrict__ dinv, float* __restrict__ cfeat) {
+  const int64_t i = (blockIdx.x * (int64_t)256 + threadIdx.x) >> 4;
+  if (i >= N) return;  // (a whole group of 16 lanes at a time)
+  const int t = threadIdx.x & 15, gbase = lane_id() & ~15;
+  const int beg = in_ptr[i], end = in_ptr[i + 1];
+  const float di = 1.0f / sqrtf((float)(end - beg + 1));
+  if (t == 0) dinv[i] = di;
+  float acc = 0.f;
+  for (int p0 = beg; p0 < end; p0 += 16) {
+    const int p = p0 + t, cnt = min(16, end - p0);
+    int e = 0;
+    float w = 0.f;
+    if (p < end) {
+      e = perm_in[p];
+      int64_t s = ei[E + e];
+      if (s < 0 || s >= N) s = 0;
+      in_src[p] = (int32_t)s;
+      w = gcn ? di * dinv_of(in_ptr, s) : 1.0f;
+    }
+    float av[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int ej = __shfl(e, gbase + j);
+      av[j] = (j < cnt && t < 9) ? ea[(int64_t)ej * 9 + t] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float wj = __shfl(w, gbase + j);
+      if (j < cnt) {
+        if (t < 9) acc += wj * av[j];
+        else if (t == 9) acc += wj;
+      }
+    }
+  }
+  const float ws = gcn ? di * di : 1.0f;  // self loop attr = one-hot(7), bio/model.py:42-43
+  if (t == 7 || t == 9) acc += ws;
+  if (t < 10) cfeat[i * 10 + t] = acc;
+  for (int p = out_ptr[i] + t; p < out_ptr[i + 1]; p += 16) {
+    int64_t d = ei[perm_out[p]];
+    if (d < 0 || d >= N) d = 0;
+    out_dst[p] = (int32_t)d;
+  }
+}
+
 // the three zero-initialised arrays of a graph build in ONE launch (three hipMemsetAsync calls are three fill kernels)
 struct ZeroJobs {
   int32_t* p[3];
@@ -494,6 +549,13 @@ int prepare_graph_jobs(const int64_t* ei, int64_t E, int64_t N, int32_t* in_ptr,
   g.jobs.j[1] = GroupJob{ei + E, 1, out_ptr, g.perm_out, cursors + N, tmp_out, bs_out};  // by source
   return PGNN_OK;
 }
+
+
+// (Measured and dropped, round 3: the whole chem build, and pgnn_group_by_key's generic path, as ONE workgroup of 1 024 threads
+// with counters, packed edges and 16-bit edge ids in LDS -- bit-identical, one launch instead of six.  A 256-molecule batch took
+// 59 us that way against ~30 us for the six launches: ~450 LDS operations per thread with random bank conflicts on one CU's LDS
+// cost more than five launch gaps, batched global loads made no difference; 45 us against 28 + 10 us for the masked-bond
+// endpoints of a bio batch.  profiles/r03/small_graph_ab.txt.)
 
 }  // namespace
 }  // namespace pgnn
@@ -544,6 +606,11 @@ int pgnn_bio_graph_build(const int64_t* ei, const float* ea, int64_t E, int64_t 
   if (rc) return rc;
   rc = run_group(g.jobs, 2, E, N, status, st);
   if (rc) return rc;
+  if (env_knob("PGNN_BIO_PAYLOAD16", 1) != 0) {
+    hipLaunchKernelGGL(k_bio_payload16, dim3((int)ceil_div(N * 16, 256)), dim3(256), 0, st, ei, ea, E, N, gcn, in_ptr,
+                       g.perm_in, in_src, out_ptr, g.perm_out, out_dst, dinv, cfeat);
+    return check_launch("bio_graph_build");
+  }
   const int nbk = (int)ceil_div(N, 256);
   hipLaunchKernelGGL(k_bio_payload, dim3(nbk), dim3(256), 0, st, ei, ea, E, N, gcn, in_ptr,
                      g.perm_in, in_src, out_ptr, g.perm_out, out_dst, dinv, cfeat);

@@ -17,7 +17,7 @@ namespace {
 constexpr int64_t kSideMaxRows = 32768;
 struct Side {
   hipStream_t stream = nullptr;
-  hipEvent_t fork[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t fork[4] = {nullptr, nullptr, nullptr, nullptr};  // [3]: chem stack backward, "embedding grouping done"
   hipEvent_t join = nullptr;
   hipEvent_t lag[2] = {nullptr, nullptr};  // stack backward: "aux finished with buffer set p"
   bool ok = false;
@@ -63,7 +63,7 @@ inline bool mlp_wp(int64_t n, int64_t d_in, int64_t d_hid, int64_t d_out, int nu
 // planes of W1 / W2 (transpose = 0) or W1^T / W2^T (1) of every layer: p1[l], p2[l] carved from `base`
 // (bump: also increment the layers' num_batches_tracked -- a training-mode forward -- in the same launch)
 inline int split_mlp_weights(const pgnn_gin_layer* layers, int num_layer, int64_t d_in, int64_t d_hid, int64_t d_out, int transpose,
-                             char* base, void** p1, void** p2, hipStream_t st, bool bump = false) {
+                             char* base, void** p1, void** p2, hipStream_t st, bool bump = false, const EncTables* tabs = nullptr) {
   const float* src[2 * kMaxPlaneLayers];
   void* dst[2 * kMaxPlaneLayers];
   int64_t rows[2 * kMaxPlaneLayers], cols[2 * kMaxPlaneLayers];
@@ -81,7 +81,7 @@ inline int split_mlp_weights(const pgnn_gin_layer* layers, int num_layer, int64_
   if (bump)
     for (int l = 0; l < num_layer; ++l)
       if (layers[l].num_batches_tracked) counters[nb++] = layers[l].num_batches_tracked;
-  return split_weights_bump(src, dst, rows, cols, tr, 2 * num_layer, counters, nb, st);
+  return split_weights_bump(src, dst, rows, cols, tr, 2 * num_layer, counters, nb, st, tabs);
 }
 // the same increment as a launch of its own, for the calls that split nothing (small batches on the fp32-MFMA products)
 __global__ void k_bump_counters(long long* c0, long long* c1, long long* c2, long long* c3, long long* c4, long long* c5, long long* c6,
@@ -432,29 +432,28 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   hipStream_t aux = sd ? sd->stream : main;
   char* aux_ws = sd ? op2 : op;
   int rc;
-  // Every event record / wait costs ~7 us of host time, so forks are spent only where they buy overlap:
-  // the atom-type / chirality grouping (a few tiny kernels) stays on the caller's stream, after the layers.
+  // Every event record / wait costs ~7 us of host time, so forks are spent only where they buy overlap.
   // (gstatus is scratch: the forward's embedding lookup validated x_idx, nobody reads the grouping's count -- no memset launch)
-  // W1^T / W2^T of the top `ntr` layers in one launch: backward-data then has both operands contiguous along the
-  // contracted dimension and runs the forward (split-bf16) kernel.  On the side stream when there is one: the first
-  // BatchNorm backward covers it.
-  // The atom-type x chirality grouping of the embedding gradients needs nothing from the backward: it goes to the side stream
-  // first, under the first BatchNorm backward of the caller's stream (the side stream has nothing to do until that is done),
-  // instead of after the last layer, where it sat on the critical path in front of the segment sums.
+  // W1^T / W2^T planes of the whole stack in one launch (without planes: transposes of the top `ntr` layers): backward-data
+  // then has both operands contiguous along the contracted dimension and runs the forward (split-bf16) kernel.
+  // The atom-type x chirality grouping of the embedding gradients needs nothing from the backward: with a side stream it
+  // runs there, behind the split, while the caller's stream does the top layer's BatchNorm backward and first products
+  // (without one it stays on the caller's stream after the layers, in front of the segment sums).
   const bool group_early = sd != nullptr;
   if (sd) {
     PGNN_HIP(hipEventRecord(sd->fork[0], main));  // (the workspace words it writes were the previous call's until here)
     PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[0], 0));
-    if ((rc = embed_tables_group(x_idx, n, rows1, rows2, dxemb1, dxemb2, gptr[0], gperm[0], gptr[1], gperm[1], gstatus, grp_ws, grp_b, aux)))
-      return rc;
   }
-  bool waited_fork2 = false;
+  // The caller's stream needs the planes (or transposes) for its first product only, i.e. after the top layer's BatchNorm
+  // backward: the wait for fork[2] is enqueued there, not here, and the side stream does the split BEFORE the grouping
+  // (fork[3], awaited in front of the embedding gradients) -- with the wait up here the step began with ~26 us of the
+  // caller's stream idling behind four tiny side-stream launches.
+  bool wait_fork2 = false;
   if (wp) {
     if ((rc = split_mlp_weights(layers, num_layer, dim, 2 * dim, dim, 1, plane_base, wp1, wp2, aux))) return rc;  // (aux already waits on fork[0])
     if (sd) {
       PGNN_HIP(hipEventRecord(sd->fork[2], aux));
-      PGNN_HIP(hipStreamWaitEvent(main, sd->fork[2], 0));
-      waited_fork2 = true;  // ... which also covers the grouping
+      wait_fork2 = true;
     }
   } else if (ntr > 0 && use_transposed_weights(n)) {
     const float* tsrc[2 * kMaxTransposed];
@@ -468,11 +467,13 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     if ((rc = pgnn_transpose_batch(tsrc, tdst, trows, tcols, 2 * ntr, aux))) return rc;  // (aux already waits on fork[0])
     if (sd) {
       PGNN_HIP(hipEventRecord(sd->fork[2], aux));
-      PGNN_HIP(hipStreamWaitEvent(main, sd->fork[2], 0));
-      waited_fork2 = true;  // ... which also covers the grouping
+      wait_fork2 = true;
     }
-  } else if (sd) {
-    PGNN_HIP(hipEventRecord(sd->fork[2], aux));  // grouping done; the caller's stream waits for it after the layers
+  }
+  if (sd) {
+    if ((rc = embed_tables_group(x_idx, n, rows1, rows2, dxemb1, dxemb2, gptr[0], gperm[0], gptr[1], gperm[1], gstatus, grp_ws, grp_b, aux)))
+      return rc;
+    PGNN_HIP(hipEventRecord(sd->fork[3], aux));
   }
   const bool tr = ntr > 0 && use_transposed_weights(n);
 
@@ -490,6 +491,10 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     const float* mean = stats + (size_t)l * 4 * dim;
     if ((rc = pgnn_bn_bwd(g, ldg, z, dim, p.gamma, p.beta, mean, mean + dim, training, l != num_layer - 1, dz[b], dim,
                           p.dgamma, p.dbeta, drop_p, drop_seed + (uint64_t)l, n, dim, op, opb, main))) return rc;
+    if (wait_fork2) {
+      PGNN_HIP(hipStreamWaitEvent(main, sd->fork[2], 0));
+      wait_fork2 = false;
+    }
     if (wp) {
       if ((rc = pgnn_linear_bwd_data_wp(dz[b], dim, wp2[l], hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main))) return rc;
       if ((rc = pgnn_linear_bwd_data_wp(dhid[b], 2 * dim, wp1[l], nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main))) return rc;
@@ -523,7 +528,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   // The embedding gradients need the last aggregation only, not the side stream's weight gradients: they run beside the
   // bottom layer's two weight-gradient products, and the join comes after them (it used to come before: ~70 us of one
   // stream idling per 256-graph step).
-  if (sd && !waited_fork2) PGNN_HIP(hipStreamWaitEvent(main, sd->fork[2], 0));  // the grouping (finished long ago)
+  if (sd) PGNN_HIP(hipStreamWaitEvent(main, sd->fork[3], 0));  // the grouping (finished long ago)
   rc = embed_tables_bwd(g, x_idx, n, dim, rows1, rows2, dxemb1, dxemb2, gptr[0], gperm[0], gptr[1], gperm[1], gstatus, grp_ws,
                         grp_b, seg_ws, seg_b, pair_sums, group_early, main);
   if (sd) {  // join: nothing of this call is in flight on the side stream once the caller's stream passes this point
@@ -697,7 +702,9 @@ size_t pgnn_bio_gin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t num_la
   // + the per-16-row column statistics of the 2D-wide pre-activation and the BatchNorm coefficients (forward, statistics from the
   // product's epilogue)
   const size_t blocks = align_up((size_t)ceil_div(n, 16) * 2 * 2 * dim * 4, 256) + align_up((size_t)2 * 2 * dim * 4, 256);
-  return 2 * bio_op_ws_bytes(n, dim) + 2 * 7 * nd + wt + blocks + 512;
+  // + the [10, dim] edge-encoder tables the forward builds when it is handed edge_encoder.weight / .bias as they are
+  const size_t tabs = align_up((size_t)std::min<int64_t>(num_layer, 16) * 10 * dim * 4, 256);
+  return 2 * bio_op_ws_bytes(n, dim) + 2 * 7 * nd + wt + blocks + tabs + 512;
 }
 
 int pgnn_bio_gin_stack_fwd(const float* h0, int64_t ldh0, const int32_t* in_ptr, const int32_t* in_src, const float* cfeat,
@@ -721,15 +728,33 @@ int pgnn_bio_gin_stack_fwd(const float* h0, int64_t ldh0, const int32_t* in_ptr,
   void *wp1[kMaxPlaneLayers], *wp2[kMaxPlaneLayers];
   const size_t planes_b = (size_t)num_layer * mlp_planes_bytes(2 * dim, 2 * dim, dim);
   const bool wp = mlp_wp(n, 2 * dim, 2 * dim, dim, num_layer) && ws_bytes >= opb + planes_b;
+  // layers[l].emb2 set: emb1 / emb2 are edge_encoder.weight [dim, 9] / .bias [dim] as the module holds them, and the [10, dim] table
+  // [W^T; b] of every layer is written by the launch that splits the weights (emb2 NULL: emb1 IS that table)
+  const bool enc_raw = layers[0].emb2 != nullptr;
+  const float* table[kMaxPlaneLayers];
+  EncTables tabs{};
+  const size_t coef_b = align_up((size_t)2 * 2 * dim * 4, 256);
+  const size_t blocks_b = align_up((size_t)ceil_div(n, 16) * 2 * 2 * dim * 4, 256);
+  if (enc_raw) {
+    const size_t tabs_off = opb + planes_b + blocks_b + coef_b, tabs_b = align_up((size_t)num_layer * 10 * dim * 4, 256);
+    PGNN_REQUIRE(num_layer <= 16 && ws_bytes >= tabs_off + tabs_b, "bio_gin_stack_fwd: workspace too small for %d encoder tables", num_layer);
+    float* tb = reinterpret_cast<float*>(static_cast<char*>(ws) + tabs_off);
+    tabs.count = num_layer, tabs.dim = (int)dim, tabs.k = 9;
+    for (int l = 0; l < num_layer; ++l) {
+      PGNN_REQUIRE(layers[l].emb1 && layers[l].emb2, "bio_gin_stack_fwd: edge encoder of layer %d missing", l);
+      tabs.w[l] = layers[l].emb1, tabs.b[l] = layers[l].emb2, tabs.dst[l] = tb + (size_t)l * 10 * dim;
+      table[l] = tabs.dst[l];
+    }
+  }
   if (wp && (rc = split_mlp_weights(layers, num_layer, 2 * dim, 2 * dim, dim, 0, static_cast<char*>(ws) + opb, wp1, wp2, (hipStream_t)stream,
-                                    training != 0)))
+                                    training != 0, enc_raw ? &tabs : nullptr)))
     return rc;
   if (!wp && training && (rc = bump_batches_tracked(layers, num_layer, (hipStream_t)stream))) return rc;
+  if (!wp && enc_raw && (rc = split_weights_bump(nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, (hipStream_t)stream, &tabs))) return rc;
   // training-mode statistics of the mlp's BatchNorm1d(2D) from the epilogue of the product that writes its input (the chem form,
   // csrc/batchnorm.hip pgnn_bn_stats_fwd_blocks): no pass over `pre` for them, two launches less per layer
-  const size_t blocks_b = align_up((size_t)ceil_div(n, 16) * 2 * 2 * dim * 4, 256);
   const bool stats_in_gemm = wp && training && n > 1 && n <= kStatsInGemmMaxRows && env_knob("PGNN_BN_STATS_IN_GEMM", 1) != 0 &&
-                             ws_bytes >= opb + planes_b + blocks_b + align_up((size_t)2 * 2 * dim * 4, 256);
+                             ws_bytes >= opb + planes_b + blocks_b + coef_b;
   float* blocks = reinterpret_cast<float*>(static_cast<char*>(ws) + opb + planes_b);
   float* coef = reinterpret_cast<float*>(static_cast<char*>(ws) + opb + planes_b + blocks_b);
   for (int l = 0; l < num_layer; ++l) {
@@ -738,11 +763,11 @@ int pgnn_bio_gin_stack_fwd(const float* h0, int64_t ldh0, const int32_t* in_ptr,
     float *agg = a, *pre = a + 2 * nd, *hid = a + 4 * nd, *y = a + 6 * nd;
     float* st = stats + (size_t)l * 4 * dim;  // mean [2D], invstd [2D]
     if (tile_start && num_tiles) {
-      rc = pgnn_neighbor_sum_tiled(h, ldh, in_ptr, in_src, nullptr, tile_start, num_tiles, agg, 2 * dim, n, dim, cfeat, 10, p.emb1,
-                                   dim, agg + dim, 2 * dim, stream);
+      rc = pgnn_neighbor_sum_tiled(h, ldh, in_ptr, in_src, nullptr, tile_start, num_tiles, agg, 2 * dim, n, dim, cfeat, 10,
+                                   enc_raw ? table[l] : p.emb1, dim, agg + dim, 2 * dim, stream);
     } else {
       if ((rc = pgnn_neighbor_sum(h, ldh, in_ptr, in_src, nullptr, agg, 2 * dim, n, dim, stream))) return rc;
-      rc = pgnn_rowfeat_matmul_fwd(cfeat, 10, p.emb1, dim, agg + dim, 2 * dim, n, dim, 0, stream);
+      rc = pgnn_rowfeat_matmul_fwd(cfeat, 10, enc_raw ? table[l] : p.emb1, dim, agg + dim, 2 * dim, n, dim, 0, stream);
     }
     if (rc) return rc;
     if (wp) rc = pgnn_linear_fwd_wp(agg, 2 * dim, wp1[l], p.b1, pre, 2 * dim, n, 2 * dim, 2 * dim, 0, stats_in_gemm ? blocks : nullptr, stream);
@@ -867,7 +892,10 @@ int pgnn_bio_gin_stack_bwd(const float* dy, int64_t lddy, const int32_t* out_ptr
     // parameter gradients (side stream when there is one): dW2 = g^T hid, dW1 = dpre^T agg, d EncT = cfeat^T dagg[:, D:]
     if ((rc = pgnn_linear_bwd_weight(g, ldg, hid, 2 * dim, p.dw2, p.db2, n, 2 * dim, dim, aux_ws, opb, aux))) return rc;
     if ((rc = pgnn_linear_bwd_weight(dpre[b], 2 * dim, agg, 2 * dim, p.dw1, p.db1, n, 2 * dim, 2 * dim, aux_ws, opb, aux))) return rc;
-    if ((rc = pgnn_rowfeat_matmul_bwd(cfeat, 10, dagg[b] + dim, 2 * dim, p.demb, dim, n, dim, aux_ws, opb, aux))) return rc;
+    // d EncT [10, dim]; with the raw encoder (emb2 set) laid out as the module's gradients: d weight [dim, 9], then d bias [dim]
+    if (p.emb2) rc = rowfeat_matmul_bwd_strided(cfeat, 10, dagg[b] + dim, 2 * dim, p.demb, 1, 9, p.demb + 9 * dim, n, dim, aux_ws, opb, aux);
+    else rc = pgnn_rowfeat_matmul_bwd(cfeat, 10, dagg[b] + dim, 2 * dim, p.demb, dim, n, dim, aux_ws, opb, aux);
+    if (rc) return rc;
     if (sd && l >= 1) PGNN_HIP(hipEventRecord(sd->lag[b], aux));
     if (l == 0 && !dh0) break;
     // dx goes to the buffer set of its consumer, layer l - 1; that set (and its dx slot, which the side stream reads as the

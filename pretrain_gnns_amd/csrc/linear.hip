@@ -1061,9 +1061,17 @@ struct SplitJobs {
   int transpose[32];
   long long* bump[16];  // device counters this launch increments by one (BatchNorm's num_batches_tracked), nbump of them
   int nbump;
+  EncTables tabs;  // edge-encoder tables written by the blocks of job 0 (count = 0: none)
 };
 __global__ void __launch_bounds__(256) k_split_jobs(SplitJobs jobs) {
   if (blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < jobs.nbump) *jobs.bump[threadIdx.x] += 1;
+  if (jobs.tabs.count && blockIdx.y == 0) {
+    const int dim = jobs.tabs.dim, k = jobs.tabs.k, per = (k + 1) * dim;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < jobs.tabs.count * per; i += gridDim.x * 256) {
+      const int l = i / per, q = i - l * per, r = q / dim, c = q - r * dim;
+      jobs.tabs.dst[l][q] = r < k ? jobs.tabs.w[l][(int64_t)c * k + r] : jobs.tabs.b[l][c];
+    }
+  }
   __shared__ float tile[32][33];
   const int j = blockIdx.y, rows = jobs.rows[j], cols = jobs.cols[j], ld = jobs.ld[j];
   const bool tr = jobs.transpose[j] != 0;
@@ -1396,10 +1404,13 @@ int pgnn_split_weights(const float* const* src, void* const* dst, const int64_t*
 }  // extern "C"
 
 int pgnn::split_weights_bump(const float* const* src, void* const* dst, const int64_t* rows, const int64_t* cols, const int32_t* transpose,
-                             int64_t count, int64_t* const* bump, int nbump, hipStream_t stream) {
+                             int64_t count, int64_t* const* bump, int nbump, hipStream_t stream, const EncTables* tabs) {
   PGNN_REQUIRE(count >= 0 && count <= 32 && nbump >= 0 && nbump <= 16, "split_weights: at most 32 matrices (and 16 counters) per call");
-  if (count == 0) return PGNN_OK;
+  PGNN_REQUIRE(!tabs || (tabs->count >= 0 && tabs->count <= 16 && tabs->dim > 0 && tabs->k > 0), "split_weights: at most 16 encoder tables");
+  const bool with_tabs = tabs && tabs->count > 0;
+  if (count == 0 && !with_tabs) return PGNN_OK;
   SplitJobs jobs{};
+  if (with_tabs) jobs.tabs = *tabs;
   for (int j = 0; j < nbump; ++j) jobs.bump[j] = reinterpret_cast<long long*>(bump[j]);
   jobs.nbump = nbump;
   int64_t most = 1;
@@ -1411,7 +1422,8 @@ int pgnn::split_weights_bump(const float* const* src, void* const* dst, const in
     jobs.ld[j] = (int)(ceil_div(jobs.cols[j], 32) * 32); jobs.transpose[j] = tr;
     most = std::max(most, ceil_div(jobs.rows[j], 32) * (jobs.ld[j] / 32));
   }
-  hipLaunchKernelGGL(k_split_jobs, dim3((int)std::min<int64_t>(most, 4096), (int)count), dim3(256), 0, stream, jobs);
+  if (with_tabs) most = std::max<int64_t>(most, std::min<int64_t>(ceil_div((int64_t)tabs->count * (tabs->k + 1) * tabs->dim, 256), 64));
+  hipLaunchKernelGGL(k_split_jobs, dim3((int)std::min<int64_t>(most, 4096), (int)std::max<int64_t>(count, 1)), dim3(256), 0, stream, jobs);
   return check_launch("split_weights");
 }
 

@@ -1428,13 +1428,12 @@ class BioGINStack(Function):
         for t in params:
             if t.dtype != torch.float32 or not t.is_contiguous():
                 raise _lib.PgnnError("model parameters must be contiguous float32 tensors")
-        # [W_enc^T; b_enc] of every layer in one [L, 10, D] tensor
-        tables = torch.cat([torch.stack([params[8 * l].t() for l in range(L)]),
-                            torch.stack([params[8 * l + 1] for l in range(L)]).unsqueeze(1)], dim=1).contiguous()
         layers = (_lib.GinLayer * L)()
         for l in range(L):
             s_, p = layers[l], params[8 * l:8 * l + 8]
-            s_.emb1 = tables[l].data_ptr()
+            # edge_encoder.weight [D, 9] / .bias [D] as they are: the call writes the [10, D] tables [W^T; b] in the launch that
+            # splits the weights (three torch.cat / stack launches per step otherwise)
+            s_.emb1, s_.emb2 = p[0].data_ptr(), p[1].data_ptr()
             s_.w1, s_.b1, s_.w2, s_.b2, s_.gamma, s_.beta = [t.data_ptr() for t in p[2:]]
             rm, rv, momentum, eps, nbt = bns[l]
             s_.running_mean = rm.data_ptr() if rm is not None else None
@@ -1449,19 +1448,21 @@ class BioGINStack(Function):
             h0.data_ptr(), h0.stride(0), graph.in_ptr.data_ptr(), graph.in_src.data_ptr(), graph.cfeat.data_ptr(),
             tiles[0].data_ptr() if tiles is not None else None, tiles[1].data_ptr() if tiles is not None else None, layers, L,
             int(training), acts.data_ptr(), stats.data_ptr(), n, dim, ws.data_ptr(), ws.numel(), stream_ptr()), "pgnn_bio_gin_stack_fwd")
-        ctx.save_for_backward(acts, stats, tables, *params)
+        ctx.save_for_backward(acts, stats, *params)
         ctx.graph, ctx.training, ctx.layers = graph, bool(training), layers
         return acts[L - 1, 6]
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        acts, stats, tables = ctx.saved_tensors[:3]
+        acts, stats = ctx.saved_tensors[:2]
         L, _, n, dim = acts.shape
         dy = _rows2d(dy)
         dev = dy.device
         graph = ctx.graph
-        # one flat gradient buffer: per layer d EncT [10, D], dw1 [2D, 2D], db1 [2D], dw2 [D, 2D], db2 [D], dgamma [2D], dbeta [2D]
+        # one flat gradient buffer: per layer d enc_w [D, 9] + d enc_b [D] (one piece for the call: the layers carry emb2, so the
+        # gradient comes in the module's layout and autograd takes the views as they are -- a [9, D] result transposed here cost
+        # one copy launch per layer), dw1 [2D, 2D], db1 [2D], dw2 [D, 2D], db2 [D], dgamma [2D], dbeta [2D]
         per = [10 * dim, 4 * dim * dim, 2 * dim, 2 * dim * dim, dim, 2 * dim, 2 * dim]
         flat = torch.empty(L * sum(per), dtype=torch.float32, device=dev)
         layers = _private_layers(ctx.layers)
@@ -1482,8 +1483,7 @@ class BioGINStack(Function):
         grads = []
         for l in range(L):
             denc, dw1, db1, dw2, db2, dgam, dbet = views[l]
-            denc = denc.view(10, dim)
-            grads += [denc[:9].t(), denc[9], dw1.view(2 * dim, 2 * dim), db1, dw2.view(dim, 2 * dim), db2, dgam, dbet]
+            grads += [denc[:9 * dim].view(dim, 9), denc[9 * dim:], dw1.view(2 * dim, 2 * dim), db1, dw2.view(dim, 2 * dim), db2, dgam, dbet]
         return (dh0, None, None) + tuple(grads)
 
 

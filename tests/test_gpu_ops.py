@@ -247,6 +247,31 @@ def test_bio_aggregate_fwd_bwd(gcn):
     torch.testing.assert_close(bb.grad.cpu(), conv.edge_encoder.bias.grad, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("gcn", [False, True])
+def test_bio_graph_payload_by_16_lanes_per_node_is_bit_identical(gcn, monkeypatch):
+    """pgnn_bio_graph_build's last launch: 16 lanes per node (a 16-edge chunk fetched at once, one feature column per lane, additions
+    in edge order) against one thread per node -- same bits in every output, hub nodes and bad source indices included"""
+    ops = _ops()
+    b = hostdata.bio_masking_batch(24, seed=11)
+    n = b.x.size(0)
+    ei, ea = b.edge_index.clone(), b.edge_attr.clone()
+    ei[0, : min(700, ei.size(1))] = 3  # a hub: 700 in-edges, several 16-edge chunks with a ragged tail
+    ei[1, 5] = n + 4                   # out-of-range source: clamped, counted
+    e = ei.size(1)
+    got = {}
+    for knob in ("0", "1"):
+        monkeypatch.setenv("PGNN_BIO_PAYLOAD16", knob)
+        ops.load().pgnn_reload_env()
+        g = ops.build_bio_graph(ei.to(DEV), ea.to(DEV), n, gcn=gcn)
+        got[knob] = ({k: getattr(g, k).cpu().numpy()[: (e if k in ("in_src", "out_dst") else None)].copy()
+                      for k in ("in_ptr", "out_ptr", "in_src", "out_dst", "dinv", "cfeat")}, int(g.status.item()))
+    monkeypatch.delenv("PGNN_BIO_PAYLOAD16")
+    ops.load().pgnn_reload_env()
+    for k, want in got["0"][0].items():
+        assert np.array_equal(want.view(np.uint8), got["1"][0][k].view(np.uint8)), k
+    assert got["0"][1] == got["1"][1] > 0
+
+
 def test_embed_fwd_bwd():
     ops = _ops()
     n, dim = 3000, 300
@@ -1052,6 +1077,21 @@ def test_bio_gat_aggregate_fwd_bwd(shape):
     torch.testing.assert_close(bb.grad.cpu(), conv.edge_encoder.bias.grad, rtol=1e-4, atol=1e-3)
     again = ops.BioGATAggregate.apply(xh.detach(), att.detach(), bias.detach(), w.detach(), bb.detach(), g, feat, conv.negative_slope)
     assert torch.equal(again, got.detach())
+
+
+@pytest.mark.parametrize("n_keys,n_items,hub", [(1500, 4000, False), (11000, 28000, True), (2000, 1, False), (5000, 40000, False)])
+def test_group_by_key_matches_the_stable_sort(n_keys, n_items, hub):
+    """pgnn_group_by_key beyond the radix pass's 1 024 keys (CSR fill + in-segment ranking): numpy's stable argsort and its
+    pointer array, a 3 000-item segment (ranked by a whole wave) included"""
+    ops = _ops()
+    rng = np.random.default_rng(n_keys + n_items)
+    key = rng.integers(0, n_keys, size=n_items)
+    if hub:
+        key[100:3100] = 77
+    want_ptr, want_perm = _ref_csr(key, n_keys)
+    ptr, perm = ops.group_by_key(torch.from_numpy(key).to(DEV), n_keys)
+    assert np.array_equal(ptr.cpu().numpy(), want_ptr)
+    assert np.array_equal(perm.cpu().numpy()[:n_items], want_perm)
 
 
 @pytest.mark.parametrize("sorted_batch", [True, False])
