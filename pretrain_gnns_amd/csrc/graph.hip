@@ -135,26 +135,42 @@ __global__ void __launch_bounds__(256) k_scan_bsum(GroupJobs jobs, int nb) {
 
 __global__ void k_scan_add(GroupJobs jobs, int64_t n);
 
-// whole scan in ONE block (any n, meant for n <= ~32k): chunks of 1024 with a running carry
-__global__ void __launch_bounds__(256) k_scan_single(GroupJobs jobs, int64_t n) {
-  __shared__ int lds[4];
+// whole scan in ONE block of 1 024 threads (any n, meant for n <= ~32k): chunks of 8 192 (8 consecutive items per thread) with a
+// running carry.  (256 threads x 4 items took seven trips and 9.7 us for the 6 741 + 1 pointers of a 256-molecule batch.)
+constexpr int kScanSingleThreads = 1024;
+__global__ void __launch_bounds__(kScanSingleThreads) k_scan_single(GroupJobs jobs, int64_t n) {
+  __shared__ int wsum[kScanSingleThreads / 64];
   int32_t* d = jobs.j[blockIdx.y].ptr;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   int carry = 0;
-  for (int64_t base0 = 0; base0 < n; base0 += kScanItems) {
-    const int64_t base = base0 + threadIdx.x * 4;
-    int v[4];
+  for (int64_t base0 = 0; base0 < n; base0 += kScanSingleThreads * 8) {
+    const int64_t base = base0 + tid * 8;
+    int v[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (base + i < n) ? d[base + i] : 0;
-    v[1] += v[0];
-    v[2] += v[1];
-    v[3] += v[2];
-    int total;
-    const int incl = block_scan_256(v[3], lds, total);
-    const int excl = carry + incl - v[3];
+    for (int i = 0; i < 8; ++i) v[i] = (base + i < n) ? d[base + i] : 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 1; i < 8; ++i) v[i] += v[i - 1];
+    int incl = v[7];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int add = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < kScanSingleThreads / 64; ++i) {
+      const int t = wsum[i];
+      add += i < w ? t : 0;
+      total += t;
+    }
+    const int excl = carry + add + incl - v[7];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
       if (base + i < n) d[base + i] = v[i] + excl;
     carry += total;
+    __syncthreads();
   }
 }
 
@@ -163,7 +179,7 @@ constexpr int64_t kScanSingleMax = 32768;
 // in-place inclusive scan of jobs.j[0..njobs).ptr[0..n)
 inline void launch_scan(GroupJobs jobs, int njobs, int64_t n, hipStream_t st) {
   if (n <= kScanSingleMax) {
-    hipLaunchKernelGGL(k_scan_single, dim3(1, njobs), dim3(256), 0, st, jobs, n);
+    hipLaunchKernelGGL(k_scan_single, dim3(1, njobs), dim3(kScanSingleThreads), 0, st, jobs, n);
     return;
   }
   const int nb = (int)ceil_div(n, kScanItems);

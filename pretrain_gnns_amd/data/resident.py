@@ -287,6 +287,7 @@ class ResidentLoader:
         self.mask_rate, self.mask_edge, self.rank, self.world = float(mask_rate), bool(mask_edge), int(rank), int(world_size)
         self.drop_last = drop_last
         self.epoch = 0
+        self._staging = None  # two pinned id buffers + the events of their last uploads (see _upload)
 
     def _keeps_tail(self):
         """the last, short global batch is used iff drop_last is off AND every rank gets at least one graph of it:
@@ -317,13 +318,32 @@ class ResidentLoader:
             out.append(glob[lo:hi])
         return out
 
+    def _upload(self, ids, epoch):
+        """the epoch's graph ids to the device WITHOUT waiting for the queue to drain: a copy from pageable host memory returns
+        only when it has executed, i.e. behind every step already enqueued -- with a few batches per epoch that was one
+        pipeline stall per epoch (measured: 4 steps per epoch, 2.46 ms per bio step against 2.30 without the stall).  Pinned
+        staging, one buffer per epoch parity; a buffer is rewritten only after the event of its previous upload."""
+        dev = torch.device(self.ds.device)
+        if dev.type != "cuda":
+            return torch.from_numpy(ids).to(dev)
+        if self._staging is None or self._staging[0][0].numel() < ids.size:
+            cap = max(ids.size, len(self.ds))
+            self._staging = [(torch.empty(cap, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+        buf, ev = self._staging[epoch & 1]
+        ev.synchronize()  # (a never-recorded event returns at once)
+        buf[:ids.size].copy_(torch.from_numpy(ids))
+        with torch.cuda.device(dev):
+            flat = buf[:ids.size].to(dev, non_blocking=True)
+            ev.record()
+        return flat
+
     def __iter__(self):
         epoch = self.epoch
         self.epoch += 1
         batches = self.batch_ids(epoch)
         if not batches:
             return
-        flat = torch.from_numpy(np.concatenate(batches)).to(self.ds.device)  # one upload per epoch
+        flat = self._upload(np.concatenate(batches), epoch)  # one upload per epoch
         off = 0
         for step, ids in enumerate(batches):
             seed = (self.seed * 1000003 + epoch) * 1000003 + step

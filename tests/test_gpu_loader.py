@@ -231,6 +231,25 @@ def test_loader_epoch_covers_dataset_once():
     assert seen_nodes == sum(g.x.size(0) for g in graphs)
 
 
+def test_loader_epochs_through_the_pinned_id_staging_match_the_host_permutation():
+    """five epochs back to back without a synchronisation in between: the graph ids of every epoch go up through one of two
+    pinned staging buffers (no pipeline stall at the epoch boundary), and every batch must still be the collate of exactly
+    ``batch_ids(epoch)`` -- node counts per batch against the host's, epoch after epoch, also after a buffer is reused"""
+    graphs = _chem_graphs(50, seed=17)
+    sizes = np.array([g.x.size(0) for g in graphs])
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    loader = resident.ResidentLoader(ds, batch_size=16, shuffle=True, seed=9)
+    got, want = [], []
+    for epoch in range(5):
+        want.append([int(sizes[ids].sum()) for ids in loader.batch_ids(epoch)])
+        got.append([b.batch for b in loader])  # device tensors only: nothing waits for the GPU inside the epochs
+    for epoch in range(5):
+        assert [int(b.numel()) for b in got[epoch]] == want[epoch]
+        for b, ids in zip(got[epoch], loader.batch_ids(epoch)):
+            counts = torch.bincount(b.cpu(), minlength=ids.size).numpy()
+            assert np.array_equal(counts, sizes[ids])
+
+
 CTX_KEYS = ("x_substruct", "edge_index_substruct", "edge_attr_substruct", "x_context", "edge_index_context",
             "edge_attr_context", "center_substruct_idx", "overlap_context_substruct_idx", "batch_overlapped_context",
             "overlapped_context_size")
