@@ -124,6 +124,13 @@ struct EncTables {
 };
 int split_weights_bump(const float* const* src, void* const* dst, const int64_t* rows, const int64_t* cols, const int32_t* transpose,
                        int64_t count, int64_t* const* bump, int nbump, hipStream_t stream, const EncTables* tabs = nullptr);
+// (tile.hip) pgnn_neighbor_sum_tiled whose result is zeroed where mask[i, c] <= 0 (the ReLU between two layers, backward), when
+// the launch that runs can do it: *mask_applied says whether it did (the pipelined kernel of large batches and the untiled
+// fall-back cannot -- the caller masks in a pass of its own then)
+int neighbor_sum_tiled_masked(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* nbr, const float* dinv,
+                              const int32_t* tile_start, const int32_t* num_tiles, float* out, int64_t ldo, int64_t num_nodes,
+                              int64_t dim, const float* cfeat, int64_t kc, const float* table, int64_t ldt, float* feat_out,
+                              int64_t ld_feat_out, const float* mask, int64_t ldm, bool* mask_applied, hipStream_t stream);
 // (aggregate.hip) pgnn_rowfeat_matmul_bwd with a strided result: row r < kc, column c of the product goes to out[r * s_row + c * s_col],
 // except that with `last_row_out` the LAST row (the bias gradient of an edge encoder whose input carries a ones column) goes
 // there, contiguous

@@ -35,6 +35,7 @@ __global__ void __launch_bounds__(kHeadThreads * kHeadSlices) k_head_fwd(const f
   __shared__ double red[kHeadThreads];
   __shared__ int redi[kHeadThreads];
   __shared__ float part[kHeadSlices][kHeadRows][kHeadThreads];
+  __shared__ float zhi[kHeadRows][64];  // logits of classes 64 .. 127, handed to wave 0
   __shared__ bool last;
   const int r0 = blockIdx.x * kHeadRows, tid = threadIdx.x, c = tid & (kHeadThreads - 1), sl = tid / kHeadThreads;
   const int nr = min(kHeadRows, m - r0);
@@ -57,7 +58,7 @@ __global__ void __launch_bounds__(kHeadThreads * kHeadSlices) k_head_fwd(const f
     for (int i = 0; i < kHeadRows; ++i) acc[i] = 0.f;
     if (c < classes) {
       const float4* wr = reinterpret_cast<const float4*>(w + (int64_t)c * dim);
-#pragma unroll 2
+#pragma unroll 4
       for (int k4 = sl; k4 < dim / 4; k4 += kHeadSlices) {  // slice sl takes every fourth float4 of its class row
         const float4 wv = wr[k4];
 #pragma unroll
@@ -87,41 +88,51 @@ __global__ void __launch_bounds__(kHeadThreads * kHeadSlices) k_head_fwd(const f
       }
   }
   if (sl != 0) return;  // the soft-max below is the first 128 threads' (whole waves: the barriers that follow count them only)
+  // Row maximum with its FIRST index (torch.max's tie rule) and the sum of exp in float64, all rows of the block at once by
+  // wave 0: classes 64.. come over from wave 1 through LDS (the s = 64 step of the 128-wide tree this replaces), the steps
+  // s = 32 .. 1 are lane shuffles with the tree's pairing -- the same operations on the same operands, bit for bit, without its
+  // fourteen barriers per row (4 rows x 18 barriers were a third of the launch).
+  if (c >= 64) {
+#pragma unroll
+    for (int i = 0; i < kHeadRows; ++i) zhi[i][c - 64] = z[i];
+  }
+  __syncthreads();
   double blk_nll = 0.0;
   int blk_hit = 0;
-  for (int i = 0; i < nr; ++i) {
-    // row maximum and its FIRST index (torch.max's tie rule), then the sum of exp in float64
-    red[c] = (double)z[i];
-    redi[c] = c;
-    __syncthreads();
-    for (int s = kHeadThreads / 2; s > 0; s >>= 1) {
-      if (c < s) {
-        const double a = red[c], o = red[c + s];
-        if (o > a || (o == a && redi[c + s] < redi[c])) {
-          red[c] = o;
-          redi[c] = redi[c + s];
+  if (c < 64) {
+#pragma unroll
+    for (int i = 0; i < kHeadRows; ++i) {
+      if (i >= nr) continue;
+      const double zlo = (double)z[i], zup = (double)zhi[i][c];
+      double a = zlo;
+      int ai = c;
+      if (zup > a) {  // (an equal value at index c + 64 loses to index c)
+        a = zup;
+        ai = c + 64;
+      }
+#pragma unroll
+      for (int sh = 32; sh > 0; sh >>= 1) {
+        const double o = __shfl_down(a, sh);
+        const int oi = __shfl_down(ai, sh);
+        if (o > a || (o == a && oi < ai)) {
+          a = o;
+          ai = oi;
         }
       }
-      __syncthreads();
+      const double zmax = __shfl(a, 0);
+      const int arg = __shfl(ai, 0);
+      double v = (c < classes ? exp(zlo - zmax) : 0.0) + (c + 64 < classes ? exp(zup - zmax) : 0.0);
+#pragma unroll
+      for (int sh = 32; sh > 0; sh >>= 1) v += __shfl_down(v, sh);
+      if (c == 0) {
+        const int64_t y = label[(int64_t)(r0 + i) * label_stride];
+        const bool yok = y >= 0 && y < classes;
+        if (!yok) atomicAdd(status, 1);
+        const double zy = yok ? (double)logits[(int64_t)(r0 + i) * classes + y] : 0.0;  // written by thread y of this block, before the barrier
+        blk_nll += log(v) + zmax - zy;  // rows of a block in order, blocks in order below: the same sums every run
+        blk_hit += (yok && arg == (int)y) ? 1 : 0;
+      }
     }
-    const double zmax = red[0];
-    const int arg = redi[0];
-    __syncthreads();
-    red[c] = c < classes ? exp((double)z[i] - zmax) : 0.0;
-    __syncthreads();
-    for (int s = kHeadThreads / 2; s > 0; s >>= 1) {
-      if (c < s) red[c] += red[c + s];
-      __syncthreads();
-    }
-    if (c == 0) {
-      const int64_t y = label[(int64_t)(r0 + i) * label_stride];
-      const bool yok = y >= 0 && y < classes;
-      if (!yok) atomicAdd(status, 1);
-      const double zy = yok ? (double)logits[(int64_t)(r0 + i) * classes + y] : 0.0;  // written by thread y of this block, before the syncs
-      blk_nll += log(red[0]) + zmax - zy;  // rows of a block in order, blocks in order below: the same sums every run
-      blk_hit += (yok && arg == (int)y) ? 1 : 0;
-    }
-    __syncthreads();
   }
   if (c == 0) {  // one partial per block (read by the last block: agent-scope, see common.h)
     publish(row_nll + blockIdx.x, blk_nll);
@@ -168,39 +179,50 @@ __global__ void __launch_bounds__(kHeadThreads * kHeadSlices) k_head_bwd_rows(co
                                                                 const float* __restrict__ w, const int64_t* __restrict__ label,
                                                                 int64_t label_stride, const double* __restrict__ gloss, int classes, int dim,
                                                                 int64_t n_rows, float* __restrict__ dl, float* __restrict__ dnode, int64_t ldd) {
-  __shared__ double red[kHeadThreads];
+  __shared__ float zhi[kHeadRows][64];
   __shared__ float dls[kHeadRows][kHeadThreads];
-  const int r0 = blockIdx.x * kHeadRows, tid = threadIdx.x, c = tid;  // the soft-max is the first 128 threads' work
-  const bool cls = tid < kHeadThreads;
+  const int r0 = blockIdx.x * kHeadRows, tid = threadIdx.x, c = tid;  // the soft-max is wave 0's work
   const int nr = min(kHeadRows, m - r0);
   const double g = *gloss / (double)m;
-  for (int i = 0; i < kHeadRows; ++i) {
-    float d = 0.f;
-    if (i < nr) {  // (uniform: every thread takes the barriers)
-      const double z = (cls && c < classes) ? (double)logits[(int64_t)(r0 + i) * classes + c] : -INFINITY;
-      if (cls) red[c] = z;
-      __syncthreads();
-      for (int s = kHeadThreads / 2; s > 0; s >>= 1) {
-        if (cls && c < s) red[c] = fmax(red[c], red[c + s]);
-        __syncthreads();
+  // the float64 soft-max of the forward, recomputed the same way (see k_head_fwd): classes 64 .. 127 reach wave 0 through LDS,
+  // the rest of the 128-wide max / sum trees are lane shuffles with the trees' pairing
+  float zl[kHeadRows];
+#pragma unroll
+  for (int i = 0; i < kHeadRows; ++i)
+    zl[i] = (tid < kHeadThreads && i < nr && c < classes) ? logits[(int64_t)(r0 + i) * classes + c] : -INFINITY;
+  if (tid >= 64 && tid < kHeadThreads) {
+#pragma unroll
+    for (int i = 0; i < kHeadRows; ++i) zhi[i][c - 64] = zl[i];
+  }
+  __syncthreads();
+  if (tid < 64) {
+#pragma unroll
+    for (int i = 0; i < kHeadRows; ++i) {
+      float dlo = 0.f, dup = 0.f;
+      if (i < nr) {  // (uniform)
+        const double zlo = (double)zl[i], zup = (double)zhi[i][c];
+        double zmax = fmax(zlo, zup);
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) zmax = fmax(zmax, __shfl_down(zmax, sh));
+        zmax = __shfl(zmax, 0);
+        const double elo = c < classes ? exp(zlo - zmax) : 0.0, eup = c + 64 < classes ? exp(zup - zmax) : 0.0;
+        double tot = elo + eup;
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) tot += __shfl_down(tot, sh);
+        tot = __shfl(tot, 0);
+        const int y = (int)label[(int64_t)(r0 + i) * label_stride];
+        if (c < classes) {
+          dlo = (float)((elo / tot - (c == y ? 1.0 : 0.0)) * g);
+          dl[(int64_t)(r0 + i) * classes + c] = dlo;
+        }
+        if (c + 64 < classes) {
+          dup = (float)((eup / tot - (c + 64 == y ? 1.0 : 0.0)) * g);
+          dl[(int64_t)(r0 + i) * classes + c + 64] = dup;
+        }
       }
-      const double zmax = red[0];
-      __syncthreads();
-      const double e = (cls && c < classes) ? exp(z - zmax) : 0.0;
-      if (cls) red[c] = e;
-      __syncthreads();
-      for (int s = kHeadThreads / 2; s > 0; s >>= 1) {
-        if (cls && c < s) red[c] += red[c + s];
-        __syncthreads();
-      }
-      if (cls && c < classes) {
-        const int64_t y = label[(int64_t)(r0 + i) * label_stride];
-        d = (float)((e / red[0] - (c == (int)y ? 1.0 : 0.0)) * g);
-        dl[(int64_t)(r0 + i) * classes + c] = d;
-      }
-      __syncthreads();
+      dls[i][c] = dlo;
+      dls[i][c + 64] = dup;
     }
-    if (cls) dls[i][c] = d;
   }
   __syncthreads();
   int64_t node[kHeadRows];

@@ -902,14 +902,17 @@ int pgnn_bio_gin_stack_bwd(const float* dy, int64_t lddy, const int32_t* out_ptr
     // `g` of layer l + 1's dW2) was last used by layer l + 1: wait for the side stream's layer l + 1 work
     if (sd && l + 1 <= num_layer - 1) PGNN_HIP(hipStreamWaitEvent(main, sd->lag[(l + 1) & 1], 0));
     float* dx = l == 0 ? dh0 : dxb[(l - 1) & 1];
+    // the ReLU between layer l-1 and l (y_{l-1} = relu(.) was written by the forward product's epilogue) masks dx: inside the
+    // tiled aggregation's store when that launch can, else as a pass of its own
+    const float* yprev = l > 0 ? acts + (size_t)(l - 1) * 7 * nd + 6 * nd : nullptr;
+    bool masked = false;
     if (tile_start && num_tiles)
-      rc = pgnn_neighbor_sum_tiled(dagg[b], 2 * dim, out_ptr, out_dst, nullptr, tile_start, num_tiles, dx, dim, n, dim, nullptr, 0,
-                                   nullptr, 0, nullptr, 0, main);
+      rc = neighbor_sum_tiled_masked(dagg[b], 2 * dim, out_ptr, out_dst, nullptr, tile_start, num_tiles, dx, dim, n, dim, nullptr, 0,
+                                     nullptr, 0, nullptr, 0, yprev, dim, &masked, main);
     else
       rc = pgnn_neighbor_sum(dagg[b], 2 * dim, out_ptr, out_dst, nullptr, dx, dim, n, dim, main);
     if (rc) return rc;
-    if (l > 0) {  // the ReLU between layer l-1 and l: y_{l-1} = relu(.) was written by the forward product's epilogue
-      const float* yprev = acts + (size_t)(l - 1) * 7 * nd + 6 * nd;
+    if (l > 0 && !masked) {
       hipLaunchKernelGGL(k_relu_mask, dim3((int)std::min<int64_t>(ceil_div(nd / 4, 256), 4096)), dim3(256), 0, main, dx, yprev,
                          (int64_t)(nd / 4));
     }

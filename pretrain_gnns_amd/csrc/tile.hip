@@ -76,7 +76,11 @@ __global__ void __launch_bounds__(1024) k_tile_compact(const uint8_t* __restrict
   if (t == 0) tile_start[0] = 0;
 }
 
-template <bool WEIGHT, int DBG = 0>  // DBG (PGNN_TILE_DEBUG, timing only): 1 = skip the gather loop, 2 = skip the row DMA
+// MASK: out[i, c] is zeroed where mask[i, c] <= 0 -- the ReLU between two layers in the backward (out = the gradient of the previous
+// layer's output, mask = that output): the chunk's mask rows are folded to one bit per value while the rows are staged (the words
+// take the LDS of the edge-feature sums, which a masked call does not have), and the store picks its four bits.  As a launch of its
+// own the mask was a read-modify-write pass over the gradient, 10-12 us per layer of a 256-ego-net batch.
+template <bool WEIGHT, int DBG = 0, bool MASK = false>  // DBG (PGNN_TILE_DEBUG, timing only): 1 = skip the gather loop, 2 = skip the row DMA
 __global__ void __launch_bounds__(kThreads) k_neighbor_sum_tile(const float* __restrict__ x, int64_t ldx,
                                                                 const int32_t* __restrict__ ptr, const int32_t* __restrict__ nbr,
                                                                 const float* __restrict__ dinv,
@@ -84,7 +88,8 @@ __global__ void __launch_bounds__(kThreads) k_neighbor_sum_tile(const float* __r
                                                                 const int32_t* __restrict__ num_tiles, float* __restrict__ out,
                                                                 int64_t ldo, int n, int dim, const float* __restrict__ cfeat,
                                                                 int kc, const float* __restrict__ table, int64_t ldt,
-                                                                float* __restrict__ fout, int64_t ldf) {
+                                                                float* __restrict__ fout, int64_t ldf,
+                                                                const float* __restrict__ mask = nullptr, int64_t ldm = 0) {
 #pragma clang fp contract(off)
   extern __shared__ __align__(16) float smem[];
   const int gs = dim >> 2;
@@ -126,6 +131,22 @@ __global__ void __launch_bounds__(kThreads) k_neighbor_sum_tile(const float* __r
       for (int q = t; q < ne; q += kThreads) idxL[q] = nbr[e0 + q];
       if (cfeat)  // contiguous: rows c0 .. c1 of cfeat [N, kc]
         for (int q = t; q < cnt * kc; q += kThreads) cfL[q] = cfeat[(int64_t)c0 * kc + q];
+      const int wpr = (gs + 7) >> 3;  // mask words per row: 8 float4 = 32 values per word
+      if (MASK) {
+        unsigned* mL = reinterpret_cast<unsigned*>(cfL);  // [kRows][wpr], wpr <= kMaxFeat
+        const float4* __restrict__ m4 = reinterpret_cast<const float4*>(mask);
+        for (int q = t; q < cnt * wpr; q += kThreads) {
+          const int r = q / wpr, wd = q - r * wpr;
+          float4 yv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) yv[u] = wd * 8 + u < gs ? m4[(int64_t)(c0 + r) * (ldm >> 2) + wd * 8 + u] : f4_zero();
+          unsigned bits = 0;
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            bits |= ((yv[u].x > 0.f ? 1u : 0u) | (yv[u].y > 0.f ? 2u : 0u) | (yv[u].z > 0.f ? 4u : 0u) | (yv[u].w > 0.f ? 8u : 0u)) << (4 * u);
+          mL[q] = bits;
+        }
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (g < groups) {
@@ -204,6 +225,13 @@ __global__ void __launch_bounds__(kThreads) k_neighbor_sum_tile(const float* __r
             }
             if (same) acc = f;
             else reinterpret_cast<float4*>(fout)[(int64_t)i * (ldf >> 2) + c4] = f;
+          }
+          if (MASK) {
+            const unsigned bits = reinterpret_cast<const unsigned*>(cfL)[li * wpr + (c4 >> 3)] >> ((c4 & 7) * 4);
+            if (!(bits & 1u)) acc.x = 0.f;
+            if (!(bits & 2u)) acc.y = 0.f;
+            if (!(bits & 4u)) acc.z = 0.f;
+            if (!(bits & 8u)) acc.w = 0.f;
           }
           reinterpret_cast<float4*>(out)[(int64_t)i * ldo4 + c4] = acc;
         }
@@ -517,6 +545,18 @@ int pgnn_neighbor_sum_tiled(const float* x, int64_t ldx, const int32_t* ptr, con
                             const int32_t* tile_start, const int32_t* num_tiles, float* out, int64_t ldo, int64_t num_nodes,
                             int64_t dim, const float* cfeat, int64_t kc, const float* table, int64_t ldt, float* feat_out,
                             int64_t ld_feat_out, pgnn_stream stream) {
+  return pgnn::neighbor_sum_tiled_masked(x, ldx, ptr, nbr, dinv, tile_start, num_tiles, out, ldo, num_nodes, dim, cfeat, kc, table, ldt,
+                                         feat_out, ld_feat_out, nullptr, 0, nullptr, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+int pgnn::neighbor_sum_tiled_masked(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* nbr, const float* dinv,
+                                    const int32_t* tile_start, const int32_t* num_tiles, float* out, int64_t ldo, int64_t num_nodes,
+                                    int64_t dim, const float* cfeat, int64_t kc, const float* table, int64_t ldt, float* feat_out,
+                                    int64_t ld_feat_out, const float* mask, int64_t ldm, bool* mask_applied, hipStream_t stream) {
+  if (mask_applied) *mask_applied = false;
+  PGNN_REQUIRE(!mask || (mask_applied && !cfeat && !dinv && ldm % 4 == 0), "neighbor_sum_tiled: a mask goes with the plain sum only");
   PGNN_REQUIRE(num_nodes > 0 && dim > 0 && dim % 4 == 0 && dim / 4 <= kThreads && ldx % 4 == 0 && ldo % 4 == 0,
                "neighbor_sum_tiled: bad shape");
   PGNN_REQUIRE(cfeat == nullptr || (kc > 0 && kc <= kMaxFeat && table && feat_out && ldt % 4 == 0 && ld_feat_out % 4 == 0),
@@ -569,6 +609,10 @@ int pgnn_neighbor_sum_tiled(const float* x, int64_t ldx, const int32_t* ptr, con
   } else if (dinv) {
     allow_big_lds((const void*)k_neighbor_sum_tile<true>, lds);
     hipLaunchKernelGGL(k_neighbor_sum_tile<true>, dim3(blocks), dim3(kThreads), lds, st, PGNN_TILE_ARGS);
+  } else if (mask && (dim / 4 + 7) / 8 <= kMaxFeat && env_knob("PGNN_TILE_MASK", 1) != 0) {
+    allow_big_lds((const void*)k_neighbor_sum_tile<false, 0, true>, lds);
+    hipLaunchKernelGGL((k_neighbor_sum_tile<false, 0, true>), dim3(blocks), dim3(kThreads), lds, st, PGNN_TILE_ARGS, mask, ldm);
+    *mask_applied = true;
   } else {
     allow_big_lds((const void*)k_neighbor_sum_tile<false>, lds);
     hipLaunchKernelGGL(k_neighbor_sum_tile<false>, dim3(blocks), dim3(kThreads), lds, st, PGNN_TILE_ARGS);
@@ -576,5 +620,3 @@ int pgnn_neighbor_sum_tiled(const float* x, int64_t ldx, const int32_t* ptr, con
 #undef PGNN_TILE_ARGS
   return check_launch("neighbor_sum_tiled");
 }
-
-}  // extern "C"
