@@ -505,6 +505,8 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
       if ((rc = pgnn_linear_bwd_data(dz[b], dim, p.w2, hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main))) return rc;
       if ((rc = pgnn_linear_bwd_data(dhid[b], 2 * dim, p.w1, nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main))) return rc;
     }
+    // (recording fork[1] behind the transposed aggregation instead -- one idle gap less on this stream per layer -- starts the side
+    // stream ~11 us later and loses: 1.107-1.111 against 1.072-1.078 ms per step, profiles/r03/fork_placement_ab.txt)
     if (sd) PGNN_HIP(hipEventRecord(sd->fork[1], main));
     // the bottom layer's edge-table gradient stays on the caller's stream: the side stream is the longer of the two there
     // (two weight-gradient products behind the data products), and the caller's stream only has the embedding gradients left
