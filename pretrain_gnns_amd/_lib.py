@@ -199,7 +199,7 @@ def status_word(dev):
     batch's ``GraphStruct.check()`` still reports that batch's own count."""
     if torch.cuda.is_current_stream_capturing():  # a captured launch keeps its word for every replay: give it its own
         return torch.zeros(1, dtype=torch.int32, device=dev)
-    key = (dev.type, dev.index)
+    key = (dev.type, dev.index, stream_ptr(dev.index))  # per stream: a pool is zero-filled on the stream that is current when it is made
     pool = _status_pools.get(key)
     if pool is None or pool[1] >= _STATUS_POOL_WORDS:  # (views keep an exhausted pool alive for as long as they are held)
         pool = _status_pools[key] = [torch.zeros(_STATUS_POOL_WORDS, dtype=torch.int32, device=dev), 0]
