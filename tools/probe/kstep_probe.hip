@@ -30,7 +30,8 @@ __device__ __forceinline__ uint64_t clk() {
 }
 
 // bits of MODE: 1 = ds reads, 2 = split VALU, 4 = DMA, 8 = barrier, 16 = block-major MFMA order (6 terms of an accumulator
-// back to back), 32 = no MFMAs at all
+// back to back), 32 = no MFMAs at all, 64 = the TWO-plane form (two fp16 planes per operand under a scale): three products per
+// accumulator instead of six (same MFMA rate as bf16), two B planes read from LDS instead of three, four DMA pieces instead of five
 template <int MODE>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k(const unsigned char* src, float* out, uint64_t* cyc, int iters) {
   extern __shared__ __align__(16) unsigned char lds[];
@@ -50,14 +51,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   for (int it = 0; it < iters; ++it) {
     const unsigned char* st = lds + (it & 3) * STAGE;
     if (MODE & 8) {
-      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      if (MODE & 64) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
     if (MODE & 4) {
       unsigned char* dst = lds + ((it + 3) & 3) * STAGE + wave * 5 * 1024;
 #pragma unroll
-      for (int j = 0; j < 5; ++j) __builtin_amdgcn_global_load_lds(GPTR(g + j * 1024 + (it & 7) * 8192), LPTR(dst + j * 1024), 16, 0, 0);
+      for (int j = 0; j < ((MODE & 64) ? 4 : 5); ++j) __builtin_amdgcn_global_load_lds(GPTR(g + j * 1024 + (it & 7) * 8192), LPTR(dst + j * 1024), 16, 0, 0);
     }
     f32x4 lo = f32x4{1.f, 2.f, 3.f, 4.f}, hi = f32x4{5.f, 6.f, 7.f, 8.f};
     if (MODE & 1) {
@@ -66,17 +68,18 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
       for (int j = 0; j < 5; ++j)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(st + 8192 + q * 10240 + ((wave & 1) * 80 + j * 16 + (lane & 15)) * 64 + (((lane >> 4) ^ ((-((lane & 15) >> 2)) & 3)) * 16));
+        for (int q = 0; q < ((MODE & 64) ? 2 : 3); ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(st + 8192 + q * 10240 + ((wave & 1) * 80 + j * 16 + (lane & 15)) * 64 + (((lane >> 4) ^ ((-((lane & 15) >> 2)) & 3)) * 16));
     }
     uint32_t pl[3][4] = {};
     __builtin_amdgcn_sched_barrier(0);
-    constexpr int TB[6] = {0, 1, 2, 0, 1, 0}, TA[6] = {2, 1, 0, 1, 0, 0};
+    constexpr int NT = (MODE & 64) ? 3 : 6;
+    constexpr int TB[6] = {0, 1, 0, 0, 1, 2}, TA[6] = {1, 0, 0, 2, 1, 0};  // (the first three: the terms of the two-plane form)
     if (MODE & 16) {
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
         if (!(MODE & 32)) {
 #pragma unroll
-          for (int t = 0; t < 6; ++t) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][TB[t]], a[TA[t]], acc[j], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][TB[t]], a[TA[t]], acc[j], 0, 0, 0);
         }
         if ((MODE & 2) && j < 4) {
           const f32x4 v = j < 2 ? lo : hi;
@@ -87,8 +90,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       }
     } else {
 #pragma unroll
-      for (int t = 0; t < 6; ++t) {
-        if (!(MODE & 32)) {
+      for (int t = 0; t < (NT == 3 ? 4 : 6); ++t) {  // (four rounds either way: the split of the next A fragment rides on them)
+        if (!(MODE & 32) && t < NT) {
 #pragma unroll
           for (int j = 0; j < 5; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][TB[t]], a[TA[t]], acc[j], 0, 0, 0);
         }
@@ -158,6 +161,9 @@ int main() {
     run<32 + 1>("17 ds_read only", src, out, cyc, threads);
     run<32 + 2>("split VALU only", src, out, cyc, threads);
     run<32 + 15>("everything but the MFMAs", src, out, cyc, threads);
+    run<64>("two planes: 15 MFMA", src, out, cyc, threads);
+    run<64 + 15>("two planes: 15 MFMA + 12 ds_read + split + 4 DMA + barrier", src, out, cyc, threads);
+    run<64 + 32 + 15>("two planes: everything but the MFMAs", src, out, cyc, threads);
   }
   return 0;
 }
