@@ -246,6 +246,172 @@ void launch_gemm2p(const Gemm2pArgs& p, hipStream_t st) {
   hipLaunchKernelGGL((k_gemm2p<BM, BN, WAVES_M, WAVES_N, STAGES>), dim3(tiles), dim3(64 * WAVES_M * WAVES_N), lds, st, p);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The weight-gradient product dW [n, k] = dy^T x (+ db as the ones column) the same way: k_gemm3's row-contiguous / row-contiguous
+// instantiation (operands staged through registers, transpose-read fragments, split over the contracted rows) with two fp16 planes.
+// The contraction runs over the ROWS of dy and x, so the scales belong to their COLUMNS: sa[nout] for dy[:, nout], sb[kcol] for x[:, kcol].
+struct Wgrad2pArgs {
+  const float* A;  // dy [rows, lda]
+  int64_t lda;
+  const float* B;  // x [rows, ldb]
+  int64_t ldb;
+  float* C;        // dW [M = n_out, ldc] (or the split partials)
+  int64_t ldc;
+  int M, N, K;     // M = out features, N = in features, K = contracted rows
+  int kchunk;
+  int64_t split_stride;
+  float* colsum;   // db [M] (or its partials)
+  const float *a_scale, *a_inv;  // [M]
+  const float *b_scale, *b_inv;  // [N + 4]: the ones column's entries are 1
+  int nxcd;
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad2p(Wgrad2pArgs p) {
+  constexpr int BK = 32;
+  constexpr int NW = WAVES_M * WAVES_N, T = 64 * NW;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int MI = WM / 16, NI = WN / 16;
+  using TA = RowMajorTile<BM>;
+  using TB = RowMajorTile<BN>;
+  constexpr int PA = TA::PLANE, PB = TB::PLANE;
+  constexpr int UA = BM * 8, UB = BN * 8;
+  constexpr int NA = (UA + T - 1) / T, NB = (UB + T - 1) / T;
+  extern __shared__ __align__(16) unsigned char smemw[];
+  unsigned char* const ldsA = smemw;
+  unsigned char* const ldsB = smemw + 2 * PA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_n = (p.N + 4 + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x, p.nxcd);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int kbeg = blockIdx.y * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  const float* srcA[NA];
+  const float* srcB[NB];
+  int offA[NA], offB[NB], kofA[NA], kofB[NB];
+  bool okA[NA], okB[NB], oneB[NB];
+  float4 scA[NA], scB[NB];  // the column scales of this thread's staging units (the same columns in every k-step)
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int u = min(tid + j * T, UA - 1);
+    const int kr = u / (BM / 4), cq = u - kr * (BM / 4);
+    okA[j] = m0 + 4 * cq < p.M;
+    kofA[j] = kr;
+    srcA[j] = p.A + (int64_t)(kbeg + kr) * p.lda + m0 + 4 * cq;
+    offA[j] = TA::offset(kr, 4 * cq);
+    scA[j] = okA[j] ? *reinterpret_cast<const float4*>(p.a_scale + m0 + 4 * cq) : make_float4(1.f, 1.f, 1.f, 1.f);
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int u = min(tid + j * T, UB - 1);
+    const int kr = u / (BN / 4), cq = u - kr * (BN / 4);
+    okB[j] = n0 + 4 * cq < p.N;
+    oneB[j] = n0 + 4 * cq == p.N;
+    kofB[j] = kr;
+    srcB[j] = p.B + (int64_t)(kbeg + kr) * p.ldb + n0 + 4 * cq;
+    offB[j] = TB::offset(kr, 4 * cq);
+    scB[j] = (okB[j] || oneB[j]) ? *reinterpret_cast<const float4*>(p.b_scale + n0 + 4 * cq) : make_float4(1.f, 1.f, 1.f, 1.f);
+  }
+  float4 ra[NA], rb[NB];
+  auto load_tile = [&](int it) {
+    const int k0 = kbeg + it * BK;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const bool ok = okA[j] && k0 + kofA[j] < kend;
+      const float* g = ok ? srcA[j] + (int64_t)it * BK * p.lda : reinterpret_cast<const float*>(g_zero_page);
+      ra[j] = *reinterpret_cast<const float4*>(g);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const bool kok = k0 + kofB[j] < kend;
+      const float* g = (okB[j] && kok) ? srcB[j] + (int64_t)it * BK * p.ldb
+                                       : reinterpret_cast<const float*>((oneB[j] && kok) ? g_ones_page : g_zero_page);
+      rb[j] = *reinterpret_cast<const float4*>(g);
+    }
+  };
+  auto store_unit = [&](const float4& v, const float4& sc, unsigned char* base, int plane, int off) {
+    uint32_t h0, l0, h1, l1;
+    split2(v.x * sc.x, v.y * sc.y, h0, l0);
+    split2(v.z * sc.z, v.w * sc.w, h1, l1);
+    *reinterpret_cast<uint2*>(base + off) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(base + plane + off) = make_uint2(l0, l1);
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) store_unit(ra[j], scA[j], ldsA, PA, offA[j]);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) store_unit(rb[j], scB[j], ldsB, PB, offB[j]);
+  };
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+  const int fr = lane & 15, fk = lane >> 4;
+  auto frag = [&](auto cols_tag, const unsigned char* base, int plane, int c0, int q) -> f16x8 {
+    using L = RowMajorTile<decltype(cols_tag)::value>;
+    const int col = (c0 + 4 * (fr & 3) + 16 * (fk & 1)) % L::S;
+    const unsigned char* a0 = base + q * plane + ((8 * fk + (fr >> 2)) * L::S + col) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * L::S * 2));
+    return __builtin_bit_cast(f16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+  using CA = std::integral_constant<int, BM>;
+  using CB = std::integral_constant<int, BN>;
+  auto compute = [&]() {
+    f16x8 a[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) a[i][q] = frag(CA{}, ldsA, PA, wm0 + i * 16, q);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      f16x8 b[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) b[q] = frag(CB{}, ldsB, PB, wn0 + j * 16, q);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[0], a[i][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[1], a[i][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[0], a[i][0], acc[i][j], 0, 0, 0);
+    }
+  };
+  if (nk > 0) {
+    load_tile(0);
+    store_tile();
+    if (1 < nk) load_tile(1);
+  }
+  __syncthreads();
+  for (int t = 0; t < nk; ++t) {
+    compute();
+    __syncthreads();
+    if (t + 1 < nk) store_tile();
+    __syncthreads();
+    if (t + 2 < nk) load_tile(t + 2);
+  }
+  float* C = p.C + (int64_t)blockIdx.y * p.split_stride;
+  float* cs = p.colsum + (int64_t)blockIdx.y * p.split_stride;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = n0 + wn0 + j * 16 + fk * 4;
+    if (n > p.N) continue;
+    const float4 bi = *reinterpret_cast<const float4*>(p.b_inv + n);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wm0 + i * 16 + fr;
+      if (m >= p.M) continue;
+      const float ai = p.a_inv[m];
+      if (n == p.N) cs[m] = acc[i][j][0] * ai;  // the ones column (scale 1): the bias gradient
+      else *reinterpret_cast<float4*>(C + (int64_t)m * p.ldc + n) =
+          make_float4(acc[i][j][0] * (ai * bi.x), acc[i][j][1] * (ai * bi.y), acc[i][j][2] * (ai * bi.z), acc[i][j][3] * (ai * bi.w));
+    }
+  }
+}
 }  // namespace
 }  // namespace pgnn
 
@@ -373,6 +539,90 @@ static void run_case(int M, int K, int N, float row_spread, float amp, hipStream
   hipFree(dA); hipFree(dW); hipFree(dC2); hipFree(dC3); hipFree(dsa); hipFree(dsai); hipFree(dsbi); hipFree(dP2); hipFree(dP3);
 }
 
+// dW [n_out, k_in] = dy^T x over `rows` rows, db = column sums of dy: the two-plane prototype (split over the rows as weight_product
+// splits, folded by the library's k_splitk_reduce) against pgnn_linear_bwd_weight
+static void run_wgrad(int rows, int n_out, int k_in, float col_spread, float amp, hipStream_t st) {
+  using namespace pgnn;
+  std::vector<float> DY((size_t)rows * n_out), X((size_t)rows * k_in);
+  unsigned s = 777u + rows + n_out;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)(s >> 8) / 8388608.0f - 1.0f; };
+  std::vector<float> cmag(n_out);
+  for (auto& c : cmag) c = amp * expf(col_spread * rnd());
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < n_out; ++c) DY[(size_t)r * n_out + c] = cmag[c] * rnd();
+  for (auto& x : X) x = 2.f * rnd();
+  std::vector<float> sa(n_out), sai(n_out), sb(k_in + 4, 1.f), sbi(k_in + 4, 1.f);
+  for (int c = 0; c < n_out; ++c) {
+    float amax = 0.f;
+    for (int r = 0; r < rows; ++r) amax = fmaxf(amax, fabsf(DY[(size_t)r * n_out + c]));
+    sa[c] = pow2_scale(amax);
+    sai[c] = 1.f / sa[c];
+  }
+  for (int c = 0; c < k_in; ++c) {
+    float amax = 0.f;
+    for (int r = 0; r < rows; ++r) amax = fmaxf(amax, fabsf(X[(size_t)r * k_in + c]));
+    sb[c] = pow2_scale(amax);
+    sbi[c] = 1.f / sb[c];
+  }
+  const int nsplit = weight_splits(rows, k_in, n_out, 64, 160);
+  int64_t chunk = ceil_div(ceil_div(rows, nsplit), 32) * 32;
+  const int used = (int)ceil_div(rows, chunk);
+  const int64_t stride = (int64_t)n_out * k_in + n_out;
+  const size_t wsb = pgnn_linear_bwd_weight_workspace_bytes(rows, k_in, n_out);
+  float *dDY, *dX, *dW2, *dB2, *dW3, *dB3, *dpart, *dsa, *dsai, *dsb, *dsbi;
+  void* ws;
+  HIP_OK(hipMalloc(&dDY, DY.size() * 4 + 256)); HIP_OK(hipMalloc(&dX, X.size() * 4 + 256));
+  HIP_OK(hipMalloc(&dW2, (size_t)n_out * k_in * 4)); HIP_OK(hipMalloc(&dB2, n_out * 4)); HIP_OK(hipMalloc(&dW3, (size_t)n_out * k_in * 4)); HIP_OK(hipMalloc(&dB3, n_out * 4));
+  HIP_OK(hipMalloc(&dpart, (size_t)used * stride * 4 + 256)); HIP_OK(hipMalloc(&ws, wsb + 256));
+  HIP_OK(hipMalloc(&dsa, n_out * 4)); HIP_OK(hipMalloc(&dsai, n_out * 4)); HIP_OK(hipMalloc(&dsb, (k_in + 4) * 4)); HIP_OK(hipMalloc(&dsbi, (k_in + 4) * 4));
+  HIP_OK(hipMemcpy(dDY, DY.data(), DY.size() * 4, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dsa, sa.data(), n_out * 4, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(dsai, sai.data(), n_out * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dsb, sb.data(), (k_in + 4) * 4, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(dsbi, sbi.data(), (k_in + 4) * 4, hipMemcpyHostToDevice));
+  Wgrad2pArgs p{};
+  p.A = dDY; p.lda = n_out; p.B = dX; p.ldb = k_in; p.M = n_out; p.N = k_in; p.K = rows; p.kchunk = (int)chunk;
+  p.C = used == 1 ? dW2 : dpart; p.ldc = k_in; p.split_stride = used == 1 ? 0 : stride; p.colsum = used == 1 ? dB2 : dpart + (size_t)n_out * k_in;
+  p.a_scale = dsa; p.a_inv = dsai; p.b_scale = dsb; p.b_inv = dsbi; p.nxcd = num_xcd();
+  constexpr size_t lds = (size_t)2 * (RowMajorTile<64>::PLANE + RowMajorTile<160>::PLANE);
+  const int tiles = (int)(ceil_div(n_out, 64) * ceil_div(k_in + 4, 160));
+  auto l2 = [&]() {
+    hipLaunchKernelGGL((k_wgrad2p<64, 160, 4, 2>), dim3(tiles, used), dim3(512), lds, st, p);
+    if (used > 1)
+      hipLaunchKernelGGL(k_splitk_reduce, dim3((int)std::min<int64_t>(ceil_div((int64_t)n_out * k_in / 4 + n_out / 4, 256), 1024)), dim3(256), 0, st, dpart,
+                         used, stride, dW2, (int64_t)n_out * k_in / 4, dB2, (int64_t)n_out / 4);
+  };
+  auto l3 = [&]() { if (pgnn_linear_bwd_weight(dDY, n_out, dX, k_in, dW3, dB3, rows, k_in, n_out, ws, wsb + 256, st)) { printf("bwd_weight failed: %s\n", pgnn_last_error()); exit(3); } };
+  l2();
+  l3();
+  HIP_OK(hipStreamSynchronize(st));
+  std::vector<float> W2((size_t)n_out * k_in), W3((size_t)n_out * k_in), B2(n_out), B3(n_out);
+  HIP_OK(hipMemcpy(W2.data(), dW2, W2.size() * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(W3.data(), dW3, W3.size() * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(B2.data(), dB2, n_out * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(B3.data(), dB3, n_out * 4, hipMemcpyDeviceToHost));
+  double e2 = 0, e3 = 0, m2 = 0, m3 = 0, eb2 = 0, eb3 = 0;
+  size_t cnt = 0;
+  for (int c = 0; c < n_out; c += std::max(1, n_out / 48)) {
+    double tb = 0, db_ = 0;
+    for (int r = 0; r < rows; ++r) { tb += DY[(size_t)r * n_out + c]; db_ += fabs(DY[(size_t)r * n_out + c]); }
+    eb2 = std::max(eb2, fabs(B2[c] - tb) / db_);
+    eb3 = std::max(eb3, fabs(B3[c] - tb) / db_);
+    for (int k = 0; k < k_in; ++k) {
+      double t = 0, d = 0;
+      for (int r = 0; r < rows; ++r) {
+        const double a = DY[(size_t)r * n_out + c], b = X[(size_t)r * k_in + k];
+        t += a * b;
+        d += fabs(a * b);
+      }
+      const double x2 = fabs(W2[(size_t)c * k_in + k] - t) / d, x3 = fabs(W3[(size_t)c * k_in + k] - t) / d;
+      e2 = std::max(e2, x2); e3 = std::max(e3, x3); m2 += x2; m3 += x3;
+      ++cnt;
+    }
+  }
+  const float t2 = time_us(l2, st, 100), t3 = time_us(l3, st, 100);
+  printf("weight gradient rows %6d dW [%3d, %3d] (%d splits) columns x e^+-%.0f amp %.0e | two fp16 planes %6.1f us  max err %.2e (db %.2e) mean %.2e | "
+         "three bf16 planes %6.1f us  max err %.2e (db %.2e) mean %.2e\n",
+         rows, n_out, k_in, used, col_spread, amp, t2, e2, eb2, m2 / cnt, t3, e3, eb3, m3 / cnt);
+  hipFree(dDY); hipFree(dX); hipFree(dW2); hipFree(dB2); hipFree(dW3); hipFree(dB3); hipFree(dpart); hipFree(ws); hipFree(dsa); hipFree(dsai); hipFree(dsb); hipFree(dsbi);
+}
+
 int main(int argc, char** argv) {
   hipStream_t st;
   HIP_OK(hipStreamCreate(&st));
@@ -384,5 +634,11 @@ int main(int argc, char** argv) {
     run_case(M, 600, 300, 0.f, 3.f, st);    // forward 600 -> 300
     run_case(M, 600, 300, 2.f, 1e-6f, st);  // backward-data shape, gradients ~1e-6
   }
+  for (int M : rows) {
+    if (M > 20000) continue;
+    run_wgrad(M, 600, 300, 2.f, 1e-6f, st);  // dW1 of a chem layer: dhid^T agg
+    run_wgrad(M, 300, 600, 2.f, 1e-6f, st);  // dW2: dz^T hid
+  }
+  run_wgrad(10249, 600, 600, 2.f, 1e-6f, st);  // bio dW1
   return 0;
 }
