@@ -46,7 +46,10 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& h, uint32_t& 
   l = pack_f16(a - (float)hh[0], b - (float)hh[1]);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+// SELF: the row scales of A are not given: the workgroup takes the maxima of its BM rows itself, in a pass over them in front of
+// the k-loop (the rows come out of L2 a second time in the k-loop; every workgroup of a row panel repeats the pass) -- no producer
+// has to supply anything.  What that pass costs is what this variant measures.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool SELF = false>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_waves_per_eu(2, 2))) k_gemm2p(Gemm2pArgs p) {
   constexpr int BK = 32, NPL = 2;
   constexpr int NW = WAVES_M * WAVES_N;
@@ -105,8 +108,28 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
   const int a_off = (wm0 + fr) * 128, a_lo = (((2 * fk) ^ ((fr & 6) | (fr >> 3))) * 16), a_hi = (((2 * fk + 1) ^ ((fr & 6) | (fr >> 3))) * 16);
   const int b_off = (wn0 + fr) * 64 + ((fk ^ ((-(fr >> 2)) & 3)) * 16);
   float sa[MI];  // the scale of this lane's A rows (the fragment's row is fr)
+  __shared__ float rowmax[BM];
+  constexpr int TPR = (64 * NW) / BM;  // threads per row of the pass (8 at 64 x 160 / 512 threads, 4 at 128 x 160)
+  float mx = 0.f;
+  if constexpr (SELF) {
+    // thread t: row t / TPR, float4 columns t % TPR, + TPR, ...: eight loads in flight per round, all older than the first DMA
+    const int r = min(m0 + tid / TPR, p.M - 1), k4 = p.K / 4;
+    const float4* row = reinterpret_cast<const float4*>(p.A + (int64_t)r * p.lda);
+    for (int c = tid % TPR; c < k4; c += 8 * TPR) {
+      float4 pre[8];
 #pragma unroll
-  for (int i = 0; i < MI; ++i) sa[i] = p.a_scale[min(m0 + wm0 + i * 16 + fr, p.M - 1)];
+      for (int u = 0; u < 8; ++u) pre[u] = row[min(c + u * TPR, k4 - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(pre[u].x), fabsf(pre[u].y)), fmaxf(fabsf(pre[u].z), fabsf(pre[u].w))));
+    }
+#pragma unroll
+    for (int off = 1; off < TPR; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (tid % TPR == 0) rowmax[tid / TPR] = mx;
+  } else {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) sa[i] = p.a_scale[min(m0 + wm0 + i * 16 + fr, p.M - 1)];
+  }
 
   auto aload = [&](int stage, f32x4 (&lo)[MI], f32x4 (&hi)[MI]) {
     const unsigned char* s = smem2p + stage * STAGE;
@@ -182,7 +205,20 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
     __builtin_amdgcn_s_barrier();
   };
   f16x8 a0[MI][NPL], a1[MI][NPL];
+  float ainv[MI];
+  if constexpr (SELF) {
+    (void)mx;  // (the pass ran in front of the prologue's DMAs; rowmax is in LDS, the barrier of sync(0) publishes it)
+  }
   sync(0);
+  if constexpr (SELF) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      // 2^(13 - floor(log2(max))) from the exponent field (max = 0 or subnormal: scale 1)
+      const unsigned e = (__float_as_uint(rowmax[wm0 + i * 16 + fr]) >> 23) & 0xffu;
+      sa[i] = e > 13u ? __uint_as_float((267u - e) << 23) : 1.f;   // 127 + 13 - (e - 127)   (tiny or zero rows: scale 1)
+      ainv[i] = e > 13u ? __uint_as_float((e - 13u) << 23) : 1.f;  // 127 - 13 + (e - 127)
+    }
+  }
   {
     f32x4 lo[MI], hi[MI];
     aload(0, lo, hi);
@@ -231,19 +267,19 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = m0 + wm0 + i * 16 + fr;
-      const float ai = p.a_inv[min(m, p.M - 1)];
+      const float ai = SELF ? ainv[i] : p.a_inv[min(m, p.M - 1)];
       const float4 v = make_float4(acc[i][j][0] * (ai * bi.x), acc[i][j][1] * (ai * bi.y), acc[i][j][2] * (ai * bi.z), acc[i][j][3] * (ai * bi.w));
       if (m < p.M && n < p.N) *reinterpret_cast<float4*>(p.C + (int64_t)m * p.ldc + n) = v;
     }
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool SELF = false>
 void launch_gemm2p(const Gemm2pArgs& p, hipStream_t st) {
   constexpr size_t lds = (size_t)STAGES * (BM * 128 + 2 * BN * 64);
   const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N, BN));
-  (void)hipFuncSetAttribute((const void*)k_gemm2p<BM, BN, WAVES_M, WAVES_N, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((k_gemm2p<BM, BN, WAVES_M, WAVES_N, STAGES>), dim3(tiles), dim3(64 * WAVES_M * WAVES_N), lds, st, p);
+  (void)hipFuncSetAttribute((const void*)k_gemm2p<BM, BN, WAVES_M, WAVES_N, STAGES, SELF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k_gemm2p<BM, BN, WAVES_M, WAVES_N, STAGES, SELF>), dim3(tiles), dim3(64 * WAVES_M * WAVES_N), lds, st, p);
 }
 
 
@@ -496,6 +532,8 @@ static void run_case(int M, int K, int N, float row_spread, float amp, hipStream
   p.a_scale = dsa; p.a_inv = dsai; p.b_inv = dsbi; p.nxcd = num_xcd();
   auto l2_64 = [&]() { launch_gemm2p<64, 160, 4, 2, 4>(p, st); };
   auto l2_128 = [&]() { launch_gemm2p<128, 160, 8, 1, 3>(p, st); };
+  auto s2_64 = [&]() { launch_gemm2p<64, 160, 4, 2, 4, true>(p, st); };
+  auto s2_128 = [&]() { launch_gemm2p<128, 160, 8, 1, 3, true>(p, st); };
   auto l3 = [&]() { if (pgnn_linear_fwd_wp(dA, K, dP3, nullptr, dC3, N, M, K, N, 0, nullptr, st)) { printf("fwd_wp failed: %s\n", pgnn_last_error()); exit(3); } };
   // float64 truth and the componentwise error scale on a sample of rows
   std::vector<float> C2((size_t)M * N), C3((size_t)M * N);
@@ -532,6 +570,21 @@ static void run_case(int M, int K, int N, float row_spread, float amp, hipStream
   HIP_OK(hipStreamSynchronize(st));
   HIP_OK(hipMemcpy(C3.data(), dC3, C3.size() * 4, hipMemcpyDeviceToHost));
   err_of(C3, e3max, e3mean);
+  double esmax = 0, esmean = 0, esbmax = 0, esbmean = 0;
+  {
+    HIP_OK(hipMemsetAsync(dC2, 0xff, (size_t)M * N * 4, st));
+    s2_64();
+    HIP_OK(hipStreamSynchronize(st));
+    HIP_OK(hipMemcpy(C2.data(), dC2, C2.size() * 4, hipMemcpyDeviceToHost));
+    err_of(C2, esmax, esmean);
+    HIP_OK(hipMemsetAsync(dC2, 0xff, (size_t)M * N * 4, st));
+    s2_128();
+    HIP_OK(hipStreamSynchronize(st));
+    HIP_OK(hipMemcpy(C2.data(), dC2, C2.size() * 4, hipMemcpyDeviceToHost));
+    err_of(C2, esbmax, esbmean);
+    printf("   scales taken by the workgroup itself (a pass over its rows): 64x160 %6.1f us  128x160 %6.1f us   max err %.2e / %.2e\n",
+           time_us(s2_64, st, 200), time_us(s2_128, st, 200), esmax, esbmax);
+  }
   const float t2a = time_us(l2_64, st, 200), t2b = time_us(l2_128, st, 200), t3 = time_us(l3, st, 200);
   printf("M %6d K %3d N %3d rows x e^+-%.0f amp %.0e | two fp16 planes: 64x160 %6.1f us  128x160 %6.1f us   max err %.2e / %.2e mean %.2e | "
          "three bf16 planes (library's choice of tile): %6.1f us   max err %.2e mean %.2e\n",
