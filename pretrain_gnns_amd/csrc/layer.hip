@@ -60,6 +60,19 @@ inline bool mlp_wp(int64_t n, int64_t d_in, int64_t d_hid, int64_t d_out, int nu
   return num_layer <= kMaxPlaneLayers && pgnn_linear_wp_preferred(n, d_in, d_hid) && pgnn_linear_wp_preferred(n, d_hid, d_out) &&
          pgnn_linear_wp_preferred(n, d_out, d_hid) && pgnn_linear_wp_preferred(n, d_hid, d_in);
 }
+// PGNN_GEMM_2P=1: the stacks' products on planes run on TWO fp16 planes + a power-of-two scale per row (csrc/linear.hip, the block at
+// its end) instead of three bf16 planes: the split, the forward products and the backward-data products switch together
+inline bool two_planes() { return env_knob("PGNN_GEMM_2P", 0) != 0; }
+inline int stack_fwd_wp(const float* x, int64_t ldx, const void* wplanes, const float* bias, float* y, int64_t ldy, int64_t m, int64_t k,
+                        int64_t n, int relu, float* colstat, pgnn_stream stream) {
+  return two_planes() ? linear_fwd_wp_2p(x, ldx, wplanes, bias, y, ldy, m, k, n, relu, colstat, (hipStream_t)stream)
+                      : pgnn_linear_fwd_wp(x, ldx, wplanes, bias, y, ldy, m, k, n, relu, colstat, stream);
+}
+inline int stack_bwd_data_wp(const float* dy, int64_t lddy, const void* wtplanes, const float* relu_out, int64_t ldr, float* dx,
+                             int64_t lddx, int64_t m, int64_t k, int64_t n, pgnn_stream stream) {
+  return two_planes() ? linear_bwd_data_wp_2p(dy, lddy, wtplanes, relu_out, ldr, dx, lddx, m, k, n, (hipStream_t)stream)
+                      : pgnn_linear_bwd_data_wp(dy, lddy, wtplanes, relu_out, ldr, dx, lddx, m, k, n, stream);
+}
 // planes of W1 / W2 (transpose = 0) or W1^T / W2^T (1) of every layer: p1[l], p2[l] carved from `base`
 // (bump: also increment the layers' num_batches_tracked -- a training-mode forward -- in the same launch)
 inline int split_mlp_weights(const pgnn_gin_layer* layers, int num_layer, int64_t d_in, int64_t d_hid, int64_t d_out, int transpose,
@@ -81,7 +94,8 @@ inline int split_mlp_weights(const pgnn_gin_layer* layers, int num_layer, int64_
   if (bump)
     for (int l = 0; l < num_layer; ++l)
       if (layers[l].num_batches_tracked) counters[nb++] = layers[l].num_batches_tracked;
-  return split_weights_bump(src, dst, rows, cols, tr, 2 * num_layer, counters, nb, st, tabs);
+  return two_planes() ? split_weights_2p(src, dst, rows, cols, tr, 2 * num_layer, counters, nb, st, tabs)
+                      : split_weights_bump(src, dst, rows, cols, tr, 2 * num_layer, counters, nb, st, tabs);
 }
 // the same increment as a launch of its own, for the calls that split nothing (small batches on the fp32-MFMA products)
 __global__ void k_bump_counters(long long* c0, long long* c1, long long* c2, long long* c3, long long* c4, long long* c5, long long* c6,
@@ -337,13 +351,13 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
       rc = pgnn_chem_aggregate_fwd(yprev, dim, in_ptr, in_src, in_code, p.emb1, p.emb2, nullptr, agg, dim, n, dim, stream);
     }
     if (rc) return rc;
-    if (wp) rc = pgnn_linear_fwd_wp(agg, dim, wp1[l], p.b1, hd, 2 * dim, n, dim, 2 * dim, 1, nullptr, stream);
+    if (wp) rc = stack_fwd_wp(agg, dim, wp1[l], p.b1, hd, 2 * dim, n, dim, 2 * dim, 1, nullptr, stream);
     else rc = pgnn_linear_fwd(agg, dim, p.w1, p.b1, hd, 2 * dim, n, dim, 2 * dim, 1, stream);
     if (rc) return rc;
     if (stats_in_gemm) {
       // the BatchNorm statistics of z fall out of the second product's epilogue: no pass over z for them, one launch less
       float* blocks = static_cast<float*>(ws);  // ceil(n/16) x 2 x dim floats <= the statistics partials of op_ws_bytes
-      if (wp) rc = pgnn_linear_fwd_wp(hd, 2 * dim, wp2[l], p.b2, z, dim, n, 2 * dim, dim, 0, blocks, stream);
+      if (wp) rc = stack_fwd_wp(hd, 2 * dim, wp2[l], p.b2, z, dim, n, 2 * dim, dim, 0, blocks, stream);
       else rc = pgnn_linear_fwd_colstats(hd, 2 * dim, p.w2, p.b2, z, dim, n, 2 * dim, dim, 0, blocks, stream);
       if (rc) return rc;
       if ((rc = pgnn_bn_stats_fwd_blocks(blocks, p.gamma, p.beta, p.running_mean, p.running_var, p.momentum, p.eps, st, st + dim,
@@ -354,7 +368,7 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
       if (rc) return rc;
       continue;
     }
-    if (wp) rc = pgnn_linear_fwd_wp(hd, 2 * dim, wp2[l], p.b2, z, dim, n, 2 * dim, dim, 0, nullptr, stream);
+    if (wp) rc = stack_fwd_wp(hd, 2 * dim, wp2[l], p.b2, z, dim, n, 2 * dim, dim, 0, nullptr, stream);
     else rc = pgnn_linear_fwd(hd, 2 * dim, p.w2, p.b2, z, dim, n, 2 * dim, dim, 0, stream);
     if (rc) return rc;
     if (fuse && !last)
@@ -496,8 +510,8 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
       wait_fork2 = false;
     }
     if (wp) {
-      if ((rc = pgnn_linear_bwd_data_wp(dz[b], dim, wp2[l], hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main))) return rc;
-      if ((rc = pgnn_linear_bwd_data_wp(dhid[b], 2 * dim, wp1[l], nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main))) return rc;
+      if ((rc = stack_bwd_data_wp(dz[b], dim, wp2[l], hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main))) return rc;
+      if ((rc = stack_bwd_data_wp(dhid[b], 2 * dim, wp1[l], nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main))) return rc;
     } else if (tr && q < ntr) {
       if ((rc = pgnn_linear_bwd_data_t(dz[b], dim, w2t[q], hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main))) return rc;
       if ((rc = pgnn_linear_bwd_data_t(dhid[b], 2 * dim, w1t[q], nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main))) return rc;
@@ -772,7 +786,7 @@ int pgnn_bio_gin_stack_fwd(const float* h0, int64_t ldh0, const int32_t* in_ptr,
       rc = pgnn_rowfeat_matmul_fwd(cfeat, 10, enc_raw ? table[l] : p.emb1, dim, agg + dim, 2 * dim, n, dim, 0, stream);
     }
     if (rc) return rc;
-    if (wp) rc = pgnn_linear_fwd_wp(agg, 2 * dim, wp1[l], p.b1, pre, 2 * dim, n, 2 * dim, 2 * dim, 0, stats_in_gemm ? blocks : nullptr, stream);
+    if (wp) rc = stack_fwd_wp(agg, 2 * dim, wp1[l], p.b1, pre, 2 * dim, n, 2 * dim, 2 * dim, 0, stats_in_gemm ? blocks : nullptr, stream);
     else rc = pgnn_linear_fwd(agg, 2 * dim, p.w1, p.b1, pre, 2 * dim, n, 2 * dim, 2 * dim, 0, stream);
     if (rc) return rc;
     if (stats_in_gemm) {
@@ -784,7 +798,7 @@ int pgnn_bio_gin_stack_fwd(const float* h0, int64_t ldh0, const int32_t* in_ptr,
                        st + 2 * dim, 0.f, 0, n, 2 * dim, ws, opb, stream);
     }
     if (rc) return rc;
-    if (wp) rc = pgnn_linear_fwd_wp(hid, 2 * dim, wp2[l], p.b2, y, dim, n, 2 * dim, dim, l != num_layer - 1, nullptr, stream);
+    if (wp) rc = stack_fwd_wp(hid, 2 * dim, wp2[l], p.b2, y, dim, n, 2 * dim, dim, l != num_layer - 1, nullptr, stream);
     else rc = pgnn_linear_fwd(hid, 2 * dim, p.w2, p.b2, y, dim, n, 2 * dim, dim, l != num_layer - 1, stream);
     if (rc) return rc;
     h = y;
@@ -877,13 +891,13 @@ int pgnn_bio_gin_stack_bwd(const float* dy, int64_t lddy, const int32_t* out_ptr
     const float* st = stats + (size_t)l * 4 * dim;
     // g = gradient of this layer's output (already masked by the ReLU that follows it, see the end of the loop body):
     // dy for the last layer, else dxb[l & 1], written by iteration l + 1
-    if (wp) rc = pgnn_linear_bwd_data_wp(g, ldg, wp2[l], nullptr, 0, dhid[b], 2 * dim, n, 2 * dim, dim, main);
+    if (wp) rc = stack_bwd_data_wp(g, ldg, wp2[l], nullptr, 0, dhid[b], 2 * dim, n, 2 * dim, dim, main);
     else if (tr && q < ntr) rc = pgnn_linear_bwd_data_t(g, ldg, w2t[q], nullptr, 0, dhid[b], 2 * dim, n, 2 * dim, dim, main);
     else rc = pgnn_linear_bwd_data(g, ldg, p.w2, nullptr, 0, dhid[b], 2 * dim, n, 2 * dim, dim, main);
     if (rc) return rc;
     if ((rc = pgnn_bn_bwd(dhid[b], 2 * dim, pre, 2 * dim, p.gamma, p.beta, st, st + 2 * dim, training, 1, dpre[b], 2 * dim,
                           p.dgamma, p.dbeta, 0.f, 0, n, 2 * dim, op, opb, main))) return rc;
-    if (wp) rc = pgnn_linear_bwd_data_wp(dpre[b], 2 * dim, wp1[l], nullptr, 0, dagg[b], 2 * dim, n, 2 * dim, 2 * dim, main);
+    if (wp) rc = stack_bwd_data_wp(dpre[b], 2 * dim, wp1[l], nullptr, 0, dagg[b], 2 * dim, n, 2 * dim, 2 * dim, main);
     else if (tr && q < ntr) rc = pgnn_linear_bwd_data_t(dpre[b], 2 * dim, w1t[q], nullptr, 0, dagg[b], 2 * dim, n, 2 * dim, 2 * dim, main);
     else rc = pgnn_linear_bwd_data(dpre[b], 2 * dim, p.w1, nullptr, 0, dagg[b], 2 * dim, n, 2 * dim, 2 * dim, main);
     if (rc) return rc;

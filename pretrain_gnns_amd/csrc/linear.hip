@@ -1599,3 +1599,401 @@ int pgnn_linear_bwd_weight_pair(const float* dy_a, int64_t lddy_a, const float* 
 }
 
 }  // extern "C"
+
+// ==================================================================================================================================
+// The planes products on TWO fp16 planes (PGNN_GEMM_2P=1; measured as a prototype at the end of round 3, DESIGN 8.1 and
+// profiles/r03/gemm2p_probe.txt): x = (h1 + h2) / s with a power-of-two scale s per ROW of each operand -- the row's largest
+// magnitude lands in [2^13, 2^14), so h2 = fp16(s x - h1) stays out of fp16's subnormals for every element that matters -- needs
+// three v_mfma_f32_16x16x32_f16 per accumulator and k-step (h1 h2, h2 h1, h1 h1) where three bf16 planes need six, at a plain fp32
+// product's error (tools/two_plane_numerics.py).  Scales and the epilogue's rescale are exact.
+//   weights: pgnn::split_weights_2p writes [2][rows][ld] fp16 planes of s W followed by 1/s per row (inside the room of three bf16 planes);
+//   activations: every workgroup takes the maxima of its own rows in a pass in front of its k-loop (no producer has to supply them);
+//   k_gemm2pw = k_gemm3w's one-tile-per-workgroup path with the plane count, the split and the epilogue's rescale changed.
+// ==================================================================================================================================
+namespace pgnn {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {  // round to nearest even, a in the low half
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, f16x2));
+}
+__device__ __forceinline__ void split2(float a, float b, uint32_t& h, uint32_t& l) {
+  const f16x2 hh = __builtin_convertvector(f32x2{a, b}, f16x2);
+  h = __builtin_bit_cast(uint32_t, hh);
+  l = pack_f16(a - (float)hh[0], b - (float)hh[1]);
+}
+// 2^(13 - floor(log2(amax))) and its inverse from amax's exponent field (zero / tiny rows: 1)
+__device__ __forceinline__ void pow2_scales(float amax, float& s, float& inv) {
+  const unsigned e = (__float_as_uint(amax) >> 23) & 0xffu;
+  const bool ok = e > 13u && e < 255u;
+  s = ok ? __uint_as_float((267u - e) << 23) : 1.f;
+  inv = ok ? __uint_as_float((e - 13u) << 23) : 1.f;
+}
+
+// one wave per output row (k_split_jobs' jobs: dst row r = src row r, or src column r when transposed): the row's maximum, then
+// the two planes of s W (zero from `cols` to `ld`) and 1/s behind the planes
+__global__ void __launch_bounds__(256) k_split2p_jobs(SplitJobs jobs) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < jobs.nbump) *jobs.bump[threadIdx.x] += 1;
+  if (jobs.tabs.count && blockIdx.y == 0) {
+    const int dim = jobs.tabs.dim, k = jobs.tabs.k, per = (k + 1) * dim;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < jobs.tabs.count * per; i += gridDim.x * 256) {
+      const int l = i / per, q = i - l * per, r = q / dim, c = q - r * dim;
+      jobs.tabs.dst[l][q] = r < k ? jobs.tabs.w[l][(int64_t)c * k + r] : jobs.tabs.b[l][c];
+    }
+  }
+  const int j = blockIdx.y, rows = jobs.rows[j], cols = jobs.cols[j], ld = jobs.ld[j];
+  const bool tr = jobs.transpose[j] != 0;
+  const float* __restrict__ src = jobs.src[j];
+  unsigned short* __restrict__ dst = jobs.dst[j];
+  if (!src) return;
+  const int64_t plane = (int64_t)rows * ld;
+  float* __restrict__ binv = reinterpret_cast<float*>(dst + 2 * plane);
+  const int lane = threadIdx.x & 63;
+  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
+    float mx = 0.f;
+    for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, fabsf(tr ? src[(int64_t)c * rows + r] : src[(int64_t)r * cols + c]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float s, inv;
+    pow2_scales(mx, s, inv);
+    for (int c = lane; c < ld; c += 64) {
+      const float v = c < cols ? (tr ? src[(int64_t)c * rows + r] : src[(int64_t)r * cols + c]) * s : 0.f;
+      const _Float16 h = (_Float16)v;
+      const _Float16 l = (_Float16)(v - (float)h);
+      dst[(int64_t)r * ld + c] = __builtin_bit_cast(unsigned short, h);
+      dst[plane + (int64_t)r * ld + c] = __builtin_bit_cast(unsigned short, l);
+    }
+    if (lane == 0) binv[r] = inv;
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_waves_per_eu(2, 2))) k_gemm2pw(GemmArgs p) {
+  constexpr int BK = 32, NPL = 2;
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int MI = WM / 16, NI = WN / 16;
+  constexpr int A_BYTES = BM * 128, B_PLANE = BN * 64, STAGE = A_BYTES + NPL * B_PLANE;
+  constexpr int PA = BM / 8, PB = BN / 16;
+  constexpr int NP = PA + NPL * PB, NJ = (NP + NW - 1) / NW;
+  constexpr int TPR = (64 * NW) / BM;  // threads per row of the row-maximum pass
+  static_assert(NI >= 5 && STAGES >= 3 && (TPR & (TPR - 1)) == 0 && TPR <= 64, "tile shape");
+
+  extern __shared__ __align__(16) unsigned char smem2p[];
+  __shared__ float rowmax[BM];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x, p.nxcd);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int nk = (p.K + BK - 1) / BK;
+  const float* __restrict__ b_inv = reinterpret_cast<const float*>(p.Bp + 2 * p.bplane);
+
+  // the maxima of this tile's rows of A: thread t takes row t / TPR, float4 columns t % TPR, + TPR, ...; eight loads in flight per
+  // round, all of them older than the first DMA
+  {
+    float mx = 0.f;
+    const int r = min(m0 + tid / TPR, p.M - 1), k4 = p.K / 4;
+    const float4* row = reinterpret_cast<const float4*>(p.A + (int64_t)r * p.lda);
+    for (int c = tid % TPR; c < k4; c += 8 * TPR) {
+      float4 pre[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pre[u] = row[min(c + u * TPR, k4 - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(pre[u].x), fabsf(pre[u].y)), fmaxf(fabsf(pre[u].z), fabsf(pre[u].w))));
+    }
+#pragma unroll
+    for (int off = 1; off < TPR; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (tid % TPR == 0) rowmax[tid / TPR] = mx;
+  }
+
+  const unsigned char* src[NJ];
+  int koff[NJ], klast[NJ], kstep[NJ], ldsoff[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int d = min(wave + j * NW, NP - 1);
+    if (d < PA) {
+      const int row = 8 * d + (lane >> 3);
+      const int c = (lane & 7) ^ (((lane >> 3) & 6) | (d & 1));
+      koff[j] = 16 * c;
+      klast[j] = 4 * (p.K - 4);
+      kstep[j] = BK * 4;
+      ldsoff[j] = d * 1024;
+      src[j] = reinterpret_cast<const unsigned char*>(p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda);
+    } else {
+      const int q = (d - PA) / PB, pb = (d - PA) % PB;
+      const int row = 16 * pb + (lane >> 2);
+      const int c = (lane & 3) ^ ((-(lane >> 4)) & 3);
+      koff[j] = 16 * c;
+      klast[j] = 2 * ((int)p.ldbp - 8);
+      kstep[j] = BK * 2;
+      ldsoff[j] = A_BYTES + (d - PA) * 1024;
+      src[j] = reinterpret_cast<const unsigned char*>(p.Bp + q * p.bplane + (int64_t)min(n0 + row, p.N - 1) * p.ldbp);
+    }
+  }
+  auto issue_piece = [&](int j, int stage) {
+    __builtin_amdgcn_global_load_lds(PGNN_GPTR(src[j] + min(koff[j], klast[j])), PGNN_LPTR(smem2p + stage * STAGE + ldsoff[j]), 16, 0, 0);
+    koff[j] += kstep[j];
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+  const int fr = lane & 15, fk = lane >> 4;
+  const int a_off = (wm0 + fr) * 128, a_lo = (((2 * fk) ^ ((fr & 6) | (fr >> 3))) * 16), a_hi = (((2 * fk + 1) ^ ((fr & 6) | (fr >> 3))) * 16);
+  const int b_off = (wn0 + fr) * 64 + ((fk ^ ((-(fr >> 2)) & 3)) * 16);
+  float sa[MI], ainv[MI];  // scale and inverse scale of this lane's A rows (fragment row fr = epilogue row fr)
+
+  auto aload = [&](int stage, f32x4 (&lo)[MI], f32x4 (&hi)[MI]) {
+    const unsigned char* s = smem2p + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      lo[i] = *reinterpret_cast<const f32x4*>(s + a_off + i * 16 * 128 + a_lo);
+      hi[i] = *reinterpret_cast<const f32x4*>(s + a_off + i * 16 * 128 + a_hi);
+    }
+  };
+  f16x8 b[NI][NPL];
+  auto bload = [&](int stage, int j) {
+    const unsigned char* s = smem2p + stage * STAGE + A_BYTES;
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) b[j][q] = *reinterpret_cast<const f16x8*>(s + q * B_PLANE + b_off + j * 16 * 64);
+  };
+  auto asplit_q = [&](int c, const f32x4 (&lo)[MI], const f32x4 (&hi)[MI], uint4 (&pl)[MI][NPL]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const f32x4 v = c < 2 ? lo[i] : hi[i];
+      uint32_t h, l;
+      split2(v[2 * (c & 1)] * sa[i], v[2 * (c & 1) + 1] * sa[i], h, l);
+      (&pl[i][0].x)[c] = h; (&pl[i][1].x)[c] = l;
+    }
+  };
+  auto pin_q = [&](int c, const uint4 (&pl)[MI][NPL]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) asm volatile("" ::"v"((&pl[i][0].x)[c]), "v"((&pl[i][1].x)[c]));
+  };
+  auto step = [&](auto do_issue, const f16x8 (&cur)[MI][NPL], f16x8 (&nxt)[MI][NPL], int stage, int next_stage, int issue_stage) {
+    f32x4 lo[MI], hi[MI];
+    uint4 pl[MI][NPL];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j][0], cur[i][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j][1], cur[i][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j][0], cur[i][0], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j >= 1 && j <= 4) {
+        asplit_q(j - 1, lo, hi, pl);
+        pin_q(j - 1, pl);
+      }
+      if (j + 2 < NI) bload(stage, j + 2);
+      else bload(next_stage, j + 2 - NI);
+      if (j == 0) aload(next_stage, lo, hi);
+      if constexpr (decltype(do_issue)::value) {
+#pragma unroll
+        for (int q = 0; q < NJ; ++q)
+          if ((NJ <= NI ? q : q * NI / NJ) == j) issue_piece(q, issue_stage);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) nxt[i][q] = __builtin_bit_cast(f16x8, pl[i][q]);
+  };
+
+  // epilogue operands, fetched before the DMAs as in k_gemm3w: the ReLU mask, the bias and the inverse scales of the B rows
+  float4 mk[EPI == EPI_MASK ? MI : 1][NI];
+  float4 bv[NI], bi[NI];
+  if constexpr (EPI == EPI_MASK) gemm_prefetch_mask<MI, NI>(p, mk, m0 + wm0, n0 + wn0, lane);
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int nn = min(n0 + wn0 + j * 16 + fk * 4, p.N - 4);
+    bi[j] = *reinterpret_cast<const float4*>(b_inv + nn);
+    bv[j] = f4_zero();
+    if constexpr (EPI == EPI_BIAS)
+      if (p.bias) bv[j] = *reinterpret_cast<const float4*>(p.bias + nn);
+  }
+#pragma unroll
+  for (int q = 0; q < STAGES - 1; ++q)
+    if (q < nk) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) issue_piece(j, q);
+    }
+  auto sync = [&](int t) {
+    const int infl = max(0, min(t + STAGES - 2, nk - 1) - (t + 1));
+    if (STAGES >= 4 && infl == STAGES - 3) gemm_wait_vmcnt_imm<(STAGES >= 4 ? STAGES - 3 : 0) * NJ>();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+  };
+  f16x8 a0[MI][NPL], a1[MI][NPL];
+  sync(0);  // (its barrier also publishes rowmax)
+#pragma unroll
+  for (int i = 0; i < MI; ++i) pow2_scales(rowmax[wm0 + i * 16 + fr], sa[i], ainv[i]);
+  {
+    f32x4 lo[MI], hi[MI];
+    aload(0, lo, hi);
+    bload(0, 0);
+    bload(0, 1);
+    uint4 pl[MI][NPL];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) asplit_q(c, lo, hi, pl);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) a0[i][q] = __builtin_bit_cast(f16x8, pl[i][q]);
+  }
+  using Yes = std::integral_constant<bool, true>;
+  using No = std::integral_constant<bool, false>;
+  const int n_main = max(0, nk - (STAGES - 1));
+  int it = 0;
+  for (; it + 2 <= n_main; it += 2) {
+    if (it > 0) sync(it);
+    step(Yes{}, a0, a1, it % STAGES, (it + 1) % STAGES, (it + STAGES - 1) % STAGES);
+    sync(it + 1);
+    step(Yes{}, a1, a0, (it + 1) % STAGES, (it + 2) % STAGES, (it + STAGES) % STAGES);
+  }
+  if (it < n_main) {
+    if (it > 0) sync(it);
+    step(Yes{}, a0, a1, it % STAGES, (it + 1) % STAGES, (it + STAGES - 1) % STAGES);
+    ++it;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) a0[i][q] = a1[i][q];
+  }
+  for (; it < nk; it += 2) {
+    if (it > 0) sync(it);
+    step(No{}, a0, a1, it % STAGES, (it + 1) % STAGES, 0);
+    if (it + 1 < nk) {
+      sync(it + 1);
+      step(No{}, a1, a0, (it + 1) % STAGES, (it + 2) % STAGES, 0);
+    }
+  }
+  // ---- epilogue (k_gemm3w's, behind the exact rescale): lane holds C[m0 + wm0 + 16 i + fr][n0 + wn0 + 16 j + 4 fk + 0..3]
+  float* C = p.C;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = n0 + wn0 + j * 16 + fk * 4;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int mb = m0 + wm0 + i * 16, m = mb + fr;
+      const float ai = ainv[i];
+      float4 v = make_float4(acc[i][j][0] * (ai * bi[j].x), acc[i][j][1] * (ai * bi[j].y), acc[i][j][2] * (ai * bi[j].z),
+                             acc[i][j][3] * (ai * bi[j].w));
+      if constexpr (EPI == EPI_BIAS) {
+        v = f4_add(v, bv[j]);
+        if (p.relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        if (p.colstat) {  // (uniform) per-16-row-block column sums and squared deviations, as in k_gemm3w
+          const int cnt = min(16, p.M - mb);
+          if (cnt > 0) {
+            const bool ok = fr < cnt;
+            float4 sm = ok ? v : f4_zero();
+            sm.x = row16_sum(sm.x); sm.y = row16_sum(sm.y); sm.z = row16_sum(sm.z); sm.w = row16_sum(sm.w);
+            const float inv = 1.f / (float)cnt;
+            float4 q;
+            q.x = ok ? v.x - sm.x * inv : 0.f; q.y = ok ? v.y - sm.y * inv : 0.f;
+            q.z = ok ? v.z - sm.z * inv : 0.f; q.w = ok ? v.w - sm.w * inv : 0.f;
+            q.x = row16_sum(q.x * q.x); q.y = row16_sum(q.y * q.y); q.z = row16_sum(q.z * q.z); q.w = row16_sum(q.w * q.w);
+            if (fr == 0 && n < p.N) {
+              float* cs = p.colstat + (int64_t)(mb >> 4) * 2 * p.N + n;
+              *reinterpret_cast<float4*>(cs) = sm;
+              *reinterpret_cast<float4*>(cs + p.N) = q;
+            }
+          }
+        }
+      }
+      if constexpr (EPI == EPI_MASK) {
+        const float4 k4 = mk[i][j];
+        if (!(k4.x > 0.f)) v.x = 0.f;
+        if (!(k4.y > 0.f)) v.y = 0.f;
+        if (!(k4.z > 0.f)) v.z = 0.f;
+        if (!(k4.w > 0.f)) v.w = 0.f;
+      }
+      if (m < p.M && n < p.N) *reinterpret_cast<float4*>(C + (int64_t)m * p.ldc + n) = v;
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI>
+int launch_gemm2pw_s(const GemmArgs& p, hipStream_t st) {
+  constexpr size_t lds = (size_t)STAGES * (BM * 128 + 2 * BN * 64);
+  const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N, BN));
+  allow_big_lds((const void*)k_gemm2pw<BM, BN, WAVES_M, WAVES_N, STAGES, EPI>, lds);
+  hipLaunchKernelGGL((k_gemm2pw<BM, BN, WAVES_M, WAVES_N, STAGES, EPI>), dim3(tiles), dim3(64 * WAVES_M * WAVES_N), lds, st, p);
+  return check_launch("gemm2pw");
+}
+// the two tiles of launch_gemm3w's default choice, under its rounds x (k-steps + fixed) model with the two-plane step times
+template <int EPI>
+int launch_gemm2pw(const GemmArgs& p, hipStream_t st) {
+  const int64_t nk = ceil_div(p.K, 32), cus = num_cu();
+  const double t64 = (double)ceil_div(ceil_div(p.M, 64) * ceil_div(p.N, 160), cus) * (0.5 * nk + 5.0);
+  const double t128 = (double)ceil_div(ceil_div(p.M, 128) * ceil_div(p.N, 160), cus) * (0.95 * nk + 6.0);
+  if (t128 <= t64) return launch_gemm2pw_s<128, 160, 8, 1, 3, EPI>(p, st);
+  return launch_gemm2pw_s<64, 160, 4, 2, 4, EPI>(p, st);
+}
+
+}  // namespace
+
+int split_weights_2p(const float* const* src, void* const* dst, const int64_t* rows, const int64_t* cols, const int32_t* transpose,
+                     int64_t count, int64_t* const* bump, int nbump, hipStream_t stream, const EncTables* tabs) {
+  PGNN_REQUIRE(count >= 0 && count <= 32 && nbump >= 0 && nbump <= 16, "split_weights: at most 32 matrices (and 16 counters) per call");
+  PGNN_REQUIRE(!tabs || (tabs->count >= 0 && tabs->count <= 16 && tabs->dim > 0 && tabs->k > 0), "split_weights: at most 16 encoder tables");
+  const bool with_tabs = tabs && tabs->count > 0;
+  if (count == 0 && !with_tabs) return PGNN_OK;
+  SplitJobs jobs{};
+  if (with_tabs) jobs.tabs = *tabs;
+  for (int j = 0; j < nbump; ++j) jobs.bump[j] = reinterpret_cast<long long*>(bump[j]);
+  jobs.nbump = nbump;
+  int64_t most = 1;
+  for (int j = 0; j < count; ++j) {
+    PGNN_REQUIRE(src[j] && dst[j] && rows[j] > 0 && cols[j] > 0 && rows[j] < (1 << 24) && cols[j] < (1 << 24), "split_weights: bad job");
+    const bool tr = transpose && transpose[j];
+    jobs.src[j] = src[j]; jobs.dst[j] = static_cast<unsigned short*>(dst[j]);
+    jobs.rows[j] = (int)(tr ? cols[j] : rows[j]); jobs.cols[j] = (int)(tr ? rows[j] : cols[j]);
+    jobs.ld[j] = (int)(ceil_div(jobs.cols[j], 32) * 32); jobs.transpose[j] = tr;
+    most = std::max(most, ceil_div(jobs.rows[j], 4));
+  }
+  if (with_tabs) most = std::max<int64_t>(most, std::min<int64_t>(ceil_div((int64_t)tabs->count * (tabs->k + 1) * tabs->dim, 256), 64));
+  hipLaunchKernelGGL(k_split2p_jobs, dim3((int)std::min<int64_t>(most, 4096), (int)std::max<int64_t>(count, 1)), dim3(256), 0, stream, jobs);
+  return check_launch("split_weights_2p");
+}
+
+int linear_fwd_wp_2p(const float* x, int64_t ldx, const void* wplanes, const float* bias, float* y, int64_t ldy, int64_t m, int64_t k,
+                     int64_t n, int relu, float* colstat, hipStream_t st) {
+  PGNN_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && wplanes,
+               "linear_fwd_wp_2p: K, N and the leading dimensions must be multiples of 4");
+  GemmArgs p{};
+  p.nxcd = num_xcd();
+  p.A = x; p.lda = ldx; p.C = y; p.ldc = ldy;
+  p.Bp = static_cast<const unsigned short*>(wplanes); p.ldbp = ceil_div(k, 32) * 32; p.bplane = n * p.ldbp;
+  p.M = (int)m; p.N = (int)n; p.K = (int)k; p.bias = bias; p.relu = relu; p.kchunk = (int)k; p.split_stride = 0;
+  p.colstat = colstat;
+  return launch_gemm2pw<EPI_BIAS>(p, st);
+}
+
+int linear_bwd_data_wp_2p(const float* dy, int64_t lddy, const void* wtplanes, const float* relu_out, int64_t ldr, float* dx, int64_t lddx,
+                          int64_t m, int64_t k, int64_t n, hipStream_t st) {
+  PGNN_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && wtplanes,
+               "linear_bwd_data_wp_2p: K, N and the leading dimensions must be multiples of 4");
+  GemmArgs p{};
+  p.nxcd = num_xcd();
+  p.A = dy; p.lda = lddy; p.C = dx; p.ldc = lddx;
+  p.Bp = static_cast<const unsigned short*>(wtplanes); p.ldbp = ceil_div(n, 32) * 32; p.bplane = k * p.ldbp;
+  p.M = (int)m; p.N = (int)k; p.K = (int)n; p.mask = relu_out; p.ldmask = ldr; p.kchunk = (int)n; p.split_stride = 0;
+  return relu_out ? launch_gemm2pw<EPI_MASK>(p, st) : launch_gemm2pw<EPI_PLAIN>(p, st);
+}
+
+}  // namespace pgnn
