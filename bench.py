@@ -232,6 +232,44 @@ def pmc_traffic(n, e, name="agg_pmc_traffic.json"):
     return None, None
 
 
+def two_plane_products_leg(dev, args, batch, steps_n):
+    """the SAME steps with PGNN_GEMM_2P=1: the one-call network's forward and backward-data products on two fp16 planes + a power-of-two
+    scale per row (three MFMA products per accumulator instead of six, csrc/linear.hip k_gemm2pw) -- opt-in at the end of
+    round 3 (every reference-fixture test passes with it; a full-suite run with it on did not fit the round's GPU budget), so it
+    is reported beside `value`, not as `value`.  Any failure of this leg is recorded, not raised."""
+    import os
+    from pretrain_gnns_amd import ops
+
+    out = {"knob": "PGNN_GEMM_2P=1", "note": "opt-in: products on two fp16 planes + row scales; everything else as in `value`"}
+    os.environ["PGNN_GEMM_2P"] = "1"
+    try:
+        ops.load().pgnn_reload_env()
+        mods = make_models(dev)
+        opts = make_optimizers(mods, args.adam)
+        step, finish = masking_stepper(mods, list(opts), args.readback, dev)
+        for _ in range(5):
+            step(batch)
+        finish()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps_n):
+            step(batch)
+        loss = finish()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out.update({"ms_per_step": round(1e3 * dt / steps_n, 4), "edges_per_s": round(batch.edge_index.size(1) * steps_n / dt, 1),
+                    "mean_loss": round(float(loss), 5)})
+    except Exception as exc:  # (an experimental leg must not take the bench line with it)
+        out["error"] = "%s: %s" % (type(exc).__name__, exc)
+    finally:
+        os.environ.pop("PGNN_GEMM_2P", None)
+        try:
+            ops.load().pgnn_reload_env()
+        except Exception:
+            pass
+    return out
+
+
 def reference_loop_leg(dev, args, batch, steps_n):
     """the same step with the reference script's loop taken literally: torch's default (foreach, multi-kernel) Adam as
     `optim.Adam(...)` builds it (chem/pretrain_masking.py:134-136), accuracy and loss read back where the script reads them
@@ -849,6 +887,7 @@ def _run():
         if per_step_readback is not None:
             res["per_step_readback"] = per_step_readback
         if world == 1:
+            res["two_plane_products"] = two_plane_products_leg(dev, args, batch, args.steps)
             res["reference_loop"] = reference_loop_leg(dev, args, batch, max(args.steps // 2, 20))
             res["forward_only"] = forward_only(dev, mods, batch, max(args.steps, 20))
         if world == 1 and not args.no_loader:
