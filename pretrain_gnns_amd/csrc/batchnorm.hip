@@ -63,6 +63,7 @@ __device__ __forceinline__ void block_col_reduce2(float4 a, float4 b, int d4, fl
     publish(dst_a + q, (lds[q] + lds[dim + q]) + (lds[2 * dim + q] + lds[3 * dim + q]));
     publish(dst_b + q, (lds[4 * dim + q] + lds[5 * dim + q]) + (lds[6 * dim + q] + lds[7 * dim + q]));
   }
+  publish_commit();  // acknowledged before whatever barrier / ticket of the caller announces them
 }
 
 __global__ void k_bn_stats_partial(const float* __restrict__ x, int64_t ldx, int n, int d4,
@@ -277,7 +278,6 @@ __global__ void k_bn_bwd_partial(const float* __restrict__ dy, int64_t lddy, con
   const int grp = blockIdx.x / kFoldGroup, gsize = min(kFoldGroup, nblk - grp * kFoldGroup);
   __syncthreads();  // this block's partial row is written (agent-scope stores, block_col_reduce2)
   if (t == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     role = __hip_atomic_fetch_add(tickets + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)gsize - 1u ? 1 : 0;
   }
   __syncthreads();
@@ -292,10 +292,11 @@ __global__ void k_bn_bwd_partial(const float* __restrict__ dy, int64_t lddy, con
       if (b < gsize) acc += (double)v[b];
     publish(gsum + (size_t)grp * 2 * dim + q, acc);
   }
+  publish_commit();
   __syncthreads();
   if (t == 0) {
     publish(tickets + 1 + grp, 0u);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    publish_commit();
     role = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ngroups - 1u ? 2 : 0;
   }
   __syncthreads();

@@ -189,11 +189,16 @@ __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 
 // their 91 us in them, the 253 blocks of the masking head 12 of 27 us.
 template <typename T>
 __device__ __forceinline__ void publish(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// publish() only ISSUES the store.  On gfx950 stores and loads share `vmcnt`, a workgroup-scope release fence and __syncthreads()
+// wait for `lgkmcnt` only, and the store and the ticket atomic that follows go to different L2 channels -- so every thread that
+// has published must call publish_commit() (s_waitcnt vmcnt(0): its write-through stores are acknowledged) BEFORE the barrier /
+// ticket that announces them (without it the last block could fetch a partial that had not landed).
+__device__ __forceinline__ void publish_commit() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <typename T>
 __device__ __forceinline__ T fetch_published(const T* p) { return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // "The last block to finish folds everybody's partial results": called by ONE thread of every block, behind a __syncthreads()
-// that follows the block's publish() stores (every wave has then waited for its own stores); true in exactly one block, which may
+// that follows the block's publish() stores AND their publish_commit() in every publishing thread; true in exactly one block, which may
 // then read every block's results with fetch_published().  No cache maintenance (see above).  Same-address device-scope atomics
 // retire at ~50 ns each, so a block first takes a ticket in one of up to 32 group words and only the last of each group takes one
 // in the top word.  words: PGNN_TICKET_WORDS uint32, zero before the launch, left zero.
@@ -202,12 +207,13 @@ __device__ __forceinline__ bool arrive_last(unsigned* words) {
   const unsigned nb = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
   const unsigned G = nb < kTicketGroups ? nb : kTicketGroups, g = b % G;
   const unsigned size = nb / G + (g < nb % G ? 1u : 0u);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt only: this thread's stores are done, nothing moves below
+  publish_commit();  // this thread's own stores (the single-thread publishers call arrive_last right behind publish())
   if (__hip_atomic_fetch_add(words + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != size - 1u) return false;
   publish(words + 1 + g, 0u);
+  publish_commit();
   if (__hip_atomic_fetch_add(words, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != G - 1u) return false;
   publish(words, 0u);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  asm volatile("" ::: "memory");  // the caller's fetch_published() loads stay below the ticket (its value was waited for above)
   return true;
 }
 

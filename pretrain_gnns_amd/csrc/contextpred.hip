@@ -94,7 +94,8 @@ __global__ void __launch_bounds__(kCtxThreads) k_ctx_scores(const float* __restr
     __syncthreads();
   }
   if (t <= neg) publish(scores + (int64_t)t * B + g, red[t][0]);  // (read by the last block: agent-scope, see common.h)
-  __syncthreads();  // (the score stores of threads 1..neg are behind this block's arrival)
+  publish_commit();
+  __syncthreads();  // (the score stores of threads 1..neg are acknowledged before this block's arrival)
   if (t == 0) last = arrive_last(counter);
   __syncthreads();
   if (!last) return;

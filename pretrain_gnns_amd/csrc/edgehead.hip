@@ -257,6 +257,7 @@ __global__ void __launch_bounds__(kEdgeBlock) k_edge_dl(const float* __restrict_
     __syncthreads();
   }
   if (threadIdx.x < kEdgeMaxC) publish(partial + (size_t)blockIdx.x * kEdgeMaxC + threadIdx.x, red[threadIdx.x][0]);
+  publish_commit();
   __syncthreads();
   if (threadIdx.x == 0) last = arrive_last(counter);
   __syncthreads();

@@ -833,8 +833,11 @@ _head_words = {}
 
 
 def _head_state(dev):
-    """[status, -, arrival tickets (PGNN_TICKET_WORDS)]: int32 words per device, zeroed once (the kernels leave the tickets at zero)"""
-    key = (dev.type, dev.index)
+    """[status, -, arrival tickets (PGNN_TICKET_WORDS)]: int32 words per (device, stream), zeroed once (the kernels leave the
+    tickets at zero).  Per stream like the workspace: two heads launched concurrently on two streams of one device (a side stream,
+    two ranks in threads on one GPU) must not count their blocks in the same words."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, stream_ptr(idx))
     t = _head_words.get(key)
     if t is None:
         t = _head_words[key] = torch.zeros(64, dtype=torch.int32, device=dev)
@@ -1046,7 +1049,18 @@ class ContextPredLoss(Function):
         return dhs, None, dhc, None, None, None, None
 
 
+def contextpred_loss_eligible(hs, hc, center, neg_samples):
+    """can ContextPredLoss take these embeddings?  fp32 [*, dim] with dim % 4 == 0 and dim <= 512 (JK = "concat" is 1 800 wide),
+    1 <= neg_samples <= min(8, graphs): the kernel pairs graph g with graph (g + k) % B, which is the reference's cycle_index only
+    while k <= B (chem/pretrain_contextpred.py:36-39 raises on the shape mismatch beyond) -- the torch path raises as it does."""
+    B = center.numel()
+    return (hs.dim() == 2 and hc.dim() == 2 and hs.dtype == torch.float32 and hc.dtype == torch.float32 and hs.size(1) == hc.size(1)
+            and hs.size(1) % 4 == 0 and hs.size(1) <= 512 and B > 0 and 1 <= int(neg_samples) <= min(8, B))
+
+
 def contextpred_loss(hs, center, hc, overlap, seg, neg_samples=1, accum=None):
+    if not contextpred_loss_eligible(hs, hc, center, neg_samples):
+        raise _lib.PgnnError("contextpred loss: needs fp32 [*, dim] embeddings, dim % 4 == 0, dim <= 512, 1 <= neg_samples <= min(8, graphs)")
     return ContextPredLoss.apply(hs, center, hc, overlap, seg, neg_samples, accum)
 
 

@@ -311,16 +311,19 @@ def cycle_index(num, shift):
     return arr
 
 
-def contextpred_logits(model_substruct, model_context, batch, neg_samples=1, mode="cbow", pool=None):
+def contextpred_logits(model_substruct, model_context, batch, neg_samples=1, mode="cbow", pool=None, node_reps=None):
     """chem/pretrain_contextpred.py:54-81 (identical in bio/pretrain_contextpred.py:49-76): the positive and
     negative dot-product scores.  cbow: centre embedding against the pooled overlap embeddings of its own graph /
     of the graph `shift` places later (cycle_index).  skipgram: every overlap node against its own / the shifted
-    centre; the reference's per-graph ``.repeat`` loops are one ``repeat_interleave`` here (a pure gather: same bits)."""
+    centre; the reference's per-graph ``.repeat`` loops are one ``repeat_interleave`` here (a pure gather: same bits).
+    ``node_reps`` = (substructure, context) node embeddings the caller has already computed (the two networks then do NOT
+    run again: a second training-mode forward would move the BatchNorm running statistics twice)."""
     pool = ops.global_mean_pool if pool is None else pool
-    substruct_rep = model_substruct(batch.x_substruct, batch.edge_index_substruct,
-                                    batch.edge_attr_substruct)[batch.center_substruct_idx]
-    overlapped_node_rep = model_context(batch.x_context, batch.edge_index_context,
-                                        batch.edge_attr_context)[batch.overlap_context_substruct_idx]
+    if node_reps is None:
+        node_reps = (model_substruct(batch.x_substruct, batch.edge_index_substruct, batch.edge_attr_substruct),
+                     model_context(batch.x_context, batch.edge_index_context, batch.edge_attr_context))
+    substruct_rep = node_reps[0][batch.center_substruct_idx]
+    overlapped_node_rep = node_reps[1][batch.overlap_context_substruct_idx]
     if mode == "cbow":
         context_rep = pool(overlapped_node_rep, batch.batch_overlapped_context)
         neg_context_rep = torch.cat([context_rep[cycle_index(len(context_rep), i + 1).to(context_rep.device)]
@@ -348,12 +351,14 @@ def chem_contextpred_step(model_substruct, model_context, optimizer_substruct, o
         raise ValueError("readback must be 'end' or 'epoch'")
     if readback == "epoch" and accum is None:
         raise ValueError("readback='epoch' needs accum=epoch_accumulator(device)")
+    node_reps = None
     if mode == "cbow" and pool is None and batch.x_substruct.is_cuda and 1 <= neg_samples <= 8:
         # the reference's defaults: the whole loss in two launches forward and one back (csrc/contextpred.hip) instead of ~50
         # torch launches a few hundred elements long, between which the GPU idled
         hs = model_substruct(batch.x_substruct, batch.edge_index_substruct, batch.edge_attr_substruct)
         hc = model_context(batch.x_context, batch.edge_index_context, batch.edge_attr_context)
-        if hs.dim() == 2 and hs.size(1) % 4 == 0 and hs.size(1) <= 512:
+        node_reps = (hs, hc)  # an ineligible shape falls through to the torch loss ON THESE embeddings (no second forward)
+        if ops.contextpred_loss_eligible(hs, hc, batch.center_substruct_idx, neg_samples):
             loss, vals = ops.contextpred_loss(hs, batch.center_substruct_idx, hc, batch.overlap_context_substruct_idx,
                                               batch.batch_overlapped_context, neg_samples, accum if readback == "epoch" else None)
             optimizer_substruct.zero_grad()
@@ -365,7 +370,7 @@ def chem_contextpred_step(model_substruct, model_context, optimizer_substruct, o
                 return None
             v = vals.cpu().tolist()
             return v[0] + v[1], 0.5 * (v[2] + v[3])
-    pred_pos, pred_neg = contextpred_logits(model_substruct, model_context, batch, neg_samples, mode, pool)
+    pred_pos, pred_neg = contextpred_logits(model_substruct, model_context, batch, neg_samples, mode, pool, node_reps)
     loss_pos = F.binary_cross_entropy_with_logits(pred_pos.double(), torch.ones_like(pred_pos).double())
     loss_neg = F.binary_cross_entropy_with_logits(pred_neg.double(), torch.zeros_like(pred_neg).double())
     optimizer_substruct.zero_grad()
