@@ -140,13 +140,10 @@ def steady_state_ms(launch, warm_s=0.1, iters=50):
     return float(ev[0].elapsed_time(ev[iters]) / iters), per, iters
 
 
-def roofline_aggregation(dev, graphs):
-    """time the GIN aggregation kernel alone at a batch whose working set exceeds the Infinity Cache."""
+def _time_aggregation(dev, big):
+    """steady-state time of pgnn_chem_aggregate_fwd on ``big`` -> (ms, per-launch ms, launches, nodes, edges, algorithmic bytes)"""
     from pretrain_gnns_amd import ops
-    from pretrain_gnns_amd.data import synthetic
 
-    base = synthetic.chem_masking_batch(2048, seed=123, device=dev)
-    big = synthetic.tile_batch(base, max(1, graphs // 2048)).to(dev)
     n, e = big.x.size(0), big.edge_index.size(1)
     g = ops.build_chem_graph(big.edge_index, big.edge_attr, n)
     torch.manual_seed(0)
@@ -162,57 +159,72 @@ def roofline_aggregation(dev, graphs):
                                               out.data_ptr(), 300, n, 300, sp), "aggregate")
 
     ms, per, iters = steady_state_ms(launch)
-    alg_bytes = 2400.0 * n + 6.0 * e + 4.0 * (n + 1)
+    return ms, per, iters, n, e, 2400.0 * n + 6.0 * e + 4.0 * (n + 1)
+
+
+def roofline_aggregation(dev, graphs):
+    """time the GIN aggregation kernel alone at a batch whose working set exceeds the Infinity Cache.  Round 4:
+    the batch's molecules carry their atoms in SMILES parse order -- what chem/loader.py:53-100 feeds the model; 6 % of its edges
+    span more than the kernel's LDS window -- and go through the product's loader, whose once-per-dataset renumbering
+    (data/relabel.py) brings that to ~0; `as_fed` is the same batch without the renumbering, `survey_order` the batch of rounds
+    1-3 (SURVEY 8d's tree, parent within 3 rows)."""
+    from pretrain_gnns_amd.data import synthetic
+
+    big, info = synthetic.chem_aggregation_batch(graphs, "smiles", True, device=dev)
+    ms, per, iters, n, e, alg_bytes = _time_aggregation(dev, big)
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     traffic, traffic_src = pmc_traffic(n, e)
-    return {"bound": "hbm", "kernel": "k_aggregate_dma<true,2,10,false,19> (pgnn_chem_aggregate_fwd; rows loaded and stored "
-                                      "non-temporally because x + out exceed the Infinity Cache; POL bit 4: source rows outside the LDS window "
-                                      "are fetched a step ahead -- this batch has none)", "achieved": round(gbs, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "traffic_source": traffic_src, "ms_per_launch": round(ms, 4), "launches_timed": iters,
-            "ms_per_launch_std": round(float(per.std()), 4), "ms_per_launch_min": round(float(per.min()), 4),
-            "ms_per_launch_max": round(float(per.max()), 4), "warmup": "0.1 s of the same kernel",
-            "algorithmic_bytes_per_launch": int(alg_bytes),
-            "bytes_per_edge_per_layer": round(alg_bytes / e, 1), "graphs": int(big.batch[-1].item()) + 1,
-            "nodes": n, "edges": e}
+    res = {"bound": "hbm", "kernel": "k_aggregate_dma<true,2,10,false,19> (pgnn_chem_aggregate_fwd; rows loaded and stored "
+                                     "non-temporally because x + out exceed the Infinity Cache; POL bit 4: source rows outside the LDS window "
+                                     "are fetched a step ahead)", "achieved": round(gbs, 1),
+           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+           "traffic_source": traffic_src, "ms_per_launch": round(ms, 4), "launches_timed": iters,
+           "ms_per_launch_std": round(float(per.std()), 4), "ms_per_launch_min": round(float(per.min()), 4),
+           "ms_per_launch_max": round(float(per.max()), 4), "warmup": "0.1 s of the same kernel",
+           "algorithmic_bytes_per_launch": int(alg_bytes),
+           "bytes_per_edge_per_layer": round(alg_bytes / e, 1), "graphs": int(big.batch[-1].item()) + 1,
+           "nodes": n, "edges": e, "batch": info}
+    del big
+    for tag, order, relabel in (("as_fed", "smiles", False), ("survey_order", "survey", False)):
+        b2, i2 = synthetic.chem_aggregation_batch(graphs, order, relabel, device=dev)
+        ms2, per2, _, n2, e2, alg2 = _time_aggregation(dev, b2)
+        res[tag] = {"frac": round(alg2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms_per_launch": round(ms2, 4),
+                    "ms_per_launch_std": round(float(per2.std()), 4), "nodes": n2, "edges": e2, "batch": i2}
+        del b2
+    return res
 
 
 def aggregation_robustness(dev, graphs):
-    """informational: the same roofline launch on atom orders less local than SURVEY 8d's generator -- parent
-    of atom i uniform in [i - 8, i), and atoms relabelled at random within each molecule -- with the fraction of edges whose source
-    row lies outside the kernel's LDS window for its destination's 8-node step ([base - 8, base + 16), base = 8 floor(i / 8): those
-    take the kernel's wave-uniform path to global memory).  Same algorithmic bytes formula, same 8 TB/s denominator."""
+    """the same roofline launch on atom orders less local than SURVEY 8d's generator -- parent of atom i uniform in [i - 8 / 12 / 16,
+    i), SMILES parse order, atoms relabelled at random within each molecule -- each AS FED and through the loader's once-per-dataset
+    renumbering (``ResidentDataset(relabel=True)``, data/relabel.py), with the fraction of edges whose source row lies outside the
+    kernel's LDS window for its destination's 8-node step ([base - 8, base + 16), base = 8 floor(i / 8): those take the far-row
+    path).  Same algorithmic bytes formula, same 8 TB/s denominator."""
     import numpy as np
-    from pretrain_gnns_amd import ops
-    from pretrain_gnns_amd.data import resident, synthetic
+    from pretrain_gnns_amd.data import relabel, resident, synthetic
 
     out = {}
-    lib, sp = ops.load(), ops.stream_ptr()
-    for tag, kw in (("survey_order", {}), ("parent_within_8", {"parent_window": 8}), ("parent_within_12", {"parent_window": 12}),
-                    ("parent_within_16", {"parent_window": 16}), ("atoms_permuted", {"permute": True})):
+    makers = (("survey_order", lambda r: synthetic.zinc_like_graph(r)),
+              ("parent_within_8", lambda r: synthetic.zinc_like_graph(r, parent_window=8)),
+              ("parent_within_12", lambda r: synthetic.zinc_like_graph(r, parent_window=12)),
+              ("parent_within_16", lambda r: synthetic.zinc_like_graph(r, parent_window=16)),
+              ("smiles_order", synthetic.zinc_like_graph_smiles),
+              ("atoms_permuted", lambda r: synthetic.zinc_like_graph(r, permute=True)))
+    for tag, make in makers:
         rng = np.random.default_rng(777)
-        gl = [synthetic.zinc_like_graph(rng, **kw) for _ in range(2048)]
-        base = resident.ResidentDataset.from_graphs(gl, dev).collate(np.arange(len(gl)))
-        big = synthetic.tile_batch(base, max(1, graphs // 2048)).to(dev)
-        n, e = big.x.size(0), big.edge_index.size(1)
-        dst, src = big.edge_index[0], big.edge_index[1]
-        lo = (dst // 8) * 8 - 8
-        miss = float(((src < lo) | (src >= lo + 24)).float().mean())
-        g = ops.build_chem_graph(big.edge_index, big.edge_attr, n)
-        torch.manual_seed(0)
-        x = torch.randn(n, 300, device=dev)
-        e1, e2 = torch.randn(6, 300, device=dev), torch.randn(3, 300, device=dev)
-        y = torch.empty(n, 300, device=dev)
-
-        def launch():
-            ops.check(lib.pgnn_chem_aggregate_fwd(x.data_ptr(), 300, g.in_ptr.data_ptr(), g.in_src.data_ptr(), g.in_code.data_ptr(),
-                                                  e1.data_ptr(), e2.data_ptr(), None, y.data_ptr(), 300, n, 300, sp), "aggregate")
-
-        ms, per, iters = steady_state_ms(launch, warm_s=0.05, iters=30)
-        alg = 2400.0 * n + 6.0 * e + 4.0 * (n + 1)
-        out[tag] = {"out_of_window_edge_fraction": round(miss, 4), "ms_per_launch": round(ms, 4), "ms_per_launch_std": round(float(per.std()), 4),
-                    "achieved_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "nodes": n, "edges": e}
-        del x, y, g, big
+        gl = [make(rng) for _ in range(2048)]
+        for suffix, rl in (("", False), ("_relabelled", True)):
+            if rl and tag == "survey_order":
+                continue
+            base = resident.ResidentDataset.from_graphs(gl, dev, relabel=rl).collate(np.arange(len(gl)))
+            big = synthetic.tile_batch(base, max(1, graphs // 2048)).to(dev)
+            dst, src = big.edge_index[0], big.edge_index[1]
+            lo = (dst // 8) * 8 - 8
+            miss = float(((src < lo) | (src >= lo + 24)).float().mean())
+            ms, per, _, n, e, alg = _time_aggregation(dev, big)
+            out[tag + suffix] = {"out_of_window_edge_fraction": round(miss, 4), "ms_per_launch": round(ms, 4), "ms_per_launch_std": round(float(per.std()), 4),
+                                 "achieved_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "nodes": n, "edges": e}
+            del big, base
     return out
 
 
@@ -221,7 +233,7 @@ def pmc_traffic(n, e, name="agg_pmc_traffic.json"):
     (profiles/r03/agg_pmc_traffic.json, bio_agg_pmc_traffic.json: FETCH_SIZE x2 (gfx950 half-count) + WRITE_SIZE, separate
     --pmc runs of tools/agg_bench.py / tools/bio_tile_pmc.py on this same batch).  Counters cannot be read from inside this
     process, so the figure is only quoted when the recorded batch shape matches; otherwise null."""
-    for rnd in ("r03", "r02"):  # (the newest pass whose batch AND kernel this run reproduces)
+    for rnd in ("r04", "r03", "r02"):  # (the newest pass whose batch AND kernel this run reproduces)
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", rnd, name)
         try:
             rec = json.load(open(path))
@@ -232,16 +244,16 @@ def pmc_traffic(n, e, name="agg_pmc_traffic.json"):
     return None, None
 
 
-def two_plane_products_leg(dev, args, batch, steps_n):
-    """the SAME steps with PGNN_GEMM_2P=1: the one-call network's forward and backward-data products on two fp16 planes + a power-of-two
-    scale per row (three MFMA products per accumulator instead of six, csrc/linear.hip k_gemm2pw) -- opt-in at the end of
-    round 3 (every reference-fixture test passes with it; a full-suite run with it on did not fit the round's GPU budget), so it
-    is reported beside `value`, not as `value`.  Any failure of this leg is recorded, not raised."""
+def three_plane_products_leg(dev, args, batch, steps_n):
+    """the SAME steps with PGNN_GEMM_2P=0: the one-call network's forward and backward-data products on three bf16 planes (six MFMA
+    products per accumulator, csrc/linear.hip k_gemm3w: round 3's default) instead of two fp16 planes + a power-of-two scale per row
+    (three products, k_gemm2pw: the default since round 4, op-level accuracy tests in tests/test_gpu_ops.py) -- reported beside
+    `value` so that the two arithmetics stay comparable.  Any failure of this leg is recorded, not raised."""
     import os
     from pretrain_gnns_amd import ops
 
-    out = {"knob": "PGNN_GEMM_2P=1", "note": "opt-in: products on two fp16 planes + row scales; everything else as in `value`"}
-    os.environ["PGNN_GEMM_2P"] = "1"
+    out = {"knob": "PGNN_GEMM_2P=0", "note": "round 3's arithmetic: products on three bf16 planes; everything else as in `value`"}
+    os.environ["PGNN_GEMM_2P"] = "0"
     try:
         ops.load().pgnn_reload_env()
         mods = make_models(dev)
@@ -881,13 +893,16 @@ def _run():
                        "nodes_per_gpu": int(batch.x.size(0)), "edges_per_gpu": int(edges_local),
                        "parallelism": "dp%d" % world, "mean_loss": round(float(loss), 5),
                        "adam": ADAM_NOTE[args.adam], "metrics_readback": READBACK_NOTE[args.readback],
-                       "direct_grads": True},
+                       "direct_grads": True,
+                       "mlp_products": "fp32 operands as two fp16 planes under a power-of-two scale per row (22 significant bits per operand), "
+                                       "three v_mfma_f32_16x16x32_f16 per accumulator, fp32 accumulate; weight gradients on three bf16 planes "
+                                       "(24 bits); error against float64 held to the fp32-MFMA kernel's bar in tests/test_gpu_ops.py"},
             "comm": comm,
         }
         if per_step_readback is not None:
             res["per_step_readback"] = per_step_readback
         if world == 1:
-            res["two_plane_products"] = two_plane_products_leg(dev, args, batch, args.steps)
+            res["three_plane_products"] = three_plane_products_leg(dev, args, batch, args.steps)
             res["reference_loop"] = reference_loop_leg(dev, args, batch, max(args.steps // 2, 20))
             res["forward_only"] = forward_only(dev, mods, batch, max(args.steps, 20))
         if world == 1 and not args.no_loader:

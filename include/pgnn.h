@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PGNN_ABI_VERSION 7
+#define PGNN_ABI_VERSION 8
 /* uint32 words behind every `counter` argument below: the arrival tickets of a launch whose last block folds the others'
  * results (one top word + up to 32 group words: same-address atomics retire at ~50 ns each, see csrc/common.h).  Zero before
  * the first call, left zero by every call; one buffer per device serves all calls of a stream. */
@@ -292,6 +292,23 @@ int pgnn_linear_fwd_wp(const float* x, int64_t ldx, const void* wplanes, const f
 /* pgnn_linear_bwd_data_t with wtplanes = the planes of W^T [k, n] */
 int pgnn_linear_bwd_data_wp(const float* dy, int64_t lddy, const void* wtplanes, const float* relu_out, int64_t ldr, float* dx,
                             int64_t lddx, int64_t m, int64_t k, int64_t n, pgnn_stream stream);
+
+/* The same products on TWO fp16 planes per operand under a power-of-two scale per ROW (round 4; the default of the one-call
+ * networks): x = (h1 + h2) / s with s x's largest magnitude of the row in [2^13, 2^14) -- 11 + 11 significant bits, the low plane
+ * clear of fp16's subnormals for every element that matters -- needs three v_mfma_f32_16x16x32_f16 per accumulator (h1 h2, h2 h1,
+ * h1 h1) where three bf16 planes need six; scales, and the epilogue's rescale, are exact.  Error against float64 as for the
+ * fp32-MFMA kernel (tests/test_gpu_ops.py); +-inf / NaN inputs give non-finite outputs in the rows fp32 gives them.
+ * pgnn_split_weights_2p: planes [2][rows][ld] fp16 of s W, then 1 / s per row as fp32, inside pgnn_weight_planes_bytes.
+ * x_amax / dy_amax: [m] uint32 = bit patterns of max |row| of the activation operand if its producer left them (a previous
+ * product's y_amax / dx_amax), NULL = every workgroup takes the maxima of its own rows in a pass in front of its k-loop.
+ * y_amax / dx_amax: NULL, or [m] words that are ZERO before the call and receive the bit patterns of the result rows' largest
+ * magnitudes (atomic maximum over the column tiles). */
+int pgnn_split_weights_2p(const float* const* src, void* const* dst, const int64_t* rows, const int64_t* cols, const int32_t* transpose,
+                          int64_t count, pgnn_stream stream);
+int pgnn_linear_fwd_2p(const float* x, int64_t ldx, const uint32_t* x_amax, const void* wplanes2, const float* bias, float* y, int64_t ldy,
+                       int64_t m, int64_t k, int64_t n, int relu, float* colstat, uint32_t* y_amax, pgnn_stream stream);
+int pgnn_linear_bwd_data_2p(const float* dy, int64_t lddy, const uint32_t* dy_amax, const void* wtplanes2, const float* relu_out, int64_t ldr,
+                            float* dx, int64_t lddx, int64_t m, int64_t k, int64_t n, uint32_t* dx_amax, pgnn_stream stream);
 
 /* dW[N,K] = dy[M,N]^T . x[M,K] ; db[N] = column sums of dy (db may be NULL).  Split over M with a
  * deterministic second-pass reduction. */

@@ -63,6 +63,9 @@ PROTOTYPES = {
     "pgnn_split_weights": (_i, [_p, _p, _p, _p, _p, _i64, _p]),
     "pgnn_linear_fwd_wp": (_i, [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _p, _p]),
     "pgnn_linear_bwd_data_wp": (_i, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p]),
+    "pgnn_split_weights_2p": (_i, [_p, _p, _p, _p, _p, _i64, _p]),
+    "pgnn_linear_fwd_2p": (_i, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _p, _p, _p]),
+    "pgnn_linear_bwd_data_2p": (_i, [_p, _i64, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _p]),
     "pgnn_linear_bwd_data": (_i, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p]),
     "pgnn_bio_gin_stack_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "pgnn_bio_gin_stack_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _i64, _p, _sz, _p]),
@@ -122,7 +125,7 @@ PROTOTYPES = {
     "pgnn_debug_aggregate_profile": (_i, [_p, _i64]),
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class GinLayer(ctypes.Structure):

@@ -127,11 +127,14 @@ int split_weights_bump(const float* const* src, void* const* dst, const int64_t*
 // (linear.hip) the planes products on TWO fp16 planes + a power-of-two scale per row (PGNN_GEMM_2P): the split (same
 // jobs as split_weights_bump; the planes and the rows' inverse scales fit the room of three bf16 planes) and the two products
 int split_weights_2p(const float* const* src, void* const* dst, const int64_t* rows, const int64_t* cols, const int32_t* transpose,
-                     int64_t count, int64_t* const* bump, int nbump, hipStream_t stream, const EncTables* tabs = nullptr);
+                     int64_t count, int64_t* const* bump, int nbump, hipStream_t stream, const EncTables* tabs = nullptr,
+                     uint32_t* zero_ptr = nullptr, int64_t zero_words = 0);  // + a region of words the launch clears
+// x_amax / dy_amax: [m] bit patterns of the rows' largest magnitudes when the producer of the operand left them (else NULL: the
+// kernel takes them); y_amax / dx_amax: [m] zeroed words that receive the result rows' largest magnitudes (NULL: not wanted)
 int linear_fwd_wp_2p(const float* x, int64_t ldx, const void* wplanes, const float* bias, float* y, int64_t ldy, int64_t m, int64_t k,
-                     int64_t n, int relu, float* colstat, hipStream_t st);
+                     int64_t n, int relu, float* colstat, hipStream_t st, const uint32_t* x_amax = nullptr, uint32_t* y_amax = nullptr);
 int linear_bwd_data_wp_2p(const float* dy, int64_t lddy, const void* wtplanes, const float* relu_out, int64_t ldr, float* dx, int64_t lddx,
-                          int64_t m, int64_t k, int64_t n, hipStream_t st);
+                          int64_t m, int64_t k, int64_t n, hipStream_t st, const uint32_t* dy_amax = nullptr, uint32_t* dx_amax = nullptr);
 // (tile.hip) pgnn_neighbor_sum_tiled whose result is zeroed where mask[i, c] <= 0 (the ReLU between two layers, backward), when
 // the launch that runs can do it: *mask_applied says whether it did (the pipelined kernel of large batches and the untiled
 // fall-back cannot -- the caller masks in a pass of its own then)

@@ -60,23 +60,29 @@ inline bool mlp_wp(int64_t n, int64_t d_in, int64_t d_hid, int64_t d_out, int nu
   return num_layer <= kMaxPlaneLayers && pgnn_linear_wp_preferred(n, d_in, d_hid) && pgnn_linear_wp_preferred(n, d_hid, d_out) &&
          pgnn_linear_wp_preferred(n, d_out, d_hid) && pgnn_linear_wp_preferred(n, d_hid, d_in);
 }
-// PGNN_GEMM_2P=1: the stacks' products on planes run on TWO fp16 planes + a power-of-two scale per row (csrc/linear.hip, the block at
-// its end) instead of three bf16 planes: the split, the forward products and the backward-data products switch together
-inline bool two_planes() { return env_knob("PGNN_GEMM_2P", 0) != 0; }
+// The stacks' products on planes run on TWO fp16 planes + a power-of-two scale per row (csrc/linear.hip, the block at its end;
+// round 4: the default) -- PGNN_GEMM_2P=0: three bf16 planes (round 3; bit-identical to the per-layer calls' split-bf16 kernel).
+// The split, the forward products and the backward-data products switch together.  x_amax / y_amax: row maxima handed from a
+// product's epilogue to the product that consumes its result (two planes only; see pgnn_linear_fwd_2p).
+inline bool two_planes() { return env_knob("PGNN_GEMM_2P", 1) != 0; }
 inline int stack_fwd_wp(const float* x, int64_t ldx, const void* wplanes, const float* bias, float* y, int64_t ldy, int64_t m, int64_t k,
-                        int64_t n, int relu, float* colstat, pgnn_stream stream) {
-  return two_planes() ? linear_fwd_wp_2p(x, ldx, wplanes, bias, y, ldy, m, k, n, relu, colstat, (hipStream_t)stream)
+                        int64_t n, int relu, float* colstat, pgnn_stream stream, const uint32_t* x_amax = nullptr, uint32_t* y_amax = nullptr) {
+  return two_planes() ? linear_fwd_wp_2p(x, ldx, wplanes, bias, y, ldy, m, k, n, relu, colstat, (hipStream_t)stream, x_amax, y_amax)
                       : pgnn_linear_fwd_wp(x, ldx, wplanes, bias, y, ldy, m, k, n, relu, colstat, stream);
 }
 inline int stack_bwd_data_wp(const float* dy, int64_t lddy, const void* wtplanes, const float* relu_out, int64_t ldr, float* dx,
-                             int64_t lddx, int64_t m, int64_t k, int64_t n, pgnn_stream stream) {
-  return two_planes() ? linear_bwd_data_wp_2p(dy, lddy, wtplanes, relu_out, ldr, dx, lddx, m, k, n, (hipStream_t)stream)
+                             int64_t lddx, int64_t m, int64_t k, int64_t n, pgnn_stream stream, const uint32_t* dy_amax = nullptr,
+                             uint32_t* dx_amax = nullptr) {
+  return two_planes() ? linear_bwd_data_wp_2p(dy, lddy, wtplanes, relu_out, ldr, dx, lddx, m, k, n, (hipStream_t)stream, dy_amax, dx_amax)
                       : pgnn_linear_bwd_data_wp(dy, lddy, wtplanes, relu_out, ldr, dx, lddx, m, k, n, stream);
 }
+inline size_t amax_words(int64_t n) { return align_up((size_t)n * 4, 256) / 4; }  // one row-maximum vector, in words
 // planes of W1 / W2 (transpose = 0) or W1^T / W2^T (1) of every layer: p1[l], p2[l] carved from `base`
-// (bump: also increment the layers' num_batches_tracked -- a training-mode forward -- in the same launch)
+// (bump: also increment the layers' num_batches_tracked -- a training-mode forward -- in the same launch;
+//  zero_ptr / zero_words: the row-maximum words of the pass, cleared by the same launch -- two planes only)
 inline int split_mlp_weights(const pgnn_gin_layer* layers, int num_layer, int64_t d_in, int64_t d_hid, int64_t d_out, int transpose,
-                             char* base, void** p1, void** p2, hipStream_t st, bool bump = false, const EncTables* tabs = nullptr) {
+                             char* base, void** p1, void** p2, hipStream_t st, bool bump = false, const EncTables* tabs = nullptr,
+                             uint32_t* zero_ptr = nullptr, int64_t zero_words = 0) {
   const float* src[2 * kMaxPlaneLayers];
   void* dst[2 * kMaxPlaneLayers];
   int64_t rows[2 * kMaxPlaneLayers], cols[2 * kMaxPlaneLayers];
@@ -94,7 +100,7 @@ inline int split_mlp_weights(const pgnn_gin_layer* layers, int num_layer, int64_
   if (bump)
     for (int l = 0; l < num_layer; ++l)
       if (layers[l].num_batches_tracked) counters[nb++] = layers[l].num_batches_tracked;
-  return two_planes() ? split_weights_2p(src, dst, rows, cols, tr, 2 * num_layer, counters, nb, st, tabs)
+  return two_planes() ? split_weights_2p(src, dst, rows, cols, tr, 2 * num_layer, counters, nb, st, tabs, zero_ptr, zero_words)
                       : split_weights_bump(src, dst, rows, cols, tr, 2 * num_layer, counters, nb, st, tabs);
 }
 // the same increment as a launch of its own, for the calls that split nothing (small batches on the fp32-MFMA products)
@@ -294,9 +300,11 @@ size_t pgnn_chem_gin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t rows1
   // transposes) -- whichever is larger
   const size_t wt = std::max((size_t)std::min<int64_t>(num_layer, kMaxTransposed) * 2 * align_up((size_t)2 * dim * dim * 4, 256),
                              (size_t)std::min<int64_t>(num_layer, kMaxPlaneLayers) * mlp_planes_bytes(dim, 2 * dim, dim));
+  // + one row-maximum vector per layer (two-plane products: the maxima of hid / dhid from the epilogue of the product that writes them)
   return 2 * op_ws_bytes(n, dim) + sets * 5 * nd + wt + 2 * align_up((size_t)n * 4, 256) +
          2 * align_up((stack_keys(rows1, rows2) + 1) * 4, 256) + 256 + stack_group_ws(n, rows1, rows2) +
-         stack_segsum_ws(n, dim, rows1, rows2) + stack_pair_sums(dim, rows1, rows2) + 256;
+         stack_segsum_ws(n, dim, rows1, rows2) + stack_pair_sums(dim, rows1, rows2) + 256 +
+         (size_t)std::min<int64_t>(num_layer, kMaxPlaneLayers) * amax_words(n) * 4;
 }
 
 int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t rows1, const float* xemb2,
@@ -326,9 +334,15 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
   // (pgnn_chem_gin_stack_workspace_bytes does; the per-layer size of older callers does not: they keep the in-kernel split)
   const size_t opb = op_ws_bytes(n, dim);
   void *wp1[kMaxPlaneLayers], *wp2[kMaxPlaneLayers];
-  const bool wp = mlp_wp(n, dim, 2 * dim, dim, num_layer) && ws_bytes >= opb + (size_t)num_layer * mlp_planes_bytes(dim, 2 * dim, dim);
+  const size_t planes_b = (size_t)num_layer * mlp_planes_bytes(dim, 2 * dim, dim);
+  const bool wp = mlp_wp(n, dim, 2 * dim, dim, num_layer) && ws_bytes >= opb + planes_b;
+  // two planes: the first product of a layer leaves the row maxima of hid for the second (one vector per layer behind the planes,
+  // cleared by the split launch) when the workspace has the room
+  uint32_t* hid_amax = nullptr;
+  if (wp && two_planes() && ws_bytes >= opb + planes_b + (size_t)num_layer * amax_words(n) * 4)
+    hid_amax = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + opb + planes_b);
   if (wp && (rc = split_mlp_weights(layers, num_layer, dim, 2 * dim, dim, 0, static_cast<char*>(ws) + opb, wp1, wp2, (hipStream_t)stream,
-                                    training != 0)))
+                                    training != 0, nullptr, hid_amax, hid_amax ? (int64_t)num_layer * (int64_t)amax_words(n) : 0)))
     return rc;
   if (!wp && training && (rc = bump_batches_tracked(layers, num_layer, (hipStream_t)stream))) return rc;
   for (int l = 0; l < num_layer; ++l) {
@@ -351,13 +365,14 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
       rc = pgnn_chem_aggregate_fwd(yprev, dim, in_ptr, in_src, in_code, p.emb1, p.emb2, nullptr, agg, dim, n, dim, stream);
     }
     if (rc) return rc;
-    if (wp) rc = stack_fwd_wp(agg, dim, wp1[l], p.b1, hd, 2 * dim, n, dim, 2 * dim, 1, nullptr, stream);
+    uint32_t* ham = hid_amax ? hid_amax + (size_t)l * amax_words(n) : nullptr;
+    if (wp) rc = stack_fwd_wp(agg, dim, wp1[l], p.b1, hd, 2 * dim, n, dim, 2 * dim, 1, nullptr, stream, nullptr, ham);
     else rc = pgnn_linear_fwd(agg, dim, p.w1, p.b1, hd, 2 * dim, n, dim, 2 * dim, 1, stream);
     if (rc) return rc;
     if (stats_in_gemm) {
       // the BatchNorm statistics of z fall out of the second product's epilogue: no pass over z for them, one launch less
       float* blocks = static_cast<float*>(ws);  // ceil(n/16) x 2 x dim floats <= the statistics partials of op_ws_bytes
-      if (wp) rc = stack_fwd_wp(hd, 2 * dim, wp2[l], p.b2, z, dim, n, 2 * dim, dim, 0, blocks, stream);
+      if (wp) rc = stack_fwd_wp(hd, 2 * dim, wp2[l], p.b2, z, dim, n, 2 * dim, dim, 0, blocks, stream, ham);
       else rc = pgnn_linear_fwd_colstats(hd, 2 * dim, p.w2, p.b2, z, dim, n, 2 * dim, dim, 0, blocks, stream);
       if (rc) return rc;
       if ((rc = pgnn_bn_stats_fwd_blocks(blocks, p.gamma, p.beta, p.running_mean, p.running_var, p.momentum, p.eps, st, st + dim,
@@ -368,7 +383,7 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
       if (rc) return rc;
       continue;
     }
-    if (wp) rc = stack_fwd_wp(hd, 2 * dim, wp2[l], p.b2, z, dim, n, 2 * dim, dim, 0, nullptr, stream);
+    if (wp) rc = stack_fwd_wp(hd, 2 * dim, wp2[l], p.b2, z, dim, n, 2 * dim, dim, 0, nullptr, stream, ham);
     else rc = pgnn_linear_fwd(hd, 2 * dim, p.w2, p.b2, z, dim, n, 2 * dim, dim, 0, stream);
     if (rc) return rc;
     if (fuse && !last)
@@ -437,6 +452,8 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   const size_t seg_b = stack_segsum_ws(n, dim, rows1, rows2);
   char* seg_ws = cv.take<char>(seg_b);
   float* pair_sums = reinterpret_cast<float*>(cv.take<char>(stack_pair_sums(dim, rows1, rows2)));
+  // two planes: the row maxima of dhid, from the epilogue of the product that writes it to the product that reads it (cleared by the split launch)
+  uint32_t* dhid_amax = (two_planes() && num_layer <= kMaxPlaneLayers) ? cv.take<uint32_t>((size_t)num_layer * amax_words(n)) : nullptr;
 
   hipStream_t main = (hipStream_t)stream;
   Side* sd = (use_side_stream() && n <= kSideMaxRows && num_layer <= kMaxSets) ? side_for_current_device() : nullptr;
@@ -464,7 +481,9 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   // caller's stream idling behind four tiny side-stream launches.
   bool wait_fork2 = false;
   if (wp) {
-    if ((rc = split_mlp_weights(layers, num_layer, dim, 2 * dim, dim, 1, plane_base, wp1, wp2, aux))) return rc;  // (aux already waits on fork[0])
+    if ((rc = split_mlp_weights(layers, num_layer, dim, 2 * dim, dim, 1, plane_base, wp1, wp2, aux, false, nullptr, dhid_amax,
+                                dhid_amax ? (int64_t)num_layer * (int64_t)amax_words(n) : 0)))  // (aux already waits on fork[0])
+      return rc;
     if (sd) {
       PGNN_HIP(hipEventRecord(sd->fork[2], aux));
       wait_fork2 = true;
@@ -510,8 +529,9 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
       wait_fork2 = false;
     }
     if (wp) {
-      if ((rc = stack_bwd_data_wp(dz[b], dim, wp2[l], hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main))) return rc;
-      if ((rc = stack_bwd_data_wp(dhid[b], 2 * dim, wp1[l], nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main))) return rc;
+      uint32_t* dam = dhid_amax ? dhid_amax + (size_t)l * amax_words(n) : nullptr;
+      if ((rc = stack_bwd_data_wp(dz[b], dim, wp2[l], hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main, nullptr, dam))) return rc;
+      if ((rc = stack_bwd_data_wp(dhid[b], 2 * dim, wp1[l], nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main, dam))) return rc;
     } else if (tr && q < ntr) {
       if ((rc = pgnn_linear_bwd_data_t(dz[b], dim, w2t[q], hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main))) return rc;
       if ((rc = pgnn_linear_bwd_data_t(dhid[b], 2 * dim, w1t[q], nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main))) return rc;

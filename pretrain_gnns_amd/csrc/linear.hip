@@ -49,6 +49,8 @@ struct GemmArgs {
   unsigned long long* dbg;   // k_gemm3w<DBG>: phase cycle totals
   const unsigned short* Bp;  // k_gemm3w: B as three pre-split bf16 planes [3][rows][ldbp], zero beyond K up to ldbp
   int64_t ldbp, bplane;      //           row pitch and plane pitch in bf16 elements
+  const uint32_t* a_amax;    // k_gemm2pw, optional: [M] bit patterns of max |A[m, :]| (from the producer of A); NULL = taken in the kernel
+  uint32_t* c_amax;          // k_gemm2pw, optional: [M] words, zero before the launch: receives max |C[m, :]| (atomic max of the tiles)
 };
 
 enum { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_MASK = 2 };
@@ -1619,23 +1621,41 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_f16(float a, float b) {  // round to nearest even, a in the low half
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, f16x2));
 }
+// the low plane's share of (a, b).  Clamped to fp16's range: a - h is at most half an fp16 ulp for every finite h, so the clamp only
+// catches h = +-inf, where a - h is NaN -- and the product would turn an fp32 +-inf into NaN.  (fminf / fmaxf drop a NaN operand.)
+__device__ __forceinline__ float low_part(float a, _Float16 h) { return fminf(fmaxf(a - (float)h, -65504.f), 65504.f); }
 __device__ __forceinline__ void split2(float a, float b, uint32_t& h, uint32_t& l) {
   const f16x2 hh = __builtin_convertvector(f32x2{a, b}, f16x2);
   h = __builtin_bit_cast(uint32_t, hh);
-  l = pack_f16(a - (float)hh[0], b - (float)hh[1]);
+  l = pack_f16(low_part(a, hh[0]), low_part(b, hh[1]));
 }
-// 2^(13 - floor(log2(amax))) and its inverse from amax's exponent field (zero / tiny rows: 1)
+// s = 2^(13 - floor(log2(amax))) and its inverse from amax's exponent field: s amax lands in [2^13, 2^14).  Rows below 2^-113
+// (exponent field <= 13: the scale would leave fp32's range) take 2^127, whose inverse is the subnormal 2^-127 -- they keep
+// 11 + 11 bits down to fp32's smallest subnormals; an all-zero row is one of them.  Exponent field 255 (the row holds an inf, or its
+// maximum was poisoned by a NaN): unscaled, the non-finite value propagates.
 __device__ __forceinline__ void pow2_scales(float amax, float& s, float& inv) {
   const unsigned e = (__float_as_uint(amax) >> 23) & 0xffu;
-  const bool ok = e > 13u && e < 255u;
-  s = ok ? __uint_as_float((267u - e) << 23) : 1.f;
-  inv = ok ? __uint_as_float((e - 13u) << 23) : 1.f;
+  if (e == 255u) {
+    s = 1.f;
+    inv = 1.f;
+  } else if (e <= 13u) {
+    s = __uint_as_float(0x7F000000u);    // 2^127
+    inv = __uint_as_float(0x00400000u);  // 2^-127
+  } else {
+    s = __uint_as_float((267u - e) << 23);
+    inv = __uint_as_float((e - 13u) << 23);
+  }
 }
 
 // one wave per output row (k_split_jobs' jobs: dst row r = src row r, or src column r when transposed): the row's maximum, then
-// the two planes of s W (zero from `cols` to `ld`) and 1/s behind the planes
-__global__ void __launch_bounds__(256) k_split2p_jobs(SplitJobs jobs) {
+// the two planes of s W (zero from `cols` to `ld`) and 1/s behind the planes.  Rows that are contiguous in the source (the forward's
+// planes: this launch opens the forward pass, on the caller's stream) are read ONCE, as float4, and held in registers (up to
+// 1 024 columns); the transposed jobs (backward, on the side stream, beside the top layer's BatchNorm backward) re-read.
+// zero_words: a region this launch clears (the row-maximum words the pass's products accumulate into)
+__global__ void __launch_bounds__(256) k_split2p_jobs(SplitJobs jobs, uint32_t* __restrict__ zero_ptr, int64_t zero_words) {
   if (blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < jobs.nbump) *jobs.bump[threadIdx.x] += 1;
+  for (int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < zero_words; i += (int64_t)gridDim.x * gridDim.y * 256)
+    zero_ptr[i] = 0u;
   if (jobs.tabs.count && blockIdx.y == 0) {
     const int dim = jobs.tabs.dim, k = jobs.tabs.k, per = (k + 1) * dim;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < jobs.tabs.count * per; i += gridDim.x * 256) {
@@ -1651,17 +1671,48 @@ __global__ void __launch_bounds__(256) k_split2p_jobs(SplitJobs jobs) {
   const int64_t plane = (int64_t)rows * ld;
   float* __restrict__ binv = reinterpret_cast<float*>(dst + 2 * plane);
   const int lane = threadIdx.x & 63;
+  if (!tr && cols % 4 == 0 && cols <= 1024) {
+    const int c4n = cols >> 2, ld4 = ld >> 2;
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
+      const float4* __restrict__ row = reinterpret_cast<const float4*>(src + (int64_t)r * cols);
+      float4 v[4];
+      float mx = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c4 = lane + 64 * u;
+        v[u] = c4 < c4n ? row[c4] : f4_zero();
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w))));
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+      float sc, inv;
+      pow2_scales(mx, sc, inv);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c4 = lane + 64 * u;
+        if (c4 < ld4) {  // (zero from cols to ld: v[u] is zero there)
+          uint32_t h0, l0, h1, l1;
+          split2(v[u].x * sc, v[u].y * sc, h0, l0);
+          split2(v[u].z * sc, v[u].w * sc, h1, l1);
+          *reinterpret_cast<uint2*>(dst + (int64_t)r * ld + 4 * c4) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(dst + plane + (int64_t)r * ld + 4 * c4) = make_uint2(l0, l1);
+        }
+      }
+      if (lane == 0) binv[r] = inv;
+    }
+    return;
+  }
   for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
     float mx = 0.f;
     for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, fabsf(tr ? src[(int64_t)c * rows + r] : src[(int64_t)r * cols + c]));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    float s, inv;
-    pow2_scales(mx, s, inv);
+    float sc, inv;
+    pow2_scales(mx, sc, inv);
     for (int c = lane; c < ld; c += 64) {
-      const float v = c < cols ? (tr ? src[(int64_t)c * rows + r] : src[(int64_t)r * cols + c]) * s : 0.f;
+      const float v = c < cols ? (tr ? src[(int64_t)c * rows + r] : src[(int64_t)r * cols + c]) * sc : 0.f;
       const _Float16 h = (_Float16)v;
-      const _Float16 l = (_Float16)(v - (float)h);
+      const _Float16 l = (_Float16)low_part(v, h);
       dst[(int64_t)r * ld + c] = __builtin_bit_cast(unsigned short, h);
       dst[plane + (int64_t)r * ld + c] = __builtin_bit_cast(unsigned short, l);
     }
@@ -1691,9 +1742,12 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
   const int nk = (p.K + BK - 1) / BK;
   const float* __restrict__ b_inv = reinterpret_cast<const float*>(p.Bp + 2 * p.bplane);
 
-  // the maxima of this tile's rows of A: thread t takes row t / TPR, float4 columns t % TPR, + TPR, ...; eight loads in flight per
-  // round, all of them older than the first DMA
-  {
+  // the maxima of this tile's rows of A: from the producer of A when it left them (a_amax: the previous product's epilogue), else
+  // thread t takes row t / TPR, float4 columns t % TPR, + TPR, ...; eight loads in flight per round, all of them older than the
+  // first DMA (that pass costs 1.7 / 2.3 us of a 17 us product at K = 300 / 600: every workgroup of a row panel repeats it)
+  if (p.a_amax) {
+    if (tid < BM) rowmax[tid] = __uint_as_float(p.a_amax[min(m0 + tid, p.M - 1)]);
+  } else {
     float mx = 0.f;
     const int r = min(m0 + tid / TPR, p.M - 1), k4 = p.K / 4;
     const float4* row = reinterpret_cast<const float4*>(p.A + (int64_t)r * p.lda);
@@ -1882,6 +1936,9 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
   }
   // ---- epilogue (k_gemm3w's, behind the exact rescale): lane holds C[m0 + wm0 + 16 i + fr][n0 + wn0 + 16 j + 4 fk + 0..3]
   float* C = p.C;
+  float cmax[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) cmax[i] = 0.f;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int n = n0 + wn0 + j * 16 + fk * 4;
@@ -1923,6 +1980,23 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
         if (!(k4.w > 0.f)) v.w = 0.f;
       }
       if (m < p.M && n < p.N) *reinterpret_cast<float4*>(C + (int64_t)m * p.ldc + n) = v;
+      if (p.c_amax) {  // (uniform) the largest magnitude this lane wrote to row i's block
+        const float lm = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        if (n < p.N) cmax[i] = fmaxf(cmax[i], lm);
+      }
+    }
+  }
+  // row maxima of C for the product that takes it as its A operand: the four lane groups (columns 4 fk ..) of a row fold by two
+  // cross-lane maxima, the column tiles and the waves side by side by an atomic maximum on the bit patterns (non-negative floats
+  // order like unsigned integers; a NaN ends up largest, and the consumer then runs that row unscaled: the NaN propagates)
+  if (p.c_amax) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      float v = cmax[i];
+      v = fmaxf(v, __shfl_xor(v, 16));
+      v = fmaxf(v, __shfl_xor(v, 32));
+      const int m = m0 + wm0 + i * 16 + fr;
+      if (fk == 0 && m < p.M) atomicMax(p.c_amax + m, __float_as_uint(v));
     }
   }
 }
@@ -1948,11 +2022,13 @@ int launch_gemm2pw(const GemmArgs& p, hipStream_t st) {
 }  // namespace
 
 int split_weights_2p(const float* const* src, void* const* dst, const int64_t* rows, const int64_t* cols, const int32_t* transpose,
-                     int64_t count, int64_t* const* bump, int nbump, hipStream_t stream, const EncTables* tabs) {
+                     int64_t count, int64_t* const* bump, int nbump, hipStream_t stream, const EncTables* tabs, uint32_t* zero_ptr,
+                     int64_t zero_words) {
   PGNN_REQUIRE(count >= 0 && count <= 32 && nbump >= 0 && nbump <= 16, "split_weights: at most 32 matrices (and 16 counters) per call");
   PGNN_REQUIRE(!tabs || (tabs->count >= 0 && tabs->count <= 16 && tabs->dim > 0 && tabs->k > 0), "split_weights: at most 16 encoder tables");
+  PGNN_REQUIRE(zero_words == 0 || zero_ptr, "split_weights: zero_ptr");
   const bool with_tabs = tabs && tabs->count > 0;
-  if (count == 0 && !with_tabs) return PGNN_OK;
+  if (count == 0 && !with_tabs && zero_words == 0) return PGNN_OK;
   SplitJobs jobs{};
   if (with_tabs) jobs.tabs = *tabs;
   for (int j = 0; j < nbump; ++j) jobs.bump[j] = reinterpret_cast<long long*>(bump[j]);
@@ -1967,33 +2043,52 @@ int split_weights_2p(const float* const* src, void* const* dst, const int64_t* r
     most = std::max(most, ceil_div(jobs.rows[j], 4));
   }
   if (with_tabs) most = std::max<int64_t>(most, std::min<int64_t>(ceil_div((int64_t)tabs->count * (tabs->k + 1) * tabs->dim, 256), 64));
-  hipLaunchKernelGGL(k_split2p_jobs, dim3((int)std::min<int64_t>(most, 4096), (int)std::max<int64_t>(count, 1)), dim3(256), 0, stream, jobs);
+  hipLaunchKernelGGL(k_split2p_jobs, dim3((int)std::min<int64_t>(most, 4096), (int)std::max<int64_t>(count, 1)), dim3(256), 0, stream, jobs,
+                     zero_ptr, zero_words);
   return check_launch("split_weights_2p");
 }
 
 int linear_fwd_wp_2p(const float* x, int64_t ldx, const void* wplanes, const float* bias, float* y, int64_t ldy, int64_t m, int64_t k,
-                     int64_t n, int relu, float* colstat, hipStream_t st) {
+                     int64_t n, int relu, float* colstat, hipStream_t st, const uint32_t* x_amax, uint32_t* y_amax) {
   PGNN_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && wplanes,
-               "linear_fwd_wp_2p: K, N and the leading dimensions must be multiples of 4");
+               "linear_fwd_2p: K, N and the leading dimensions must be multiples of 4");
   GemmArgs p{};
   p.nxcd = num_xcd();
   p.A = x; p.lda = ldx; p.C = y; p.ldc = ldy;
   p.Bp = static_cast<const unsigned short*>(wplanes); p.ldbp = ceil_div(k, 32) * 32; p.bplane = n * p.ldbp;
   p.M = (int)m; p.N = (int)n; p.K = (int)k; p.bias = bias; p.relu = relu; p.kchunk = (int)k; p.split_stride = 0;
-  p.colstat = colstat;
+  p.colstat = colstat; p.a_amax = x_amax; p.c_amax = y_amax;
   return launch_gemm2pw<EPI_BIAS>(p, st);
 }
 
 int linear_bwd_data_wp_2p(const float* dy, int64_t lddy, const void* wtplanes, const float* relu_out, int64_t ldr, float* dx, int64_t lddx,
-                          int64_t m, int64_t k, int64_t n, hipStream_t st) {
+                          int64_t m, int64_t k, int64_t n, hipStream_t st, const uint32_t* dy_amax, uint32_t* dx_amax) {
   PGNN_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && wtplanes,
-               "linear_bwd_data_wp_2p: K, N and the leading dimensions must be multiples of 4");
+               "linear_bwd_data_2p: K, N and the leading dimensions must be multiples of 4");
   GemmArgs p{};
   p.nxcd = num_xcd();
   p.A = dy; p.lda = lddy; p.C = dx; p.ldc = lddx;
   p.Bp = static_cast<const unsigned short*>(wtplanes); p.ldbp = ceil_div(n, 32) * 32; p.bplane = k * p.ldbp;
   p.M = (int)m; p.N = (int)k; p.K = (int)n; p.mask = relu_out; p.ldmask = ldr; p.kchunk = (int)n; p.split_stride = 0;
+  p.a_amax = dy_amax; p.c_amax = dx_amax;
   return relu_out ? launch_gemm2pw<EPI_MASK>(p, st) : launch_gemm2pw<EPI_PLAIN>(p, st);
 }
 
 }  // namespace pgnn
+
+extern "C" {
+
+int pgnn_split_weights_2p(const float* const* src, void* const* dst, const int64_t* rows, const int64_t* cols, const int32_t* transpose,
+                          int64_t count, pgnn_stream stream) {
+  return pgnn::split_weights_2p(src, dst, rows, cols, transpose, count, nullptr, 0, (hipStream_t)stream, nullptr, nullptr, 0);
+}
+int pgnn_linear_fwd_2p(const float* x, int64_t ldx, const uint32_t* x_amax, const void* wplanes2, const float* bias, float* y, int64_t ldy,
+                       int64_t m, int64_t k, int64_t n, int relu, float* colstat, uint32_t* y_amax, pgnn_stream stream) {
+  return pgnn::linear_fwd_wp_2p(x, ldx, wplanes2, bias, y, ldy, m, k, n, relu, colstat, (hipStream_t)stream, x_amax, y_amax);
+}
+int pgnn_linear_bwd_data_2p(const float* dy, int64_t lddy, const uint32_t* dy_amax, const void* wtplanes2, const float* relu_out, int64_t ldr,
+                            float* dx, int64_t lddx, int64_t m, int64_t k, int64_t n, uint32_t* dx_amax, pgnn_stream stream) {
+  return pgnn::linear_bwd_data_wp_2p(dy, lddy, wtplanes2, relu_out, ldr, dx, lddx, m, k, n, (hipStream_t)stream, dy_amax, dx_amax);
+}
+
+}  // extern "C"

@@ -41,9 +41,30 @@ class ResidentDataset:
     ``slices['edge_attr']``.
     """
 
-    def __init__(self, x, edge_index, edge_attr, node_slice, edge_slice, device="cuda", center_node_idx=None):
+    def __init__(self, x, edge_index, edge_attr, node_slice, edge_slice, device="cuda", center_node_idx=None, relabel=False):
+        """relabel=True: the nodes of every graph are renumbered ONCE, here, in Cuthill-McKee order (``relabel.bandwidth_order``:
+        neighbours within a couple of rows of each other) -- the aggregation kernel then finds every source row in its LDS window
+        whatever order the dataset came in (SMILES parse order: 6 % of the edges outside it; an arbitrary order: a third).  Only
+        labels change: ``edge_index`` keeps its column order, so every sum runs in the reference's order and node-level results are
+        those of the original order, permuted (``old_of_new``: row j here is original row ``old_of_new[j]``).  Masked atoms,
+        centre nodes and pooling act on whole graphs / on rows drawn after the renumbering, so the training loops need nothing
+        else; explicit ``masked_atom_indices`` are positions in THIS order (map original positions through ``new_of_old``)."""
         node_slice = torch.as_tensor(node_slice, dtype=torch.int64).cpu()
         edge_slice = torch.as_tensor(edge_slice, dtype=torch.int64).cpu()
+        self.new_of_old = self.old_of_new = None
+        if relabel:
+            from . import relabel as _relabel
+            ns_h, es_h = node_slice.numpy(), edge_slice.numpy()
+            ei_h = edge_index.cpu().numpy()
+            new_local = _relabel.bandwidth_order(ei_h, ns_h, es_h)           # [sum n]: new graph-local label of every node
+            old_of_new = _relabel.apply_order(new_local, ns_h)               # [sum n]: global original row of every new row
+            e_graph = np.repeat(np.arange(ns_h.size - 1), np.diff(es_h))
+            edge_index = torch.from_numpy(new_local[ei_h + ns_h[e_graph]])   # same columns, new labels
+            x = x.cpu()[torch.from_numpy(old_of_new)]
+            if center_node_idx is not None:
+                c = np.asarray(torch.as_tensor(center_node_idx).cpu(), dtype=np.int64).reshape(-1)
+                center_node_idx = torch.from_numpy(new_local[ns_h[:-1] + c])
+            self.new_of_old, self.old_of_new = new_local, old_of_new
         if node_slice.numel() != edge_slice.numel() or node_slice.numel() < 2:
             raise ValueError("node_slice and edge_slice must both be [G+1]")
         if int(node_slice[-1]) != x.size(0) or int(edge_slice[-1]) != edge_index.size(1) or edge_attr.size(0) != edge_index.size(1):
@@ -71,7 +92,7 @@ class ResidentDataset:
         return self.num_graphs
 
     @classmethod
-    def from_graphs(cls, graphs, device="cuda"):
+    def from_graphs(cls, graphs, device="cuda", relabel=False):
         """from a list of per-graph ``Data`` objects (x, edge_index, edge_attr)"""
         ns = np.cumsum([0] + [g.x.size(0) for g in graphs])
         es = np.cumsum([0] + [g.edge_index.size(1) for g in graphs])
@@ -79,14 +100,28 @@ class ResidentDataset:
         if all(getattr(g, "center_node_idx", None) is not None for g in graphs):
             center = torch.cat([g.center_node_idx.view(-1)[:1] for g in graphs])
         return cls(torch.cat([g.x for g in graphs], 0), torch.cat([g.edge_index for g in graphs], 1),
-                   torch.cat([g.edge_attr for g in graphs], 0), ns, es, device, center_node_idx=center)
+                   torch.cat([g.edge_attr for g in graphs], 0), ns, es, device, center_node_idx=center, relabel=relabel)
 
     @classmethod
-    def from_inmemory(cls, data, slices, device="cuda"):
+    def from_inmemory(cls, data, slices, device="cuda", relabel=False):
         """from the ``(data, slices)`` pair of a torch_geometric InMemoryDataset processed file
         (what ``torch.load(processed_paths[0])`` returns in chem/loader.py / bio/loader.py)"""
         return cls(data.x, data.edge_index, data.edge_attr, slices["x"], slices["edge_attr"], device,
-                   center_node_idx=getattr(data, "center_node_idx", None))
+                   center_node_idx=getattr(data, "center_node_idx", None), relabel=relabel)
+
+    def batch_rows_in_original_order(self, graph_ids):
+        """for a batch collated from ``graph_ids``: ``perm`` [n] with ``row_of_this_batch[j]`` = row ``perm[j]`` of the batch the
+        ORIGINAL (not renumbered) dataset would have collated from the same ids -- identity without relabel.  (Checks and
+        callers that hold node positions in the dataset's original numbering.)"""
+        ids = np.asarray(graph_ids, dtype=np.int64).reshape(-1)
+        ns = np.concatenate([[0], np.cumsum(self._nodes)])
+        starts = np.concatenate([[0], np.cumsum(self._nodes[ids])])
+        out = np.empty(int(starts[-1]), dtype=np.int64)
+        for b, g in enumerate(ids):
+            lo, hi = ns[g], ns[g + 1]
+            local = np.arange(hi - lo) if self.old_of_new is None else self.old_of_new[lo:hi] - lo
+            out[starts[b]:starts[b + 1]] = starts[b] + local
+        return out
 
     # ------------------------------------------------------------------ batching
     def _ids(self, graph_ids, ids_device=None):

@@ -21,3 +21,15 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _reload_library_env_after_the_test():
+    """a test that flips a PGNN_* knob restores os.environ through monkeypatch; the library caches the values per call site, so it
+    is told to look again AFTER monkeypatch's teardown (this fixture is set up first, hence torn down last) -- also when the test
+    failed half way, so that one failure does not cascade into the tests behind it"""
+    yield
+    mod = sys.modules.get("pretrain_gnns_amd._lib")
+    lib = getattr(mod, "_lib", None) if mod is not None else None
+    if lib is not None:
+        lib.pgnn_reload_env()

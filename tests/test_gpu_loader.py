@@ -356,3 +356,86 @@ def test_from_inmemory_dataset_layout():
     _same(out, hostdata.collate([graphs[i] for i in ids]))
     with pytest.raises(ValueError):
         resident.ResidentDataset(data.x, data.edge_index, data.edge_attr, ns[:-1], es, DEV)
+
+
+@pytest.mark.parametrize("order", ["smiles", "permuted"])
+def test_relabelled_dataset_gives_the_same_sums_in_permuted_rows(order):
+    """ResidentDataset(relabel=True) (data/relabel.py): the loader renumbers every graph's atoms once so that
+    the aggregation kernel finds its source rows in LDS; only labels change, edge_index keeps its column order, so the GIN
+    aggregation of chem/model.py:37-52 -- forward instance (CSR by destination) AND transposed instance (CSR by source, the
+    backward's) -- gives BIT-identical rows, permuted: equal to the kernel on the dataset as fed, and equal to the oracle's
+    sequential index_add_ on the dataset as fed.  The renumbered batch leaves (next to) no edge outside the kernel's window."""
+    from oracle import chem as ochem
+    from pretrain_gnns_amd import ops
+    from pretrain_gnns_amd.data import relabel
+
+    rng = np.random.default_rng(11)
+    make = synthetic.zinc_like_graph_smiles if order == "smiles" else (lambda r: synthetic.zinc_like_graph(r, permute=True))
+    graphs = [make(rng) for _ in range(300)]
+    ids = rng.permutation(300)[:257]
+    fed = resident.ResidentDataset.from_graphs(graphs, DEV)
+    ren = resident.ResidentDataset.from_graphs(graphs, DEV, relabel=True)
+    b0, b1 = fed.collate(ids), ren.collate(ids)
+    perm = torch.from_numpy(ren.batch_rows_in_original_order(ids)).to(DEV)  # row j of b1 = row perm[j] of b0
+    assert torch.equal(b1.x, b0.x[perm]) and torch.equal(b1.batch, b0.batch[perm]) and torch.equal(b1.edge_attr, b0.edge_attr)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(perm.numel(), device=DEV)
+    assert torch.equal(b1.edge_index, inv[b0.edge_index])  # the same edges in the same columns, new labels
+
+    def miss(b):
+        lo = (b.edge_index[0] // 8) * 8 - 8
+        return float(((b.edge_index[1] < lo) | (b.edge_index[1] >= lo + 24)).float().mean())
+    assert miss(b1) < 0.003 < miss(b0)
+    n = b0.x.size(0)
+    torch.manual_seed(0)
+    conv = ochem.GINConv(300)
+    x0 = torch.randn(n, 300)
+    want = conv.aggregate(x0, b0.edge_index.cpu(), b0.edge_attr.cpu()).detach()  # the oracle, on the batch as fed
+    e1, e2 = conv.edge_embedding1.weight.detach().to(DEV), conv.edge_embedding2.weight.detach().to(DEV)
+    x0 = x0.to(DEV)
+    g0 = ops.build_chem_graph(b0.edge_index, b0.edge_attr, n)
+    g1 = ops.build_chem_graph(b1.edge_index, b1.edge_attr, n)
+    y0 = ops.ChemAggregate.apply(x0, e1, e2, g0)
+    y1 = ops.ChemAggregate.apply(x0[perm].contiguous(), e1, e2, g1)
+    assert torch.equal(y0.cpu(), want)
+    assert torch.equal(y1, y0[perm])
+    # the transposed instance (what the backward runs: sums over OUT-edges, self row last)
+    lib, sp = ops.load(), ops.stream_ptr()
+    t0, t1 = torch.empty(n, 300, device=DEV), torch.empty(n, 300, device=DEV)
+    x1 = x0[perm].contiguous()
+    ops.check(lib.pgnn_neighbor_sum(x0.data_ptr(), 300, g0.out_ptr.data_ptr(), g0.out_dst.data_ptr(), None, t0.data_ptr(), 300, n, 300, sp), "nsum")
+    ops.check(lib.pgnn_neighbor_sum(x1.data_ptr(), 300, g1.out_ptr.data_ptr(), g1.out_dst.data_ptr(), None, t1.data_ptr(), 300, n, 300, sp), "nsum")
+    assert torch.equal(t1, t0[perm])
+
+
+def test_relabelled_dataset_drives_the_masking_step():
+    """the masking train step on a renumbered dataset: MaskAtom draws, the head's gather and the loss act on rows of the
+    renumbered batch -- the same graphs, the same number of masked atoms per graph, finite loss, accuracy in [0, 1]; and with the
+    SAME atoms masked (explicit indices mapped through the renumbering) the node embeddings are the as-fed ones, permuted, to
+    fp32 rounding (BatchNorm's column sums meet the rows in another order)"""
+    from pretrain_gnns_amd.chem import model as hmodel
+
+    rng = np.random.default_rng(3)
+    graphs = [synthetic.zinc_like_graph_smiles(rng) for _ in range(96)]
+    fed = resident.ResidentDataset.from_graphs(graphs, DEV)
+    ren = resident.ResidentDataset.from_graphs(graphs, DEV, relabel=True)
+    ids = np.arange(96)
+    b0 = fed.collate(ids, mask_rate=0.15, seed=4)
+    perm = torch.from_numpy(ren.batch_rows_in_original_order(ids)).to(DEV)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(perm.numel(), device=DEV)
+    b1 = ren.collate(ids, masked_atom_indices=inv[b0.masked_atom_indices])
+    assert torch.equal(b1.x, b0.x[perm]) and torch.equal(b1.mask_node_label, b0.mask_node_label)
+    torch.manual_seed(0)
+    net = hmodel.GNN(5, 300).to(DEV).eval()
+    with torch.no_grad():
+        h0 = net(b0.x, b0.edge_index, b0.edge_attr)
+        h1 = net(b1.x, b1.edge_index, b1.edge_attr)
+    assert torch.equal(h1, h0[perm])  # eval mode: no batch statistics, every row is a function of its own neighbourhood
+    net.train()
+    h0 = net(b0.x, b0.edge_index, b0.edge_attr)
+    h1 = net(b1.x, b1.edge_index, b1.edge_attr)
+    torch.testing.assert_close(h1, h0[perm], rtol=1e-4, atol=1e-4)
+    b2 = ren.collate(ids, mask_rate=0.15, seed=4)
+    assert b2.masked_atom_indices.numel() == b0.masked_atom_indices.numel()
+    assert torch.equal(torch.bincount(b2.batch[b2.masked_atom_indices], minlength=96), torch.bincount(b0.batch[b0.masked_atom_indices], minlength=96))

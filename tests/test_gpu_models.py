@@ -627,6 +627,9 @@ def test_one_call_network_equals_per_layer_path(graphs, layers, training, monkey
     # split-bf16 kernel (from 160 tiles; the 1500-graph case); below, the per-layer calls run the fp32-MFMA kernel, so the planes
     # are held off there -- test_one_call_network_on_weight_planes_below_the_split_threshold holds that pairing to fp32 rounding
     monkeypatch.setenv("PGNN_GEMM_WP_MIN_TILES", "160")
+    # ... on THREE bf16 planes: the default since round 4, two fp16 planes + row scales, is a different (equally accurate) arithmetic
+    # -- test_one_call_network_on_two_planes_against_the_per_layer_path holds that pairing to fp32 rounding
+    monkeypatch.setenv("PGNN_GEMM_2P", "0")
     ops.load().pgnn_reload_env()
     _, a = _pair(ochem.GNN, hchem.GNN, layers, 300, seed=5)
     b = copy.deepcopy(a)
@@ -659,14 +662,17 @@ def test_one_call_network_equals_per_layer_path(graphs, layers, training, monkey
     ops.load().pgnn_reload_env()
 
 
-@pytest.mark.parametrize("graphs", [64, 90])
-def test_one_call_network_on_weight_planes_below_the_split_threshold(graphs, monkeypatch):
+@pytest.mark.parametrize("graphs,two_planes", [(64, "0"), (90, "0"), (64, "1"), (90, "1"), (256, "1"), (1500, "1")])
+def test_one_call_network_on_weight_planes_below_the_split_threshold(graphs, two_planes, monkeypatch):
     """between 48 and 160 tiles (~1 500 .. 2 600 rows) the one-call network multiplies on weight planes (split-bf16 arithmetic)
     while the per-layer calls still take the fp32-MFMA kernel: equal to fp32 rounding carried through five BatchNorm'ed layers,
-    not bit for bit"""
+    not bit for bit.  two_planes = "1" (the default since round 4, at every size where the network runs on planes): the one-call
+    network's products on two fp16 planes + row scales against the per-layer calls' fp32-MFMA / split-bf16 kernels, same bar."""
     import copy
     from pretrain_gnns_amd import ops
     hchem, _ = _hip()
+    monkeypatch.setenv("PGNN_GEMM_2P", two_planes)
+    ops.load().pgnn_reload_env()
     _, a = _pair(ochem.GNN, hchem.GNN, 5, 300, seed=5)
     b = copy.deepcopy(a)
     a.train(), b.train()

@@ -540,6 +540,191 @@ def test_products_on_weight_planes(m, k, n, monkeypatch):
     assert errd.max().item() < 2e-6
 
 
+# ----------------------------------------------------------------------------- products on two fp16 planes + row scales (round 4)
+def _weight_planes_2p(lib, sp, mats, transpose):
+    """pgnn_split_weights_2p on a list of fp32 matrices -> list of (int16 planes [2, rows, ld], float32 inverse scales [rows]) views
+    of one byte buffer of pgnn_weight_planes_bytes each (NaN-patterned first: everything the products read must be written)"""
+    import ctypes
+    cnt = len(mats)
+    bufs, views = [], []
+    for w, tr in zip(mats, transpose):
+        r, c = (w.size(1), w.size(0)) if tr else (w.size(0), w.size(1))
+        ld = (c + 31) // 32 * 32
+        nbytes = int(lib.pgnn_weight_planes_bytes(r, c))
+        assert nbytes >= 2 * r * ld * 2 + 4 * r
+        buf = torch.full((nbytes // 2,), 0x7e00, dtype=torch.int16, device=DEV)
+        bufs.append(buf)
+        views.append((buf[: 2 * r * ld].view(2, r, ld), buf[2 * r * ld: 2 * r * ld + 2 * r].view(torch.float32)))
+    arr = lambda vals, ty: (ty * cnt)(*vals)
+    _ops().check(lib.pgnn_split_weights_2p(arr([w.data_ptr() for w in mats], ctypes.c_void_p), arr([b.data_ptr() for b in bufs], ctypes.c_void_p),
+                                          arr([w.size(0) for w in mats], ctypes.c_int64), arr([w.size(1) for w in mats], ctypes.c_int64),
+                                          arr([int(t) for t in transpose], ctypes.c_int32), cnt, sp), "split 2p")
+    return bufs, views
+
+
+def _log_two_plane(rec):
+    import json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "two_plane_accuracy.jsonl"), "a") as f:
+        f.write(json.dumps(rec) + "\n")
+
+
+@pytest.mark.parametrize("rows,cols", [(600, 300), (300, 600), (7, 100), (119, 300), (33, 32), (5, 1028)])
+def test_split_weights_2p_planes_and_scales(rows, cols):
+    """pgnn_split_weights_2p: h1 + h2 = s W to 2^-22 of the row's largest magnitude (s W in [2^13, 2^14) there), s a power of two
+    whose inverse sits behind the planes, zero padding from cols to ld; plain and transposed; an all-zero row, a row of 1e-30s, a
+    row spanning twelve decades and a row of fp32 subnormals among ordinary weight rows"""
+    ops = _ops()
+    lib, sp = ops.load(), ops.stream_ptr()
+    torch.manual_seed(rows * 7 + cols)
+    w = torch.randn(rows, cols) * 0.05
+    w[0] = 0.0
+    if rows > 3:
+        w[1] = torch.randn(cols) * 1e-30
+        w[2] = torch.randn(cols) * torch.logspace(-6, 6, cols)
+        w[3] = torch.randn(cols) * 1e-41
+    w = w.to(DEV)
+    _, views = _weight_planes_2p(lib, sp, [w, w], [False, True])
+    for (planes, inv), ref in zip(views, (w, w.t().contiguous())):
+        r, c = ref.shape
+        ld = planes.size(2)
+        hl = planes.view(torch.float16).double()
+        assert bool((hl[:, :, c:] == 0).all())  # padding
+        amax = ref.abs().max(dim=1).values.double()
+        inv64 = inv.double()
+        m, e = torch.frexp(inv)
+        assert bool((m == 0.5).all())  # powers of two
+        scaled = amax / inv64
+        ok = (amax >= 2.0 ** -113)
+        assert bool(((scaled[ok] >= 2.0 ** 13) & (scaled[ok] < 2.0 ** 14)).all())
+        assert bool((inv[~ok] == 2.0 ** -127).all())
+        got = (hl[0, :, :c] + hl[1, :, :c]) * inv64[:, None]
+        err = (got - ref.double()).abs()
+        # (the largest entry: h1 in [2^13, 2^14) has ulp 8, the residual |r| <= 4 goes to fp16 with 11 bits: 2^-22 of the maximum; a
+        # row of fp32 subnormals keeps fp32's own spacing)
+        bound = torch.clamp(amax[:, None] * 2.0 ** -21, min=2.0 ** -149)
+        assert bool((err <= bound).all()), float((err / bound).max())
+
+
+_ROW_CASES = ("six_decades", "zero_rows", "outlier_rows", "gradient_rows", "subnormal_rows", "mixed_scales")
+
+
+def _adversarial_rows(case, m, k):
+    """activation operands for the two-plane products: what a per-row scale has to survive"""
+    g = torch.Generator().manual_seed(m * 31 + k)
+    x = torch.randn(m, k, generator=g)
+    if case == "six_decades":
+        x = x * torch.logspace(-3, 3, k)
+    elif case == "zero_rows":
+        x[::3] = 0.0
+    elif case == "outlier_rows":  # a row whose largest entry is 2^30 times its median
+        x[:, 0] *= 2.0 ** 30
+    elif case == "gradient_rows":  # what the backward products see
+        x = x * 1e-8
+    elif case == "subnormal_rows":  # below fp32's normal range: the scale saturates at 2^127
+        x = x * 1e-39
+    elif case == "mixed_scales":  # neighbouring rows sixty binades apart: a scale per tile or per 16-row block would not do
+        x = x * torch.exp2(torch.randint(-30, 31, (m, 1), generator=g).float())
+    return x
+
+
+@pytest.mark.parametrize("case", _ROW_CASES)
+@pytest.mark.parametrize("m,k,n", [(6747, 300, 600), (6747, 600, 300), (41269, 300, 600), (63, 600, 600), (1, 300, 600), (129, 36, 124), (513, 12, 300)])
+def test_products_on_two_fp16_planes_against_float64(case, m, k, n, monkeypatch):
+    """pgnn_linear_fwd_2p / pgnn_linear_bwd_data_2p (k_gemm2pw; chem/model.py:29,54-55, bio/model.py:24: nn.Linear forward and its
+    input gradient) against float64, the statistic of test_linear_fwd_split_bf16_is_as_accurate_as_the_fp32_mfma -- error over the
+    |a|.|b| bound of each entry -- at the bar of the three-plane products (max < 2e-6, rms < 3e-7) and, where results are sums of
+    many comparable terms, at that test's bar against the fp32-MFMA kernel on the same inputs (rms <= 1.25 x, max <= 2 x); on
+    operands chosen against a scale per row; ragged M / N, K not a multiple of 32, one-row and 41 269-row operands.  Then the hand-over of the row maxima: y_amax of the first product is max |y| of every row, bit for bit,
+    and a second product given those maxima equals the one that takes them itself, bit for bit."""
+    ops = _ops()
+    lib, sp = ops.load(), ops.stream_ptr()
+    x = _adversarial_rows(case, m, k).to(DEV)
+    torch.manual_seed(n)
+    w = (torch.randn(n, k) * 0.05).to(DEV)
+    b = torch.randn(n, device=DEV) if case not in ("gradient_rows", "subnormal_rows") else torch.zeros(n, device=DEV)  # (a bias would drown them)
+    bufs, _ = _weight_planes_2p(lib, sp, [w, w], [False, True])
+    wp, wtp = bufs
+    want = torch.relu(x.double() @ w.double().t() + b.double())
+    scale = x.double().abs() @ w.double().abs().t() + b.double().abs()
+    tiny = 4 * 2.0 ** -149  # results below fp32's normal range carry its subnormal spacing, whatever computes them
+    y = torch.full((m, n), float("nan"), device=DEV)
+    yam = torch.zeros(m, dtype=torch.int32, device=DEV)
+    ops.check(lib.pgnn_linear_fwd_2p(x.data_ptr(), k, None, wp.data_ptr(), b.data_ptr(), y.data_ptr(), n, m, k, n, 1, None, yam.data_ptr(), sp), "fwd 2p")
+    y2 = torch.full((m, n), float("nan"), device=DEV)
+    ops.check(lib.pgnn_linear_fwd_2p(x.data_ptr(), k, None, wp.data_ptr(), b.data_ptr(), y2.data_ptr(), n, m, k, n, 1, None, None, sp), "fwd 2p")
+    assert torch.equal(y, y2)  # reproducible, and the maxima's atomics do not touch the result
+    err = ((y.double() - want).abs() - tiny).clamp(min=0) / scale.clamp(min=1e-300)
+    monkeypatch.setenv("PGNN_GEMM_SPLIT", "0")  # the fp32-MFMA kernel on the same inputs
+    lib.pgnn_reload_env()
+    y32 = torch.empty(m, n, device=DEV)
+    ops.check(lib.pgnn_linear_fwd(x.data_ptr(), k, w.data_ptr(), b.data_ptr(), y32.data_ptr(), n, m, k, n, 1, sp), "fwd fp32")
+    monkeypatch.delenv("PGNN_GEMM_SPLIT")
+    lib.pgnn_reload_env()
+    err32 = ((y32.double() - want).abs() - tiny).clamp(min=0) / scale.clamp(min=1e-300)
+    rec = {"test": "two_planes_fwd", "case": case, "m": m, "k": k, "n": n, "max": err.max().item(), "rms": err.pow(2).mean().sqrt().item(),
+           "max_fp32_mfma": err32.max().item(), "rms_fp32_mfma": err32.pow(2).mean().sqrt().item()}
+    _log_two_plane(rec)
+    assert rec["max"] < 2e-6 and rec["rms"] < 3e-7, rec  # (the bar of test_products_on_weight_planes)
+    # against the fp32-MFMA kernel on the same inputs wherever a result is a sum of many comparable terms.  (Two planes carry 22
+    # significant bits per operand, fp32 24: where ONE term dominates a result -- the outlier rows, the top decade of the
+    # six-decade columns, K = 12 -- its representation error, <= 2^-21 of the term, shows undiluted; with hundreds of comparable
+    # terms both kernels are bound by the fp32 accumulation they share.)
+    if case in ("zero_rows", "gradient_rows", "mixed_scales") and k >= 300:
+        assert rec["rms"] <= 1.25 * rec["rms_fp32_mfma"] + 1e-9 and rec["max"] <= 2.0 * rec["max_fp32_mfma"] + 1e-9, rec
+    # the row maxima the epilogue leaves: exactly max |y| per row
+    assert torch.equal(yam.view(torch.float32), y.abs().max(dim=1).values)
+    # backward-data on the transposed planes, ReLU mask in the epilogue: dx [m, k] = (dy [m, n] . W) * (mask > 0)
+    dy = (_adversarial_rows(case, m, n) * (1e-3 if case not in ("gradient_rows", "subnormal_rows") else 1.0)).to(DEV)
+    mask = torch.relu(torch.randn(m, k, device=DEV))
+    wantd = (dy.double() @ w.double()) * (mask > 0)
+    scaled = dy.double().abs() @ w.double().abs()
+    dx = torch.full((m, k), float("nan"), device=DEV)
+    dxam = torch.zeros(m, dtype=torch.int32, device=DEV)
+    ops.check(lib.pgnn_linear_bwd_data_2p(dy.data_ptr(), n, None, wtp.data_ptr(), mask.data_ptr(), k, dx.data_ptr(), k, m, k, n, dxam.data_ptr(), sp), "bwd 2p")
+    errd = ((dx.double() - wantd).abs() - tiny).clamp(min=0) / scaled.clamp(min=1e-300)
+    _log_two_plane({"test": "two_planes_bwd_data", "case": case, "m": m, "k": k, "n": n, "max": errd.max().item(), "rms": errd.pow(2).mean().sqrt().item()})
+    assert errd.max().item() < 2e-6
+    assert torch.equal(dxam.view(torch.float32), dx.abs().max(dim=1).values)
+    # hand-over: the second product of an mlp on the first one's maxima (k2 = n of the first)
+    if n % 4 == 0 and n >= 8:
+        w2 = (torch.randn(k, n) * 0.05).to(DEV)
+        (wp2,), _ = _weight_planes_2p(lib, sp, [w2], [False])
+        za, zb = torch.full((m, k), float("nan"), device=DEV), torch.full((m, k), float("nan"), device=DEV)
+        ops.check(lib.pgnn_linear_fwd_2p(y.data_ptr(), n, yam.data_ptr(), wp2.data_ptr(), None, za.data_ptr(), k, m, n, k, 0, None, None, sp), "fwd 2p given")
+        ops.check(lib.pgnn_linear_fwd_2p(y.data_ptr(), n, None, wp2.data_ptr(), None, zb.data_ptr(), k, m, n, k, 0, None, None, sp), "fwd 2p self")
+        assert torch.equal(za, zb)
+
+
+@pytest.mark.parametrize("m,k,n", [(6747, 300, 600), (200, 600, 300)])
+def test_two_plane_products_propagate_inf_and_nan_by_row(m, k, n):
+    """an inf or a NaN in a row of the activation operand makes every result of THAT row non-finite (NaN for a NaN), as the fp32
+    product does (there: +-inf by the weight's sign, NaN where the weight is zero), and leaves every other row as accurate as
+    without it -- the maxima are per row, and a row whose maximum is not finite runs unscaled"""
+    ops = _ops()
+    lib, sp = ops.load(), ops.stream_ptr()
+    torch.manual_seed(3)
+    x = torch.randn(m, k)
+    x[5, 17] = float("inf")
+    x[6, 100] = float("-inf")
+    x[70, 3] = float("nan")
+    x = x.to(DEV)
+    w = (torch.randn(n, k) * 0.05).to(DEV)
+    (wp,), _ = _weight_planes_2p(lib, sp, [w], [False])
+    y = torch.empty(m, n, device=DEV)
+    ops.check(lib.pgnn_linear_fwd_2p(x.data_ptr(), k, None, wp.data_ptr(), None, y.data_ptr(), n, m, k, n, 0, None, None, sp), "fwd 2p")
+    bad = torch.zeros(m, dtype=torch.bool, device=DEV)
+    bad[[5, 6, 70]] = True
+    assert bool((~torch.isfinite(y[bad])).all())
+    assert bool(torch.isnan(y[70]).all())
+    ref = x.double() @ w.double().t()
+    assert bool(((ref[5] > 0) == (y[5] > 0))[torch.isfinite(y[5]) | torch.isinf(y[5])].all())  # where it is an inf, it has fp32's sign
+    good = ~bad
+    scale = x[good].double().abs() @ w.double().abs().t()
+    assert float(((y[good].double() - ref[good]).abs() / scale).max()) < 2e-6
+
+
 @pytest.mark.parametrize("m,k,n", [(6747, 600, 300), (6747, 300, 600), (1000, 600, 300), (130, 300, 300), (17, 64, 32), (16, 64, 36), (1, 32, 8)])
 @pytest.mark.parametrize("offset", [0.0, 1000.0])
 def test_linear_fwd_colstats_and_batchnorm_statistics_from_blocks(m, k, n, offset):

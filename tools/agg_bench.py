@@ -7,8 +7,9 @@ from pretrain_gnns_amd.data import synthetic
 
 graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 dev = "cuda"
-base = synthetic.chem_masking_batch(2048, seed=123)
-big = synthetic.tile_batch(base, max(1, graphs // 2048)).to(dev)
+# bench.py's roofline batch: SMILES-ordered molecules through the loader's renumbering (ORDER=survey|smiles|permuted, RELABEL=0|1 override)
+big, info = synthetic.chem_aggregation_batch(graphs, os.environ.get("ORDER", "smiles"), os.environ.get("RELABEL", "1") != "0", device=dev)
+print("batch:", info)
 n, e = big.x.size(0), big.edge_index.size(1)
 g = ops.build_chem_graph(big.edge_index, big.edge_attr, n)
 torch.manual_seed(0)
