@@ -308,6 +308,56 @@ def reference_loop_leg(dev, args, batch, steps_n):
             "adam": "foreach (torch default)", "metrics_readback": "inline", "direct_grads": False}
 
 
+def unchanged_script_leg(dev, args, batch, steps_n):
+    """what an UNCHANGED chem/pretrain_masking.py gets: its train() body taken statement by statement
+    (:47-78) -- the script's own torch ops for the prediction head (`linear_pred_atoms(node_rep[masked_atom_indices])`, float64
+    cross-entropy, compute_accuracy with its .item()), its three torch.optim.Adam, `float(loss.cpu().item())` per step -- around
+    the drop-in GNN.  Nothing of train.py / optim.py is used.  Two runs: as imported, and with PGNN_DIRECT_GRADS=1 in the
+    environment (no change to the script; the one-call network then writes `.grad` itself -- assign when None, add otherwise,
+    what AccumulateGrad does -- which torch.optim.Adam cannot tell from autograd's: tests/test_gpu_models.py)."""
+    import torch.nn.functional as F
+    from pretrain_gnns_amd import ops
+
+    def compute_accuracy(pred, target):  # chem/pretrain_masking.py:30-31
+        return float(torch.sum(torch.max(pred.detach(), dim=1)[1] == target).cpu().item()) / len(pred)
+
+    out = {}
+    for tag, direct in (("as_imported", False), ("PGNN_DIRECT_GRADS=1", True)):
+        model, linear_pred_atoms, linear_pred_bonds = make_models(dev)
+        opts = [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0) for m in (model, linear_pred_atoms, linear_pred_bonds)]
+        criterion = torch.nn.CrossEntropyLoss()
+        prev = ops.set_direct_grads(direct)
+        try:
+            def one_step():
+                node_rep = model(batch.x, batch.edge_index, batch.edge_attr)
+                pred_node = linear_pred_atoms(node_rep[batch.masked_atom_indices])
+                loss = criterion(pred_node.double(), batch.mask_node_label[:, 0])
+                acc = compute_accuracy(pred_node, batch.mask_node_label[:, 0])
+                for o in opts:
+                    o.zero_grad()
+                loss.backward()
+                for o in opts:
+                    o.step()
+                return float(loss.cpu().item()), acc
+
+            model.train()
+            for _ in range(5):
+                one_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps_n):
+                loss, acc = one_step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps_n
+            out[tag] = {"ms_per_step": round(dt * 1e3, 4), "edges_per_s": round(batch.edge_index.size(1) / dt, 1), "last_loss": round(loss, 5)}
+        except Exception as exc:
+            out[tag] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        finally:
+            ops.set_direct_grads(prev)
+    out["note"] = "torch head ops + three torch.optim.Adam (foreach) + two device->host syncs per step, as the script has them"
+    return out
+
+
 def forward_only(dev, mods, batch, iters):
     """edges/s of the GNN forward alone (training-mode BatchNorm, no autograd tape): SURVEY 8(d)(ii)."""
     model = mods[0]
@@ -846,6 +896,29 @@ def _run():
     loss = finish()  # (readback="epoch": the one device->host fetch of the K steps, inside the timed region)
     sync()
     elapsed = time.perf_counter() - t0
+    # the same K-step window, repeated: a K = 20 window is ~20 ms, too short to judge to 5 % by itself.  After a
+    # 0.2 s clock warm-up of the same steps: at least five consecutive windows, each bracketed like `value`'s.  Reported beside
+    # `value`, which stays the driver's window.
+    value_windows = None
+    if world == 1:
+        tw = time.perf_counter()
+        while time.perf_counter() - tw < 0.2:
+            step(batch)
+        finish()
+        sync()
+        wins = []
+        for _ in range(7):
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step(batch)
+            finish()
+            sync()
+            wins.append(1e3 * (time.perf_counter() - t1) / args.steps)
+        sw = sorted(wins)
+        value_windows = {"windows": len(wins), "steps_per_window": args.steps, "clock_warmup_s": 0.2,
+                         "ms_per_step_min": round(sw[0], 4), "ms_per_step_median": round(sw[len(sw) // 2], 4), "ms_per_step_max": round(sw[-1], 4),
+                         "edges_per_s_median": round(edges_local / (sw[len(sw) // 2] * 1e-3), 1), "ms_per_step_each": [round(w, 4) for w in wins]}
     per_step_readback = None
     if world == 1 and args.readback == "epoch":  # the same K steps fetching (loss, correct) after every step, for comparison
         step2, finish2 = masking_stepper(mods, list(opts), "end", dev)
@@ -899,11 +972,14 @@ def _run():
                                        "(24 bits); error against float64 held to the fp32-MFMA kernel's bar in tests/test_gpu_ops.py"},
             "comm": comm,
         }
+        if value_windows is not None:
+            res["value_windows"] = value_windows
         if per_step_readback is not None:
             res["per_step_readback"] = per_step_readback
         if world == 1:
             res["three_plane_products"] = three_plane_products_leg(dev, args, batch, args.steps)
             res["reference_loop"] = reference_loop_leg(dev, args, batch, max(args.steps // 2, 20))
+            res["unchanged_script"] = unchanged_script_leg(dev, args, batch, max(args.steps // 2, 20))
             res["forward_only"] = forward_only(dev, mods, batch, max(args.steps, 20))
         if world == 1 and not args.no_loader:
             res["resident_loader"] = resident_loader_leg(dev, args, max(args.steps, 20))

@@ -19,6 +19,7 @@
 // aggregation reproduces the reference's CPU scatter_add order exactly.
 #include <stdlib.h>
 
+#include "bn_fold.h"
 #include "common.h"
 
 namespace pgnn {
@@ -354,13 +355,53 @@ typedef float v4f_t __attribute__((ext_vector_type(4)));
 // WEIGHT: GCN symmetric normaliser w_e = dinv[i] * dinv[src_e], w_ii = dinv[i]^2 (chem/model.py:73-82,104).  dinv of the
 // block's rows and of the 8-row halo either side sits in LDS (every source inside the ring window is covered), the
 // products are formed exactly as k_aggregate_grp forms them: the two kernels are bit-identical.
-template <bool TABLE, int P, int NROW, bool PRE, int POL, bool WEIGHT>
+// TAIL (round 4; the transposed instance of the GIN stack's backward, out = dL/dy of the layer below): every consumer thread also
+// reads its float4 of that layer's BatchNorm input z, forms dyr = the row it has just summed, masked by the recomputed ReLU, and
+// keeps the column sums of dyr and dyr * xhat over its rows; the block folds its eight node slots through LDS, publishes one
+// partial row and joins bn_bwd_fold (bn_fold.h) -- the launch leaves what pgnn_bn_bwd's partial-sum launch left (coef, dgamma,
+// dbeta), and that launch (14-25 us on the backward's critical path, beside a weight-gradient product) is gone.  The rows are
+// summed in another order than k_bn_bwd_partial sums them (per thread: rows g, g + 8, ...; then the eight slots; then the blocks
+// in order): fixed, so still deterministic, equal to fp32 rounding.
+struct AggTail {
+  const float* z;
+  int64_t ldz;
+  const float* gamma;
+  const float* beta;
+  const float* save_mean;
+  const float* save_invstd;
+  int relu;
+  BnBwdFold fold;
+};
+
+// The block's end of the tail, entered by EVERY thread of the block -- the loader wave too (with nothing to add): no wave of a block
+// that still has a barrier ahead may have ended (a barrier counts the surviving waves only, but a workgroup that is saved and
+// restored between two processes' time slices with one wave gone and the others parked at a barrier is not a state to rely on).
+__device__ __forceinline__ void agg_tail_finish(const AggTail& tail, float* redL, bool active, int g, int c4, float4 s1, float4 s2, int dim) {
+  const int t = threadIdx.x, nt = blockDim.x;
+  if (active) {
+    reinterpret_cast<float4*>(redL + (g * 2 + 0) * dim)[c4] = s1;
+    reinterpret_cast<float4*>(redL + (g * 2 + 1) * dim)[c4] = s2;
+  }
+  __syncthreads();
+  float* prow = tail.fold.partial + (size_t)blockIdx.x * 2 * dim;
+  for (int q = t; q < 2 * dim; q += nt) {  // q < dim: sums of dyr, else of dyr * xhat; the eight node slots in order
+    const int h = q >= dim ? 1 : 0, c = q - h * dim;
+    float a0 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a0 += redL[(k * 2 + h) * dim + c];
+    publish(prow + q, a0);
+  }
+  publish_commit();
+  bn_bwd_fold(tail.fold, dim, blockIdx.x, gridDim.x, t, nt);
+}
+
+template <bool TABLE, int P, int NROW, bool PRE, int POL, bool WEIGHT, bool TAIL = false>
 __global__ void __launch_bounds__(704)
 k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ ptr,
                 const int32_t* __restrict__ nbr, const uint8_t* __restrict__ code,
                 const float* __restrict__ emb1, const float* __restrict__ emb2, float* __restrict__ out,
                 int64_t ldo, int n, int dim, int npb, const float* __restrict__ pre_coef, int pre_relu,
-                unsigned long long* __restrict__ prof, const float* __restrict__ dinv) {
+                unsigned long long* __restrict__ prof, const float* __restrict__ dinv, AggTail tail) {
 #pragma clang fp contract(off)
   // POL bit 4 (PF): source rows OUTSIDE the ring window are fetched into registers ONE STEP AHEAD of their use (the step's edge
   // slots are then staged one step earlier), instead of on the spot behind a wave-uniform branch that waits a memory round trip
@@ -386,6 +427,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
   int* codeL = idxL + NBUF * kDmaEdges;                                              // [NBUF][64] (byte DMA lands as dwords)
   float* dinvL = reinterpret_cast<float*>(codeL + NBUF * kDmaEdges);                 // [8 (nsteps + 2)] rows n0-8 .. (WEIGHT)
   int* farL = codeL + NBUF * kDmaEdges;  // (PF; never together with WEIGHT) [NBUF][2]: bit k = staged edge slot k of the step is far
+  float* redL = reinterpret_cast<float*>(farL + 16);  // (TAIL; never together with WEIGHT) [8][2][dim]: the node slots' column sums
   const float4* __restrict__ T4 = reinterpret_cast<const float4*>(T);
   const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
   const int64_t ldx4 = ldx >> 2, ldo4 = ldo >> 2;
@@ -489,6 +531,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
       pr[0] = c_wait; pr[1] = c_bar; pr[2] = c_issue;
       pr[5] = __builtin_readcyclecounter() - t_begin; pr[6] = (unsigned long long)nsteps;
     }
+    if (TAIL) agg_tail_finish(tail, redL, false, 0, 0, f4_zero(), f4_zero(), dim);
     return;
   }
 
@@ -523,6 +566,22 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
     }
   __syncthreads();  // prologue
 
+  // (TAIL) forward coefficients y = a z + b of the BatchNorm below, recomputed exactly as k_bn_bwd_partial recomputes them
+  float4 ta = f4_zero(), tb = f4_zero(), tmu = f4_zero(), tis = f4_zero(), ts1 = f4_zero(), ts2 = f4_zero();
+  if (TAIL && active) {
+    const float4 gm = reinterpret_cast<const float4*>(tail.gamma)[c4], bt = reinterpret_cast<const float4*>(tail.beta)[c4];
+    tmu = reinterpret_cast<const float4*>(tail.save_mean)[c4];
+    tis = reinterpret_cast<const float4*>(tail.save_invstd)[c4];
+    ta = make_float4(tis.x * gm.x, tis.y * gm.y, tis.z * gm.z, tis.w * gm.w);
+    tb = make_float4(fmaf(-tmu.x, ta.x, bt.x), fmaf(-tmu.y, ta.y, bt.y), fmaf(-tmu.z, ta.z, bt.z), fmaf(-tmu.w, ta.w, bt.w));
+    if (blockIdx.x == 0 && g == 0) {
+      float* coef = tail.fold.coef;
+      reinterpret_cast<float4*>(coef)[c4] = ta;
+      reinterpret_cast<float4*>(coef + dim)[c4] = tb;
+      reinterpret_cast<float4*>(coef + 2 * dim)[c4] = tmu;
+      reinterpret_cast<float4*>(coef + 3 * dim)[c4] = tis;
+    }
+  }
   // per-step row pointers are read one step ahead (they sit in LDS for the whole block), so the chain
   // after a barrier is only: edge indices -> rows -> adds -> store
   int nb_e0 = ptrL[0], nb_beg = 0, nb_end = 0;
@@ -554,6 +613,8 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
     const int win_lo = max(base - kDmaG, 0), win_hi = min(base + 2 * kDmaG, n);
     const int* idxB = idxL + (s % NBUF) * kDmaEdges;
     const int* codeB = codeL + (s % NBUF) * kDmaEdges;
+    float4 zrow = f4_zero();
+    if (TAIL) zrow = reinterpret_cast<const float4*>(tail.z + (int64_t)i * tail.ldz)[c4];  // (lands under the edge loop)
     // the node's own row (self loop) does not depend on the edge list: fetch it first
     float4 self = act(ring[slot_of(i) * gs + c4]);
     if (TABLE) self = f4_add(self, T4[kSelfLoopCode * gs + c4]);
@@ -661,7 +722,22 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
     } else {
       reinterpret_cast<float4*>(out)[(int64_t)i * ldo4 + c4] = acc;
     }
+    if (TAIL) {  // the same expressions as k_bn_bwd_partial's
+      float4 gq = acc;
+      if (tail.relu) {
+        if (!(fmaf(ta.x, zrow.x, tb.x) > 0.f)) gq.x = 0.f;
+        if (!(fmaf(ta.y, zrow.y, tb.y) > 0.f)) gq.y = 0.f;
+        if (!(fmaf(ta.z, zrow.z, tb.z) > 0.f)) gq.z = 0.f;
+        if (!(fmaf(ta.w, zrow.w, tb.w) > 0.f)) gq.w = 0.f;
+      }
+      ts1.x += gq.x; ts1.y += gq.y; ts1.z += gq.z; ts1.w += gq.w;
+      ts2.x = fmaf(gq.x, (zrow.x - tmu.x) * tis.x, ts2.x);
+      ts2.y = fmaf(gq.y, (zrow.y - tmu.y) * tis.y, ts2.y);
+      ts2.z = fmaf(gq.z, (zrow.z - tmu.z) * tis.z, ts2.z);
+      ts2.w = fmaf(gq.w, (zrow.w - tmu.w) * tis.w, ts2.w);
+    }
   }
+  if (TAIL) agg_tail_finish(tail, redL, active, g, c4, ts1, ts2, dim);
   if (PROF && prof && t == 0) {
     unsigned long long* pr = prof + (size_t)blockIdx.x * 8;
     pr[3] = c_cbar; pr[4] = c_work;
@@ -671,16 +747,18 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
 unsigned long long* g_agg_prof = nullptr;  // set by pgnn_debug_aggregate_profile
 int64_t g_agg_prof_blocks = 0;
 
-template <bool TABLE, int P, int NROW, bool PRE = false, int POL = 0, bool WEIGHT = false>
+template <bool TABLE, int P, int NROW, bool PRE = false, int POL = 0, bool WEIGHT = false, bool TAIL = false>
 int launch_aggregate_dma_p(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* nbr, const uint8_t* code,
                            const float* emb1, const float* emb2, float* out, int64_t ldo, int64_t n, int64_t dim,
-                           hipStream_t st, const float* pre_coef = nullptr, int pre_relu = 0, const float* dinv = nullptr) {
+                           hipStream_t st, const float* pre_coef = nullptr, int pre_relu = 0, const float* dinv = nullptr,
+                           const AggTail* tail = nullptr, int max_blocks = 0) {
+  static_assert(!(TAIL && WEIGHT), "the tail's LDS sits where the GCN normalisers would");
   const int gs = (int)(dim / 4);
   const int cthreads = (int)align_up((size_t)kDmaG * gs, kWave);
   const int threads = cthreads + kWave;
   const size_t lds = (size_t)(TABLE ? kNumCodes * dim : 0) * 4 + (size_t)(P + 3) * kDmaG * dim * 4 +
                      (size_t)(kDmaMaxNodes + 4) * 4 + (size_t)2 * (P + 1 + ((POL & 16) ? 1 : 0)) * kDmaEdges * 4 +
-                     (WEIGHT ? (size_t)(kDmaMaxNodes + 3 * kDmaG) * 4 : 0) + 64;
+                     (WEIGHT ? (size_t)(kDmaMaxNodes + 3 * kDmaG) * 4 : 0) + 64 + (TAIL ? (size_t)kDmaG * 2 * dim * 4 + 64 : 0);
   const int resident = (int)std::max<size_t>(1, (160 * 1024) / lds);
   const int64_t target_blocks = (int64_t)num_cu() * std::min(resident, env_int("PGNN_DMA_BPC", 2));
   int64_t npb = ceil_div(n, target_blocks);
@@ -688,10 +766,14 @@ int launch_aggregate_dma_p(const float* x, int64_t ldx, const int32_t* ptr, cons
   npb = ceil_div(npb, kDmaG) * kDmaG;
   if (npb > kDmaMaxNodes) npb = kDmaMaxNodes;
   const int grid = (int)ceil_div(n, npb);
+  if (TAIL && (grid > max_blocks || ceil_div(grid, kFoldGroup) > kFoldMaxGroups)) {
+    set_error("aggregate_dma: %d blocks exceed the BatchNorm-backward scratch (%d)", grid, max_blocks);
+    return PGNN_ERR_WORKSPACE;
+  }
   unsigned long long* prof = ((POL & 8) && g_agg_prof_blocks >= grid) ? g_agg_prof : nullptr;
-  allow_big_lds((const void*)k_aggregate_dma<TABLE, P, NROW, PRE, POL, WEIGHT>, lds);
-  hipLaunchKernelGGL((k_aggregate_dma<TABLE, P, NROW, PRE, POL, WEIGHT>), dim3(grid), dim3(threads), lds, st, x, ldx, ptr, nbr,
-                     code, emb1, emb2, out, ldo, (int)n, (int)dim, (int)npb, pre_coef, pre_relu, prof, dinv);
+  allow_big_lds((const void*)k_aggregate_dma<TABLE, P, NROW, PRE, POL, WEIGHT, TAIL>, lds);
+  hipLaunchKernelGGL((k_aggregate_dma<TABLE, P, NROW, PRE, POL, WEIGHT, TAIL>), dim3(grid), dim3(threads), lds, st, x, ldx, ptr, nbr,
+                     code, emb1, emb2, out, ldo, (int)n, (int)dim, (int)npb, pre_coef, pre_relu, prof, dinv, tail ? *tail : AggTail{});
   return check_launch("aggregate_dma");
 }
 
@@ -1281,6 +1363,33 @@ int pgnn_neighbor_sum(const float* x, int64_t ldx, const int32_t* ptr, const int
   if (dinv) return launch_aggregate<false, true>(x, ldx, ptr, nbr, nullptr, nullptr, nullptr, dinv, out, ldo, n, dim, st);
   return launch_aggregate<false, false>(x, ldx, ptr, nbr, nullptr, nullptr, nullptr, dinv, out, ldo, n, dim, st);
 }
+
+}  // extern "C"
+
+// pgnn_neighbor_sum + the BatchNorm-backward column sums of the layer below in the same launch (bn_fold.h).  Fused only on the
+// tuned instantiation (feature width 300, far rows prefetched, the default cache policy of batches below 128 MB); anything else
+// is the plain sum and *fused = false: the caller then runs pgnn_bn_bwd as before.
+int pgnn::neighbor_sum_bn_bwd(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* nbr, float* out, int64_t ldo, int64_t n,
+                              int64_t dim, const BnBwdTail& tail, bool* fused, hipStream_t st) {
+  if (int rc = check_dim(dim)) return rc;
+  PGNN_REQUIRE(n > 0 && ldx % 4 == 0 && ldo % 4 == 0 && tail.ldz % 4 == 0, "bad neighbor_sum arguments");
+  const int nrow = (int)ceil_div(kDmaG * (dim / 4), kWave);
+  const bool small_ld = ldx * 4 * kDmaG < (1ll << 31);
+  const bool tuned = dim <= 320 && nrow == 10 && small_ld && env_int("PGNN_AGG_VARIANT", 3) == 3 && env_int("PGNN_DMA_P", 2) == 2 &&
+                     !env_int("PGNN_DMA_GENERIC", 0) && env_int("PGNN_DMA_PF", 1) != 0 &&
+                     env_int("PGNN_DMA_POL", (int64_t)n * dim * 4 >= (128ll << 20) ? 3 : 0) == 0 && env_int("PGNN_BN_BWD_IN_AGG", 1) != 0;
+  *fused = tuned && tail.z && tail.scratch.partial && tail.scratch.tickets;
+  if (!*fused) return launch_aggregate<false, false>(x, ldx, ptr, nbr, nullptr, nullptr, nullptr, nullptr, out, ldo, n, dim, st);
+  AggTail t{};
+  t.z = tail.z; t.ldz = tail.ldz; t.gamma = tail.gamma; t.beta = tail.beta; t.save_mean = tail.save_mean; t.save_invstd = tail.save_invstd;
+  t.relu = tail.relu;
+  t.fold = BnBwdFold{tail.gamma, tail.save_invstd, tail.scratch.partial, tail.scratch.gsum, tail.scratch.tickets, tail.scratch.coef,
+                     tail.dgamma, tail.dbeta, tail.training, (int)n};
+  return launch_aggregate_dma_p<false, 2, 10, false, 16, false, true>(x, ldx, ptr, nbr, nullptr, nullptr, nullptr, out, ldo, n, dim, st, nullptr,
+                                                                       0, nullptr, &t, tail.scratch.max_blocks);
+}
+
+extern "C" {
 
 int pgnn_rowfeat_matmul_fwd(const float* cfeat, int64_t kc, const float* table, int64_t ldt, float* out,
                             int64_t ldo, int64_t n, int64_t dim, int accumulate, pgnn_stream stream) {

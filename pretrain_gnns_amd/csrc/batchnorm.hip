@@ -8,16 +8,15 @@
 // cancel catastrophically when |mean| >> std.
 #include <atomic>
 
+#include "bn_fold.h"
 #include "common.h"
 
 namespace pgnn {
 namespace {
 
-constexpr int kMaxBlocks = 1024;
-constexpr int kFoldGroup = 16;       // blocks per group of the in-launch fold of k_bn_bwd_partial
-constexpr int kFoldMaxGroups = 64;   // (kMaxBlocks / kFoldGroup)
-constexpr int kFoldSlots = 256;      // ticket sets; a launch draws the next one, every launch leaves its set zeroed
+constexpr int kMaxBlocks = kBnMaxBlocks;
 __device__ unsigned g_bn_fold_tickets[kFoldSlots][kFoldMaxGroups + 8];
+__device__ unsigned g_bn_fwd_fold_tickets[kFoldSlots / 4][kFwdFoldPanels][kFoldMaxGroups + 8];
 
 // Inverted dropout fused into the normalise pass (F.dropout after the ReLU, chem/model.py:271-275).
 // Counter-based: the keep bits of float4 (row r, column group c4) come from one splitmix64 of
@@ -269,70 +268,9 @@ __global__ void k_bn_bwd_partial(const float* __restrict__ dy, int64_t lddy, con
   block_col_reduce2(s1, s2, d4, lds, p, p + dim);
   if (!tickets) return;  // (the fold is k_bn_bwd_final's: more than kFoldMaxGroups groups)
   // ---- the fold of the partials, inside this launch (a launch of its own cost 6-8 us + a kernel boundary per layer on the
-  // backward's critical path): blocks are grouped by kFoldGroup consecutive ids; the LAST block of a group to arrive adds the
-  // group's partials in block order (float64) into gsum[group]; the last GROUP leader to arrive adds the groups in order and
-  // finishes as k_bn_bwd_final does.  Which block does the adding varies, what is added in which order does not.  Partials cross
-  // blocks as agent-scope stores / loads and relaxed tickets (common.h: no L2 write-backs).
-  __shared__ int role;
-  const int nblk = gridDim.x, ngroups = (nblk + kFoldGroup - 1) / kFoldGroup;
-  const int grp = blockIdx.x / kFoldGroup, gsize = min(kFoldGroup, nblk - grp * kFoldGroup);
-  __syncthreads();  // this block's partial row is written (agent-scope stores, block_col_reduce2)
-  if (t == 0) {
-    role = __hip_atomic_fetch_add(tickets + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)gsize - 1u ? 1 : 0;
-  }
-  __syncthreads();
-  if (role == 0) return;
-  for (int q = t; q < 2 * dim; q += blockDim.x) {
-    float v[kFoldGroup];  // every load of the group in flight at once (clamped, unconditional), added in block order
-#pragma unroll
-    for (int b = 0; b < kFoldGroup; ++b) v[b] = fetch_published(partial + (size_t)(grp * kFoldGroup + min(b, gsize - 1)) * 2 * dim + q);
-    double acc = 0.0;
-#pragma unroll
-    for (int b = 0; b < kFoldGroup; ++b)
-      if (b < gsize) acc += (double)v[b];
-    publish(gsum + (size_t)grp * 2 * dim + q, acc);
-  }
-  publish_commit();
-  __syncthreads();
-  if (t == 0) {
-    publish(tickets + 1 + grp, 0u);
-    publish_commit();
-    role = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ngroups - 1u ? 2 : 0;
-  }
-  __syncthreads();
-  if (role != 2) return;
-  if (t == 0) publish(tickets, 0u);
-  for (int c = t; c < dim; c += blockDim.x) {
-    double t1 = 0.0, t2 = 0.0;
-    for (int g0 = 0; g0 < ngroups; g0 += 8) {  // eight groups' sums in flight at once, added in group order
-      double u1[8], u2[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int gq = min(g0 + j, ngroups - 1);
-        u1[j] = fetch_published(gsum + (size_t)gq * 2 * dim + c);
-        u2[j] = fetch_published(gsum + (size_t)gq * 2 * dim + dim + c);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (g0 + j < ngroups) {
-          t1 += u1[j];
-          t2 += u2[j];
-        }
-    }
-    if (dgamma) dgamma[c] = (float)t2;
-    if (dbeta) dbeta[c] = (float)t1;
-    const float invstd = save_invstd[c];
-    const float k1 = gamma[c] * invstd;
-    float k2 = 0.f, k3 = 0.f;
-    if (training) {  // dx = k1 * (dyr - s1/n - xhat * s2/n),  xhat = (x - mean) * invstd
-      const float m1 = (float)(t1 / n), m2 = (float)(t2 / n);
-      k2 = -k1 * invstd * m2;
-      k3 = -k1 * m1;
-    }
-    coef[4 * dim + c] = k1;
-    coef[5 * dim + c] = k2;
-    coef[6 * dim + c] = k3;
-  }
+  // backward's critical path): bn_fold.h
+  const BnBwdFold f{gamma, save_invstd, partial, gsum, tickets, coef, dgamma, dbeta, training, n};
+  bn_bwd_fold(f, dim, blockIdx.x, gridDim.x, t, blockDim.x);
 }
 
 // coef layout for backward: [a, b, mean, invstd, k1, k2, k3] each [dim]
@@ -413,7 +351,69 @@ inline int check_args(int64_t n, int64_t dim) {
   return PGNN_OK;
 }
 
+unsigned* draw_fold_tickets() {
+  static std::atomic<unsigned> next_slot{0};
+  static thread_local unsigned* base = nullptr;  // (one device per process; the lookup takes the runtime's locks)
+  static thread_local int base_dev = -1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!base || base_dev != dev) {
+    if (hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_bn_fold_tickets)) != hipSuccess) return nullptr;
+    base_dev = dev;
+  }
+  return base + (size_t)(next_slot.fetch_add(1, std::memory_order_relaxed) % kFoldSlots) * (kFoldMaxGroups + 8);
+}
+
 }  // namespace
+
+bool bn_fwd_fold_scratch(void* ws, size_t ws_bytes, int64_t n, int64_t dim, BnFwdFold* f) {
+  const size_t tiles = (size_t)ceil_div(n, 64);
+  if (n <= 1 || dim <= 0 || ceil_div((int64_t)tiles, kFoldGroup) > kFoldMaxGroups || ceil_div(dim, 160) > kFwdFoldPanels) return false;
+  const size_t need = align_up(tiles * 2 * dim * sizeof(double), 256) + align_up((size_t)kFoldMaxGroups * 2 * dim * sizeof(double), 256);
+  if (ws_bytes < need) return false;
+  static std::atomic<unsigned> next_slot{0};
+  static thread_local unsigned* base = nullptr;
+  static thread_local int base_dev = -1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!base || base_dev != dev) {
+    if (hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_bn_fwd_fold_tickets)) != hipSuccess) return false;
+    base_dev = dev;
+  }
+  Carver cv(ws);
+  f->part = cv.take<double>(tiles * 2 * dim);
+  f->gpart = cv.take<double>((size_t)kFoldMaxGroups * 2 * dim);
+  f->tickets = base + (size_t)(next_slot.fetch_add(1, std::memory_order_relaxed) % (kFoldSlots / 4)) * kFwdFoldPanels * (kFoldMaxGroups + 8);
+  f->n = (int)n;
+  return true;
+}
+
+int bn_bwd_scratch(void* ws, size_t ws_bytes, int64_t n, int64_t dim, BnBwdScratch* s) {
+  if (int rc = check_args(n, dim)) return rc;
+  if (ws_bytes < pgnn_bn_workspace_bytes(n, dim)) {
+    set_error("batchnorm workspace too small");
+    return PGNN_ERR_WORKSPACE;
+  }
+  Carver cv(ws);
+  s->max_blocks = stat_blocks(n);
+  s->partial = cv.take<float>((size_t)s->max_blocks * 2 * dim);
+  s->coef = cv.take<float>((size_t)7 * dim);
+  s->gsum = cv.take<double>((size_t)kFoldMaxGroups * 2 * dim);
+  s->tickets = draw_fold_tickets();
+  PGNN_REQUIRE(s->tickets != nullptr, "batchnorm: ticket words unavailable");
+  return PGNN_OK;
+}
+
+int bn_bwd_apply_only(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* coef, int relu, float* dx, int64_t lddx,
+                      int64_t n, int64_t dim, hipStream_t st) {
+  if (int rc = check_args(n, dim)) return rc;
+  PGNN_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "batchnorm: leading dimensions must be multiples of 4");
+  const int grid = (int)std::min<int64_t>(ceil_div(n, 4), (int64_t)num_cu() * 16);
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid), dim3(stat_threads(dim)), 0, st, dy, lddy, x, ldx, coef, relu, dx, lddx, (int)n,
+                     (int)(dim / 4), make_drop(0.f, 0));
+  return check_launch("bn_bwd_apply");
+}
+
 }  // namespace pgnn
 
 using namespace pgnn;
@@ -521,18 +521,10 @@ int pgnn_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, cons
   const int d4 = (int)(dim / 4);
   double* gsum = cv.take<double>((size_t)kFoldMaxGroups * 2 * dim);
   const bool fold = ceil_div(nblk, kFoldGroup) <= kFoldMaxGroups && env_knob("PGNN_BN_BWD_FOLD", 1) != 0;
-  static std::atomic<unsigned> next_slot{0};
   unsigned* tickets = nullptr;
   if (fold) {
-    static thread_local unsigned* base = nullptr;  // (one device per process; the lookup takes the runtime's locks)
-    static thread_local int base_dev = -1;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!base || base_dev != dev) {
-      PGNN_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_bn_fold_tickets)));
-      base_dev = dev;
-    }
-    tickets = base + (size_t)(next_slot.fetch_add(1, std::memory_order_relaxed) % kFoldSlots) * (kFoldMaxGroups + 8);
+    tickets = draw_fold_tickets();
+    PGNN_REQUIRE(tickets != nullptr, "batchnorm: ticket words unavailable");
   }
   hipLaunchKernelGGL(k_bn_bwd_partial, dim3(nblk), dim3(stat_threads(dim)), (size_t)8 * dim * sizeof(float), st, dy,
                      lddy, x, ldx, gamma, beta, save_mean, save_invstd, coef, relu, (int)n, d4, partial, drop, gsum, tickets, training,

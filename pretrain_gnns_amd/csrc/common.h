@@ -131,8 +131,10 @@ int split_weights_2p(const float* const* src, void* const* dst, const int64_t* r
                      uint32_t* zero_ptr = nullptr, int64_t zero_words = 0);  // + a region of words the launch clears
 // x_amax / dy_amax: [m] bit patterns of the rows' largest magnitudes when the producer of the operand left them (else NULL: the
 // kernel takes them); y_amax / dx_amax: [m] zeroed words that receive the result rows' largest magnitudes (NULL: not wanted)
+struct BnFwdFold;  // (bn_fold.h) non-NULL: the statistics of the BatchNorm behind y are folded inside the product's launch
 int linear_fwd_wp_2p(const float* x, int64_t ldx, const void* wplanes, const float* bias, float* y, int64_t ldy, int64_t m, int64_t k,
-                     int64_t n, int relu, float* colstat, hipStream_t st, const uint32_t* x_amax = nullptr, uint32_t* y_amax = nullptr);
+                     int64_t n, int relu, float* colstat, hipStream_t st, const uint32_t* x_amax = nullptr, uint32_t* y_amax = nullptr,
+                     const BnFwdFold* bnf = nullptr);
 int linear_bwd_data_wp_2p(const float* dy, int64_t lddy, const void* wtplanes, const float* relu_out, int64_t ldr, float* dx, int64_t lddx,
                           int64_t m, int64_t k, int64_t n, hipStream_t st, const uint32_t* dy_amax = nullptr, uint32_t* dx_amax = nullptr);
 // (tile.hip) pgnn_neighbor_sum_tiled whose result is zeroed where mask[i, c] <= 0 (the ReLU between two layers, backward), when

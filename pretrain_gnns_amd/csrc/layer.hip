@@ -5,6 +5,7 @@
 // kernel costs more than the kernel.  (chem/model.py:37-55 + :269-275 under autograd.)
 #include <stdlib.h>
 
+#include "bn_fold.h"
 #include "common.h"
 
 using namespace pgnn;
@@ -372,11 +373,22 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
     if (stats_in_gemm) {
       // the BatchNorm statistics of z fall out of the second product's epilogue: no pass over z for them, one launch less
       float* blocks = static_cast<float*>(ws);  // ceil(n/16) x 2 x dim floats <= the statistics partials of op_ws_bytes
-      if (wp) rc = stack_fwd_wp(hd, 2 * dim, wp2[l], p.b2, z, dim, n, 2 * dim, dim, 0, blocks, stream, ham);
-      else rc = pgnn_linear_fwd_colstats(hd, 2 * dim, p.w2, p.b2, z, dim, n, 2 * dim, dim, 0, blocks, stream);
+      // two planes (round 4): the merge of those blocks happens inside the product's launch too (bn_fold.h: tile, group of
+      // tiles, column panel) -- no k_bn_stats_final_blocks launch between the product and the next aggregation
+      BnFwdFold ff{};
+      const bool folded = wp && two_planes() && env_knob("PGNN_BN_STATS_FOLD", 1) != 0 && bn_fwd_fold_scratch(ws, opb, n, dim, &ff);
+      if (folded) {
+        ff.gamma = p.gamma; ff.beta = p.beta; ff.running_mean = p.running_mean; ff.running_var = p.running_var;
+        ff.momentum = p.momentum; ff.eps = p.eps; ff.save_mean = st; ff.save_invstd = st + dim; ff.coef = st + 2 * dim;
+        rc = linear_fwd_wp_2p(hd, 2 * dim, wp2[l], p.b2, z, dim, n, 2 * dim, dim, 0, nullptr, (hipStream_t)stream, ham, nullptr, &ff);
+      } else if (wp) {
+        rc = stack_fwd_wp(hd, 2 * dim, wp2[l], p.b2, z, dim, n, 2 * dim, dim, 0, blocks, stream, ham);
+      } else {
+        rc = pgnn_linear_fwd_colstats(hd, 2 * dim, p.w2, p.b2, z, dim, n, 2 * dim, dim, 0, blocks, stream);
+      }
       if (rc) return rc;
-      if ((rc = pgnn_bn_stats_fwd_blocks(blocks, p.gamma, p.beta, p.running_mean, p.running_var, p.momentum, p.eps, st, st + dim,
-                                         st + 2 * dim, n, dim, stream)))
+      if (!folded && (rc = pgnn_bn_stats_fwd_blocks(blocks, p.gamma, p.beta, p.running_mean, p.running_var, p.momentum, p.eps, st, st + dim,
+                                                    st + 2 * dim, n, dim, stream)))
         return rc;
       if (!(fuse && !last))
         rc = pgnn_bn_apply_fwd(z, dim, st + 2 * dim, !last, y, dim, drop_p, drop_seed + (uint64_t)l, n, dim, stream);
@@ -512,6 +524,8 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
 
   const float* g = dy;
   int64_t ldg = lddy;
+  bool sums_ready = false;   // the BatchNorm-backward sums of the layer about to run are already folded (in bn_scratch.coef)
+  BnBwdScratch bn_scratch{};
   for (int l = num_layer - 1; l >= 0; --l) {
     const pgnn_gin_layer& p = layers[l];
     const int q = num_layer - 1 - l;  // index into the transposed weights
@@ -522,8 +536,15 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     const float* z = a + nd;
     const float* hd = hid + (size_t)l * 2 * nd;
     const float* mean = stats + (size_t)l * 4 * dim;
-    if ((rc = pgnn_bn_bwd(g, ldg, z, dim, p.gamma, p.beta, mean, mean + dim, training, l != num_layer - 1, dz[b], dim,
-                          p.dgamma, p.dbeta, drop_p, drop_seed + (uint64_t)l, n, dim, op, opb, main))) return rc;
+    // BatchNorm backward.  Below the top layer its column sums came out of the aggregation that produced g (the layer above's
+    // transposed aggregation, neighbor_sum_bn_bwd below): only the elementwise pass is left.
+    if (sums_ready)
+      rc = bn_bwd_apply_only(g, ldg, z, dim, bn_scratch.coef, l != num_layer - 1, dz[b], dim, n, dim, main);
+    else
+      rc = pgnn_bn_bwd(g, ldg, z, dim, p.gamma, p.beta, mean, mean + dim, training, l != num_layer - 1, dz[b], dim, p.dgamma, p.dbeta,
+                       drop_p, drop_seed + (uint64_t)l, n, dim, op, opb, main);
+    if (rc) return rc;
+    sums_ready = false;
     if (wait_fork2) {
       PGNN_HIP(hipStreamWaitEvent(main, sd->fork[2], 0));
       wait_fork2 = false;
@@ -547,8 +568,21 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     const bool demb_on_main = sd && l == 0;
     // The caller's stream is the critical path: its transposed aggregation is enqueued BEFORE the side stream's five launches
     // (it reads dagg, which they only read, and writes dx, which they never touch), so that stream is never waiting for the host.
+    // the transposed aggregation; for l > 0 its launch also leaves the BatchNorm-backward sums of layer l - 1 (whose output
+    // gradient it is writing) in the caller's op scratch -- folded, as pgnn_bn_bwd's first launch would
+    auto aggregate_t = [&]() -> int {
+      if (l > 0 && drop_p == 0.f) {
+        const pgnn_gin_layer& q1 = layers[l - 1];
+        const float* st1 = stats + (size_t)(l - 1) * 4 * dim;
+        BnBwdTail tail{acts + (size_t)(l - 1) * 3 * nd + nd, dim, q1.gamma, q1.beta, st1, st1 + dim, 1, training, BnBwdScratch{}, q1.dgamma, q1.dbeta};
+        if (int r = bn_bwd_scratch(op, opb, n, dim, &tail.scratch)) return r;
+        bn_scratch = tail.scratch;
+        return neighbor_sum_bn_bwd(dagg[b], dim, out_ptr, out_dst, dxb[b], dim, n, dim, tail, &sums_ready, main);
+      }
+      return pgnn_neighbor_sum(dagg[b], dim, out_ptr, out_dst, nullptr, dxb[b], dim, n, dim, main);
+    };
     if (sd) {
-      if ((rc = pgnn_neighbor_sum(dagg[b], dim, out_ptr, out_dst, nullptr, dxb[b], dim, n, dim, main))) return rc;
+      if ((rc = aggregate_t())) return rc;
       if (demb_on_main && (rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, op, opb, main))) return rc;
       PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[1], 0));
     }
@@ -557,7 +591,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
       return rc;
     if (!demb_on_main && (rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, aux_ws, opb, aux))) return rc;
     if (sd && !per_layer && l >= 2) PGNN_HIP(hipEventRecord(sd->lag[b], aux));  // awaited by layer l-2 only
-    if (!sd && (rc = pgnn_neighbor_sum(dagg[b], dim, out_ptr, out_dst, nullptr, dxb[b], dim, n, dim, main))) return rc;
+    if (!sd && (rc = aggregate_t())) return rc;
     g = dxb[b];
     ldg = dim;
   }

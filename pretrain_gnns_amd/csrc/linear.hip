@@ -21,6 +21,7 @@
 
 #include <type_traits>
 
+#include "bn_fold.h"
 #include "common.h"
 
 namespace pgnn {
@@ -51,6 +52,7 @@ struct GemmArgs {
   int64_t ldbp, bplane;      //           row pitch and plane pitch in bf16 elements
   const uint32_t* a_amax;    // k_gemm2pw, optional: [M] bit patterns of max |A[m, :]| (from the producer of A); NULL = taken in the kernel
   uint32_t* c_amax;          // k_gemm2pw, optional: [M] words, zero before the launch: receives max |C[m, :]| (atomic max of the tiles)
+  BnFwdFold bnf;             // k_gemm2pw, EPI_BIAS, bnf.n > 0: the statistics of the BatchNorm behind C, folded in this launch (bn_fold.h)
 };
 
 enum { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_MASK = 2 };
@@ -413,7 +415,7 @@ struct KMajorTile {
 // backward-data (dy k-contiguous, W row-contiguous), backward-weight (both row-contiguous, split over k = rows, optional
 // ones column for the bias gradient).
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES>
-__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3(GemmArgs p) {
+__device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x, const int grid_x) {
   constexpr int BK = 32;
   constexpr int NW = WAVES_M * WAVES_N, T = 64 * NW;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -430,7 +432,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3(GemmArgs p) {
   unsigned char* const ldsB = smem3 + 3 * PA;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_n = (p.N + (ONES ? 4 : 0) + BN - 1) / BN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x, p.nxcd);
+  const int tile = xcd_remap(block_x, grid_x, p.nxcd);
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
   const int kbeg = blockIdx.y * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
@@ -583,6 +585,24 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3(GemmArgs p) {
   }
   if constexpr (EPI == EPI_MASK) gemm_epilogue_pre<EPI, ONES, MI, NI, MI>(p, acc, m0 + wm0, n0 + wn0, lane, mk);
   else gemm_epilogue<EPI, ONES, MI, NI>(p, acc, m0 + wm0, n0 + wn0, lane);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3(GemmArgs p) {
+  gemm3_body<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, blockIdx.x, gridDim.x);
+}
+// Two products of one shape family in ONE launch (blockIdx.z picks the product; round 4: the two weight gradients of a layer --
+// twice the tiles per launch, so half the splits over the contracted rows: half the partial matrices to write and to fold, and a
+// workgroup's pipeline fill paid once per 17 k-steps instead of once per 9)
+struct GemmArgs2 {
+  GemmArgs a[2];
+  int tiles[2];
+};
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3_pair(GemmArgs2 q) {
+  const int z = blockIdx.z;
+  if ((int)blockIdx.x >= q.tiles[z]) return;
+  gemm3_body<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES>(q.a[z], blockIdx.x, q.tiles[z]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1586,6 +1606,45 @@ int pgnn_linear_bwd_weight_pair(const float* dy_a, int64_t lddy_a, const float* 
   hipStream_t st = (hipStream_t)stream;
   ReduceJobs jobs;
   int rc;
+  // both products in one launch of 64x160 tiles (k_gemm3_pair) where the single products would take that tile and split:
+  // PGNN_DW_PAIR=0 = two launches (round 3; bit-identical to two pgnn_linear_bwd_weight calls)
+  if (weight_split(m) && m < kWeightBigRows && db_a && db_b && env_knob("PGNN_DW_PAIR", 1) != 0) {
+    const int64_t tiles_a = ceil_div(n_a, 64) * ceil_div(k_a + 4, 160), tiles_b = ceil_div(n_b, 64) * ceil_div(k_b + 4, 160);
+    int64_t splits = ceil_div(2 * num_cu(), tiles_a + tiles_b);
+    splits = std::max<int64_t>(std::min<int64_t>(splits, std::max<int64_t>(m / (4 * 32), 1)), 1);
+    const int64_t chunk = ceil_div(ceil_div(m, splits), 32) * 32;
+    const int used = (int)ceil_div(m, chunk);
+    if (used > 1 && (size_t)used * (n_a * k_a + n_a) * sizeof(float) <= wa && (size_t)used * (n_b * k_b + n_b) * sizeof(float) <= wb) {
+      GemmArgs2 q{};
+      float* parts[2] = {static_cast<float*>(ws), reinterpret_cast<float*>(static_cast<char*>(ws) + wa)};
+      const float* dys[2] = {dy_a, dy_b};
+      const float* xs[2] = {x_a, x_b};
+      const int64_t lddys[2] = {lddy_a, lddy_b}, ldxs[2] = {ldx_a, ldx_b}, ks[2] = {k_a, k_b}, ns[2] = {n_a, n_b};
+      float* dws[2] = {dw_a, dw_b};
+      float* dbs[2] = {db_a, db_b};
+      for (int z = 0; z < 2; ++z) {
+        GemmArgs& p = q.a[z];
+        p.nxcd = num_xcd();
+        p.A = dys[z]; p.lda = lddys[z]; p.B = xs[z]; p.ldb = ldxs[z];
+        p.M = (int)ns[z]; p.N = (int)ks[z]; p.K = (int)m;
+        p.kchunk = (int)chunk;
+        p.C = parts[z]; p.ldc = ks[z];
+        p.split_stride = ns[z] * ks[z] + ns[z];
+        p.colsum = parts[z] + ns[z] * ks[z];
+        jobs.j[z] = ReduceJob{parts[z], used, ns[z] * ks[z] + ns[z], dws[z], ns[z] * ks[z] / 4, dbs[z], ns[z] / 4};
+      }
+      q.tiles[0] = (int)tiles_a; q.tiles[1] = (int)tiles_b;
+      using TA = RowMajorTile<64>;
+      using TB = RowMajorTile<160>;
+      constexpr size_t lds = (size_t)3 * (TA::PLANE + TB::PLANE);
+      allow_big_lds((const void*)k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true>, lds);
+      hipLaunchKernelGGL((k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true>), dim3((int)std::max(tiles_a, tiles_b), used, 2), dim3(512), lds,
+                         st, q);
+      const int64_t work = std::max(jobs.j[0].n4a + jobs.j[0].n4b, jobs.j[1].n4a + jobs.j[1].n4b);
+      hipLaunchKernelGGL(k_splitk_reduce_jobs, dim3((int)std::min<int64_t>(ceil_div(work, 256), 1024), 2), dim3(256), 0, st, jobs);
+      return check_launch("linear_bwd_weight_pair");
+    }
+  }
   if ((rc = weight_product(dy_a, lddy_a, x_a, ldx_a, dw_a, db_a, m, k_a, n_a, ws, st, jobs.j[0]))) return rc;
   if ((rc = weight_product(dy_b, lddy_b, x_b, ldx_b, dw_b, db_b, m, k_b, n_b, static_cast<char*>(ws) + wa, st, jobs.j[1]))) return rc;
   if (jobs.j[0].used > 1 && jobs.j[1].used > 1) {  // both split (the same m: they split together in practice)
@@ -1939,6 +1998,9 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
   float cmax[MI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) cmax[i] = 0.f;
+  const bool fold_stats = EPI == EPI_BIAS && p.bnf.n > 0;  // (uniform) the BatchNorm statistics of C are folded in this launch
+  float* const elds = reinterpret_cast<float*>(smem2p);     // [BM / 16][2][BN]: the ring is free once every wave has left the k-loop
+  if (fold_stats) __syncthreads();
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int n = n0 + wn0 + j * 16 + fk * 4;
@@ -1953,7 +2015,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
         if (p.relu) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        if (p.colstat) {  // (uniform) per-16-row-block column sums and squared deviations, as in k_gemm3w
+        if (p.colstat || fold_stats) {  // (uniform) per-16-row-block column sums and squared deviations, as in k_gemm3w
           const int cnt = min(16, p.M - mb);
           if (cnt > 0) {
             const bool ok = fr < cnt;
@@ -1965,9 +2027,15 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
             q.z = ok ? v.z - sm.z * inv : 0.f; q.w = ok ? v.w - sm.w * inv : 0.f;
             q.x = row16_sum(q.x * q.x); q.y = row16_sum(q.y * q.y); q.z = row16_sum(q.z * q.z); q.w = row16_sum(q.w * q.w);
             if (fr == 0 && n < p.N) {
-              float* cs = p.colstat + (int64_t)(mb >> 4) * 2 * p.N + n;
-              *reinterpret_cast<float4*>(cs) = sm;
-              *reinterpret_cast<float4*>(cs + p.N) = q;
+              if (fold_stats) {  // into the tile's LDS image: merged below, inside this launch
+                float* e = elds + ((wm0 / 16 + i) * 2) * BN + (wn0 + j * 16 + fk * 4);
+                *reinterpret_cast<float4*>(e) = sm;
+                *reinterpret_cast<float4*>(e + BN) = q;
+              } else {
+                float* cs = p.colstat + (int64_t)(mb >> 4) * 2 * p.N + n;
+                *reinterpret_cast<float4*>(cs) = sm;
+                *reinterpret_cast<float4*>(cs + p.N) = q;
+              }
             }
           }
         }
@@ -1998,6 +2066,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
       const int m = m0 + wm0 + i * 16 + fr;
       if (fk == 0 && m < p.M) atomicMax(p.c_amax + m, __float_as_uint(v));
     }
+  }
+  if constexpr (EPI == EPI_BIAS) {
+    if (fold_stats)
+      bn_fwd_fold_tile<BM, BN>(p.bnf, elds, tile / tiles_n, (p.M + BM - 1) / BM, tile % tiles_n, m0, n0, p.M, p.N, tid, 64 * NW);
   }
 }
 
@@ -2049,7 +2121,7 @@ int split_weights_2p(const float* const* src, void* const* dst, const int64_t* r
 }
 
 int linear_fwd_wp_2p(const float* x, int64_t ldx, const void* wplanes, const float* bias, float* y, int64_t ldy, int64_t m, int64_t k,
-                     int64_t n, int relu, float* colstat, hipStream_t st, const uint32_t* x_amax, uint32_t* y_amax) {
+                     int64_t n, int relu, float* colstat, hipStream_t st, const uint32_t* x_amax, uint32_t* y_amax, const BnFwdFold* bnf) {
   PGNN_REQUIRE(m > 0 && k > 0 && n > 0 && k % 4 == 0 && n % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && wplanes,
                "linear_fwd_2p: K, N and the leading dimensions must be multiples of 4");
   GemmArgs p{};
@@ -2058,6 +2130,10 @@ int linear_fwd_wp_2p(const float* x, int64_t ldx, const void* wplanes, const flo
   p.Bp = static_cast<const unsigned short*>(wplanes); p.ldbp = ceil_div(k, 32) * 32; p.bplane = n * p.ldbp;
   p.M = (int)m; p.N = (int)n; p.K = (int)k; p.bias = bias; p.relu = relu; p.kchunk = (int)k; p.split_stride = 0;
   p.colstat = colstat; p.a_amax = x_amax; p.c_amax = y_amax;
+  if (bnf) {
+    PGNN_REQUIRE(bnf->n == m && bnf->part && bnf->gpart && bnf->tickets && ceil_div(n, 160) <= kFwdFoldPanels, "linear_fwd_2p: bad statistics fold");
+    p.bnf = *bnf;
+  }
   return launch_gemm2pw<EPI_BIAS>(p, st);
 }
 
@@ -2084,7 +2160,7 @@ int pgnn_split_weights_2p(const float* const* src, void* const* dst, const int64
 }
 int pgnn_linear_fwd_2p(const float* x, int64_t ldx, const uint32_t* x_amax, const void* wplanes2, const float* bias, float* y, int64_t ldy,
                        int64_t m, int64_t k, int64_t n, int relu, float* colstat, uint32_t* y_amax, pgnn_stream stream) {
-  return pgnn::linear_fwd_wp_2p(x, ldx, wplanes2, bias, y, ldy, m, k, n, relu, colstat, (hipStream_t)stream, x_amax, y_amax);
+  return pgnn::linear_fwd_wp_2p(x, ldx, wplanes2, bias, y, ldy, m, k, n, relu, colstat, (hipStream_t)stream, x_amax, y_amax, nullptr);
 }
 int pgnn_linear_bwd_data_2p(const float* dy, int64_t lddy, const uint32_t* dy_amax, const void* wtplanes2, const float* relu_out, int64_t ldr,
                             float* dx, int64_t lddx, int64_t m, int64_t k, int64_t n, uint32_t* dx_amax, pgnn_stream stream) {

@@ -630,6 +630,11 @@ def test_one_call_network_equals_per_layer_path(graphs, layers, training, monkey
     # ... on THREE bf16 planes: the default since round 4, two fp16 planes + row scales, is a different (equally accurate) arithmetic
     # -- test_one_call_network_on_two_planes_against_the_per_layer_path holds that pairing to fp32 rounding
     monkeypatch.setenv("PGNN_GEMM_2P", "0")
+    # ... and with the BatchNorm-backward column sums taken by a pass of their own, as the per-layer path takes them: the one-call
+    # backward's default (round 4) takes them in the transposed aggregation's epilogue, in another (fixed) order of the rows --
+    # test_batchnorm_backward_sums_from_the_transposed_aggregation holds that pairing to fp32 rounding
+    monkeypatch.setenv("PGNN_BN_BWD_IN_AGG", "0")
+    monkeypatch.setenv("PGNN_DW_PAIR", "0")  # ... and the two weight gradients of a layer as two launches (one launch: half the splits over the rows)
     ops.load().pgnn_reload_env()
     _, a = _pair(ochem.GNN, hchem.GNN, layers, 300, seed=5)
     b = copy.deepcopy(a)
@@ -693,6 +698,46 @@ def test_one_call_network_on_weight_planes_below_the_split_threshold(graphs, two
         assert d <= 2e-2 * float(res[1][1][k].double().norm()) + 1e-4 * top, k
 
 
+@pytest.mark.parametrize("graphs,training", [(256, True), (64, True), (3, True), (200, False), (1400, True)])
+def test_batchnorm_backward_sums_from_the_transposed_aggregation(graphs, training, monkeypatch):
+    """one-call chem GIN backward (chem/model.py:269-275 under autograd): below the top layer the column sums of the BatchNorm
+    backward -- sum of dyr and of dyr * xhat over the rows -- come out of the transposed aggregation that writes dy
+    (k_aggregate_dma's TAIL, csrc/aggregate.hip), folded in the same launch; PGNN_BN_BWD_IN_AGG=0 takes them by the pass of their
+    own (k_bn_bwd_partial).  Same forward bit for bit; every gradient -- dgamma / dbeta are those sums themselves -- equal to fp32
+    rounding of sums taken in another order; and the fused form is deterministic (three runs, bit-equal)."""
+    import copy
+    from pretrain_gnns_amd import ops
+    hchem, _ = _hip()
+    _, a = _pair(ochem.GNN, hchem.GNN, 5, 300, seed=15)
+    b = copy.deepcopy(a)
+    a.train(training), b.train(training)
+    d = hostdata.chem_masking_batch(graphs, seed=16).to(DEV)
+    w = torch.randn(d.x.size(0), 300, device=DEV)
+    res = []
+    for m, flag in ((a, "1"), (b, "0"), (a, "1"), (a, "1")):
+        monkeypatch.setenv("PGNN_BN_BWD_IN_AGG", flag)
+        ops.load().pgnn_reload_env()
+        m.zero_grad()
+        out = m(d.x, d.edge_index, d.edge_attr)
+        (out * w).sum().backward()
+        res.append((out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+        if training and len(res) == 2:
+            a.load_state_dict(b.state_dict())  # (same running statistics before the repeats; they do not enter a training-mode pass anyway)
+    if not training:
+        assert torch.equal(res[0][0], res[1][0])
+    else:
+        assert torch.equal(res[0][0], res[1][0])  # (the first pass of two identical copies)
+    top = max(float(g.abs().max()) for g in res[1][1].values())
+    for k, g in res[1][1].items():
+        assert bool(torch.isfinite(res[0][1][k]).all()), k
+        if float(g.abs().max()) < 1e-3 * top:
+            continue  # (a bias in front of a BatchNorm: its gradient is zero up to rounding -- pure summation-order noise)
+        dnorm = float((res[0][1][k] - g).double().norm())
+        assert dnorm <= 1e-4 * float(g.double().norm()) + 1e-6 * top, (k, dnorm, float(g.double().norm()))
+    for k in res[0][1]:
+        assert torch.equal(res[2][1][k], res[3][1][k]), k  # deterministic
+
+
 @pytest.mark.parametrize("graphs", [4, 256])
 def test_num_batches_tracked_is_counted_inside_the_stack_call(graphs):
     """nn.BatchNorm1d.forward adds one to num_batches_tracked per training-mode forward; the one-call GIN networks do it inside
@@ -754,6 +799,42 @@ def test_batchnorm_statistics_from_the_gemm_epilogue_match_the_separate_pass(gra
             torch.testing.assert_close(res[0][2][k], res[1][2][k], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("graphs", [64, 256, 700, 1200])
+def test_batchnorm_statistics_folded_inside_the_product_launch(graphs, monkeypatch):
+    """one-call chem network, training mode: the per-16-row-block statistics of z = the second product's result are merged inside
+    that product's launch (tile through LDS, groups of 16 row tiles by the last tile to arrive, the column panel by the last group:
+    bn_fold.h; round 4, the default on two planes) against PGNN_BN_STATS_FOLD=0, the launch of its own that merges the same blocks
+    (k_bn_stats_final_blocks).  The same blocks merged in another association order, in float64: save_mean / invstd and the
+    running statistics to a few fp32 ulps, the forward output to fp32 rounding carried through five layers; deterministic."""
+    import copy
+    from pretrain_gnns_amd import ops
+    hchem, _ = _hip()
+    _, a = _pair(ochem.GNN, hchem.GNN, 5, 300, seed=18)
+    b = copy.deepcopy(a)
+    d = hostdata.chem_masking_batch(graphs, seed=19).to(DEV)
+    assert int(ops.load().pgnn_linear_wp_preferred(d.x.size(0), 600, 300)) == 1
+    res = []
+    for m, flag in ((a, "1"), (b, "0"), (copy.deepcopy(b), "1")):
+        monkeypatch.setenv("PGNN_BN_STATS_FOLD", flag)
+        ops.load().pgnn_reload_env()
+        if len(res) == 2:
+            m.load_state_dict(res[0][2])  # the third run repeats the first from the first's initial state
+        state0 = copy.deepcopy(m.state_dict())
+        m.train()
+        with torch.no_grad():
+            out = m(d.x, d.edge_index, d.edge_attr)
+        res.append((out.clone(), {k: v.clone() for k, v in m.named_buffers()}, state0))
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=2e-5, atol=2e-5)
+    for k in res[0][1]:
+        if res[0][1][k].is_floating_point():
+            torch.testing.assert_close(res[0][1][k], res[1][1][k], rtol=2e-6, atol=1e-7)
+        else:
+            assert torch.equal(res[0][1][k], res[1][1][k]), k  # num_batches_tracked
+    assert torch.equal(res[0][0], res[2][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[2][1][k]), k
+
+
 @pytest.mark.parametrize("graphs,layers", [(48, 5), (1500, 5), (3, 2)])
 def test_transposed_backward_data_matches_the_fp32_mfma_backward(graphs, layers, monkeypatch):
     """one-call backward with backward-data on pre-transposed weights (forward split-bf16 kernel, pgnn_linear_bwd_data_t)
@@ -813,6 +894,42 @@ def test_one_call_gcn_and_graphsage_equal_per_layer_path(gnn_type, graphs, layer
             assert torch.equal(res[0][1][k], res[1][1][k]), k
     for k in res[0][2]:
         assert torch.equal(res[0][2][k], res[1][2][k]), k
+
+
+@pytest.mark.parametrize("graphs", [64, 256, 700, 1200])
+def test_batchnorm_statistics_folded_inside_the_product_launch(graphs, monkeypatch):
+    """one-call chem network, training mode: the per-16-row-block statistics of z = the second product's result are merged inside
+    that product's launch (tile through LDS, groups of 16 row tiles by the last tile to arrive, the column panel by the last group:
+    bn_fold.h; round 4, the default on two planes) against PGNN_BN_STATS_FOLD=0, the launch of its own that merges the same blocks
+    (k_bn_stats_final_blocks).  The same blocks merged in another association order, in float64: save_mean / invstd and the
+    running statistics to a few fp32 ulps, the forward output to fp32 rounding carried through five layers; deterministic."""
+    import copy
+    from pretrain_gnns_amd import ops
+    hchem, _ = _hip()
+    _, a = _pair(ochem.GNN, hchem.GNN, 5, 300, seed=18)
+    b = copy.deepcopy(a)
+    d = hostdata.chem_masking_batch(graphs, seed=19).to(DEV)
+    assert int(ops.load().pgnn_linear_wp_preferred(d.x.size(0), 600, 300)) == 1
+    res = []
+    for m, flag in ((a, "1"), (b, "0"), (copy.deepcopy(b), "1")):
+        monkeypatch.setenv("PGNN_BN_STATS_FOLD", flag)
+        ops.load().pgnn_reload_env()
+        if len(res) == 2:
+            m.load_state_dict(res[0][2])  # the third run repeats the first from the first's initial state
+        state0 = copy.deepcopy(m.state_dict())
+        m.train()
+        with torch.no_grad():
+            out = m(d.x, d.edge_index, d.edge_attr)
+        res.append((out.clone(), {k: v.clone() for k, v in m.named_buffers()}, state0))
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=2e-5, atol=2e-5)
+    for k in res[0][1]:
+        if res[0][1][k].is_floating_point():
+            torch.testing.assert_close(res[0][1][k], res[1][1][k], rtol=2e-6, atol=1e-7)
+        else:
+            assert torch.equal(res[0][1][k], res[1][1][k]), k  # num_batches_tracked
+    assert torch.equal(res[0][0], res[2][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[2][1][k]), k
 
 
 @pytest.mark.parametrize("graphs,layers", [(48, 5), (1500, 5), (3, 2)])

@@ -540,6 +540,52 @@ def test_products_on_weight_planes(m, k, n, monkeypatch):
     assert errd.max().item() < 2e-6
 
 
+@pytest.mark.parametrize("m", [6747, 2100, 20000])
+def test_weight_gradient_pair_in_one_launch(m, monkeypatch):
+    """pgnn_linear_bwd_weight_pair (the two weight gradients of a GIN layer, dW2 = dz^T hid and dW1 = dhid^T agg with their bias
+    gradients; chem/model.py:29 under loss.backward()): since round 4 ONE launch for both products where each would split over the
+    rows (k_gemm3_pair: twice the tiles, half the splits, half the partial matrices to fold).  Against float64 at the bar of the
+    single products, against two pgnn_linear_bwd_weight calls to fp32 rounding (another split of the same sum), bit-identical to
+    them with PGNN_DW_PAIR=0, and reproducible."""
+    ops = _ops()
+    lib, sp = ops.load(), ops.stream_ptr()
+    torch.manual_seed(m)
+    d = 300
+    dz, hid = (torch.randn(m, d) * 1e-3).to(DEV), torch.relu(torch.randn(m, 2 * d)).to(DEV)
+    dhid, agg = (torch.randn(m, 2 * d) * 1e-3).to(DEV), torch.randn(m, d).to(DEV)
+    nb = lambda k, n: int(lib.pgnn_linear_bwd_weight_workspace_bytes(m, k, n))
+    ws = torch.empty(nb(2 * d, d) + nb(d, 2 * d), dtype=torch.uint8, device=DEV)
+
+    def pair():
+        dw2, db2 = torch.full((d, 2 * d), float("nan"), device=DEV), torch.full((d,), float("nan"), device=DEV)
+        dw1, db1 = torch.full((2 * d, d), float("nan"), device=DEV), torch.full((2 * d,), float("nan"), device=DEV)
+        ops.check(lib.pgnn_linear_bwd_weight_pair(dz.data_ptr(), d, hid.data_ptr(), 2 * d, dw2.data_ptr(), db2.data_ptr(), 2 * d, d,
+                                                  dhid.data_ptr(), 2 * d, agg.data_ptr(), d, dw1.data_ptr(), db1.data_ptr(), d, 2 * d, m,
+                                                  ws.data_ptr(), ws.numel(), sp), "pair")
+        return dw2, db2, dw1, db1
+
+    def singles():
+        dw2, db2 = torch.empty(d, 2 * d, device=DEV), torch.empty(d, device=DEV)
+        dw1, db1 = torch.empty(2 * d, d, device=DEV), torch.empty(2 * d, device=DEV)
+        ops.check(lib.pgnn_linear_bwd_weight(dz.data_ptr(), d, hid.data_ptr(), 2 * d, dw2.data_ptr(), db2.data_ptr(), m, 2 * d, d, ws.data_ptr(), ws.numel(), sp), "single")
+        ops.check(lib.pgnn_linear_bwd_weight(dhid.data_ptr(), 2 * d, agg.data_ptr(), d, dw1.data_ptr(), db1.data_ptr(), m, d, 2 * d, ws.data_ptr(), ws.numel(), sp), "single")
+        return dw2, db2, dw1, db1
+
+    got, again, ref = pair(), pair(), singles()
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)
+    want = (dz.double().t() @ hid.double(), dz.double().sum(0), dhid.double().t() @ agg.double(), dhid.double().sum(0))
+    scale = (dz.double().abs().t() @ hid.double().abs(), dz.double().abs().sum(0), dhid.double().abs().t() @ agg.double().abs(), dhid.double().abs().sum(0))
+    for g, r, w, sc in zip(got, ref, want, scale):
+        assert float(((g.double() - w).abs() / sc).max()) < 2e-6
+        assert float(((r.double() - w).abs() / sc).max()) < 2e-6
+        assert float((g - r).abs().max()) <= 4e-6 * float(sc.max())
+    monkeypatch.setenv("PGNN_DW_PAIR", "0")
+    lib.pgnn_reload_env()
+    for a, b in zip(pair(), ref):
+        assert torch.equal(a, b)
+
+
 # ----------------------------------------------------------------------------- products on two fp16 planes + row scales (round 4)
 def _weight_planes_2p(lib, sp, mats, transpose):
     """pgnn_split_weights_2p on a list of fp32 matrices -> list of (int16 planes [2, rows, ld], float32 inverse scales [rows]) views

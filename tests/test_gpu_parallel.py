@@ -13,6 +13,7 @@ device-side batches.  Checked:
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 
@@ -32,6 +33,11 @@ def _worker(rank, world, port, out_dir):
     import torch.distributed as dist
     import torch.nn.functional as F
 
+    import faulthandler
+    import sys
+    # a rank that stops returning leaves its Python stacks on stderr and exits, instead of sitting out the test's timeout
+    # (one unexplained non-return of the two-rank flow in round 3, one more in round 4)
+    faulthandler.dump_traceback_later(150, exit=True, file=sys.stderr)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0", PGNN_DP_BACKEND="gloo")
     from pretrain_gnns_amd import ops, parallel
@@ -125,7 +131,7 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
+@pytest.mark.timeout(240)
 def test_two_ranks_on_one_gpu(tmp_path):
     import torch.multiprocessing as mp
     port = _free_port()
@@ -148,6 +154,9 @@ def test_two_ranks_on_one_gpu(tmp_path):
 
 
 def _bio_worker(rank, world, port, out_dir):
+    import faulthandler
+    import sys
+    faulthandler.dump_traceback_later(150, exit=True, file=sys.stderr)  # (see _worker)
     """BASELINE configs[4]: bio masking pre-training, data parallel -- the one-call bio GIN network + the edge head through
     AllReduceOptimizers over optim.Adam.shared, ResidentLoader(rank, world) batches with device-side MaskEdge"""
     import numpy as np
@@ -218,7 +227,7 @@ def _bio_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
+@pytest.mark.timeout(240)
 def test_two_ranks_on_one_gpu_bio_masking(tmp_path):
     """BASELINE configs[4] (bio PPI ego-net masking pre-train, DDP): two ranks on one GPU drive the HIP bio stack; ranks start
     and stay bit-identical while training on different shards, run the same number of steps, keep ONE flat bucket, and the sum
@@ -240,6 +249,9 @@ def test_two_ranks_on_one_gpu_bio_masking(tmp_path):
 
 
 def _rccl_single_rank_worker(port, out_path):
+    import faulthandler
+    import sys
+    faulthandler.dump_traceback_later(150, exit=True, file=sys.stderr)  # (see _worker)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", PGNN_DP_FORCE_INIT="1")
     os.environ.pop("PGNN_DP_BACKEND", None)
     import copy
@@ -283,3 +295,54 @@ def test_single_rank_rccl_step_equals_the_plain_step(tmp_path):
     assert res["same"] and res["in_bucket"], res
     assert res["out_a"] == res["out_b"]
     assert res["report"]["backend"] == "nccl" and res["report"]["world"] == 1 and res["report"]["bucket_bytes"] > 7e6
+
+
+def _rccl_two_rank_worker(rank, world, port, out_dir):
+    import faulthandler
+    import sys
+    faulthandler.dump_traceback_later(150, exit=True, file=sys.stderr)
+    import numpy as np
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.pop("PGNN_DP_BACKEND", None)
+    from pretrain_gnns_amd import ops, optim, parallel
+    from pretrain_gnns_amd import train as ptrain
+    from pretrain_gnns_amd.chem import model as hchem
+    from pretrain_gnns_amd.data import resident, synthetic
+
+    r, local, w = parallel.init_from_env()
+    assert (r, w, dist.get_backend()) == (rank, world, "nccl")  # RCCL
+    dev = torch.device("cuda", local)
+    ops.set_direct_grads(True)
+    rng = np.random.default_rng(5)
+    ds = resident.ResidentDataset.from_graphs([synthetic.zinc_like_graph(rng) for _ in range(64)], dev)
+    torch.manual_seed(100 + rank)
+    mods = [hchem.GNN(5, 300).to(dev), torch.nn.Linear(300, 119).to(dev), torch.nn.Linear(300, 4).to(dev)]
+    parallel.broadcast_parameters(mods)
+    opts = parallel.AllReduceOptimizers(optim.Adam.shared([m.parameters() for m in mods], lr=1e-3))
+    loader = resident.ResidentLoader(ds, 16, shuffle=True, seed=9, mask_rate=0.15, rank=rank, world_size=world)
+    for m in mods:
+        m.train()
+    losses = [ptrain.chem_masking_step(mods, list(opts), batch)[0] for _ in range(2) for batch in loader]
+    torch.save({"losses": losses, "params": [p.detach().cpu().clone() for m in mods for p in m.parameters()],
+                "comm": parallel.comm_report(opts, iters=3)}, os.path.join(out_dir, "rccl_rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+def test_rccl_two_ranks(tmp_path):
+    """two processes, two GPUs, backend "nccl" (= RCCL over xGMI): the data-parallel masking step of bench.py --gpus N -- broadcast
+    of the initial parameters, one flat all-reduce (AVG) per step through parallel.AllReduceOptimizers, identical Adam on both
+    ranks.  Skipped on a one-GPU box (there the same layer runs on gloo with both ranks on one device, above); on a multi-GPU box
+    this exercises RCCL through pytest before bench.py does."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_rccl_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "rccl_rank0.pt"), torch.load(tmp_path / "rccl_rank1.pt")
+    assert len(r0["losses"]) == len(r1["losses"]) > 0 and all(np.isfinite(l) for l in r0["losses"] + r1["losses"])
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)  # ranks stay bit-identical: same bucket after the all-reduce, same Adam
+    assert r0["comm"]["backend"] == "nccl" and r0["comm"]["world"] == 2
