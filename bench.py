@@ -447,8 +447,10 @@ def resident_loader_leg(dev, args, steps_n):
 
 
 def roofline_mlp(dev, rows):
-    """time the forward GEMM of the GIN mlp (first Linear 300->600 + bias + ReLU) alone: the split-bf16 kernel the
-    product path runs, and the fp32-MFMA kernel (PGNN_GEMM_SPLIT=0) that keeps the smallest shapes."""
+    """time the forward product of the GIN mlp (first Linear 300->600 + bias + ReLU) alone at a large row count: the kernel the
+    one-call networks run there since round 4 (two fp16 planes + row scales, k_gemm2pw), with the split-bf16 kernel of
+    pgnn_linear_fwd (three bf16 planes, k_gemm3: rounds 2-3) and the fp32-MFMA kernel (PGNN_GEMM_SPLIT=0, which keeps the
+    smallest shapes) beside it.  Fractions against the planes' own ceiling (dense fp16 MFMA peak / 3) AND the fp32 MFMA peak."""
     import os
     from pretrain_gnns_amd import ops
 
@@ -458,12 +460,18 @@ def roofline_mlp(dev, rows):
     b = torch.randn(600, device=dev)
     y = torch.empty(rows, 600, device=dev)
     lib, sp = ops.load(), ops.stream_ptr()
+    (p2,) = ops.weight_planes_2p([w])
+
+    def launch2p():
+        ops.linear_fwd_2p(x, p2, b, 600, relu=True, out=y)
 
     def launch():
         ops.check(lib.pgnn_linear_fwd(x.data_ptr(), 300, w.data_ptr(), b.data_ptr(), y.data_ptr(), 600, rows, 300, 600,
                                       1, sp), "linear")
 
     flops = 2.0 * rows * 300 * 600
+    ms2, per2, iters2 = steady_state_ms(launch2p, iters=30)
+    tf2 = flops / (ms2 * 1e-3) / 1e12
     ms, per, iters = steady_state_ms(launch, iters=30)
     tf = flops / (ms * 1e-3) / 1e12
     prev = os.environ.get("PGNN_GEMM_SPLIT")
@@ -478,17 +486,21 @@ def roofline_mlp(dev, rows):
             os.environ["PGNN_GEMM_SPLIT"] = prev
         lib.pgnn_reload_env()
     tf32 = flops / (ms32 * 1e-3) / 1e12
-    split_peak = MFMA_BF16_PEAK_TF / 6.0
+    planes_peak, split_peak = MFMA_BF16_PEAK_TF / 3.0, MFMA_BF16_PEAK_TF / 6.0
     return {"bound": "mfma",
-            "kernel": "k_gemm3<128,160,4,2,true,true,EPI_BIAS,false> (pgnn_linear_fwd 300->600: fp32 values as three bf16 terms, six "
-                      "v_mfma_f32_16x16x32_bf16 products per k-step, fp32 accumulate; error vs float64 not above the fp32-MFMA "
-                      "kernel's, tests/test_gpu_ops.py)",
-            "achieved": round(tf, 2), "peak": round(split_peak, 1), "unit": "TFLOP/s (fp32-equivalent)",
-            "frac": round(tf / split_peak, 4),
-            "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / 6 products per fp32 product; the fp32 MFMA peak is %.1f, of which "
-                         "this kernel reaches %.3f" % (MFMA_F32_PEAK_TF, tf / MFMA_F32_PEAK_TF),
-            "ms_per_launch": round(ms, 4), "ms_per_launch_std": round(float(per.std()), 4), "launches_timed": iters,
+            "kernel": "k_gemm2pw<128,160,8,1,3,EPI_BIAS> (pgnn_linear_fwd_2p 300->600: fp32 values as two fp16 planes under a "
+                      "power-of-two scale per row, three v_mfma_f32_16x16x32_f16 products per k-step, fp32 accumulate; the row maxima taken "
+                      "by every workgroup in front of its k-loop; error vs float64 at the fp32-MFMA kernel's, tests/test_gpu_ops.py)",
+            "achieved": round(tf2, 2), "peak": round(planes_peak, 1), "unit": "TFLOP/s (fp32-equivalent)",
+            "frac": round(tf2 / planes_peak, 4), "frac_of_fp32_mfma_peak": round(tf2 / MFMA_F32_PEAK_TF, 4),
+            "peak_note": "dense fp16 MFMA peak 2500 TFLOP/s / 3 products per fp32 product = 833; the fp32 MFMA peak is %.1f" % MFMA_F32_PEAK_TF,
+            "ms_per_launch": round(ms2, 4), "ms_per_launch_std": round(float(per2.std()), 4), "launches_timed": iters2,
             "rows": rows,
+            "three_plane_kernel": {"kernel": "k_gemm3<128,160,4,2,true,true,EPI_BIAS,false> (pgnn_linear_fwd: three bf16 terms, six products; "
+                                             "the per-op entry point's kernel and round 3's roofline_mlp)",
+                                   "achieved": round(tf, 2), "peak": round(split_peak, 1), "frac": round(tf / split_peak, 4),
+                                   "frac_of_fp32_mfma_peak": round(tf / MFMA_F32_PEAK_TF, 4),
+                                   "ms_per_launch": round(ms, 4), "ms_per_launch_std": round(float(per.std()), 4), "launches_timed": iters},
             "fp32_mfma_kernel": {"kernel": "k_gemm<64,160,4,2,true,true,EPI_BIAS> (v_mfma_f32_16x16x4_f32; PGNN_GEMM_SPLIT=0; products "
                                            "below ~160 tiles still run this template)",
                                  "achieved": round(tf32, 2), "peak": MFMA_F32_PEAK_TF, "frac": round(tf32 / MFMA_F32_PEAK_TF, 4),
@@ -496,30 +508,36 @@ def roofline_mlp(dev, rows):
 
 
 def roofline_mlp_planes(dev, rows, what):
-    """the two forward products of one GIN mlp (300->600 + ReLU, 600->300) at `rows` rows on pre-split weight planes -- what the
-    one-call networks run from ~1 500 to 65 536 rows (csrc/linear.hip k_gemm3w) -- each timed alone in the steady state, against
-    the split-bf16 ceiling (dense bf16 MFMA peak / 6 products per fp32 product)"""
+    """the two forward products of one GIN mlp (300->600 + ReLU, 600->300) at `rows` rows as the one-call networks run them since
+    round 4 -- weights pre-split into two fp16 planes under a power-of-two scale per row, activations DMA'd as fp32 and split by the
+    consuming wave under their own row scales (the second product takes the row maxima the first one's epilogue left), three
+    v_mfma_f32_16x16x32_f16 per accumulator (csrc/linear.hip k_gemm2pw) -- each timed alone in the steady state.  Fractions
+    against BOTH ceilings: the fp32 MFMA peak (157.3: what an fp32 product may cost at best without the
+    planes) and the planes' own ceiling, dense fp16 MFMA peak / 3 products per fp32 product (833)."""
     from pretrain_gnns_amd import ops
 
     torch.manual_seed(0)
     x = torch.randn(rows, 300, device=dev)
     w1, b1 = torch.randn(600, 300, device=dev) * 0.05, torch.randn(600, device=dev)
     w2, b2 = torch.randn(300, 600, device=dev) * 0.05, torch.randn(300, device=dev)
-    p1, p2 = ops.weight_planes([w1, w2])
+    p1, p2 = ops.weight_planes_2p([w1, w2])
     hid = torch.empty(rows, 600, device=dev)
     z = torch.empty(rows, 300, device=dev)
-    split_peak = MFMA_BF16_PEAK_TF / 6.0
+    amax = torch.zeros(rows, dtype=torch.int32, device=dev)
+    ops.linear_fwd_2p(x, p1, b1, 600, relu=True, out=hid, y_amax=amax)
+    planes_peak = MFMA_BF16_PEAK_TF / 3.0
     flops = 2.0 * rows * 300 * 600
-    out = {"bound": "mfma", "rows": rows, "what": what, "peak": round(split_peak, 1), "unit": "TFLOP/s (fp32-equivalent)",
-           "kernel": "k_gemm3w (pgnn_linear_fwd_wp: weights pre-split into three bf16 planes once per pass, activations DMA'd as fp32 "
-                     "and split by the consuming wave, six v_mfma_f32_16x16x32_bf16 per 16x16x32 block, fp32 accumulate; bit-identical "
-                     "to the split-bf16 kernel of pgnn_linear_fwd)"}
-    for tag, fn in (("300_to_600", lambda: ops.linear_fwd_wp(x, p1, b1, 600, relu=True, out=hid)),
-                    ("600_to_300", lambda: ops.linear_fwd_wp(hid, p2, b2, 300, out=z))):
+    out = {"bound": "mfma", "rows": rows, "what": what, "peak": round(planes_peak, 1), "peak_fp32_mfma": MFMA_F32_PEAK_TF,
+           "unit": "TFLOP/s (fp32-equivalent)",
+           "kernel": "k_gemm2pw (pgnn_linear_fwd_2p: two fp16 planes + power-of-two row scales per operand, three "
+                     "v_mfma_f32_16x16x32_f16 per 16x16x32 block, fp32 accumulate; error against float64 at the fp32-MFMA kernel's, "
+                     "tests/test_gpu_ops.py::test_products_on_two_fp16_planes_against_float64)"}
+    for tag, fn in (("300_to_600", lambda: ops.linear_fwd_2p(x, p1, b1, 600, relu=True, out=hid)),
+                    ("600_to_300", lambda: ops.linear_fwd_2p(hid, p2, b2, 300, out=z, x_amax=amax))):
         ms, per, iters = steady_state_ms(fn, warm_s=0.05, iters=50)
         tf = flops / (ms * 1e-3) / 1e12
-        out[tag] = {"achieved": round(tf, 2), "frac": round(tf / split_peak, 4), "ms_per_launch": round(ms, 5),
-                    "ms_per_launch_std": round(float(per.std()), 5), "launches_timed": iters}
+        out[tag] = {"achieved": round(tf, 2), "frac": round(tf / planes_peak, 4), "frac_of_fp32_mfma_peak": round(tf / MFMA_F32_PEAK_TF, 4),
+                    "ms_per_launch": round(ms, 5), "ms_per_launch_std": round(float(per.std()), 5), "launches_timed": iters}
     return out
 
 
@@ -667,13 +685,13 @@ def bio_leg(dev, args, steps_n, with_cpu):
         cores = usable_cores()
         torch.set_num_threads(cores)
         from oracle import hostdata
-        hb = hostdata.bio_masking_batch(64, seed=0)
+        hb = hostdata.bio_masking_batch(256, seed=0)  # the GPU leg's batch size (64 graphs before)
         torch.manual_seed(0)
         om = [obio.GNN(5, 300), torch.nn.Linear(300, 7)]
         oo = [torch.optim.Adam(m.parameters(), lr=1e-3) for m in om]
         rate, k, el = _cpu_sample(lambda: osteps.bio_masking_step(om, oo, hb), hb.edge_index.size(1), max(2.0, args.cpu_seconds / 3), 50)
         out["cpu_baseline"] = {"value": round(rate, 1), "unit": "edges/s", "cores": cores, "cpu": host_cpu_model(), "kind": "port",
-                               "sample": "%d bio masking train steps of the torch-CPU oracle on one 64-graph batch (%d edges), %.1f s"
+                               "sample": "%d bio masking train steps of the torch-CPU oracle on one 256-graph batch (%d edges), %.1f s"
                                          % (k, hb.edge_index.size(1), el)}
     return out
 
@@ -706,6 +724,10 @@ def bio_roofline(dev, ds=None, num_graphs=1024):
                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                        "ms_per_launch": round(ms, 4), "ms_per_launch_std": round(float(per.std()), 4),
                        "algorithmic_bytes_per_launch": int(alg), "nodes": n, "edges": e,
+                       # the same launch priced on what this implementation must move (3644 N + 4 E) and on what it did move (PMC)
+                       "own_compulsory_bytes_per_launch": int(3644.0 * n + 4.0 * e),
+                       "frac_on_own_bytes": round((3644.0 * n + 4.0 * e) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       "frac_on_traffic": round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                        "note": "3604 N + 40 E (SURVEY 8d) counts the fp32 [E,9] attributes a layer would read; this implementation reads "
                                "them once per batch (per-node feature sums), so a layer moves 3600 N + 4 E + 40 N bytes"}
 

@@ -1634,6 +1634,10 @@ int pgnn_linear_bwd_weight_pair(const float* dy_a, int64_t lddy_a, const float* 
         jobs.j[z] = ReduceJob{parts[z], used, ns[z] * ks[z] + ns[z], dws[z], ns[z] * ks[z] / 4, dbs[z], ns[z] / 4};
       }
       q.tiles[0] = (int)tiles_a; q.tiles[1] = (int)tiles_b;
+      // (Measured and NOT kept, profiles/r04/wgrad2p_and_ctx_two_streams_ab.txt: the same launch on two fp16 planes under column
+      // scales that every workgroup takes from its own chunk of rows in a pass in front of its k-loop, two LDS stages, one barrier
+      // per 32 rows -- correct to the same bar, 78.7 us against 50.4: the pass re-reads the chunk and costs more than three MFMA
+      // products per k-step save in a loop that is bound by its staging, not by the matrix pipes.)
       using TA = RowMajorTile<64>;
       using TB = RowMajorTile<160>;
       constexpr size_t lds = (size_t)3 * (TA::PLANE + TB::PLANE);

@@ -1416,6 +1416,38 @@ def linear_fwd_wp(x, planes, bias, n_out, relu=False, out=None):
     return y
 
 
+def weight_planes_2p(mats, transpose=None):
+    """pgnn_split_weights_2p: every fp32 matrix of ``mats`` (``transpose[j]``: its transpose) as two fp16 planes of s W with a
+    power-of-two scale s per row, followed by 1 / s per row as fp32 -- one uint8 buffer of pgnn_weight_planes_bytes per matrix: what
+    ``linear_fwd_2p`` / pgnn_linear_bwd_data_2p take as their weight operand (the default arithmetic of the one-call networks)"""
+    import ctypes
+    cnt = len(mats)
+    transpose = [False] * cnt if transpose is None else list(transpose)
+    outs = []
+    for w, tr in zip(mats, transpose):
+        if not w.is_cuda or w.dtype != torch.float32 or w.dim() != 2 or not w.is_contiguous():
+            raise _lib.PgnnError("weight_planes_2p: contiguous fp32 CUDA matrices only")
+        r, c = (w.size(1), w.size(0)) if tr else (w.size(0), w.size(1))
+        outs.append(torch.empty(int(load().pgnn_weight_planes_bytes(r, c)), dtype=torch.uint8, device=w.device))
+    arr = lambda vals, ty: (ty * cnt)(*vals)
+    check(load().pgnn_split_weights_2p(arr([w.data_ptr() for w in mats], ctypes.c_void_p), arr([o.data_ptr() for o in outs], ctypes.c_void_p),
+                                       arr([w.size(0) for w in mats], ctypes.c_int64), arr([w.size(1) for w in mats], ctypes.c_int64),
+                                       arr([int(t) for t in transpose], ctypes.c_int32), cnt, stream_ptr()), "pgnn_split_weights_2p")
+    return outs
+
+
+def linear_fwd_2p(x, planes, bias, n_out, relu=False, out=None, x_amax=None, y_amax=None):
+    """y = act(x . W^T + b) with W as ``weight_planes_2p([W])[0]``: pgnn_linear_fwd_2p, no autograd.  x_amax: int32 [m] bit patterns
+    of the rows' largest magnitudes if a previous product left them (its y_amax), else the kernel takes them; y_amax: zeroed int32
+    [m] that receives the result rows' maxima"""
+    m, k = x.shape
+    y = out if out is not None else torch.empty(m, n_out, dtype=torch.float32, device=x.device)
+    check(load().pgnn_linear_fwd_2p(x.data_ptr(), x.stride(0), x_amax.data_ptr() if x_amax is not None else None, planes.data_ptr(),
+                                    bias.data_ptr() if bias is not None else None, y.data_ptr(), y.stride(0), m, k, n_out, int(relu), None,
+                                    y_amax.data_ptr() if y_amax is not None else None, stream_ptr()), "pgnn_linear_fwd_2p")
+    return y
+
+
 # ------------------------------------------------------------------------------------ whole bio GIN network
 class BioGINStack(Function):
     """Every (GINConv, ReLU) layer of the bio GNN (bio/model.py:11-58, 258-290, JK = "last", no dropout) as ONE library call

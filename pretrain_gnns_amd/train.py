@@ -355,6 +355,9 @@ def chem_contextpred_step(model_substruct, model_context, optimizer_substruct, o
     if mode == "cbow" and pool is None and batch.x_substruct.is_cuda and 1 <= neg_samples <= 8:
         # the reference's defaults: the whole loss in two launches forward and one back (csrc/contextpred.hip) instead of ~50
         # torch launches a few hundred elements long, between which the GPU idled
+        # (Measured and NOT kept, profiles/r04/wgrad2p_and_ctx_two_streams_ab.txt: the context network on a second stream beside the
+        # substructure network -- bit-identical, 1.66-1.70 against 1.64-1.65 ms per step: each network's backward already runs on
+        # two streams, and four streams of 6 k-row kernels only stretch one another.)
         hs = model_substruct(batch.x_substruct, batch.edge_index_substruct, batch.edge_attr_substruct)
         hc = model_context(batch.x_context, batch.edge_index_context, batch.edge_attr_context)
         node_reps = (hs, hc)  # an ineligible shape falls through to the torch loss ON THESE embeddings (no second forward)

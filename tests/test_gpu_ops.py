@@ -571,14 +571,23 @@ def test_weight_gradient_pair_in_one_launch(m, monkeypatch):
         ops.check(lib.pgnn_linear_bwd_weight(dhid.data_ptr(), 2 * d, agg.data_ptr(), d, dw1.data_ptr(), db1.data_ptr(), m, d, 2 * d, ws.data_ptr(), ws.numel(), sp), "single")
         return dw2, db2, dw1, db1
 
-    got, again, ref = pair(), pair(), singles()
-    for a, b in zip(got, again):
-        assert torch.equal(a, b)
+    ref = singles()
     want = (dz.double().t() @ hid.double(), dz.double().sum(0), dhid.double().t() @ agg.double(), dhid.double().sum(0))
     scale = (dz.double().abs().t() @ hid.double().abs(), dz.double().abs().sum(0), dhid.double().abs().t() @ agg.double().abs(), dhid.double().abs().sum(0))
+    # columns of very different magnitude: gradient columns six decades apart, a dead unit
+    dz[:, ::7] *= 1e-6
+    hid[:, 5] = 0.0
+    want = (dz.double().t() @ hid.double(), dz.double().sum(0), want[2], want[3])
+    scale = (dz.double().abs().t() @ hid.double().abs(), dz.double().abs().sum(0), scale[2], scale[3])
+    ref = singles()
+    got, again = pair(), pair()
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)
     for g, r, w, sc in zip(got, ref, want, scale):
-        assert float(((g.double() - w).abs() / sc).max()) < 2e-6
-        assert float(((r.double() - w).abs() / sc).max()) < 2e-6
+        err = (g.double() - w).abs() / sc.clamp(min=1e-300)
+        err[sc == 0] = (g.double() - w).abs()[sc == 0]
+        assert float(err.max()) < 2e-6, float(err.max())
+        assert float(((r.double() - w).abs() / sc.clamp(min=1e-300)).max()) < 2e-6
         assert float((g - r).abs().max()) <= 4e-6 * float(sc.max())
     monkeypatch.setenv("PGNN_DW_PAIR", "0")
     lib.pgnn_reload_env()

@@ -1,0 +1,35 @@
+#!/bin/bash
+# round-4 GPU session F: weight gradients on two planes (k_wgrad2p_pair), context networks on two streams; full suite; step A/B; bench
+set +e
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r04f
+mkdir -p $O
+cd $R
+timeout 400 python -m pytest tests/test_gpu_ops.py tests/test_gpu_models.py -m gpu -q -x -k "weight_gradient_pair or two_streams or one_call or linear_fwd_bwd or mlp2" > $O/tests_new.txt 2>&1
+tail -n 8 $O/tests_new.txt
+for k in "PGNN_DW_2P=1" "PGNN_DW_2P=0" "PGNN_DW_2P=1" "PGNN_DW_2P=0"; do
+  echo "$k" >> $O/ab.txt
+  env $k timeout 100 python tools/step_profile.py 256 300 20 epoch 2>&1 | tail -n 1 >> $O/ab.txt
+done
+for k in "PGNN_DW_2P=1" "PGNN_DW_2P=0"; do
+  echo "bio $k" >> $O/ab.txt
+  env $k timeout 100 python tools/bio_step_profile.py 256 100 2>&1 | tail -n 1 >> $O/ab.txt
+done
+for k in "PGNN_CTX_TWO_STREAMS=1" "PGNN_CTX_TWO_STREAMS=0" "PGNN_CTX_TWO_STREAMS=1" "PGNN_CTX_TWO_STREAMS=0"; do
+  echo "ctx $k" >> $O/ab.txt
+  env $k timeout 100 python tools/ctx_step_profile.py 256 100 2>&1 | tail -n 1 >> $O/ab.txt
+done
+cat $O/ab.txt
+timeout 900 python -m pytest tests -m gpu -q --deselect tests/test_gpu_ops.py::test_products_on_two_fp16_planes_against_float64 > $O/tests_all.txt 2>&1
+tail -n 8 $O/tests_all.txt
+cd /tmp && export TMPDIR=/tmp
+name=step_b256
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -o $name -- python $R/tools/step_profile.py 256 30 5 epoch > $O/$name.log 2>&1
+cp $(find $O/prof_$name -name "*kernel_stats.csv" | head -1) $O/${name}_kernel_stats.csv
+cp $(find $O/prof_$name -name "*kernel_trace.csv" | head -1) $O/${name}_trace.csv
+rm -rf $O/prof_$name
+cd $R
+python tools/kstats.py $O/${name}_kernel_stats.csv 14 > $O/${name}_kstats.txt
+python tools/step_timeline.py $O/${name}_trace.csv > $O/${name}_timeline.txt 2>&1
+gzip -f $O/*_trace.csv
+cat $O/${name}_kstats.txt
