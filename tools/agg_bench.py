@@ -26,6 +26,7 @@ def timeit(fn, iters=20):
     return s.elapsed_time(t) / iters
 
 alg = 2400.0 * n + 6.0 * e + 4.0 * (n + 1)
+print("nodes %d edges %d algorithmic bytes %d" % (n, e, int(alg)))
 def agg():
     ops.check(lib.pgnn_chem_aggregate_fwd(x.data_ptr(), 300, g.in_ptr.data_ptr(), g.in_src.data_ptr(), g.in_code.data_ptr(),
               e1.data_ptr(), e2.data_ptr(), None, out.data_ptr(), 300, n, 300, sp), "agg")
