@@ -408,7 +408,9 @@ int bn_bwd_apply_only(const float* dy, int64_t lddy, const float* x, int64_t ldx
                       int64_t n, int64_t dim, hipStream_t st) {
   if (int rc = check_args(n, dim)) return rc;
   PGNN_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "batchnorm: leading dimensions must be multiples of 4");
-  const int grid = (int)std::min<int64_t>(ceil_div(n, 4), (int64_t)num_cu() * env_knob("PGNN_BN_APPLY_BPC", 16));
+  // (four blocks per CU walking the rows instead of sixteen with one or two rows each: 0.982-0.991 against 0.990-0.996 ms per chem
+  // step in four A/B pairs, profiles/r04/step_unprofiled.txt -- beside a weight-gradient product fewer, longer-lived blocks win)
+  const int grid = (int)std::min<int64_t>(ceil_div(n, 4), (int64_t)num_cu() * env_knob("PGNN_BN_APPLY_BPC", 4));
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid), dim3(stat_threads(dim)), 0, st, dy, lddy, x, ldx, coef, relu, dx, lddx, (int)n,
                      (int)(dim / 4), make_drop(0.f, 0));
   return check_launch("bn_bwd_apply");

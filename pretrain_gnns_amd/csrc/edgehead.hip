@@ -194,6 +194,10 @@ __global__ void __launch_bounds__(kEdgeBlock) k_edge_ce(const float* __restrict_
   }
   if (threadIdx.x == 0) {
     double l = red[0] / (double)m;
+    // The bio loop's F.cross_entropy reduces fp32 row losses in fp32 (bio/pretrain_masking.py:58); here the per-row fp32 losses are
+    // summed in float64 in a fixed tree and the MEAN is rounded to fp32 once -- at least as close to the exact mean as any fp32
+    // summation order, but not bit-comparable with the unfused torch fallback of readback="inline" (which sums in torch's order):
+    // the two read-back modes may differ in the last fp32 digit of the loss and hence of the gradient scale.
     if (!f64) l = (double)(float)l;  // the reference's loss is an fp32 tensor there
     *loss64 = l;
     if (loss32) *loss32 = (float)l;

@@ -738,6 +738,37 @@ def test_batchnorm_backward_sums_from_the_transposed_aggregation(graphs, trainin
         assert torch.equal(res[2][1][k], res[3][1][k]), k  # deterministic
 
 
+@pytest.mark.parametrize("graphs", [64, 256])
+def test_side_stream_schedules_of_the_backward_give_the_same_bits(graphs, monkeypatch):
+    """one-call chem GIN backward: where the per-layer fork event sits (behind both backward-data products, or between them with
+    the edge-table gradient deferred to the head of the next layer's side-stream work: PGNN_FORK_EARLY) and whether there is a side
+    stream at all (PGNN_SIDE_STREAM=0) are schedules of the SAME kernels on the same buffers -- every gradient bit-identical, run
+    after run"""
+    import copy
+    from pretrain_gnns_amd import ops
+    hchem, _ = _hip()
+    _, a = _pair(ochem.GNN, hchem.GNN, 5, 300, seed=21)
+    d = hostdata.chem_masking_batch(graphs, seed=22).to(DEV)
+    w = torch.randn(d.x.size(0), 300, device=DEV)
+    res = []
+    for env in ({}, {"PGNN_FORK_EARLY": "1"}, {"PGNN_SIDE_STREAM": "0"}, {"PGNN_FORK_EARLY": "1"}, {}):
+        for k in ("PGNN_FORK_EARLY", "PGNN_SIDE_STREAM"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ops.load().pgnn_reload_env()
+        m = copy.deepcopy(a).train()
+        for _ in range(2):
+            m.zero_grad()
+            out = m(d.x, d.edge_index, d.edge_attr)
+            (out * w).sum().backward()
+        torch.cuda.synchronize()
+        res.append({k: p.grad.clone() for k, p in m.named_parameters()})
+    for other in res[1:]:
+        for k in res[0]:
+            assert torch.equal(res[0][k], other[k]), k
+
+
 @pytest.mark.parametrize("graphs", [4, 256])
 def test_num_batches_tracked_is_counted_inside_the_stack_call(graphs):
     """nn.BatchNorm1d.forward adds one to num_batches_tracked per training-mode forward; the one-call GIN networks do it inside
