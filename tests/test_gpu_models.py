@@ -740,9 +740,8 @@ def test_batchnorm_backward_sums_from_the_transposed_aggregation(graphs, trainin
 
 @pytest.mark.parametrize("graphs", [64, 256])
 def test_side_stream_schedules_of_the_backward_give_the_same_bits(graphs, monkeypatch):
-    """one-call chem GIN backward: where the per-layer fork event sits (behind both backward-data products, or between them with
-    the edge-table gradient deferred to the head of the next layer's side-stream work: PGNN_FORK_EARLY) and whether there is a side
-    stream at all (PGNN_SIDE_STREAM=0) are schedules of the SAME kernels on the same buffers -- every gradient bit-identical, run
+    """one-call chem GIN backward: with the weight gradients and bond tables on the side stream (default) or everything on the
+    caller's stream (PGNN_SIDE_STREAM=0) -- schedules of the SAME kernels on the same buffers: every gradient bit-identical, run
     after run"""
     import copy
     from pretrain_gnns_amd import ops
@@ -751,8 +750,8 @@ def test_side_stream_schedules_of_the_backward_give_the_same_bits(graphs, monkey
     d = hostdata.chem_masking_batch(graphs, seed=22).to(DEV)
     w = torch.randn(d.x.size(0), 300, device=DEV)
     res = []
-    for env in ({}, {"PGNN_FORK_EARLY": "1"}, {"PGNN_SIDE_STREAM": "0"}, {"PGNN_FORK_EARLY": "1"}, {}):
-        for k in ("PGNN_FORK_EARLY", "PGNN_SIDE_STREAM"):
+    for env in ({}, {"PGNN_SIDE_STREAM": "0"}, {}, {"PGNN_SIDE_STREAM": "0"}):
+        for k in ("PGNN_SIDE_STREAM",):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
