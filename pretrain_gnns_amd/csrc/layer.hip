@@ -525,12 +525,6 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
 
   const float* g = dy;
   int64_t ldg = lddy;
-  // PGNN_FORK_EARLY=1 (A/B, round 4): the per-layer fork event is recorded between the two backward-data products instead of
-  // behind them; the edge-table gradient, which needs the second one's result, then runs at the head of the NEXT layer's side work
-  const bool fork_early = sd && wp && !per_layer && env_knob("PGNN_FORK_EARLY", 0) != 0;
-  const float* pend_dagg = nullptr;
-  float* pend_demb = nullptr;
-  int pend_l = 0;
   bool sums_ready = false;   // the BatchNorm-backward sums of the layer about to run are already folded (in bn_scratch.coef)
   BnBwdScratch bn_scratch{};
   for (int l = num_layer - 1; l >= 0; --l) {
@@ -559,8 +553,6 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     if (wp) {
       uint32_t* dam = dhid_amax ? dhid_amax + (size_t)l * amax_words(n) : nullptr;
       if ((rc = stack_bwd_data_wp(dz[b], dim, wp2[l], hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main, nullptr, dam))) return rc;
-      // (fork_early: the weight gradients need dz and dhid, not dagg -- the side stream may start one product earlier)
-      if (fork_early) PGNN_HIP(hipEventRecord(sd->fork[1], main));
       if ((rc = stack_bwd_data_wp(dhid[b], 2 * dim, wp1[l], nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main, dam))) return rc;
     } else if (tr && q < ntr) {
       if ((rc = pgnn_linear_bwd_data_t(dz[b], dim, w2t[q], hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main))) return rc;
@@ -571,7 +563,10 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     }
     // (recording fork[1] behind the transposed aggregation instead -- one idle gap less on this stream per layer -- starts the side
     // stream ~11 us later and loses: 1.107-1.111 against 1.072-1.078 ms per step, profiles/r03/fork_placement_ab.txt)
-    if (sd && !fork_early) PGNN_HIP(hipEventRecord(sd->fork[1], main));
+    // (round 4: recording it EARLIER, between the two backward-data products -- the weight gradients need dz and dhid, not dagg -- with
+    // the edge-table gradient deferred to the head of the next layer's side work: bit-identical, 1.001-1.010 against 0.997-1.001 ms,
+    // profiles/r04/fork_early_ab.txt; not kept)
+    if (sd) PGNN_HIP(hipEventRecord(sd->fork[1], main));
     // the bottom layer's edge-table gradient stays on the caller's stream: the side stream is the longer of the two there
     // (two weight-gradient products behind the data products), and the caller's stream only has the embedding gradients left
     const bool demb_on_main = sd && l == 0;
@@ -595,22 +590,11 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
       if (demb_on_main && (rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, op, opb, main))) return rc;
       PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[1], 0));
     }
-    if (fork_early && pend_demb) {
-      // the layer above's edge-table gradient: its dagg was complete before this layer's first product, i.e. before the event the
-      // side stream has just waited for; only now is the side stream done with that layer's buffer set
-      if ((rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, pend_dagg, dim, pend_demb, dim, n, dim, aux_ws, opb, aux))) return rc;
-      if (pend_l >= 2) PGNN_HIP(hipEventRecord(sd->lag[pend_l & 1], aux));
-      pend_demb = nullptr;
-    }
     if ((rc = pgnn_linear_bwd_weight_pair(dz[b], dim, hd, 2 * dim, p.dw2, p.db2, 2 * dim, dim, dhid[b], 2 * dim, agg, dim, p.dw1, p.db1,
                                           dim, 2 * dim, n, aux_ws, opb, aux)))  // both products, one fold of the split-K partials
       return rc;
-    if (fork_early && !demb_on_main) {
-      pend_dagg = dagg[b]; pend_demb = p.demb; pend_l = l;
-    } else {
-      if (!demb_on_main && (rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, aux_ws, opb, aux))) return rc;
-      if (sd && !per_layer && l >= 2) PGNN_HIP(hipEventRecord(sd->lag[b], aux));  // awaited by layer l-2 only
-    }
+    if (!demb_on_main && (rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, aux_ws, opb, aux))) return rc;
+    if (sd && !per_layer && l >= 2) PGNN_HIP(hipEventRecord(sd->lag[b], aux));  // awaited by layer l-2 only
     if (!sd && (rc = aggregate_t())) return rc;
     g = dxb[b];
     ldg = dim;
