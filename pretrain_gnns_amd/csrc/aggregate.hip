@@ -371,6 +371,8 @@ struct AggTail {
   const float* save_invstd;
   int relu;
   BnBwdFold fold;
+  uint32_t* amax;  // any instance, optional: [n] words that receive the bit patterns of max |out[i, :]| (the row maxima the two-plane
+                   // product behind this aggregation would otherwise take in a pass of its own); plain stores, one per row
 };
 
 // The block's end of the tail, entered by EVERY thread of the block -- the loader wave too (with nothing to add): no wave of a block
@@ -427,7 +429,8 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
   int* codeL = idxL + NBUF * kDmaEdges;                                              // [NBUF][64] (byte DMA lands as dwords)
   float* dinvL = reinterpret_cast<float*>(codeL + NBUF * kDmaEdges);                 // [8 (nsteps + 2)] rows n0-8 .. (WEIGHT)
   int* farL = codeL + NBUF * kDmaEdges;  // (PF; never together with WEIGHT) [NBUF][2]: bit k = staged edge slot k of the step is far
-  float* redL = reinterpret_cast<float*>(farL + 16);  // (TAIL; never together with WEIGHT) [8][2][dim]: the node slots' column sums
+  unsigned* amaxL = reinterpret_cast<unsigned*>(farL + 16);  // (tail.amax) [2][8]: the row maxima of the step in flight / being flushed
+  float* redL = reinterpret_cast<float*>(farL + 32);  // (TAIL; never together with WEIGHT) [8][2][dim]: the node slots' column sums
   const float4* __restrict__ T4 = reinterpret_cast<const float4*>(T);
   const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
   const int64_t ldx4 = ldx >> 2, ldo4 = ldo >> 2;
@@ -531,6 +534,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
       pr[0] = c_wait; pr[1] = c_bar; pr[2] = c_issue;
       pr[5] = __builtin_readcyclecounter() - t_begin; pr[6] = (unsigned long long)nsteps;
     }
+    if (!WEIGHT && tail.amax) __syncthreads();  // (the consumers' barrier in front of their last flush of the row maxima)
     if (TAIL) agg_tail_finish(tail, redL, false, 0, 0, f4_zero(), f4_zero(), dim);
     return;
   }
@@ -558,6 +562,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
       T[q] = emb1[(c / 3) * dim + d] + emb2[(c % 3) * dim + d];
     }
   }
+  if (!WEIGHT && tail.amax && t < 2 * kDmaG) amaxL[t] = 0u;
   for (int q = t; q <= cnt; q += cthreads) ptrL[q] = ptr[n0 + q];
   if (WEIGHT)
     for (int q = t; q < (nsteps + 2) * kDmaG; q += cthreads) {  // the ring window of the last step ends at n0 + 8 nsteps + 8
@@ -601,6 +606,10 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
       __syncthreads();  // B(s)
     }
     const int li = s * kDmaG + g;
+    if (!WEIGHT && tail.amax && s > 0 && active && c4 == 0 && li - kDmaG < cnt) {  // the row this slot finished in step s - 1
+      tail.amax[n0 + li - kDmaG] = amaxL[((s - 1) & 1) * kDmaG + g];
+      amaxL[((s - 1) & 1) * kDmaG + g] = 0u;  // (next written in step s + 1, behind B(s + 1))
+    }
     const int e0 = nb_e0, beg = nb_beg, end = nb_end;
     {
       const int ln = li + kDmaG;
@@ -722,6 +731,8 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
     } else {
       reinterpret_cast<float4*>(out)[(int64_t)i * ldo4 + c4] = acc;
     }
+    if (!WEIGHT && tail.amax)
+      atomicMax(amaxL + (s & 1) * kDmaG + g, __float_as_uint(fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w)))));
     if (TAIL) {  // the same expressions as k_bn_bwd_partial's
       float4 gq = acc;
       if (tail.relu) {
@@ -736,6 +747,11 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
       ts2.z = fmaf(gq.z, (zrow.z - tmu.z) * tis.z, ts2.z);
       ts2.w = fmaf(gq.w, (zrow.w - tmu.w) * tis.w, ts2.w);
     }
+  }
+  if (!WEIGHT && tail.amax) {
+    __syncthreads();  // the last step's maxima are complete (the loader wave meets this barrier too)
+    const int li = (nsteps - 1) * kDmaG + g;
+    if (nsteps > 0 && active && c4 == 0 && li < cnt) tail.amax[n0 + li] = amaxL[((nsteps - 1) & 1) * kDmaG + g];
   }
   if (TAIL) agg_tail_finish(tail, redL, active, g, c4, ts1, ts2, dim);
   if (PROF && prof && t == 0) {
@@ -758,7 +774,7 @@ int launch_aggregate_dma_p(const float* x, int64_t ldx, const int32_t* ptr, cons
   const int threads = cthreads + kWave;
   const size_t lds = (size_t)(TABLE ? kNumCodes * dim : 0) * 4 + (size_t)(P + 3) * kDmaG * dim * 4 +
                      (size_t)(kDmaMaxNodes + 4) * 4 + (size_t)2 * (P + 1 + ((POL & 16) ? 1 : 0)) * kDmaEdges * 4 +
-                     (WEIGHT ? (size_t)(kDmaMaxNodes + 3 * kDmaG) * 4 : 0) + 64 + (TAIL ? (size_t)kDmaG * 2 * dim * 4 + 64 : 0);
+                     (WEIGHT ? (size_t)(kDmaMaxNodes + 3 * kDmaG) * 4 : 0) + 128 + (TAIL ? (size_t)kDmaG * 2 * dim * 4 + 64 : 0);
   const int resident = (int)std::max<size_t>(1, (160 * 1024) / lds);
   const int64_t target_blocks = (int64_t)num_cu() * std::min(resident, env_int("PGNN_DMA_BPC", 2));
   int64_t npb = ceil_div(n, target_blocks);
@@ -780,14 +796,14 @@ int launch_aggregate_dma_p(const float* x, int64_t ldx, const int32_t* ptr, cons
 // BatchNorm(+ReLU)-on-read variant: D = 300 gets the tuned instantiation, every other width the generic one
 int launch_aggregate_dma_pre(const float* z, int64_t ldz, const float* coef, int relu, const int32_t* ptr,
                              const int32_t* nbr, const uint8_t* code, const float* emb1, const float* emb2, float* out,
-                             int64_t ldo, int64_t n, int64_t dim, hipStream_t st) {
+                             int64_t ldo, int64_t n, int64_t dim, hipStream_t st, const AggTail* tail = nullptr) {
   const int nrow = (int)ceil_div(kDmaG * (dim / 4), kWave);
   const bool small_ld = ldz * 4 * kDmaG < (1ll << 31);
   if (nrow == 10 && small_ld) {
     const bool nt = env_int("PGNN_DMA_POL", (int64_t)n * dim * 4 >= (128ll << 20) ? 3 : 0) == 3;
     if (env_int("PGNN_DMA_PF", 1) != 0) {
       if (nt) return launch_aggregate_dma_p<true, 2, 10, true, 19>(z, ldz, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, coef, relu);
-      return launch_aggregate_dma_p<true, 2, 10, true, 16>(z, ldz, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, coef, relu);
+      return launch_aggregate_dma_p<true, 2, 10, true, 16>(z, ldz, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, coef, relu, nullptr, tail);
     }
     if (nt) return launch_aggregate_dma_p<true, 2, 10, true, 3>(z, ldz, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, coef, relu);
     return launch_aggregate_dma_p<true, 2, 10, true>(z, ldz, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, coef, relu);
@@ -1365,6 +1381,29 @@ int pgnn_neighbor_sum(const float* x, int64_t ldx, const int32_t* ptr, const int
 }
 
 }  // extern "C"
+
+// pgnn_chem_aggregate_fwd / pgnn_chem_aggregate_bn_fwd (coef != NULL) that also leave the row maxima of `out` in amax [n] (bit
+// patterns) for the two-plane product behind them -- on the tuned instantiation only (feature width 300, default policies); else the
+// plain aggregation and *done = false (the product then takes the maxima itself).
+int pgnn::chem_aggregate_fwd_amax(const float* x, int64_t ldx, const float* coef, int relu, const int32_t* in_ptr, const int32_t* in_src,
+                                  const uint8_t* in_code, const float* emb1, const float* emb2, float* out, int64_t ldo, int64_t n,
+                                  int64_t dim, uint32_t* amax, bool* done, hipStream_t st) {
+  if (int rc = check_dim(dim)) return rc;
+  PGNN_REQUIRE(n > 0 && ldx % 4 == 0 && ldo % 4 == 0, "bad aggregate arguments");
+  const int nrow = (int)ceil_div(kDmaG * (dim / 4), kWave);
+  const bool small_ld = ldx * 4 * kDmaG < (1ll << 31);
+  *done = amax && dim <= 320 && nrow == 10 && small_ld && env_int("PGNN_AGG_VARIANT", 3) == 3 && env_int("PGNN_DMA_P", 2) == 2 &&
+          !env_int("PGNN_DMA_GENERIC", 0) && env_int("PGNN_DMA_PF", 1) != 0 &&
+          env_int("PGNN_DMA_POL", (int64_t)n * dim * 4 >= (128ll << 20) ? 3 : 0) == 0;
+  if (!*done) {
+    if (coef) return launch_aggregate_dma_pre(x, ldx, coef, relu, in_ptr, in_src, in_code, emb1, emb2, out, ldo, n, dim, st);
+    return launch_aggregate<true, false>(x, ldx, in_ptr, in_src, in_code, emb1, emb2, nullptr, out, ldo, n, dim, st);
+  }
+  AggTail t{};
+  t.amax = amax;
+  if (coef) return launch_aggregate_dma_p<true, 2, 10, true, 16>(x, ldx, in_ptr, in_src, in_code, emb1, emb2, out, ldo, n, dim, st, coef, relu, nullptr, &t);
+  return launch_aggregate_dma_p<true, 2, 10, false, 16>(x, ldx, in_ptr, in_src, in_code, emb1, emb2, out, ldo, n, dim, st, nullptr, 0, nullptr, &t);
+}
 
 // pgnn_neighbor_sum + the BatchNorm-backward column sums of the layer below in the same launch (bn_fold.h).  Fused only on the
 // tuned instantiation (feature width 300, far rows prefetched, the default cache policy of batches below 128 MB); anything else

@@ -301,10 +301,46 @@ __global__ void k_bn_bwd_final(const float* __restrict__ partial, int nblk, int 
   coef[6 * dim + c] = k3;
 }
 
+// rowmax (optional): the bit patterns of max |dx[r, :]| per row -- a row's d4 threads fold theirs by an LDS atomic maximum, two
+// barriers per trip of four rows (every trip count is block-uniform; the lanes beyond the fourth row lane stay in the loop, idle)
 __global__ void k_bn_bwd_apply(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
                                int64_t ldx, const float* __restrict__ coef, int relu, float* __restrict__ dx,
-                               int64_t lddx, int n, int d4, Drop drop) {
+                               int64_t lddx, int n, int d4, Drop drop, uint32_t* __restrict__ rowmax) {
   const int t = threadIdx.x, c4 = t % d4, rl = t / d4, dim = d4 * 4;
+  __shared__ unsigned rmax[4];
+  if (rowmax) {
+    const float4 a = reinterpret_cast<const float4*>(coef)[min(c4, d4 - 1)];
+    const float4 b = reinterpret_cast<const float4*>(coef + dim)[min(c4, d4 - 1)];
+    const float4 mu = reinterpret_cast<const float4*>(coef + 2 * dim)[min(c4, d4 - 1)];
+    const float4 k1 = reinterpret_cast<const float4*>(coef + 4 * dim)[min(c4, d4 - 1)];
+    const float4 k2 = reinterpret_cast<const float4*>(coef + 5 * dim)[min(c4, d4 - 1)];
+    const float4 k3 = reinterpret_cast<const float4*>(coef + 6 * dim)[min(c4, d4 - 1)];
+    for (int64_t r0 = (int64_t)blockIdx.x * 4; r0 < n; r0 += (int64_t)gridDim.x * 4) {
+      if (t < 4) rmax[t] = 0u;
+      __syncthreads();
+      const int64_t r = r0 + rl;
+      if (rl < 4 && r < n) {
+        const float4 v = reinterpret_cast<const float4*>(x + r * ldx)[c4];
+        float4 g = reinterpret_cast<const float4*>(dy + r * lddy)[c4];
+        if (relu) {
+          if (!(fmaf(a.x, v.x, b.x) > 0.f)) g.x = 0.f;
+          if (!(fmaf(a.y, v.y, b.y) > 0.f)) g.y = 0.f;
+          if (!(fmaf(a.z, v.z, b.z) > 0.f)) g.z = 0.f;
+          if (!(fmaf(a.w, v.w, b.w) > 0.f)) g.w = 0.f;
+        }
+        float4 o;
+        o.x = fmaf(k1.x, g.x, fmaf(k2.x, v.x - mu.x, k3.x));
+        o.y = fmaf(k1.y, g.y, fmaf(k2.y, v.y - mu.y, k3.y));
+        o.z = fmaf(k1.z, g.z, fmaf(k2.z, v.z - mu.z, k3.z));
+        o.w = fmaf(k1.w, g.w, fmaf(k2.w, v.w - mu.w, k3.w));
+        reinterpret_cast<float4*>(dx + r * lddx)[c4] = o;
+        atomicMax(&rmax[rl], __float_as_uint(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)))));
+      }
+      __syncthreads();
+      if (t < 4 && r0 + t < n) rowmax[r0 + t] = rmax[t];
+    }
+    return;
+  }
   if (rl >= 4) return;
   const float4 a = reinterpret_cast<const float4*>(coef)[c4];
   const float4 b = reinterpret_cast<const float4*>(coef + dim)[c4];
@@ -405,14 +441,14 @@ int bn_bwd_scratch(void* ws, size_t ws_bytes, int64_t n, int64_t dim, BnBwdScrat
 }
 
 int bn_bwd_apply_only(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* coef, int relu, float* dx, int64_t lddx,
-                      int64_t n, int64_t dim, hipStream_t st) {
+                      int64_t n, int64_t dim, hipStream_t st, uint32_t* rowmax) {
   if (int rc = check_args(n, dim)) return rc;
   PGNN_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "batchnorm: leading dimensions must be multiples of 4");
   // (four blocks per CU walking the rows instead of sixteen with one or two rows each: 0.982-0.991 against 0.990-0.996 ms per chem
   // step in four A/B pairs, profiles/r04/step_unprofiled.txt -- beside a weight-gradient product fewer, longer-lived blocks win)
   const int grid = (int)std::min<int64_t>(ceil_div(n, 4), (int64_t)num_cu() * env_knob("PGNN_BN_APPLY_BPC", 4));
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid), dim3(stat_threads(dim)), 0, st, dy, lddy, x, ldx, coef, relu, dx, lddx, (int)n,
-                     (int)(dim / 4), make_drop(0.f, 0));
+                     (int)(dim / 4), make_drop(0.f, 0), rowmax);
   return check_launch("bn_bwd_apply");
 }
 
@@ -536,7 +572,7 @@ int pgnn_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, cons
                        coef, dgamma, dbeta);
   const int grid = (int)std::min<int64_t>(ceil_div(n, 4), (int64_t)num_cu() * 16);
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid), dim3(stat_threads(dim)), 0, st, dy, lddy, x, ldx, coef, relu, dx, lddx,
-                     (int)n, d4, drop);
+                     (int)n, d4, drop, static_cast<uint32_t*>(nullptr));
   return check_launch("bn_bwd");
 }
 

@@ -231,8 +231,9 @@ struct BnBwdScratch {
 };
 int bn_bwd_scratch(void* ws, size_t ws_bytes, int64_t n, int64_t dim, BnBwdScratch* s);
 // the elementwise pass alone (no dropout): dx = k1 * dyr + k2 * (x - mean) + k3 from coef [7][dim]
+// rowmax (optional): [n] words that receive the bit patterns of max |dx[i, :]| (for the two-plane product that reads dx)
 int bn_bwd_apply_only(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* coef, int relu, float* dx, int64_t lddx,
-                      int64_t n, int64_t dim, hipStream_t st);
+                      int64_t n, int64_t dim, hipStream_t st, uint32_t* rowmax = nullptr);
 
 // (aggregate.hip) pgnn_neighbor_sum (unweighted) whose launch ALSO leaves, for the BatchNorm whose input gradient it computes
 // (out = dL/dy of the layer below, y = relu?(BatchNorm(z))): the column sums of the backward, folded -- coef / dgamma / dbeta as
@@ -250,6 +251,9 @@ struct BnBwdTail {
   float* dgamma;
   float* dbeta;
 };
+int chem_aggregate_fwd_amax(const float* x, int64_t ldx, const float* coef, int relu, const int32_t* in_ptr, const int32_t* in_src,
+                            const uint8_t* in_code, const float* emb1, const float* emb2, float* out, int64_t ldo, int64_t n, int64_t dim,
+                            uint32_t* amax, bool* done, hipStream_t st);
 int neighbor_sum_bn_bwd(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* nbr, float* out, int64_t ldo, int64_t n,
                         int64_t dim, const BnBwdTail& tail, bool* fused, hipStream_t st);
 

@@ -306,7 +306,7 @@ size_t pgnn_chem_gin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t rows1
   return 2 * op_ws_bytes(n, dim) + sets * 5 * nd + wt + 2 * align_up((size_t)n * 4, 256) +
          2 * align_up((stack_keys(rows1, rows2) + 1) * 4, 256) + 256 + stack_group_ws(n, rows1, rows2) +
          stack_segsum_ws(n, dim, rows1, rows2) + stack_pair_sums(dim, rows1, rows2) + 256 +
-         (size_t)std::min<int64_t>(num_layer, kMaxPlaneLayers) * amax_words(n) * 4;
+         ((size_t)std::min<int64_t>(num_layer, kMaxPlaneLayers) + 2) * amax_words(n) * 4;  // (+ the maxima of agg / dz: one vector each)
 }
 
 int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t rows1, const float* xemb2,
@@ -341,8 +341,11 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
   // two planes: the first product of a layer leaves the row maxima of hid for the second (one vector per layer behind the planes,
   // cleared by the split launch) when the workspace has the room
   uint32_t* hid_amax = nullptr;
-  if (wp && two_planes() && ws_bytes >= opb + planes_b + (size_t)num_layer * amax_words(n) * 4)
+  if (wp && two_planes() && ws_bytes >= opb + planes_b + ((size_t)num_layer + 1) * amax_words(n) * 4)
     hid_amax = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + opb + planes_b);
+  // ... and the aggregation leaves the row maxima of agg for the first (one vector, rewritten by every layer: plain stores)
+  // (PGNN_PRODUCER_AMAX=0: the products take those two kinds of maxima themselves -- the same maxima, the same bits)
+  uint32_t* const agg_amax = (hid_amax && env_knob("PGNN_PRODUCER_AMAX", 1) != 0) ? hid_amax + (size_t)num_layer * amax_words(n) : nullptr;
   if (wp && (rc = split_mlp_weights(layers, num_layer, dim, 2 * dim, dim, 0, static_cast<char*>(ws) + opb, wp1, wp2, (hipStream_t)stream,
                                     training != 0, nullptr, hid_amax, hid_amax ? (int64_t)num_layer * (int64_t)amax_words(n) : 0)))
     return rc;
@@ -356,19 +359,23 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
     float* hd = hid + (size_t)l * 2 * nd;
     float* st = stats + (size_t)l * 4 * dim;  // mean, invstd, a, b
     const bool last = l == num_layer - 1;
+    bool agg_has_amax = false;
     if (l == 0) {
-      rc = pgnn_chem_aggregate_fwd(h0, dim, in_ptr, in_src, in_code, p.emb1, p.emb2, nullptr, agg, dim, n, dim, stream);
+      if (agg_amax) rc = chem_aggregate_fwd_amax(h0, dim, nullptr, 0, in_ptr, in_src, in_code, p.emb1, p.emb2, agg, dim, n, dim, agg_amax, &agg_has_amax, (hipStream_t)stream);
+      else rc = pgnn_chem_aggregate_fwd(h0, dim, in_ptr, in_src, in_code, p.emb1, p.emb2, nullptr, agg, dim, n, dim, stream);
     } else if (fuse) {
       const float* zprev = acts + (size_t)(l - 1) * 3 * nd + nd;
-      rc = pgnn_chem_aggregate_bn_fwd(zprev, dim, stats + (size_t)(l - 1) * 4 * dim + 2 * dim, 1, in_ptr, in_src, in_code,
-                                      p.emb1, p.emb2, agg, dim, n, dim, stream);
+      const float* cprev = stats + (size_t)(l - 1) * 4 * dim + 2 * dim;
+      if (agg_amax) rc = chem_aggregate_fwd_amax(zprev, dim, cprev, 1, in_ptr, in_src, in_code, p.emb1, p.emb2, agg, dim, n, dim, agg_amax, &agg_has_amax, (hipStream_t)stream);
+      else rc = pgnn_chem_aggregate_bn_fwd(zprev, dim, cprev, 1, in_ptr, in_src, in_code, p.emb1, p.emb2, agg, dim, n, dim, stream);
     } else {
       const float* yprev = acts + (size_t)(l - 1) * 3 * nd + 2 * nd;
-      rc = pgnn_chem_aggregate_fwd(yprev, dim, in_ptr, in_src, in_code, p.emb1, p.emb2, nullptr, agg, dim, n, dim, stream);
+      if (agg_amax) rc = chem_aggregate_fwd_amax(yprev, dim, nullptr, 0, in_ptr, in_src, in_code, p.emb1, p.emb2, agg, dim, n, dim, agg_amax, &agg_has_amax, (hipStream_t)stream);
+      else rc = pgnn_chem_aggregate_fwd(yprev, dim, in_ptr, in_src, in_code, p.emb1, p.emb2, nullptr, agg, dim, n, dim, stream);
     }
     if (rc) return rc;
     uint32_t* ham = hid_amax ? hid_amax + (size_t)l * amax_words(n) : nullptr;
-    if (wp) rc = stack_fwd_wp(agg, dim, wp1[l], p.b1, hd, 2 * dim, n, dim, 2 * dim, 1, nullptr, stream, nullptr, ham);
+    if (wp) rc = stack_fwd_wp(agg, dim, wp1[l], p.b1, hd, 2 * dim, n, dim, 2 * dim, 1, nullptr, stream, agg_has_amax ? agg_amax : nullptr, ham);
     else rc = pgnn_linear_fwd(agg, dim, p.w1, p.b1, hd, 2 * dim, n, dim, 2 * dim, 1, stream);
     if (rc) return rc;
     if (stats_in_gemm) {
@@ -467,6 +474,8 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   float* pair_sums = reinterpret_cast<float*>(cv.take<char>(stack_pair_sums(dim, rows1, rows2)));
   // two planes: the row maxima of dhid, from the epilogue of the product that writes it to the product that reads it (cleared by the split launch)
   uint32_t* dhid_amax = (two_planes() && num_layer <= kMaxPlaneLayers) ? cv.take<uint32_t>((size_t)num_layer * amax_words(n)) : nullptr;
+  // ... and the BatchNorm backward's elementwise pass those of dz (one vector, rewritten by every layer: plain stores)
+  uint32_t* const dz_amax = (dhid_amax && env_knob("PGNN_PRODUCER_AMAX", 1) != 0) ? cv.take<uint32_t>(amax_words(n)) : nullptr;
 
   hipStream_t main = (hipStream_t)stream;
   Side* sd = (use_side_stream() && n <= kSideMaxRows && num_layer <= kMaxSets) ? side_for_current_device() : nullptr;
@@ -539,8 +548,9 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     const float* mean = stats + (size_t)l * 4 * dim;
     // BatchNorm backward.  Below the top layer its column sums came out of the aggregation that produced g (the layer above's
     // transposed aggregation, neighbor_sum_bn_bwd below): only the elementwise pass is left.
+    const bool dz_has_amax = sums_ready && wp && dz_amax != nullptr;
     if (sums_ready)
-      rc = bn_bwd_apply_only(g, ldg, z, dim, bn_scratch.coef, l != num_layer - 1, dz[b], dim, n, dim, main);
+      rc = bn_bwd_apply_only(g, ldg, z, dim, bn_scratch.coef, l != num_layer - 1, dz[b], dim, n, dim, main, dz_has_amax ? dz_amax : nullptr);
     else
       rc = pgnn_bn_bwd(g, ldg, z, dim, p.gamma, p.beta, mean, mean + dim, training, l != num_layer - 1, dz[b], dim, p.dgamma, p.dbeta,
                        drop_p, drop_seed + (uint64_t)l, n, dim, op, opb, main);
@@ -552,7 +562,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     }
     if (wp) {
       uint32_t* dam = dhid_amax ? dhid_amax + (size_t)l * amax_words(n) : nullptr;
-      if ((rc = stack_bwd_data_wp(dz[b], dim, wp2[l], hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main, nullptr, dam))) return rc;
+      if ((rc = stack_bwd_data_wp(dz[b], dim, wp2[l], hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main, dz_has_amax ? dz_amax : nullptr, dam))) return rc;
       if ((rc = stack_bwd_data_wp(dhid[b], 2 * dim, wp1[l], nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main, dam))) return rc;
     } else if (tr && q < ntr) {
       if ((rc = pgnn_linear_bwd_data_t(dz[b], dim, w2t[q], hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main))) return rc;
