@@ -2091,6 +2091,10 @@ int launch_gemm2pw(const GemmArgs& p, hipStream_t st) {
   const int64_t nk = ceil_div(p.K, 32), cus = num_cu();
   const double t64 = (double)ceil_div(ceil_div(p.M, 64) * ceil_div(p.N, 160), cus) * (0.5 * nk + 5.0);
   const double t128 = (double)ceil_div(ceil_div(p.M, 128) * ceil_div(p.N, 160), cus) * (0.95 * nk + 6.0);
+  // 112 rows (seven waves of 16 x 160): where 128-row tiles leave a sixth of the CUs without one -- 6 7xx x 600: 212 tiles of 128 rows
+  // on 256 CUs, 244 of 112 -- the same single round with an eighth less work per tile (PGNN_GEMM2P_T112=0: off)
+  const double t112 = env_knob("PGNN_GEMM2P_T112", 1) ? (double)ceil_div(ceil_div(p.M, 112) * ceil_div(p.N, 160), cus) * (0.84 * nk + 5.8) : 1e30;
+  if (t112 < t128 && t112 < t64) return launch_gemm2pw_s<112, 160, 7, 1, 3, EPI>(p, st);
   if (t128 <= t64) return launch_gemm2pw_s<128, 160, 8, 1, 3, EPI>(p, st);
   return launch_gemm2pw_s<64, 160, 4, 2, 4, EPI>(p, st);
 }
