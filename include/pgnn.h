@@ -360,15 +360,6 @@ int pgnn_masked_head_fwd(const float* h, int64_t ldh, int64_t n_rows, const int6
 int pgnn_masked_head_bwd(const float* h, int64_t ldh, int64_t n_rows, const int64_t* idx, int64_t m, const float* w,
                          const int64_t* label, int64_t label_stride, const float* logits, const double* gloss, int64_t classes,
                          int64_t dim, float* dnode, int64_t ldd, float* dw, float* db, void* ws, size_t ws_bytes, pgnn_stream stream);
-/* The same backward with the head's OWN parameter gradients (dw, db: needed by the optimizer only) computed on the device's
- * auxiliary stream, behind the rows pass, while `stream` is free to go on into the network's backward (round 4: 26 us of a 1 ms
- * step at the head of the backward, where nothing else runs beside them).  dnode is complete in `stream` order as before; dw / db
- * -- and the workspace, h, idx -- may be read / released only behind pgnn_aux_join(stream), which makes `stream` wait for the
- * auxiliary stream (a no-op when nothing is pending).  chem/pretrain_masking.py:70 (loss.backward()) -> :72-74 (optimizer steps). */
-int pgnn_masked_head_bwd_deferred(const float* h, int64_t ldh, int64_t n_rows, const int64_t* idx, int64_t m, const float* w,
-                         const int64_t* label, int64_t label_stride, const float* logits, const double* gloss, int64_t classes,
-                         int64_t dim, float* dnode, int64_t ldd, float* dw, float* db, void* ws, size_t ws_bytes, pgnn_stream stream);
-int pgnn_aux_join(pgnn_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Edge-prediction head of the masking pre-training steps (bio/pretrain_masking.py:45-58; chem/pretrain_masking.py:60-66):

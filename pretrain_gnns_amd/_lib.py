@@ -75,8 +75,6 @@ PROTOTYPES = {
     "pgnn_masked_head_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "pgnn_masked_head_fwd": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "pgnn_masked_head_bwd": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _i64, _p, _p, _i64, _i64, _p, _i64, _p, _p, _p, _sz, _p]),
-    "pgnn_masked_head_bwd_deferred": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _i64, _p, _p, _i64, _i64, _p, _i64, _p, _p, _p, _sz, _p]),
-    "pgnn_aux_join": (_i, [_p]),
     "pgnn_edge_head_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "pgnn_edge_head_fwd": (_i, [_p, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p,
                                 _p, _sz, _p]),

@@ -150,11 +150,6 @@ int neighbor_sum_tiled_masked(const float* x, int64_t ldx, const int32_t* ptr, c
 int rowfeat_matmul_bwd_strided(const float* cfeat, int64_t kc, const float* g, int64_t ldg, float* out, int64_t s_row, int64_t s_col,
                                float* last_row_out, int64_t n, int64_t dim, void* ws, size_t ws_bytes, hipStream_t stream);
 
-// (layer.hip) the device's AUXILIARY stream (one per device, beside the backward's side stream): made to wait for everything enqueued
-// on `main` so far and returned (NULL: unavailable -- the caller then stays on `main`).  Work put on it is complete for `main` only
-// behind pgnn_aux_join(main).
-hipStream_t aux_stream_after(hipStream_t main);
-
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

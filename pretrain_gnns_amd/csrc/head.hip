@@ -365,10 +365,9 @@ int pgnn_masked_head_fwd(const float* h, int64_t ldh, int64_t n_rows, const int6
   return check_launch("masked_head_fwd");
 }
 
-static int masked_head_bwd_impl(const float* h, int64_t ldh, int64_t n_rows, const int64_t* idx, int64_t m, const float* w,
-                                const int64_t* label, int64_t label_stride, const float* logits, const double* gloss, int64_t classes,
-                                int64_t dim, float* dnode, int64_t ldd, float* dw, float* db, void* ws, size_t ws_bytes, pgnn_stream stream,
-                                bool defer) {
+int pgnn_masked_head_bwd(const float* h, int64_t ldh, int64_t n_rows, const int64_t* idx, int64_t m, const float* w,
+                         const int64_t* label, int64_t label_stride, const float* logits, const double* gloss, int64_t classes,
+                         int64_t dim, float* dnode, int64_t ldd, float* dw, float* db, void* ws, size_t ws_bytes, pgnn_stream stream) {
   PGNN_REQUIRE(m > 0 && classes > 0 && classes <= kHeadThreads && dim > 0 && dim % 4 == 0 && dim <= kHeadMaxDim && ldd >= dim,
                "masked_head: 1..%d classes, dim a multiple of 4 up to %d", kHeadThreads, kHeadMaxDim);
   if (ws_bytes < pgnn_masked_head_workspace_bytes(m, classes, dim)) {
@@ -386,33 +385,11 @@ static int masked_head_bwd_impl(const float* h, int64_t ldh, int64_t n_rows, con
   PGNN_HIP(hipMemsetAsync(dnode, 0, (size_t)n_rows * ldd * sizeof(float), st));
   hipLaunchKernelGGL(k_head_bwd_rows, dim3((int)ceil_div(m, kHeadRows)), dim3(kHeadThreads * kHeadSlices), 0, st, logits, idx, (int)m, w, label,
                      label_stride, gloss, (int)classes, (int)dim, n_rows, dl, dnode, ldd);
-  // The head's own parameter gradients are needed by the optimizer only: deferred, they run on the device's auxiliary stream (behind
-  // an event recorded here, after the rows kernel that writes dl) while the caller's stream goes on into the network's backward
-  hipStream_t wst = st;
-  if (defer) {
-    wst = aux_stream_after(st);
-    if (!wst) wst = st;
-  }
-  hipLaunchKernelGGL(k_head_bwd_weight, dim3((int)ceil_div(classes, kHeadClassGroup), nchunk), dim3(256), 0, wst, dl, h, ldh, idx, (int)m,
+  hipLaunchKernelGGL(k_head_bwd_weight, dim3((int)ceil_div(classes, kHeadClassGroup), nchunk), dim3(256), 0, st, dl, h, ldh, idx, (int)m,
                      chunk, (int)classes, (int)dim, n_rows, partial);
-  hipLaunchKernelGGL(k_head_fold, dim3((int)std::min<int64_t>(ceil_div(classes * (dim + 1), 256), 1024)), dim3(256), 0, wst, partial, nchunk,
+  hipLaunchKernelGGL(k_head_fold, dim3((int)std::min<int64_t>(ceil_div(classes * (dim + 1), 256), 1024)), dim3(256), 0, st, partial, nchunk,
                      (int)classes, (int)dim, dw, db);
   return check_launch("masked_head_bwd");
-}
-
-int pgnn_masked_head_bwd(const float* h, int64_t ldh, int64_t n_rows, const int64_t* idx, int64_t m, const float* w,
-                         const int64_t* label, int64_t label_stride, const float* logits, const double* gloss, int64_t classes,
-                         int64_t dim, float* dnode, int64_t ldd, float* dw, float* db, void* ws, size_t ws_bytes, pgnn_stream stream) {
-  return masked_head_bwd_impl(h, ldh, n_rows, idx, m, w, label, label_stride, logits, gloss, classes, dim, dnode, ldd, dw, db, ws, ws_bytes,
-                              stream, false);
-}
-
-int pgnn_masked_head_bwd_deferred(const float* h, int64_t ldh, int64_t n_rows, const int64_t* idx, int64_t m, const float* w,
-                                  const int64_t* label, int64_t label_stride, const float* logits, const double* gloss, int64_t classes,
-                                  int64_t dim, float* dnode, int64_t ldd, float* dw, float* db, void* ws, size_t ws_bytes,
-                                  pgnn_stream stream) {
-  return masked_head_bwd_impl(h, ldh, n_rows, idx, m, w, label, label_stride, logits, gloss, classes, dim, dnode, ldd, dw, db, ws, ws_bytes,
-                              stream, true);
 }
 
 }  // extern "C"

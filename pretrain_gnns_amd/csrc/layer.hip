@@ -21,9 +21,6 @@ struct Side {
   hipEvent_t fork[4] = {nullptr, nullptr, nullptr, nullptr};  // [3]: chem stack backward, "embedding grouping done"
   hipEvent_t join = nullptr;
   hipEvent_t lag[2] = {nullptr, nullptr};  // stack backward: "aux finished with buffer set p"
-  hipStream_t aux2 = nullptr;              // the auxiliary stream of aux_stream_after / pgnn_aux_join (deferred head gradients)
-  hipEvent_t aux2_fork = nullptr, aux2_join = nullptr;
-  bool aux2_used = false;                  // something was put on aux2 since the last join
   bool ok = false;
 };
 Side* side_for_current_device() {
@@ -41,9 +38,6 @@ Side* side_for_current_device() {
     if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
     for (auto& e : s.lag)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipStreamCreateWithFlags(&s.aux2, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&s.aux2_fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&s.aux2_join, hipEventDisableTiming) != hipSuccess) return nullptr;
     s.ok = true;
   }
   return &s;
@@ -146,24 +140,7 @@ inline size_t op_ws_bytes(int64_t n, int64_t d) {
 }
 }  // namespace
 
-hipStream_t pgnn::aux_stream_after(hipStream_t main) {
-  Side* sd = side_for_current_device();
-  if (!sd) return nullptr;
-  if (hipEventRecord(sd->aux2_fork, main) != hipSuccess || hipStreamWaitEvent(sd->aux2, sd->aux2_fork, 0) != hipSuccess) return nullptr;
-  sd->aux2_used = true;
-  return sd->aux2;
-}
-
 extern "C" {
-
-int pgnn_aux_join(pgnn_stream stream) {
-  Side* sd = side_for_current_device();
-  if (!sd || !sd->aux2_used) return PGNN_OK;
-  PGNN_HIP(hipEventRecord(sd->aux2_join, sd->aux2));
-  PGNN_HIP(hipStreamWaitEvent((hipStream_t)stream, sd->aux2_join, 0));
-  sd->aux2_used = false;
-  return PGNN_OK;
-}
 
 size_t pgnn_chem_gin_layer_workspace_bytes(int64_t n, int64_t dim) {
   // 2 x op scratch (main / side stream) + dhid [n, 2*dim] + dagg [n, dim] + dz [n, dim]

@@ -899,42 +899,11 @@ class MaskedHead(Function):
         dnode = torch.empty(n, dim, dtype=torch.float32, device=dev)
         dw = torch.empty(classes, dim, dtype=torch.float32, device=dev)
         db = torch.empty(classes, dtype=torch.float32, device=dev) if ctx.has_bias else None
-        defer = _DEFER_HEAD_GRADS and not torch.cuda.is_current_stream_capturing()
-        fn = load().pgnn_masked_head_bwd_deferred if defer else load().pgnn_masked_head_bwd
-        check(fn(h.data_ptr(), h.stride(0), n, idx.data_ptr(), m, w.data_ptr(), label.data_ptr(), label.stride(0), logits.data_ptr(),
-                 gloss.data_ptr(), classes, dim, dnode.data_ptr(), dim, dw.data_ptr(), db.data_ptr() if db is not None else None,
-                 ctx.ws.data_ptr(), ctx.ws.numel(), stream_ptr()), "pgnn_masked_head_bwd")
-        if defer:  # the auxiliary stream still reads these when autograd drops its references: held until join_deferred()
-            _deferred_keep.append((ctx.ws, h, idx, logits, label, gloss, w))
+        check(load().pgnn_masked_head_bwd(h.data_ptr(), h.stride(0), n, idx.data_ptr(), m, w.data_ptr(), label.data_ptr(),
+                                          label.stride(0), logits.data_ptr(), gloss.data_ptr(), classes, dim, dnode.data_ptr(), dim,
+                                          dw.data_ptr(), db.data_ptr() if db is not None else None, ctx.ws.data_ptr(), ctx.ws.numel(),
+                                          stream_ptr()), "pgnn_masked_head_bwd")
         return dnode, None, dw, db, None, None
-
-
-# Deferred head gradients (OPT-IN, round 4): inside ``deferred_head_grads()`` MaskedHead.backward computes the head's own weight /
-# bias gradients on the library's auxiliary stream -- they are needed by the optimizer only, and at the head of the backward nothing
-# else runs beside them -- and the caller's stream is joined with it when the context ends.  Until then ``linear.weight.grad`` may be
-# incomplete: the context is for loops that call ``backward()`` inside it and touch gradients only after it (train.chem_masking_step).
-_DEFER_HEAD_GRADS = False
-_deferred_keep = []
-
-
-def join_deferred():
-    """make the current stream wait for everything deferred to the auxiliary stream; release what was kept alive for it"""
-    if _deferred_keep:
-        check(load().pgnn_aux_join(stream_ptr()), "pgnn_aux_join")
-        _deferred_keep.clear()
-
-
-class deferred_head_grads:
-    def __enter__(self):
-        global _DEFER_HEAD_GRADS
-        self.prev, _DEFER_HEAD_GRADS = _DEFER_HEAD_GRADS, True
-        return self
-
-    def __exit__(self, *exc):
-        global _DEFER_HEAD_GRADS
-        _DEFER_HEAD_GRADS = self.prev
-        join_deferred()
-        return False
 
 
 def masked_head(node_rep, idx, linear, label, with_metrics=False, accum=None):
