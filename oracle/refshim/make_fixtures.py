@@ -572,6 +572,61 @@ def make_bio_finetune(ref):
     save("ref_bio_finetune_b32", fx)
 
 
+# ----------------------------------------------------------------------------- bio: edge prediction, Deep Graph Infomax
+def make_bio_edgepred(ref):
+    """bio/util.py:16-44 NegativeEdge -> bio/batch.py:123-172 BatchAE (bio/dataloader.py:45 DataLoaderAE) ->
+    bio/pretrain_edgepred.py:20-43 train() (sums divided by the step COUNT, unlike the chem script)"""
+    pe = ref.pretrain_edgepred
+    raw = bio_raw(4 * 16, seed=16)
+    torch.manual_seed(17)  # NegativeEdge draws its candidates with torch.randint
+    tf = ref.util.NegativeEdge()
+    graphs = [tf(to_ref_bio(ref, g)) for g in raw]
+    fx = {"raw": raw_pack(raw), "batch_size": 16, "neg": ragged([g.negative_edge_index.t().reshape(-1).tolist() for g in graphs])}
+    loader = ref.dataloader.DataLoaderAE(graphs, batch_size=16, shuffle=False, num_workers=0)
+    fx["batch0"] = batch_pack(next(iter(loader)))
+    for gt in ("gin", "gcn"):
+        torch.manual_seed(0)
+        model = ref.model.GNN(5, 300, JK="last", drop_ratio=0, gnn_type=gt)
+        opt = adam(model.parameters())
+        with Recorder(pe, "criterion") as crit:
+            ret = pe.train(argparse.Namespace(), model, torch.device("cpu"), loader, opt)
+        vals = [float(v) for v in crit.values]  # two calls per step: positive pairs, negative pairs
+        fx[gt] = {"returned": np.array(ret, dtype=np.float64), "loss": np.array([a + b for a, b in zip(vals[0::2], vals[1::2])]),
+                  "final_params": pack_params(list(model.named_parameters()), lambda p: p)}
+    save("ref_bio_edgepred_b16", fx)
+
+
+def make_bio_infomax(ref):
+    """torch_geometric DataLoader (bio/pretrain_deepgraphinfomax.py:4) -> its Infomax / Discriminator :27-50 -> train() :52-84"""
+    dgi = ref.pretrain_deepgraphinfomax
+    raw = bio_raw(4 * 16, seed=18)
+    graphs = [to_ref_bio(ref, g) for g in raw]
+    loader = dgi.DataLoader(graphs, batch_size=16, shuffle=False, num_workers=0)
+    torch.manual_seed(0)
+    gnn = ref.model.GNN(5, 300, JK="last", drop_ratio=0, gnn_type="gin")
+    model = dgi.Infomax(gnn, dgi.Discriminator(300))
+    disc0 = model.discriminator.weight.detach().clone()
+    opt = adam(model.parameters())
+    vals = []
+
+    class RecordingLoss(torch.nn.Module):  # `loss` is a registered child module: its stand-in has to be one too
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, *a):
+            r = self.inner(*a)
+            vals.append(float(r))
+            return r
+
+    model.loss = RecordingLoss(model.loss)
+    ret = dgi.train(argparse.Namespace(), model, torch.device("cpu"), loader, opt)
+    fx = {"raw": raw_pack(raw), "batch_size": 16, "discriminator_init": disc0, "returned": np.array(ret, dtype=np.float64),
+          "loss": np.array([a + b for a, b in zip(vals[0::2], vals[1::2])]),
+          "final_params": pack_params(list(model.gnn.named_parameters()) + [("discriminator.weight", model.discriminator.weight)], lambda p: p)}
+    save("ref_bio_infomax_b16", fx)
+
+
 # ----------------------------------------------------------------------------- main
 def main():
     if not refshim.available():
@@ -584,7 +639,8 @@ def main():
             ("chem_contextpred", make_chem_contextpred, chem), ("chem_finetune", make_chem_finetune, chem),
             ("chem_edgepred", make_chem_edgepred, chem), ("chem_infomax", make_chem_infomax, chem),
             ("bio_masking", make_bio_masking, bio), ("bio_contextpred", make_bio_contextpred, bio),
-            ("bio_finetune", make_bio_finetune, bio)]
+            ("bio_finetune", make_bio_finetune, bio), ("bio_edgepred", make_bio_edgepred, bio),
+            ("bio_infomax", make_bio_infomax, bio)]
     for tag, fn, ref in jobs:
         if not only or tag in only:
             fn(ref)

@@ -258,3 +258,13 @@ def chem_infomax_step(gnn, discriminator, optimizer, batch, pool=pyg.global_mean
     optimizer.step()
     acc = (torch.sum(positive_score > 0) + torch.sum(negative_score < 0)).to(torch.float32) / float(2 * len(positive_score))
     return float(loss.detach().cpu().item()), float(acc.detach().cpu().item())
+
+
+def bio_edgepred_step(model, optimizer, batch):
+    """bio/pretrain_edgepred.py:26-40: the same loop body as the chem script's, on bio/model.py's GNN."""
+    return chem_edgepred_step(model, optimizer, batch)
+
+
+def bio_infomax_step(gnn, discriminator, optimizer, batch, pool=pyg.global_mean_pool):
+    """bio/pretrain_deepgraphinfomax.py:59-81: the same loop body as the chem script's, on bio/model.py's GNN."""
+    return chem_infomax_step(gnn, discriminator, optimizer, batch, pool)

@@ -567,3 +567,47 @@ def chem_infomax_step(model, optimizer, batch):
     acc = (torch.sum(positive_score > 0) + torch.sum(negative_score < 0)).to(torch.float32) / float(2 * len(positive_score))
     out = torch.stack([loss.detach(), acc]).cpu().tolist()
     return out[0], out[1]
+
+
+def bio_edgepred_step(model, optimizer, batch):
+    """One iteration of bio/pretrain_edgepred.py:26-40: the loop body is the chem script's (scores of one direction
+    of every PPI edge against the NegativeEdge pairs of bio/util.py:16-44) on a bio ``GNN``."""
+    return chem_edgepred_step(model, optimizer, batch)
+
+
+def bio_infomax_step(model, optimizer, batch):
+    """One iteration of bio/pretrain_deepgraphinfomax.py:59-81 on an ``Infomax`` model holding a bio ``GNN``."""
+    return chem_infomax_step(model, optimizer, batch)
+
+
+def _pair_epoch(step, model, optimizer, loader, device, count_last_index):
+    acc_sum = loss_sum = 0.0
+    steps = 0
+    for batch in loader:
+        loss, acc = step(model, optimizer, batch.to(device) if device is not None else batch)
+        loss_sum += loss
+        acc_sum += acc
+        steps += 1
+    div = steps - 1 if count_last_index else steps
+    return acc_sum / div, loss_sum / div
+
+
+def chem_edgepred_epoch(model, optimizer, loader, device=None):
+    """chem/pretrain_edgepred.py:25-52 train(): returns (accuracy, loss) sums divided by the LAST step index (:52 divides by
+    ``step``, not ``step + 1``) -- kept, so that logged curves line up with the reference's."""
+    return _pair_epoch(chem_edgepred_step, model, optimizer, loader, device, True)
+
+
+def chem_infomax_epoch(model, optimizer, loader, device=None):
+    """chem/pretrain_deepgraphinfomax.py:52-90 train(): the same last-index divisor (:90)."""
+    return _pair_epoch(chem_infomax_step, model, optimizer, loader, device, True)
+
+
+def bio_edgepred_epoch(model, optimizer, loader, device=None):
+    """bio/pretrain_edgepred.py:20-43 train(): sums divided by the step count (:43)."""
+    return _pair_epoch(bio_edgepred_step, model, optimizer, loader, device, False)
+
+
+def bio_infomax_epoch(model, optimizer, loader, device=None):
+    """bio/pretrain_deepgraphinfomax.py:52-84 train(): sums divided by the step count (:84)."""
+    return _pair_epoch(bio_infomax_step, model, optimizer, loader, device, False)

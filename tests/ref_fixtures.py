@@ -206,19 +206,21 @@ def assert_same_bio_context(fx, raw, graphs, want):
 
 
 
-def edgepred_batches(fx):
-    """raw graphs + the reference's stored NegativeEdge draws -> BatchAE layout through the host collate"""
-    raw = raw_graphs(fx["raw"])
+def edgepred_batches(fx, bio=False):
+    """raw graphs + the reference's stored NegativeEdge draws -> BatchAE layout through the host collate (bio/batch.py:147-154 shifts
+    edge_index and negative_edge_index only: ``center_node_idx`` stays graph-local)"""
+    raw = raw_graphs(fx["raw"], bio=bio)
     graphs = []
     for i, g in enumerate(raw):
         neg = ragged(fx["neg"], i).reshape(-1, 2).t().contiguous()
-        graphs.append(synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr, negative_edge_index=neg))
+        extra = {"center_node_idx": g.center_node_idx} if bio else {}
+        graphs.append(synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr, negative_edge_index=neg, **extra))
     bs = int(fx["batch_size"])
-    return [hostdata.collate(graphs[i:i + bs]) for i in range(0, len(graphs), bs)]
+    return [hostdata.collate(graphs[i:i + bs], shift_center=False) for i in range(0, len(graphs), bs)]
 
 
-def plain_batches(fx):
-    raw = raw_graphs(fx["raw"])
+def plain_batches(fx, bio=False):
+    raw = raw_graphs(fx["raw"], bio=bio)
     graphs = [synthetic.Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr) for g in raw]
     bs = int(fx["batch_size"])
     return [hostdata.collate(graphs[i:i + bs]) for i in range(0, len(graphs), bs)]

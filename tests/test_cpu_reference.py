@@ -327,6 +327,74 @@ def test_infomax_mirrors_reproduce_reference():
         rf.check_params(named, fx["final_params"], lambda p: p, rtol=2e-5)
 
 
+@pytest.mark.parametrize("gt", ["gin", "gcn"])
+def test_bio_edgepred_mirrors_reproduce_reference(gt):
+    """bio/util.py:16-44 NegativeEdge + bio/batch.py:123-172 BatchAE + bio/pretrain_edgepred.py:20-43 train() run by the reference"""
+    fx = rf.load("ref_bio_edgepred_b16")
+    batches = rf.edgepred_batches(fx, bio=True)
+    for k, v in fx["batch0"].items():
+        assert torch.equal(getattr(batches[0], k).to(v.dtype), v), k  # the BatchAE collate (graph-local center_node_idx), bit for bit
+    want = fx[gt]
+    for step, epoch in ((steps.bio_edgepred_step, None), (ptrain.bio_edgepred_step, ptrain.bio_edgepred_epoch)):
+        torch.manual_seed(0)
+        model = obio.GNN(5, 300, JK="last", drop_ratio=0, gnn_type=gt)
+        model.train()
+        opt = adam(model.parameters())
+        if epoch is None:
+            out = [step(model, opt, b) for b in batches]
+            losses, accs = np.array([o[0] for o in out]), np.array([o[1] for o in out])
+            np.testing.assert_allclose(losses, want["loss"].numpy(), rtol=2e-6)
+            ret = [accs.mean(), losses.mean()]  # the bio script divides by the step count (bio/pretrain_edgepred.py:43)
+        else:
+            ret = epoch(model, opt, batches)
+        np.testing.assert_allclose(ret, want["returned"].numpy(), rtol=2e-6)
+        rf.check_params(list(model.named_parameters()), want["final_params"], lambda p: p, rtol=2e-5)
+
+
+def test_bio_infomax_mirrors_reproduce_reference():
+    """torch_geometric DataLoader collate + bio/pretrain_deepgraphinfomax.py:27-84 (Discriminator, Infomax, train()) run by the reference"""
+    fx = rf.load("ref_bio_infomax_b16")
+    batches = rf.plain_batches(fx, bio=True)
+    for driver in ("oracle_steps", "product_mirror"):
+        torch.manual_seed(0)
+        gnn = obio.GNN(5, 300, JK="last", drop_ratio=0, gnn_type="gin")
+        disc = steps.Discriminator(300) if driver == "oracle_steps" else ptrain.Discriminator(300)
+        assert torch.equal(disc.weight.detach(), fx["discriminator_init"])
+        gnn.train()
+        if driver == "oracle_steps":
+            opt = adam(list(gnn.parameters()) + list(disc.parameters()))
+            out = [steps.bio_infomax_step(gnn, disc, opt, b) for b in batches]
+            losses, accs = np.array([o[0] for o in out]), np.array([o[1] for o in out])
+            np.testing.assert_allclose(losses, fx["loss"].numpy(), rtol=2e-6)
+            ret = [accs.mean(), losses.mean()]
+        else:
+            model = ptrain.Infomax(gnn, disc)
+            model.pool = pyg.global_mean_pool  # CPU run: the HIP pooling op needs the GPU
+            opt = adam(model.parameters())
+            ret = ptrain.bio_infomax_epoch(model, opt, batches)
+        np.testing.assert_allclose(ret, fx["returned"].numpy(), rtol=2e-6)
+        named = list(gnn.named_parameters()) + [("discriminator.weight", disc.weight)]
+        rf.check_params(named, fx["final_params"], lambda p: p, rtol=2e-5)
+
+
+def test_chem_pair_epochs_keep_the_last_index_divisor():
+    """chem/pretrain_edgepred.py:52 and chem/pretrain_deepgraphinfomax.py:90 divide by ``step``: the epoch mirrors return the same"""
+    fx = rf.load("ref_chem_edgepred_b32")
+    torch.manual_seed(0)
+    model = ochem.GNN(5, 300, JK="last", drop_ratio=0, gnn_type="gin")
+    model.train()
+    ret = ptrain.chem_edgepred_epoch(model, adam(model.parameters()), rf.edgepred_batches(fx))
+    np.testing.assert_allclose(ret, fx["gin"]["returned"].numpy(), rtol=2e-6)
+    fx = rf.load("ref_chem_infomax_b32")
+    torch.manual_seed(0)
+    gnn = ochem.GNN(5, 300, JK="last", drop_ratio=0, gnn_type="gin")
+    model = ptrain.Infomax(gnn, ptrain.Discriminator(300))
+    model.pool = pyg.global_mean_pool
+    model.train()
+    ret = ptrain.chem_infomax_epoch(model, adam(model.parameters()), rf.plain_batches(fx))
+    np.testing.assert_allclose(ret, fx["returned"].numpy(), rtol=2e-6)
+
+
 # ============================================================================== bio fine-tuning
 @pytest.mark.parametrize("pooling", ["mean", "sum"])
 def test_bio_finetune_mirrors_reproduce_reference(pooling):

@@ -1455,3 +1455,64 @@ def test_bio_aggregate_fused_tile_path_is_bit_identical(gcn, monkeypatch, tile_k
         res.append((out.detach(), xi.grad, wi.grad, bi.grad))
     for a, c in zip(*res):
         assert torch.equal(a, c)
+
+
+def test_last_block_folds_read_committed_partials_under_memory_pressure():
+    """the "last block to finish folds everybody's partial results" launches -- BatchNorm backward's grouped
+    fold (k_bn_bwd_partial / bn_bwd_fold), the masking head's loss / accuracy fold (k_head_fwd), the context-prediction loss
+    (k_ctx_scores), Adam's step counter -- publish partials with agent-scope stores and count arrivals with relaxed tickets; since
+    round 4 every publishing thread waits for its stores (s_waitcnt vmcnt(0), common.h publish_commit) before the barrier / ticket
+    that announces them.  Stress: many blocks, and a second stream saturating HBM with large copies while the launches run, 40
+    repetitions each -- every repetition must reproduce the unstressed result bit for bit (the kernels are deterministic, so a
+    partial fetched before it landed shows as a mismatch)."""
+    ops = _ops()
+    from pretrain_gnns_amd import ops as pops
+    torch.manual_seed(0)
+    dev = torch.device(DEV)
+    # BatchNorm backward over 32 k rows (1 024 partial blocks, 64 fold groups)
+    n, dim = 32768, 300
+    bn = torch.nn.BatchNorm1d(dim).to(dev)
+    x = (torch.randn(n, dim, device=dev) * 2 + 1)
+    gout = torch.randn(n, dim, device=dev)
+
+    def bn_pass():
+        bn.zero_grad()
+        xd = x.clone().requires_grad_(True)
+        pops.batch_norm(xd, bn, True).backward(gout)
+        return xd.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()
+
+    # masking head: 20 000 gathered rows -> 5 000 blocks folding loss and accuracy
+    h = torch.randn(60000, dim, device=dev)
+    idx = torch.randperm(60000, device=dev)[:20000].contiguous()
+    lin = torch.nn.Linear(dim, 119).to(dev)
+    label = torch.randint(0, 119, (20000,), device=dev)
+
+    def head_pass():
+        loss, correct = pops.masked_head(h, idx, lin, label)
+        return loss.clone(), correct.clone()
+
+    # context-prediction loss: 2 048 graphs
+    B = 2048
+    hs, hc = torch.randn(B * 20, dim, device=dev), torch.randn(B * 12, dim, device=dev)
+    center = (torch.arange(B, device=dev) * 20).contiguous()
+    overlap = torch.arange(B * 12, device=dev)
+    seg = torch.arange(B, device=dev).repeat_interleave(12).contiguous()
+
+    def ctx_pass():
+        loss, vals = pops.contextpred_loss(hs, center, hc, overlap, seg, 2)
+        return loss.clone(), vals.clone()
+
+    passes = (bn_pass, head_pass, ctx_pass)
+    want = [p() for p in passes]
+    torch.cuda.synchronize()
+    hog_a, hog_b = torch.empty(1 << 28, dtype=torch.float32, device=dev), torch.empty(1 << 28, dtype=torch.float32, device=dev)  # 1 GiB each
+    side = torch.cuda.Stream()
+    for rep in range(40):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                hog_b.copy_(hog_a, non_blocking=True)
+        for p, w in zip(passes, want):
+            got = p()
+            for a, b in zip(got, w):
+                assert torch.equal(a, b), (p.__name__, rep)
+    torch.cuda.synchronize()

@@ -404,6 +404,40 @@ def test_infomax_vs_reference():
     assert abs(sum(o[1] for o in out) / (len(out) - 1) - float(fx["returned"][0])) <= 0.03
 
 
+@pytest.mark.parametrize("gt", ["gin", "gcn"])
+def test_bio_edgepred_vs_reference(gt):
+    """bio/pretrain_edgepred.py:20-43 train() run by the reference (NegativeEdge draws and BatchAE collate from the fixture)"""
+    fx = rf.load("ref_bio_edgepred_b16")
+    _, hbio = hip_models()
+    batches = [b.to(DEV) for b in rf.edgepred_batches(fx, bio=True)]
+    torch.manual_seed(0)
+    model = hbio.GNN(5, 300, JK="last", drop_ratio=0, gnn_type=gt).to(DEV)
+    model.train()
+    opt = adam(model.parameters())
+    out = [ptrain.bio_edgepred_step(model, opt, b) for b in batches]
+    want = fx[gt]
+    _traj([o[0] for o in out], want["loss"].numpy(), "bio_edgepred/%s" % gt)
+    ret = np.array([sum(o[1] for o in out) / len(out), sum(o[0] for o in out) / len(out)])  # divided by the step count (bio/pretrain_edgepred.py:43)
+    assert abs(ret[0] - float(want["returned"][0])) <= 0.03 and abs(ret[1] - float(want["returned"][1])) <= TRAJ_RTOL * float(want["returned"][1])
+
+
+def test_bio_infomax_vs_reference():
+    """bio/pretrain_deepgraphinfomax.py:27-84 (Discriminator, Infomax, train()) run by the reference"""
+    fx = rf.load("ref_bio_infomax_b16")
+    _, hbio = hip_models()
+    batches = [b.to(DEV) for b in rf.plain_batches(fx, bio=True)]
+    torch.manual_seed(0)
+    gnn = hbio.GNN(5, 300, JK="last", drop_ratio=0, gnn_type="gin")
+    disc = ptrain.Discriminator(300)
+    assert torch.equal(disc.weight.detach(), fx["discriminator_init"])
+    model = ptrain.Infomax(gnn, disc).to(DEV)
+    model.train()
+    opt = adam(model.parameters())
+    out = [ptrain.bio_infomax_step(model, opt, b) for b in batches]
+    _traj([o[0] for o in out], fx["loss"].numpy(), "bio_infomax")
+    assert abs(sum(o[1] for o in out) / len(out) - float(fx["returned"][0])) <= 0.03
+
+
 # ============================================================================== bio fine-tuning
 @pytest.mark.parametrize("pooling", ["mean", "sum"])
 def test_bio_finetune_vs_reference(pooling):
