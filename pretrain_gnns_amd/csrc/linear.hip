@@ -2085,9 +2085,301 @@ int launch_gemm2pw_s(const GemmArgs& p, hipStream_t st) {
   hipLaunchKernelGGL((k_gemm2pw<BM, BN, WAVES_M, WAVES_N, STAGES, EPI>), dim3(tiles), dim3(64 * WAVES_M * WAVES_N), lds, st, p);
   return check_launch("gemm2pw");
 }
+// ==================================================================================================================================
+// Large M: the weight planes RESIDENT in LDS, the activations streamed through registers, no barrier in the loop (k_gemm2pr).
+// At 262 144 x 300 -> 600 the tiled kernel above spends its time waiting, not multiplying (tools/gemm2p_large.py: the same 540-640 us
+// with its MFMAs removed): every 64/128-row tile pays a workgroup launch, a pipeline fill and an epilogue, and every 32 of k a
+// barrier, with one or two workgroups per CU to hide them behind.  Here one persistent workgroup per CU DMAs the two planes of ITS
+// 16 NI weight rows -- all NK k-steps of them, 100-152 KB in the ring's [row][32 k] image -- into LDS once; then its waves never
+// synchronise again.  A wave owns 16-row blocks of A (block w, w + NW, ... of the workgroup's row range): each lane fetches its own
+// MFMA fragments -- row fr, floats 32 s + 8 fk .. + 7 -- straight into registers, a WHOLE BLOCK ahead (fragment s of the next block
+// goes into the registers fragment s of this block has just been split out of: 8 NK registers, static indices, the k-loop fully
+// unrolled), splits them under the row's scale, multiplies against fragments read from the resident planes and writes its 16 x 16 NI
+// results.  The 16 NI-column workgroups that share a row range sit on one XCD and walk it at the same pace: A comes from HBM once.
+// Loads are inline asm with counted s_waitcnt (hipcc's own pass would drain vmcnt(0) at every first use while LDS-DMA or younger
+// loads are outstanding); the counts below hold with stores in flight (loads return in order among themselves: if a load is
+// outstanding so is every younger load, so "at most <number of younger loads> outstanding" implies it has landed).
+// Same fragments, same k order, same term order as k_gemm2pw: bit-identical (tests/test_gpu_ops.py).
+// ==================================================================================================================================
+template <int NK, int NI, int NW, int EPI>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) k_gemm2pr(GemmArgs p, int ranges_per_xcd) {
+  constexpr int BN = 16 * NI, B_PLANE = BN * 64, STAGE = 2 * B_PLANE;
+  constexpr int NIM = EPI == EPI_MASK ? NI : 0;       // mask loads per block
+  constexpr int Y_STEP = 2 * NK - 1 + NIM;            // loads younger than fragment s + 1 of this block when step s claims it
+  constexpr int Y_BLOCK = 2 * NK - 2;                 // ... than fragment 0 / the row maximum at the top of a block, than the mask in its epilogue
+  static_assert(NI >= 4 && NK >= 2 && Y_STEP < 64 && NW % 4 == 0, "shape");
+  extern __shared__ __align__(16) unsigned char smem2r[];
+  float* const epi = reinterpret_cast<float*>(smem2r + NK * STAGE);  // [2][BN]: 1 / scale of the weight rows, bias
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fk = lane >> 4;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int xcd = blockIdx.x % p.nxcd, slot = blockIdx.x / p.nxcd;  // (workgroups go round-robin over the XCDs)
+  const int rloc = slot / tiles_n;
+  if (rloc >= ranges_per_xcd) return;
+  const int n0 = (slot % tiles_n) * BN;
+  const int nranges = ranges_per_xcd * p.nxcd, range = xcd * ranges_per_xcd + rloc;
+  const int nblocks = (p.M + 15) / 16;
+  const int lo = (int)((int64_t)nblocks * range / nranges), hi = (int)((int64_t)nblocks * (range + 1) / nranges);
+  const float* __restrict__ b_inv = reinterpret_cast<const float*>(p.Bp + 2 * p.bplane);
+
+  // ---- the planes of rows n0 .. n0 + BN, every k-step: piece e of stage s = plane e / NI, rows 16 (e % NI) ..
+  for (int d = wave; d < NK * 2 * NI; d += NW) {
+    const int s = d / (2 * NI), e = d % (2 * NI), q = e / NI, pb = e % NI;
+    const int row = 16 * pb + (lane >> 2);
+    const int c = (lane & 3) ^ ((-(lane >> 4)) & 3);
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(p.Bp + q * p.bplane + (int64_t)min(n0 + row, p.N - 1) * p.ldbp);
+    __builtin_amdgcn_global_load_lds(PGNN_GPTR(src + min(64 * s + 16 * c, 2 * ((int)p.ldbp - 8))), PGNN_LPTR(smem2r + s * STAGE + e * 1024), 16, 0, 0);
+  }
+  for (int i = tid; i < BN; i += 64 * NW) {
+    const int nn = min(n0 + i, p.N - 1);
+    epi[i] = b_inv[nn];
+    epi[BN + i] = (EPI == EPI_BIAS && p.bias) ? p.bias[nn] : 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int rb = lo + wave;
+  if (rb >= hi) return;  // (no barrier below)
+
+  const int b_off = fr * 64 + ((fk ^ ((-(fr >> 2)) & 3)) * 16);
+  f16x8 b[NI][2];
+  auto bload = [&](int stage, int j) {
+    const unsigned char* s = smem2r + stage * STAGE;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) b[j][q] = *reinterpret_cast<const f16x8*>(s + q * B_PLANE + b_off + j * 16 * 64);
+  };
+  // this lane's fragments: raw[s] = floats 32 s + 8 fk .. + 7 of its row (fetching 64 contiguous bytes per row and load, with two
+  // v_permlane swaps per dword back to this map, measured the same: tools/probe/permlane_probe.hip, profiles/r04/gemm2pr_ab.txt); the
+  // last k-step re-reads the row's last four floats past the end (the planes are zero there), like the tiled kernel's DMA
+  f32x4 raw[NK][2];
+  float amx;
+  f32x4 mk[EPI == EPI_MASK ? NI : 1];
+  const int last0 = min(32 * (NK - 1) + 8 * fk, p.K - 4), last1 = min(32 * (NK - 1) + 8 * fk + 4, p.K - 4);
+  auto row_of = [&](int blk) { return min(16 * blk + fr, p.M - 1); };
+  auto issue_frag = [&](auto sc, const float* rowp) {
+    constexpr int S = decltype(sc)::value;
+    if constexpr (S < NK - 1) {
+      const float* q = rowp + 8 * fk;
+      asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(raw[S][0]) : "v"(q), "n"(S * 128) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(raw[S][1]) : "v"(q), "n"(S * 128 + 16) : "memory");
+    } else {
+      const float* q0 = rowp + last0;
+      const float* q1 = rowp + last1;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[S][0]) : "v"(q0) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[S][1]) : "v"(q1) : "memory");
+    }
+  };
+  auto issue_amax = [&](int blk) {  // (without maxima from the producer the slot is loaded all the same: the counts stay put)
+    const uint32_t* q = p.a_amax ? p.a_amax + row_of(blk) : reinterpret_cast<const uint32_t*>(p.A);
+    asm volatile("global_load_dword %0, %1, off" : "=v"(amx) : "v"(q) : "memory");
+  };
+#define PGNN_CLAIM(x) asm volatile("" : "+v"(x))  /* behind the wait that covers x's load: from here on x may be read */
+  auto split_q = [&](int c, const f32x4& lo, const f32x4& hi, float sa, uint4 (&pl)[2]) {
+    const f32x4 v = c < 2 ? lo : hi;
+    uint32_t h, l;
+    split2(v[2 * (c & 1)] * sa, v[2 * (c & 1) + 1] * sa, h, l);
+    (&pl[0].x)[c] = h; (&pl[1].x)[c] = l;
+  };
+
+  {
+    const float* rowp = p.A + (int64_t)row_of(rb) * p.lda;
+    issue_amax(rb);
+    auto all = [&](auto self, auto sc) {
+      constexpr int S = decltype(sc)::value;
+      if constexpr (S < NK) {
+        issue_frag(sc, rowp);
+        self(self, std::integral_constant<int, S + 1>{});
+      }
+    };
+    all(all, std::integral_constant<int, 0>{});
+  }
+  bload(0, 0);
+  bload(0, 1);
+  f32x4 acc[NI];
+  f16x8 a0[2], a1[2];
+  for (;;) {
+    const int nxt = rb + NW < hi ? rb + NW : rb;  // (past the end: this block again -- every load lands in memory that exists)
+    const float* rowp = p.A + (int64_t)row_of(nxt) * p.lda;
+    // ---- top of the block: its row maximum and fragment 0 have landed
+    gemm_wait_vmcnt_imm<Y_BLOCK>();
+    asm volatile("" : "+v"(amx));
+    PGNN_CLAIM(raw[0][0]);
+    PGNN_CLAIM(raw[0][1]);
+    if (!p.a_amax) {  // (uniform) no maxima from a producer: the wave holds its rows entirely -- fold them out of the fragments
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      float mx = 0.f;
+      auto fold = [&](auto self, auto sc) {
+        constexpr int S = decltype(sc)::value;
+        if constexpr (S < NK) {
+          PGNN_CLAIM(raw[S][0]);
+          PGNN_CLAIM(raw[S][1]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fmaxf(fabsf(raw[S][0][u]), fabsf(raw[S][1][u])));
+          self(self, std::integral_constant<int, S + 1>{});
+        }
+      };
+      fold(fold, std::integral_constant<int, 0>{});
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      amx = fmaxf(mx, __shfl_xor(mx, 32));
+    }
+    float sa, ainv;
+    pow2_scales(amx, sa, ainv);
+    {
+      uint4 pl[2];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) split_q(c, raw[0][0], raw[0][1], sa, pl);
+      a0[0] = __builtin_bit_cast(f16x8, pl[0]);
+      a0[1] = __builtin_bit_cast(f16x8, pl[1]);
+    }
+    issue_amax(nxt);
+    issue_frag(std::integral_constant<int, 0>{}, rowp);
+    const int mrow = row_of(rb);
+    if constexpr (EPI == EPI_MASK) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const float* q = p.mask + (int64_t)mrow * p.ldmask + min(n0 + j * 16 + fk * 4, p.N - 4);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(mk[j]) : "v"(q) : "memory");
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto kstep = [&](auto sc, const f16x8 (&cur)[2], f16x8 (&nx)[2]) {
+      constexpr int S = decltype(sc)::value;
+      constexpr bool MORE = S + 1 < NK;          // a fragment of THIS block is still to be split
+      constexpr int NS = MORE ? S + 1 : 0;
+      uint4 pl[2];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j][0], cur[1], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j][1], cur[0], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j][0], cur[0], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MORE) {
+          if (j == 0) {
+            gemm_wait_vmcnt_imm<Y_STEP>();
+            PGNN_CLAIM(raw[NS][0]);
+            PGNN_CLAIM(raw[NS][1]);
+          }
+          // the four quarters of the next fragment behind blocks 1 .. NI - 1
+          constexpr int Q0 = 1;
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if ((NI >= 5 ? Q0 + c : (c == 0 ? 1 : c)) == j) {
+              split_q(c, raw[NS][0], raw[NS][1], sa, pl);
+              asm volatile("" ::"v"((&pl[0].x)[c]), "v"((&pl[1].x)[c]));
+            }
+          if (j == (NI >= 5 ? 4 : 3)) issue_frag(std::integral_constant<int, NS>{}, rowp);  // the next block's, into the registers just split
+        }
+        if (j + 2 < NI) bload(S, j + 2);
+        else bload(MORE ? S + 1 : 0, j + 2 - NI);  // (the last step wraps: the next block starts at stage 0)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (MORE) {
+        nx[0] = __builtin_bit_cast(f16x8, pl[0]);
+        nx[1] = __builtin_bit_cast(f16x8, pl[1]);
+      }
+    };
+    auto ksteps = [&](auto self, auto sc) {
+      constexpr int S = decltype(sc)::value;
+      if constexpr (S < NK) {
+        if constexpr (S % 2 == 0) kstep(sc, a0, a1);
+        else kstep(sc, a1, a0);
+        self(self, std::integral_constant<int, S + 1>{});
+      }
+    };
+    ksteps(ksteps, std::integral_constant<int, 0>{});
+
+    // ---- epilogue: lane holds C[16 rb + fr][n0 + 16 j + 4 fk + 0..3]
+    if constexpr (EPI == EPI_MASK) {
+      gemm_wait_vmcnt_imm<Y_BLOCK>();
+#pragma unroll
+      for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(mk[j]));
+    }
+    const int mb = 16 * rb, m = mb + fr;
+    float cmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + j * 16 + fk * 4;
+      const float4 bi = *reinterpret_cast<const float4*>(epi + j * 16 + fk * 4);
+      float4 v = make_float4(acc[j][0] * (ainv * bi.x), acc[j][1] * (ainv * bi.y), acc[j][2] * (ainv * bi.z), acc[j][3] * (ainv * bi.w));
+      if constexpr (EPI == EPI_BIAS) {
+        v = f4_add(v, *reinterpret_cast<const float4*>(epi + BN + j * 16 + fk * 4));
+        if (p.relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        if (p.colstat) {  // (uniform) per-16-row-block column sums and squared deviations, as in k_gemm2pw
+          const int cnt = min(16, p.M - mb);
+          const bool ok = fr < cnt;
+          float4 sm = ok ? v : f4_zero();
+          sm.x = row16_sum(sm.x); sm.y = row16_sum(sm.y); sm.z = row16_sum(sm.z); sm.w = row16_sum(sm.w);
+          const float inv = 1.f / (float)cnt;
+          float4 q;
+          q.x = ok ? v.x - sm.x * inv : 0.f; q.y = ok ? v.y - sm.y * inv : 0.f;
+          q.z = ok ? v.z - sm.z * inv : 0.f; q.w = ok ? v.w - sm.w * inv : 0.f;
+          q.x = row16_sum(q.x * q.x); q.y = row16_sum(q.y * q.y); q.z = row16_sum(q.z * q.z); q.w = row16_sum(q.w * q.w);
+          if (fr == 0 && n < p.N) {
+            float* cs = p.colstat + (int64_t)rb * 2 * p.N + n;
+            *reinterpret_cast<float4*>(cs) = sm;
+            *reinterpret_cast<float4*>(cs + p.N) = q;
+          }
+        }
+      }
+      if constexpr (EPI == EPI_MASK) {
+        const f32x4 k4 = mk[j];
+        if (!(k4[0] > 0.f)) v.x = 0.f;
+        if (!(k4[1] > 0.f)) v.y = 0.f;
+        if (!(k4[2] > 0.f)) v.z = 0.f;
+        if (!(k4[3] > 0.f)) v.w = 0.f;
+      }
+      if (m < p.M && n < p.N) *reinterpret_cast<float4*>(p.C + (int64_t)m * p.ldc + n) = v;
+      if (n < p.N) cmax = fmaxf(cmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    if (p.c_amax) {  // (uniform) as in k_gemm2pw: the row's maximum over this workgroup's columns, atomic over the column workgroups
+      cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
+      cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+      if (fk == 0 && m < p.M) atomicMax(p.c_amax + m, __float_as_uint(cmax));
+    }
+    if (rb + NW >= hi) break;
+    rb += NW;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the fetches past the last block land in registers nobody reads: let them)
+#undef PGNN_CLAIM
+}
+
+// can k_gemm2pr take this product?  K of 257-320 (10 k-steps, 80 columns per workgroup) or 577-608 (19, 64): the GIN mlp's two shapes;
+// enough 16-row blocks for every wave of every workgroup to stream a few; one workgroup per CU, a whole number of row ranges per XCD
+inline int gemm2pr_ranges(const GemmArgs& p, int bn) {
+  const int per_xcd = num_cu() / std::max(1, p.nxcd);
+  return per_xcd / (int)ceil_div(p.N, bn);
+}
+inline bool gemm2pr_eligible(const GemmArgs& p) {
+  const int knob = env_knob("PGNN_GEMM2P_RES", 1);
+  if (!knob || p.bnf.n > 0 || p.nxcd <= 0 || num_cu() % p.nxcd != 0) return false;
+  const int64_t nk = ceil_div(p.K, 32);
+  const int bn = nk == 10 ? 80 : nk == 19 ? 64 : 0;
+  if (!bn || gemm2pr_ranges(p, bn) < 1) return false;
+  return knob >= 2 || p.M >= (nk == 10 ? 16384 : 32768);  // (measured against the tiled kernel: tools/gemm2p_large.py)
+}
+template <int NK, int NI, int NW, int EPI>
+int launch_gemm2pr_s(const GemmArgs& p, hipStream_t st) {
+  constexpr size_t lds = (size_t)NK * 2 * (16 * NI) * 64 + 2 * (16 * NI) * 4;
+  const int ranges = gemm2pr_ranges(p, 16 * NI);
+  allow_big_lds((const void*)k_gemm2pr<NK, NI, NW, EPI>, lds);
+  hipLaunchKernelGGL((k_gemm2pr<NK, NI, NW, EPI>), dim3(num_cu()), dim3(64 * NW), lds, st, p, ranges);
+  return check_launch("gemm2pr");
+}
+template <int EPI>
+int launch_gemm2pr(const GemmArgs& p, hipStream_t st) {
+  if (ceil_div(p.K, 32) == 10) return launch_gemm2pr_s<10, 5, 8, EPI>(p, st);
+  return launch_gemm2pr_s<19, 4, 8, EPI>(p, st);
+}
+
 // the two tiles of launch_gemm3w's default choice, under its rounds x (k-steps + fixed) model with the two-plane step times
 template <int EPI>
 int launch_gemm2pw(const GemmArgs& p, hipStream_t st) {
+  if (gemm2pr_eligible(p)) return launch_gemm2pr<EPI>(p, st);
   const int64_t nk = ceil_div(p.K, 32), cus = num_cu();
   const double t64 = (double)ceil_div(ceil_div(p.M, 64) * ceil_div(p.N, 160), cus) * (0.5 * nk + 5.0);
   const double t128 = (double)ceil_div(ceil_div(p.M, 128) * ceil_div(p.N, 160), cus) * (0.95 * nk + 6.0);

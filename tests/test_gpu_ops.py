@@ -752,6 +752,53 @@ def test_products_on_two_fp16_planes_against_float64(case, m, k, n, monkeypatch)
         assert torch.equal(za, zb)
 
 
+@pytest.mark.parametrize("m,k,n", [(6747, 300, 600), (6747, 600, 300), (41269, 300, 600), (63, 600, 600), (1, 300, 600), (17, 600, 300), (70001, 600, 300), (139283, 300, 600)])
+def test_resident_plane_products_give_the_bits_of_the_tiled_ones(m, k, n, monkeypatch):
+    """k_gemm2pr (large M: the weight planes of 80 / 64 output columns resident in LDS for all 10 / 19 k-steps, one persistent workgroup
+    per CU, every wave streaming its own 16-row blocks of the activations through registers a whole block ahead, no barrier in the
+    loop) takes over from 65 536 rows on; forced onto every row count (PGNN_GEMM2P_RES=2) it gives the bits of the tiled kernel (=0):
+    forward with bias + ReLU, the per-16-row column statistics and the row maxima; backward-data with the ReLU mask and without; row
+    maxima handed in or folded out of the fragments the wave holds.  Row counts that leave most workgroups / waves without a block,
+    ragged last blocks, 2 x 272 rows per wave."""
+    ops = _ops()
+    lib, sp = ops.load(), ops.stream_ptr()
+    x = _adversarial_rows("mixed_scales", m, k).to(DEV)
+    torch.manual_seed(n)
+    w = (torch.randn(n, k) * 0.05).to(DEV)
+    b = torch.randn(n, device=DEV)
+    (wp, wtp), _ = _weight_planes_2p(lib, sp, [w, w], [False, True])
+    xam = x.abs().max(dim=1).values.contiguous().view(torch.int32)
+    dy = (_adversarial_rows("gradient_rows", m, n)).to(DEV)
+    mask = torch.relu(torch.randn(m, k, device=DEV))
+
+    def run(knob, given):
+        monkeypatch.setenv("PGNN_GEMM2P_RES", knob)
+        lib.pgnn_reload_env()
+        y = torch.full((m, n), float("nan"), device=DEV)
+        yam = torch.zeros(m, dtype=torch.int32, device=DEV)
+        cs = torch.full(((m + 15) // 16, 2, n), float("nan"), device=DEV)
+        ops.check(lib.pgnn_linear_fwd_2p(x.data_ptr(), k, xam.data_ptr() if given else None, wp.data_ptr(), b.data_ptr(), y.data_ptr(), n, m, k, n, 1,
+                                         cs.data_ptr(), yam.data_ptr(), sp), "fwd 2p")
+        dx = torch.full((m, k), float("nan"), device=DEV)
+        dxam = torch.zeros(m, dtype=torch.int32, device=DEV)
+        ops.check(lib.pgnn_linear_bwd_data_2p(dy.data_ptr(), n, None, wtp.data_ptr(), mask.data_ptr(), k, dx.data_ptr(), k, m, k, n, dxam.data_ptr(), sp), "bwd 2p")
+        dx0 = torch.full((m, k), float("nan"), device=DEV)
+        ops.check(lib.pgnn_linear_bwd_data_2p(dy.data_ptr(), n, None, wtp.data_ptr(), None, 0, dx0.data_ptr(), k, m, k, n, None, sp), "bwd 2p plain")
+        torch.cuda.synchronize()
+        return y, yam, cs, dx, dxam, dx0
+
+    try:
+        want = run("0", False)
+        for given in (False, True):
+            got = run("2", given)
+            for a, c, name in zip(got, want, ("y", "y_amax", "colstat", "dx", "dx_amax", "dx_plain")):
+                assert torch.equal(a, c), (name, given)
+        assert not torch.isnan(want[0]).any() and not torch.isnan(want[3]).any()
+    finally:
+        monkeypatch.delenv("PGNN_GEMM2P_RES")
+        lib.pgnn_reload_env()
+
+
 @pytest.mark.parametrize("m,k,n", [(6747, 300, 600), (200, 600, 300)])
 def test_two_plane_products_propagate_inf_and_nan_by_row(m, k, n):
     """an inf or a NaN in a row of the activation operand makes every result of THAT row non-finite (NaN for a NaN), as the fp32
