@@ -2101,15 +2101,22 @@ int launch_gemm2pw_s(const GemmArgs& p, hipStream_t st) {
 // outstanding so is every younger load, so "at most <number of younger loads> outstanding" implies it has landed).
 // Same fragments, same k order, same term order as k_gemm2pw: bit-identical (tests/test_gpu_ops.py).
 // ==================================================================================================================================
-template <int NK, int NI, int NW, int EPI>
+// BN: the weight rows (output columns) a workgroup holds -- a multiple of 8: 120 of them at K = 300 fill the 160 KB (five workgroups
+// cover N = 600, so A passes through five L1s, not eight: at ~20 bytes per clock and CU for a stream that misses the L1, THAT traffic
+// is the kernel's bound, profiles/r04/gemm2pr_ab.txt); the last 16-column block of such a tile is half a block: eight weight rows in
+// LDS, lanes 8-15 of the fragment read re-read rows 0-7, and the columns they produce are never stored.
+template <int NK, int BN, int NW, int EPI>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) k_gemm2pr(GemmArgs p, int ranges_per_xcd) {
-  constexpr int BN = 16 * NI, B_PLANE = BN * 64, STAGE = 2 * B_PLANE;
+  constexpr int NI = (BN + 15) / 16, NFULL = BN / 16, B_PLANE = BN * 64, STAGE = 2 * B_PLANE;
+  constexpr bool HALF = BN % 16 != 0;
+  static_assert(BN % 8 == 0, "whole or half 16-column blocks");
   constexpr int NIM = EPI == EPI_MASK ? NI : 0;       // mask loads per block
   constexpr int Y_STEP = 2 * NK - 1 + NIM;            // loads younger than fragment s + 1 of this block when step s claims it
   constexpr int Y_BLOCK = 2 * NK - 2;                 // ... than fragment 0 / the row maximum at the top of a block, than the mask in its epilogue
   static_assert(NI >= 4 && NK >= 2 && Y_STEP < 64 && NW % 4 == 0, "shape");
   extern __shared__ __align__(16) unsigned char smem2r[];
-  float* const epi = reinterpret_cast<float*>(smem2r + NK * STAGE);  // [2][BN]: 1 / scale of the weight rows, bias
+  constexpr int EPN = 16 * NI;
+  float* const epi = reinterpret_cast<float*>(smem2r + NK * STAGE);  // [2][EPN]: 1 / scale of the weight rows, bias
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fk = lane >> 4;
@@ -2123,18 +2130,20 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
   const int lo = (int)((int64_t)nblocks * range / nranges), hi = (int)((int64_t)nblocks * (range + 1) / nranges);
   const float* __restrict__ b_inv = reinterpret_cast<const float*>(p.Bp + 2 * p.bplane);
 
-  // ---- the planes of rows n0 .. n0 + BN, every k-step: piece e of stage s = plane e / NI, rows 16 (e % NI) ..
+  // ---- the planes of rows n0 .. n0 + BN, every k-step: piece pb of plane q of stage s = rows 16 pb .. (a half piece: lanes 0-31)
   for (int d = wave; d < NK * 2 * NI; d += NW) {
     const int s = d / (2 * NI), e = d % (2 * NI), q = e / NI, pb = e % NI;
     const int row = 16 * pb + (lane >> 2);
     const int c = (lane & 3) ^ ((-(lane >> 4)) & 3);
     const unsigned char* src = reinterpret_cast<const unsigned char*>(p.Bp + q * p.bplane + (int64_t)min(n0 + row, p.N - 1) * p.ldbp);
-    __builtin_amdgcn_global_load_lds(PGNN_GPTR(src + min(64 * s + 16 * c, 2 * ((int)p.ldbp - 8))), PGNN_LPTR(smem2r + s * STAGE + e * 1024), 16, 0, 0);
+    if (!HALF || pb < NFULL || lane < 32)
+      __builtin_amdgcn_global_load_lds(PGNN_GPTR(src + min(64 * s + 16 * c, 2 * ((int)p.ldbp - 8))),
+                                       PGNN_LPTR(smem2r + s * STAGE + q * B_PLANE + pb * 1024), 16, 0, 0);
   }
-  for (int i = tid; i < BN; i += 64 * NW) {
+  for (int i = tid; i < EPN; i += 64 * NW) {
     const int nn = min(n0 + i, p.N - 1);
     epi[i] = b_inv[nn];
-    epi[BN + i] = (EPI == EPI_BIAS && p.bias) ? p.bias[nn] : 0.f;
+    epi[EPN + i] = (EPI == EPI_BIAS && p.bias) ? p.bias[nn] : 0.f;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -2142,11 +2151,12 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
   if (rb >= hi) return;  // (no barrier below)
 
   const int b_off = fr * 64 + ((fk ^ ((-(fr >> 2)) & 3)) * 16);
+  const int b_off_half = (fr & 7) * 64 + ((fk ^ ((-((fr & 7) >> 2)) & 3)) * 16);
   f16x8 b[NI][2];
   auto bload = [&](int stage, int j) {
-    const unsigned char* s = smem2r + stage * STAGE;
+    const unsigned char* s = smem2r + stage * STAGE + (HALF && j == NI - 1 ? b_off_half : b_off);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) b[j][q] = *reinterpret_cast<const f16x8*>(s + q * B_PLANE + b_off + j * 16 * 64);
+    for (int q = 0; q < 2; ++q) b[j][q] = *reinterpret_cast<const f16x8*>(s + q * B_PLANE + j * 16 * 64);
   };
   // this lane's fragments: raw[s] = floats 32 s + 8 fk .. + 7 of its row (fetching 64 contiguous bytes per row and load, with two
   // v_permlane swaps per dword back to this map, measured the same: tools/probe/permlane_probe.hip, profiles/r04/gemm2pr_ab.txt); the
@@ -2193,8 +2203,9 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
     };
     all(all, std::integral_constant<int, 0>{});
   }
-  bload(0, 0);
-  bload(0, 1);
+  constexpr int BD = NK == 10 ? 3 : 2;  // column blocks the plane fragments are read ahead (registers permitting)
+#pragma unroll
+  for (int j = 0; j < BD; ++j) bload(0, j);
   f32x4 acc[NI];
   f16x8 a0[2], a1[2];
   for (;;) {
@@ -2272,8 +2283,8 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
             }
           if (j == (NI >= 5 ? 4 : 3)) issue_frag(std::integral_constant<int, NS>{}, rowp);  // the next block's, into the registers just split
         }
-        if (j + 2 < NI) bload(S, j + 2);
-        else bload(MORE ? S + 1 : 0, j + 2 - NI);  // (the last step wraps: the next block starts at stage 0)
+        if (j + BD < NI) bload(S, j + BD);
+        else bload(MORE ? S + 1 : 0, j + BD - NI);  // (the last step wraps: the next block starts at stage 0)
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (MORE) {
@@ -2305,7 +2316,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
       const float4 bi = *reinterpret_cast<const float4*>(epi + j * 16 + fk * 4);
       float4 v = make_float4(acc[j][0] * (ainv * bi.x), acc[j][1] * (ainv * bi.y), acc[j][2] * (ainv * bi.z), acc[j][3] * (ainv * bi.w));
       if constexpr (EPI == EPI_BIAS) {
-        v = f4_add(v, *reinterpret_cast<const float4*>(epi + BN + j * 16 + fk * 4));
+        v = f4_add(v, *reinterpret_cast<const float4*>(epi + EPN + j * 16 + fk * 4));
         if (p.relu) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
@@ -2319,7 +2330,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
           q.x = ok ? v.x - sm.x * inv : 0.f; q.y = ok ? v.y - sm.y * inv : 0.f;
           q.z = ok ? v.z - sm.z * inv : 0.f; q.w = ok ? v.w - sm.w * inv : 0.f;
           q.x = row16_sum(q.x * q.x); q.y = row16_sum(q.y * q.y); q.z = row16_sum(q.z * q.z); q.w = row16_sum(q.w * q.w);
-          if (fr == 0 && n < p.N) {
+          if (fr == 0 && n < p.N && (!HALF || j < NI - 1 || fk < 2)) {
             float* cs = p.colstat + (int64_t)rb * 2 * p.N + n;
             *reinterpret_cast<float4*>(cs) = sm;
             *reinterpret_cast<float4*>(cs + p.N) = q;
@@ -2333,8 +2344,9 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
         if (!(k4[2] > 0.f)) v.z = 0.f;
         if (!(k4[3] > 0.f)) v.w = 0.f;
       }
-      if (m < p.M && n < p.N) *reinterpret_cast<float4*>(p.C + (int64_t)m * p.ldc + n) = v;
-      if (n < p.N) cmax = fmaxf(cmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+      const bool mine = n < p.N && (!HALF || j < NI - 1 || fk < 2);  // (the second half of a half block belongs to the next workgroup)
+      if (m < p.M && mine) *reinterpret_cast<float4*>(p.C + (int64_t)m * p.ldc + n) = v;
+      if (mine) cmax = fmaxf(cmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
     if (p.c_amax) {  // (uniform) as in k_gemm2pw: the row's maximum over this workgroup's columns, atomic over the column workgroups
       cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
@@ -2348,7 +2360,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
 #undef PGNN_CLAIM
 }
 
-// can k_gemm2pr take this product?  K of 257-320 (10 k-steps, 80 columns per workgroup) or 577-608 (19, 64): the GIN mlp's two shapes;
+// can k_gemm2pr take this product?  K of 289-320 (10 k-steps, 120 columns per workgroup) or 577-608 (19, 64): the GIN mlp's two shapes;
 // enough 16-row blocks for every wave of every workgroup to stream a few; one workgroup per CU, a whole number of row ranges per XCD
 inline int gemm2pr_ranges(const GemmArgs& p, int bn) {
   const int per_xcd = num_cu() / std::max(1, p.nxcd);
@@ -2358,22 +2370,23 @@ inline bool gemm2pr_eligible(const GemmArgs& p) {
   const int knob = env_knob("PGNN_GEMM2P_RES", 1);
   if (!knob || p.bnf.n > 0 || p.nxcd <= 0 || num_cu() % p.nxcd != 0) return false;
   const int64_t nk = ceil_div(p.K, 32);
-  const int bn = nk == 10 ? 80 : nk == 19 ? 64 : 0;
+  const int bn = nk == 10 ? 120 : nk == 19 ? 64 : 0;
   if (!bn || gemm2pr_ranges(p, bn) < 1) return false;
   return knob >= 2 || p.M >= (nk == 10 ? 16384 : 32768);  // (measured against the tiled kernel: tools/gemm2p_large.py)
 }
-template <int NK, int NI, int NW, int EPI>
+template <int NK, int BN, int NW, int EPI>
 int launch_gemm2pr_s(const GemmArgs& p, hipStream_t st) {
-  constexpr size_t lds = (size_t)NK * 2 * (16 * NI) * 64 + 2 * (16 * NI) * 4;
-  const int ranges = gemm2pr_ranges(p, 16 * NI);
-  allow_big_lds((const void*)k_gemm2pr<NK, NI, NW, EPI>, lds);
-  hipLaunchKernelGGL((k_gemm2pr<NK, NI, NW, EPI>), dim3(num_cu()), dim3(64 * NW), lds, st, p, ranges);
+  constexpr size_t lds = (size_t)NK * 2 * BN * 64 + 2 * (16 * ((BN + 15) / 16)) * 4;
+  static_assert(lds <= 160 * 1024, "LDS");
+  const int ranges = gemm2pr_ranges(p, BN);
+  allow_big_lds((const void*)k_gemm2pr<NK, BN, NW, EPI>, lds);
+  hipLaunchKernelGGL((k_gemm2pr<NK, BN, NW, EPI>), dim3(num_cu()), dim3(64 * NW), lds, st, p, ranges);
   return check_launch("gemm2pr");
 }
 template <int EPI>
 int launch_gemm2pr(const GemmArgs& p, hipStream_t st) {
-  if (ceil_div(p.K, 32) == 10) return launch_gemm2pr_s<10, 5, 8, EPI>(p, st);
-  return launch_gemm2pr_s<19, 4, 8, EPI>(p, st);
+  if (ceil_div(p.K, 32) == 10) return launch_gemm2pr_s<10, 120, 8, EPI>(p, st);
+  return launch_gemm2pr_s<19, 64, 8, EPI>(p, st);
 }
 
 // the two tiles of launch_gemm3w's default choice, under its rounds x (k-steps + fixed) model with the two-plane step times
