@@ -448,7 +448,8 @@ def resident_loader_leg(dev, args, steps_n):
 
 def roofline_mlp(dev, rows):
     """time the forward product of the GIN mlp (first Linear 300->600 + bias + ReLU) alone at a large row count: the kernel the
-    one-call networks run there since round 4 (two fp16 planes + row scales, k_gemm2pw), with the split-bf16 kernel of
+    one-call networks run there since round 4 (two fp16 planes + row scales; from 16 384 rows on k_gemm2pr, the weight planes resident
+    in LDS), with the tiled two-plane kernel (PGNN_GEMM2P_RES=0: k_gemm2pw, what smaller batches run), the split-bf16 kernel of
     pgnn_linear_fwd (three bf16 planes, k_gemm3: rounds 2-3) and the fp32-MFMA kernel (PGNN_GEMM_SPLIT=0, which keeps the
     smallest shapes) beside it.  Fractions against the planes' own ceiling (dense fp16 MFMA peak / 3) AND the fp32 MFMA peak."""
     import os
@@ -474,6 +475,14 @@ def roofline_mlp(dev, rows):
     tf2 = flops / (ms2 * 1e-3) / 1e12
     ms, per, iters = steady_state_ms(launch, iters=30)
     tf = flops / (ms * 1e-3) / 1e12
+    os.environ["PGNN_GEMM2P_RES"] = "0"
+    lib.pgnn_reload_env()
+    try:
+        mst, pert, _ = steady_state_ms(launch2p, iters=30)
+    finally:
+        del os.environ["PGNN_GEMM2P_RES"]
+        lib.pgnn_reload_env()
+    tft = flops / (mst * 1e-3) / 1e12
     prev = os.environ.get("PGNN_GEMM_SPLIT")
     os.environ["PGNN_GEMM_SPLIT"] = "0"
     lib.pgnn_reload_env()
@@ -488,14 +497,20 @@ def roofline_mlp(dev, rows):
     tf32 = flops / (ms32 * 1e-3) / 1e12
     planes_peak, split_peak = MFMA_BF16_PEAK_TF / 3.0, MFMA_BF16_PEAK_TF / 6.0
     return {"bound": "mfma",
-            "kernel": "k_gemm2pw<128,160,8,1,3,EPI_BIAS> (pgnn_linear_fwd_2p 300->600: fp32 values as two fp16 planes under a "
-                      "power-of-two scale per row, three v_mfma_f32_16x16x32_f16 products per k-step, fp32 accumulate; the row maxima taken "
-                      "by every workgroup in front of its k-loop; error vs float64 at the fp32-MFMA kernel's, tests/test_gpu_ops.py)",
+            "kernel": "k_gemm2pr<10,120,8,EPI_BIAS> (pgnn_linear_fwd_2p 300->600 from 16 384 rows on: fp32 values as two fp16 planes under a "
+                      "power-of-two scale per row, three v_mfma_f32_16x16x32_f16 products per k-step, fp32 accumulate; the planes of 120 weight "
+                      "rows resident in LDS per persistent workgroup, the activations streamed through registers a 16-row block ahead, no "
+                      "barrier in the loop; the row maxima folded out of the fragments the wave holds; bit-identical to the tiled k_gemm2pw; "
+                      "error vs float64 at the fp32-MFMA kernel's, tests/test_gpu_ops.py)",
             "achieved": round(tf2, 2), "peak": round(planes_peak, 1), "unit": "TFLOP/s (fp32-equivalent)",
             "frac": round(tf2 / planes_peak, 4), "frac_of_fp32_mfma_peak": round(tf2 / MFMA_F32_PEAK_TF, 4),
             "peak_note": "dense fp16 MFMA peak 2500 TFLOP/s / 3 products per fp32 product = 833; the fp32 MFMA peak is %.1f" % MFMA_F32_PEAK_TF,
             "ms_per_launch": round(ms2, 4), "ms_per_launch_std": round(float(per2.std()), 4), "launches_timed": iters2,
             "rows": rows,
+            "tiled_two_plane_kernel": {"kernel": "k_gemm2pw<128,160,8,1,3,EPI_BIAS> (PGNN_GEMM2P_RES=0: one tile per workgroup, both operands through an LDS "
+                                                 "ring; what this leg timed before the resident-plane kernel)",
+                                       "achieved": round(tft, 2), "frac": round(tft / planes_peak, 4), "ms_per_launch": round(mst, 4),
+                                       "ms_per_launch_std": round(float(pert.std()), 4)},
             "three_plane_kernel": {"kernel": "k_gemm3<128,160,4,2,true,true,EPI_BIAS,false> (pgnn_linear_fwd: three bf16 terms, six products; "
                                              "the per-op entry point's kernel and round 3's roofline_mlp)",
                                    "achieved": round(tf, 2), "peak": round(split_peak, 1), "frac": round(tf / split_peak, 4),
