@@ -2372,7 +2372,10 @@ inline bool gemm2pr_eligible(const GemmArgs& p) {
   const int64_t nk = ceil_div(p.K, 32);
   const int bn = nk == 10 ? 120 : nk == 19 ? 64 : 0;
   if (!bn || gemm2pr_ranges(p, bn) < 1) return false;
-  return knob >= 2 || p.M >= (nk == 10 ? 16384 : 32768);  // (measured against the tiled kernel: tools/gemm2p_large.py)
+  // where it overtakes the tiled kernel (tools/gemm2p_sweep.py, profiles/r04/gemm2pr_sweep.txt): 300 -> 600 from ~8 k rows, 600 -> 600
+  // (ten column workgroups) from ~9 k, 600 -> 300 from ~20 k
+  const int64_t from = nk == 10 ? 8192 : p.N > 320 ? 9216 : 20480;
+  return knob >= 2 || p.M >= from;
 }
 template <int NK, int BN, int NW, int EPI>
 int launch_gemm2pr_s(const GemmArgs& p, hipStream_t st) {
