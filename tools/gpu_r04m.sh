@@ -3,7 +3,7 @@
 # the profiles behind the bench line (roofline-only launches, the three step kernel mixes), unprofiled steps, bench
 set +e
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r04m
+O=$R/gpurun_out/r04m2
 mkdir -p $O
 cd $R
 rm -f gpurun_out/parity_metrics.jsonl gpurun_out/two_plane_accuracy.jsonl
