@@ -2209,10 +2209,13 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
   f32x4 acc[NI];
   f16x8 a0[2], a1[2];
   for (;;) {
-    const int nxt = rb + NW < hi ? rb + NW : rb;  // (past the end: this block again -- every load lands in memory that exists)
-    const float* rowp = p.A + (int64_t)row_of(nxt) * p.lda;
+    // the wave's last block fetches nothing ahead (a fetch nobody claims lands in registers hipcc believes free), and waits for
+    // everything instead of counting: its fragments were issued a block ago
+    const bool more = rb + NW < hi;
+    const float* rowp = p.A + (int64_t)row_of(rb + NW) * p.lda;
     // ---- top of the block: its row maximum and fragment 0 have landed
-    gemm_wait_vmcnt_imm<Y_BLOCK>();
+    if (more) gemm_wait_vmcnt_imm<Y_BLOCK>();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("" : "+v"(amx));
     PGNN_CLAIM(raw[0][0]);
     PGNN_CLAIM(raw[0][1]);
@@ -2242,8 +2245,10 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
       a0[0] = __builtin_bit_cast(f16x8, pl[0]);
       a0[1] = __builtin_bit_cast(f16x8, pl[1]);
     }
-    issue_amax(nxt);
-    issue_frag(std::integral_constant<int, 0>{}, rowp);
+    if (more) {
+      issue_amax(rb + NW);
+      issue_frag(std::integral_constant<int, 0>{}, rowp);
+    }
     const int mrow = row_of(rb);
     if constexpr (EPI == EPI_MASK) {
 #pragma unroll
@@ -2281,7 +2286,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
               split_q(c, raw[NS][0], raw[NS][1], sa, pl);
               asm volatile("" ::"v"((&pl[0].x)[c]), "v"((&pl[1].x)[c]));
             }
-          if (j == (NI >= 5 ? 4 : 3)) issue_frag(std::integral_constant<int, NS>{}, rowp);  // the next block's, into the registers just split
+          if (j == (NI >= 5 ? 4 : 3) && more) issue_frag(std::integral_constant<int, NS>{}, rowp);  // the next block's, into the registers just split
         }
         if (j + BD < NI) bload(S, j + BD);
         else bload(MORE ? S + 1 : 0, j + BD - NI);  // (the last step wraps: the next block starts at stage 0)
@@ -2304,7 +2309,8 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
 
     // ---- epilogue: lane holds C[16 rb + fr][n0 + 16 j + 4 fk + 0..3]
     if constexpr (EPI == EPI_MASK) {
-      gemm_wait_vmcnt_imm<Y_BLOCK>();
+      if (more) gemm_wait_vmcnt_imm<Y_BLOCK>();
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
       for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(mk[j]));
     }
@@ -2353,10 +2359,9 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
       cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
       if (fk == 0 && m < p.M) atomicMax(p.c_amax + m, __float_as_uint(cmax));
     }
-    if (rb + NW >= hi) break;
+    if (!more) break;
     rb += NW;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the fetches past the last block land in registers nobody reads: let them)
 #undef PGNN_CLAIM
 }
 
