@@ -908,7 +908,10 @@ def _run():
     parallel.broadcast_parameters(mods)
     opts = make_optimizers(mods, args.adam)
     if world > 1 or dist.is_initialized():
-        opts = parallel.AllReduceOptimizers(opts)
+        # PGNN_DP_OVERLAP=1 (opt-in: only one-GPU functional runs of it exist): the all-reduce of the heads and layers 2-4 on a
+        # communication stream behind the backward's milestone events, under the backward of layers 1-0
+        overlap = (mods[0], 2) if os.environ.get("PGNN_DP_OVERLAP") == "1" else None
+        opts = parallel.AllReduceOptimizers(opts, overlap=overlap)
     batch = synthetic.chem_masking_batch(args.graphs_per_gpu, seed=rank, device=dev)  # collated and MaskAtom'ed on the device
     edges_local = batch.edge_index.size(1)
 
@@ -973,6 +976,9 @@ def _run():
     gc.enable()
 
     comm = parallel.comm_report(opts) if dist.is_initialized() else {"initialized": False, "world": 1}
+    if isinstance(opts, parallel.AllReduceOptimizers) and opts.overlap_layer is not None:
+        comm["overlap"] = {"from_layer": opts.overlap_layer, "steps_behind_the_milestone": opts.overlapped_steps,
+                           "head_bytes": opts.bucket.split * 4}
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     etot = torch.tensor([float(edges_local)], dtype=torch.float64, device=dev)
     if world > 1:

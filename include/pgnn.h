@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PGNN_ABI_VERSION 8
+#define PGNN_ABI_VERSION 9
 /* uint32 words behind every `counter` argument below: the arrival tickets of a launch whose last block folds the others'
  * results (one top word + up to 32 group words: same-address atomics retire at ~50 ns each, see csrc/common.h).  Zero before
  * the first call, left zero by every call; one buffer per device serves all calls of a stream. */
@@ -456,6 +456,15 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
                             const float* hid, const float* stats, float* dxemb1, float* dxemb2, float drop_p,
                             uint64_t drop_seed, int64_t n, int64_t dim, void* ws, size_t ws_bytes,
                             pgnn_stream stream);
+
+/* Gradient milestone of the next pgnn_chem_gin_stack_bwd on the current device, whichever host thread runs it (data parallelism: the reference is single-device,
+ * chem/pretrain_masking.py:114; this is what lets the gradient all-reduce of the top layers start under the backward of the lower
+ * ones).  arm(layer): once the backward has enqueued layer `layer`, every parameter gradient of layers >= `layer` (weights, biases,
+ * BatchNorm, edge tables) is behind one of two events, one per stream the backward uses; layer < 0 disarms.
+ * wait(stream): makes `stream` wait for both events and returns 0; returns 1 -- and enqueues nothing -- when no backward has
+ * reached the armed layer since arm() (another network, fewer layers): order the stream behind the whole backward instead. */
+int pgnn_stack_bwd_milestone_arm(int layer);
+int pgnn_stack_bwd_milestone_wait(pgnn_stream stream);
 
 /* The same one-call network for the "Linear, then aggregate" convolutions: kind 1 = GCNConv
  * (chem/model.py:58-104, needs dinv), kind 2 = GraphSAGEConv (chem/model.py:165-202, needs norms).

@@ -7,6 +7,7 @@
 
 #include "bn_fold.h"
 #include "common.h"
+#include <mutex>
 
 using namespace pgnn;
 
@@ -43,6 +44,36 @@ Side* side_for_current_device() {
   return &s;
 }
 inline bool use_side_stream() { return env_knob("PGNN_SIDE_STREAM", 1) != 0; }
+
+// Gradient milestone of a stack backward (pgnn_stack_bwd_milestone_arm / _wait): once layer `layer` has been enqueued, every
+// parameter gradient of layers >= `layer` is behind one of two events -- the caller's stream, the side stream -- so a
+// communication stream that waits for both can all-reduce the top of the network while the layers below are still running.
+// One armed milestone per DEVICE, not per host thread: torch runs the backward on its autograd thread, the arming and the wait
+// happen on the caller's.  A backward that never reaches the layer (other networks, fewer layers) leaves it unrecorded.
+struct GradMilestone {
+  int layer = -1;
+  bool recorded = false;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+};
+std::mutex g_milestone_mutex;
+GradMilestone g_milestones[64];
+GradMilestone* milestone_of_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  return &g_milestones[dev];
+}
+int milestone_record(int l, hipStream_t main, hipStream_t aux) {
+  GradMilestone* m = milestone_of_current_device();
+  if (!m || m->layer < 0) return PGNN_OK;  // (unlocked peek: the production path without data parallelism never takes the lock)
+  std::lock_guard<std::mutex> lock(g_milestone_mutex);
+  if (l != m->layer || m->recorded) return PGNN_OK;
+  for (auto& e : m->ev)
+    if (!e) PGNN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  PGNN_HIP(hipEventRecord(m->ev[0], main));
+  PGNN_HIP(hipEventRecord(m->ev[1], aux));
+  m->recorded = true;
+  return PGNN_OK;
+}
 // backward-data on pre-transposed weights (both operands k-contiguous): 0 = never, 2 = always, 1 (default) = from 16 384 rows,
 // where the k-contiguous form pulls ahead of pgnn_linear_bwd_data's transpose-read form (44 / 45 us against 54 / 56 at 16 384
 // rows, 145 / 135 against 204 / 244 at 65 536); at one 256-graph batch the two are level and the extra launch is not worth it
@@ -417,6 +448,28 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
   return PGNN_OK;
 }
 
+int pgnn_stack_bwd_milestone_arm(int layer) {
+  GradMilestone* m = milestone_of_current_device();
+  if (!m) {
+    set_error("stack_bwd_milestone_arm: no current device");
+    return PGNN_ERR_HIP;
+  }
+  std::lock_guard<std::mutex> lock(g_milestone_mutex);
+  m->layer = layer;
+  m->recorded = false;
+  return PGNN_OK;
+}
+
+int pgnn_stack_bwd_milestone_wait(pgnn_stream stream) {
+  GradMilestone* m = milestone_of_current_device();
+  if (!m) return 1;
+  std::lock_guard<std::mutex> lock(g_milestone_mutex);
+  if (m->layer < 0 || !m->recorded) return 1;  // nothing behind an event: the caller orders its stream behind the whole backward
+  PGNN_HIP(hipStreamWaitEvent((hipStream_t)stream, m->ev[0], 0));
+  PGNN_HIP(hipStreamWaitEvent((hipStream_t)stream, m->ev[1], 0));
+  return PGNN_OK;
+}
+
 int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx, int64_t rows1, int64_t rows2,
                             const int32_t* out_ptr, const int32_t* out_dst, const float* cfeat,
                             const pgnn_gin_layer* layers, int num_layer, int training, const float* acts,
@@ -606,6 +659,9 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     if (!demb_on_main && (rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, aux_ws, opb, aux))) return rc;
     if (sd && !per_layer && l >= 2) PGNN_HIP(hipEventRecord(sd->lag[b], aux));  // awaited by layer l-2 only
     if (!sd && (rc = aggregate_t())) return rc;
+    // every parameter gradient of layers >= l is enqueued now (weights, biases and edge tables on `aux`, the BatchNorm's on `main`;
+    // layer l - 1's BatchNorm sums, which the transposed aggregation above also left, only arrive early)
+    if ((rc = milestone_record(l, main, aux))) return rc;
     g = dxb[b];
     ldg = dim;
   }

@@ -47,45 +47,103 @@ def broadcast_parameters(modules, src=0):
             off += t.numel()
 
 
+def top_of_network(gnn, from_layer):
+    """the parameters of a chem / bio ``GNN`` whose gradients a one-call backward has finished once layer ``from_layer`` is
+    enqueued: ``gnns[l]`` and ``batch_norms[l]`` for l >= from_layer (the backward runs from the top layer down; the atom
+    embeddings come last)"""
+    out = []
+    for l in range(from_layer, len(gnn.gnns)):
+        out += list(gnn.gnns[l].parameters()) + list(gnn.batch_norms[l].parameters())
+    return out
+
+
 class GradBucket:
     """One flat buffer for all gradients of a parameter list; ``allreduce()`` = pack -> scale -> one
     all_reduce(SUM) (RCCL: one all_reduce(AVG)) -> ``p.grad`` = the bucket's views.  ``weight`` (this rank's share of the global loss
     normaliser, e.g. local_masked/global_masked) reproduces the single-process big-batch gradient
-    exactly; the default 1/world_size is the usual DDP mean."""
+    exactly; the default 1/world_size is the usual DDP mean.
 
-    def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
+    ``late`` (optional): parameters whose gradients arrive LAST in a backward -- they are laid out behind everything else, so
+    that ``allreduce_overlapped`` can reduce the head of the buffer on a communication stream while the backward is still
+    producing the tail (see ``AllReduceOptimizers(overlap=...)``)."""
+
+    def __init__(self, params, late=()):
+        late_ids = {id(p) for p in late}
+        params = [p for p in params if p.requires_grad]
+        self.params = [p for p in params if id(p) not in late_ids] + [p for p in params if id(p) in late_ids]
+        self.n_early = sum(1 for p in params if id(p) not in late_ids)
         n = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
         self.views, off = [], 0
-        for p in self.params:
+        for i, p in enumerate(self.params):
+            if i == self.n_early:
+                self.split = off
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        if self.n_early == len(self.params):
+            self.split = off
 
     @property
     def nbytes(self):
         return self.flat.numel() * self.flat.element_size()
 
-    def allreduce(self, weight=None):
-        if not dist.is_initialized():
-            return
-        world = dist.get_world_size()
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-        src, dst = [], []
-        for v, g in zip(self.views, grads):
+    def _pack(self, lo, hi, stream=None):
+        """gradients of params[lo:hi] into their views; returns False if one of them already lived in the bucket (it got there by
+        an in-place accumulation on the caller's stream, i.e. late)"""
+        src, dst, fresh = [], [], True
+        for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
             if g.data_ptr() != v.data_ptr():  # (a gradient kept from the last step already lives in the bucket)
                 src.append(g)
                 dst.append(v)
+                if stream is not None and g.is_cuda:
+                    g.record_stream(stream)
+            else:
+                fresh = False
         if dst:
             torch._foreach_copy_(dst, src)
+        return fresh
+
+    def _reduce(self, flat, weight, async_op=False):
         if weight is None and dist.get_backend() == "nccl":
-            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)  # RCCL scales each contribution by 1/world itself: no launch for it
-        else:
-            self.flat.mul_(weight if weight is not None else 1.0 / world)
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            return dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=async_op)  # RCCL scales each contribution by 1/world itself
+        flat.mul_(weight if weight is not None else 1.0 / dist.get_world_size())
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)
+
+    def _adopt(self):
         for p, v in zip(self.params, self.views):
             p.grad = v  # the reduced gradients stay where they are: the optimizers read the bucket, nothing is copied back
+
+    def allreduce(self, weight=None):
+        if not dist.is_initialized():
+            return
+        self._pack(0, len(self.params))
+        self._reduce(self.flat, weight)
+        self._adopt()
+
+    def allreduce_overlapped(self, weight, comm_stream, wait_for_milestone):
+        """the same result as ``allreduce`` in two collectives: the head of the buffer (everything but ``late``) on
+        ``comm_stream`` as soon as ``wait_for_milestone(comm_stream)`` says its gradients are behind events the stream now
+        waits for, the tail on the caller's stream behind the whole backward.  Falls back to ordering ``comm_stream`` behind
+        the caller's stream when there is no milestone, or when a head gradient reached the bucket by in-place accumulation."""
+        if not dist.is_initialized():
+            return
+        cur = torch.cuda.current_stream(self.flat.device)
+        in_place = any(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+                       for p, v in zip(self.params[:self.n_early], self.views[:self.n_early]))
+        if in_place or not wait_for_milestone(comm_stream):
+            comm_stream.wait_stream(cur)
+        with torch.cuda.stream(comm_stream):
+            self._pack(0, self.n_early, stream=comm_stream)
+            work = self._reduce(self.flat[:self.split], weight, async_op=True)
+        if self.split < self.flat.numel():
+            self._pack(self.n_early, len(self.params))
+            self._reduce(self.flat[self.split:], weight)
+        if work is not None:
+            work.wait()
+        cur.wait_stream(comm_stream)
+        self._adopt()
 
 
 class AllReduceOptimizers:
@@ -94,12 +152,25 @@ class AllReduceOptimizers:
     first ``step()`` after a backward all-reduces the one flat gradient bucket, then every wrapped
     optimizer applies its update."""
 
-    def __init__(self, optimizers, weight_fn=None):
+    def __init__(self, optimizers, weight_fn=None, overlap=None):
+        """``overlap=(gnn, from_layer)`` (opt-in; chem GIN one-call network with direct gradient deposit, CUDA): the all-reduce of
+        everything the backward has finished once layer ``from_layer`` of ``gnn`` is enqueued -- the heads, layers >=
+        from_layer -- runs on a communication stream under the backward of the layers below; the rest (those layers, the atom
+        embeddings) follows on the caller's stream.  Same sums, same bits as the single collective."""
         params = [p for o in optimizers for g in o.param_groups for p in g["params"]]
-        self.bucket = GradBucket(params)
+        self.overlap_layer, self.comm_stream, late = None, None, ()
+        if overlap is not None and params and params[0].is_cuda:
+            gnn, from_layer = overlap
+            top = {id(p) for p in top_of_network(gnn, from_layer)}
+            late = [p for p in gnn.parameters() if id(p) not in top]  # layers below from_layer, the atom embeddings
+            self.overlap_layer = int(from_layer)
+            self.comm_stream = torch.cuda.Stream(device=params[0].device)
+        self.bucket = GradBucket(params, late=late)
         self._pending = True
         self.weight_fn = weight_fn
+        self.overlapped_steps = 0  # steps whose head collective waited for the backward's milestone, not for the whole backward
         self.optimizers = [_Wrapped(o, self) for o in optimizers]
+        self._arm()
 
     def __iter__(self):
         return iter(self.optimizers)
@@ -110,9 +181,26 @@ class AllReduceOptimizers:
     def __len__(self):
         return len(self.optimizers)
 
+    def _arm(self):
+        if self.overlap_layer is not None and dist.is_initialized():
+            from . import _lib
+            _lib.load().pgnn_stack_bwd_milestone_arm(self.overlap_layer)
+
+    def _wait_for_milestone(self, stream):
+        from . import _lib, ops
+        if not ops.direct_grads_enabled():  # autograd's AccumulateGrad writes .grad behind the whole backward
+            return False
+        ok = _lib.load().pgnn_stack_bwd_milestone_wait(stream.cuda_stream) == 0
+        self.overlapped_steps += int(ok)
+        return ok
+
     def _before_step(self):
         if self._pending:
-            self.bucket.allreduce(self.weight_fn() if self.weight_fn else None)
+            weight = self.weight_fn() if self.weight_fn else None
+            if self.overlap_layer is not None:
+                self.bucket.allreduce_overlapped(weight, self.comm_stream, self._wait_for_milestone)
+            else:
+                self.bucket.allreduce(weight)
             self._pending = False
 
 
@@ -121,6 +209,8 @@ class _Wrapped:
         self.opt, self.owner = opt, owner
 
     def zero_grad(self, *a, **k):
+        if not self.owner._pending:
+            self.owner._arm()  # once per step: the next backward records its gradient milestone
         self.owner._pending = True
         return self.opt.zero_grad(*a, **k)
 

@@ -60,7 +60,9 @@ def _worker(rank, world, port, out_dir):
     torch.manual_seed(100 + rank)  # deliberately different initial weights per rank
     mods = [hchem.GNN(5, 300).to(dev), torch.nn.Linear(300, 119).to(dev), torch.nn.Linear(300, 4).to(dev)]
     parallel.broadcast_parameters(mods)
+    import copy
     from pretrain_gnns_amd import optim
+    mods_o = copy.deepcopy(mods)
     opts = parallel.AllReduceOptimizers(optim.Adam.shared([m.parameters() for m in mods], lr=1e-3))  # what bench.py builds
     loader = resident.ResidentLoader(ds, 16, shuffle=True, seed=9, mask_rate=0.15, rank=rank, world_size=world)
     res["len_loader"] = len(loader)
@@ -73,6 +75,16 @@ def _worker(rank, world, port, out_dir):
             steps_run += 1
     res["steps_run"], res["losses"] = steps_run, losses
     res["params"] = [p.detach().cpu().clone() for m in mods for p in m.parameters()]
+    # ---- (i b): the same steps with the gradient all-reduce in two collectives, the first one (heads, layers 2-4) on a
+    # communication stream behind the milestone events of the backward (bench.py under PGNN_DP_OVERLAP=1): same bits
+    opts_o = parallel.AllReduceOptimizers(optim.Adam.shared([m.parameters() for m in mods_o], lr=1e-3), overlap=(mods_o[0], 2))
+    loader_o = resident.ResidentLoader(ds, 16, shuffle=True, seed=9, mask_rate=0.15, rank=rank, world_size=world)
+    for m in mods_o:
+        m.train()
+    losses_o = [ptrain.chem_masking_step(mods_o, list(opts_o), batch)[0] for _ in range(2) for batch in loader_o]
+    res["overlap_same"] = (losses_o == losses and all(torch.equal(a, b) for ma, mb in zip(mods, mods_o)
+                                                       for a, b in zip(ma.parameters(), mb.parameters())))
+    res["overlapped_steps"] = opts_o.overlapped_steps
     res["bucket_bytes"] = opts.bucket.nbytes
     res["comm"] = parallel.comm_report(opts, iters=3)
 
@@ -145,6 +157,9 @@ def test_two_ranks_on_one_gpu(tmp_path):
     for a, b in zip(r0["params"], r1["params"]):
         assert torch.equal(a, b)
     assert r0["losses"] != r1["losses"]  # ... while every rank really trained on its own shard
+    # (i b) the overlapped all-reduce (two collectives, the first behind the backward's milestone events): the same bits, every step
+    for r in (r0, r1):
+        assert r["overlap_same"] and r["overlapped_steps"] == r["steps_run"], (r["overlap_same"], r["overlapped_steps"])
     # (ii) summed gradients == whole-batch gradient; (iii) weighted == gradient of the global mean; (iv) exact BatchNorm
     for key_dp, key_single, tol in (("sum_dp", "sum_single", 2e-5), ("mean_dp", "mean_single", 2e-5), ("exact_dp", "exact_single", 3e-3)):
         for r in (r0, r1):
@@ -270,13 +285,23 @@ def _rccl_single_rank_worker(port, out_path):
     mods_a = [hchem.GNN(5, 300).to(dev), torch.nn.Linear(300, 119).to(dev), torch.nn.Linear(300, 4).to(dev)]
     mods_b = copy.deepcopy(mods_a)
     batches = [hostdata.chem_masking_batch(12 + i, seed=30 + i).to(dev) for i in range(3)]
+    mods_c = copy.deepcopy(mods_a)
     plain = optim.Adam.shared([m.parameters() for m in mods_a], lr=1e-3)
     dp = parallel.AllReduceOptimizers(optim.Adam.shared([m.parameters() for m in mods_b], lr=1e-3))
+    # the overlapped form: heads + layers >= 2 reduced on a communication stream behind the backward's milestone events
+    dpo = parallel.AllReduceOptimizers(optim.Adam.shared([m.parameters() for m in mods_c], lr=1e-3), overlap=(mods_c[0], 2))
     out_a = [ptrain.chem_masking_step(mods_a, plain, b) for b in batches]
     out_b = [ptrain.chem_masking_step(mods_b, list(dp), b) for b in batches]
+    out_c = [ptrain.chem_masking_step(mods_c, list(dpo), b) for b in batches]
     same = all(torch.equal(pa, pb) for ma, mb in zip(mods_a, mods_b) for pa, pb in zip(ma.parameters(), mb.parameters()))
+    same_c = all(torch.equal(pa, pc) for ma, mc in zip(mods_a, mods_c) for pa, pc in zip(ma.parameters(), mc.parameters()))
     in_bucket = all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(dp.bucket.params, dp.bucket.views))
-    torch.save({"out_a": out_a, "out_b": out_b, "same": same, "in_bucket": in_bucket, "report": parallel.comm_report(dp)}, out_path)
+    late = {id(p) for l in range(2) for p in list(mods_c[0].gnns[l].parameters()) + list(mods_c[0].batch_norms[l].parameters())}
+    late |= {id(p) for p in list(mods_c[0].x_embedding1.parameters()) + list(mods_c[0].x_embedding2.parameters())}
+    layout_ok = ({id(p) for p in dpo.bucket.params[dpo.bucket.n_early:]} == late
+                 and dpo.bucket.split == sum(p.numel() for p in dpo.bucket.params[:dpo.bucket.n_early]))
+    torch.save({"out_a": out_a, "out_b": out_b, "out_c": out_c, "same": same, "same_c": same_c, "in_bucket": in_bucket,
+                "overlapped_steps": dpo.overlapped_steps, "layout_ok": layout_ok, "report": parallel.comm_report(dp)}, out_path)
     dist.destroy_process_group()
 
 
@@ -294,6 +319,10 @@ def test_single_rank_rccl_step_equals_the_plain_step(tmp_path):
     res = torch.load(out)
     assert res["same"] and res["in_bucket"], res
     assert res["out_a"] == res["out_b"]
+    # ... and so is the overlapped form (parallel.AllReduceOptimizers(overlap=...)): every step's head collective waited for the two
+    # milestone events pgnn_chem_gin_stack_bwd recorded behind layer 2, on RCCL's own stream, not for the whole backward
+    assert res["same_c"] and res["out_a"] == res["out_c"] and res["layout_ok"], res
+    assert res["overlapped_steps"] == len(res["out_c"]), res["overlapped_steps"]
     assert res["report"]["backend"] == "nccl" and res["report"]["world"] == 1 and res["report"]["bucket_bytes"] > 7e6
 
 
