@@ -2087,15 +2087,15 @@ int launch_gemm2pw_s(const GemmArgs& p, hipStream_t st) {
 }
 // ==================================================================================================================================
 // Large M: the weight planes RESIDENT in LDS, the activations streamed through registers, no barrier in the loop (k_gemm2pr).
-// At 262 144 x 300 -> 600 the tiled kernel above spends its time waiting, not multiplying (tools/gemm2p_large.py: the same 540-640 us
-// with its MFMAs removed): every 64/128-row tile pays a workgroup launch, a pipeline fill and an epilogue, and every 32 of k a
+// At 262 144 x 300 -> 600 the tiled kernel above spends its time waiting, not multiplying (profiles/r04/gemm2pr_ab.txt: the same
+// 540-640 us with its MFMAs removed): every 64/128-row tile pays a workgroup launch, a pipeline fill and an epilogue, and every 32 of k a
 // barrier, with one or two workgroups per CU to hide them behind.  Here one persistent workgroup per CU DMAs the two planes of ITS
-// 16 NI weight rows -- all NK k-steps of them, 100-152 KB in the ring's [row][32 k] image -- into LDS once; then its waves never
+// BN weight rows -- all NK k-steps of them, 150-152 KB in the ring's [row][32 k] image -- into LDS once; then its waves never
 // synchronise again.  A wave owns 16-row blocks of A (block w, w + NW, ... of the workgroup's row range): each lane fetches its own
 // MFMA fragments -- row fr, floats 32 s + 8 fk .. + 7 -- straight into registers, a WHOLE BLOCK ahead (fragment s of the next block
 // goes into the registers fragment s of this block has just been split out of: 8 NK registers, static indices, the k-loop fully
-// unrolled), splits them under the row's scale, multiplies against fragments read from the resident planes and writes its 16 x 16 NI
-// results.  The 16 NI-column workgroups that share a row range sit on one XCD and walk it at the same pace: A comes from HBM once.
+// unrolled), splits them under the row's scale, multiplies against fragments read from the resident planes and writes its 16 x BN
+// results.  The column workgroups that share a row range sit on one XCD and walk it at the same pace: A comes from HBM once.
 // Loads are inline asm with counted s_waitcnt (hipcc's own pass would drain vmcnt(0) at every first use while LDS-DMA or younger
 // loads are outstanding); the counts below hold with stores in flight (loads return in order among themselves: if a load is
 // outstanding so is every younger load, so "at most <number of younger loads> outstanding" implies it has landed).
