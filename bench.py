@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--settle-steps", type=int, default=200,
+                    help="untimed steps of the same train step in FRONT of the W warm-up steps (same count on every rank): ~0.2 s that take the "
+                         "chip out of its idle state -- coming out of an idle gap it runs a few launches at boost clocks, then the power "
+                         "controller undershoots for some milliseconds, and a K = 20 window is ~20 ms; 0 = none.  Reported in config")
     ap.add_argument("--graphs-per-gpu", type=int, default=256)
     ap.add_argument("--roofline-graphs", type=int, default=16384)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
@@ -916,6 +920,12 @@ def _run():
     edges_local = batch.edge_index.size(1)
 
     step, finish = masking_stepper(mods, list(opts), args.readback, dev)
+    import gc
+    gc.collect()  # BEFORE the warm-up: a collection between warm-up and timed steps leaves the GPU idle for tens of milliseconds, and
+    gc.disable()  # the K = 20 window then starts on a chip that has clocked down (1.04 against 1.00 ms per step, profiles/r04/bench_window_ab.txt)
+    for _ in range(max(args.settle_steps, 0)):  # (untimed, see --settle-steps; the W warm-up steps follow as the contract has them)
+        step(batch)
+    finish()
     for _ in range(args.warmup):
         step(batch)
     finish()
@@ -926,10 +936,7 @@ def _run():
             dist.barrier()
         torch.cuda.synchronize()
 
-    import gc
-    gc.collect()
-    gc.disable()  # keep collector pauses of the host interpreter out of the timed region
-    sync()
+    sync()  # (the collector is off since before the warm-up: no pauses of the host interpreter inside the timed region)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(batch)
@@ -1009,7 +1016,7 @@ def _run():
                        "nodes_per_gpu": int(batch.x.size(0)), "edges_per_gpu": int(edges_local),
                        "parallelism": "dp%d" % world, "mean_loss": round(float(loss), 5),
                        "adam": ADAM_NOTE[args.adam], "metrics_readback": READBACK_NOTE[args.readback],
-                       "direct_grads": True,
+                       "direct_grads": True, "settle_steps_before_warmup": max(args.settle_steps, 0),
                        "mlp_products": "fp32 operands as two fp16 planes under a power-of-two scale per row (22 significant bits per operand), "
                                        "three v_mfma_f32_16x16x32_f16 per accumulator, fp32 accumulate; weight gradients on three bf16 planes "
                                        "(24 bits); error against float64 held to the fp32-MFMA kernel's bar in tests/test_gpu_ops.py"},
