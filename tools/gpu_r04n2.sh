@@ -4,7 +4,7 @@
 # whose kernel-dispatch gaps were ~2.5 us longer: 1.21 ms steps with the same kernel durations; its bench line is kept as bench_v4_slow_box.json)
 set +e
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r04n2
+O=$R/gpurun_out/r04n3
 mkdir -p $O
 cd $R
 (grep "model name" /proc/cpuinfo | head -1; nproc) > $O/host.txt
