@@ -1416,7 +1416,13 @@ int pgnn::neighbor_sum_bn_bwd(const float* x, int64_t ldx, const int32_t* ptr, c
   const bool small_ld = ldx * 4 * kDmaG < (1ll << 31);
   const bool tuned = dim <= 320 && nrow == 10 && small_ld && env_int("PGNN_AGG_VARIANT", 3) == 3 && env_int("PGNN_DMA_P", 2) == 2 &&
                      !env_int("PGNN_DMA_GENERIC", 0) && env_int("PGNN_DMA_PF", 1) != 0 &&
-                     env_int("PGNN_DMA_POL", (int64_t)n * dim * 4 >= (128ll << 20) ? 3 : 0) == 0 && env_int("PGNN_BN_BWD_IN_AGG", 1) != 0;
+                     env_int("PGNN_BN_BWD_IN_AGG", 1) != 0;
+  const int pol = (int)env_int("PGNN_DMA_POL", (int64_t)n * dim * 4 >= (128ll << 20) ? 3 : 0);  // large: non-temporal row loads and stores
+  // (pol 3: the instance of the large batches, since the end of round 4 -- 438 792 rows: 31.67 against 32.09 ms per 16 384-graph step)
+  if (pol != 0 && pol != 3) {
+    *fused = false;
+    return launch_aggregate<false, false>(x, ldx, ptr, nbr, nullptr, nullptr, nullptr, nullptr, out, ldo, n, dim, st);
+  }
   *fused = tuned && tail.z && tail.scratch.partial && tail.scratch.tickets;
   if (!*fused) return launch_aggregate<false, false>(x, ldx, ptr, nbr, nullptr, nullptr, nullptr, nullptr, out, ldo, n, dim, st);
   AggTail t{};
@@ -1424,6 +1430,9 @@ int pgnn::neighbor_sum_bn_bwd(const float* x, int64_t ldx, const int32_t* ptr, c
   t.relu = tail.relu;
   t.fold = BnBwdFold{tail.gamma, tail.save_invstd, tail.scratch.partial, tail.scratch.gsum, tail.scratch.tickets, tail.scratch.coef,
                      tail.dgamma, tail.dbeta, tail.training, (int)n};
+  if (pol == 3)
+    return launch_aggregate_dma_p<false, 2, 10, false, 19, false, true>(x, ldx, ptr, nbr, nullptr, nullptr, nullptr, out, ldo, n, dim, st, nullptr,
+                                                                         0, nullptr, &t, tail.scratch.max_blocks);
   return launch_aggregate_dma_p<false, 2, 10, false, 16, false, true>(x, ldx, ptr, nbr, nullptr, nullptr, nullptr, out, ldo, n, dim, st, nullptr,
                                                                        0, nullptr, &t, tail.scratch.max_blocks);
 }

@@ -362,6 +362,7 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
   const bool fuse = drop_p == 0.f && dim <= 320 && env_knob("PGNN_FUSE_BN_AGG", 1) != 0;
   // Training-mode statistics from the epilogue of the product in front (PGNN_BN_STATS_IN_GEMM=0: the separate partial-sum
   // pass).  Up to kStatsInGemmMaxRows rows: beyond, the per-16-row blocks (150 B a row) cost more than the pass they replace.
+  // (re-measured with the resident-plane products at 438 792 rows: 32.99 against 32.11 ms per step with the blocks -- still a loss)
   const bool stats_in_gemm = training && n > 1 && n <= kStatsInGemmMaxRows && env_knob("PGNN_BN_STATS_IN_GEMM", 1) != 0;
   // both products of every layer on pre-split weight planes when the caller's workspace has room for them behind the op scratch
   // (pgnn_chem_gin_stack_workspace_bytes does; the per-layer size of older callers does not: they keep the in-kernel split)

@@ -698,15 +698,19 @@ def test_one_call_network_on_weight_planes_below_the_split_threshold(graphs, two
         assert d <= 2e-2 * float(res[1][1][k].double().norm()) + 1e-4 * top, k
 
 
-@pytest.mark.parametrize("graphs,training", [(256, True), (64, True), (3, True), (200, False), (1400, True)])
-def test_batchnorm_backward_sums_from_the_transposed_aggregation(graphs, training, monkeypatch):
+@pytest.mark.parametrize("graphs,training,pol", [(256, True, None), (64, True, None), (3, True, None), (200, False, None), (1400, True, None),
+                                                 (256, True, "3"), (1400, True, "3")])
+def test_batchnorm_backward_sums_from_the_transposed_aggregation(graphs, training, pol, monkeypatch):
     """one-call chem GIN backward (chem/model.py:269-275 under autograd): below the top layer the column sums of the BatchNorm
     backward -- sum of dyr and of dyr * xhat over the rows -- come out of the transposed aggregation that writes dy
     (k_aggregate_dma's TAIL, csrc/aggregate.hip), folded in the same launch; PGNN_BN_BWD_IN_AGG=0 takes them by the pass of their
     own (k_bn_bwd_partial).  Same forward bit for bit; every gradient -- dgamma / dbeta are those sums themselves -- equal to fp32
-    rounding of sums taken in another order; and the fused form is deterministic (three runs, bit-equal)."""
+    rounding of sums taken in another order; and the fused form is deterministic (three runs, bit-equal).  pol "3": the kernel
+    instance of the large batches (non-temporal row loads and stores; what a batch beyond 128 MB of rows runs) forced onto these."""
     import copy
     from pretrain_gnns_amd import ops
+    if pol is not None:
+        monkeypatch.setenv("PGNN_DMA_POL", pol)
     hchem, _ = _hip()
     _, a = _pair(ochem.GNN, hchem.GNN, 5, 300, seed=15)
     b = copy.deepcopy(a)
