@@ -880,7 +880,7 @@ def test_linear_fwd_colstats_and_batchnorm_statistics_from_blocks(m, k, n, offse
     torch.testing.assert_close(out.double().cpu(), want, rtol=1e-4, atol=1e-4 * (1.0 + offset * 0.02))
 
 
-@pytest.mark.parametrize("n,m,classes,dim", [(6747, 1007, 119, 300), (300, 41, 4, 300), (50, 1, 128, 64), (900, 257, 119, 2048)])
+@pytest.mark.parametrize("n,m,classes,dim", [(6747, 1007, 119, 300), (300, 41, 4, 300), (50, 1, 128, 64), (900, 257, 119, 2048), (70001, 17003, 119, 300)])
 def test_masked_head_fwd_bwd(n, m, classes, dim):
     """pgnn_masked_head_fwd/_bwd (linear_pred + CrossEntropyLoss(pred.double()) + compute_accuracy of
     chem/pretrain_masking.py:52-57 in one launch per direction) vs the torch composition: loss (float64), correct count
