@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PGNN_ABI_VERSION 9
+#define PGNN_ABI_VERSION 10
 /* uint32 words behind every `counter` argument below: the arrival tickets of a launch whose last block folds the others'
  * results (one top word + up to 32 group words: same-address atomics retire at ~50 ns each, see csrc/common.h).  Zero before
  * the first call, left zero by every call; one buffer per device serves all calls of a stream. */
@@ -309,6 +309,24 @@ int pgnn_linear_fwd_2p(const float* x, int64_t ldx, const uint32_t* x_amax, cons
                        int64_t m, int64_t k, int64_t n, int relu, float* colstat, uint32_t* y_amax, pgnn_stream stream);
 int pgnn_linear_bwd_data_2p(const float* dy, int64_t lddy, const uint32_t* dy_amax, const void* wtplanes2, const float* relu_out, int64_t ldr,
                             float* dx, int64_t lddx, int64_t m, int64_t k, int64_t n, uint32_t* dx_amax, pgnn_stream stream);
+
+/* The GIN mlp (chem/model.py:29,54-55: Linear(D, 2D) -> ReLU -> Linear(2D, D)) as ONE launch per direction on two-plane weights
+ * (ABI 10, csrc/mlp_fused.hip): a wave owns 16 rows for both products, the [m, n1] hidden activation is produced 32 columns at a
+ * time in registers, WRITTEN ONCE (the backward needs it) and consumed on chip as a k-step of the second product -- it is never
+ * re-read, and the activations are fetched once instead of once per column workgroup.  The planes of the hidden rows take a
+ * running power-of-two scale (lowered, with an exact rescale of the accumulators, when a 32-column chunk would leave fp16's range).
+ *   forward:        hid = relu(x . W1^T + b1) [m, n1],  y = hid . W2^T + b2 [m, n2]; wplanes1 / wplanes2 = pgnn_split_weights_2p of
+ *                   W1 [n1, k1] / W2 [n2, n1]; colstat as in pgnn_linear_fwd_2p (per-16-row-block column statistics of y) or NULL
+ *   backward-data:  dhid = (dy . W2) * (relu_out > 0) [m, n1],  dx = dhid . W1 [m, n2]; w2tplanes / w1tplanes = the planes of
+ *                   W2^T [n1, k1] / W1^T [n2, n1] (transpose[j] = 1); here k1 = columns of dy (the mlp's output width)
+ * Shapes covered (pgnn_mlp_2p_fused_supported): k1 in (288, 320], n2 in (288, 304], n1 in [32, 608], all multiples of 4 -- the
+ * emb_dim = 300 mlp; everything else takes the two products above.  Error against float64 as for them (tests/test_gpu_ops.py). */
+int pgnn_mlp_2p_fused_supported(int64_t m, int64_t k1, int64_t n1, int64_t n2);
+int pgnn_mlp_fwd_2p_fused(const float* x, int64_t ldx, const void* wplanes1, const float* b1, const void* wplanes2, const float* b2, float* hid,
+                          int64_t ldh, float* y, int64_t ldy, int64_t m, int64_t k1, int64_t n1, int64_t n2, float* colstat, pgnn_stream stream);
+int pgnn_mlp_bwd_data_2p_fused(const float* dy, int64_t lddy, const void* w2tplanes, const float* relu_out, int64_t ldr, const void* w1tplanes,
+                               float* dhid, int64_t lddh, float* dx, int64_t lddx, int64_t m, int64_t k1, int64_t n1, int64_t n2,
+                               pgnn_stream stream);
 
 /* dW[N,K] = dy[M,N]^T . x[M,K] ; db[N] = column sums of dy (db may be NULL).  Split over M with a
  * deterministic second-pass reduction. */

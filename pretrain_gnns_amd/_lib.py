@@ -68,6 +68,9 @@ PROTOTYPES = {
     "pgnn_stack_bwd_milestone_wait": (_i, [_p]),
     "pgnn_linear_fwd_2p": (_i, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _p, _p, _p]),
     "pgnn_linear_bwd_data_2p": (_i, [_p, _i64, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _p]),
+    "pgnn_mlp_2p_fused_supported": (_i, [_i64, _i64, _i64, _i64]),
+    "pgnn_mlp_fwd_2p_fused": (_i, [_p, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p, _p]),
+    "pgnn_mlp_bwd_data_2p_fused": (_i, [_p, _i64, _p, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p]),
     "pgnn_linear_bwd_data": (_i, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p]),
     "pgnn_bio_gin_stack_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "pgnn_bio_gin_stack_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _i64, _p, _sz, _p]),
@@ -127,7 +130,7 @@ PROTOTYPES = {
     "pgnn_debug_aggregate_profile": (_i, [_p, _i64]),
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class GinLayer(ctypes.Structure):

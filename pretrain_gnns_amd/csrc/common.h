@@ -137,6 +137,12 @@ int linear_fwd_wp_2p(const float* x, int64_t ldx, const void* wplanes, const flo
                      const BnFwdFold* bnf = nullptr);
 int linear_bwd_data_wp_2p(const float* dy, int64_t lddy, const void* wtplanes, const float* relu_out, int64_t ldr, float* dx, int64_t lddx,
                           int64_t m, int64_t k, int64_t n, hipStream_t st, const uint32_t* dy_amax = nullptr, uint32_t* dx_amax = nullptr);
+// (mlp_fused.hip) both products of a GIN mlp in one launch, H written once and never re-read (pgnn_mlp_fwd_2p_fused / _bwd_data_2p_fused)
+int mlp_fused_supported(int64_t m, int64_t k1, int64_t n1, int64_t n2);
+int mlp_fwd_2p_fused(const float* x, int64_t ldx, const void* planes1, const float* b1, const void* planes2, const float* b2, float* hid,
+                     int64_t ldh, float* y, int64_t ldy, int64_t m, int64_t k1, int64_t n1, int64_t n2, float* colstat, hipStream_t st);
+int mlp_bwd_data_2p_fused(const float* dy, int64_t lddy, const void* planes2t, const float* relu_out, int64_t ldr, const void* planes1t,
+                          float* dhid, int64_t lddh, float* dx, int64_t lddx, int64_t m, int64_t k1, int64_t n1, int64_t n2, hipStream_t st);
 // (tile.hip) pgnn_neighbor_sum_tiled whose result is zeroed where mask[i, c] <= 0 (the ReLU between two layers, backward), when
 // the launch that runs can do it: *mask_applied says whether it did (the pipelined kernel of large batches and the untiled
 // fall-back cannot -- the caller masks in a pass of its own then)

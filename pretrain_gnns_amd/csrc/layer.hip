@@ -109,6 +109,14 @@ inline int stack_bwd_data_wp(const float* dy, int64_t lddy, const void* wtplanes
   return two_planes() ? linear_bwd_data_wp_2p(dy, lddy, wtplanes, relu_out, ldr, dx, lddx, m, k, n, (hipStream_t)stream, dy_amax, dx_amax)
                       : pgnn_linear_bwd_data_wp(dy, lddy, wtplanes, relu_out, ldr, dx, lddx, m, k, n, stream);
 }
+// Both products of a chem GIN mlp in ONE launch (csrc/mlp_fused.hip: the hidden activation written once, never re-read; the
+// activations fetched once): PGNN_MLP_FUSED = 0 never, 1 (default) from kFusedMinRows rows on -- below, a workgroup's 128 rows do not
+// amortise the 1.5 MB of weight planes it streams from L2, and the tiled products win --, 2 wherever the shape is covered.
+constexpr int64_t kFusedMinRows = 32768;
+inline bool mlp_fused(int64_t n, int64_t d_in, int64_t d_hid, int64_t d_out) {
+  const int v = env_knob("PGNN_MLP_FUSED", 1);
+  return v != 0 && two_planes() && (v >= 2 || n >= kFusedMinRows) && mlp_fused_supported(n, d_in, d_hid, d_out);
+}
 inline size_t amax_words(int64_t n) { return align_up((size_t)n * 4, 256) / 4; }  // one row-maximum vector, in words
 // planes of W1 / W2 (transpose = 0) or W1^T / W2^T (1) of every layer: p1[l], p2[l] carved from `base`
 // (bump: also increment the layers' num_batches_tracked -- a training-mode forward -- in the same launch;
@@ -382,6 +390,7 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
                                     training != 0, nullptr, hid_amax, hid_amax ? (int64_t)num_layer * (int64_t)amax_words(n) : 0)))
     return rc;
   if (!wp && training && (rc = bump_batches_tracked(layers, num_layer, (hipStream_t)stream))) return rc;
+  const bool fused_mlp = wp && mlp_fused(n, dim, 2 * dim, dim);
   for (int l = 0; l < num_layer; ++l) {
     const pgnn_gin_layer& p = layers[l];
     float* a = acts + (size_t)l * 3 * nd;  // agg, z, y
@@ -407,6 +416,28 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
     }
     if (rc) return rc;
     uint32_t* ham = hid_amax ? hid_amax + (size_t)l * amax_words(n) : nullptr;
+    if (wp && fused_mlp) {
+      // one launch for both products; the statistics of z as per-16-row blocks from its epilogue where the unfused path takes them
+      // from the second product's (the in-launch fold of bn_fold.h belongs to the tiled kernel: blocks + their merge launch here)
+      float* blocks = stats_in_gemm ? static_cast<float*>(ws) : nullptr;
+      if ((rc = mlp_fwd_2p_fused(agg, dim, wp1[l], p.b1, wp2[l], p.b2, hd, 2 * dim, z, dim, n, dim, 2 * dim, dim, blocks, (hipStream_t)stream)))
+        return rc;
+      if (stats_in_gemm) {
+        if ((rc = pgnn_bn_stats_fwd_blocks(blocks, p.gamma, p.beta, p.running_mean, p.running_var, p.momentum, p.eps, st, st + dim,
+                                           st + 2 * dim, n, dim, stream)))
+          return rc;
+        if (!(fuse && !last))
+          rc = pgnn_bn_apply_fwd(z, dim, st + 2 * dim, !last, y, dim, drop_p, drop_seed + (uint64_t)l, n, dim, stream);
+      } else if (fuse && !last) {
+        rc = pgnn_bn_stats_fwd(z, dim, p.gamma, p.beta, p.running_mean, p.running_var, p.momentum, p.eps, training, st, st + dim,
+                               st + 2 * dim, n, dim, ws, opb, stream);
+      } else {
+        rc = pgnn_bn_fwd(z, dim, p.gamma, p.beta, p.running_mean, p.running_var, p.momentum, p.eps, training, !last, y, dim, st, st + dim,
+                         drop_p, drop_seed + (uint64_t)l, n, dim, ws, opb, stream);
+      }
+      if (rc) return rc;
+      continue;
+    }
     if (wp) rc = stack_fwd_wp(agg, dim, wp1[l], p.b1, hd, 2 * dim, n, dim, 2 * dim, 1, nullptr, stream, agg_has_amax ? agg_amax : nullptr, ham);
     else rc = pgnn_linear_fwd(agg, dim, p.w1, p.b1, hd, 2 * dim, n, dim, 2 * dim, 1, stream);
     if (rc) return rc;
@@ -585,6 +616,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     PGNN_HIP(hipEventRecord(sd->fork[3], aux));
   }
   const bool tr = ntr > 0 && use_transposed_weights(n);
+  const bool fused_mlp = wp && mlp_fused(n, dim, 2 * dim, dim);
 
   const float* g = dy;
   int64_t ldg = lddy;
@@ -614,7 +646,10 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
       PGNN_HIP(hipStreamWaitEvent(main, sd->fork[2], 0));
       wait_fork2 = false;
     }
-    if (wp) {
+    if (wp && fused_mlp) {
+      // dhid = (dz . W2) * (hid > 0) and dagg = dhid . W1 in one launch: dhid written once (the weight gradient reads it), never re-read here
+      if ((rc = mlp_bwd_data_2p_fused(dz[b], dim, wp2[l], hd, 2 * dim, wp1[l], dhid[b], 2 * dim, dagg[b], dim, n, dim, 2 * dim, dim, main))) return rc;
+    } else if (wp) {
       uint32_t* dam = dhid_amax ? dhid_amax + (size_t)l * amax_words(n) : nullptr;
       if ((rc = stack_bwd_data_wp(dz[b], dim, wp2[l], hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main, dz_has_amax ? dz_amax : nullptr, dam))) return rc;
       if ((rc = stack_bwd_data_wp(dhid[b], 2 * dim, wp1[l], nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main, dam))) return rc;

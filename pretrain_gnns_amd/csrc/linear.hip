@@ -23,11 +23,10 @@
 
 #include "bn_fold.h"
 #include "common.h"
+#include "two_plane.h"
 
 namespace pgnn {
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmArgs {
   const float* A;
@@ -60,8 +59,6 @@ enum { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_MASK = 2 };
 __device__ float4 g_zero_page[4];  // zero-initialised: DMA source for lanes past the K / M / N edge
 __device__ float4 g_ones_page[1] = {{1.f, 0.f, 0.f, 0.f}};  // DMA source of the "ones column" (bias gradient)
 
-#define PGNN_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
-#define PGNN_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 // epilogue shared by the fp32-MFMA and the split-bf16 kernels (identical C/D register layout): lane holds
 // C[m = mw + 16 i + (lane & 15)][n = nw + 16 j + (lane >> 4) * 4 + 0..3] of each 16x16 block
@@ -183,12 +180,6 @@ __device__ __forceinline__ void gemm_wait_vmcnt(int n) {
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 #undef PGNN_W
-}
-
-template <int N>
-__device__ __forceinline__ void gemm_wait_vmcnt_imm() {
-  static_assert(N >= 0 && N < 64, "vmcnt immediate");
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // KSS encodes the k-step depth and the ring depth: 1 / 2 = KS images per barrier with a 2-stage ring; 11 / 12 = one image per
@@ -370,7 +361,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm(GemmArgs p) {
 //    MFMA up to ~32 k rows (backward-weight) / ~65 k rows (backward-data).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {  // round to nearest even, a in the low half
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
@@ -1677,38 +1667,6 @@ int pgnn_linear_bwd_weight_pair(const float* dy_a, int64_t lddy_a, const float* 
 // ==================================================================================================================================
 namespace pgnn {
 namespace {
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t pack_f16(float a, float b) {  // round to nearest even, a in the low half
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, f16x2));
-}
-// the low plane's share of (a, b).  Clamped to fp16's range: a - h is at most half an fp16 ulp for every finite h, so the clamp only
-// catches h = +-inf, where a - h is NaN -- and the product would turn an fp32 +-inf into NaN.  (fminf / fmaxf drop a NaN operand.)
-__device__ __forceinline__ float low_part(float a, _Float16 h) { return fminf(fmaxf(a - (float)h, -65504.f), 65504.f); }
-__device__ __forceinline__ void split2(float a, float b, uint32_t& h, uint32_t& l) {
-  const f16x2 hh = __builtin_convertvector(f32x2{a, b}, f16x2);
-  h = __builtin_bit_cast(uint32_t, hh);
-  l = pack_f16(low_part(a, hh[0]), low_part(b, hh[1]));
-}
-// s = 2^(13 - floor(log2(amax))) and its inverse from amax's exponent field: s amax lands in [2^13, 2^14).  Rows below 2^-113
-// (exponent field <= 13: the scale would leave fp32's range) take 2^127, whose inverse is the subnormal 2^-127 -- they keep
-// 11 + 11 bits down to fp32's smallest subnormals; an all-zero row is one of them.  Exponent field 255 (the row holds an inf, or its
-// maximum was poisoned by a NaN): unscaled, the non-finite value propagates.
-__device__ __forceinline__ void pow2_scales(float amax, float& s, float& inv) {
-  const unsigned e = (__float_as_uint(amax) >> 23) & 0xffu;
-  if (e == 255u) {
-    s = 1.f;
-    inv = 1.f;
-  } else if (e <= 13u) {
-    s = __uint_as_float(0x7F000000u);    // 2^127
-    inv = __uint_as_float(0x00400000u);  // 2^-127
-  } else {
-    s = __uint_as_float((267u - e) << 23);
-    inv = __uint_as_float((e - 13u) << 23);
-  }
-}
 
 // one wave per output row (k_split_jobs' jobs: dst row r = src row r, or src column r when transposed): the row's maximum, then
 // the two planes of s W (zero from `cols` to `ld`) and 1/s behind the planes.  Rows that are contiguous in the source (the forward's

@@ -932,68 +932,53 @@ def test_one_call_gcn_and_graphsage_equal_per_layer_path(gnn_type, graphs, layer
         assert torch.equal(res[0][2][k], res[1][2][k]), k
 
 
-@pytest.mark.parametrize("graphs", [64, 256, 700, 1200])
-def test_batchnorm_statistics_folded_inside_the_product_launch(graphs, monkeypatch):
-    """one-call chem network, training mode: the per-16-row-block statistics of z = the second product's result are merged inside
-    that product's launch (tile through LDS, groups of 16 row tiles by the last tile to arrive, the column panel by the last group:
-    bn_fold.h; round 4, the default on two planes) against PGNN_BN_STATS_FOLD=0, the launch of its own that merges the same blocks
-    (k_bn_stats_final_blocks).  The same blocks merged in another association order, in float64: save_mean / invstd and the
-    running statistics to a few fp32 ulps, the forward output to fp32 rounding carried through five layers; deterministic."""
+@pytest.mark.parametrize("graphs,forced", [(1400, False), (300, True), (37, True)])
+def test_fused_mlp_network_equals_the_two_products(graphs, forced, monkeypatch):
+    """one-call chem GIN network with both products of every mlp in ONE launch per direction (k_mlp2p_fused, csrc/mlp_fused.hip: from
+    32 768 rows on by default, PGNN_MLP_FUSED=2 everywhere) against PGNN_MLP_FUSED=0, the two products on planes: the hidden
+    activations have the same bits and so has every product that consumes them, so outputs, every gradient and the running statistics
+    are EQUAL where the BatchNorm statistics take the same route (above 32 768 rows: a pass of their own either way); below, the
+    fused launch hands per-16-row blocks to the merge launch where the tiled product folds them in its own launch -- the same
+    blocks in another association order: fp32 rounding carried through five layers (the bar of the fold's own test)."""
     import copy
     from pretrain_gnns_amd import ops
     hchem, _ = _hip()
-    _, a = _pair(ochem.GNN, hchem.GNN, 5, 300, seed=18)
+    _, a = _pair(ochem.GNN, hchem.GNN, 5, 300, seed=28)
     b = copy.deepcopy(a)
-    d = hostdata.chem_masking_batch(graphs, seed=19).to(DEV)
-    assert int(ops.load().pgnn_linear_wp_preferred(d.x.size(0), 600, 300)) == 1
+    d = hostdata.chem_masking_batch(graphs, seed=29).to(DEV)
+    n = d.x.size(0)
+    assert (n >= 32768) != forced
+    w = torch.randn(n, 300, device=DEV)
     res = []
-    for m, flag in ((a, "1"), (b, "0"), (copy.deepcopy(b), "1")):
-        monkeypatch.setenv("PGNN_BN_STATS_FOLD", flag)
+    for m, flag in ((a, "2" if forced else "1"), (b, "0")):
+        monkeypatch.setenv("PGNN_MLP_FUSED", flag)
         ops.load().pgnn_reload_env()
-        if len(res) == 2:
-            m.load_state_dict(res[0][2])  # the third run repeats the first from the first's initial state
-        state0 = copy.deepcopy(m.state_dict())
         m.train()
-        with torch.no_grad():
+        for _ in range(2):
+            m.zero_grad()
             out = m(d.x, d.edge_index, d.edge_attr)
-        res.append((out.clone(), {k: v.clone() for k, v in m.named_buffers()}, state0))
-    torch.testing.assert_close(res[0][0], res[1][0], rtol=2e-5, atol=2e-5)
-    for k in res[0][1]:
-        if res[0][1][k].is_floating_point():
-            torch.testing.assert_close(res[0][1][k], res[1][1][k], rtol=2e-6, atol=1e-7)
-        else:
-            assert torch.equal(res[0][1][k], res[1][1][k]), k  # num_batches_tracked
-    assert torch.equal(res[0][0], res[2][0])
-    for k in res[0][1]:
-        assert torch.equal(res[0][1][k], res[2][1][k]), k
-
-
-@pytest.mark.parametrize("graphs,layers", [(48, 5), (1500, 5), (3, 2)])
-def test_transposed_backward_data_matches_the_fp32_mfma_backward(graphs, layers, monkeypatch):
-    """one-call backward with backward-data on pre-transposed weights (forward split-bf16 kernel, pgnn_linear_bwd_data_t)
-    against the same call with PGNN_BWD_TRANSPOSED=0 (fp32 MFMA, exact FMA chains): every gradient within 2e-5 of its
-    tensor's largest entry (+ 1e-5 of the largest gradient of the network: biases in front of a BatchNorm have a
-    mathematically zero gradient, what is left of them is the cancellation noise of 6747 terms) -- fp32 rounding of a different summation order carried through 5 BatchNorm'ed
-    layers, nothing coarser"""
-    from pretrain_gnns_amd import ops
-    hchem, _ = _hip()
-    _, m = _pair(ochem.GNN, hchem.GNN, layers, 300, seed=8)
-    m.train()
-    d = hostdata.chem_masking_batch(graphs, seed=9).to(DEV)
-    w = torch.randn(d.x.size(0), 300, device=DEV)
-    grads = []
-    for flag in ("2", "0"):  # 2 = transposed weights at every size (the default switches at 16 384 rows)
-        monkeypatch.setenv("PGNN_BWD_TRANSPOSED", flag)
-        ops.load().pgnn_reload_env()
-        m.zero_grad()
-        (m(d.x, d.edge_index, d.edge_attr) * w).sum().backward()
-        grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
-    monkeypatch.delenv("PGNN_BWD_TRANSPOSED")
+            (out * w).sum().backward()
+        res.append((out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}, {k: v.clone() for k, v in m.named_buffers()}))
+    monkeypatch.delenv("PGNN_MLP_FUSED")
     ops.load().pgnn_reload_env()
-    top = max(float(g.abs().max()) for g in grads[1].values())
-    for k in grads[0]:
-        scale = float(grads[1][k].abs().max())
-        assert float((grads[0][k] - grads[1][k]).abs().max()) <= 2e-5 * scale + 1e-5 * top, (k, scale, top)
+    if not forced:
+        assert torch.equal(res[0][0], res[1][0])
+        for k in res[0][1]:
+            assert torch.equal(res[0][1][k], res[1][1][k]), k
+        for k in res[0][2]:
+            assert torch.equal(res[0][2][k], res[1][2][k]), k
+    else:
+        torch.testing.assert_close(res[0][0], res[1][0], rtol=2e-5, atol=2e-5)
+        top = max(float(g.abs().max()) for g in res[1][1].values())
+        for k in res[0][1]:
+            scale = float(res[1][1][k].abs().max())
+            assert float((res[0][1][k] - res[1][1][k]).abs().max()) <= 2e-5 * scale + 1e-5 * top, (k, scale, top)
+        for k in res[0][2]:
+            if res[0][2][k].is_floating_point():
+                torch.testing.assert_close(res[0][2][k], res[1][2][k], rtol=2e-6, atol=1e-7)
+            else:
+                assert torch.equal(res[0][2][k], res[1][2][k]), k
+
 
 
 @pytest.mark.parametrize("gnn_type", ["gin", "gcn"])

@@ -752,6 +752,90 @@ def test_products_on_two_fp16_planes_against_float64(case, m, k, n, monkeypatch)
         assert torch.equal(za, zb)
 
 
+@pytest.mark.parametrize("case", _ROW_CASES)
+@pytest.mark.parametrize("m,k1,n1,n2", [(6747, 300, 600, 300), (41269, 300, 600, 300), (1, 300, 600, 300), (127, 304, 608, 304), (129, 292, 36, 300),
+                                        (2049, 304, 596, 296), (70001, 300, 600, 300)])
+def test_fused_mlp_against_float64_and_the_two_products(case, m, k1, n1, n2):
+    """pgnn_mlp_fwd_2p_fused / pgnn_mlp_bwd_data_2p_fused (k_mlp2p_fused; chem/model.py:29,54-55: Linear -> ReLU -> Linear and its input
+    gradient, the [m, n1] hidden activation written once and consumed on chip) against float64 with the statistic of the two-plane
+    products -- error over the |a|.|b| bound of each entry, for y over the bound of the whole chain -- at their bar, and against the
+    two separate products on the same inputs: the hidden activation bit for bit (same fragments, same k and term order), the
+    second result no worse than theirs (rms <= 1.25 x, max <= 2 x: it differs by the running scale of the hidden rows' planes
+    and the k order inside an MFMA).  Row families chosen against a scale per row, ragged M, every covered width class."""
+    ops = _ops()
+    lib, sp = ops.load(), ops.stream_ptr()
+    assert lib.pgnn_mlp_2p_fused_supported(m, k1, n1, n2) == 1
+    x = _adversarial_rows(case, m, k1).to(DEV)
+    torch.manual_seed(n1)
+    w1 = (torch.randn(n1, k1) * 0.05).to(DEV)
+    w2 = (torch.randn(n2, n1) * 0.05).to(DEV)
+    quiet = case in ("gradient_rows", "subnormal_rows")  # (a bias would drown them)
+    b1 = torch.zeros(n1, device=DEV) if quiet else torch.randn(n1, device=DEV) * 0.1
+    b2 = torch.zeros(n2, device=DEV) if quiet else torch.randn(n2, device=DEV)
+    (p1, p2, p2t, p1t), _ = _weight_planes_2p(lib, sp, [w1, w2, w2, w1], [False, False, True, True])
+    tiny = 4 * 2.0 ** -149
+    # ---- forward
+    h64 = torch.relu(x.double() @ w1.double().t() + b1.double())
+    hs = x.double().abs() @ w1.double().abs().t() + b1.double().abs()
+    y64 = h64 @ w2.double().t() + b2.double()
+    ys = hs @ w2.double().abs().t() + b2.double().abs()
+    hid = torch.full((m, n1), float("nan"), device=DEV)
+    y = torch.full((m, n2), float("nan"), device=DEV)
+    blocks = torch.full(((m + 15) // 16, 2, n2), float("nan"), device=DEV)
+    ops.check(lib.pgnn_mlp_fwd_2p_fused(x.data_ptr(), k1, p1.data_ptr(), b1.data_ptr(), p2.data_ptr(), b2.data_ptr(), hid.data_ptr(), n1, y.data_ptr(),
+                                        n2, m, k1, n1, n2, blocks.data_ptr(), sp), "mlp fused fwd")
+    hid_u = torch.full((m, n1), float("nan"), device=DEV)
+    y_u = torch.full((m, n2), float("nan"), device=DEV)
+    ham = torch.zeros(m, dtype=torch.int32, device=DEV)
+    blocks_u = torch.full(((m + 15) // 16, 2, n2), float("nan"), device=DEV)
+    ops.check(lib.pgnn_linear_fwd_2p(x.data_ptr(), k1, None, p1.data_ptr(), b1.data_ptr(), hid_u.data_ptr(), n1, m, k1, n1, 1, None, ham.data_ptr(), sp), "fwd 2p")
+    ops.check(lib.pgnn_linear_fwd_2p(hid_u.data_ptr(), n1, ham.data_ptr(), p2.data_ptr(), b2.data_ptr(), y_u.data_ptr(), n2, m, n1, n2, 0, blocks_u.data_ptr(), None, sp), "fwd 2p")
+    assert torch.equal(hid, hid_u)
+    eh = ((hid.double() - h64).abs() - tiny).clamp(min=0) / hs.clamp(min=1e-300)
+    ey = ((y.double() - y64).abs() - tiny).clamp(min=0) / ys.clamp(min=1e-300)
+    eyu = ((y_u.double() - y64).abs() - tiny).clamp(min=0) / ys.clamp(min=1e-300)
+    rec = {"test": "fused_mlp_fwd", "case": case, "m": m, "k1": k1, "n1": n1, "n2": n2, "hid_max": eh.max().item(), "y_max": ey.max().item(),
+           "y_rms": ey.pow(2).mean().sqrt().item(), "y_max_two_products": eyu.max().item(), "y_rms_two_products": eyu.pow(2).mean().sqrt().item()}
+    _log_two_plane(rec)
+    assert rec["hid_max"] < 2e-6 and rec["y_max"] < 2e-6 and rec["y_rms"] < 3e-7, rec
+    assert rec["y_rms"] <= 1.25 * rec["y_rms_two_products"] + 1e-9 and rec["y_max"] <= 2.0 * rec["y_max_two_products"] + 1e-9, rec
+    # the per-16-row column statistics of y the BatchNorm behind it is built from: sums and squared deviations of what was stored
+    yb = torch.cat([y, torch.zeros((-m) % 16, n2, device=DEV)]).view(-1, 16, n2).double()
+    cnt = torch.full((yb.size(0), 1), 16.0, dtype=torch.float64, device=DEV)
+    if m % 16:
+        cnt[-1] = m % 16
+    sums = yb.sum(1)
+    live = (torch.arange(yb.size(0) * 16, device=DEV) < m).view(-1, 16, 1)
+    dev2 = (((yb - (sums / cnt).unsqueeze(1)) * live) ** 2).sum(1)
+    bound = yb.abs().sum(1) * 1e-6 + 1e-30
+    assert ((blocks[:, 0].double() - sums).abs() <= bound).all()
+    assert ((blocks[:, 1].double() - dev2).abs() <= 1e-5 * dev2 + (yb.abs().amax(1) ** 2) * 1e-5 + 1e-30).all()
+    # ---- backward-data: dhid = (dy . W2) * (hid > 0), dx = dhid . W1
+    dy = (_adversarial_rows(case, m, n2) * (1.0 if quiet else 1e-3)).to(DEV)
+    mask = hid if not quiet else torch.relu(torch.randn(m, n1, device=DEV))
+    d64 = (dy.double() @ w2.double()) * (mask > 0)
+    ds = dy.double().abs() @ w2.double().abs()
+    dx64 = d64 @ w1.double()
+    dxs = ds @ w1.double().abs()
+    dhid = torch.full((m, n1), float("nan"), device=DEV)
+    dx = torch.full((m, k1), float("nan"), device=DEV)
+    ops.check(lib.pgnn_mlp_bwd_data_2p_fused(dy.data_ptr(), n2, p2t.data_ptr(), mask.data_ptr(), n1, p1t.data_ptr(), dhid.data_ptr(), n1, dx.data_ptr(), k1,
+                                             m, n2, n1, k1, sp), "mlp fused bwd")
+    dhid_u = torch.full((m, n1), float("nan"), device=DEV)
+    dx_u = torch.full((m, k1), float("nan"), device=DEV)
+    dam = torch.zeros(m, dtype=torch.int32, device=DEV)
+    ops.check(lib.pgnn_linear_bwd_data_2p(dy.data_ptr(), n2, None, p2t.data_ptr(), mask.data_ptr(), n1, dhid_u.data_ptr(), n1, m, n1, n2, dam.data_ptr(), sp), "bwd 2p")
+    ops.check(lib.pgnn_linear_bwd_data_2p(dhid_u.data_ptr(), n1, dam.data_ptr(), p1t.data_ptr(), None, 0, dx_u.data_ptr(), k1, m, k1, n1, None, sp), "bwd 2p")
+    assert torch.equal(dhid, dhid_u)
+    ed = ((dx.double() - dx64).abs() - tiny).clamp(min=0) / dxs.clamp(min=1e-300)
+    edu = ((dx_u.double() - dx64).abs() - tiny).clamp(min=0) / dxs.clamp(min=1e-300)
+    rec = {"test": "fused_mlp_bwd", "case": case, "m": m, "k1": k1, "n1": n1, "n2": n2, "dx_max": ed.max().item(), "dx_rms": ed.pow(2).mean().sqrt().item(),
+           "dx_max_two_products": edu.max().item(), "dx_rms_two_products": edu.pow(2).mean().sqrt().item()}
+    _log_two_plane(rec)
+    assert rec["dx_max"] < 2e-6 and rec["dx_rms"] < 3e-7, rec
+    assert rec["dx_rms"] <= 1.25 * rec["dx_rms_two_products"] + 1e-9 and rec["dx_max"] <= 2.0 * rec["dx_max_two_products"] + 1e-9, rec
+
+
 @pytest.mark.parametrize("m,k,n", [(6747, 300, 600), (6747, 600, 300), (41269, 300, 600), (63, 600, 600), (1, 300, 600), (17, 600, 300), (70001, 600, 300), (139283, 300, 600)])
 def test_resident_plane_products_give_the_bits_of_the_tiled_ones(m, k, n, monkeypatch):
     """k_gemm2pr (large M: the weight planes of 80 / 64 output columns resident in LDS for all 10 / 19 k-steps, one persistent workgroup
