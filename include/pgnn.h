@@ -475,13 +475,17 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
                             uint64_t drop_seed, int64_t n, int64_t dim, void* ws, size_t ws_bytes,
                             pgnn_stream stream);
 
-/* Gradient milestone of the next pgnn_chem_gin_stack_bwd on the current device, whichever host thread runs it (data parallelism: the reference is single-device,
- * chem/pretrain_masking.py:114; this is what lets the gradient all-reduce of the top layers start under the backward of the lower
- * ones).  arm(layer): once the backward has enqueued layer `layer`, every parameter gradient of layers >= `layer` (weights, biases,
- * BatchNorm, edge tables) is behind one of two events, one per stream the backward uses; layer < 0 disarms.
- * wait(stream): makes `stream` wait for both events and returns 0; returns 1 -- and enqueues nothing -- when no backward has
- * reached the armed layer since arm() (another network, fewer layers): order the stream behind the whole backward instead. */
-int pgnn_stack_bwd_milestone_arm(int layer);
+/* Gradient milestone of the next pgnn_chem_gin_stack_bwd of ONE network on the current device, whichever host thread runs it (data
+ * parallelism: the reference is single-device, chem/pretrain_masking.py:114; this is what lets the gradient all-reduce of the top
+ * layers start under the backward of the lower ones).  arm(layer, network): `network` = the w1 pointer of that network's layer
+ * `layer` (pgnn_gin_layer.w1: parameter storage is stable across steps) -- the backwards of other networks leave the milestone
+ * alone (ABI 10; context prediction runs two networks under one set of optimizers).  Once the armed network's backward has
+ * enqueued layer `layer`, every parameter gradient of layers >= `layer` (weights, biases, BatchNorm, edge tables) is behind one
+ * of two events, one per stream the backward uses; layer < 0 disarms.
+ * wait(stream): makes `stream` wait for both events and returns 0; returns 1 -- and enqueues nothing -- when no backward of the
+ * armed network has reached the layer since arm(), or when MORE THAN ONE has (gradient accumulation: the later backwards add
+ * into gradients the recorded events do not cover): order the stream behind the whole backward instead. */
+int pgnn_stack_bwd_milestone_arm(int layer, const void* network);
 int pgnn_stack_bwd_milestone_wait(pgnn_stream stream);
 
 /* The same one-call network for the "Linear, then aggregate" convolutions: kind 1 = GCNConv

@@ -64,7 +64,7 @@ PROTOTYPES = {
     "pgnn_linear_fwd_wp": (_i, [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _p, _p]),
     "pgnn_linear_bwd_data_wp": (_i, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p]),
     "pgnn_split_weights_2p": (_i, [_p, _p, _p, _p, _p, _i64, _p]),
-    "pgnn_stack_bwd_milestone_arm": (_i, [_i]),
+    "pgnn_stack_bwd_milestone_arm": (_i, [_i, _p]),
     "pgnn_stack_bwd_milestone_wait": (_i, [_p]),
     "pgnn_linear_fwd_2p": (_i, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _p, _p, _p]),
     "pgnn_linear_bwd_data_2p": (_i, [_p, _i64, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _p]),

@@ -1430,11 +1430,15 @@ int pgnn::neighbor_sum_bn_bwd(const float* x, int64_t ldx, const int32_t* ptr, c
   t.relu = tail.relu;
   t.fold = BnBwdFold{tail.gamma, tail.save_invstd, tail.scratch.partial, tail.scratch.gsum, tail.scratch.tickets, tail.scratch.coef,
                      tail.dgamma, tail.dbeta, tail.training, (int)n};
-  if (pol == 3)
-    return launch_aggregate_dma_p<false, 2, 10, false, 19, false, true>(x, ldx, ptr, nbr, nullptr, nullptr, nullptr, out, ldo, n, dim, st, nullptr,
-                                                                         0, nullptr, &t, tail.scratch.max_blocks);
-  return launch_aggregate_dma_p<false, 2, 10, false, 16, false, true>(x, ldx, ptr, nbr, nullptr, nullptr, nullptr, out, ldo, n, dim, st, nullptr,
-                                                                       0, nullptr, &t, tail.scratch.max_blocks);
+  const int rc = pol == 3 ? launch_aggregate_dma_p<false, 2, 10, false, 19, false, true>(x, ldx, ptr, nbr, nullptr, nullptr, nullptr, out, ldo, n, dim,
+                                                                                         st, nullptr, 0, nullptr, &t, tail.scratch.max_blocks)
+                          : launch_aggregate_dma_p<false, 2, 10, false, 16, false, true>(x, ldx, ptr, nbr, nullptr, nullptr, nullptr, out, ldo, n, dim,
+                                                                                         st, nullptr, 0, nullptr, &t, tail.scratch.max_blocks);
+  if (rc != PGNN_ERR_WORKSPACE) return rc;
+  // more blocks than the BatchNorm-backward scratch has partial rows for (beyond 1 048 576 nodes, or PGNN_BN_ROWS_PER_BLOCK above 32;
+  // nothing was launched): the plain sum, and the caller's pgnn_bn_bwd takes the sums in a pass of its own
+  *fused = false;
+  return launch_aggregate<false, false>(x, ldx, ptr, nbr, nullptr, nullptr, nullptr, nullptr, out, ldo, n, dim, st);
 }
 
 extern "C" {

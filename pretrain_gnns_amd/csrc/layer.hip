@@ -52,6 +52,8 @@ inline bool use_side_stream() { return env_knob("PGNN_SIDE_STREAM", 1) != 0; }
 // happen on the caller's.  A backward that never reaches the layer (other networks, fewer layers) leaves it unrecorded.
 struct GradMilestone {
   int layer = -1;
+  const void* network = nullptr;  // the armed network: the w1 of its layer `layer` (parameter storage is stable across steps)
+  int backwards = 0;              // stack backwards of that network that reached the layer since it was armed
   bool recorded = false;
   hipEvent_t ev[2] = {nullptr, nullptr};
 };
@@ -62,11 +64,16 @@ GradMilestone* milestone_of_current_device() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   return &g_milestones[dev];
 }
-int milestone_record(int l, hipStream_t main, hipStream_t aux) {
+// `network`: layers[l].w1 of the backward that calls -- another network's backward (context prediction runs two under one set of
+// optimizers) must not record the armed one's milestone.  A SECOND backward of the armed network before the wait
+// (gradient accumulation) adds into gradients the first one's events no longer cover: counted, and the wait then refuses.
+int milestone_record(int l, const void* network, hipStream_t main, hipStream_t aux) {
   GradMilestone* m = milestone_of_current_device();
   if (!m || m->layer < 0) return PGNN_OK;  // (unlocked peek: the production path without data parallelism never takes the lock)
   std::lock_guard<std::mutex> lock(g_milestone_mutex);
-  if (l != m->layer || m->recorded) return PGNN_OK;
+  if (l != m->layer || network != m->network) return PGNN_OK;
+  ++m->backwards;
+  if (m->recorded) return PGNN_OK;
   for (auto& e : m->ev)
     if (!e) PGNN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   PGNN_HIP(hipEventRecord(m->ev[0], main));
@@ -480,7 +487,7 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
   return PGNN_OK;
 }
 
-int pgnn_stack_bwd_milestone_arm(int layer) {
+int pgnn_stack_bwd_milestone_arm(int layer, const void* network) {
   GradMilestone* m = milestone_of_current_device();
   if (!m) {
     set_error("stack_bwd_milestone_arm: no current device");
@@ -488,6 +495,8 @@ int pgnn_stack_bwd_milestone_arm(int layer) {
   }
   std::lock_guard<std::mutex> lock(g_milestone_mutex);
   m->layer = layer;
+  m->network = network;
+  m->backwards = 0;
   m->recorded = false;
   return PGNN_OK;
 }
@@ -496,7 +505,9 @@ int pgnn_stack_bwd_milestone_wait(pgnn_stream stream) {
   GradMilestone* m = milestone_of_current_device();
   if (!m) return 1;
   std::lock_guard<std::mutex> lock(g_milestone_mutex);
-  if (m->layer < 0 || !m->recorded) return 1;  // nothing behind an event: the caller orders its stream behind the whole backward
+  // nothing behind an event, or more than one backward ran since the arming (the later ones ACCUMULATE into gradients the
+  // recorded events do not cover): the caller orders its stream behind the whole backward
+  if (m->layer < 0 || !m->recorded || m->backwards != 1) return 1;
   PGNN_HIP(hipStreamWaitEvent((hipStream_t)stream, m->ev[0], 0));
   PGNN_HIP(hipStreamWaitEvent((hipStream_t)stream, m->ev[1], 0));
   return PGNN_OK;
@@ -697,7 +708,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     if (!sd && (rc = aggregate_t())) return rc;
     // every parameter gradient of layers >= l is enqueued now (weights, biases and edge tables on `aux`, the BatchNorm's on `main`;
     // layer l - 1's BatchNorm sums, which the transposed aggregation above also left, only arrive early)
-    if ((rc = milestone_record(l, main, aux))) return rc;
+    if ((rc = milestone_record(l, p.w1, main, aux))) return rc;
     g = dxb[b];
     ldg = dim;
   }

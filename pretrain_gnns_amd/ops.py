@@ -840,6 +840,8 @@ def _head_state(dev):
     key = (idx, stream_ptr(idx))
     t = _head_words.get(key)
     if t is None:
+        if len(_head_words) >= 16:  # streams come and go: keep the most recent few, oldest out first
+            _head_words.pop(next(iter(_head_words)))
         t = _head_words[key] = torch.zeros(64, dtype=torch.int32, device=dev)
     return t
 
@@ -1308,7 +1310,18 @@ class ChemGINStack(Function):
         if ctx.direct is not None:
             _deposit_grads(ctx.direct, ctx.versions, grads[2:])
             return (None, None, None) + grads[:2]
+        global _autograd_path_backwards
+        _autograd_path_backwards += 1  # these gradients reach .grad through AccumulateGrad, behind the whole backward (parallel.py)
         return (None, None, None) + grads
+
+
+_autograd_path_backwards = 0
+
+
+def autograd_path_backwards():
+    """how many chem GIN stack backwards handed their parameter gradients to autograd instead of depositing them (hooks on a
+    parameter, direct deposit off): what the overlapped all-reduce compares before trusting a gradient milestone"""
+    return _autograd_path_backwards
 
 
 _stack_layouts = {}

@@ -153,17 +153,25 @@ class AllReduceOptimizers:
     optimizer applies its update."""
 
     def __init__(self, optimizers, weight_fn=None, overlap=None):
-        """``overlap=(gnn, from_layer)`` (opt-in; chem GIN one-call network with direct gradient deposit, CUDA): the all-reduce of
+        """``overlap=(gnn, from_layer[, other_networks])`` (opt-in; chem GIN one-call network with direct gradient deposit, CUDA; any
+        further one-call network whose parameters these optimizers hold must be listed: its gradients are reduced last): the all-reduce of
         everything the backward has finished once layer ``from_layer`` of ``gnn`` is enqueued -- the heads, layers >=
         from_layer -- runs on a communication stream under the backward of the layers below; the rest (those layers, the atom
         embeddings) follows on the caller's stream.  Same sums, same bits as the single collective."""
         params = [p for o in optimizers for g in o.param_groups for p in g["params"]]
         self.overlap_layer, self.comm_stream, late = None, None, ()
+        self._overlap_w1, self._autograd_backwards = None, 0
         if overlap is not None and params and params[0].is_cuda:
-            gnn, from_layer = overlap
+            gnn, from_layer = overlap[0], overlap[1]
+            others = overlap[2] if len(overlap) > 2 else ()
             top = {id(p) for p in top_of_network(gnn, from_layer)}
             late = [p for p in gnn.parameters() if id(p) not in top]  # layers below from_layer, the atom embeddings
+            # every OTHER one-call network under these optimizers (context prediction: the context network) records no milestone
+            # -- the arming is keyed on `gnn` -- so none of its gradients is behind the events: they go last too (ADVICE r04)
+            for net in others:
+                late += list(net.parameters())
             self.overlap_layer = int(from_layer)
+            self._overlap_w1 = gnn.gnns[from_layer].mlp[0].weight  # pgnn_gin_layer.w1 of that layer: the network's identity
             self.comm_stream = torch.cuda.Stream(device=params[0].device)
         self.bucket = GradBucket(params, late=late)
         self._pending = True
@@ -183,13 +191,17 @@ class AllReduceOptimizers:
 
     def _arm(self):
         if self.overlap_layer is not None and dist.is_initialized():
-            from . import _lib
-            _lib.load().pgnn_stack_bwd_milestone_arm(self.overlap_layer)
+            from . import _lib, ops
+            self._autograd_backwards = ops.autograd_path_backwards()
+            _lib.load().pgnn_stack_bwd_milestone_arm(self.overlap_layer, self._overlap_w1.data_ptr())
 
     def _wait_for_milestone(self, stream):
         from . import _lib, ops
-        if not ops.direct_grads_enabled():  # autograd's AccumulateGrad writes .grad behind the whole backward
+        # autograd's AccumulateGrad writes .grad behind the whole backward: with direct deposit off, or when ANY stack backward since
+        # the arming fell back to it (hooks on a parameter), the events cover nothing
+        if not ops.direct_grads_enabled() or ops.autograd_path_backwards() != self._autograd_backwards:
             return False
+        # (the C side refuses when no backward of the armed network, or more than one -- gradient accumulation -- reached the layer)
         ok = _lib.load().pgnn_stack_bwd_milestone_wait(stream.cuda_stream) == 0
         self.overlapped_steps += int(ok)
         return ok
@@ -197,6 +209,9 @@ class AllReduceOptimizers:
     def _before_step(self):
         if self._pending:
             weight = self.weight_fn() if self.weight_fn else None
+            if weight is not None and not isinstance(weight, (int, float)):
+                # a device tensor produced on the caller's stream would be read on the communication stream unordered
+                raise TypeError("weight_fn must return a Python float (fetch a device scalar with .item() first), got %s" % type(weight).__name__)
             if self.overlap_layer is not None:
                 self.bucket.allreduce_overlapped(weight, self.comm_stream, self._wait_for_milestone)
             else:

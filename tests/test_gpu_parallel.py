@@ -375,3 +375,42 @@ def test_rccl_two_ranks(tmp_path):
     for a, b in zip(r0["params"], r1["params"]):
         assert torch.equal(a, b)  # ranks stay bit-identical: same bucket after the all-reduce, same Adam
     assert r0["comm"]["backend"] == "nccl" and r0["comm"]["world"] == 2
+
+
+def test_gradient_milestone_is_keyed_on_the_network_and_refuses_accumulation():
+    """pgnn_stack_bwd_milestone_arm(layer, network) / _wait (ABI 10): the backward of ANOTHER one-call network must not
+    record the armed network's milestone (context prediction runs two under one set of optimizers: the head collective would race
+    with the producers of the armed network's top gradients), and a SECOND backward of the armed network before the wait --
+    gradient accumulation: it adds into gradients the first one's events do not cover -- makes the wait refuse, so the caller
+    orders its communication stream behind the whole backward.  Single process, no process group: the C entry points directly."""
+    from oracle import hostdata
+    from pretrain_gnns_amd import ops
+    from pretrain_gnns_amd.chem import model as hchem
+
+    dev = torch.device("cuda", 0)
+    lib = ops.load()
+    torch.manual_seed(3)
+    a, b = hchem.GNN(5, 300).to(dev), hchem.GNN(3, 300).to(dev)
+    d = hostdata.chem_masking_batch(24, seed=4).to(dev)
+    prev = ops.set_direct_grads(True)
+    side = torch.cuda.Stream()
+    try:
+        def backward(net):
+            net(d.x, d.edge_index, d.edge_attr).square().sum().backward()
+
+        token = a.gnns[2].mlp[0].weight.data_ptr()
+        assert lib.pgnn_stack_bwd_milestone_arm(2, token) == 0
+        assert lib.pgnn_stack_bwd_milestone_wait(side.cuda_stream) == 1   # nothing ran
+        backward(b)                                                        # the other network reaches ITS layer 2
+        assert lib.pgnn_stack_bwd_milestone_wait(side.cuda_stream) == 1   # ... and records nothing
+        backward(a)
+        assert lib.pgnn_stack_bwd_milestone_wait(side.cuda_stream) == 0   # the armed network's first backward: behind two events
+        backward(a)                                                        # accumulation into the same .grad
+        assert lib.pgnn_stack_bwd_milestone_wait(side.cuda_stream) == 1
+        assert lib.pgnn_stack_bwd_milestone_arm(2, token) == 0            # re-armed (the next step's zero_grad): counts again
+        backward(a)
+        assert lib.pgnn_stack_bwd_milestone_wait(side.cuda_stream) == 0
+    finally:
+        lib.pgnn_stack_bwd_milestone_arm(-1, None)
+        ops.set_direct_grads(prev)
+        torch.cuda.synchronize()
