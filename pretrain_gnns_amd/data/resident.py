@@ -41,17 +41,30 @@ class ResidentDataset:
     ``slices['edge_attr']``.
     """
 
-    def __init__(self, x, edge_index, edge_attr, node_slice, edge_slice, device="cuda", center_node_idx=None, relabel=False):
+    def __init__(self, x, edge_index, edge_attr, node_slice, edge_slice, device="cuda", center_node_idx=None, relabel=None):
         """relabel=True: the nodes of every graph are renumbered ONCE, here, in Cuthill-McKee order (``relabel.bandwidth_order``:
         neighbours within a couple of rows of each other) -- the aggregation kernel then finds every source row in its LDS window
         whatever order the dataset came in (SMILES parse order: 6 % of the edges outside it; an arbitrary order: a third).  Only
         labels change: ``edge_index`` keeps its column order, so every sum runs in the reference's order and node-level results are
         those of the original order, permuted (``old_of_new``: row j here is original row ``old_of_new[j]``).  Masked atoms,
         centre nodes and pooling act on whole graphs / on rows drawn after the renumbering, so the training loops need nothing
-        else; explicit ``masked_atom_indices`` are positions in THIS order (map original positions through ``new_of_old``)."""
+        else; explicit ``masked_atom_indices`` are positions in THIS order (map original positions through ``new_of_old``).
+        relabel=None (the default since round 5): True for molecule datasets (integer ``edge_attr``: chem/loader.py's layout), False
+        for the ego networks of bio/loader.py (float ``edge_attr``; their aggregation keeps a whole graph in LDS and does not care).
+        relabel=False keeps the rows as fed -- what a comparison against the reference's own collate, row for row, needs."""
+        if relabel is None:
+            relabel = not torch.as_tensor(edge_attr).is_floating_point()
         node_slice = torch.as_tensor(node_slice, dtype=torch.int64).cpu()
         edge_slice = torch.as_tensor(edge_slice, dtype=torch.int64).cpu()
         self.new_of_old = self.old_of_new = None
+        if node_slice.numel() != edge_slice.numel() or node_slice.numel() < 2:
+            raise ValueError("node_slice and edge_slice must both be [G+1]")
+        if int(node_slice[-1]) != x.size(0) or int(edge_slice[-1]) != edge_index.size(1) or edge_attr.size(0) != edge_index.size(1):
+            raise ValueError("slices do not match the concatenated tensors")
+        if x.dim() != 2 or edge_attr.dim() != 2 or edge_index.dtype != torch.int64:
+            raise ValueError("x / edge_attr must be 2-D, edge_index int64 [2, E]")
+        if (x.element_size() * x.size(1)) % 4 or (edge_attr.element_size() * edge_attr.size(1)) % 4:
+            raise ValueError("feature rows must be multiples of 4 bytes")
         if relabel:
             from . import relabel as _relabel
             ns_h, es_h = node_slice.numpy(), edge_slice.numpy()
@@ -65,14 +78,6 @@ class ResidentDataset:
                 c = np.asarray(torch.as_tensor(center_node_idx).cpu(), dtype=np.int64).reshape(-1)
                 center_node_idx = torch.from_numpy(new_local[ns_h[:-1] + c])
             self.new_of_old, self.old_of_new = new_local, old_of_new
-        if node_slice.numel() != edge_slice.numel() or node_slice.numel() < 2:
-            raise ValueError("node_slice and edge_slice must both be [G+1]")
-        if int(node_slice[-1]) != x.size(0) or int(edge_slice[-1]) != edge_index.size(1) or edge_attr.size(0) != edge_index.size(1):
-            raise ValueError("slices do not match the concatenated tensors")
-        if x.dim() != 2 or edge_attr.dim() != 2 or edge_index.dtype != torch.int64:
-            raise ValueError("x / edge_attr must be 2-D, edge_index int64 [2, E]")
-        if (x.element_size() * x.size(1)) % 4 or (edge_attr.element_size() * edge_attr.size(1)) % 4:
-            raise ValueError("feature rows must be multiples of 4 bytes")
         self.device = torch.device(device)
         self.x = x.contiguous().to(self.device)
         self.edge_index = edge_index.contiguous().to(self.device)
@@ -92,7 +97,7 @@ class ResidentDataset:
         return self.num_graphs
 
     @classmethod
-    def from_graphs(cls, graphs, device="cuda", relabel=False):
+    def from_graphs(cls, graphs, device="cuda", relabel=None):
         """from a list of per-graph ``Data`` objects (x, edge_index, edge_attr)"""
         ns = np.cumsum([0] + [g.x.size(0) for g in graphs])
         es = np.cumsum([0] + [g.edge_index.size(1) for g in graphs])
@@ -103,7 +108,7 @@ class ResidentDataset:
                    torch.cat([g.edge_attr for g in graphs], 0), ns, es, device, center_node_idx=center, relabel=relabel)
 
     @classmethod
-    def from_inmemory(cls, data, slices, device="cuda", relabel=False):
+    def from_inmemory(cls, data, slices, device="cuda", relabel=None):
         """from the ``(data, slices)`` pair of a torch_geometric InMemoryDataset processed file
         (what ``torch.load(processed_paths[0])`` returns in chem/loader.py / bio/loader.py)"""
         return cls(data.x, data.edge_index, data.edge_attr, slices["x"], slices["edge_attr"], device,

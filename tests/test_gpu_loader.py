@@ -27,7 +27,7 @@ def _same(batch, want, keys=("x", "edge_index", "edge_attr", "batch")):
 @pytest.mark.parametrize("batch_size", [1, 7, 64, 2500])
 def test_collate_matches_host_collate_chem(batch_size):
     graphs = _chem_graphs(50, seed=1)
-    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV, relabel=False)
     ids = np.random.default_rng(batch_size).integers(0, len(graphs), size=batch_size)  # with repeats; > 1024 ids = scan carry
     out = ds.collate(ids)
     ds.check(out)
@@ -38,7 +38,7 @@ def test_collate_matches_host_collate_chem(batch_size):
 def test_collate_matches_host_collate_bio():
     rng = np.random.default_rng(2)
     graphs = [synthetic.ppi_like_graph(rng) for _ in range(12)]
-    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV, relabel=False)
     ids = [3, 3, 0, 11, 7]
     out = ds.collate(ids)
     ds.check(out)
@@ -52,7 +52,7 @@ def test_collate_ragged_and_empty_graphs():
     pair = Data(x=torch.tensor([[6, 0], [7, 1]]), edge_index=torch.tensor([[0, 1], [1, 0]]),
                 edge_attr=torch.tensor([[1, 0], [1, 0]]))
     graphs = [lone, pair] + _chem_graphs(3, seed=3)
-    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV, relabel=False)
     for ids in ([0], [0, 0, 0], [0, 1, 2], [2, 0, 3, 0, 1], [1, 0]):
         out = ds.collate(ids)
         ds.check(out)
@@ -60,7 +60,7 @@ def test_collate_ragged_and_empty_graphs():
 
 
 def test_bad_graph_ids_are_refused():
-    ds = resident.ResidentDataset.from_graphs(_chem_graphs(4), DEV)
+    ds = resident.ResidentDataset.from_graphs(_chem_graphs(4), DEV, relabel=False)
     with pytest.raises(IndexError):
         ds.collate([0, 4])
     with pytest.raises(ValueError):
@@ -69,7 +69,7 @@ def test_bad_graph_ids_are_refused():
 
 def test_mask_atoms_properties_and_determinism():
     graphs = _chem_graphs(40, seed=4)
-    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV, relabel=False)
     ids = np.arange(40)[::-1].copy()
     plain = ds.collate(ids)
     a = ds.collate(ids, mask_rate=0.15, seed=11)
@@ -110,7 +110,7 @@ def test_mask_atoms_is_uniform():
     """every atom of a 20-atom graph is picked with frequency k/n = 4/20 over many seeds"""
     g = Data(x=torch.tensor([[5, 0]] * 20), edge_index=torch.zeros(2, 0, dtype=torch.int64),
              edge_attr=torch.zeros(0, 2, dtype=torch.int64))
-    ds = resident.ResidentDataset.from_graphs([g], DEV)
+    ds = resident.ResidentDataset.from_graphs([g], DEV, relabel=False)
     counts = torch.zeros(20)
     trials = 600
     for seed in range(trials):
@@ -146,7 +146,7 @@ def test_explicit_indices_match_host_maskatom(mask_edge):
         picks.append(idx + off)
         off += n
     want = hostdata.collate(masked)
-    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV, relabel=False)
     out = ds.collate(np.arange(16), masked_atom_indices=np.concatenate(picks), mask_edge=mask_edge)
     ds.check(out)
     keys = ["x", "edge_index", "edge_attr", "batch", "masked_atom_indices", "mask_node_label"]
@@ -161,7 +161,7 @@ def test_bio_mask_edge_matches_host_and_properties():
     overwritten with the mask row, labels = original rows."""
     rng = np.random.default_rng(8)
     graphs = [synthetic.ppi_like_graph(rng) for _ in range(6)]
-    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV, relabel=False)
     masked = [hostdata.mask_edges(g, rng) for g in graphs]
     want = hostdata.collate(masked)
     out = ds.collate(np.arange(6), masked_edge_idx=want.masked_edge_idx)
@@ -205,7 +205,7 @@ def test_resident_batch_drives_the_train_step_identically():
         g = synthetic.zinc_like_graph(rng)
         hostdata.mask_atoms(g, rng)
         graphs.append(g)
-    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV, relabel=False)
     dev_batch = ds.collate(np.arange(32), masked_atom_indices=host.masked_atom_indices)
     _same(dev_batch, host, ("x", "edge_index", "edge_attr", "batch", "masked_atom_indices", "mask_node_label"))
     losses = []
@@ -219,7 +219,7 @@ def test_resident_batch_drives_the_train_step_identically():
 
 def test_loader_epoch_covers_dataset_once():
     graphs = _chem_graphs(37, seed=7)
-    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV, relabel=False)
     loader = resident.ResidentLoader(ds, batch_size=8, shuffle=True, seed=3, mask_rate=0.15)
     seen_nodes, batches = 0, 0
     for batch in loader:
@@ -237,7 +237,7 @@ def test_loader_epochs_through_the_pinned_id_staging_match_the_host_permutation(
     ``batch_ids(epoch)`` -- node counts per batch against the host's, epoch after epoch, also after a buffer is reused"""
     graphs = _chem_graphs(50, seed=17)
     sizes = np.array([g.x.size(0) for g in graphs])
-    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV, relabel=False)
     loader = resident.ResidentLoader(ds, batch_size=16, shuffle=True, seed=9)
     got, want = [], []
     for epoch in range(5):
@@ -269,7 +269,7 @@ def test_substruct_context_matches_host_extraction(k, l1, l2):
     roots = [int(rng.integers(0, graphs[i].x.size(0))) for i in ids]
     want = hostdata.collate_substruct_context(
         [hostdata.extract_substruct_context(graphs[i], rng, k=k, l1=l1, l2=l2, root=r) for i, r in zip(ids, roots)])
-    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV, relabel=False)
     out = ds.collate_substruct_context(ids, k=k, l1=l1, l2=l2, roots=roots)
     ds.check(out)
     _same(out, want, CTX_KEYS)
@@ -277,7 +277,7 @@ def test_substruct_context_matches_host_extraction(k, l1, l2):
 
 def test_substruct_context_all_graphs_dropped():
     """k < l1: substructure and context rings cannot overlap, every graph is dropped -> empty batch"""
-    ds = resident.ResidentDataset.from_graphs(_chem_graphs(9, seed=14), DEV)
+    ds = resident.ResidentDataset.from_graphs(_chem_graphs(9, seed=14), DEV, relabel=False)
     out = ds.collate_substruct_context(np.arange(9), k=2, l1=3, l2=4, seed=1)
     ds.check(out)
     assert out.num_graphs == 0
@@ -291,7 +291,7 @@ def test_substruct_context_random_roots_and_training_step():
     from pretrain_gnns_amd import train
     from pretrain_gnns_amd.chem import model as hmodel
     graphs = _chem_graphs(64, seed=13)
-    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV, relabel=False)
     ids = np.arange(64)
     a = ds.collate_substruct_context(ids, seed=3)
     b = ds.collate_substruct_context(ids, seed=3)
@@ -319,7 +319,7 @@ def test_bio_resident_loader_drives_the_masking_step():
     from pretrain_gnns_amd.bio import model as hbio
     rng = np.random.default_rng(21)
     graphs = [synthetic.ppi_like_graph(rng) for _ in range(24)]
-    ds = resident.ResidentDataset.from_graphs(graphs, DEV)
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV, relabel=False)
     loader = resident.ResidentLoader(ds, batch_size=8, shuffle=True, seed=2, mask_rate=0.15)
     torch.manual_seed(0)
     mods = [hbio.GNN(3, 300).to(DEV), torch.nn.Linear(300, 7).to(DEV)]
@@ -349,7 +349,7 @@ def test_from_inmemory_dataset_layout():
     ns = torch.tensor(np.cumsum([0] + [g.x.size(0) for g in graphs]))
     es = torch.tensor(np.cumsum([0] + [g.edge_index.size(1) for g in graphs]))
     slices = {"x": ns, "edge_index": es, "edge_attr": es}
-    ds = resident.ResidentDataset.from_inmemory(data, slices, DEV)
+    ds = resident.ResidentDataset.from_inmemory(data, slices, DEV, relabel=False)
     ids = [10, 0, 4, 4]
     out = ds.collate(ids)
     ds.check(out)
@@ -373,7 +373,7 @@ def test_relabelled_dataset_gives_the_same_sums_in_permuted_rows(order):
     make = synthetic.zinc_like_graph_smiles if order == "smiles" else (lambda r: synthetic.zinc_like_graph(r, permute=True))
     graphs = [make(rng) for _ in range(300)]
     ids = rng.permutation(300)[:257]
-    fed = resident.ResidentDataset.from_graphs(graphs, DEV)
+    fed = resident.ResidentDataset.from_graphs(graphs, DEV, relabel=False)
     ren = resident.ResidentDataset.from_graphs(graphs, DEV, relabel=True)
     b0, b1 = fed.collate(ids), ren.collate(ids)
     perm = torch.from_numpy(ren.batch_rows_in_original_order(ids)).to(DEV)  # row j of b1 = row perm[j] of b0
@@ -417,7 +417,7 @@ def test_relabelled_dataset_drives_the_masking_step():
 
     rng = np.random.default_rng(3)
     graphs = [synthetic.zinc_like_graph_smiles(rng) for _ in range(96)]
-    fed = resident.ResidentDataset.from_graphs(graphs, DEV)
+    fed = resident.ResidentDataset.from_graphs(graphs, DEV, relabel=False)
     ren = resident.ResidentDataset.from_graphs(graphs, DEV, relabel=True)
     ids = np.arange(96)
     b0 = fed.collate(ids, mask_rate=0.15, seed=4)

@@ -191,7 +191,7 @@ def device_masked_batches(fx, tag, mask_edge):
     """the reference loader's batches rebuilt ON THE DEVICE: HBM-resident raw graphs -> pgnn_collate_graphs +
     pgnn_mask_atoms_apply with the reference's per-graph atom choices (its masked_atom_indices debugging hook)"""
     raw = [Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr) for g in rf.raw_graphs(fx["raw"])]
-    ds = resident.ResidentDataset.from_graphs(raw, DEV)
+    ds = resident.ResidentDataset.from_graphs(raw, DEV, relabel=False)
     counts, local = fx[tag]["mask_counts"].tolist(), fx[tag]["mask_local"]
     bs = int(fx["batch_size"]) if "batch_size" in fx else len(raw)
     node_off = np.asarray(fx["raw"]["node_slices"])
@@ -281,7 +281,7 @@ def test_device_context_transform_vs_reference(name):
     fx = rf.load(name)
     bs = int(fx["batch_size"])
     raw = [Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr) for g in rf.raw_graphs(fx["raw"])]
-    ds = resident.ResidentDataset.from_graphs(raw, DEV)
+    ds = resident.ResidentDataset.from_graphs(raw, DEV, relabel=False)
     got = ds.collate_substruct_context(np.arange(bs), k=5, l1=4, l2=7, roots=fx["roots"][:bs])
     ds.check(got)
     want = fx["batches"]["0"]
@@ -479,7 +479,7 @@ def test_bio_masking_vs_reference(name, types):
     _, hbio = hip_models()
     raw = [Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr, center_node_idx=g.center_node_idx)
            for g in rf.raw_graphs(fx["raw"], bio=True)]
-    ds = resident.ResidentDataset.from_graphs(raw, DEV)
+    ds = resident.ResidentDataset.from_graphs(raw, DEV, relabel=False)
     bs = int(fx["batch_size"])
     counts, local = fx["mask_counts"].tolist(), fx["mask_local"]
     edge_off = np.asarray(fx["raw"]["edge_slices"])
@@ -532,7 +532,7 @@ def test_bio_contextpred_vs_reference(name):
     # bit, == the reference's batch as labelled graphs (its context numbering is networkx's)
     raw_b = rf.raw_graphs(fx["raw"], bio=True)
     raw = [Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr, center_node_idx=g.center_node_idx) for g in raw_b]
-    ds = resident.ResidentDataset.from_graphs(raw, DEV)
+    ds = resident.ResidentDataset.from_graphs(raw, DEV, relabel=False)
     got = ds.collate_substruct_context(np.arange(bs), l1=1)
     ds.check(got)
     host = [hostdata.bio_extract_substruct_context(g, l1=1) for g in raw[:bs]]
