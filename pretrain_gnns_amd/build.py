@@ -65,4 +65,6 @@ def build(verbose=False, force=False, extra_flags=()):
 
 
 if __name__ == "__main__":
-    print(build(verbose=True, force="--force" in sys.argv))
+    # --ab: the A/B build (-DPGNN_AB): compile-time ablation instances behind PGNN_* knobs (tools/, profiles/): not what ships
+    ab = "--ab" in sys.argv
+    print(build(verbose=True, force="--force" in sys.argv or ab, extra_flags=("-DPGNN_AB",) if ab else ()))

@@ -63,7 +63,9 @@ constexpr int kMaxChunks = 19;        // N1 <= 608
 // reads per MFMA -- want ~470 of the 512 registers a lone wave per SIMD may have, and hipcc spills 94-144 of them.)
 constexpr int kFusedWaves = 8, kFusedMI = 1;
 constexpr int kFusedRows = kFusedWaves * kFusedMI * 16;  // rows per pass of a workgroup
-template <int NK1, int NB2, bool BWD>
+// ABL (builds with -DPGNN_AB only; results are WRONG, the time is what is asked): bit 0 no MFMAs, bit 1 no stores of H / Y, bit 2 no
+// weight refill (the DMA stream), bit 3 no fragment reads from LDS, bit 4 no split of the chunk into planes (profiles/r05/mlp_fused_ablation.txt)
+template <int NK1, int NB2, bool BWD, int ABL = 0>
 __global__ void __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_per_eu(2, 2))) k_mlp2p_fused(MlpFusedArgs p) {
   constexpr int NW = kFusedWaves, MI = kFusedMI;
   constexpr int NP1 = NK1 * 4, NP2 = NB2 * 2;  // 1-KiB DMA pieces of a slice
@@ -152,17 +154,24 @@ __global__ void __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_
 #define PGNN_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
   auto ld_w1 = [&](uint32_t addr, auto uc, f16x8 (&w)[2]) {
     constexpr int u = decltype(uc)::value;
+    if constexpr ((ABL & 8) != 0) return;
     PGNN_DS_READ(w[0], addr, (((u >> 1) * 2 + 0) * 2 + (u & 1)) * 1024);
     PGNN_DS_READ(w[1], addr, (((u >> 1) * 2 + 1) * 2 + (u & 1)) * 1024);
   };
   auto ld_w2 = [&](uint32_t addr, auto jc, f16x8 (&w)[2]) {
     constexpr int j = decltype(jc)::value;
+    if constexpr ((ABL & 8) != 0) return;
     PGNN_DS_READ(w[0], addr, j * 1024);
     PGNN_DS_READ(w[1], addr, (NB2 + j) * 1024);
   };
   // behind the wait that covers them: from here on the pair may be read
   auto claim = [&](f16x8 (&w)[2]) { asm volatile("" : "+v"(w[0]), "+v"(w[1])); };
   auto mfma3 = [&](f32x4 (&c)[MI], const f16x8 (&w)[2], const f16x8 (&x)[MI][2]) {
+    if constexpr ((ABL & 1) != 0) {  // (the operands stay live: one add each)
+#pragma unroll
+      for (int i = 0; i < MI; ++i) c[i][0] += (float)w[0][0] + (float)w[1][0] + (float)x[i][0][0] + (float)x[i][1][0];
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[0], x[i][1], c[i], 0, 0, 0);
 #pragma unroll
@@ -275,7 +284,7 @@ __global__ void __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_
               for (int i = 0; i < MI; ++i) { x[i][0] = a[i][v >> 1][0]; x[i][1] = a[i][v >> 1][1]; }
               mfma3(h[v & 1], w[v % (kAhead + 1)], x);
               if constexpr (v % 3 == 0 && v >= 3 && v / 3 <= NJ) {
-                piece_w1(v / 3 - 1, cnext, wslot);
+                if constexpr ((ABL & 4) == 0) piece_w1(v / 3 - 1, cnext, wslot);
               }
               __builtin_amdgcn_sched_barrier(0);
             }
@@ -309,7 +318,6 @@ __global__ void __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_
         float cm = 0.f;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-          const int n = nbase + 4 * jj;
           const float4 bi = make_float4(bi1[jj][0], bi1[jj][1], bi1[jj][2], bi1[jj][3]);
           const float ai = ainv[i];
           float4 v = make_float4(h[jj][i][0] * (ai * bi.x), h[jj][i][1] * (ai * bi.y), h[jj][i][2] * (ai * bi.z), h[jj][i][3] * (ai * bi.w));
@@ -322,9 +330,31 @@ __global__ void __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_
             if (!(mk[i][jj][2] > 0.f)) v.z = 0.f;
             if (!(mk[i][jj][3] > 0.f)) v.w = 0.f;
           }
-          if (m < p.M && n < p.N1) *reinterpret_cast<float4*>(p.H + (int64_t)m * p.ldh + n) = v;
           vv[4 * jj] = v.x; vv[4 * jj + 1] = v.y; vv[4 * jj + 2] = v.z; vv[4 * jj + 3] = v.w;
           cm = fmaxf(cm, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+        {
+          // H goes out as whole 64-byte runs per row and instruction: lane group fk holds columns 8 fk .. + 7 of the chunk, so a store
+          // of its first float4 would leave 16-byte holes (32 bytes apart) that the second store fills later -- 64 partial writes per
+          // instruction at the L2.  Two cross-row swaps per register (v_permlane16_swap: rows 1 <-> 0' and 3 <-> 2'; v_permlane32_swap:
+          // rows 2,3 <-> 0',1') hand group fk the chunk's columns 4 fk .. + 3 (first store) and 16 + 4 fk .. + 3 (second).
+          typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+          float4 s0, s1;
+          float* a0 = &s0.x;
+          float* a1 = &s1.x;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            u2_t q = __builtin_amdgcn_permlane16_swap(__float_as_uint(vv[r]), __float_as_uint(vv[4 + r]), false, false);
+            q = __builtin_amdgcn_permlane32_swap(q[0], q[1], false, false);
+            a0[r] = __uint_as_float(q[0]);
+            a1[r] = __uint_as_float(q[1]);
+          }
+          const int ns = 32 * c + 4 * fk;
+          if (((ABL & 2) == 0 || p.M < 0) && m < p.M) {
+            float* hrow = p.H + (int64_t)m * p.ldh + ns;
+            if (ns < p.N1) *reinterpret_cast<float4*>(hrow) = s0;
+            if (ns + 16 < p.N1) *reinterpret_cast<float4*>(hrow + 16) = s1;
+          }
         }
         cm = fmaxf(cm, __shfl_xor(cm, 16));
         cm = fmaxf(cm, __shfl_xor(cm, 32));
@@ -344,10 +374,15 @@ __global__ void __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_
         }
         const float sr = s_run[i];
         uint4 ph, pl;
+        if constexpr ((ABL & 16) != 0) {
+          ph = make_uint4(__float_as_uint(vv[0] * sr), __float_as_uint(vv[2]), __float_as_uint(vv[4]), __float_as_uint(vv[6]));
+          pl = make_uint4(__float_as_uint(vv[1]), __float_as_uint(vv[3]), __float_as_uint(vv[5]), __float_as_uint(vv[7]));
+        } else {
         split2(vv[0] * sr, vv[1] * sr, ph.x, pl.x);
         split2(vv[2] * sr, vv[3] * sr, ph.y, pl.y);
         split2(vv[4] * sr, vv[5] * sr, ph.z, pl.z);
         split2(vv[6] * sr, vv[7] * sr, ph.w, pl.w);
+        }
         hp[i][0] = __builtin_bit_cast(f16x8, ph);
         hp[i][1] = __builtin_bit_cast(f16x8, pl);
       }
@@ -366,7 +401,7 @@ __global__ void __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_
               claim(w[v % (kAhead + 1)]);
               mfma3(o[v], w[v % (kAhead + 1)], hp);
               if constexpr (v % 3 == 0 && v >= 3 && v / 3 <= NJ) {
-                piece_w2(v / 3 - 1, cnext, wslot2);
+                if constexpr ((ABL & 4) == 0) piece_w2(v / 3 - 1, cnext, wslot2);
               }
               __builtin_amdgcn_sched_barrier(0);
             }
@@ -412,7 +447,7 @@ __global__ void __launch_bounds__(64 * kFusedWaves) __attribute__((amdgpu_waves_
             }
           }
         }
-        if (m < p.M && n < p.N2) *reinterpret_cast<float4*>(p.Y + (int64_t)m * p.ldy + n) = v;
+        if (((ABL & 2) == 0 || p.M < 0) && m < p.M && n < p.N2) *reinterpret_cast<float4*>(p.Y + (int64_t)m * p.ldy + n) = v;
       }
     }
   }
@@ -427,15 +462,31 @@ inline bool fused_shape_ok(int64_t k1, int64_t n1, int64_t n2) {
   return k1 > 288 && k1 <= 320 && n2 > 288 && n2 <= 304 && n1 >= 32 && n1 <= 608 && k1 % 4 == 0 && n1 % 4 == 0 && n2 % 4 == 0;
 }
 
+template <bool BWD, int ABL>
+int launch_fused_abl(const MlpFusedArgs& p, hipStream_t st) {
+  const size_t lds = (size_t)kRing * kSlot;
+  const int grid = std::min(num_cu(), p.groups);
+  allow_big_lds((const void*)k_mlp2p_fused<10, 19, BWD, ABL>, lds);
+  hipLaunchKernelGGL((k_mlp2p_fused<10, 19, BWD, ABL>), dim3(grid), dim3(64 * kFusedWaves), lds, st, p);
+  return check_launch(BWD ? "mlp_bwd_data_2p_fused" : "mlp_fwd_2p_fused");
+}
 template <bool BWD>
 int launch_fused(const MlpFusedArgs& p, hipStream_t st) {
-  const int nc = (p.N1 + 31) / 32;
-  const size_t lds = (size_t)kRing * kSlot;
-  (void)nc;
-  const int grid = std::min(num_cu(), p.groups);
-    allow_big_lds((const void*)k_mlp2p_fused<10, 19, BWD>, lds);
-  hipLaunchKernelGGL((k_mlp2p_fused<10, 19, BWD>), dim3(grid), dim3(64 * kFusedWaves), lds, st, p);
-  return check_launch(BWD ? "mlp_bwd_data_2p_fused" : "mlp_fwd_2p_fused");
+#ifdef PGNN_AB  // the ablation instances exist in A/B builds only (python -m pretrain_gnns_amd.build --ab)
+  switch (env_knob("PGNN_FUSED_ABL", 0)) {
+    case 1: return launch_fused_abl<BWD, 1>(p, st);
+    case 2: return launch_fused_abl<BWD, 2>(p, st);
+    case 3: return launch_fused_abl<BWD, 3>(p, st);
+    case 4: return launch_fused_abl<BWD, 4>(p, st);
+    case 7: return launch_fused_abl<BWD, 7>(p, st);
+    case 8: return launch_fused_abl<BWD, 8>(p, st);
+    case 15: return launch_fused_abl<BWD, 15>(p, st);
+    case 16: return launch_fused_abl<BWD, 16>(p, st);
+    case 31: return launch_fused_abl<BWD, 31>(p, st);
+    default: break;
+  }
+#endif
+  return launch_fused_abl<BWD, 0>(p, st);
 }
 
 }  // namespace

@@ -685,13 +685,17 @@ def _adversarial_rows(case, m, k):
 
 
 @pytest.mark.parametrize("case", _ROW_CASES)
-@pytest.mark.parametrize("m,k,n", [(6747, 300, 600), (6747, 600, 300), (41269, 300, 600), (63, 600, 600), (1, 300, 600), (129, 36, 124), (513, 12, 300)])
+@pytest.mark.parametrize("m,k,n", [(6747, 300, 600), (6747, 600, 300), (41269, 300, 600), (63, 600, 600), (1, 300, 600), (129, 36, 124), (513, 12, 300),
+                                   (6747, 304, 608), (6747, 320, 600), (10249, 600, 600)])
 def test_products_on_two_fp16_planes_against_float64(case, m, k, n, monkeypatch):
     """pgnn_linear_fwd_2p / pgnn_linear_bwd_data_2p (k_gemm2pw; chem/model.py:29,54-55, bio/model.py:24: nn.Linear forward and its
     input gradient) against float64, the statistic of test_linear_fwd_split_bf16_is_as_accurate_as_the_fp32_mfma -- error over the
-    |a|.|b| bound of each entry -- at the bar of the three-plane products (max < 2e-6, rms < 3e-7) and, where results are sums of
-    many comparable terms, at that test's bar against the fp32-MFMA kernel on the same inputs (rms <= 1.25 x, max <= 2 x); on
-    operands chosen against a scale per row; ragged M / N, K not a multiple of 32, one-row and 41 269-row operands.  Then the hand-over of the row maxima: y_amax of the first product is max |y| of every row, bit for bit,
+    |a|.|b| bound of each entry -- at a bar set by what is measured (round 5, VERDICT r04 item 6: max < 5e-7, rms < 5e-8; rows whose
+    largest entry is 2^30 times their median: max < 3e-6, rms < 3e-7 -- ONE term dominates a result there and its 22-bit
+    representation error shows undiluted) and, for every row family at K >= 300, at that test's bar against the fp32-MFMA kernel
+    on the same inputs (rms <= 1.25 x, max <= 2 x); on operands chosen against a scale per row; ragged M / N, K not a multiple of
+    32, the other embedding widths' shapes (304 -> 608, 320 -> 600), the bio mlp's 600 -> 600 at 10 249 rows (the resident-plane
+    kernel's 19-step instance), one-row and 41 269-row operands.  Then the hand-over of the row maxima: y_amax of the first product is max |y| of every row, bit for bit,
     and a second product given those maxima equals the one that takes them itself, bit for bit."""
     ops = _ops()
     lib, sp = ops.load(), ops.stream_ptr()
@@ -721,12 +725,14 @@ def test_products_on_two_fp16_planes_against_float64(case, m, k, n, monkeypatch)
     rec = {"test": "two_planes_fwd", "case": case, "m": m, "k": k, "n": n, "max": err.max().item(), "rms": err.pow(2).mean().sqrt().item(),
            "max_fp32_mfma": err32.max().item(), "rms_fp32_mfma": err32.pow(2).mean().sqrt().item()}
     _log_two_plane(rec)
-    assert rec["max"] < 2e-6 and rec["rms"] < 3e-7, rec  # (the bar of test_products_on_weight_planes)
-    # against the fp32-MFMA kernel on the same inputs wherever a result is a sum of many comparable terms.  (Two planes carry 22
-    # significant bits per operand, fp32 24: where ONE term dominates a result -- the outlier rows, the top decade of the
-    # six-decade columns, K = 12 -- its representation error, <= 2^-21 of the term, shows undiluted; with hundreds of comparable
-    # terms both kernels are bound by the fp32 accumulation they share.)
-    if case in ("zero_rows", "gradient_rows", "mixed_scales") and k >= 300:
+    if case == "outlier_rows":
+        assert rec["max"] < 3e-6 and rec["rms"] < 3e-7, rec
+    else:
+        assert rec["max"] < 5e-7 and rec["rms"] < 5e-8, rec
+    # against the fp32-MFMA kernel on the same inputs at the path's depths.  (Two planes carry 22 significant bits per operand, fp32
+    # 24: at K = 12 / 36 single terms dominate and their representation error, <= 2^-21 of the term, shows undiluted -- up to 2.1 x
+    # there, which the path never runs; with hundreds of terms both kernels are bound by the fp32 accumulation they share.)
+    if k >= 300:
         assert rec["rms"] <= 1.25 * rec["rms_fp32_mfma"] + 1e-9 and rec["max"] <= 2.0 * rec["max_fp32_mfma"] + 1e-9, rec
     # the row maxima the epilogue leaves: exactly max |y| per row
     assert torch.equal(yam.view(torch.float32), y.abs().max(dim=1).values)
@@ -740,7 +746,7 @@ def test_products_on_two_fp16_planes_against_float64(case, m, k, n, monkeypatch)
     ops.check(lib.pgnn_linear_bwd_data_2p(dy.data_ptr(), n, None, wtp.data_ptr(), mask.data_ptr(), k, dx.data_ptr(), k, m, k, n, dxam.data_ptr(), sp), "bwd 2p")
     errd = ((dx.double() - wantd).abs() - tiny).clamp(min=0) / scaled.clamp(min=1e-300)
     _log_two_plane({"test": "two_planes_bwd_data", "case": case, "m": m, "k": k, "n": n, "max": errd.max().item(), "rms": errd.pow(2).mean().sqrt().item()})
-    assert errd.max().item() < 2e-6
+    assert errd.max().item() < (3e-6 if case == "outlier_rows" else 5e-7)
     assert torch.equal(dxam.view(torch.float32), dx.abs().max(dim=1).values)
     # hand-over: the second product of an mlp on the first one's maxima (k2 = n of the first)
     if n % 4 == 0 and n >= 8:
@@ -797,7 +803,8 @@ def test_fused_mlp_against_float64_and_the_two_products(case, m, k1, n1, n2):
     rec = {"test": "fused_mlp_fwd", "case": case, "m": m, "k1": k1, "n1": n1, "n2": n2, "hid_max": eh.max().item(), "y_max": ey.max().item(),
            "y_rms": ey.pow(2).mean().sqrt().item(), "y_max_two_products": eyu.max().item(), "y_rms_two_products": eyu.pow(2).mean().sqrt().item()}
     _log_two_plane(rec)
-    assert rec["hid_max"] < 2e-6 and rec["y_max"] < 2e-6 and rec["y_rms"] < 3e-7, rec
+    loose = case == "outlier_rows"
+    assert rec["hid_max"] < (3e-6 if loose else 5e-7) and rec["y_max"] < (3e-6 if loose else 5e-7) and rec["y_rms"] < (3e-7 if loose else 5e-8), rec
     assert rec["y_rms"] <= 1.25 * rec["y_rms_two_products"] + 1e-9 and rec["y_max"] <= 2.0 * rec["y_max_two_products"] + 1e-9, rec
     # the per-16-row column statistics of y the BatchNorm behind it is built from: sums and squared deviations of what was stored
     yb = torch.cat([y, torch.zeros((-m) % 16, n2, device=DEV)]).view(-1, 16, n2).double()
@@ -832,7 +839,7 @@ def test_fused_mlp_against_float64_and_the_two_products(case, m, k1, n1, n2):
     rec = {"test": "fused_mlp_bwd", "case": case, "m": m, "k1": k1, "n1": n1, "n2": n2, "dx_max": ed.max().item(), "dx_rms": ed.pow(2).mean().sqrt().item(),
            "dx_max_two_products": edu.max().item(), "dx_rms_two_products": edu.pow(2).mean().sqrt().item()}
     _log_two_plane(rec)
-    assert rec["dx_max"] < 2e-6 and rec["dx_rms"] < 3e-7, rec
+    assert rec["dx_max"] < (3e-6 if loose else 5e-7) and rec["dx_rms"] < (3e-7 if loose else 5e-8), rec
     assert rec["dx_rms"] <= 1.25 * rec["dx_rms_two_products"] + 1e-9 and rec["dx_max"] <= 2.0 * rec["dx_max_two_products"] + 1e-9, rec
 
 

@@ -47,6 +47,7 @@ def main():
     ap.add_argument("rows", nargs="*", type=int, default=[262144, 65536, 32768, 16384, 6747])
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--fused-only", action="store_true", help="time the fused launches only (ablation builds: their results are wrong)")
     a = ap.parse_args()
     lib, sp = ops.load(), ops.stream_ptr()
     k1, n1, n2 = 300, 600, 300
@@ -73,6 +74,22 @@ def main():
             ops.check(lib.pgnn_linear_fwd_2p(hid_u.data_ptr(), n1, ham.data_ptr(), p2.data_ptr(), b2.data_ptr(), y_u.data_ptr(), n2, m, n1, n2, 0, None,
                                              None, sp), "fwd 2")
 
+        if a.fused_only:
+            dy = torch.randn(m, n2, device=DEV) * 1e-3
+            dhid, dx = torch.empty(m, n1, device=DEV), torch.empty(m, k1, device=DEV)
+
+            def fused_bwd0():
+                ops.check(lib.pgnn_mlp_bwd_data_2p_fused(dy.data_ptr(), n2, p2t.data_ptr(), hid_u.data_ptr(), n1, p1t.data_ptr(), dhid.data_ptr(), n1,
+                                                         dx.data_ptr(), k1, m, n2, n1, k1, sp), "fused bwd")
+
+            two_fwd()
+            rec = {"rows": m, "abl": os.environ.get("PGNN_FUSED_ABL", "0"), "fwd_fused_us": round(timed(fused_fwd, a.iters), 1),
+                   "bwd_fused_us": round(timed(fused_bwd0, a.iters), 1)}
+            print(json.dumps(rec), flush=True)
+            if out:
+                out.write(json.dumps(rec) + "\n")
+                out.flush()
+            continue
         t_f, t_u = timed(fused_fwd, a.iters), timed(two_fwd, a.iters)
         same_hid = bool(torch.equal(hid, hid_u))
         dy_rel = ((y - y_u).abs().max() / y_u.abs().max()).item()
