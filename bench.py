@@ -503,7 +503,8 @@ def roofline_mlp(dev, rows):
         lib.pgnn_reload_env()
     tf32 = flops / (ms32 * 1e-3) / 1e12
     planes_peak, split_peak = MFMA_BF16_PEAK_TF / 3.0, MFMA_BF16_PEAK_TF / 6.0
-    return {"bound": "mfma",
+    fused = fused_mlp_pair(dev, rows, planes_peak)
+    return {"bound": "mfma", "fused_pair": fused, "mfma_util": MFMA_UTIL_PMC["k_gemm2pr<10,120>"], "mfma_util_source": MFMA_UTIL_SOURCE,
             "kernel": "k_gemm2pr<10,120,8,EPI_BIAS> (pgnn_linear_fwd_2p 300->600 from 16 384 rows on: fp32 values as two fp16 planes under a "
                       "power-of-two scale per row, three v_mfma_f32_16x16x32_f16 products per k-step, fp32 accumulate; the planes of 120 weight "
                       "rows resident in LDS per persistent workgroup, the activations streamed through registers a 16-row block ahead, no "
@@ -527,6 +528,79 @@ def roofline_mlp(dev, rows):
                                            "below ~160 tiles still run this template)",
                                  "achieved": round(tf32, 2), "peak": MFMA_F32_PEAK_TF, "frac": round(tf32 / MFMA_F32_PEAK_TF, 4),
                                  "ms_per_launch": round(ms32, 4), "ms_per_launch_std": round(float(per32.std()), 4)}}
+
+
+# MFMA utilisation from hardware counters: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), rocprofv3 --pmc,
+# one pass per counter pair (tools/gpu_r05b.sh .. gpu_r05g.sh); recorded figures of this round's kernels -- bench.py itself cannot
+# collect them (the counters need the profiler around the process).  Wave counters are 4-cycle quanta; the clock under these
+# kernels is 1.5-1.85 GHz (SQ_BUSY_CU_CYCLES / 256 over the event time), not the 2.4 GHz behind the 2 500 TFLOP/s peak.
+MFMA_UTIL_PMC = {"k_mlp2p_fused fwd (262144 rows)": 0.517, "k_mlp2p_fused bwd (262144 rows)": 0.430, "k_gemm2pr<10,120>": 0.417,
+                 "k_gemm2pr<19,64>": 0.340, "k_gemm2pw<112,160> (6740 rows)": 0.234, "k_gemm2pw<64,160> (6740 rows)": 0.241,
+                 "k_gemm3_pair<64,160> (6740 rows)": 0.372}
+MFMA_UTIL_SOURCE = ("profiles/r05/mlp_fused_pmc_summary.txt (large M), profiles/r05/step_b256_gemm_pmc_summary.txt (the 256-graph step): "
+                    "SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) per launch, rocprofv3 --pmc")
+
+
+def fused_mlp_pair(dev, rows, planes_peak):
+    """both products of the GIN mlp in ONE launch per direction (round 5, csrc/mlp_fused.hip: k_mlp2p_fused -- a wave owns 16 rows
+    for both products, the [rows, 600] hidden activation is written once and never re-read, the weights stream from L2 through an LDS
+    ring) against the two products on planes it replaces, forward (300 -> 600 + ReLU -> 300) and backward-data, HIP events, steady
+    state.  What the one-call chem network runs from 32 768 rows on."""
+    import ctypes
+    from pretrain_gnns_amd import ops
+
+    lib, sp = ops.load(), ops.stream_ptr()
+    k1, n1, n2 = 300, 600, 300
+    if not lib.pgnn_mlp_2p_fused_supported(rows, k1, n1, n2):
+        return None
+    torch.manual_seed(0)
+    x = torch.randn(rows, k1, device=dev)
+    w1, b1 = torch.randn(n1, k1, device=dev) * 0.05, torch.randn(n1, device=dev) * 0.1
+    w2, b2 = torch.randn(n2, n1, device=dev) * 0.05, torch.randn(n2, device=dev)
+    p1, p2 = ops.weight_planes_2p([w1, w2])
+    p2t, p1t = ops.weight_planes_2p([w2, w1], transpose=[True, True])
+    hid, y = torch.empty(rows, n1, device=dev), torch.empty(rows, n2, device=dev)
+    ham = torch.zeros(rows, dtype=torch.int32, device=dev)
+    dy = torch.randn(rows, n2, device=dev) * 1e-3
+    dhid, dx = torch.empty(rows, n1, device=dev), torch.empty(rows, k1, device=dev)
+
+    def fused_fwd():
+        ops.check(lib.pgnn_mlp_fwd_2p_fused(x.data_ptr(), k1, p1.data_ptr(), b1.data_ptr(), p2.data_ptr(), b2.data_ptr(), hid.data_ptr(), n1,
+                                            y.data_ptr(), n2, rows, k1, n1, n2, None, sp), "mlp fused fwd")
+
+    def two_fwd():
+        ham.zero_()
+        ops.linear_fwd_2p(x, p1, b1, n1, relu=True, out=hid, y_amax=ham)
+        ops.linear_fwd_2p(hid, p2, b2, n2, out=y, x_amax=ham)
+
+    def fused_bwd():
+        ops.check(lib.pgnn_mlp_bwd_data_2p_fused(dy.data_ptr(), n2, p2t.data_ptr(), hid.data_ptr(), n1, p1t.data_ptr(), dhid.data_ptr(), n1,
+                                                 dx.data_ptr(), k1, rows, n2, n1, k1, sp), "mlp fused bwd")
+
+    def two_bwd():
+        ham.zero_()
+        ops.check(lib.pgnn_linear_bwd_data_2p(dy.data_ptr(), n2, None, p2t.data_ptr(), hid.data_ptr(), n1, dhid.data_ptr(), n1, rows, n1, n2,
+                                              ham.data_ptr(), sp), "bwd 1")
+        ops.check(lib.pgnn_linear_bwd_data_2p(dhid.data_ptr(), n1, ham.data_ptr(), p1t.data_ptr(), None, 0, dx.data_ptr(), k1, rows, k1, n1, None,
+                                              sp), "bwd 2")
+
+    two_fwd()
+    flops = 2.0 * rows * (k1 * n1 + n1 * n2)
+    out = {"kernel": "k_mlp2p_fused<10,19> (pgnn_mlp_fwd_2p_fused / pgnn_mlp_bwd_data_2p_fused; H has the bits of the two products', "
+                     "tests/test_gpu_ops.py::test_fused_mlp_against_float64_and_the_two_products)", "rows": rows,
+           "unit": "TFLOP/s (fp32-equivalent, both products of the pair)", "peak": round(planes_peak, 1)}
+    for tag, f_fused, f_two in (("forward", fused_fwd, two_fwd), ("backward_data", fused_bwd, two_bwd)):
+        msf, perf, it = steady_state_ms(f_fused, iters=20)
+        mst, pert, _ = steady_state_ms(f_two, iters=20)
+        tf = flops / (msf * 1e-3) / 1e12
+        out[tag] = {"ms_per_launch": round(msf, 4), "ms_per_launch_std": round(float(perf.std()), 4), "launches_timed": it,
+                    "achieved": round(tf, 2), "frac": round(tf / planes_peak, 4), "two_products_ms": round(mst, 4),
+                    "speedup_vs_two_products": round(mst / msf, 3)}
+    out["forward"]["mfma_util"] = MFMA_UTIL_PMC["k_mlp2p_fused fwd (262144 rows)"]
+    out["backward_data"]["mfma_util"] = MFMA_UTIL_PMC["k_mlp2p_fused bwd (262144 rows)"]
+    out["mfma_util_source"] = MFMA_UTIL_SOURCE
+    out["ablation"] = "profiles/r05/mlp_fused_ablation.txt"
+    return out
 
 
 def roofline_mlp_planes(dev, rows, what):
@@ -560,6 +634,11 @@ def roofline_mlp_planes(dev, rows, what):
         tf = flops / (ms * 1e-3) / 1e12
         out[tag] = {"achieved": round(tf, 2), "frac": round(tf / planes_peak, 4), "frac_of_fp32_mfma_peak": round(tf / MFMA_F32_PEAK_TF, 4),
                     "ms_per_launch": round(ms, 5), "ms_per_launch_std": round(float(per.std()), 5), "launches_timed": iters}
+    if rows < 16384:  # (the tiled kernel's counters were taken at the 256-graph batch)
+        out["300_to_600"]["mfma_util"] = MFMA_UTIL_PMC["k_gemm2pw<112,160> (6740 rows)"]
+        out["600_to_300"]["mfma_util"] = MFMA_UTIL_PMC["k_gemm2pw<64,160> (6740 rows)"]
+        out["weight_gradient_pair_mfma_util"] = MFMA_UTIL_PMC["k_gemm3_pair<64,160> (6740 rows)"]
+        out["mfma_util_source"] = MFMA_UTIL_SOURCE
     return out
 
 
@@ -1022,7 +1101,9 @@ def _run():
                        "direct_grads": True, "settle_steps_before_warmup": max(args.settle_steps, 0),
                        "mlp_products": "fp32 operands as two fp16 planes under a power-of-two scale per row (22 significant bits per operand), "
                                        "three v_mfma_f32_16x16x32_f16 per accumulator, fp32 accumulate; weight gradients on three bf16 planes "
-                                       "(24 bits); error against float64 held to the fp32-MFMA kernel's bar in tests/test_gpu_ops.py"},
+                                       "(24 bits); error against float64 held to the fp32-MFMA kernel's bar in tests/test_gpu_ops.py; from 32 768 rows on "
+                                       "(the large_batch legs, not this batch) both products of an mlp run as ONE launch per direction "
+                                       "(k_mlp2p_fused: same bits)"},
             "comm": comm,
         }
         if value_windows is not None:
