@@ -414,3 +414,36 @@ def test_gradient_milestone_is_keyed_on_the_network_and_refuses_accumulation():
         lib.pgnn_stack_bwd_milestone_arm(-1, None)
         ops.set_direct_grads(prev)
         torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_bench_two_ranks_under_torchrun(overlap, tmp_path):
+    """bench.py launched exactly as the driver launches it for N = 2 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2
+    --master-addr 127.0.0.1 ...`), both ranks on the one GPU of the box over gloo (PGNN_DP_BACKEND; RCCL refuses two ranks on a
+    device), as shipped and with the overlapped all-reduce (PGNN_DP_OVERLAP=1): rank 0 prints ONE JSON line whose aggregate is the
+    two ranks' edges over the slower rank's time, `comm` names the world, every rank's own time and -- with the overlap -- that every
+    timed step's head collective waited for the backward's milestone events, not for the whole backward."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PGNN_DP_BACKEND="gloo", PGNN_DP_OVERLAP=overlap, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3",
+           "--settle-steps", "10", "--no-roofline", "--no-extra-configs", "--no-cpu-baseline", "--no-hipgraph", "--no-loader",
+           "--sweep-graphs="]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=420)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["steps"] == 12 and b["warmup"] == 3 and b["scaling"] == "weak" and b["value"] > 0
+    comm = b["comm"]
+    assert comm["world"] == 2 and len(comm["ms_per_step_by_rank"]) == 2
+    assert abs(max(comm["ms_per_step_by_rank"]) - b["ms_per_step"]) < 1e-3 * b["ms_per_step"] + 1e-3  # MAX over ranks
+    assert abs(b["value"] - 2 * b["config"]["edges_per_gpu"] / (b["ms_per_step"] * 1e-3)) < 0.2 * b["value"]  # ~ both shards (seeds differ)
+    if overlap == "1":
+        ov = comm["overlap"]
+        assert ov["from_layer"] == 2 and ov["steps_behind_the_milestone"] >= 12 and ov["head_bytes"] > 0
