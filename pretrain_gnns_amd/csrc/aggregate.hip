@@ -818,9 +818,13 @@ int launch_aggregate_dma(const float* x, int64_t ldx, const int32_t* ptr, const 
   const int nrow = (int)ceil_div(kDmaG * (dim / 4), kWave);
   const bool small_ld = ldx * 4 * kDmaG < (1ll << 31);
 #define PGNN_DMA_ARGS x, ldx, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st
+#ifdef PGNN_AB  // ring depths 1 and 3 (measured behind 2): A/B builds only
   if (env_int("PGNN_DMA_P", 2) == 1) return launch_aggregate_dma_p<TABLE, 1, 0>(PGNN_DMA_ARGS);
+#endif
   if (!small_ld || env_int("PGNN_DMA_GENERIC", 0)) return launch_aggregate_dma_p<TABLE, 2, 0>(PGNN_DMA_ARGS);
+#ifdef PGNN_AB
   if (nrow == 10 && env_int("PGNN_DMA_P", 2) == 3) return launch_aggregate_dma_p<TABLE, 3, 10>(PGNN_DMA_ARGS);
+#endif
   // Streaming hint.  When x and out together exceed the 256 MB Infinity Cache nothing this launch touches can be
   // re-used from cache by a later one: rows are then loaded and stored non-temporally (POL 3), which measured
   // 229.8 -> 214.3 us on the roofline batch (tools/agg_sweep.py; nt loads alone 224.9, nt stores alone 217.9, loader
@@ -833,7 +837,8 @@ int launch_aggregate_dma(const float* x, int64_t ldx, const int32_t* ptr, const 
   }
   if (nrow == 10) {
     if (pol == 3) return launch_aggregate_dma_p<TABLE, 2, 10, false, 3>(PGNN_DMA_ARGS);
-    if (TABLE) {  // further A/B variants and the instrumented build: production instantiation only
+#ifdef PGNN_AB
+    if (TABLE) {  // further A/B variants and the instrumented build (A/B builds only): production instantiation only
       switch (pol) {
         case 1: return launch_aggregate_dma_p<TABLE, 2, 10, false, 1>(PGNN_DMA_ARGS);
         case 2: return launch_aggregate_dma_p<TABLE, 2, 10, false, 2>(PGNN_DMA_ARGS);
@@ -843,6 +848,7 @@ int launch_aggregate_dma(const float* x, int64_t ldx, const int32_t* ptr, const 
         default: break;
       }
     }
+#endif
   }
   switch (nrow) {
     case 10: return launch_aggregate_dma_p<TABLE, 2, 10>(PGNN_DMA_ARGS);  // D = 300 (the reference's emb_dim)

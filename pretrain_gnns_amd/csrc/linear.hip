@@ -1229,11 +1229,15 @@ int launch_gemm(const GemmArgs& p, int nsplit, hipStream_t st) {
   // faster than the plain 2-stage loop -- DMA issue, fragment reads and the barrier are *issue-time*
   // costs that both waves of a SIMD pay in lockstep in front of their MFMA burst -- so the lever is
   // fewer barriers per FLOP, i.e. a deeper k-step.
+  // (the deeper / ring variants -- PGNN_GEMM_KS = 2, 11, 12 -- measured level or behind and exist in A/B builds only: they were
+  //  three quarters of this file's 224 k_gemm instances, 1.8 MB of device code)
+#ifdef PGNN_AB
   const int ks = env_ks(kDefaultKS);
   if (ks == 11) return launch_gemm_s<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, 11>(p, nsplit, st);
   if (ks == 12) return launch_gemm_s<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, 12>(p, nsplit, st);
   if (ks >= 2) return launch_gemm_s<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, 2>(p, nsplit, st);
-  return launch_gemm_s<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, 1>(p, nsplit, st);
+#endif
+  return launch_gemm_s<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, kDefaultKS>(p, nsplit, st);
 }
 
 // Tile configurations (all 4 waves, BK = 16).  N = 300 / 600 are 18.75 / 37.5 MFMA blocks wide, so the
@@ -1280,12 +1284,18 @@ template <bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES = false>
 int launch_cfg(TileCfg c, const GemmArgs& p, int nsplit, hipStream_t st) {
   switch (c) {
     case T128x304: return launch_gemm<128, 304, 4, 1, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
+#ifdef PGNN_AB  // tiles no default path picks (PGNN_GEMM_CFG / PGNN_GEMM_WIDE reach them): A/B builds only -- the default build falls to 64x160 on 8 waves
     case T64x160: return launch_gemm<64, 160, 2, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
     case T128x160: return launch_gemm<128, 160, 2, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
+    case T256x304: return launch_gemm<256, 304, 8, 1, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
+#else
+    case T64x160:
+    case T128x160:
+    case T256x304: return launch_gemm<64, 160, 4, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
+#endif
     case T128x128: return launch_gemm<128, 128, 2, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
     case T64x160w8: return launch_gemm<64, 160, 4, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
     case T320x160: return launch_gemm<320, 160, 4, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
-    case T256x304: return launch_gemm<256, 304, 8, 1, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
     default: return launch_gemm<64, 64, 2, 2, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, nsplit, st);
   }
 }
@@ -1463,12 +1473,19 @@ int pgnn_debug_gemm3w_profile(const float* x, int64_t ldx, const void* wplanes, 
   p.Bp = static_cast<const unsigned short*>(wplanes); p.ldbp = ceil_div(k, 32) * 32; p.bplane = n * p.ldbp;
   p.M = (int)m; p.N = (int)n; p.K = (int)k; p.bias = bias; p.relu = 1; p.kchunk = (int)k;
   p.dbg = reinterpret_cast<unsigned long long*>(buffer);
+#ifdef PGNN_AB  // the instrumented instances exist in A/B builds only (python -m pretrain_gnns_amd.build --ab)
   hipStream_t st = (hipStream_t)stream;
   switch (cfg) {
     case 0: return launch_gemm3w_s<128, 160, 8, 1, 3, EPI_BIAS, false, true>(p, st);
     case 4: return launch_gemm3w_s<64, 80, 4, 1, 3, EPI_BIAS, false, true>(p, st);
     default: return launch_gemm3w_s<64, 160, 4, 2, 4, EPI_BIAS, false, true>(p, st);
   }
+#else
+  (void)cfg;
+  (void)stream;
+  set_error("pgnn_debug_gemm3w_profile: instrumented kernels are compiled into A/B builds only (-DPGNN_AB)");
+  return PGNN_ERR_ARG;
+#endif
 }
 
 int pgnn_linear_bwd_data_wp(const float* dy, int64_t lddy, const void* wtplanes, const float* relu_out, int64_t ldr, float* dx,
