@@ -143,6 +143,30 @@ int mlp_fwd_2p_fused(const float* x, int64_t ldx, const void* planes1, const flo
                      int64_t ldh, float* y, int64_t ldy, int64_t m, int64_t k1, int64_t n1, int64_t n2, float* colstat, hipStream_t st);
 int mlp_bwd_data_2p_fused(const float* dy, int64_t lddy, const void* planes2t, const float* relu_out, int64_t ldr, const void* planes1t,
                           float* dhid, int64_t lddh, float* dx, int64_t lddx, int64_t m, int64_t k1, int64_t n1, int64_t n2, hipStream_t st);
+// (linear.hip) pgnn_linear_bwd_weight_pair that can also leave g_out [n_b][12] = dy_b^T . cfeat12 ([m][12]: twelve more columns of
+// product b's second operand, riding in the column padding of its last tile) where its one-launch path runs -- *g_done says whether it
+// did; linear_bwd_weight_pair_ext_ok: whether it would.  The chem GIN stack's bond-table gradients: demb = (cfeat^T dhid) W1
+// (bond_tables_from_g: one launch for up to kMaxBondJobs layers) instead of a pass over dagg per layer; pad_rowfeat12: cfeat [n][kc] ->
+// [n][12], zero-filled.
+bool linear_bwd_weight_pair_ext_ok(int64_t m, int64_t k_a, int64_t n_a, int64_t k_b, int64_t n_b);
+int linear_bwd_weight_pair_ext(const float* dy_a, int64_t lddy_a, const float* x_a, int64_t ldx_a, float* dw_a, float* db_a, int64_t k_a,
+                               int64_t n_a, const float* dy_b, int64_t lddy_b, const float* x_b, int64_t ldx_b, float* dw_b, float* db_b,
+                               int64_t k_b, int64_t n_b, int64_t m, void* ws, size_t ws_bytes, hipStream_t stream, const float* cfeat12,
+                               float* g_out, bool* g_done);
+int pad_rowfeat12(const float* cfeat, int64_t kc, float* out12, int64_t n, hipStream_t st);
+constexpr int kMaxBondJobs = 16;
+struct BondTableJob {
+  const float* g;  // [rows][12]
+  const float* w;  // [rows][ldw]: W1
+  int64_t ldw;
+  float* demb;     // [kc][ldd]
+  int64_t ldd;
+};
+int bond_tables_from_g(const BondTableJob* jobs, int count, int64_t rows, int64_t dim, int64_t kc, hipStream_t st);
+// (layer.hip) the stop event of the NEXT tiled two-plane product launched by this host thread (hipExtLaunchKernelGGL): the launch
+// takes it; whoever set it checks afterwards whether it is still there (another kernel ran: record the event the ordinary way)
+void set_next_launch_stop_event(hipEvent_t ev);
+hipEvent_t take_next_launch_stop_event();
 // (tile.hip) pgnn_neighbor_sum_tiled whose result is zeroed where mask[i, c] <= 0 (the ReLU between two layers, backward), when
 // the launch that runs can do it: *mask_applied says whether it did (the pipelined kernel of large batches and the untiled
 // fall-back cannot -- the caller masks in a pass of its own then)

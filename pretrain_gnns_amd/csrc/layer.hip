@@ -11,6 +11,18 @@
 
 using namespace pgnn;
 
+namespace pgnn {
+namespace {
+thread_local hipEvent_t t_next_stop_event = nullptr;
+}
+void set_next_launch_stop_event(hipEvent_t ev) { t_next_stop_event = ev; }
+hipEvent_t take_next_launch_stop_event() {
+  hipEvent_t ev = t_next_stop_event;
+  t_next_stop_event = nullptr;
+  return ev;
+}
+}  // namespace pgnn
+
 namespace {
 // Side stream for the backward's independent branches.  At ~6.8k rows one GEMM only gives each CU ~1.7
 // tiles, so the weight-gradient product (needs dz/dhid + saved activations) runs concurrently with the
@@ -34,11 +46,14 @@ Side* side_for_current_device() {
     // and made HIP-graph replay of the step 50 % slower (2.8 vs 1.8 ms, measured)
     // (round 4 re-measured it with the caller's stream the longer one: lowest priority 0.994-0.997 against 0.990-0.993 ms, no effect)
     if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    // PGNN_EVENT_DEVICE_RELEASE=1: the fork / lag events release to DEVICE scope only (both streams are this device's; the join, which
+    // the caller's later host reads sit behind, keeps the default)
+    const unsigned fl = hipEventDisableTiming | (env_knob("PGNN_EVENT_DEVICE_RELEASE", 0) != 0 ? hipEventReleaseToDevice : 0u);
     for (auto& e : s.fork)
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+      if (hipEventCreateWithFlags(&e, fl) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
     for (auto& e : s.lag)
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+      if (hipEventCreateWithFlags(&e, fl) != hipSuccess) return nullptr;
     s.ok = true;
   }
   return &s;
@@ -80,6 +95,10 @@ int milestone_record(int l, const void* network, hipStream_t main, hipStream_t a
   PGNN_HIP(hipEventRecord(m->ev[1], aux));
   m->recorded = true;
   return PGNN_OK;
+}
+inline bool milestone_armed() {
+  GradMilestone* m = milestone_of_current_device();
+  return m && m->layer >= 0;  // (unlocked peek, as in milestone_record)
 }
 // backward-data on pre-transposed weights (both operands k-contiguous): 0 = never, 2 = always, 1 (default) = from 16 384 rows,
 // where the k-contiguous form pulls ahead of pgnn_linear_bwd_data's transpose-read form (44 / 45 us against 54 / 56 at 16 384
@@ -123,6 +142,11 @@ constexpr int64_t kFusedMinRows = 32768;
 inline bool mlp_fused(int64_t n, int64_t d_in, int64_t d_hid, int64_t d_out) {
   const int v = env_knob("PGNN_MLP_FUSED", 1);
   return v != 0 && two_planes() && (v >= 2 || n >= kFusedMinRows) && mlp_fused_supported(n, d_in, d_hid, d_out);
+}
+// the chem GIN stack's bond-table gradients as twelve more columns of its dW1 products (linear.hip, linear_bwd_weight_pair_ext):
+// cfeat [n][9] padded to [n][12] once per backward + G = dhid^T cfeat [2 dim][12] per layer (PGNN_BOND_IN_DW=0: a pass over dagg per layer)
+inline size_t bond_ws_bytes(int64_t n, int64_t dim, int64_t num_layer) {
+  return align_up((size_t)n * 12 * 4, 256) + (size_t)std::min<int64_t>(num_layer, kMaxBondJobs) * align_up((size_t)2 * dim * 12 * 4, 256) + 256;
 }
 inline size_t amax_words(int64_t n) { return align_up((size_t)n * 4, 256) / 4; }  // one row-maximum vector, in words
 // planes of W1 / W2 (transpose = 0) or W1^T / W2^T (1) of every layer: p1[l], p2[l] carved from `base`
@@ -352,7 +376,8 @@ size_t pgnn_chem_gin_stack_workspace_bytes(int64_t n, int64_t dim, int64_t rows1
   return 2 * op_ws_bytes(n, dim) + sets * 5 * nd + wt + 2 * align_up((size_t)n * 4, 256) +
          2 * align_up((stack_keys(rows1, rows2) + 1) * 4, 256) + 256 + stack_group_ws(n, rows1, rows2) +
          stack_segsum_ws(n, dim, rows1, rows2) + stack_pair_sums(dim, rows1, rows2) + 256 +
-         ((size_t)std::min<int64_t>(num_layer, kMaxPlaneLayers) + 2) * amax_words(n) * 4;  // (+ the maxima of agg / dz: one vector each)
+         ((size_t)std::min<int64_t>(num_layer, kMaxPlaneLayers) + 2) * amax_words(n) * 4 +  // (+ the maxima of agg / dz: one vector each)
+         bond_ws_bytes(n, dim, num_layer);  // the bond-table gradients out of the dW1 products: cfeat padded to 12 floats a row, G per layer
 }
 
 int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t rows1, const float* xemb2,
@@ -572,6 +597,18 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   uint32_t* dhid_amax = (two_planes() && num_layer <= kMaxPlaneLayers) ? cv.take<uint32_t>((size_t)num_layer * amax_words(n)) : nullptr;
   // ... and the BatchNorm backward's elementwise pass those of dz (one vector, rewritten by every layer: plain stores)
   uint32_t* const dz_amax = (dhid_amax && env_knob("PGNN_PRODUCER_AMAX", 1) != 0) ? cv.take<uint32_t>(amax_words(n)) : nullptr;
+  // bond-table gradients out of the dW1 products (see bond_ws_bytes).  The amax vectors above are carved conditionally, so these
+  // come from the END of the workspace, whose size does not depend on any knob.
+  const bool bond_in_dw = cfeat && num_layer <= kMaxBondJobs && linear_bwd_weight_pair_ext_ok(n, 2 * dim, dim, dim, 2 * dim);
+  float* cfeat12 = nullptr;
+  float* gbond[kMaxBondJobs];
+  if (bond_in_dw) {
+    Carver bv(static_cast<char*>(ws) + pgnn_chem_gin_stack_workspace_bytes(n, dim, rows1, rows2, num_layer) - bond_ws_bytes(n, dim, num_layer));
+    cfeat12 = bv.take<float>((size_t)n * 12);
+    for (int l = 0; l < num_layer; ++l) gbond[l] = bv.take<float>((size_t)2 * dim * 12);
+  }
+  BondTableJob bond_jobs[kMaxBondJobs];
+  int n_bond_jobs = 0;
 
   hipStream_t main = (hipStream_t)stream;
   Side* sd = (use_side_stream() && n <= kSideMaxRows && num_layer <= kMaxSets) ? side_for_current_device() : nullptr;
@@ -626,8 +663,11 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
       return rc;
     PGNN_HIP(hipEventRecord(sd->fork[3], aux));
   }
+  // (behind everything the caller's stream waits for; first read by the top layer's weight gradients, on aux too)
+  if (bond_in_dw && (rc = pad_rowfeat12(cfeat, 9, cfeat12, n, aux))) return rc;
   const bool tr = ntr > 0 && use_transposed_weights(n);
   const bool fused_mlp = wp && mlp_fused(n, dim, 2 * dim, dim);
+  const bool fork_via_launch = env_knob("PGNN_FORK_VIA_LAUNCH", 1) != 0;
 
   const float* g = dy;
   int64_t ldg = lddy;
@@ -653,6 +693,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
                        drop_p, drop_seed + (uint64_t)l, n, dim, op, opb, main);
     if (rc) return rc;
     sums_ready = false;
+    bool fork_recorded = false;
     if (wait_fork2) {
       PGNN_HIP(hipStreamWaitEvent(main, sd->fork[2], 0));
       wait_fork2 = false;
@@ -663,7 +704,10 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     } else if (wp) {
       uint32_t* dam = dhid_amax ? dhid_amax + (size_t)l * amax_words(n) : nullptr;
       if ((rc = stack_bwd_data_wp(dz[b], dim, wp2[l], hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main, dz_has_amax ? dz_amax : nullptr, dam))) return rc;
+      // PGNN_FORK_VIA_LAUNCH=1: fork[1] is the completion of this product's own dispatch instead of a marker behind it
+      if (sd && fork_via_launch) set_next_launch_stop_event(sd->fork[1]);
       if ((rc = stack_bwd_data_wp(dhid[b], 2 * dim, wp1[l], nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main, dam))) return rc;
+      fork_recorded = sd && fork_via_launch && take_next_launch_stop_event() == nullptr;  // (taken by the launch; else another kernel ran)
     } else if (tr && q < ntr) {
       if ((rc = pgnn_linear_bwd_data_t(dz[b], dim, w2t[q], hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main))) return rc;
       if ((rc = pgnn_linear_bwd_data_t(dhid[b], 2 * dim, w1t[q], nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main))) return rc;
@@ -676,7 +720,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     // (round 4: recording it EARLIER, between the two backward-data products -- the weight gradients need dz and dhid, not dagg -- with
     // the edge-table gradient deferred to the head of the next layer's side work: bit-identical, 1.001-1.010 against 0.997-1.001 ms,
     // profiles/r04/fork_early_ab.txt; not kept)
-    if (sd) PGNN_HIP(hipEventRecord(sd->fork[1], main));
+    if (sd && !fork_recorded) PGNN_HIP(hipEventRecord(sd->fork[1], main));
     // the bottom layer's edge-table gradient stays on the caller's stream: the side stream is the longer of the two there
     // (two weight-gradient products behind the data products), and the caller's stream only has the embedding gradients left
     const bool demb_on_main = sd && l == 0;
@@ -697,13 +741,25 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     };
     if (sd) {
       if ((rc = aggregate_t())) return rc;
-      if (demb_on_main && (rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, op, opb, main))) return rc;
+      if (demb_on_main && !bond_in_dw && (rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, op, opb, main))) return rc;
       PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[1], 0));
     }
-    if ((rc = pgnn_linear_bwd_weight_pair(dz[b], dim, hd, 2 * dim, p.dw2, p.db2, 2 * dim, dim, dhid[b], 2 * dim, agg, dim, p.dw1, p.db1,
-                                          dim, 2 * dim, n, aux_ws, opb, aux)))  // both products, one fold of the split-K partials
+    // both products, one fold of the split-K partials; with bond_in_dw the dW1 product carries G = dhid^T cfeat along (twelve columns
+    // of its tile padding) and the bond-table gradient demb = G^T W1 needs no pass over dagg: one launch for all layers behind the loop
+    bool g_done = false;
+    if ((rc = linear_bwd_weight_pair_ext(dz[b], dim, hd, 2 * dim, p.dw2, p.db2, 2 * dim, dim, dhid[b], 2 * dim, agg, dim, p.dw1, p.db1, dim,
+                                         2 * dim, n, aux_ws, opb, aux, bond_in_dw ? cfeat12 : nullptr, bond_in_dw ? gbond[l] : nullptr, &g_done)))
       return rc;
-    if (!demb_on_main && (rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, aux_ws, opb, aux))) return rc;
+    if (g_done) {
+      bond_jobs[n_bond_jobs++] = BondTableJob{gbond[l], p.w1, dim, p.demb, dim};
+      if (milestone_armed()) {  // a communication stream may be waiting for this layer's gradients: no deferral
+        if ((rc = bond_tables_from_g(bond_jobs + n_bond_jobs - 1, 1, 2 * dim, dim, 9, aux))) return rc;
+        --n_bond_jobs;
+      }
+    } else if (bond_in_dw && demb_on_main) {  // (cannot happen: linear_bwd_weight_pair_ext_ok said the one-launch path runs)
+      if ((rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, aux_ws, opb, aux))) return rc;
+    }
+    if (!g_done && !demb_on_main && (rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, aux_ws, opb, aux))) return rc;
     if (sd && !per_layer && l >= 2) PGNN_HIP(hipEventRecord(sd->lag[b], aux));  // awaited by layer l-2 only
     if (!sd && (rc = aggregate_t())) return rc;
     // every parameter gradient of layers >= l is enqueued now (weights, biases and edge tables on `aux`, the BatchNorm's on `main`;
@@ -718,6 +774,8 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   if (sd) PGNN_HIP(hipStreamWaitEvent(main, sd->fork[3], 0));  // the grouping (finished long ago)
   rc = embed_tables_bwd(g, x_idx, n, dim, rows1, rows2, dxemb1, dxemb2, gptr[0], gperm[0], gptr[1], gperm[1], gstatus, grp_ws,
                         grp_b, seg_ws, seg_b, pair_sums, group_early, main);
+  if (rc) return rc;
+  if (n_bond_jobs > 0) rc = bond_tables_from_g(bond_jobs, n_bond_jobs, 2 * dim, dim, 9, aux);  // every layer's demb = G^T W1, one launch
   if (sd) {  // join: nothing of this call is in flight on the side stream once the caller's stream passes this point
     PGNN_HIP(hipEventRecord(sd->join, aux));
     PGNN_HIP(hipStreamWaitEvent(main, sd->join, 0));

@@ -21,6 +21,8 @@
 
 #include <type_traits>
 
+#include <hip/hip_ext.h>
+
 #include "bn_fold.h"
 #include "common.h"
 #include "two_plane.h"
@@ -52,6 +54,8 @@ struct GemmArgs {
   const uint32_t* a_amax;    // k_gemm2pw, optional: [M] bit patterns of max |A[m, :]| (from the producer of A); NULL = taken in the kernel
   uint32_t* c_amax;          // k_gemm2pw, optional: [M] words, zero before the launch: receives max |C[m, :]| (atomic max of the tiles)
   BnFwdFold bnf;             // k_gemm2pw, EPI_BIAS, bnf.n > 0: the statistics of the BatchNorm behind C, folded in this launch (bn_fold.h)
+  const float* F;            // gemm3_body<EXTRA>, optional: [K][12] more rows of Bop behind the ones column (Bop columns N + 4 .. N + 15)
+  float* extra;              //                    their products [M][12] (same split stride as C)
 };
 
 enum { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_MASK = 2 };
@@ -404,8 +408,11 @@ struct KMajorTile {
 // One kernel, four operand-layout instantiations: forward / backward-data on transposed weights (both k-contiguous),
 // backward-data (dy k-contiguous, W row-contiguous), backward-weight (both row-contiguous, split over k = rows, optional
 // ones column for the bias gradient).
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES>
+// EXTRA (row-contiguous B with ONES only): twelve more columns of Bop behind the ones column, from p.F [K][12] -- they ride in the
+// column padding of the last tile (N + 16 <= tiles_n BN) and their products leave through p.extra [M][12]; see linear_bwd_weight_pair_ext
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, bool EXTRA = false>
 __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x, const int grid_x) {
+  static_assert(!EXTRA || (ONES && !B_KMAJOR), "EXTRA rides behind the ones column of a row-contiguous B");
   constexpr int BK = 32;
   constexpr int NW = WAVES_M * WAVES_N, T = 64 * NW;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -433,7 +440,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
   const float* srcA[NA];
   const float* srcB[NB];
   int offA[NA], offB[NB], kofA[NA], kofB[NB];
-  bool okA[NA], okB[NB], oneB[NB];
+  bool okA[NA], okB[NB], oneB[NB], extB[NB];
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     const int u = min(tid + j * T, UA - 1);  // (a clamped duplicate rewrites the same LDS bytes with the same values)
@@ -455,6 +462,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
   for (int j = 0; j < NB; ++j) {
     const int u = min(tid + j * T, UB - 1);
     oneB[j] = false;
+    extB[j] = false;
     if (B_KMAJOR) {
       const int row = u >> 3, kq = u & 7;
       okB[j] = n0 + row < p.N;
@@ -467,6 +475,10 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
       oneB[j] = ONES && n0 + 4 * cq == p.N;  // the ones column: C[m][N] = sum_k Aop(m, k) = the bias gradient
       kofB[j] = kr;
       srcB[j] = p.B + (int64_t)(kbeg + kr) * p.ldb + n0 + 4 * cq;
+      if constexpr (EXTRA) {
+        extB[j] = p.F != nullptr && n0 + 4 * cq >= p.N + 4 && n0 + 4 * cq < p.N + 16;
+        if (extB[j]) srcB[j] = p.F + (int64_t)(kbeg + kr) * 12 + (n0 + 4 * cq - p.N - 4);
+      }
       offB[j] = RowMajorTile<BN>::offset(kr, 4 * cq);
     }
   }
@@ -484,6 +496,9 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
       const bool kok = k0 + kofB[j] < kend;
       const float* g = (okB[j] && kok) ? srcB[j] + (B_KMAJOR ? (int64_t)it * BK : (int64_t)it * BK * p.ldb)
                                        : reinterpret_cast<const float*>((ONES && oneB[j] && kok) ? g_ones_page : g_zero_page);
+      if constexpr (EXTRA) {
+        if (extB[j] && kok) g = srcB[j] + (int64_t)it * BK * 12;
+      }
       rb[j] = *reinterpret_cast<const float4*>(g);
     }
   };
@@ -575,6 +590,21 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
   }
   if constexpr (EPI == EPI_MASK) gemm_epilogue_pre<EPI, ONES, MI, NI, MI>(p, acc, m0 + wm0, n0 + wn0, lane, mk);
   else gemm_epilogue<EPI, ONES, MI, NI>(p, acc, m0 + wm0, n0 + wn0, lane);
+  if constexpr (EXTRA) {  // Bop columns N + 4 .. N + 15 (the epilogue above skips everything beyond the ones column)
+    if (p.F != nullptr) {
+      float* gx = p.extra + (int64_t)blockIdx.y * p.split_stride;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn0 + j * 16 + fk * 4;
+        if (n < p.N + 4 || n >= p.N + 16) continue;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int m = m0 + wm0 + i * 16 + fr;
+          if (m < p.M) *reinterpret_cast<float4*>(gx + (int64_t)m * 12 + (n - p.N - 4)) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+      }
+    }
+  }
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES>
@@ -588,11 +618,11 @@ struct GemmArgs2 {
   GemmArgs a[2];
   int tiles[2];
 };
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, bool EXTRA = false>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3_pair(GemmArgs2 q) {
   const int z = blockIdx.z;
   if ((int)blockIdx.x >= q.tiles[z]) return;
-  gemm3_body<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES>(q.a[z], blockIdx.x, q.tiles[z]);
+  gemm3_body<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, EXTRA>(q.a[z], blockIdx.x, q.tiles[z]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1525,6 +1555,8 @@ struct ReduceJob {
   int64_t n4a;
   float* db;
   int64_t n4b;
+  float* g;     // the [n][12] products of the twelve extra columns (linear_bwd_weight_pair_ext), behind db in every partial
+  int64_t n4c;
 };
 struct ReduceJobs {
   ReduceJob j[2];
@@ -1532,7 +1564,7 @@ struct ReduceJobs {
 // the same fold as k_splitk_reduce for two weight gradients in one launch (blockIdx.y picks the job)
 __global__ void __launch_bounds__(256) k_splitk_reduce_jobs(ReduceJobs jobs) {
   const ReduceJob r = jobs.j[blockIdx.y];
-  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < r.n4a + r.n4b; q += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < r.n4a + r.n4b + r.n4c; q += (int64_t)gridDim.x * blockDim.x) {
     float4 s = reinterpret_cast<const float4*>(r.partial)[q];
     int z = 1;
     for (; z + 4 <= r.used; z += 4) {  // four independent loads in flight, added in split order
@@ -1544,7 +1576,76 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_jobs(ReduceJobs jobs) {
     }
     for (; z < r.used; ++z) s = f4_add(s, reinterpret_cast<const float4*>(r.partial + z * r.stride)[q]);
     if (q < r.n4a) reinterpret_cast<float4*>(r.dw)[q] = s;
-    else reinterpret_cast<float4*>(r.db)[q - r.n4a] = s;
+    else if (q < r.n4a + r.n4b) reinterpret_cast<float4*>(r.db)[q - r.n4a] = s;
+    else reinterpret_cast<float4*>(r.g)[q - r.n4a - r.n4b] = s;
+  }
+}
+
+// ---- the bond-table gradient of a chem GIN layer without a pass of its own (round 5) ------------------------------------------
+// chem/model.py:37-52 under autograd: demb [9, D] = cfeat^T [9, n] . dagg [n, D] with dagg = dhid . W1, i.e. (cfeat^T . dhid) . W1.
+// G = dhid^T . cfeat [2D, 9] is twelve more columns of the dW1 product (dhid^T . [agg | 1 | cfeat]): they sit in the column padding of
+// its last tile (300 + 4 + 12 <= 320), so the launch that runs anyway computes them for nothing, the fold of the split-K partials
+// folds them too, and what is left is [9, 2D] x [2D, D] -- 3 MFLOP, one small launch for every layer of a network together.
+// cfeat comes padded to 12 floats a row (float4 staging units): k_pad_rowfeat12, once per backward.
+__global__ void __launch_bounds__(256) k_pad_rowfeat12(const float* __restrict__ cfeat, int kc, float* __restrict__ out, int64_t n) {
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n * 3; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = q / 3;
+    const int c = (int)(q - i * 3) * 4;
+    const float* src = cfeat + i * kc;
+    float4 v;
+    v.x = c + 0 < kc ? src[c + 0] : 0.f;
+    v.y = c + 1 < kc ? src[c + 1] : 0.f;
+    v.z = c + 2 < kc ? src[c + 2] : 0.f;
+    v.w = c + 3 < kc ? src[c + 3] : 0.f;
+    reinterpret_cast<float4*>(out)[q] = v;
+  }
+}
+struct BondJobs {
+  BondTableJob j[kMaxBondJobs];
+};
+// demb[t][c] = sum_r G[r][t] W1[r][c], float64 accumulators (the pass it replaces folds its block partials in float64 too).  A block:
+// 64 columns x four of the twelve t; sixteen waves, each over every sixteenth row with eight rows' loads in flight (a loop of one
+// load and its use per trip pays a full L2 round trip per row: 30 us on the backward's tail in the first version), folded through
+// LDS in wave order.
+constexpr int kBondWaves = 16;
+__global__ void __launch_bounds__(64 * kBondWaves) k_bond_tables_from_g(BondJobs jobs, int rows, int dim, int kc) {
+  const BondTableJob jb = jobs.j[blockIdx.y];
+  __shared__ double red[kBondWaves][4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int t0 = 4 * blockIdx.z;
+  const int c = blockIdx.x * 64 + lane, cc = min(c, dim - 1);
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  constexpr int U = 8;
+  for (int r0 = w; r0 < rows; r0 += kBondWaves * U) {
+    float wv[U];
+    float4 gv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = min(r0 + kBondWaves * u, rows - 1);
+      wv[u] = jb.w[(int64_t)r * jb.ldw + cc];
+      gv[u] = *reinterpret_cast<const float4*>(jb.g + (int64_t)r * 12 + t0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (r0 + kBondWaves * u < rows) {
+        const double wd = (double)wv[u];
+        acc[0] += (double)gv[u].x * wd;
+        acc[1] += (double)gv[u].y * wd;
+        acc[2] += (double)gv[u].z * wd;
+        acc[3] += (double)gv[u].w * wd;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[w][k][lane] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < 4 * 64) {
+    const int k = threadIdx.x >> 6, l = threadIdx.x & 63;
+    double s = red[0][k][l];
+#pragma unroll
+    for (int ww = 1; ww < kBondWaves; ++ww) s += red[ww][k][l];
+    const int col = blockIdx.x * 64 + l, t = t0 + k;
+    if (col < dim && t < kc) jb.demb[(int64_t)t * jb.ldd + col] = (float)s;
   }
 }
 
@@ -1603,6 +1704,49 @@ int pgnn_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_
 int pgnn_linear_bwd_weight_pair(const float* dy_a, int64_t lddy_a, const float* x_a, int64_t ldx_a, float* dw_a, float* db_a, int64_t k_a,
                                 int64_t n_a, const float* dy_b, int64_t lddy_b, const float* x_b, int64_t ldx_b, float* dw_b, float* db_b,
                                 int64_t k_b, int64_t n_b, int64_t m, void* ws, size_t ws_bytes, pgnn_stream stream) {
+  return pgnn::linear_bwd_weight_pair_ext(dy_a, lddy_a, x_a, ldx_a, dw_a, db_a, k_a, n_a, dy_b, lddy_b, x_b, ldx_b, dw_b, db_b, k_b, n_b, m, ws,
+                                          ws_bytes, (hipStream_t)stream, nullptr, nullptr, nullptr);
+}
+
+}  // extern "C"
+
+// workgroups the paired weight gradients aim at: two per CU (PGNN_DW_PAIR_WGS: A/B)
+static inline int64_t pair_split_cus() { return env_knob("PGNN_DW_PAIR_WGS", 0) > 0 ? env_knob("PGNN_DW_PAIR_WGS", 0) : 2 * num_cu(); }
+// the conditions under which linear_bwd_weight_pair_ext takes its one-launch path AND has room for twelve extra columns in product b
+bool pgnn::linear_bwd_weight_pair_ext_ok(int64_t m, int64_t k_a, int64_t n_a, int64_t k_b, int64_t n_b) {
+  if (!(weight_split(m) && m < kWeightBigRows && env_knob("PGNN_DW_PAIR", 1) != 0 && env_knob("PGNN_BOND_IN_DW", 1) != 0)) return false;
+  if (k_b + 16 > ceil_div(k_b + 4, 160) * 160) return false;  // no column padding to ride in
+  const int64_t tiles_a = ceil_div(n_a, 64) * ceil_div(k_a + 4, 160), tiles_b = ceil_div(n_b, 64) * ceil_div(k_b + 4, 160);
+  int64_t splits = ceil_div(pair_split_cus(), tiles_a + tiles_b);
+  splits = std::max<int64_t>(std::min<int64_t>(splits, std::max<int64_t>(m / (4 * 32), 1)), 1);
+  const int64_t chunk = ceil_div(ceil_div(m, splits), 32) * 32;
+  const int64_t used = ceil_div(m, chunk);
+  return used > 1 && (size_t)used * (n_a * k_a + n_a) * sizeof(float) <= pgnn_linear_bwd_weight_workspace_bytes(m, k_a, n_a) &&
+         (size_t)used * (n_b * k_b + n_b + 12 * n_b) * sizeof(float) <= pgnn_linear_bwd_weight_workspace_bytes(m, k_b, n_b);
+}
+
+int pgnn::pad_rowfeat12(const float* cfeat, int64_t kc, float* out12, int64_t n, hipStream_t st) {
+  PGNN_REQUIRE(cfeat && out12 && n > 0 && kc > 0 && kc <= 12, "pad_rowfeat12: bad arguments");
+  hipLaunchKernelGGL(k_pad_rowfeat12, dim3((int)std::min<int64_t>(ceil_div(n * 3, 256), 2048)), dim3(256), 0, st, cfeat, (int)kc, out12, n);
+  return check_launch("pad_rowfeat12");
+}
+
+int pgnn::bond_tables_from_g(const BondTableJob* jobs, int count, int64_t rows, int64_t dim, int64_t kc, hipStream_t st) {
+  PGNN_REQUIRE(jobs && count > 0 && count <= kMaxBondJobs && rows > 0 && dim > 0 && kc > 0 && kc <= 12, "bond_tables_from_g: bad arguments");
+  BondJobs bj{};
+  for (int i = 0; i < count; ++i) bj.j[i] = jobs[i];
+  hipLaunchKernelGGL(k_bond_tables_from_g, dim3((int)ceil_div(dim, 64), count, (int)ceil_div(kc, 4)), dim3(64 * kBondWaves), 0, st, bj, (int)rows, (int)dim,
+                     (int)kc);
+  return check_launch("bond_tables_from_g");
+}
+
+// pgnn_linear_bwd_weight_pair; with cfeat12 [m][12] and g_out [n_b][12] it also leaves g_out = dy_b^T . cfeat12 where the one-launch
+// path runs (*g_done says whether it did -- the caller takes its own pass otherwise)
+int pgnn::linear_bwd_weight_pair_ext(const float* dy_a, int64_t lddy_a, const float* x_a, int64_t ldx_a, float* dw_a, float* db_a, int64_t k_a,
+                                     int64_t n_a, const float* dy_b, int64_t lddy_b, const float* x_b, int64_t ldx_b, float* dw_b, float* db_b,
+                                     int64_t k_b, int64_t n_b, int64_t m, void* ws, size_t ws_bytes, hipStream_t stream, const float* cfeat12,
+                                     float* g_out, bool* g_done) {
+  if (g_done) *g_done = false;
   PGNN_REQUIRE(m > 0 && k_a > 0 && n_a > 0 && k_b > 0 && n_b > 0 && (k_a | n_a | k_b | n_b | lddy_a | ldx_a | lddy_b | ldx_b) % 4 == 0,
                "linear_bwd_weight_pair: K, N and leading dimensions must be multiples of 4");
   const size_t wa = pgnn_linear_bwd_weight_workspace_bytes(m, k_a, n_a), wb = pgnn_linear_bwd_weight_workspace_bytes(m, k_b, n_b);
@@ -1611,17 +1755,19 @@ int pgnn_linear_bwd_weight_pair(const float* dy_a, int64_t lddy_a, const float* 
     return PGNN_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  ReduceJobs jobs;
+  ReduceJobs jobs{};
   int rc;
   // both products in one launch of 64x160 tiles (k_gemm3_pair) where the single products would take that tile and split:
   // PGNN_DW_PAIR=0 = two launches (round 3; bit-identical to two pgnn_linear_bwd_weight calls)
   if (weight_split(m) && m < kWeightBigRows && db_a && db_b && env_knob("PGNN_DW_PAIR", 1) != 0) {
     const int64_t tiles_a = ceil_div(n_a, 64) * ceil_div(k_a + 4, 160), tiles_b = ceil_div(n_b, 64) * ceil_div(k_b + 4, 160);
-    int64_t splits = ceil_div(2 * num_cu(), tiles_a + tiles_b);
+    int64_t splits = ceil_div(pair_split_cus(), tiles_a + tiles_b);
     splits = std::max<int64_t>(std::min<int64_t>(splits, std::max<int64_t>(m / (4 * 32), 1)), 1);
     const int64_t chunk = ceil_div(ceil_div(m, splits), 32) * 32;
     const int used = (int)ceil_div(m, chunk);
-    if (used > 1 && (size_t)used * (n_a * k_a + n_a) * sizeof(float) <= wa && (size_t)used * (n_b * k_b + n_b) * sizeof(float) <= wb) {
+    const bool ext = cfeat12 && g_out && g_done && linear_bwd_weight_pair_ext_ok(m, k_a, n_a, k_b, n_b);
+    const int64_t gcols = ext ? 12 : 0;  // floats per row of product b's partials behind its bias gradient
+    if (used > 1 && (size_t)used * (n_a * k_a + n_a) * sizeof(float) <= wa && (size_t)used * (n_b * k_b + n_b + gcols * n_b) * sizeof(float) <= wb) {
       GemmArgs2 q{};
       float* parts[2] = {static_cast<float*>(ws), reinterpret_cast<float*>(static_cast<char*>(ws) + wa)};
       const float* dys[2] = {dy_a, dy_b};
@@ -1636,9 +1782,16 @@ int pgnn_linear_bwd_weight_pair(const float* dy_a, int64_t lddy_a, const float* 
         p.M = (int)ns[z]; p.N = (int)ks[z]; p.K = (int)m;
         p.kchunk = (int)chunk;
         p.C = parts[z]; p.ldc = ks[z];
-        p.split_stride = ns[z] * ks[z] + ns[z];
+        const int64_t gz = z == 1 ? gcols : 0;
+        p.split_stride = ns[z] * ks[z] + ns[z] + gz * ns[z];
         p.colsum = parts[z] + ns[z] * ks[z];
-        jobs.j[z] = ReduceJob{parts[z], used, ns[z] * ks[z] + ns[z], dws[z], ns[z] * ks[z] / 4, dbs[z], ns[z] / 4};
+        jobs.j[z] = ReduceJob{parts[z], used, p.split_stride, dws[z], ns[z] * ks[z] / 4, dbs[z], ns[z] / 4, nullptr, 0};
+        if (gz) {
+          p.F = cfeat12;
+          p.extra = parts[z] + ns[z] * ks[z] + ns[z];
+          jobs.j[z].g = g_out;
+          jobs.j[z].n4c = gz * ns[z] / 4;
+        }
       }
       q.tiles[0] = (int)tiles_a; q.tiles[1] = (int)tiles_b;
       // (Measured and NOT kept, profiles/r04/wgrad2p_and_ctx_two_streams_ab.txt: the same launch on two fp16 planes under column
@@ -1647,11 +1800,19 @@ int pgnn_linear_bwd_weight_pair(const float* dy_a, int64_t lddy_a, const float* 
       // products per k-step save in a loop that is bound by its staging, not by the matrix pipes.)
       using TA = RowMajorTile<64>;
       using TB = RowMajorTile<160>;
-      constexpr size_t lds = (size_t)3 * (TA::PLANE + TB::PLANE);
-      allow_big_lds((const void*)k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true>, lds);
-      hipLaunchKernelGGL((k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true>), dim3((int)std::max(tiles_a, tiles_b), used, 2), dim3(512), lds,
-                         st, q);
-      const int64_t work = std::max(jobs.j[0].n4a + jobs.j[0].n4b, jobs.j[1].n4a + jobs.j[1].n4b);
+      // PGNN_DW_ONE_PER_CU=1 (A/B): the launch asks for more LDS than it uses, so ONE workgroup per CU is resident instead of two
+      const size_t lds = env_knob("PGNN_DW_ONE_PER_CU", 0) != 0 ? (size_t)96 * 1024 : (size_t)3 * (TA::PLANE + TB::PLANE);
+      if (ext) {
+        allow_big_lds((const void*)k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true, true>, lds);
+        hipLaunchKernelGGL((k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true, true>), dim3((int)std::max(tiles_a, tiles_b), used, 2), dim3(512),
+                           lds, st, q);
+        *g_done = true;
+      } else {
+        allow_big_lds((const void*)k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true>, lds);
+        hipLaunchKernelGGL((k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true>), dim3((int)std::max(tiles_a, tiles_b), used, 2), dim3(512), lds,
+                           st, q);
+      }
+      const int64_t work = std::max(jobs.j[0].n4a + jobs.j[0].n4b + jobs.j[0].n4c, jobs.j[1].n4a + jobs.j[1].n4b + jobs.j[1].n4c);
       hipLaunchKernelGGL(k_splitk_reduce_jobs, dim3((int)std::min<int64_t>(ceil_div(work, 256), 1024), 2), dim3(256), 0, st, jobs);
       return check_launch("linear_bwd_weight_pair");
     }
@@ -1669,8 +1830,6 @@ int pgnn_linear_bwd_weight_pair(const float* dy_a, int64_t lddy_a, const float* 
   }
   return check_launch("linear_bwd_weight_pair");
 }
-
-}  // extern "C"
 
 // ==================================================================================================================================
 // The planes products on TWO fp16 planes (PGNN_GEMM_2P=1; measured as a prototype at the end of round 3, DESIGN 8.1 and
@@ -2057,7 +2216,13 @@ int launch_gemm2pw_s(const GemmArgs& p, hipStream_t st) {
   constexpr size_t lds = (size_t)STAGES * (BM * 128 + 2 * BN * 64);
   const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N, BN));
   allow_big_lds((const void*)k_gemm2pw<BM, BN, WAVES_M, WAVES_N, STAGES, EPI>, lds);
-  hipLaunchKernelGGL((k_gemm2pw<BM, BN, WAVES_M, WAVES_N, STAGES, EPI>), dim3(tiles), dim3(64 * WAVES_M * WAVES_N), lds, st, p);
+  // a stop event handed over by the caller (set_next_launch_stop_event) becomes THIS dispatch's completion: a fork point for another
+  // stream without a marker packet behind the kernel in this one (a hipEventRecord there idles the stream 7-8 us per layer of the
+  // chem backward, profiles/r05/step_b256_timeline_bond.txt)
+  if (hipEvent_t stop = take_next_launch_stop_event())
+    hipExtLaunchKernelGGL((k_gemm2pw<BM, BN, WAVES_M, WAVES_N, STAGES, EPI>), dim3(tiles), dim3(64 * WAVES_M * WAVES_N), lds, st, nullptr, stop, 0, p);
+  else
+    hipLaunchKernelGGL((k_gemm2pw<BM, BN, WAVES_M, WAVES_N, STAGES, EPI>), dim3(tiles), dim3(64 * WAVES_M * WAVES_N), lds, st, p);
   return check_launch("gemm2pw");
 }
 // ==================================================================================================================================

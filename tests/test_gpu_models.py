@@ -742,6 +742,47 @@ def test_batchnorm_backward_sums_from_the_transposed_aggregation(graphs, trainin
         assert torch.equal(res[2][1][k], res[3][1][k]), k  # deterministic
 
 
+@pytest.mark.parametrize("graphs,layers", [(256, 5), (96, 3), (700, 2)])
+def test_bond_table_gradients_out_of_the_weight_gradient_product(graphs, layers, monkeypatch):
+    """one-call chem GIN backward (chem/model.py:37-52 under autograd): the gradients of edge_embedding1 / 2,
+    demb = cfeat^T dagg with dagg = dhid W1, are taken as (cfeat^T dhid) W1 -- cfeat^T dhid rides as twelve columns in the tile padding
+    of the dW1 product that runs anyway (linear.hip, linear_bwd_weight_pair_ext), the fold of its split-K partials folds it, one small
+    launch per backward does G^T W1 for every layer (float64 accumulators).  PGNN_BOND_IN_DW=0: the pass over dagg per layer
+    (k_rowfeat_bwd_partial / _final).  Every OTHER gradient bit-identical (the extra columns touch no other accumulator); the bond
+    tables equal to fp32 rounding of a re-associated product; deterministic."""
+    import copy
+    from pretrain_gnns_amd import ops
+    hchem, _ = _hip()
+    _, a = _pair(ochem.GNN, hchem.GNN, layers, 300, seed=31)
+    a.train()
+    d = hostdata.chem_masking_batch(graphs, seed=32).to(DEV)
+    w = torch.randn(d.x.size(0), 300, device=DEV)
+    res = []
+    for flag in ("1", "0", "1"):
+        monkeypatch.setenv("PGNN_BOND_IN_DW", flag)
+        ops.load().pgnn_reload_env()
+        m = copy.deepcopy(a)
+        m.zero_grad()
+        out = m(d.x, d.edge_index, d.edge_attr)
+        (out * w).sum().backward()
+        torch.cuda.synchronize()
+        res.append(dict({k: p.grad.clone() for k, p in m.named_parameters()}, __out=out.detach().clone()))
+    monkeypatch.delenv("PGNN_BOND_IN_DW")
+    ops.load().pgnn_reload_env()
+    bonds = [k for k in res[0] if "edge_embedding" in k]
+    assert len(bonds) == 2 * layers
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[2][k]), k  # deterministic
+        if k in bonds:
+            # rows of the tables no edge of the batch uses have a zero gradient either way
+            ref = res[1][k].double()
+            err = float((res[0][k].double() - ref).abs().max())
+            assert err <= 2e-5 * float(ref.abs().max()) + 1e-30, (k, err, float(ref.abs().max()))
+            assert torch.equal(res[0][k] == 0, res[1][k] == 0) or err <= 1e-6 * float(ref.abs().max()), k
+        else:
+            assert torch.equal(res[0][k], res[1][k]), k
+
+
 @pytest.mark.parametrize("graphs", [64, 256])
 def test_side_stream_schedules_of_the_backward_give_the_same_bits(graphs, monkeypatch):
     """one-call chem GIN backward: with the weight gradients and bond tables on the side stream (default) or everything on the
