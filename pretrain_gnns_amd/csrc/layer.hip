@@ -46,9 +46,8 @@ Side* side_for_current_device() {
     // and made HIP-graph replay of the step 50 % slower (2.8 vs 1.8 ms, measured)
     // (round 4 re-measured it with the caller's stream the longer one: lowest priority 0.994-0.997 against 0.990-0.993 ms, no effect)
     if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    // PGNN_EVENT_DEVICE_RELEASE=1: the fork / lag events release to DEVICE scope only (both streams are this device's; the join, which
-    // the caller's later host reads sit behind, keeps the default)
-    const unsigned fl = hipEventDisableTiming | (env_knob("PGNN_EVENT_DEVICE_RELEASE", 0) != 0 ? hipEventReleaseToDevice : 0u);
+    // (hipEventReleaseToDevice on the fork / lag events: measured level, profiles/r05/fork_via_launch_ab.txt)
+    const unsigned fl = hipEventDisableTiming;
     for (auto& e : s.fork)
       if (hipEventCreateWithFlags(&e, fl) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -673,13 +672,44 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   int64_t ldg = lddy;
   bool sums_ready = false;   // the BatchNorm-backward sums of the layer about to run are already folded (in bn_scratch.coef)
   BnBwdScratch bn_scratch{};
+  // The parameter gradients of layer l on `aux` behind fork[1]: both weight-gradient products in one launch + the fold of their
+  // split-K partials (with bond_in_dw the dW1 product carries G = dhid^T cfeat along -- twelve columns of its tile padding -- and the
+  // bond-table gradient demb = G^T W1 needs no pass over dagg: one launch for all layers behind the loop), else the bond tables' own pass
+  auto side_work = [&](int l, bool demb_on_main) -> int {
+    const pgnn_gin_layer& p = layers[l];
+    const int b = per_layer ? l : (l & 1);
+    const float* agg = acts + (size_t)l * 3 * nd;
+    const float* hd = hid + (size_t)l * 2 * nd;
+    int r;
+    if (sd) PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[1], 0));
+    bool g_done = false;
+    if ((r = linear_bwd_weight_pair_ext(dz[b], dim, hd, 2 * dim, p.dw2, p.db2, 2 * dim, dim, dhid[b], 2 * dim, agg, dim, p.dw1, p.db1, dim,
+                                        2 * dim, n, aux_ws, opb, aux, bond_in_dw ? cfeat12 : nullptr, bond_in_dw ? gbond[l] : nullptr, &g_done)))
+      return r;
+    if (g_done) {
+      bond_jobs[n_bond_jobs++] = BondTableJob{gbond[l], p.w1, dim, p.demb, dim};
+      if (milestone_armed()) {  // a communication stream may be waiting for this layer's gradients: no deferral
+        if ((r = bond_tables_from_g(bond_jobs + n_bond_jobs - 1, 1, 2 * dim, dim, 9, aux))) return r;
+        --n_bond_jobs;
+      }
+    } else if (!demb_on_main || bond_in_dw) {  // (bond_in_dw without g_done cannot happen: linear_bwd_weight_pair_ext_ok said the one-launch path runs)
+      if ((r = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, aux_ws, opb, aux))) return r;
+    }
+    if (sd && !per_layer && l >= 2) PGNN_HIP(hipEventRecord(sd->lag[b], aux));  // awaited by layer l-2 only
+    // every parameter gradient of layers >= l is enqueued now (weights, biases and edge tables on `aux`, the BatchNorm's on `main`;
+    // layer l - 1's BatchNorm sums, which the transposed aggregation also leaves, only arrive early)
+    return milestone_record(l, p.w1, main, aux);
+  };
+  // (Measured and NOT kept, profiles/r05/fork_late_ab.txt: forking layer l's parameter gradients behind layer l - 1's BatchNorm
+  // elementwise pass instead -- that pass and the transposed aggregation then run alone (6 and 17 us instead of 26 and 19), but the
+  // second backward-data product, whose 115 KB of LDS cannot share a CU with two 55 KB weight-gradient workgroups, waits for them to
+  // retire: 49-58 us instead of 15-18, step 1.007-1.012 against 0.968-0.972 ms.)
   for (int l = num_layer - 1; l >= 0; --l) {
     const pgnn_gin_layer& p = layers[l];
     const int q = num_layer - 1 - l;  // index into the transposed weights
     const int b = per_layer ? l : (l & 1);  // own buffer set per layer, or ping-pong guarded by lag events
     if (sd && !per_layer && l + 2 <= num_layer - 1) PGNN_HIP(hipStreamWaitEvent(main, sd->lag[b], 0));
     const float* a = acts + (size_t)l * 3 * nd;  // agg, z, y
-    const float* agg = a;
     const float* z = a + nd;
     const float* hd = hid + (size_t)l * 2 * nd;
     const float* mean = stats + (size_t)l * 4 * dim;
@@ -724,7 +754,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     // the bottom layer's edge-table gradient stays on the caller's stream: the side stream is the longer of the two there
     // (two weight-gradient products behind the data products), and the caller's stream only has the embedding gradients left
     const bool demb_on_main = sd && l == 0;
-    // The caller's stream is the critical path: its transposed aggregation is enqueued BEFORE the side stream's five launches
+    // The caller's stream is the critical path: its transposed aggregation is enqueued BEFORE the side stream's launches
     // (it reads dagg, which they only read, and writes dx, which they never touch), so that stream is never waiting for the host.
     // the transposed aggregation; for l > 0 its launch also leaves the BatchNorm-backward sums of layer l - 1 (whose output
     // gradient it is writing) in the caller's op scratch -- folded, as pgnn_bn_bwd's first launch would
@@ -742,29 +772,9 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     if (sd) {
       if ((rc = aggregate_t())) return rc;
       if (demb_on_main && !bond_in_dw && (rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, op, opb, main))) return rc;
-      PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[1], 0));
     }
-    // both products, one fold of the split-K partials; with bond_in_dw the dW1 product carries G = dhid^T cfeat along (twelve columns
-    // of its tile padding) and the bond-table gradient demb = G^T W1 needs no pass over dagg: one launch for all layers behind the loop
-    bool g_done = false;
-    if ((rc = linear_bwd_weight_pair_ext(dz[b], dim, hd, 2 * dim, p.dw2, p.db2, 2 * dim, dim, dhid[b], 2 * dim, agg, dim, p.dw1, p.db1, dim,
-                                         2 * dim, n, aux_ws, opb, aux, bond_in_dw ? cfeat12 : nullptr, bond_in_dw ? gbond[l] : nullptr, &g_done)))
-      return rc;
-    if (g_done) {
-      bond_jobs[n_bond_jobs++] = BondTableJob{gbond[l], p.w1, dim, p.demb, dim};
-      if (milestone_armed()) {  // a communication stream may be waiting for this layer's gradients: no deferral
-        if ((rc = bond_tables_from_g(bond_jobs + n_bond_jobs - 1, 1, 2 * dim, dim, 9, aux))) return rc;
-        --n_bond_jobs;
-      }
-    } else if (bond_in_dw && demb_on_main) {  // (cannot happen: linear_bwd_weight_pair_ext_ok said the one-launch path runs)
-      if ((rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, aux_ws, opb, aux))) return rc;
-    }
-    if (!g_done && !demb_on_main && (rc = pgnn_rowfeat_matmul_bwd(cfeat, 9, dagg[b], dim, p.demb, dim, n, dim, aux_ws, opb, aux))) return rc;
-    if (sd && !per_layer && l >= 2) PGNN_HIP(hipEventRecord(sd->lag[b], aux));  // awaited by layer l-2 only
+    if ((rc = side_work(l, demb_on_main))) return rc;
     if (!sd && (rc = aggregate_t())) return rc;
-    // every parameter gradient of layers >= l is enqueued now (weights, biases and edge tables on `aux`, the BatchNorm's on `main`;
-    // layer l - 1's BatchNorm sums, which the transposed aggregation above also left, only arrive early)
-    if ((rc = milestone_record(l, p.w1, main, aux))) return rc;
     g = dxb[b];
     ldg = dim;
   }

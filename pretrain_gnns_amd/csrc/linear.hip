@@ -1710,8 +1710,8 @@ int pgnn_linear_bwd_weight_pair(const float* dy_a, int64_t lddy_a, const float* 
 
 }  // extern "C"
 
-// workgroups the paired weight gradients aim at: two per CU (PGNN_DW_PAIR_WGS: A/B)
-static inline int64_t pair_split_cus() { return env_knob("PGNN_DW_PAIR_WGS", 0) > 0 ? env_knob("PGNN_DW_PAIR_WGS", 0) : 2 * num_cu(); }
+// workgroups the paired weight gradients aim at: two per CU
+static inline int64_t pair_split_cus() { return 2 * num_cu(); }
 // the conditions under which linear_bwd_weight_pair_ext takes its one-launch path AND has room for twelve extra columns in product b
 bool pgnn::linear_bwd_weight_pair_ext_ok(int64_t m, int64_t k_a, int64_t n_a, int64_t k_b, int64_t n_b) {
   if (!(weight_split(m) && m < kWeightBigRows && env_knob("PGNN_DW_PAIR", 1) != 0 && env_knob("PGNN_BOND_IN_DW", 1) != 0)) return false;
@@ -1800,8 +1800,8 @@ int pgnn::linear_bwd_weight_pair_ext(const float* dy_a, int64_t lddy_a, const fl
       // products per k-step save in a loop that is bound by its staging, not by the matrix pipes.)
       using TA = RowMajorTile<64>;
       using TB = RowMajorTile<160>;
-      // PGNN_DW_ONE_PER_CU=1 (A/B): the launch asks for more LDS than it uses, so ONE workgroup per CU is resident instead of two
-      const size_t lds = env_knob("PGNN_DW_ONE_PER_CU", 0) != 0 ? (size_t)96 * 1024 : (size_t)3 * (TA::PLANE + TB::PLANE);
+      // (512 workgroups, two per CU: 384 / 768 / 256 aimed at, or one resident per CU, all measured slower -- profiles/r05/dw_pair_grid_ab.txt)
+      constexpr size_t lds = (size_t)3 * (TA::PLANE + TB::PLANE);
       if (ext) {
         allow_big_lds((const void*)k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true, true>, lds);
         hipLaunchKernelGGL((k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true, true>), dim3((int)std::max(tiles_a, tiles_b), used, 2), dim3(512),
