@@ -1333,9 +1333,13 @@ int launch_cfg(TileCfg c, const GemmArgs& p, int nsplit, hipStream_t st) {
 constexpr int kWgtBK = 16;
 
 // split count for dW = dy^T x: every SIMD should get ~2 waves, each split at least 4 k-tiles deep
+// (round 5) 64x160 tiles of the split-bf16 kernel: two 55 KB workgroups are resident per CU, and a grid just above 2 x CUs -- 13
+// splits x 40 tiles = 520 -- runs its last eight workgroups in a second round: as many splits as fit in ONE round instead (12 x 40 =
+// 480: chem step 0.969-0.972 -> 0.953-0.960 ms, profiles/r05/dw_one_round_ab.txt; PGNN_DW_SPLIT_MODE=0 = rounded up)
+inline bool one_round_splits() { return env_knob("PGNN_DW_SPLIT_MODE", 1) == 1; }
 inline int weight_splits(int64_t m, int64_t k, int64_t n, int bm, int bn) {
   const int64_t tiles = ceil_div(n, bm) * ceil_div(k, bn);
-  int64_t s = ceil_div(2 * num_cu(), tiles);
+  int64_t s = (bm == 64 && bn == 160 && one_round_splits()) ? std::max<int64_t>(2 * num_cu() / tiles, 1) : ceil_div(2 * num_cu(), tiles);
   s = std::min<int64_t>(s, std::max<int64_t>(m / (4 * kWgtBK), 1));
   return (int)std::max<int64_t>(std::min<int64_t>(s, 256), 1);
 }
@@ -1710,14 +1714,17 @@ int pgnn_linear_bwd_weight_pair(const float* dy_a, int64_t lddy_a, const float* 
 
 }  // extern "C"
 
-// workgroups the paired weight gradients aim at: two per CU
-static inline int64_t pair_split_cus() { return 2 * num_cu(); }
+// splits over the rows of the paired weight gradients: as many as fit in one round of two resident workgroups per CU (see weight_splits)
+static inline int64_t pair_splits(int64_t tiles) {
+  const int64_t slots = 2 * num_cu();
+  return one_round_splits() ? std::max<int64_t>(slots / tiles, 1) : ceil_div(slots, tiles);
+}
 // the conditions under which linear_bwd_weight_pair_ext takes its one-launch path AND has room for twelve extra columns in product b
 bool pgnn::linear_bwd_weight_pair_ext_ok(int64_t m, int64_t k_a, int64_t n_a, int64_t k_b, int64_t n_b) {
   if (!(weight_split(m) && m < kWeightBigRows && env_knob("PGNN_DW_PAIR", 1) != 0 && env_knob("PGNN_BOND_IN_DW", 1) != 0)) return false;
   if (k_b + 16 > ceil_div(k_b + 4, 160) * 160) return false;  // no column padding to ride in
   const int64_t tiles_a = ceil_div(n_a, 64) * ceil_div(k_a + 4, 160), tiles_b = ceil_div(n_b, 64) * ceil_div(k_b + 4, 160);
-  int64_t splits = ceil_div(pair_split_cus(), tiles_a + tiles_b);
+  int64_t splits = pair_splits(tiles_a + tiles_b);
   splits = std::max<int64_t>(std::min<int64_t>(splits, std::max<int64_t>(m / (4 * 32), 1)), 1);
   const int64_t chunk = ceil_div(ceil_div(m, splits), 32) * 32;
   const int64_t used = ceil_div(m, chunk);
@@ -1761,7 +1768,7 @@ int pgnn::linear_bwd_weight_pair_ext(const float* dy_a, int64_t lddy_a, const fl
   // PGNN_DW_PAIR=0 = two launches (round 3; bit-identical to two pgnn_linear_bwd_weight calls)
   if (weight_split(m) && m < kWeightBigRows && db_a && db_b && env_knob("PGNN_DW_PAIR", 1) != 0) {
     const int64_t tiles_a = ceil_div(n_a, 64) * ceil_div(k_a + 4, 160), tiles_b = ceil_div(n_b, 64) * ceil_div(k_b + 4, 160);
-    int64_t splits = ceil_div(pair_split_cus(), tiles_a + tiles_b);
+    int64_t splits = pair_splits(tiles_a + tiles_b);
     splits = std::max<int64_t>(std::min<int64_t>(splits, std::max<int64_t>(m / (4 * 32), 1)), 1);
     const int64_t chunk = ceil_div(ceil_div(m, splits), 32) * 32;
     const int used = (int)ceil_div(m, chunk);
