@@ -58,6 +58,11 @@ Side* side_for_current_device() {
   return &s;
 }
 inline bool use_side_stream() { return env_knob("PGNN_SIDE_STREAM", 1) != 0; }
+// PGNN_SIDE_MIN_ROWS: rows below which the one-call chem GIN backward stays on the caller's stream.  0 (always fork) is the default: a
+// fork / lag / join costs the HOST ~25 us per layer (four event calls), and whether the overlap pays below ~5 000 rows depends on
+// which side bounds the step -- the context-prediction step (4 1xx + 1 9xx rows) measures 1.33-1.38 ms forked against 1.46 (then
+// GPU-bound) on one stream on boxes with a fast host, 1.65-1.68 against 1.46-1.47 on a slow one (profiles/r05/ctx_side_stream_ab.txt)
+inline int64_t side_min_rows() { return env_knob("PGNN_SIDE_MIN_ROWS", 0); }
 
 // Gradient milestone of a stack backward (pgnn_stack_bwd_milestone_arm / _wait): once layer `layer` has been enqueued, every
 // parameter gradient of layers >= `layer` is behind one of two events -- the caller's stream, the side stream -- so a
@@ -610,7 +615,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   int n_bond_jobs = 0;
 
   hipStream_t main = (hipStream_t)stream;
-  Side* sd = (use_side_stream() && n <= kSideMaxRows && num_layer <= kMaxSets) ? side_for_current_device() : nullptr;
+  Side* sd = (use_side_stream() && n >= side_min_rows() && n <= kSideMaxRows && num_layer <= kMaxSets) ? side_for_current_device() : nullptr;
   // One buffer set per layer would save the lag events (8 event calls per step), but the ping-pong pair stays
   // resident in the 256 MB Infinity Cache and wins on the GPU side: 1.80 vs 1.85 ms per replayed step (measured).
   const bool per_layer = sd && per_layer_buffers();

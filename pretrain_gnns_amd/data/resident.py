@@ -14,6 +14,8 @@ Output batches have the field layout of the reference's ``BatchMasking`` (restat
 mask_edge_label]; bio: masked_edge_idx, mask_edge_label), so ``train.chem_masking_step`` /
 ``train.bio_masking_step`` consume them unchanged.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -223,7 +225,15 @@ class ResidentDataset:
         bio (float features): ExtractSubstructureContextPair(l1, center=True) (bio/util.py:123-209, bio/batch.py:127-232):
         the substructure is the whole ego net, the context every node farther than ``l1`` hops from the centre node;
         ``k`` / ``l2`` are ignored, the roots are the dataset's ``center_node_idx``.
-        One host sync: the totals that size the outputs (sub-graph sizes are data dependent)."""
+        One host sync: the totals that size the outputs (sub-graph sizes are data dependent).  ``plan_substruct_context`` /
+        ``fill_substruct_context`` are its two halves: a loader that plans batch t + 1 BEFORE the train step of batch t is enqueued
+        finds the totals on the host when it needs them (ResidentLoader does)."""
+        return self.fill_substruct_context(self.plan_substruct_context(graph_ids, k, l1, l2, seed, roots, ids_device))
+
+    def plan_substruct_context(self, graph_ids, k=5, l1=4, l2=7, seed=0, roots=None, ids_device=None, staging=None):
+        """first half of ``collate_substruct_context``: the per-graph plan (BFS distances, ranks, counts, prefix sums) on the device
+        and the six totals on their way to pinned host memory behind an event.  ``staging``: (pinned int64[6], torch.cuda.Event)
+        to reuse; returns the state ``fill_substruct_context`` takes."""
         bio = self.x.dtype == torch.float32
         if bio:
             if self.edge_attr.dtype != torch.float32 or self.edge_attr.size(1) != 9:
@@ -262,7 +272,26 @@ class ResidentDataset:
             roots_dev.data_ptr() if roots_dev is not None else None, int(seed) & 0xFFFFFFFFFFFFFFFF, int(k), int(l1), int(l2),
             inode[0].data_ptr(), inode[1].data_ptr(), inode[2].data_ptr(), iedge[0].data_ptr(), iedge[1].data_ptr(),
             counts.data_ptr(), root_out.data_ptr(), coffs.data_ptr(), sp), "pgnn_substruct_context_plan")
-        n_sub, e_sub, n_ctx, e_ctx, n_ov, kept = [int(v) for v in coffs[:, b].tolist()]  # the one sync
+        totals_dev = coffs[:, b].contiguous()
+        if torch.device(dev).type == "cuda":
+            host, ev = staging if staging is not None else (torch.empty(6, dtype=torch.int64).pin_memory(), torch.cuda.Event())
+            with torch.cuda.device(dev):
+                host.copy_(totals_dev, non_blocking=True)
+                ev.record()
+        else:
+            host, ev = totals_dev.clone(), None
+        return dict(ids=ids, b=b, n=n, e=e, offs=offs, status=status, inode=inode, iedge=iedge, counts=counts, root_out=root_out,
+                    coffs=coffs, roots_dev=roots_dev, zero_from=zero_from, totals=host, event=ev)
+
+    def fill_substruct_context(self, st):
+        """second half of ``collate_substruct_context``: wait for the plan's totals (the one host sync -- on an event that lies
+        BEFORE whatever was enqueued after the plan), size the outputs, fill them"""
+        lib, sp, dev = load(), stream_ptr(), self.device
+        if st["event"] is not None:
+            st["event"].synchronize()
+        n_sub, e_sub, n_ctx, e_ctx, n_ov, kept = [int(v) for v in st["totals"].tolist()]
+        ids, b, n, e, offs, coffs, counts, root_out, inode, iedge = (st[k] for k in ("ids", "b", "n", "e", "offs", "coffs", "counts", "root_out",
+                                                                                      "inode", "iedge"))
         cx, ca = self.x.size(1), self.edge_attr.size(1)
         out = Data()
         out.x_substruct = torch.empty(n_sub, cx, dtype=self.x.dtype, device=dev)
@@ -281,13 +310,13 @@ class ResidentDataset:
                 offs[0].data_ptr(), offs[1].data_ptr(), coffs.data_ptr(), counts.data_ptr(), root_out.data_ptr(),
                 inode[1].data_ptr(), inode[2].data_ptr(), iedge[0].data_ptr(), iedge[1].data_ptr(), self.x.data_ptr(),
                 cx * self.x.element_size(), self.edge_index.data_ptr(), self.edge_index.size(1), self.edge_attr.data_ptr(),
-                ca * self.edge_attr.element_size(), zero_from, n, e,
+                ca * self.edge_attr.element_size(), st["zero_from"], n, e,
                 out.x_substruct.data_ptr(), out.edge_index_substruct.data_ptr(), out.edge_attr_substruct.data_ptr(),
                 out.x_context.data_ptr(), out.edge_index_context.data_ptr(), out.edge_attr_context.data_ptr(),
                 out.center_substruct_idx.data_ptr(), out.overlap_context_substruct_idx.data_ptr(),
                 out.batch_overlapped_context.data_ptr(), out.overlapped_context_size.data_ptr(), sp),
                 "pgnn_substruct_context_fill")
-        out._num_graphs, out._status, out._roots = kept, status, root_out
+        out._num_graphs, out._status, out._roots = kept, st["status"], root_out
         return out
 
     def check(self, batch):
@@ -328,6 +357,7 @@ class ResidentLoader:
         self.drop_last = drop_last
         self.epoch = 0
         self._staging = None  # two pinned id buffers + the events of their last uploads (see _upload)
+        self._plan_staging = None  # substruct/context: two (pinned totals, event) pairs, batch parity (see __iter__)
 
     def _keeps_tail(self):
         """the last, short global batch is used iff drop_last is off AND every rank gets at least one graph of it:
@@ -385,6 +415,28 @@ class ResidentLoader:
             return
         flat = self._upload(np.concatenate(batches), epoch)  # one upload per epoch
         off = 0
+        if self.substruct_context is not None and os.environ.get("PGNN_CTX_PIPELINE", "1") != "0":
+            # the plan of batch t + 1 (and the copy of its totals to pinned memory) is enqueued BEFORE batch t is handed out, i.e. in
+            # front of the train step of batch t: when the loader comes back for batch t + 1 its totals have long arrived, and the
+            # host never waits for a train step to drain (one sync per step before: the context-prediction step was exactly as long
+            # as its host enqueue, 1.447 ms -- profiles/r05/ctx_host.txt)
+            k, l1, l2 = self.substruct_context
+            offs_ = np.concatenate([[0], np.cumsum([ids.size for ids in batches])])
+            if self._plan_staging is None and torch.device(self.ds.device).type == "cuda":
+                self._plan_staging = [(torch.empty(6, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+
+            def plan(step):
+                seed = (self.seed * 1000003 + epoch) * 1000003 + step
+                return self.ds.plan_substruct_context(batches[step], k=k, l1=l1, l2=l2, seed=seed,
+                                                      ids_device=flat[offs_[step]:offs_[step + 1]],
+                                                      staging=self._plan_staging[step & 1] if self._plan_staging else None)
+
+            pending = plan(0)
+            for step in range(len(batches)):
+                nxt = plan(step + 1) if step + 1 < len(batches) else None
+                yield self.ds.fill_substruct_context(pending)
+                pending = nxt
+            return
         for step, ids in enumerate(batches):
             seed = (self.seed * 1000003 + epoch) * 1000003 + step
             if self.substruct_context is not None:

@@ -1380,6 +1380,34 @@ def _bn_meta(bns, in_call=False):
     return meta
 
 
+def _chem_gin_flat(plan, convs, bns):
+    """the 8 parameters per layer of a chem GIN network, in StackPlan order.  Forty ``conv.mlp[0].weight``-style reads go through
+    nn.Module.__getattr__ / Sequential.__getitem__ (~1 us each, 45 us per call: the host-bound context-prediction step makes four
+    such calls); the sub-MODULES are remembered instead, re-checked by identity through the ``_modules`` dicts, and the parameters
+    read from their ``_parameters`` dicts every call (a replaced Parameter or sub-module is picked up)."""
+    cache = plan.__dict__.get("flat_mods")
+    cm, bm = convs._modules, bns._modules
+    if cache is not None and len(cache) == len(cm) == len(bm):
+        flat = []
+        for (conv, e1, e2, mlp, l0, l2, bn), c, b in zip(cache, cm.values(), bm.values()):
+            m = c._modules
+            if c is not conv or b is not bn or m.get("edge_embedding1") is not e1 or m.get("edge_embedding2") is not e2 or m.get("mlp") is not mlp:
+                break
+            mm = mlp._modules
+            if mm.get("0") is not l0 or mm.get("2") is not l2:
+                break
+            p0, p2, pb = l0._parameters, l2._parameters, bn._parameters
+            flat += (e1._parameters["weight"], e2._parameters["weight"], p0["weight"], p0["bias"], p2["weight"], p2["bias"],
+                     pb["weight"], pb["bias"])
+        else:
+            return flat
+    plan.flat_mods = [(conv, conv.edge_embedding1, conv.edge_embedding2, conv.mlp, conv.mlp[0], conv.mlp[2], bn)
+                      for conv, bn in zip(convs, bns)]
+    return [t for conv, bn in zip(convs, bns) for t in (
+        conv.edge_embedding1.weight, conv.edge_embedding2.weight, conv.mlp[0].weight, conv.mlp[0].bias,
+        conv.mlp[2].weight, conv.mlp[2].bias, bn.weight, bn.bias)]
+
+
 def chem_gin_stack(owner, x_idx, graph, x_embedding1, x_embedding2, convs, bns, drop_p=0.0):
     """run the atom embedding and all (conv, bn) layers through the stack call; ReLU after every layer
     but the last and (``drop_p`` > 0) dropout after every layer, as GNN.forward of the reference does.
@@ -1388,9 +1416,7 @@ def chem_gin_stack(owner, x_idx, graph, x_embedding1, x_embedding2, convs, bns, 
     if plan is None:
         plan = _plans[owner] = StackPlan()
     training = bns[0].training or bns[0].running_mean is None
-    flat = [t for conv, bn in zip(convs, bns) for t in (
-        conv.edge_embedding1.weight, conv.edge_embedding2.weight, conv.mlp[0].weight, conv.mlp[0].bias,
-        conv.mlp[2].weight, conv.mlp[2].bias, bn.weight, bn.bias)]
+    flat = _chem_gin_flat(plan, convs, bns)
     seed = dropout_seed() if drop_p > 0 else 0
     if x_embedding1.weight.requires_grad and _use_direct(flat):
         return ChemGINStack.apply(x_idx, graph, (training, _bn_meta(bns, in_call=True), drop_p, seed, plan, flat),
