@@ -1139,14 +1139,21 @@ int pgnn_bio_gin_stack_bwd(const float* dy, int64_t lddy, const int32_t* out_ptr
     else if (tr && q < ntr) rc = pgnn_linear_bwd_data_t(g, ldg, w2t[q], nullptr, 0, dhid[b], 2 * dim, n, 2 * dim, dim, main);
     else rc = pgnn_linear_bwd_data(g, ldg, p.w2, nullptr, 0, dhid[b], 2 * dim, n, 2 * dim, dim, main);
     if (rc) return rc;
+    // (Measured and NOT kept, profiles/r05/bio_bn_bwd_in_gemm_ab.txt: the BatchNorm backward's column sums per 16-row block out of this
+    // product's epilogue -- k_gemm2pr with the ReLU mask recomputed from `pre` -- + a fold of the 641 blocks instead of
+    // k_bn_bwd_partial: correct, 2.034-2.037 against 2.011-2.016 ms per step.  The pass it removes was waiting for CUs the side
+    // stream's weight gradients hold; the elementwise pass behind it inherits the wait, 18 -> 40 us.)
     if ((rc = pgnn_bn_bwd(dhid[b], 2 * dim, pre, 2 * dim, p.gamma, p.beta, st, st + 2 * dim, training, 1, dpre[b], 2 * dim,
                           p.dgamma, p.dbeta, 0.f, 0, n, 2 * dim, op, opb, main))) return rc;
+    // (fork[1] as the completion of this product's own dispatch where a two-plane kernel runs it: see pgnn_chem_gin_stack_bwd)
+    const bool fork_via_launch = sd && wp && two_planes() && env_knob("PGNN_FORK_VIA_LAUNCH", 1) != 0;
+    if (fork_via_launch) set_next_launch_stop_event(sd->fork[1]);
     if (wp) rc = stack_bwd_data_wp(dpre[b], 2 * dim, wp1[l], nullptr, 0, dagg[b], 2 * dim, n, 2 * dim, 2 * dim, main);
     else if (tr && q < ntr) rc = pgnn_linear_bwd_data_t(dpre[b], 2 * dim, w1t[q], nullptr, 0, dagg[b], 2 * dim, n, 2 * dim, 2 * dim, main);
     else rc = pgnn_linear_bwd_data(dpre[b], 2 * dim, p.w1, nullptr, 0, dagg[b], 2 * dim, n, 2 * dim, 2 * dim, main);
     if (rc) return rc;
     if (sd) {
-      PGNN_HIP(hipEventRecord(sd->fork[1], main));
+      if (!fork_via_launch || take_next_launch_stop_event() != nullptr) PGNN_HIP(hipEventRecord(sd->fork[1], main));  // (not taken: another kernel ran)
       PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[1], 0));
     }
     // parameter gradients (side stream when there is one): dW2 = g^T hid, dW1 = dpre^T agg, d EncT = cfeat^T dagg[:, D:]

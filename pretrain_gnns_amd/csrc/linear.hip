@@ -2535,7 +2535,11 @@ int launch_gemm2pr_s(const GemmArgs& p, hipStream_t st) {
   static_assert(lds <= 160 * 1024, "LDS");
   const int ranges = gemm2pr_ranges(p, BN);
   allow_big_lds((const void*)k_gemm2pr<NK, BN, NW, EPI>, lds);
-  hipLaunchKernelGGL((k_gemm2pr<NK, BN, NW, EPI>), dim3(num_cu()), dim3(64 * NW), lds, st, p, ranges);
+  // (a stop event handed over by the caller becomes this dispatch's completion, as in launch_gemm2pw_s)
+  if (hipEvent_t stop = take_next_launch_stop_event())
+    hipExtLaunchKernelGGL((k_gemm2pr<NK, BN, NW, EPI>), dim3(num_cu()), dim3(64 * NW), lds, st, nullptr, stop, 0, p, ranges);
+  else
+    hipLaunchKernelGGL((k_gemm2pr<NK, BN, NW, EPI>), dim3(num_cu()), dim3(64 * NW), lds, st, p, ranges);
   return check_launch("gemm2pr");
 }
 template <int EPI>
