@@ -240,7 +240,7 @@ def pmc_traffic(n, e, name="agg_pmc_traffic.json"):
     (profiles/r03/agg_pmc_traffic.json, bio_agg_pmc_traffic.json: FETCH_SIZE x2 (gfx950 half-count) + WRITE_SIZE, separate
     --pmc runs of tools/agg_bench.py / tools/bio_tile_pmc.py on this same batch).  Counters cannot be read from inside this
     process, so the figure is only quoted when the recorded batch shape matches; otherwise null."""
-    for rnd in ("r04", "r03", "r02"):  # (the newest pass whose batch AND kernel this run reproduces)
+    for rnd in ("r05", "r04", "r03", "r02"):  # (the newest pass whose batch AND kernel this run reproduces)
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", rnd, name)
         try:
             rec = json.load(open(path))
@@ -535,8 +535,8 @@ def roofline_mlp(dev, rows):
 # collect them (the counters need the profiler around the process).  Wave counters are 4-cycle quanta; the clock under these
 # kernels is 1.5-1.85 GHz (SQ_BUSY_CU_CYCLES / 256 over the event time), not the 2.4 GHz behind the 2 500 TFLOP/s peak.
 MFMA_UTIL_PMC = {"k_mlp2p_fused fwd (262144 rows)": 0.517, "k_mlp2p_fused bwd (262144 rows)": 0.430, "k_gemm2pr<10,120>": 0.417,
-                 "k_gemm2pr<19,64>": 0.340, "k_gemm2pw<112,160> (6740 rows)": 0.234, "k_gemm2pw<64,160> (6740 rows)": 0.241,
-                 "k_gemm3_pair<64,160> (6740 rows)": 0.372}
+                 "k_gemm2pr<19,64>": 0.340, "k_gemm2pw<112,160> (6740 rows)": 0.239, "k_gemm2pw<64,160> (6740 rows)": 0.240,
+                 "k_gemm3_pair<64,160> (6740 rows)": 0.360}  # (the last three: tools/gpu_r05af.sh, the final binary's instances)
 MFMA_UTIL_SOURCE = ("profiles/r05/mlp_fused_pmc_summary.txt (large M), profiles/r05/step_b256_gemm_pmc_summary.txt (the 256-graph step): "
                     "SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) per launch, rocprofv3 --pmc")
 
