@@ -1542,6 +1542,10 @@ int pgnn_linear_bwd_data_wp(const float* dy, int64_t lddy, const void* wtplanes,
 // tile takes 975; the two tiles cross at ~24 k rows: 95 vs 90 us)
 constexpr int64_t kWeightBigRows = 24576;
 inline bool weight_split(int64_t m) { return gemm_mode() == 1 && env_knob("PGNN_GEMM3_BWD", 1) && m >= 2048; }
+// ... the paired launch (both weight gradients + the bond-table columns in one launch, one fold) already from 1 024 rows: the context
+// network of the context-prediction step (1 9xx rows) then takes 3 launches per layer instead of 7 (two fp32-MFMA products, fold, two
+// bond-table passes): 1.495-1.549 -> 1.446-1.450 ms per step (profiles/r05/ctx_pair_min_rows_ab.txt; PGNN_DW_PAIR_MIN_ROWS)
+inline bool pair_split(int64_t m) { return gemm_mode() == 1 && env_knob("PGNN_GEMM3_BWD", 1) && m >= env_knob("PGNN_DW_PAIR_MIN_ROWS", 1024); }
 
 size_t pgnn_linear_bwd_weight_workspace_bytes(int64_t m, int64_t k, int64_t n) {
   const TileCfg c = weight_cfg(m);
@@ -1721,7 +1725,7 @@ static inline int64_t pair_splits(int64_t tiles) {
 }
 // the conditions under which linear_bwd_weight_pair_ext takes its one-launch path AND has room for twelve extra columns in product b
 bool pgnn::linear_bwd_weight_pair_ext_ok(int64_t m, int64_t k_a, int64_t n_a, int64_t k_b, int64_t n_b) {
-  if (!(weight_split(m) && m < kWeightBigRows && env_knob("PGNN_DW_PAIR", 1) != 0 && env_knob("PGNN_BOND_IN_DW", 1) != 0)) return false;
+  if (!(pair_split(m) && m < kWeightBigRows && env_knob("PGNN_DW_PAIR", 1) != 0 && env_knob("PGNN_BOND_IN_DW", 1) != 0)) return false;
   if (k_b + 16 > ceil_div(k_b + 4, 160) * 160) return false;  // no column padding to ride in
   const int64_t tiles_a = ceil_div(n_a, 64) * ceil_div(k_a + 4, 160), tiles_b = ceil_div(n_b, 64) * ceil_div(k_b + 4, 160);
   int64_t splits = pair_splits(tiles_a + tiles_b);
@@ -1766,7 +1770,7 @@ int pgnn::linear_bwd_weight_pair_ext(const float* dy_a, int64_t lddy_a, const fl
   int rc;
   // both products in one launch of 64x160 tiles (k_gemm3_pair) where the single products would take that tile and split:
   // PGNN_DW_PAIR=0 = two launches (round 3; bit-identical to two pgnn_linear_bwd_weight calls)
-  if (weight_split(m) && m < kWeightBigRows && db_a && db_b && env_knob("PGNN_DW_PAIR", 1) != 0) {
+  if (pair_split(m) && m < kWeightBigRows && db_a && db_b && env_knob("PGNN_DW_PAIR", 1) != 0) {
     const int64_t tiles_a = ceil_div(n_a, 64) * ceil_div(k_a + 4, 160), tiles_b = ceil_div(n_b, 64) * ceil_div(k_b + 4, 160);
     int64_t splits = pair_splits(tiles_a + tiles_b);
     splits = std::max<int64_t>(std::min<int64_t>(splits, std::max<int64_t>(m / (4 * 32), 1)), 1);

@@ -313,6 +313,30 @@ def test_substruct_context_random_roots_and_training_step():
     assert loss == loss and 0.0 <= acc <= 1.0
 
 
+def test_substruct_context_loader_plans_ahead_with_the_same_batches(monkeypatch):
+    """ResidentLoader(substruct_context=...) enqueues the plan of batch t + 1 (and the copy of its totals to pinned memory) in front of
+    the work the consumer enqueues for batch t -- plan_substruct_context / fill_substruct_context, csrc/loader.hip unchanged -- so the one
+    sync per step waits for nothing.  Same batches bit for bit as plan and fill back to back (PGNN_CTX_PIPELINE=0), over two epochs,
+    with device work enqueued between the batches and a short last batch."""
+    graphs = _chem_graphs(70, seed=17)
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV, relabel=False)
+    runs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PGNN_CTX_PIPELINE", flag)
+        loader = resident.ResidentLoader(ds, 16, shuffle=True, seed=5, drop_last=False, substruct_context=(5, 4, 7))
+        got = []
+        for _ in range(2):
+            for batch in loader:
+                torch.randn(512, 512, device=DEV) @ torch.randn(512, 512, device=DEV)  # (what a train step would put between two batches)
+                got.append({key: getattr(batch, key).clone() for key in CTX_KEYS})
+        runs.append(got)
+    monkeypatch.delenv("PGNN_CTX_PIPELINE")
+    assert len(runs[0]) == len(runs[1]) == 2 * 5
+    for a, b in zip(*runs):
+        for key in CTX_KEYS:
+            assert torch.equal(a[key], b[key]), key
+
+
 def test_bio_resident_loader_drives_the_masking_step():
     """PPI-shaped dataset resident in HBM -> device MaskEdge batches -> bio masking train step"""
     from pretrain_gnns_amd import train
