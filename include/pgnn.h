@@ -302,7 +302,8 @@ int pgnn_linear_bwd_data_wp(const float* dy, int64_t lddy, const void* wtplanes,
  * x_amax / dy_amax: [m] uint32 = bit patterns of max |row| of the activation operand if its producer left them (a previous
  * product's y_amax / dx_amax), NULL = every workgroup takes the maxima of its own rows in a pass in front of its k-loop.
  * y_amax / dx_amax: NULL, or [m] words that are ZERO before the call and receive the bit patterns of the result rows' largest
- * magnitudes (atomic maximum over the column tiles). */
+ * magnitudes (atomic maximum over the column tiles; the maximum of a row's non-NaN entries -- a NaN entry does not change the row's
+ * scale, it propagates through the planes themselves). */
 int pgnn_split_weights_2p(const float* const* src, void* const* dst, const int64_t* rows, const int64_t* cols, const int32_t* transpose,
                           int64_t count, pgnn_stream stream);
 int pgnn_linear_fwd_2p(const float* x, int64_t ldx, const uint32_t* x_amax, const void* wplanes2, const float* bias, float* y, int64_t ldy,

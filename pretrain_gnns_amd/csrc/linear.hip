@@ -2205,7 +2205,9 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_
   }
   // row maxima of C for the product that takes it as its A operand: the four lane groups (columns 4 fk ..) of a row fold by two
   // cross-lane maxima, the column tiles and the waves side by side by an atomic maximum on the bit patterns (non-negative floats
-  // order like unsigned integers; a NaN ends up largest, and the consumer then runs that row unscaled: the NaN propagates)
+  // order like unsigned integers).  fmaxf drops a NaN operand: a row holding a NaN gets the maximum of its FINITE entries and is scaled
+  // like any other row -- the NaN itself goes through the high plane (fp16(NaN s) = NaN) and poisons its row of the next product, as
+  // it would in fp32; an infinite entry makes the maximum infinite and pow2_scales runs that row unscaled.
   if (p.c_amax) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
