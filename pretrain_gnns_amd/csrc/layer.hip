@@ -59,9 +59,9 @@ Side* side_for_current_device() {
 }
 inline bool use_side_stream() { return env_knob("PGNN_SIDE_STREAM", 1) != 0; }
 // PGNN_SIDE_MIN_ROWS: rows below which the one-call chem GIN backward stays on the caller's stream.  0 (always fork) is the default: a
-// fork / lag / join costs the HOST ~25 us per layer (four event calls), and whether the overlap pays below ~5 000 rows depends on
-// which side bounds the step -- the context-prediction step (4 1xx + 1 9xx rows) measures 1.33-1.38 ms forked against 1.46 (then
-// GPU-bound) on one stream on boxes with a fast host, 1.65-1.68 against 1.46-1.47 on a slow one (profiles/r05/ctx_side_stream_ab.txt)
+// fork / lag / join costs the host ~25 us per layer (four event calls), and whether the overlap pays below ~5 000 rows depends on the
+// box -- the context-prediction step (4 1xx + 1 9xx rows) measures 1.30-1.38 ms forked against 1.46 on one stream on most boxes,
+// 1.61-1.68 against 1.46-1.47 on the ones that run every small kernel ~20 % slower (profiles/r05/ctx_side_stream_ab.txt)
 inline int64_t side_min_rows() { return env_knob("PGNN_SIDE_MIN_ROWS", 0); }
 
 // Gradient milestone of a stack backward (pgnn_stack_bwd_milestone_arm / _wait): once layer `layer` has been enqueued, every
@@ -741,8 +741,10 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
       if ((rc = stack_bwd_data_wp(dz[b], dim, wp2[l], hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main, dz_has_amax ? dz_amax : nullptr, dam))) return rc;
       // PGNN_FORK_VIA_LAUNCH=1: fork[1] is the completion of this product's own dispatch instead of a marker behind it
       if (sd && fork_via_launch) set_next_launch_stop_event(sd->fork[1]);
-      if ((rc = stack_bwd_data_wp(dhid[b], 2 * dim, wp1[l], nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main, dam))) return rc;
-      fork_recorded = sd && fork_via_launch && take_next_launch_stop_event() == nullptr;  // (taken by the launch; else another kernel ran)
+      rc = stack_bwd_data_wp(dhid[b], 2 * dim, wp1[l], nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main, dam);
+      const bool taken = take_next_launch_stop_event() == nullptr;  // (always cleared here: by the launch, or -- another kernel ran, an error -- now)
+      if (rc) return rc;
+      fork_recorded = sd && fork_via_launch && taken;
     } else if (tr && q < ntr) {
       if ((rc = pgnn_linear_bwd_data_t(dz[b], dim, w2t[q], hd, 2 * dim, dhid[b], 2 * dim, n, 2 * dim, dim, main))) return rc;
       if ((rc = pgnn_linear_bwd_data_t(dhid[b], 2 * dim, w1t[q], nullptr, 0, dagg[b], dim, n, dim, 2 * dim, main))) return rc;
@@ -1151,9 +1153,10 @@ int pgnn_bio_gin_stack_bwd(const float* dy, int64_t lddy, const int32_t* out_ptr
     if (wp) rc = stack_bwd_data_wp(dpre[b], 2 * dim, wp1[l], nullptr, 0, dagg[b], 2 * dim, n, 2 * dim, 2 * dim, main);
     else if (tr && q < ntr) rc = pgnn_linear_bwd_data_t(dpre[b], 2 * dim, w1t[q], nullptr, 0, dagg[b], 2 * dim, n, 2 * dim, 2 * dim, main);
     else rc = pgnn_linear_bwd_data(dpre[b], 2 * dim, p.w1, nullptr, 0, dagg[b], 2 * dim, n, 2 * dim, 2 * dim, main);
+    const bool taken = take_next_launch_stop_event() == nullptr;  // (always cleared here)
     if (rc) return rc;
     if (sd) {
-      if (!fork_via_launch || take_next_launch_stop_event() != nullptr) PGNN_HIP(hipEventRecord(sd->fork[1], main));  // (not taken: another kernel ran)
+      if (!fork_via_launch || !taken) PGNN_HIP(hipEventRecord(sd->fork[1], main));  // (not taken: another kernel ran)
       PGNN_HIP(hipStreamWaitEvent(aux, sd->fork[1], 0));
     }
     // parameter gradients (side stream when there is one): dW2 = g^T hid, dW1 = dpre^T agg, d EncT = cfeat^T dagg[:, D:]
