@@ -1365,16 +1365,18 @@ def _bn_meta(bns, in_call=False):
     for bn in bns:
         momentum = 0.0 if bn.momentum is None else bn.momentum
         counter = None
-        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        buf = bn._buffers  # (running_mean / running_var / num_batches_tracked without three trips through nn.Module.__getattr__)
+        nbt = buf.get("num_batches_tracked")
+        if bn.training and bn.track_running_stats and nbt is not None:
             if bn.momentum is None:
-                momentum = 1.0 / float(bn.num_batches_tracked + 1)
-                counters.append(bn.num_batches_tracked)
-            elif in_call and bn.num_batches_tracked.is_cuda and bn.num_batches_tracked.dtype == torch.int64:
-                counter = bn.num_batches_tracked
+                momentum = 1.0 / float(nbt + 1)
+                counters.append(nbt)
+            elif in_call and nbt.is_cuda and nbt.dtype == torch.int64:
+                counter = nbt
             else:
-                counters.append(bn.num_batches_tracked)
-        meta.append((bn.running_mean if bn.track_running_stats else None,
-                     bn.running_var if bn.track_running_stats else None, float(momentum), float(bn.eps), counter))
+                counters.append(nbt)
+        meta.append((buf.get("running_mean") if bn.track_running_stats else None,
+                     buf.get("running_var") if bn.track_running_stats else None, float(momentum), float(bn.eps), counter))
     if counters:
         torch._foreach_add_(counters, 1)  # num_batches_tracked of every layer in one launch
     return meta
