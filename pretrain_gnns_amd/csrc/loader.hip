@@ -298,6 +298,15 @@ __device__ __forceinline__ int wave_excl_rank(bool flag, int lane, int* total) {
   return __popcll(m & ((1ull << lane) - 1ull));
 }
 
+// (round 5) One wave per graph.  The BFS used to keep `dist` in global memory: seven levels of load edge -> load dist[u] -> load dist[v] ->
+// store -> fence, every link a full memory round trip -- 47 us for 256 molecules, the longest kernel of the context-prediction
+// step.  Now, for graphs of up to kPlanLdsNodes nodes (every molecule, every PPI ego net of the shapes here), the distances -- and after
+// them the two membership flags the bond pass needs -- live in the wave's slice of LDS, and a lane's first two bonds stay in
+// registers: a level is LDS traffic inside one wave.  Larger graphs take the global-memory path unchanged.  Same distances (a BFS
+// level is unique), same ranks, same counts: tests/test_gpu_loader.py holds the batches to the host extraction bit for bit.
+constexpr int kPlanLdsNodes = 1024;
+__device__ __forceinline__ int lds_ld(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+__device__ __forceinline__ void lds_st(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 __global__ void __launch_bounds__(256) k_ctx_plan(const int64_t* __restrict__ ids, int64_t B, int64_t G,
                                                   const int64_t* __restrict__ node_slice,
                                                   const int64_t* __restrict__ edge_slice,
@@ -308,40 +317,63 @@ __global__ void __launch_bounds__(256) k_ctx_plan(const int64_t* __restrict__ id
                                                   int32_t* __restrict__ ctx_rank, int32_t* __restrict__ esub_rank,
                                                   int32_t* __restrict__ ectx_rank, int64_t* __restrict__ counts,
                                                   int64_t* __restrict__ root_out) {
+  __shared__ int32_t s_all[4][kPlanLdsNodes];
   const int lane = threadIdx.x & 63;
   const int64_t g = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
   if (g >= B) return;
+  int32_t* const sd = s_all[threadIdx.x >> 6];
   const int64_t id = min(max(ids[g], (int64_t)0), G - 1);
   const int64_t n0 = node_off[g], n = node_off[g + 1] - n0;
   const int64_t e0 = edge_off[g], e = edge_off[g + 1] - e0;
   const int64_t es = edge_slice[id];
+  const bool lds = n <= kPlanLdsNodes;  // (wave-uniform)
   int64_t root = roots ? roots[g] : (n > 0 ? (int64_t)(atom_key(graph_stream(seed, id), 0x5bd1e995) % (uint64_t)n) : 0);
   root = min(max(root, (int64_t)0), max(n - 1, (int64_t)0));
   if (lane == 0) root_out[g] = root;
-  for (int64_t a = lane; a < n; a += 64) st_i32(&dist[n0 + a], a == root ? 0 : -1);
+  // this lane's first two bonds (graph-local ids): every molecule's, most of an ego net's
+  int64_t cu[2] = {0, 0}, cv[2] = {0, 0};
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    if (lane + 64 * j < e) {
+      cu[j] = ei_all[es + lane + 64 * j];
+      cv[j] = ei_all[e_all + es + lane + 64 * j];
+    }
+  auto get = [&](int64_t a) -> int { return lds ? lds_ld(&sd[a]) : ld_i32(&dist[n0 + a]); };
+  auto put = [&](int64_t a, int v) {
+    if (lds) lds_st(&sd[a], v);
+    else st_i32(&dist[n0 + a], v);
+  };
+  auto fence = [&]() {
+    if (lds) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    else wave_fence();
+  };
+  for (int64_t a = lane; a < n; a += 64) put(a, a == root ? 0 : -1);
   // level-synchronous BFS by edge relaxation; writers of one level all store the same value.  The bio transform
   // (k < 0: substructure = the whole graph; l2 < 0: context = everything farther than l1, unreachable nodes included)
   // only has to know which nodes lie within l1 hops.
   const bool whole = k < 0, open_end = l2 < 0;
   const int depth = open_end ? (whole ? l1 : max(k, l1)) : max(k, l2);
   for (int level = 0; level < depth; ++level) {
-    wave_fence();
+    fence();
     bool grew = false;
-    for (int64_t q = lane; q < e; q += 64) {
-      const int64_t u = ei_all[es + q], v = ei_all[e_all + es + q];  // graph-local ids
-      if (ld_i32(&dist[n0 + u]) == level && ld_i32(&dist[n0 + v]) < 0) {
-        st_i32(&dist[n0 + v], level + 1);
+    auto relax = [&](int64_t u, int64_t v) {
+      if (get(u) == level && get(v) < 0) {
+        put(v, level + 1);
         grew = true;
       }
-    }
+    };
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (lane + 64 * j < e) relax(cu[j], cv[j]);
+    for (int64_t q = lane + 128; q < e; q += 64) relax(ei_all[es + q], ei_all[e_all + es + q]);
     if (!__any(grew)) break;
   }
-  wave_fence();
+  fence();
   // ranks of the kept atoms / bonds (stable, by wave ballots), and the five counts
   int n_sub = 0, n_ctx = 0, n_ov = 0;
   for (int64_t b0 = 0; b0 < n; b0 += 64) {
     const int64_t a = b0 + lane;
-    const int d = a < n ? ld_i32(&dist[n0 + a]) : -1;
+    const int d = a < n ? get(a) : -1;
     const bool s = a < n && (whole || (d >= 0 && d <= k));
     const bool c = a < n && (open_end ? (d < 0 || d > l1) : (d > l1 && d <= l2));
     int ts, tc, to;
@@ -350,18 +382,32 @@ __global__ void __launch_bounds__(256) k_ctx_plan(const int64_t* __restrict__ id
     if (a < n) {
       st_i32(&sub_rank[n0 + a], s ? n_sub + rs : -1);
       st_i32(&ctx_rank[n0 + a], c ? n_ctx + rc : -1);
+      if (lds) {
+        st_i32(&dist[n0 + a], d);                   // (the distances as the global path leaves them)
+        lds_st(&sd[a], (s ? 1 : 0) | (c ? 2 : 0));  // from here on: membership flags (each lane rewrites the slot it has just read)
+      }
     }
     n_sub += ts; n_ctx += tc; n_ov += to;
   }
-  wave_fence();
+  fence();
   int e_sub = 0, e_ctx = 0;
+  auto member = [&](int64_t u, int64_t v, bool& s, bool& c) {
+    if (lds) {
+      const int fu = lds_ld(&sd[u]), fv = lds_ld(&sd[v]);
+      s = (fu & fv & 1) != 0;
+      c = (fu & fv & 2) != 0;
+    } else {
+      s = ld_i32(&sub_rank[n0 + u]) >= 0 && ld_i32(&sub_rank[n0 + v]) >= 0;
+      c = ld_i32(&ctx_rank[n0 + u]) >= 0 && ld_i32(&ctx_rank[n0 + v]) >= 0;
+    }
+  };
   for (int64_t b0 = 0; b0 < e; b0 += 64) {
     const int64_t q = b0 + lane;
     bool s = false, c = false;
     if (q < e) {
-      const int64_t u = ei_all[es + q], v = ei_all[e_all + es + q];
-      s = ld_i32(&sub_rank[n0 + u]) >= 0 && ld_i32(&sub_rank[n0 + v]) >= 0;
-      c = ld_i32(&ctx_rank[n0 + u]) >= 0 && ld_i32(&ctx_rank[n0 + v]) >= 0;
+      if (b0 == 0) member(cu[0], cv[0], s, c);
+      else if (b0 == 64) member(cu[1], cv[1], s, c);
+      else member(ei_all[es + q], ei_all[e_all + es + q], s, c);
     }
     int ts, tc;
     const int rs = wave_excl_rank(s, lane, &ts), rc = wave_excl_rank(c, lane, &tc);
