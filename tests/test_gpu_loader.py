@@ -275,6 +275,40 @@ def test_substruct_context_matches_host_extraction(k, l1, l2):
     _same(out, want, CTX_KEYS)
 
 
+def _big_graph(n, chords, seed):
+    """a chain of n atoms with `chords` extra bonds (both directions stored, as the datasets have them)"""
+    rng = np.random.default_rng(seed)
+    pairs = [(i, i + 1) for i in range(n - 1)]
+    while len(pairs) < n - 1 + chords:
+        a, b = (int(v) for v in rng.integers(0, n, size=2))
+        if a != b:
+            pairs.append((a, b))
+    src = [a for a, b in pairs] + [b for a, b in pairs]
+    dst = [b for a, b in pairs] + [a for a, b in pairs]
+    e = len(src)
+    return Data(x=torch.stack([torch.from_numpy(rng.integers(0, 119, size=n)), torch.from_numpy(rng.integers(0, 3, size=n))], 1),
+                edge_index=torch.tensor([src, dst], dtype=torch.int64),
+                edge_attr=torch.stack([torch.from_numpy(rng.integers(0, 4, size=e)), torch.from_numpy(rng.integers(0, 3, size=e))], 1))
+
+
+def test_substruct_context_on_graphs_beyond_the_lds_window():
+    """k_ctx_plan keeps the BFS distances of a graph in its wave's LDS slice up to 1 024 nodes and a lane's first two bonds in
+    registers (round 5); beyond, distances stay in global memory and further bonds are re-read: a 1 500-atom chain with chords
+    (global path), a 900-atom one with 700 bonds (LDS path, eleven bonds per lane) and molecules in one batch, against the host
+    extraction, every field bit for bit"""
+    graphs = _chem_graphs(6, seed=31) + [_big_graph(1500, 40, 32), _big_graph(900, 250, 33), _big_graph(1024, 5, 34), _big_graph(1025, 5, 35)]
+    rng = np.random.default_rng(36)
+    ids = np.array([6, 0, 7, 3, 8, 9, 6, 5])
+    roots = [int(rng.integers(0, graphs[i].x.size(0))) for i in ids]
+    for k, l1, l2 in ((5, 4, 7), (9, 6, 12)):
+        want = hostdata.collate_substruct_context(
+            [hostdata.extract_substruct_context(graphs[i], rng, k=k, l1=l1, l2=l2, root=r) for i, r in zip(ids, roots)])
+        ds = resident.ResidentDataset.from_graphs(graphs, DEV, relabel=False)
+        out = ds.collate_substruct_context(ids, k=k, l1=l1, l2=l2, roots=roots)
+        ds.check(out)
+        _same(out, want, CTX_KEYS)
+
+
 def test_substruct_context_all_graphs_dropped():
     """k < l1: substructure and context rings cannot overlap, every graph is dropped -> empty batch"""
     ds = resident.ResidentDataset.from_graphs(_chem_graphs(9, seed=14), DEV, relabel=False)
