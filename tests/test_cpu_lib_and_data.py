@@ -380,3 +380,44 @@ def test_smiles_order_generator_follows_the_survey_shape_statistics():
         assert torch.equal(ei[:, 0::2], ei[:, 1::2].flip(0)) and torch.equal(g.edge_attr[0::2], g.edge_attr[1::2])
         assert int(torch.bincount(ei[0], minlength=g.x.size(0)).max()) <= 4
         assert int(ei.max()) < g.x.size(0)
+
+
+def test_stack_parameter_list_and_batchnorm_meta_follow_the_modules():
+    """host plumbing of the one-call chem GIN network (ops.chem_gin_stack): the 8 parameters per layer come from remembered
+    sub-modules re-checked by identity (round 5: forty `conv.mlp[0].weight`-style reads through nn.Module.__getattr__ were 45 us per
+    call); a replaced sub-module or Parameter must be picked up at the next call, and the BatchNorm metadata must be the buffers
+    themselves with nn.BatchNorm1d's counting rules (chem/model.py:258-277 under torch's BatchNorm1d.forward)."""
+    from pretrain_gnns_amd import ops
+    from pretrain_gnns_amd.chem import model as hmodel
+
+    torch.manual_seed(0)
+    m = hmodel.GNN(3, 16, gnn_type="gin")
+    convs, bns = m.gnns, m.batch_norms
+
+    def slow():
+        return [t for conv, bn in zip(convs, bns) for t in (
+            conv.edge_embedding1.weight, conv.edge_embedding2.weight, conv.mlp[0].weight, conv.mlp[0].bias,
+            conv.mlp[2].weight, conv.mlp[2].bias, bn.weight, bn.bias)]
+
+    plan = ops.StackPlan()
+    for _ in range(2):  # first call builds the cache, second uses it
+        got = ops._chem_gin_flat(plan, convs, bns)
+        assert len(got) == 24 and all(a is b for a, b in zip(got, slow()))
+    convs[1].mlp[0] = torch.nn.Linear(16, 32)          # a replaced sub-module
+    bns[2].weight = torch.nn.Parameter(torch.ones(16))  # a replaced Parameter
+    convs[0].edge_embedding2 = torch.nn.Embedding(3, 16)
+    for _ in range(2):
+        got = ops._chem_gin_flat(plan, convs, bns)
+        assert all(a is b for a, b in zip(got, slow()))
+
+    m.train()
+    before = [int(bn.num_batches_tracked) for bn in bns]
+    meta = ops._bn_meta(bns)  # CPU counters: incremented here, one foreach launch
+    assert [int(bn.num_batches_tracked) for bn in bns] == [b + 1 for b in before]
+    for (rm, rv, momentum, eps, counter), bn in zip(meta, bns):
+        assert rm is bn.running_mean and rv is bn.running_var and momentum == bn.momentum and eps == bn.eps and counter is None
+    m.eval()
+    ops._bn_meta(bns)
+    assert [int(bn.num_batches_tracked) for bn in bns] == [b + 1 for b in before]  # eval: no counting
+    free = torch.nn.ModuleList([torch.nn.BatchNorm1d(16, track_running_stats=False)])
+    assert ops._bn_meta(free)[0][:2] == (None, None)
