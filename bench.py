@@ -2,8 +2,9 @@
 """Benchmark of the hot path: edges/sec through the 5-layer GIN (emb_dim 300) masking pre-train step.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
-          --master-port P bench.py --gpus N --steps K --warmup W)
+  N > 1 either way: under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+  --master-port P bench.py --gpus N ...: WORLD_SIZE is set, this process is one rank), or bare (`python bench.py --gpus 8`:
+  WORLD_SIZE is unset, bench.py starts the N ranks itself through the same launcher on a free port -- self_launch()).
 
 One "step" = the loop body of the reference train() (chem/pretrain_masking.py:47-76): GNN forward
 (CSR build + 5 x [aggregation, mlp, BatchNorm]) -> masked-atom head -> float64 CE -> backward ->
@@ -958,7 +959,45 @@ class _StdoutToStderr:
         os.close(self.saved)
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start the N ranks ourselves -- the same
+    command line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>`
+    (one process per GPU, RCCL), pass rank 0's ONE JSON line through and return the launcher's exit status.  A rank that does not
+    come back: every rank dumps its Python stacks after PGNN_BENCH_WATCHDOG seconds (main() below) and exits 1, torchrun then
+    ends the others; the launcher itself is killed (whole process group) 60 s after that."""
+    import signal
+    import subprocess
+    wd = float(os.environ.get("PGNN_BENCH_WATCHDOG", "900"))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", str(max(1, usable_cores() // n))), PGNN_BENCH_SELF_LAUNCHED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without a launcher: starting %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=wd + 60 if wd > 0 else None)
+    except subprocess.TimeoutExpired:
+        print("bench.py: the %d-rank launch did not end within %.0f s: killing its process group" % (n, wd + 60), file=sys.stderr, flush=True)
+        os.killpg(proc.pid, signal.SIGKILL)
+        proc.wait()
+        return 1
+    except KeyboardInterrupt:
+        os.killpg(proc.pid, signal.SIGTERM)
+        raise
+
+
 def main():
+    if "WORLD_SIZE" not in os.environ:
+        n = parse().gpus
+        if n > 1:
+            sys.exit(self_launch(n))
     # a run that does not come back is worse than one that fails: after PGNN_BENCH_WATCHDOG seconds (default 900, 0 = off; a default
     # run takes ~70 s) every thread's Python stack goes to stderr and the process exits with status 1
     wd = float(os.environ.get("PGNN_BENCH_WATCHDOG", "900"))
@@ -979,8 +1018,7 @@ def _run():
 
     rank, local, world = parallel.init_from_env()
     if world != args.gpus:
-        if args.gpus > 1 and world == 1:
-            raise SystemExit("--gpus %d needs a torchrun launch (see the module docstring)" % args.gpus)
+        raise SystemExit("--gpus %d inside a launch of WORLD_SIZE=%d ranks" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -1065,6 +1103,9 @@ def _run():
     gc.enable()
 
     comm = parallel.comm_report(opts) if dist.is_initialized() else {"initialized": False, "world": 1}
+    if dist.is_initialized():
+        comm["launched_by"] = "bench.py itself (self_launch)" if os.environ.get("PGNN_BENCH_SELF_LAUNCHED") == "1" else "the caller's launcher"
+        comm["overlap_default"] = "off: the all-reduce under the backward is opt-in (PGNN_DP_OVERLAP=1) because no two-GPU RCCL run of it exists"
     if isinstance(opts, parallel.AllReduceOptimizers) and opts.overlap_layer is not None:
         comm["overlap"] = {"from_layer": opts.overlap_layer, "steps_behind_the_milestone": opts.overlapped_steps,
                            "head_bytes": opts.bucket.split * 4}

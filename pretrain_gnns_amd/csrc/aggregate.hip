@@ -340,10 +340,14 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 // NROW = ceil(8*gs/64) row-DMA instructions per step when known at compile time (their per-lane
 // byte offsets are then hoisted into registers: the loader issues a step with ~2 instructions per
 // KiB); NROW = 0 selects a generic run-time loop for other feature widths.
-// PRE: the rows of x are pre-activations z of the previous layer's BatchNorm; every row read from LDS (or
-// from memory on the slow path) becomes relu?(a*z + b) with the SAME fmaf/fmaxf expression k_bn_apply
-// uses, so the previous layer's output is never materialised and the sums are bit-identical to
-// aggregating the materialised tensor.
+// PRE: the rows of x are pre-activations z of the previous layer's BatchNorm; every row becomes relu?(a*z + b) with the SAME
+// fmaf/fmaxf expression k_bn_apply uses, so the previous layer's output is never materialised and the sums are bit-identical to
+// aggregating the materialised tensor.  Round 6: a landed ring region is activated ONCE, IN PLACE, BY THE LOADER WAVE between its
+// vmcnt wait and the barrier that publishes the region (8 rows = 16 ds_read_b128 / ds_write_b128 of a wave that would otherwise sit at
+// the barrier) -- the consumers read activated rows, their inner loop and register count are the plain instance's, and two blocks
+// stay resident per CU (rounds 3-5 activated every gathered row in the consumers, 3.2 times per row: 86 VGPRs = 5 waves per SIMD = ONE
+// 11-wave block per CU, 337.7 us against the plain instance's 215 us on the same bytes).  Rows that bypass the ring (far sources) are
+// activated where they are used, with the coefficients kept in LDS.  POL bit 5 keeps the consumer-side activation for A/B builds.
 // POL (cache / scheduling policy, A/B-measured through PGNN_DMA_POL; 0 = none):
 //   bit 0: row DMAs carry the non-temporal hint (every row of x is read once per block)
 //   bit 1: result rows are stored non-temporally (written once, never re-read by this kernel)
@@ -398,7 +402,7 @@ __device__ __forceinline__ void agg_tail_finish(const AggTail& tail, float* redL
 }
 
 template <bool TABLE, int P, int NROW, bool PRE, int POL, bool WEIGHT, bool TAIL = false>
-__global__ void __launch_bounds__(704)
+__global__ void __launch_bounds__(704, (PRE || TAIL) ? 6 : 1)
 k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ ptr,
                 const int32_t* __restrict__ nbr, const uint8_t* __restrict__ code,
                 const float* __restrict__ emb1, const float* __restrict__ emb2, float* __restrict__ out,
@@ -417,6 +421,8 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
   constexpr int NREG = P + 3, NBUF = P + 1 + EL;
   constexpr int AUX = (POL & 1) ? 2 : 0;
   constexpr bool PROF = (POL & 8) != 0;
+  constexpr bool LACT = PRE && (POL & 32) == 0;  // the loader activates landed regions in place (POL bit 5: the consumers do, per gathered row)
+  static_assert(!(PRE && (WEIGHT || TAIL)), "the BatchNorm-on-read coefficients sit where dinv / the tail's column sums would");
   unsigned long long t_begin = 0;
   if (PROF) t_begin = __builtin_readcyclecounter();
   extern __shared__ __align__(16) float smem[];
@@ -431,6 +437,8 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
   int* farL = codeL + NBUF * kDmaEdges;  // (PF; never together with WEIGHT) [NBUF][2]: bit k = staged edge slot k of the step is far
   unsigned* amaxL = reinterpret_cast<unsigned*>(farL + 16);  // (tail.amax) [2][8]: the row maxima of the step in flight / being flushed
   float* redL = reinterpret_cast<float*>(farL + 32);  // (TAIL; never together with WEIGHT) [8][2][dim]: the node slots' column sums
+  float* coefL = redL;                                // (PRE; never together with TAIL or WEIGHT) [2][dim]: a, b of y = a z + b
+  float* tailL = redL + kDmaG * 2 * dim + 16;         // (TAIL) [4][dim]: a, b, mean, invstd of the BatchNorm below
   const float4* __restrict__ T4 = reinterpret_cast<const float4*>(T);
   const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
   const int64_t ldx4 = ldx >> 2, ldo4 = ldo >> 2;
@@ -491,11 +499,75 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
       if (TABLE)
         __builtin_amdgcn_global_load_lds(PGNN_GPTR(code + p), PGNN_LPTR(codeL + (s % NBUF) * kDmaEdges), 1, 0, 0);
     };
+    // (LACT) lane l owns float4 column l of a region's eight rows (lanes < gs); the columns from 64 on -- 8 x (gs - 64) float4, 88 at
+    // D = 300 -- are dealt flat over the lanes, two per lane at most (gs <= 80), so a region costs 10 ds_read_b128 + 10 ds_write_b128
+    // instead of 16 + 16 with eleven lanes live in half of them.  Inline asm for the LDS traffic: behind a C++ ds_read hipcc drains
+    // vmcnt to 0 on this path (every DMA in flight), and the waits below are the only ones needed.
+    v4f_t ca0 = {0.f, 0.f, 0.f, 0.f}, cb0 = ca0;
+    const int wide = max(gs - kWave, 0), nwide = kDmaG * wide;  // float4 columns past the first 64, and how many float4 that is per region
+    const bool act0 = lane < gs, act1 = lane < nwide, act2 = lane + kWave < nwide;
+    unsigned woff1 = 0, woff2 = 0;  // byte offsets of this lane's one or two wide float4 inside a region,
+    unsigned wc1 = 0, wc2 = 0;      // and the LDS addresses of their columns' a (b: + dim * 4) in coefL (kept there: registers are the consumers')
+    if (LACT) {
+      const v4f_t* pc = reinterpret_cast<const v4f_t*>(pre_coef);
+      const unsigned cl = (unsigned)(unsigned long long)PGNN_LPTR(coefL);
+      if (act0) { ca0 = pc[lane]; cb0 = pc[gs + lane]; }
+      if (act1) { const int r = lane / wide, c = kWave + lane - r * wide; wc1 = cl + (unsigned)c * 16u; woff1 = (unsigned)(r * gs + c) * 16u; }
+      if (act2) { const int i = lane + kWave, r = i / wide, c = kWave + i - r * wide; wc2 = cl + (unsigned)c * 16u; woff2 = (unsigned)(r * gs + c) * 16u; }
+    }
+    auto act4 = [&](v4f_t& v, const v4f_t& a, const v4f_t& b) {  // the expression of k_bn_apply
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float y = fmaf(a[c], v[c], b[c]);
+        if (pre_relu) y = fmaxf(y, 0.f);
+        v[c] = y;
+      }
+    };
+    auto activate = [&](int q) {  // the region of load-step q, landed and not yet published
+      const int r0 = n0 + q * kDmaG;
+      const unsigned region = (unsigned)(unsigned long long)PGNN_LPTR(ring + (((max(r0, 0)) >> 3) % NREG) * row_f4);
+      const unsigned base = region + (unsigned)lane * 16u, rb = (unsigned)gs * 16u;
+      v4f_t w1 = {0.f, 0.f, 0.f, 0.f}, w2 = w1, ca1 = w1, cb1 = w1, ca2 = w1, cb2 = w1;
+      const unsigned cbo = (unsigned)dim * 4u;
+      if (act1) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(w1) : "v"(region + woff1) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(ca1) : "v"(wc1) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(cb1) : "v"(wc1 + cbo) : "memory");
+      }
+      if (act2) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(w2) : "v"(region + woff2) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(ca2) : "v"(wc2) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(cb2) : "v"(wc2 + cbo) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w1), "+v"(w2), "+v"(ca1), "+v"(cb1), "+v"(ca2), "+v"(cb2)::"memory");
+      if (act1) { act4(w1, ca1, cb1); asm volatile("ds_write_b128 %0, %1" ::"v"(region + woff1), "v"(w1) : "memory"); }
+      if (act2) { act4(w2, ca2, cb2); asm volatile("ds_write_b128 %0, %1" ::"v"(region + woff2), "v"(w2) : "memory"); }
+      if (act0) {
+#pragma unroll
+        for (int h = 0; h < kDmaG; h += 4) {  // four rows in flight (the register count of the kernel stays the consumers')
+          v4f_t v[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1" : "=v"(v[g]) : "v"(base + (h + g) * rb) : "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            act4(v[g], ca0, cb0);
+            asm volatile("ds_write_b128 %0, %1" ::"v"(base + (h + g) * rb), "v"(v[g]) : "memory");
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the barrier that follows publishes the region)
+    };
     if (n0 > 0) issue_rows(-1);
     for (int q = 0; q <= P; ++q) issue_rows(q);
     for (int q = 0; q < P + EL; ++q) issue_edges(q, ptr[min(n0 + q * kDmaG, n1)]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // prologue: T, ptrL (consumers) and the first window (loader) are in LDS
+    __syncthreads();  // prologue: T, ptrL, coefL (consumers) and the first window (loader) are in LDS
+    if (LACT) {
+      if (n0 > 0) activate(-1);
+      activate(0);  // (region s + 1 is step s's, below)
+      __syncthreads();
+    }
     unsigned long long c_wait = 0, c_bar = 0, c_issue = 0;
     for (int s = 0; s < nsteps; ++s) {
       unsigned long long t0 = 0, t1 = 0, t2 = 0;
@@ -517,6 +589,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
           farL[(sn % NBUF) * 2 + 1] = (int)(unsigned)(m >> 32);
         }
       }
+      if (LACT) activate(s + 1);      // rows <= s + 1 have landed; the consumers of step s are the first to read region s + 1
       if (PROF) t1 = __builtin_readcyclecounter();
       __syncthreads();                // B(s)
       if (PROF) t2 = __builtin_readcyclecounter();
@@ -543,12 +616,16 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
   const int g = t / gs, c4 = t - g * gs;
   const bool active = g < kDmaG;
   float4 pa = f4_zero(), pb = f4_zero();
-  if (PRE && active) {
+  if (PRE && !LACT && active) {
     pa = reinterpret_cast<const float4*>(pre_coef)[c4];
     pb = reinterpret_cast<const float4*>(pre_coef + dim)[c4];
   }
-  auto act = [&](float4 v) {
+  auto act = [&](float4 v) {  // a row that did not pass through the ring (LACT: coefficients from LDS, this is the rare path)
     if (PRE) {
+      if (LACT) {
+        pa = reinterpret_cast<const float4*>(coefL)[c4];
+        pb = reinterpret_cast<const float4*>(coefL + dim)[c4];
+      }
       v = make_float4(fmaf(pa.x, v.x, pb.x), fmaf(pa.y, v.y, pb.y), fmaf(pa.z, v.z, pb.z), fmaf(pa.w, v.w, pb.w));
       if (pre_relu) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -556,6 +633,9 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
     }
     return v;
   };
+  auto act_ring = [&](float4 v) { return LACT ? v : act(v); };  // a row read from the ring
+  if (LACT)
+    for (int q = t; q < 2 * dim; q += cthreads) coefL[q] = pre_coef[q];
   if (TABLE) {
     for (int q = t; q < kNumCodes * dim; q += cthreads) {
       const int c = q / dim, d = q - c * dim;
@@ -569,17 +649,21 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
       const int r = n0 - kDmaG + q;
       dinvL[q] = (r >= 0 && r < n) ? dinv[r] : 0.f;
     }
-  __syncthreads();  // prologue
-
-  // (TAIL) forward coefficients y = a z + b of the BatchNorm below, recomputed exactly as k_bn_bwd_partial recomputes them
-  float4 ta = f4_zero(), tb = f4_zero(), tmu = f4_zero(), tis = f4_zero(), ts1 = f4_zero(), ts2 = f4_zero();
-  if (TAIL && active) {
+  // (TAIL) forward coefficients y = a z + b of the BatchNorm below, recomputed exactly as k_bn_bwd_partial recomputes them.  They live
+  // in LDS (tailL [4][dim]: a, b, mean, invstd), not in 16 registers per thread: with them the instance needed 93 VGPRs = 5 waves
+  // per SIMD = ONE 11-wave block per CU (rounds 4-5: 325.8 us); four ds_read_b128 per node row buy the second resident block.
+  float4 ts1 = f4_zero(), ts2 = f4_zero();
+  if (TAIL && g == 0 && c4 < gs) {
     const float4 gm = reinterpret_cast<const float4*>(tail.gamma)[c4], bt = reinterpret_cast<const float4*>(tail.beta)[c4];
-    tmu = reinterpret_cast<const float4*>(tail.save_mean)[c4];
-    tis = reinterpret_cast<const float4*>(tail.save_invstd)[c4];
-    ta = make_float4(tis.x * gm.x, tis.y * gm.y, tis.z * gm.z, tis.w * gm.w);
-    tb = make_float4(fmaf(-tmu.x, ta.x, bt.x), fmaf(-tmu.y, ta.y, bt.y), fmaf(-tmu.z, ta.z, bt.z), fmaf(-tmu.w, ta.w, bt.w));
-    if (blockIdx.x == 0 && g == 0) {
+    const float4 tmu = reinterpret_cast<const float4*>(tail.save_mean)[c4];
+    const float4 tis = reinterpret_cast<const float4*>(tail.save_invstd)[c4];
+    const float4 ta = make_float4(tis.x * gm.x, tis.y * gm.y, tis.z * gm.z, tis.w * gm.w);
+    const float4 tb = make_float4(fmaf(-tmu.x, ta.x, bt.x), fmaf(-tmu.y, ta.y, bt.y), fmaf(-tmu.z, ta.z, bt.z), fmaf(-tmu.w, ta.w, bt.w));
+    reinterpret_cast<float4*>(tailL)[c4] = ta;
+    reinterpret_cast<float4*>(tailL + dim)[c4] = tb;
+    reinterpret_cast<float4*>(tailL + 2 * dim)[c4] = tmu;
+    reinterpret_cast<float4*>(tailL + 3 * dim)[c4] = tis;
+    if (blockIdx.x == 0) {
       float* coef = tail.fold.coef;
       reinterpret_cast<float4*>(coef)[c4] = ta;
       reinterpret_cast<float4*>(coef + dim)[c4] = tb;
@@ -587,6 +671,9 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
       reinterpret_cast<float4*>(coef + 3 * dim)[c4] = tis;
     }
   }
+  __syncthreads();  // prologue
+  if (LACT) __syncthreads();  // (the loader has activated the rows of regions -1 and 0 with the coefficients published above)
+
   // per-step row pointers are read one step ahead (they sit in LDS for the whole block), so the chain
   // after a barrier is only: edge indices -> rows -> adds -> store
   int nb_e0 = ptrL[0], nb_beg = 0, nb_end = 0;
@@ -625,7 +712,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
     float4 zrow = f4_zero();
     if (TAIL) zrow = reinterpret_cast<const float4*>(tail.z + (int64_t)i * tail.ldz)[c4];  // (lands under the edge loop)
     // the node's own row (self loop) does not depend on the edge list: fetch it first
-    float4 self = act(ring[slot_of(i) * gs + c4]);
+    float4 self = act_ring(ring[slot_of(i) * gs + c4]);
     if (TABLE) self = f4_add(self, T4[kSelfLoopCode * gs + c4]);
     float di = 1.f;
     if (WEIGHT) {
@@ -684,7 +771,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
           if (p + j < end) {
             v[j] = ring[slot_of(sidx[j]) * gs + c4];
             if (PF) {
-              if (psel[j] >= 0) v[j] = psel[j] == 0 ? pf0 : pf1;
+              if (psel[j] >= 0) v[j] = LACT ? act(psel[j] == 0 ? pf0 : pf1) : (psel[j] == 0 ? pf0 : pf1);
             }
             if (TABLE) tv[j] = T4[cd[j] * gs + c4];
           }
@@ -692,7 +779,7 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
           if (p + j < end) {
-            float4 m = act(v[j]);
+            float4 m = act_ring(v[j]);
             if (TABLE) m = f4_add(m, tv[j]);
             if (WEIGHT) m = f4_scale(m, di * dinvL[sidx[j] - n0 + kDmaG]);
             acc = f4_add(acc, m);
@@ -735,7 +822,9 @@ k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restr
       atomicMax(amaxL + (s & 1) * kDmaG + g, __float_as_uint(fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w)))));
     if (TAIL) {  // the same expressions as k_bn_bwd_partial's
       float4 gq = acc;
+      const float4 tmu = reinterpret_cast<const float4*>(tailL + 2 * dim)[c4], tis = reinterpret_cast<const float4*>(tailL + 3 * dim)[c4];
       if (tail.relu) {
+        const float4 ta = reinterpret_cast<const float4*>(tailL)[c4], tb = reinterpret_cast<const float4*>(tailL + dim)[c4];
         if (!(fmaf(ta.x, zrow.x, tb.x) > 0.f)) gq.x = 0.f;
         if (!(fmaf(ta.y, zrow.y, tb.y) > 0.f)) gq.y = 0.f;
         if (!(fmaf(ta.z, zrow.z, tb.z) > 0.f)) gq.z = 0.f;
@@ -774,7 +863,8 @@ int launch_aggregate_dma_p(const float* x, int64_t ldx, const int32_t* ptr, cons
   const int threads = cthreads + kWave;
   const size_t lds = (size_t)(TABLE ? kNumCodes * dim : 0) * 4 + (size_t)(P + 3) * kDmaG * dim * 4 +
                      (size_t)(kDmaMaxNodes + 4) * 4 + (size_t)2 * (P + 1 + ((POL & 16) ? 1 : 0)) * kDmaEdges * 4 +
-                     (WEIGHT ? (size_t)(kDmaMaxNodes + 3 * kDmaG) * 4 : 0) + 128 + (TAIL ? (size_t)kDmaG * 2 * dim * 4 + 64 : 0);
+                     (WEIGHT ? (size_t)(kDmaMaxNodes + 3 * kDmaG) * 4 : 0) + 128 + (TAIL ? (size_t)(kDmaG * 2 + 4) * dim * 4 + 64 : 0) +
+                     (PRE ? (size_t)2 * dim * 4 : 0);
   const int resident = (int)std::max<size_t>(1, (160 * 1024) / lds);
   const int64_t target_blocks = (int64_t)num_cu() * std::min(resident, env_int("PGNN_DMA_BPC", 2));
   int64_t npb = ceil_div(n, target_blocks);

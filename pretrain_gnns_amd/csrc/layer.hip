@@ -58,6 +58,18 @@ Side* side_for_current_device() {
   return &s;
 }
 inline bool use_side_stream() { return env_knob("PGNN_SIDE_STREAM", 1) != 0; }
+// Is `st` being captured into a HIP graph?  The completion event of a hipExtLaunchKernelGGL dispatch is NOT a capture edge: under
+// capture a hipStreamWaitEvent on it orders nothing, and the side stream's weight gradients then read dz / dhid of an earlier replay
+// (hipgraph_replay's loss went 0.37 -> 0.99 and stopped being bit-stable once the fork became the product's own
+// dispatch).  While capturing, the fork is an ordinary hipEventRecord behind the product.
+inline bool stream_is_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+    (void)hipGetLastError();
+    return true;  // (cannot tell: take the path that is correct either way)
+  }
+  return cs != hipStreamCaptureStatusNone;
+}
 // PGNN_SIDE_MIN_ROWS: rows below which the one-call chem GIN backward stays on the caller's stream.  0 (always fork) is the default: a
 // fork / lag / join costs the host ~25 us per layer (four event calls), and whether the overlap pays below ~5 000 rows depends on the
 // box -- the context-prediction step (4 1xx + 1 9xx rows) measures 1.30-1.38 ms forked against 1.46 on one stream on most boxes,
@@ -671,7 +683,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   if (bond_in_dw && (rc = pad_rowfeat12(cfeat, 9, cfeat12, n, aux))) return rc;
   const bool tr = ntr > 0 && use_transposed_weights(n);
   const bool fused_mlp = wp && mlp_fused(n, dim, 2 * dim, dim);
-  const bool fork_via_launch = env_knob("PGNN_FORK_VIA_LAUNCH", 1) != 0;
+  const bool fork_via_launch = env_knob("PGNN_FORK_VIA_LAUNCH", 1) != 0 && sd && !stream_is_capturing(main);
 
   const float* g = dy;
   int64_t ldg = lddy;
@@ -1148,7 +1160,7 @@ int pgnn_bio_gin_stack_bwd(const float* dy, int64_t lddy, const int32_t* out_ptr
     if ((rc = pgnn_bn_bwd(dhid[b], 2 * dim, pre, 2 * dim, p.gamma, p.beta, st, st + 2 * dim, training, 1, dpre[b], 2 * dim,
                           p.dgamma, p.dbeta, 0.f, 0, n, 2 * dim, op, opb, main))) return rc;
     // (fork[1] as the completion of this product's own dispatch where a two-plane kernel runs it: see pgnn_chem_gin_stack_bwd)
-    const bool fork_via_launch = sd && wp && two_planes() && env_knob("PGNN_FORK_VIA_LAUNCH", 1) != 0;
+    const bool fork_via_launch = sd && wp && two_planes() && env_knob("PGNN_FORK_VIA_LAUNCH", 1) != 0 && !stream_is_capturing(main);
     if (fork_via_launch) set_next_launch_stop_event(sd->fork[1]);
     if (wp) rc = stack_bwd_data_wp(dpre[b], 2 * dim, wp1[l], nullptr, 0, dagg[b], 2 * dim, n, 2 * dim, 2 * dim, main);
     else if (tr && q < ntr) rc = pgnn_linear_bwd_data_t(dpre[b], 2 * dim, w1t[q], nullptr, 0, dagg[b], 2 * dim, n, 2 * dim, 2 * dim, main);

@@ -214,3 +214,23 @@ def test_grad_bucket_lays_late_parameters_behind_the_rest():
         off += p.numel()
     opts = parallel.AllReduceOptimizers([torch.optim.Adam(params)], overlap=(gnn, 2))
     assert opts.overlap_layer is None and opts.comm_stream is None and opts.bucket.n_early == len(opts.bucket.params)
+
+
+def test_bench_gpus_n_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset) must start its two ranks itself
+    instead of exiting.  Without a GPU the ranks end in bench.py's own "needs an MI355X" assertion -- which proves both were
+    started with RANK / WORLD_SIZE set, and that the launcher's failure status comes back as bench.py's."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("the GPU suite runs the literal command to completion (test_gpu_parallel.py)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PGNN_BENCH_WATCHDOG"] = "120"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "--gpus 2 without a launcher: starting" in p.stderr and "--nproc-per-node 2" in p.stderr
+    assert p.stderr.count("bench.py needs an MI355X") >= 2, p.stderr[-3000:]  # both ranks got as far as the device check
+    assert "needs a torchrun launch" not in p.stderr

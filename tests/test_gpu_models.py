@@ -419,6 +419,37 @@ def test_hip_graph_replay_of_the_masking_step_equals_eager_steps(readback):
     assert int(opts_b[0].step_count) == 5
 
 
+def test_hip_graph_replay_at_the_benchmarked_batch_takes_the_same_path_and_is_deterministic():
+    """The capture test above runs 24 graphs (~550 rows): below the two-plane products' 48-tile threshold and below
+    PGNN_DW_PAIR_MIN_ROWS, so the captured step never met the fork that is a product's own dispatch (hipExtLaunchKernelGGL's stop
+    event), the paired weight-gradient launch with the bond columns or the deferred bond-table launch -- and a lost fork edge under
+    capture went through the suite (replayed loss 0.99 against 0.37, different from run to run).  256 graphs, the
+    benchmarked batch: 3 warm-up + 3 replays against 6 eager steps, parameters equal; and two independent captures from the same
+    state replay to the same bits."""
+    import copy
+    from pretrain_gnns_amd import optim, train as ptrain
+    hchem, _ = _hip()
+    torch.manual_seed(21)
+    mods_a = [hchem.GNN(5, 300).to(DEV), torch.nn.Linear(300, 119).to(DEV), torch.nn.Linear(300, 4).to(DEV)]
+    mods_b, mods_c = copy.deepcopy(mods_a), copy.deepcopy(mods_a)
+    b = hostdata.chem_masking_batch(256, seed=22).to(DEV)
+    opts_a = optim.Adam.shared([m.parameters() for m in mods_a], lr=1e-3)
+    eager = [ptrain.chem_masking_step(mods_a, opts_a, b) for _ in range(6)]
+    replayed = []
+    for mods in (mods_b, mods_c):
+        opts = optim.Adam.shared([m.parameters() for m in mods], lr=1e-3)
+        g = ptrain.GraphedChemMaskingStep(mods, opts, b, warmup=3, readback="end")
+        replayed.append([g(), g(), g()])
+        assert int(opts[0].step_count) == 6
+        torch.cuda.synchronize()
+    for want, have in zip(eager[3:], replayed[0]):
+        assert abs(want[0] - have[0]) <= 2e-5 * abs(want[0]) + 1e-7 and abs(want[1] - have[1]) <= 1e-12, (eager, replayed)
+    assert replayed[0] == replayed[1], replayed  # bit-stable from capture to capture
+    for pa, pb, pc in zip(mods_a[0].parameters(), mods_b[0].parameters(), mods_c[0].parameters()):
+        assert torch.equal(pb, pc)
+        torch.testing.assert_close(pa, pb, rtol=2e-5, atol=2e-6)
+
+
 def test_product_train_step_mirrors_oracle_step():
     """pretrain_gnns_amd.train (what bench.py times) == oracle.steps on the same HIP model, for both
     readback placements, including with torch's fused Adam."""

@@ -447,3 +447,29 @@ def test_bench_two_ranks_under_torchrun(overlap, tmp_path):
     if overlap == "1":
         ov = comm["overlap"]
         assert ov["from_layer"] == 2 and ov["steps_behind_the_milestone"] >= 12 and ov["head_bytes"] > 0
+
+
+def test_bench_gpus_2_launches_itself(tmp_path):
+    """The literal `python bench.py --gpus 2 --steps 5 --warmup 2` -- no torchrun in the command: bench.py starts
+    its two ranks itself (self_launch), here both on the one GPU of the box over gloo (PGNN_DP_BACKEND; RCCL refuses two ranks on a
+    device).  Rank 0's ONE JSON line names the world, the backend, every rank's own time, the bucket and the all-reduce."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PGNN_DP_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", PGNN_BENCH_WATCHDOG="400")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PGNN_DP_OVERLAP"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["steps"] == 5 and b["warmup"] == 2 and b["scaling"] == "weak" and b["value"] > 0
+    comm = b["comm"]
+    assert comm["world"] == 2 and comm["backend"] == "gloo" and comm["launched_by"].startswith("bench.py itself")
+    assert len(comm["ms_per_step_by_rank"]) == 2 and comm["ms_per_step_min"] <= comm["ms_per_step_max"]
+    assert comm["bucket_bytes"] > 7_000_000 and comm["allreduce_us"] > 0
+    assert "opt-in" in comm["overlap_default"]
