@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PGNN_ABI_VERSION 10
+#define PGNN_ABI_VERSION 11
 /* uint32 words behind every `counter` argument below: the arrival tickets of a launch whose last block folds the others'
  * results (one top word + up to 32 group words: same-address atomics retire at ~50 ns each, see csrc/common.h).  Zero before
  * the first call, left zero by every call; one buffer per device serves all calls of a stream. */
@@ -559,6 +559,18 @@ int pgnn_collate_graphs(const int64_t* graph_ids, int64_t num_graphs, int64_t da
                         const int64_t* edge_index_all, int64_t edges_all, const void* edge_attr_all,
                         int64_t attr_row_bytes, int64_t num_nodes, int64_t num_edges, void* x,
                         int64_t* edge_index, void* edge_attr, int64_t* batch, pgnn_stream stream);
+/* The batch's graph structure -- what pgnn_chem_graph_build / pgnn_bio_graph_build (gcn = 0) would compute from the collated
+ * edge_index / edge_attr -- by offset-add from ONE structure built over the whole resident dataset (ds_* arrays: that build's outputs
+ * on the dataset's graphs taken as one block-diagonal batch, i.e. dataset-global row pointers and node ids): a batch of whole graphs
+ * is block diagonal (chem/batch.py:31-52, bio/batch.py:70-106), so its CSRs are the per-graph CSRs concatenated.  Bit-identical to
+ * the per-batch build; replaces its histogram / scan / fill / sort launches (and the int64 COO as their input: SURVEY 8f rank 1) by
+ * one gather.  ds_in_code / in_code: chem only (both NULL for bio).  node_off / edge_off: from pgnn_batch_offsets. */
+int pgnn_collate_structure(const int64_t* graph_ids, int64_t num_graphs, int64_t dataset_graphs, const int64_t* node_slice,
+                           const int64_t* edge_slice, const int64_t* node_off, const int64_t* edge_off, const int32_t* ds_in_ptr,
+                           const int32_t* ds_in_src, const uint8_t* ds_in_code, const int32_t* ds_out_ptr, const int32_t* ds_out_dst,
+                           const float* ds_dinv, const float* ds_cfeat, int64_t cfeat_cols, int64_t num_nodes, int64_t num_edges,
+                           int32_t* in_ptr, int32_t* in_src, uint8_t* in_code, int32_t* out_ptr, int32_t* out_dst, float* dinv,
+                           float* cfeat, pgnn_stream stream);
 /* masked_indices [M]: per graph, its share of distinct items drawn uniformly (counter-based keys from
  * (seed, graph id, item): the same graph gets the same draw wherever it sits in a batch).
  * unit_div 1: items = atoms, unit_off = node_off, output = batch node positions (batch.py:39-40);

@@ -108,6 +108,8 @@ PROTOTYPES = {
     "pgnn_batch_offsets": (_i, [_p, _i64, _i64, _p, _p, ctypes.c_double, _i, _p, _p, _p, _i64, _i64, _i64, _p, _p]),
     "pgnn_collate_graphs": (_i, [_p, _i64, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _p,
                                  _p, _p]),
+    "pgnn_collate_structure": (_i, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p,
+                                    _p, _p, _p]),
     "pgnn_mask_select": (_i, [_p, _i64, _p, _i, _p, _i64, _u64, _p, _p]),
     "pgnn_mask_edges_apply": (_i, [_p, _i64, _p, _i64, _i64, _p, _p, _p]),
     "pgnn_mask_atoms_apply": (_i, [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _p]),
@@ -130,7 +132,7 @@ PROTOTYPES = {
     "pgnn_debug_aggregate_profile": (_i, [_p, _i64]),
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class GinLayer(ctypes.Structure):

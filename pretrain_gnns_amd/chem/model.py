@@ -172,7 +172,8 @@ class GNN(torch.nn.Module):
             raise ValueError("unmatched number of arguments.")
 
         # one structure build for all layers, forward and backward
-        graph = ops.build_chem_graph(edge_index, edge_attr, x.size(0), gcn=(self.gnn_type == "gcn"))
+        # (a batch of the resident loader brings it along, built by offset-add: ops.attach_graph)
+        graph = ops.build_chem_graph(edge_index, edge_attr, x.size(0), gcn=(self.gnn_type == "gcn"), reuse=True)
         exact_bn = getattr(self.batch_norms[0], "pgnn_exact", False)  # parallel.use_exact_batchnorm: per-layer path
         fused = self.gnn_type == "gin" and type(self.gnns[0]) is GINConv and self.batch_norms[0].affine and not exact_bn
         # F.dropout of the reference (chem/model.py:271-275) is fused into the BatchNorm(+ReLU) pass

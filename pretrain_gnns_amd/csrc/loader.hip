@@ -136,6 +136,46 @@ __global__ void __launch_bounds__(kBlock) k_gather_edges(const int64_t* __restri
   }
 }
 
+// The batch's graph structure by OFFSET-ADD ("emitting int32 CSR + packed attrs directly removes K1/K2").  A batch
+// is a block-diagonal union of whole graphs whose nodes and edges stay contiguous (chem/batch.py:31-52), so both CSRs of the batch
+// are the concatenation of the per-graph CSRs: row pointers shifted by the graph's edge offset, node ids by its node offset, bond
+// codes / per-node feature sums / normalisers copied.  The per-graph CSRs are slices of ONE structure built over the whole dataset
+// when it went to HBM (ds_* arrays, dataset-global positions) -- no histogram, scan or sort per batch.  One thread per output node
+// (p < n), per output edge (n <= p < n + e), and one for the two closing row pointers.
+__global__ void __launch_bounds__(kBlock) k_collate_structure(
+    const int64_t* __restrict__ ids, int64_t B, int64_t G, const int64_t* __restrict__ node_slice, const int64_t* __restrict__ edge_slice,
+    const int64_t* __restrict__ node_off, const int64_t* __restrict__ edge_off, const int32_t* __restrict__ ds_in_ptr,
+    const int32_t* __restrict__ ds_in_src, const uint8_t* __restrict__ ds_in_code, const int32_t* __restrict__ ds_out_ptr,
+    const int32_t* __restrict__ ds_out_dst, const float* __restrict__ ds_dinv, const float* __restrict__ ds_cfeat, int kc,
+    int32_t* __restrict__ in_ptr, int32_t* __restrict__ in_src, uint8_t* __restrict__ in_code, int32_t* __restrict__ out_ptr,
+    int32_t* __restrict__ out_dst, float* __restrict__ dinv, float* __restrict__ cfeat) {
+  const int64_t n = node_off[B], e = edge_off[B];
+  for (int64_t p = blockIdx.x * (int64_t)kBlock + threadIdx.x; p <= n + e; p += (int64_t)gridDim.x * kBlock) {
+    if (p < n) {
+      const int64_t g = find_graph(node_off, B, p);
+      const int64_t id = min(max(ids[g], (int64_t)0), G - 1);
+      const int64_t src = node_slice[id] + (p - node_off[g]);
+      const int64_t shift = edge_off[g] - edge_slice[id];
+      in_ptr[p] = (int32_t)(ds_in_ptr[src] + shift);
+      out_ptr[p] = (int32_t)(ds_out_ptr[src] + shift);
+      dinv[p] = ds_dinv[src];
+      for (int w = 0; w < kc; ++w) cfeat[p * kc + w] = ds_cfeat[src * kc + w];
+    } else if (p < n + e) {
+      const int64_t q = p - n;
+      const int64_t g = find_graph(edge_off, B, q);
+      const int64_t id = min(max(ids[g], (int64_t)0), G - 1);
+      const int64_t src = edge_slice[id] + (q - edge_off[g]);
+      const int64_t shift = node_off[g] - node_slice[id];
+      in_src[q] = (int32_t)(ds_in_src[src] + shift);
+      out_dst[q] = (int32_t)(ds_out_dst[src] + shift);
+      if (in_code) in_code[q] = ds_in_code[src];
+    } else {
+      in_ptr[n] = (int32_t)e;
+      out_ptr[n] = (int32_t)e;
+    }
+  }
+}
+
 // MaskAtom / MaskEdge selection.  Items are atoms (div = 1, unit_off = node offsets) or undirected
 // edges (div = 2, unit_off = directed-edge offsets; the reference stores both directions adjacently and
 // samples pairs, bio/util.py:77-83).  Item (graph g, local a) is masked iff fewer than k_g items of its
@@ -238,6 +278,23 @@ int pgnn_collate_graphs(const int64_t* graph_ids, int64_t num_graphs, int64_t da
                        node_off, edge_off, edge_index_all, edges_all, (const uint32_t*)edge_attr_all,
                        (int)(attr_row_bytes / 4), edge_index, (uint32_t*)edge_attr, dataset_graphs);
   return check_launch("collate_graphs");
+}
+
+int pgnn_collate_structure(const int64_t* graph_ids, int64_t num_graphs, int64_t dataset_graphs, const int64_t* node_slice,
+                           const int64_t* edge_slice, const int64_t* node_off, const int64_t* edge_off, const int32_t* ds_in_ptr,
+                           const int32_t* ds_in_src, const uint8_t* ds_in_code, const int32_t* ds_out_ptr, const int32_t* ds_out_dst,
+                           const float* ds_dinv, const float* ds_cfeat, int64_t cfeat_cols, int64_t num_nodes, int64_t num_edges,
+                           int32_t* in_ptr, int32_t* in_src, uint8_t* in_code, int32_t* out_ptr, int32_t* out_dst, float* dinv,
+                           float* cfeat, pgnn_stream stream) {
+  PGNN_REQUIRE(num_graphs > 0 && num_nodes >= 0 && num_edges >= 0 && cfeat_cols > 0 && cfeat_cols <= 16 && ds_in_ptr && ds_in_src &&
+                   ds_out_ptr && ds_out_dst && ds_dinv && ds_cfeat && in_ptr && in_src && out_ptr && out_dst && dinv && cfeat &&
+                   (ds_in_code != nullptr) == (in_code != nullptr),
+               "bad collate_structure arguments");
+  PGNN_REQUIRE(num_nodes < (1ll << 31) && num_edges < (1ll << 31), "collate_structure: the batch exceeds int32 positions");
+  hipLaunchKernelGGL(k_collate_structure, dim3(grid_for(num_nodes + num_edges + 1)), dim3(kBlock), 0, (hipStream_t)stream, graph_ids,
+                     num_graphs, dataset_graphs, node_slice, edge_slice, node_off, edge_off, ds_in_ptr, ds_in_src, ds_in_code, ds_out_ptr,
+                     ds_out_dst, ds_dinv, ds_cfeat, (int)cfeat_cols, in_ptr, in_src, in_code, out_ptr, out_dst, dinv, cfeat);
+  return check_launch("collate_structure");
 }
 
 int pgnn_mask_select(const int64_t* graph_ids, int64_t num_graphs, const int64_t* unit_off, int unit_div,

@@ -94,6 +94,63 @@ class ResidentDataset:
         self._center = None if center_node_idx is None else np.asarray(torch.as_tensor(center_node_idx).cpu(), dtype=np.int64).reshape(-1)
         if self._center is not None and self._center.size != self.num_graphs:
             raise ValueError("center_node_idx must hold one entry per graph")
+        self._structure = None  # chem: (in_ptr, in_src, in_code, out_ptr, out_dst, dinv, cfeat) of the whole dataset, built on first use
+
+    # ------------------------------------------------------------------ structure (CSR out of the loader)
+    def dataset_structure(self):
+        """both CSRs, bond codes, normalisers and per-node bond counts of EVERY graph, as slices of one structure over the whole
+        dataset (dataset-global row pointers / node ids; int32), built once with the library's own ``pgnn_chem_graph_build`` -- in
+        chunks of whole graphs, each chunk one block-diagonal batch.  ``collate`` then emits a batch's structure by offset-add
+        (``pgnn_collate_structure``) instead of histogram / scan / fill / sort per step.  chem datasets only (integer attributes);
+        None otherwise."""
+        if self._structure is not None or self.edge_attr.dtype != torch.int64 or self.edge_attr.size(1) != 2 or self.device.type != "cuda":
+            return self._structure
+        from .. import ops
+        n_tot, e_tot = int(self.x.size(0)), int(self.edge_index.size(1))
+        if n_tot >= 2 ** 31 or e_tot >= 2 ** 31:
+            return None
+        ns, es = np.concatenate([[0], np.cumsum(self._nodes)]), np.concatenate([[0], np.cumsum(self._edges)])
+        parts, g0 = [], 0
+        while g0 < self.num_graphs:  # chunks of whole graphs, <= 4 Mi edges each (at least one graph)
+            g1 = int(np.searchsorted(es, es[g0] + (1 << 22), side="right")) - 1
+            g1 = min(max(g1, g0 + 1), self.num_graphs)
+            n0, n1, e0, e1 = int(ns[g0]), int(ns[g1]), int(es[g0]), int(es[g1])
+            shift = torch.repeat_interleave(self.node_slice[g0:g1] - n0, self.edge_slice[g0 + 1:g1 + 1] - self.edge_slice[g0:g1],
+                                            output_size=e1 - e0)
+            g = ops.build_chem_graph(self.edge_index[:, e0:e1] + shift, self.edge_attr[e0:e1], n1 - n0)
+            g.check()
+            parts.append((g.in_ptr[:-1] + e0, g.in_src[:e1 - e0] + n0, g.in_code[:e1 - e0], g.out_ptr[:-1] + e0, g.out_dst[:e1 - e0] + n0,
+                          g.dinv, g.cfeat))
+            g0 = g1
+        cat = [torch.cat([p[k] for p in parts]).contiguous() for k in range(7)]
+        self._structure = tuple(cat)
+        return self._structure
+
+    def _collate_structure(self, out, ids, b, n, e, offs):
+        """attach the batch's ``ops.GraphStruct`` to the ``edge_index`` tensor it describes (``ops.attach_graph``): ``GNN.forward`` finds
+        it there as long as that very tensor (and ``edge_attr``) arrives unmodified, and builds from the COO as before otherwise."""
+        ds = self.dataset_structure()
+        if ds is None:
+            return
+        from .. import ops
+        dev = self.device
+        g = ops.GraphStruct()
+        g.kind, g.gcn, g.n, g.e, g.tiles, g.slot_feat = "chem", False, n, e, None, None
+        g.in_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        g.out_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        g.in_src = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+        g.out_dst = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+        g.in_code = torch.empty(max(e, 1), dtype=torch.uint8, device=dev)
+        g.dinv = torch.empty(n, dtype=torch.float32, device=dev)
+        g.cfeat = torch.empty(n, 9, dtype=torch.float32, device=dev)
+        g.status = out._status
+        check(load().pgnn_collate_structure(ids.data_ptr(), b, self.num_graphs, self.node_slice.data_ptr(), self.edge_slice.data_ptr(),
+                                            offs[0].data_ptr(), offs[1].data_ptr(), ds[0].data_ptr(), ds[1].data_ptr(), ds[2].data_ptr(),
+                                            ds[3].data_ptr(), ds[4].data_ptr(), ds[5].data_ptr(), ds[6].data_ptr(), 9, n, e,
+                                            g.in_ptr.data_ptr(), g.in_src.data_ptr(), g.in_code.data_ptr(), g.out_ptr.data_ptr(),
+                                            g.out_dst.data_ptr(), g.dinv.data_ptr(), g.cfeat.data_ptr(), stream_ptr()),
+              "pgnn_collate_structure")
+        ops.attach_graph(out.edge_index, out.edge_attr, g)
 
     def __len__(self):
         return self.num_graphs
@@ -144,13 +201,15 @@ class ResidentDataset:
         return ids_host, ids_device
 
     def collate(self, graph_ids, mask_rate=0.0, seed=0, mask_edge=False, masked_atom_indices=None,
-                masked_edge_idx=None, mask_target=None, ids_device=None):
+                masked_edge_idx=None, mask_target=None, ids_device=None, structure=True):
         """BatchMasking.from_data_list over ``graph_ids``, plus the masking transform when ``mask_rate`` > 0:
         ``mask_target`` "atom" = chem MaskAtom (default for integer node features; ``mask_edge`` adds its
         bond masking), "edge" = bio MaskEdge (default for float features).  Explicit
         ``masked_atom_indices`` / ``masked_edge_idx`` (batch positions; the reference's debugging hook)
         replace the random draw.  ``ids_device``: the same ids already on the GPU (ResidentLoader uploads a
-        whole epoch's permutation once instead of one small copy per step)."""
+        whole epoch's permutation once instead of one small copy per step).  ``structure`` (chem): the batch's int32 CSRs, bond
+        codes and bond counts come with it, by offset-add from the dataset's (``dataset_structure``), attached to
+        ``edge_index`` for ``GNN.forward`` to pick up -- False leaves the batch as the reference's collate would."""
         lib, sp, dev = load(), stream_ptr(), self.device
         ids_host, ids = self._ids(graph_ids, ids_device)
         b = ids_host.size
@@ -188,6 +247,8 @@ class ResidentDataset:
               "pgnn_collate_graphs")
         out._num_graphs = b
         out._status, out._node_off, out._edge_off = status, offs[0], offs[1]
+        if structure and not mask_edge:  # (bond masking rewrites edge_attr: the bond codes and counts would be stale)
+            self._collate_structure(out, ids, b, n, e, offs)
         if unit == 0 and explicit is None:
             return out
         if explicit is not None:

@@ -15,6 +15,7 @@ from . import _lib
 from ._lib import check, load, require_cuda, stream_ptr
 
 _CHECK_INDICES = os.environ.get("PGNN_CHECK_INDICES", "0") == "1"
+_NO_ATTACHED_GRAPH = os.environ.get("PGNN_LOADER_STRUCTURE", "1") == "0"  # A/B: always build the structure from the COO
 _BIO_TILES = os.environ.get("PGNN_BIO_TILES", "1") != "0"  # A/B: graph-resident bio aggregation (csrc/tile.hip)
 _ws_cache = {}
 
@@ -130,7 +131,32 @@ def _build_graph(kind, edge_index, edge_attr, num_nodes, gcn):
     return g
 
 
-def build_chem_graph(edge_index, edge_attr, num_nodes, gcn=False):
+def attach_graph(edge_index, edge_attr, graph):
+    """The loader's hand-over of a batch's structure (data/resident.py: built by offset-add from the dataset's):
+    it rides on the ``edge_index`` tensor OBJECT, valid for as long as that tensor and ``edge_attr`` are the ones the loader made and
+    nobody has written to them (``Tensor._version``).  The class surface is untouched -- ``GNN.forward(x, edge_index, edge_attr)``
+    looks here first (``attached_graph``) and builds from the COO whenever anything differs."""
+    import weakref
+    edge_index._pgnn_graph = (graph, edge_index._version, weakref.ref(edge_attr), edge_attr._version)
+
+
+def attached_graph(kind, edge_index, edge_attr, num_nodes, gcn):
+    rec = getattr(edge_index, "_pgnn_graph", None)
+    if rec is None or _NO_ATTACHED_GRAPH:
+        return None
+    g, v_ei, ea_ref, v_ea = rec
+    if (ea_ref() is not edge_attr or edge_index._version != v_ei or edge_attr._version != v_ea or g.kind != kind or g.gcn != bool(gcn)
+            or g.n != int(num_nodes) or g.e != edge_index.size(1) or g.in_ptr.device != edge_index.device):
+        return None
+    return g
+
+
+def build_chem_graph(edge_index, edge_attr, num_nodes, gcn=False, reuse=False):
+    """``reuse``: take the structure the loader attached to this very ``edge_index`` if there is one (the model's forward)"""
+    if reuse:
+        g = attached_graph("chem", edge_index, edge_attr, num_nodes, gcn)
+        if g is not None:
+            return g
     return _build_graph("chem", edge_index, edge_attr, num_nodes, gcn)
 
 

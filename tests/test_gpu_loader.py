@@ -497,3 +497,74 @@ def test_relabelled_dataset_drives_the_masking_step():
     b2 = ren.collate(ids, mask_rate=0.15, seed=4)
     assert b2.masked_atom_indices.numel() == b0.masked_atom_indices.numel()
     assert torch.equal(torch.bincount(b2.batch[b2.masked_atom_indices], minlength=96), torch.bincount(b0.batch[b0.masked_atom_indices], minlength=96))
+
+
+def _struct_equal(a, b):
+    n, e = a.n, a.e
+    assert (a.n, a.e, a.kind, a.gcn) == (b.n, b.e, b.kind, b.gcn)
+    for name, cnt in (("in_ptr", n + 1), ("out_ptr", n + 1), ("in_src", e), ("out_dst", e), ("in_code", e), ("dinv", n), ("cfeat", n)):
+        assert torch.equal(getattr(a, name)[:cnt], getattr(b, name)[:cnt]), name
+
+
+@pytest.mark.parametrize("relabel", [False, True])
+def test_loader_structure_by_offset_add_equals_the_per_batch_build(relabel):
+    """SURVEY 8f rank 1, the CSR half: the structure ``collate`` attaches (``pgnn_collate_structure``: slices of ONE structure over the
+    whole dataset, shifted) is bit for bit what ``pgnn_chem_graph_build`` computes from the collated COO -- both CSRs, bond codes,
+    normalisers, per-node bond counts -- on ragged batches: a lone atom (no bonds) in every position, a 700-bond hub, repeated
+    graphs, more than 1024 graphs (the offset scan's carry)."""
+    from pretrain_gnns_amd import ops
+    lone = Data(x=torch.tensor([[5, 0]]), edge_index=torch.zeros(2, 0, dtype=torch.int64), edge_attr=torch.zeros(0, 2, dtype=torch.int64))
+    pair = Data(x=torch.tensor([[6, 0], [7, 1]]), edge_index=torch.tensor([[0, 1], [1, 0]]), edge_attr=torch.tensor([[1, 0], [1, 0]]))
+    hub_n = 351
+    spokes = torch.arange(1, hub_n)
+    hub_ei = torch.stack([torch.stack([torch.zeros_like(spokes), spokes], 1).view(-1), torch.stack([spokes, torch.zeros_like(spokes)], 1).view(-1)])
+    hub = Data(x=torch.tensor([[5, 0]]).repeat(hub_n, 1), edge_index=hub_ei,
+               edge_attr=torch.stack([torch.arange(hub_ei.size(1)) // 2 % 4, torch.arange(hub_ei.size(1)) // 2 % 3], 1))
+    graphs = [lone, pair, hub] + _chem_graphs(40, seed=5)
+    ds = resident.ResidentDataset.from_graphs(graphs, DEV, relabel=relabel)
+    rng = np.random.default_rng(9)
+    for ids in ([0], [0, 0], [2], [1, 0, 2, 0, 5, 5, 0], list(range(len(graphs))), rng.integers(0, len(graphs), size=1500)):
+        out = ds.collate(ids, mask_rate=0.15, seed=3)
+        ds.check(out)
+        got = ops.attached_graph("chem", out.edge_index, out.edge_attr, out.x.size(0), False)
+        assert got is not None
+        want = ops.build_chem_graph(out.edge_index, out.edge_attr, out.x.size(0))
+        _struct_equal(got, want)
+        assert ops.build_chem_graph(out.edge_index, out.edge_attr, out.x.size(0), reuse=True) is got
+        assert ops.attached_graph("chem", out.edge_index, out.edge_attr, out.x.size(0), True) is None       # a GCN model builds its own
+        assert ops.attached_graph("chem", out.edge_index.clone(), out.edge_attr, out.x.size(0), False) is None  # another tensor
+    plain = ds.collate([3, 4], structure=False)
+    assert ops.attached_graph("chem", plain.edge_index, plain.edge_attr, plain.x.size(0), False) is None
+    edged = ds.collate([3, 4, 2], mask_rate=0.15, seed=1, mask_edge=True)  # bond masking rewrites edge_attr: nothing attached
+    assert ops.attached_graph("chem", edged.edge_index, edged.edge_attr, edged.x.size(0), False) is None
+    out = ds.collate([3, 4])
+    out.edge_attr[0, 0] = 2  # written to after the hand-over: stale, must not be used
+    assert ops.attached_graph("chem", out.edge_index, out.edge_attr, out.x.size(0), False) is None
+
+
+def test_model_forward_uses_the_loader_structure_and_gives_the_same_bits():
+    """GNN.forward(x, edge_index, edge_attr) on a loader batch (structure attached) == on clones of the same tensors (structure
+    built from the COO): embeddings and every gradient bit-identical, and the attached structure is really the one used."""
+    from pretrain_gnns_amd import ops
+    from pretrain_gnns_amd.chem import model as hchem
+    ds = resident.ResidentDataset.from_graphs(_chem_graphs(64, seed=8), DEV)
+    b = ds.collate(np.arange(64), mask_rate=0.15, seed=2)
+    torch.manual_seed(3)
+    m = hchem.GNN(5, 300).to(DEV)
+    calls = []
+    real = ops._build_graph
+    ops._build_graph = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        y1 = m(b.x, b.edge_index, b.edge_attr)
+        assert not calls
+        y1.square().sum().backward()
+        g1 = [p.grad.clone() for p in m.parameters()]
+        m.zero_grad(set_to_none=True)
+        y2 = m(b.x, b.edge_index.clone(), b.edge_attr.clone())
+        assert calls
+        y2.square().sum().backward()
+    finally:
+        ops._build_graph = real
+    assert torch.equal(y1, y2)
+    for a, p in zip(g1, m.parameters()):
+        assert torch.equal(a, p.grad)
