@@ -206,6 +206,15 @@ int pgnn_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, cons
                 uint64_t drop_seed, int64_t num_rows, int64_t dim, void* ws, size_t ws_bytes,
                 pgnn_stream stream);
 
+/* pgnn_neighbor_sum (unweighted, transposed CSR = the backward of the aggregation, chem/model.py:49-52 under autograd) whose launch
+ * ALSO leaves the column sums of the BatchNorm backward of the layer below (chem/model.py:269-273: out = dL/dy, y = relu?(BN(z))),
+ * folded: dgamma / dbeta final, and *coef_out -> [7, dim] floats inside ws from which the elementwise pass of pgnn_bn_bwd forms dz.
+ * ws: pgnn_bn_workspace_bytes(n, dim).  *fused = 0: outside the tuned instance (feature width 300): plain sum, nothing else written. */
+int pgnn_neighbor_sum_bn_bwd(const float* x, int64_t ldx, const int32_t* out_ptr, const int32_t* out_dst, float* out, int64_t ldo,
+                             const float* z, int64_t ldz, const float* gamma, const float* beta, const float* save_mean,
+                             const float* save_invstd, int relu, int training, float* dgamma, float* dbeta, int64_t num_nodes,
+                             int64_t dim, void* ws, size_t ws_bytes, const float** coef_out, int* fused, pgnn_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * GraphSAGE update (chem/model.py:165-202, bio/model.py:183-224): aggr="mean" + F.normalize(p=2).
  * `sum` is the unweighted aggregation incl. the self loop (pgnn_chem_aggregate_fwd with dinv == NULL, or

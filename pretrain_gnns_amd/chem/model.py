@@ -7,7 +7,7 @@ as /root/reference/chem/model.py (GINConv :15-55, GCNConv :58-104, GNN :206-290,
 
 What differs is everything underneath: the per-layer ``add_self_loops`` / attr ``cat`` / embedding
 gather / COO ``scatter_add`` of the reference is replaced by one CSR build per batch plus a fused
-aggregation kernel per layer; the mlp runs on fp32-accurate matrix-core GEMMs (split-bf16, csrc/linear.hip); BatchNorm+ReLU is one fused pass.
+aggregation kernel per layer; the mlp runs on fp32-accurate matrix-core GEMMs (two fp16 planes under a power-of-two scale per row, csrc/linear.hip; weight gradients on three bf16 planes); BatchNorm+ReLU is one fused pass.
 Tensors must be on the GPU -- there is no CPU path here (the CPU restatement lives in oracle/).
 """
 import os

@@ -1209,3 +1209,22 @@ int pgnn_bio_gin_stack_bwd(const float* dy, int64_t lddy, const int32_t* out_ptr
 }
 
 }  // extern "C"
+
+// pgnn_neighbor_sum whose launch also leaves the BatchNorm-backward column sums of the layer below, folded (aggregate.hip TAIL) --
+// the step of pgnn_chem_gin_stack_bwd between two layers, as an entry of its own: `out` = dL/dy of y = relu?(BatchNorm(z)); after the
+// call coef [7, dim] (inside ws: returned through *coef_out) holds what pgnn_bn_bwd's elementwise pass needs and dgamma / dbeta are
+// final.  *fused = 0: shape / policy outside the tuned instance -- the plain sum ran, nothing else was written.
+extern "C" int pgnn_neighbor_sum_bn_bwd(const float* x, int64_t ldx, const int32_t* out_ptr, const int32_t* out_dst, float* out, int64_t ldo,
+                                        const float* z, int64_t ldz, const float* gamma, const float* beta, const float* save_mean,
+                                        const float* save_invstd, int relu, int training, float* dgamma, float* dbeta, int64_t n,
+                                        int64_t dim, void* ws, size_t ws_bytes, const float** coef_out, int* fused, pgnn_stream stream) {
+  PGNN_REQUIRE(x && out_ptr && out_dst && out && z && gamma && beta && save_mean && save_invstd && dgamma && dbeta && ws && fused,
+               "bad neighbor_sum_bn_bwd arguments");
+  BnBwdTail tail{z, ldz, gamma, beta, save_mean, save_invstd, relu, training, BnBwdScratch{}, dgamma, dbeta};
+  if (int r = bn_bwd_scratch(ws, ws_bytes, n, dim, &tail.scratch)) return r;
+  bool f = false;
+  const int rc = neighbor_sum_bn_bwd(x, ldx, out_ptr, out_dst, out, ldo, n, dim, tail, &f, (hipStream_t)stream);
+  *fused = f ? 1 : 0;
+  if (coef_out) *coef_out = tail.scratch.coef;
+  return rc;
+}

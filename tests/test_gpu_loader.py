@@ -568,3 +568,36 @@ def test_model_forward_uses_the_loader_structure_and_gives_the_same_bits():
     assert torch.equal(y1, y2)
     for a, p in zip(g1, m.parameters()):
         assert torch.equal(a, p.grad)
+
+
+def test_prefetching_loader_hands_out_the_same_batches(monkeypatch):
+    """ResidentLoader collates batch t + 1 on a side stream while step t runs (PGNN_LOADER_PREFETCH, default on): every batch, its
+    masks and its attached structure are bit-identical to the in-line collate's, across two epochs, and a train loop over either
+    loader ends in the same parameters."""
+    from pretrain_gnns_amd import ops, optim, train as ptrain
+    from pretrain_gnns_amd.chem import model as hchem
+    ds = resident.ResidentDataset.from_graphs(_chem_graphs(100, seed=21), DEV)
+    runs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("PGNN_LOADER_PREFETCH", flag)
+        loader = resident.ResidentLoader(ds, 16, shuffle=True, seed=4, mask_rate=0.15)
+        torch.manual_seed(5)
+        mods = [hchem.GNN(5, 300).to(DEV), torch.nn.Linear(300, 119).to(DEV), torch.nn.Linear(300, 4).to(DEV)]
+        opts = optim.Adam.shared([m.parameters() for m in mods], lr=1e-3)
+        seen = []
+        for _ in range(2):
+            for b in loader:
+                g = ops.attached_graph("chem", b.edge_index, b.edge_attr, b.x.size(0), False)
+                assert g is not None
+                seen.append([t.clone() for t in (b.x, b.edge_index, b.edge_attr, b.batch, b.masked_atom_indices, b.mask_node_label,
+                                                 g.in_ptr, g.in_src[:g.e], g.in_code[:g.e], g.out_ptr, g.out_dst[:g.e], g.cfeat)])
+                ptrain.chem_masking_step(mods, opts, b)
+                ds.check(b)
+        torch.cuda.synchronize()
+        runs[flag] = (seen, [p.detach().clone() for p in mods[0].parameters()])
+    assert len(runs["0"][0]) == len(runs["1"][0]) == 14
+    for a, b in zip(runs["0"][0], runs["1"][0]):
+        for ta, tb in zip(a, b):
+            assert torch.equal(ta, tb)
+    for pa, pb in zip(runs["0"][1], runs["1"][1]):
+        assert torch.equal(pa, pb)

@@ -90,21 +90,24 @@ def check_rows(t, tree, what, tree64=None):
         assert float(dm.max()) <= 2e-5, "%s: column mean off by %.3e" % (what, float(dm.max()))
 
 
-def grad_stats(got_fn, tree, against):
+def grad_stats(got_fn, tree, against, per_tensor_out=None):
     """normalised elementwise error statistics of a gradient set against the packed reference `against`:
     e = |g - ref| / (|ref| + 1e-2 max|ref tensor| + 1e-1 max|ref any|); returns the worst max / q99 / median over tensors"""
     ref = rf.unpack_params(against)
     top = max(float((r["full"] if "full" in r else r["val"]).abs().max()) for r in ref.values())
     worst = {"max": 0.0, "q99": 0.0, "median": 0.0}
+    per_tensor = {}
     for name, r in ref.items():
         got = got_fn(name, r)
         if got is None:
             continue
         want = r["full"] if "full" in r else r["val"]
         e = ((got - want).abs() / (want.abs() + 1e-2 * float(want.abs().max()) + 1e-1 * top)).float()
-        worst["max"] = max(worst["max"], float(e.max()))
-        worst["q99"] = max(worst["q99"], float(torch.quantile(e, 0.99)))
-        worst["median"] = max(worst["median"], float(e.median()))
+        per_tensor[name] = {"max": float(e.max()), "q99": float(torch.quantile(e, 0.99)), "median": float(e.median())}
+        for k in worst:
+            worst[k] = max(worst[k], per_tensor[name][k])
+    if per_tensor_out is not None:
+        per_tensor_out.update(per_tensor)
     return worst
 
 
@@ -134,8 +137,12 @@ def check_grads(named, want, what):
         q = ref32[name]
         return q["full"] if "full" in q else q["val"]
 
-    mine, yard = grad_stats(hip, None, want["f64"]["grads"]), grad_stats(cpu32, None, want["f64"]["grads"])
+    pt_mine, pt_yard = {}, {}
+    mine, yard = grad_stats(hip, None, want["f64"]["grads"], pt_mine), grad_stats(cpu32, None, want["f64"]["grads"], pt_yard)
     log(test=what, hip_vs_f64=mine, ref32_vs_f64=yard)
+    # attribution: the three tensors with the largest median error, HIP and the reference's fp32 run side by side
+    top3 = sorted(pt_mine, key=lambda n: -pt_mine[n]["median"])[:3]
+    log(test=what + "/per_tensor", worst_median=[{"tensor": n, "hip": pt_mine[n], "ref32": pt_yard.get(n)} for n in top3])
     # floors: on ill-conditioned inputs (8 PPI graphs whose first-layer features are near-constant columns under a
     # BatchNorm) which fp32 implementation lands closer to float64 is arithmetic luck -- measured 3e-4 (HIP) vs 4e-5
     # (torch CPU) there, and the other way round, 9e-5 vs 5.5e-4, on the 256-molecule batch
