@@ -411,7 +411,7 @@ struct KMajorTile {
 // EXTRA (row-contiguous B with ONES only): twelve more columns of Bop behind the ones column, from p.F [K][12] -- they ride in the
 // column padding of the last tile (N + 16 <= tiles_n BN) and their products leave through p.extra [M][12]; see linear_bwd_weight_pair_ext
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, bool EXTRA = false>
-__device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x, const int grid_x) {
+__device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x, const int grid_x, const int split = -1, const int tile_direct = -1) {
   static_assert(!EXTRA || (ONES && !B_KMAJOR), "EXTRA rides behind the ones column of a row-contiguous B");
   constexpr int BK = 32;
   constexpr int NW = WAVES_M * WAVES_N, T = 64 * NW;
@@ -429,9 +429,9 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
   unsigned char* const ldsB = smem3 + 3 * PA;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_n = (p.N + (ONES ? 4 : 0) + BN - 1) / BN;
-  const int tile = xcd_remap(block_x, grid_x, p.nxcd);
+  const int tile = tile_direct >= 0 ? tile_direct : xcd_remap(block_x, grid_x, p.nxcd);
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-  const int kbeg = blockIdx.y * p.kchunk;
+  const int kbeg = (split >= 0 ? split : (int)blockIdx.y) * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
   const int nk = (kend - kbeg + BK - 1) / BK;
 
@@ -610,6 +610,22 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3(GemmArgs p) {
   gemm3_body<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, blockIdx.x, gridDim.x);
+}
+// The same product on a ONE-dimensional grid that keeps the tiles of a split on one XCD (round 6; the large weight gradients).  A tile
+// of dW = dy^T x re-streams its two operand panels over ALL rows; the `tiles` workgroups of one split read the SAME rows -- at
+// 438 792 rows and 320x160 tiles every byte of dy and x is wanted by two (dW1) or four / one (dW2) workgroups, 3.2 GB against
+// 1.6 GB if each were fetched once.  Workgroups are dealt to the XCDs round-robin by linear id; on the (tiles, splits) grid the
+// tiles of a split therefore land on `tiles` DIFFERENT XCDs, each with its own L2, and every one of them fetches the panels from
+// HBM / MALL itself.  Here workgroup id = xcd + nxcd * j is tile j % tiles of split xcd + nxcd * (j / tiles): the tiles of a split are
+// neighbours in dispatch order on ONE XCD, walk the rows at the same pace, and the second reader of a panel finds it in that L2.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3_xg(GemmArgs p, int tiles) {
+  const int id = blockIdx.x, xcd = id % p.nxcd, j = id / p.nxcd;
+  const int tile = j % tiles, split = xcd + p.nxcd * (j / tiles);
+  GemmArgs q = p;  // (the epilogues index the partial matrices by blockIdx.y, which is 0 here)
+  q.C = p.C + (int64_t)split * p.split_stride;
+  if (ONES) q.colsum = p.colsum + (int64_t)split * p.split_stride;
+  gemm3_body<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES>(q, 0, 1, split, tile);
 }
 // Two products of one shape family in ONE launch (blockIdx.z picks the product; round 4: the two weight gradients of a layer --
 // twice the tiles per launch, so half the splits over the contracted rows: half the partial matrices to write and to fold, and a
@@ -1164,6 +1180,14 @@ int launch_gemm3_s(const GemmArgs& p, int nsplit, hipStream_t st) {
   using TB = typename std::conditional<B_KMAJOR, KMajorTile<BN>, RowMajorTile<BN>>::type;
   constexpr size_t lds = (size_t)3 * (TA::PLANE + TB::PLANE);
   const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N + (ONES ? 4 : 0), BN));
+  if constexpr (!A_KMAJOR && !B_KMAJOR && EPI == EPI_PLAIN && BM == 320) {
+    if (nsplit > 1 && p.nxcd > 1 && nsplit % p.nxcd == 0 && env_knob("PGNN_DW_XCD_GROUP", 1) != 0) {
+      allow_big_lds((const void*)k_gemm3_xg<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES>, lds);
+      hipLaunchKernelGGL((k_gemm3_xg<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES>), dim3(tiles * nsplit), dim3(64 * WAVES_M * WAVES_N),
+                         lds, st, p, tiles);
+      return check_launch("gemm3_xg");
+    }
+  }
   allow_big_lds((const void*)k_gemm3<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES>, lds);
   hipLaunchKernelGGL((k_gemm3<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES>), dim3(tiles, nsplit),
                      dim3(64 * WAVES_M * WAVES_N), lds, st, p);

@@ -1654,3 +1654,38 @@ def test_last_block_folds_read_committed_partials_under_memory_pressure():
             for a, b in zip(got, w):
                 assert torch.equal(a, b), (p.__name__, rep)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("graphs,relu", [(96, 1), (96, 0), (700, 1)])
+def test_neighbor_sum_with_batchnorm_backward_sums_entry(graphs, relu):
+    """pgnn_neighbor_sum_bn_bwd (the transposed aggregation whose launch also folds the BatchNorm-backward column sums of the layer
+    below: k_aggregate_dma's TAIL, two workgroups per CU since round 6): `out` bit-identical to pgnn_neighbor_sum, dgamma / dbeta
+    against float64 sums over the masked rows."""
+    import ctypes
+    from pretrain_gnns_amd import ops
+    b = hostdata.chem_plain_batch(graphs, seed=graphs + relu).to(DEV)
+    n = b.x.size(0)
+    g = ops.build_chem_graph(b.edge_index, b.edge_attr, n)
+    torch.manual_seed(relu)
+    x, z = torch.randn(n, 300, device=DEV), torch.randn(n, 300, device=DEV) * 1.3 + 0.1
+    gamma, beta = torch.rand(300, device=DEV) + 0.5, torch.randn(300, device=DEV) * 0.2
+    mean = z.mean(0).contiguous()
+    invstd = (1.0 / torch.sqrt(z.var(0, unbiased=False) + 1e-5)).contiguous()
+    lib, sp = ops.load(), ops.stream_ptr()
+    want = torch.empty(n, 300, device=DEV)
+    ops.check(lib.pgnn_neighbor_sum(x.data_ptr(), 300, g.out_ptr.data_ptr(), g.out_dst.data_ptr(), None, want.data_ptr(), 300, n, 300, sp), "ns")
+    got = torch.empty(n, 300, device=DEV)
+    dgamma, dbeta = torch.empty(300, device=DEV), torch.empty(300, device=DEV)
+    ws = torch.empty(int(lib.pgnn_bn_workspace_bytes(n, 300)), dtype=torch.uint8, device=DEV)
+    fused, coef = ctypes.c_int(0), ctypes.c_void_p()
+    ops.check(lib.pgnn_neighbor_sum_bn_bwd(x.data_ptr(), 300, g.out_ptr.data_ptr(), g.out_dst.data_ptr(), got.data_ptr(), 300, z.data_ptr(), 300,
+                                           gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), invstd.data_ptr(), relu, 1, dgamma.data_ptr(),
+                                           dbeta.data_ptr(), n, 300, ws.data_ptr(), ws.numel(), ctypes.byref(coef), ctypes.byref(fused), sp), "nsbn")
+    assert fused.value == 1 and coef.value
+    assert torch.equal(got, want)
+    a = invstd * gamma
+    y = torch.addcmul(torch.addcmul(beta, -mean, a), a, z)  # y = a z + (beta - mean a)
+    dyr = want.double() * ((y > 0).double() if relu else 1.0)
+    xhat = (z.double() - mean.double()) * invstd.double()
+    torch.testing.assert_close(dbeta.double(), dyr.sum(0), rtol=2e-5, atol=2e-4)
+    torch.testing.assert_close(dgamma.double(), (dyr * xhat).sum(0), rtol=2e-5, atol=2e-4)
