@@ -56,6 +56,8 @@ struct GemmArgs {
   BnFwdFold bnf;             // k_gemm2pw, EPI_BIAS, bnf.n > 0: the statistics of the BatchNorm behind C, folded in this launch (bn_fold.h)
   const float* F;            // gemm3_body<EXTRA>, optional: [K][12] more rows of Bop behind the ones column (Bop columns N + 4 .. N + 15)
   float* extra;              //                    their products [M][12] (same split stride as C)
+  const uint32_t* a_colmax;  // gemm3_body<TWO>: [M] bit patterns of max_k |Aop(m, k)| (the column maxima of the row-contiguous A)
+  const uint32_t* b_colmax;  //                  [N] the same for B; the ones column and the twelve extra columns run unscaled
 };
 
 enum { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_MASK = 2 };
@@ -410,9 +412,18 @@ struct KMajorTile {
 // ones column for the bias gradient).
 // EXTRA (row-contiguous B with ONES only): twelve more columns of Bop behind the ones column, from p.F [K][12] -- they ride in the
 // column padding of the last tile (N + 16 <= tiles_n BN) and their products leave through p.extra [M][12]; see linear_bwd_weight_pair_ext
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, bool EXTRA = false>
+// TWO (round 6; weight gradients, both operands row-contiguous): the operands on TWO fp16 planes under a power-of-two scale per
+// COLUMN instead of three bf16 planes -- dW = dy^T x contracts over the rows, so the scales that factor out of the sum belong to the
+// columns of dy and of x: C[m][n] = (1 / sa_m)(1 / sb_n) sum_k (sa_m A[k][m]) (sb_n B[k][n]).  The staging thread, which keeps the
+// same four columns for the whole k-loop, multiplies its float4 by their scales (registers) and splits it into two planes; three
+// v_mfma_f32_16x16x32_f16 per accumulator (low.high, high.low, high.high) instead of six bf16 products, a third less LDS traffic
+// either way, 36 instead of 55 KB per 64x160 workgroup; the epilogue's rescale is exact.  The column maxima come from the caller
+// (p.a_colmax / p.b_colmax: k_colmax_jobs, or the producers of the operands).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, bool EXTRA = false, bool TWO = false>
 __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x, const int grid_x, const int split = -1, const int tile_direct = -1) {
   static_assert(!EXTRA || (ONES && !B_KMAJOR), "EXTRA rides behind the ones column of a row-contiguous B");
+  static_assert(!TWO || (!A_KMAJOR && !B_KMAJOR && EPI == EPI_PLAIN), "column scales: both operands row-contiguous, plain epilogue");
+  constexpr int PL = TWO ? 2 : 3;  // planes per operand
   constexpr int BK = 32;
   constexpr int NW = WAVES_M * WAVES_N, T = 64 * NW;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -426,7 +437,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
 
   extern __shared__ __align__(16) unsigned char smem3[];
   unsigned char* const ldsA = smem3;
-  unsigned char* const ldsB = smem3 + 3 * PA;
+  unsigned char* const ldsB = smem3 + PL * PA;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_n = (p.N + (ONES ? 4 : 0) + BN - 1) / BN;
   const int tile = tile_direct >= 0 ? tile_direct : xcd_remap(block_x, grid_x, p.nxcd);
@@ -482,6 +493,27 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
       offB[j] = RowMajorTile<BN>::offset(kr, 4 * cq);
     }
   }
+  // (TWO) the power-of-two scales of this thread's four columns per staging unit: s amax lands in [2^13, 2^14) (two_plane.h)
+  float4 scA[TWO ? NA : 1], scB[TWO ? NB : 1];
+  if constexpr (TWO) {
+    auto scale_of = [&](const uint32_t* cm, int c, int lim) {
+      float sc = 1.f, inv;
+      if (cm != nullptr && c < lim) pow2_scales(__uint_as_float(cm[c]), sc, inv);
+      return sc;
+    };
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int u = min(tid + j * T, UA - 1);
+      const int c = m0 + 4 * (u % (BM / 4));
+      scA[j] = make_float4(scale_of(p.a_colmax, c, p.M), scale_of(p.a_colmax, c + 1, p.M), scale_of(p.a_colmax, c + 2, p.M), scale_of(p.a_colmax, c + 3, p.M));
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int u = min(tid + j * T, UB - 1);
+      const int c = n0 + 4 * (u % (BN / 4));  // (columns from N on -- the ones column, the extra columns, padding -- are not scaled)
+      scB[j] = make_float4(scale_of(p.b_colmax, c, p.N), scale_of(p.b_colmax, c + 1, p.N), scale_of(p.b_colmax, c + 2, p.N), scale_of(p.b_colmax, c + 3, p.N));
+    }
+  }
   float4 ra[NA], rb[NB];
   auto load_tile = [&](int it) {
     const int k0 = kbeg + it * BK;
@@ -510,7 +542,21 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
     *reinterpret_cast<uint2*>(base + plane + off) = make_uint2(m0_, m1);
     *reinterpret_cast<uint2*>(base + 2 * plane + off) = make_uint2(l0, l1);
   };
+  auto store_unit2 = [&](const float4& v, const float4& sc, unsigned char* base, int plane, int off) {
+    uint32_t h0, l0, h1, l1;
+    split2(v.x * sc.x, v.y * sc.y, h0, l0);
+    split2(v.z * sc.z, v.w * sc.w, h1, l1);
+    *reinterpret_cast<uint2*>(base + off) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(base + plane + off) = make_uint2(l0, l1);
+  };
   auto store_tile = [&]() {
+    if constexpr (TWO) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) store_unit2(ra[j], scA[j], ldsA, PA, offA[j]);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) store_unit2(rb[j], scB[j], ldsB, PB, offB[j]);
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NA; ++j) store_unit(ra[j], ldsA, PA, offA[j]);
 #pragma unroll
@@ -547,6 +593,27 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
   using CB = std::integral_constant<int, BN>;
 
   auto compute = [&]() {
+    if constexpr (TWO) {
+      f16x8 a[MI][2];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a[i][q] = __builtin_bit_cast(f16x8, frag(KA{}, CA{}, ldsA, PA, wm0 + i * 16, q));
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        f16x8 b[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) b[q] = __builtin_bit_cast(f16x8, frag(KB{}, CB{}, ldsB, PB, wn0 + j * 16, q));
+        // smallest terms first (the order of k_gemm2pw); operands swapped (D = B x A) as below
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[1], a[i][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[0], a[i][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[0], a[i][0], acc[i][j], 0, 0, 0);
+      }
+      return;
+    }
     bf16x8 a[MI][3];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -587,6 +654,28 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
     if (t + 1 < nk) store_tile();
     __syncthreads();
     if (t + 2 < nk) load_tile(t + 2);
+  }
+  if constexpr (TWO) {  // back to the operands' own scale: exact (powers of two)
+    auto inv_of = [&](const uint32_t* cm, int c, int lim) {
+      float sc, inv = 1.f;
+      if (cm != nullptr && c < lim) pow2_scales(__uint_as_float(cm[c]), sc, inv);
+      return inv;
+    };
+    float ia[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) ia[i] = inv_of(p.a_colmax, m0 + wm0 + i * 16 + fr, p.M);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + wn0 + j * 16 + fk * 4;
+      const float i0 = inv_of(p.b_colmax, n, p.N), i1 = inv_of(p.b_colmax, n + 1, p.N), i2 = inv_of(p.b_colmax, n + 2, p.N), i3 = inv_of(p.b_colmax, n + 3, p.N);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        acc[i][j][0] = acc[i][j][0] * ia[i] * i0;
+        acc[i][j][1] = acc[i][j][1] * ia[i] * i1;
+        acc[i][j][2] = acc[i][j][2] * ia[i] * i2;
+        acc[i][j][3] = acc[i][j][3] * ia[i] * i3;
+      }
+    }
   }
   if constexpr (EPI == EPI_MASK) gemm_epilogue_pre<EPI, ONES, MI, NI, MI>(p, acc, m0 + wm0, n0 + wn0, lane, mk);
   else gemm_epilogue<EPI, ONES, MI, NI>(p, acc, m0 + wm0, n0 + wn0, lane);
@@ -634,11 +723,11 @@ struct GemmArgs2 {
   GemmArgs a[2];
   int tiles[2];
 };
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, bool EXTRA = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, bool EXTRA = false, bool TWO = false>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3_pair(GemmArgs2 q) {
   const int z = blockIdx.z;
   if ((int)blockIdx.x >= q.tiles[z]) return;
-  gemm3_body<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, EXTRA>(q.a[z], blockIdx.x, q.tiles[z]);
+  gemm3_body<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, EXTRA, TWO>(q.a[z], blockIdx.x, q.tiles[z]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1574,7 +1663,7 @@ inline bool pair_split(int64_t m) { return gemm_mode() == 1 && env_knob("PGNN_GE
 size_t pgnn_linear_bwd_weight_workspace_bytes(int64_t m, int64_t k, int64_t n) {
   const TileCfg c = weight_cfg(m);
   const int64_t splits = std::max({weight_splits(m, k, n, kCfg[c].bm, kCfg[c].bn), weight_splits(m, k, n, 64, 160), weight_splits(m, k, n, 320, 160)});
-  return align_up((size_t)splits * (n * k + n) * sizeof(float), 256) + 256;
+  return align_up((size_t)splits * (n * k + n) * sizeof(float), 256) + 256 + align_up((size_t)(n + k) * sizeof(uint32_t), 256);  // (+ column maxima)
 }
 
 namespace {
@@ -1611,6 +1700,71 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_jobs(ReduceJobs jobs) {
     else if (q < r.n4a + r.n4b) reinterpret_cast<float4*>(r.db)[q - r.n4a] = s;
     else reinterpret_cast<float4*>(r.g)[q - r.n4a - r.n4b] = s;
   }
+}
+
+// ---- column maxima for the two-plane weight gradients (round 6) ----------------------------------------------------------------
+// out[c] = bit pattern of max_r |x[r][c]| for up to four matrices of n rows in one launch (blockIdx.y = matrix): the power-of-two
+// column scales of gemm3_body<TWO>.  A block takes a slab of rows, four row lanes x cols / 4 float4 columns (the BatchNorm kernels'
+// thread map), four rows' loads in flight per lane; the block's maxima go out by atomic maximum on the bit patterns (non-negative
+// floats order like unsigned integers; a NaN's pattern is above every number's and leaves the column unscaled, as an inf does),
+// skipped where the word already holds as much.  `out` must be zero before the launch.
+struct ColmaxJob {
+  const float* x;
+  int64_t ld;
+  int cols;
+  uint32_t* out;
+};
+struct ColmaxJobs {
+  ColmaxJob j[4];
+};
+constexpr int kColmaxThreads = 640;  // 4 row lanes x 150 float4 columns (600 columns: the widest operand of the chem mlp)
+__global__ void __launch_bounds__(kColmaxThreads) k_colmax_jobs(ColmaxJobs jobs, int n, int rows_per_block) {
+  const ColmaxJob jb = jobs.j[blockIdx.y];
+  const int d4 = jb.cols >> 2, t = threadIdx.x, rl = t / d4, c4 = t - rl * d4;
+  __shared__ uint4 red[kColmaxThreads];
+  uint4 m = make_uint4(0u, 0u, 0u, 0u);
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
+  auto fold = [&](const float4& v) {
+    m.x = max(m.x, __float_as_uint(fabsf(v.x))); m.y = max(m.y, __float_as_uint(fabsf(v.y)));
+    m.z = max(m.z, __float_as_uint(fabsf(v.z))); m.w = max(m.w, __float_as_uint(fabsf(v.w)));
+  };
+  if (rl < 4) {
+    int r = r0 + rl;
+    for (; r + 12 < r1; r += 16) {
+      const float4 v0 = reinterpret_cast<const float4*>(jb.x + (int64_t)r * jb.ld)[c4];
+      const float4 v1 = reinterpret_cast<const float4*>(jb.x + (int64_t)(r + 4) * jb.ld)[c4];
+      const float4 v2 = reinterpret_cast<const float4*>(jb.x + (int64_t)(r + 8) * jb.ld)[c4];
+      const float4 v3 = reinterpret_cast<const float4*>(jb.x + (int64_t)(r + 12) * jb.ld)[c4];
+      fold(v0); fold(v1); fold(v2); fold(v3);
+    }
+    for (; r < r1; r += 4) fold(reinterpret_cast<const float4*>(jb.x + (int64_t)r * jb.ld)[c4]);
+  }
+  red[t] = m;
+  __syncthreads();
+  if (rl == 0) {
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+      const uint4 o = red[q * d4 + c4];
+      m.x = max(m.x, o.x); m.y = max(m.y, o.y); m.z = max(m.z, o.z); m.w = max(m.w, o.w);
+    }
+    uint32_t* o = jb.out + 4 * c4;
+    if (m.x > o[0]) atomicMax(o + 0, m.x);
+    if (m.y > o[1]) atomicMax(o + 1, m.y);
+    if (m.z > o[2]) atomicMax(o + 2, m.z);
+    if (m.w > o[3]) atomicMax(o + 3, m.w);
+  }
+}
+int launch_colmax(const ColmaxJob* jobs, int count, int64_t n, hipStream_t st) {
+  ColmaxJobs cj{};
+  for (int i = 0; i < count; ++i) {
+    PGNN_REQUIRE(jobs[i].cols % 4 == 0 && jobs[i].cols > 0 && jobs[i].cols * 1 <= kColmaxThreads && jobs[i].ld % 4 == 0, "colmax: bad shape");
+    cj.j[i] = jobs[i];
+  }
+  // slabs of >= 32 rows, at most four blocks per CU and matrix
+  const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, 32), (int64_t)num_cu() * 4));
+  const int rpb = (int)(ceil_div(ceil_div(n, blocks), 4) * 4);
+  hipLaunchKernelGGL(k_colmax_jobs, dim3((int)ceil_div(n, rpb), count), dim3(kColmaxThreads), 0, st, cj, (int)n, rpb);
+  return check_launch("colmax");
 }
 
 // ---- the bond-table gradient of a chem GIN layer without a pass of its own (round 5) ------------------------------------------
@@ -1756,8 +1910,9 @@ bool pgnn::linear_bwd_weight_pair_ext_ok(int64_t m, int64_t k_a, int64_t n_a, in
   splits = std::max<int64_t>(std::min<int64_t>(splits, std::max<int64_t>(m / (4 * 32), 1)), 1);
   const int64_t chunk = ceil_div(ceil_div(m, splits), 32) * 32;
   const int64_t used = ceil_div(m, chunk);
-  return used > 1 && (size_t)used * (n_a * k_a + n_a) * sizeof(float) <= pgnn_linear_bwd_weight_workspace_bytes(m, k_a, n_a) &&
-         (size_t)used * (n_b * k_b + n_b + 12 * n_b) * sizeof(float) <= pgnn_linear_bwd_weight_workspace_bytes(m, k_b, n_b);
+  const size_t cma = align_up((size_t)(n_a + k_a) * sizeof(uint32_t), 256), cmb = align_up((size_t)(n_b + k_b) * sizeof(uint32_t), 256);
+  return used > 1 && (size_t)used * (n_a * k_a + n_a) * sizeof(float) + cma <= pgnn_linear_bwd_weight_workspace_bytes(m, k_a, n_a) &&
+         (size_t)used * (n_b * k_b + n_b + 12 * n_b) * sizeof(float) + cmb <= pgnn_linear_bwd_weight_workspace_bytes(m, k_b, n_b);
 }
 
 int pgnn::pad_rowfeat12(const float* cfeat, int64_t kc, float* out12, int64_t n, hipStream_t st) {
@@ -1802,9 +1957,15 @@ int pgnn::linear_bwd_weight_pair_ext(const float* dy_a, int64_t lddy_a, const fl
     const int used = (int)ceil_div(m, chunk);
     const bool ext = cfeat12 && g_out && g_done && linear_bwd_weight_pair_ext_ok(m, k_a, n_a, k_b, n_b);
     const int64_t gcols = ext ? 12 : 0;  // floats per row of product b's partials behind its bias gradient
-    if (used > 1 && (size_t)used * (n_a * k_a + n_a) * sizeof(float) <= wa && (size_t)used * (n_b * k_b + n_b + gcols * n_b) * sizeof(float) <= wb) {
+    // (round 6) PGNN_DW_2P=1: the two products on two fp16 planes under power-of-two COLUMN scales (gemm3_body<TWO>); the four column
+    // maxima vectors live at the end of the two workspace halves and are taken by one launch over the four operands (k_colmax_jobs)
+    const size_t cma = align_up((size_t)(n_a + k_a) * sizeof(uint32_t), 256), cmb = align_up((size_t)(n_b + k_b) * sizeof(uint32_t), 256);
+    const bool two = env_knob("PGNN_DW_2P", 1) != 0;
+    if (used > 1 && (size_t)used * (n_a * k_a + n_a) * sizeof(float) + cma <= wa &&
+        (size_t)used * (n_b * k_b + n_b + gcols * n_b) * sizeof(float) + cmb <= wb) {
       GemmArgs2 q{};
       float* parts[2] = {static_cast<float*>(ws), reinterpret_cast<float*>(static_cast<char*>(ws) + wa)};
+      uint32_t* cms[2] = {reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + wa - cma), reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + wa + wb - cmb)};
       const float* dys[2] = {dy_a, dy_b};
       const float* xs[2] = {x_a, x_b};
       const int64_t lddys[2] = {lddy_a, lddy_b}, ldxs[2] = {ldx_a, ldx_b}, ks[2] = {k_a, k_b}, ns[2] = {n_a, n_b};
@@ -1827,8 +1988,35 @@ int pgnn::linear_bwd_weight_pair_ext(const float* dy_a, int64_t lddy_a, const fl
           jobs.j[z].g = g_out;
           jobs.j[z].n4c = gz * ns[z] / 4;
         }
+        if (two) {  // A = dy [m rows][n columns], B = x [m rows][k columns]
+          p.a_colmax = cms[z];
+          p.b_colmax = cms[z] + ns[z];
+        }
       }
       q.tiles[0] = (int)tiles_a; q.tiles[1] = (int)tiles_b;
+      if (two) {
+        PGNN_HIP(hipMemsetAsync(cms[0], 0, cma, st));
+        PGNN_HIP(hipMemsetAsync(cms[1], 0, cmb, st));
+        const ColmaxJob cj[4] = {{dy_a, lddy_a, (int)n_a, cms[0]}, {x_a, ldx_a, (int)k_a, cms[0] + n_a},
+                                 {dy_b, lddy_b, (int)n_b, cms[1]}, {x_b, ldx_b, (int)k_b, cms[1] + n_b}};
+        if ((rc = launch_colmax(cj, 4, m, st))) return rc;
+        using TA2 = RowMajorTile<64>;
+        using TB2 = RowMajorTile<160>;
+        constexpr size_t lds2 = (size_t)2 * (TA2::PLANE + TB2::PLANE);
+        if (ext) {
+          allow_big_lds((const void*)k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true, true, true>, lds2);
+          hipLaunchKernelGGL((k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true, true, true>), dim3((int)std::max(tiles_a, tiles_b), used, 2),
+                             dim3(512), lds2, st, q);
+          *g_done = true;
+        } else {
+          allow_big_lds((const void*)k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true, false, true>, lds2);
+          hipLaunchKernelGGL((k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true, false, true>), dim3((int)std::max(tiles_a, tiles_b), used, 2),
+                             dim3(512), lds2, st, q);
+        }
+        const int64_t work2 = std::max(jobs.j[0].n4a + jobs.j[0].n4b + jobs.j[0].n4c, jobs.j[1].n4a + jobs.j[1].n4b + jobs.j[1].n4c);
+        hipLaunchKernelGGL(k_splitk_reduce_jobs, dim3((int)std::min<int64_t>(ceil_div(work2, 256), 1024), 2), dim3(256), 0, st, jobs);
+        return check_launch("linear_bwd_weight_pair_2p");
+      }
       // (Measured and NOT kept, profiles/r04/wgrad2p_and_ctx_two_streams_ab.txt: the same launch on two fp16 planes under column
       // scales that every workgroup takes from its own chunk of rows in a pass in front of its k-loop, two LDS stages, one barrier
       // per 32 rows -- correct to the same bar, 78.7 us against 50.4: the pass re-reads the chunk and costs more than three MFMA

@@ -595,6 +595,81 @@ def test_weight_gradient_pair_in_one_launch(m, monkeypatch):
         assert torch.equal(a, b)
 
 
+_COL_CASES = ("six_decades", "zero_cols", "outlier_rows", "gradient_cols", "subnormal_cols", "mixed_scales", "outlier_cols")
+
+
+def _adversarial_cols(case, m, k, seed=0):
+    """operands of a weight-gradient product dW = dy^T x (contraction over the m ROWS): what a power-of-two scale per COLUMN has to
+    survive -- the families of _adversarial_rows, transposed"""
+    g = torch.Generator().manual_seed(m * 17 + k + seed)
+    x = torch.randn(m, k, generator=g)
+    if case == "six_decades":  # inside every column the entries span six decades
+        x = x * torch.logspace(-3, 3, m)[:, None]
+    elif case == "zero_cols":  # dead units
+        x[:, ::3] = 0.0
+    elif case == "outlier_rows":  # ONE row 2^30 times the others: every column's maximum is an outlier
+        x[0] *= 2.0 ** 30
+    elif case == "gradient_cols":
+        x = x * 1e-8
+    elif case == "subnormal_cols":  # below fp32's normal range: the scale saturates at 2^127
+        x = x * 1e-39
+    elif case == "mixed_scales":  # neighbouring columns sixty binades apart: a scale per tile would not do
+        x = x * torch.exp2(torch.randint(-30, 31, (1, k), generator=g).float())
+    elif case == "outlier_cols":  # one column 2^30 times the others (a global scale would flush the rest)
+        x[:, 1] *= 2.0 ** 30
+    return x
+
+
+@pytest.mark.parametrize("case", _COL_CASES)
+@pytest.mark.parametrize("m", [6747, 2100, 20000])
+def test_weight_gradients_on_two_fp16_planes_under_column_scales(case, m, monkeypatch):
+    """Round 6: the paired weight gradients (chem/model.py:29 under autograd: dW2 = dz^T hid, dW1 = dhid^T agg,
+    bias gradients as the ones column) on TWO fp16 planes under a power-of-two scale per COLUMN (gemm3_body<TWO>, column maxima by
+    k_colmax_jobs) against float64 -- error over the |a|.|b| bound of each entry, the statistic of the other product tests -- on
+    operand families chosen against a per-column scale, and against the three-bf16-plane kernel (PGNN_DW_2P=0) on the same inputs:
+    rms <= 1.25 x, max <= 2 x of its error.  Reproducible bit for bit."""
+    ops = _ops()
+    lib, sp = ops.load(), ops.stream_ptr()
+    d = 300
+    quiet = 1.0 if case in ("gradient_cols", "subnormal_cols") else 1e-3
+    dz, hid = (_adversarial_cols(case, m, d, 1) * quiet).to(DEV), torch.relu(_adversarial_cols(case, m, 2 * d, 2)).to(DEV)
+    dhid, agg = (_adversarial_cols(case, m, 2 * d, 3) * quiet).to(DEV), _adversarial_cols(case, m, d, 4).to(DEV)
+    nb = lambda k, n: int(lib.pgnn_linear_bwd_weight_workspace_bytes(m, k, n))
+    ws = torch.empty(nb(2 * d, d) + nb(d, 2 * d), dtype=torch.uint8, device=DEV)
+
+    def pair():
+        dw2, db2 = torch.full((d, 2 * d), float("nan"), device=DEV), torch.full((d,), float("nan"), device=DEV)
+        dw1, db1 = torch.full((2 * d, d), float("nan"), device=DEV), torch.full((2 * d,), float("nan"), device=DEV)
+        ops.check(lib.pgnn_linear_bwd_weight_pair(dz.data_ptr(), d, hid.data_ptr(), 2 * d, dw2.data_ptr(), db2.data_ptr(), 2 * d, d,
+                                                  dhid.data_ptr(), 2 * d, agg.data_ptr(), d, dw1.data_ptr(), db1.data_ptr(), d, 2 * d, m,
+                                                  ws.data_ptr(), ws.numel(), sp), "pair")
+        return dw2, db2, dw1, db1
+
+    want = (dz.double().t() @ hid.double(), dz.double().sum(0), dhid.double().t() @ agg.double(), dhid.double().sum(0))
+    scale = (dz.double().abs().t() @ hid.double().abs(), dz.double().abs().sum(0), dhid.double().abs().t() @ agg.double().abs(), dhid.double().abs().sum(0))
+    tiny = 4 * 2.0 ** -149
+
+    def stats(res):
+        mx, sq, cnt = 0.0, 0.0, 0
+        for g, w, sc in zip(res, want, scale):
+            err = ((g.double() - w).abs() - tiny).clamp(min=0) / sc.clamp(min=1e-300)
+            mx, sq, cnt = max(mx, float(err.max())), sq + float(err.pow(2).sum()), cnt + err.numel()
+        return mx, (sq / cnt) ** 0.5
+
+    got, again = pair(), pair()
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)
+    monkeypatch.setenv("PGNN_DW_2P", "0")
+    lib.pgnn_reload_env()
+    three = pair()
+    monkeypatch.delenv("PGNN_DW_2P")
+    lib.pgnn_reload_env()
+    (mx2, rms2), (mx3, rms3) = stats(got), stats(three)
+    _log_two_plane({"test": "weight_gradients_two_planes", "case": case, "m": m, "max": mx2, "rms": rms2, "max_three_bf16_planes": mx3, "rms_three_bf16_planes": rms3})
+    assert mx2 < (3e-6 if case in ("outlier_rows",) else 2e-6) and rms2 < 3e-7, (mx2, rms2, mx3, rms3)
+    assert rms2 <= 1.25 * rms3 + 1e-9 and mx2 <= 2.0 * mx3 + 1e-9, (mx2, rms2, mx3, rms3)
+
+
 # ----------------------------------------------------------------------------- products on two fp16 planes + row scales (round 4)
 def _weight_planes_2p(lib, sp, mats, transpose):
     """pgnn_split_weights_2p on a list of fp32 matrices -> list of (int16 planes [2, rows, ld], float32 inverse scales [rows]) views
