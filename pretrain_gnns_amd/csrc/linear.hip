@@ -419,8 +419,13 @@ struct KMajorTile {
 // v_mfma_f32_16x16x32_f16 per accumulator (low.high, high.low, high.high) instead of six bf16 products, a third less LDS traffic
 // either way, 36 instead of 55 KB per 64x160 workgroup; the epilogue's rescale is exact.  The column maxima come from the caller
 // (p.a_colmax / p.b_colmax: k_colmax_jobs, or the producers of the operands).
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, bool EXTRA = false, bool TWO = false>
+// PFD (round 6): register stages of the staging loads.  1: the loads of k-step t + 2 are issued behind the stores of t + 1 and waited
+// for one k-step later -- a lead of ONE compute phase (30 MFMAs at the 64x160 tile: ~0.2 us) against a memory round trip of 1-2 us: a
+// k-step of the paired weight gradients took 2.7 us with matrix pipes and LDS idle.  2: two register sets, k-step t + 3 is issued
+// where t + 2 was -- the wait in front of a store covers loads that are two k-steps old.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, bool EXTRA = false, bool TWO = false, int PFD = 1>
 __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x, const int grid_x, const int split = -1, const int tile_direct = -1) {
+  static_assert(PFD == 1 || PFD == 2, "one or two register stages");
   static_assert(!EXTRA || (ONES && !B_KMAJOR), "EXTRA rides behind the ones column of a row-contiguous B");
   static_assert(!TWO || (!A_KMAJOR && !B_KMAJOR && EPI == EPI_PLAIN), "column scales: both operands row-contiguous, plain epilogue");
   constexpr int PL = TWO ? 2 : 3;  // planes per operand
@@ -514,8 +519,8 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
       scB[j] = make_float4(scale_of(p.b_colmax, c, p.N), scale_of(p.b_colmax, c + 1, p.N), scale_of(p.b_colmax, c + 2, p.N), scale_of(p.b_colmax, c + 3, p.N));
     }
   }
-  float4 ra[NA], rb[NB];
-  auto load_tile = [&](int it) {
+  float4 rA[PFD][NA], rB[PFD][NB];
+  auto load_tile_into = [&](int it, float4 (&ra)[NA], float4 (&rb)[NB]) {
     const int k0 = kbeg + it * BK;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
@@ -549,7 +554,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
     *reinterpret_cast<uint2*>(base + off) = make_uint2(h0, h1);
     *reinterpret_cast<uint2*>(base + plane + off) = make_uint2(l0, l1);
   };
-  auto store_tile = [&]() {
+  auto store_tile_from = [&](const float4 (&ra)[NA], const float4 (&rb)[NB]) {
     if constexpr (TWO) {
 #pragma unroll
       for (int j = 0; j < NA; ++j) store_unit2(ra[j], scA[j], ldsA, PA, offA[j]);
@@ -640,20 +645,38 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
     }
   };
 
-  if (nk > 0) {
-    load_tile(0);
-    store_tile();
-    if (1 < nk) load_tile(1);
+  if (nk > 0) {  // (k-step j lives in register set j % PFD)
+    load_tile_into(0, rA[0], rB[0]);
+    store_tile_from(rA[0], rB[0]);
+    if (1 < nk) load_tile_into(1, rA[PFD - 1], rB[PFD - 1]);
+    if (PFD == 2 && 2 < nk) load_tile_into(2, rA[0], rB[0]);
   }
   float4 mk[MI][NI];
   if constexpr (EPI == EPI_MASK) gemm_prefetch_mask<MI, NI>(p, mk, m0 + wm0, n0 + wn0, lane);  // lands under the k-loop
   __syncthreads();
-  for (int t = 0; t < nk; ++t) {
-    compute();
-    __syncthreads();  // every wave is done reading the stage
-    if (t + 1 < nk) store_tile();
-    __syncthreads();
-    if (t + 2 < nk) load_tile(t + 2);
+  if constexpr (PFD == 1) {
+    for (int t = 0; t < nk; ++t) {
+      compute();
+      __syncthreads();  // every wave is done reading the stage
+      if (t + 1 < nk) store_tile_from(rA[0], rB[0]);
+      __syncthreads();
+      if (t + 2 < nk) load_tile_into(t + 2, rA[0], rB[0]);
+    }
+  } else {
+    auto kstep = [&](int t, auto set_tag) {  // stores k-step t + 1 (set (t + 1) % 2), refills that set with k-step t + 3
+      constexpr int S = decltype(set_tag)::value;
+      compute();
+      __syncthreads();
+      if (t + 1 < nk) store_tile_from(rA[S], rB[S]);
+      __syncthreads();
+      if (t + 3 < nk) load_tile_into(t + 3, rA[S], rB[S]);
+    };
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+      kstep(t, std::integral_constant<int, PFD - 1>{});
+      kstep(t + 1, std::integral_constant<int, 0>{});
+    }
+    if (t < nk) kstep(t, std::integral_constant<int, PFD - 1>{});
   }
   if constexpr (TWO) {  // back to the operands' own scale: exact (powers of two)
     auto inv_of = [&](const uint32_t* cm, int c, int lim) {
@@ -723,11 +746,11 @@ struct GemmArgs2 {
   GemmArgs a[2];
   int tiles[2];
 };
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, bool EXTRA = false, bool TWO = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, bool EXTRA = false, bool TWO = false, int PFD = 1>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3_pair(GemmArgs2 q) {
   const int z = blockIdx.z;
   if ((int)blockIdx.x >= q.tiles[z]) return;
-  gemm3_body<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, EXTRA, TWO>(q.a[z], blockIdx.x, q.tiles[z]);
+  gemm3_body<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, EXTRA, TWO, PFD>(q.a[z], blockIdx.x, q.tiles[z]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1703,11 +1726,13 @@ __global__ void __launch_bounds__(256) k_splitk_reduce_jobs(ReduceJobs jobs) {
 }
 
 // ---- column maxima for the two-plane weight gradients (round 6) ----------------------------------------------------------------
-// out[c] = bit pattern of max_r |x[r][c]| for up to four matrices of n rows in one launch (blockIdx.y = matrix): the power-of-two
-// column scales of gemm3_body<TWO>.  A block takes a slab of rows, four row lanes x cols / 4 float4 columns (the BatchNorm kernels'
-// thread map), four rows' loads in flight per lane; the block's maxima go out by atomic maximum on the bit patterns (non-negative
-// floats order like unsigned integers; a NaN's pattern is above every number's and leaves the column unscaled, as an inf does),
-// skipped where the word already holds as much.  `out` must be zero before the launch.
+// out[c] = bit pattern of max_r |x[r][c]| for up to four matrices of n rows in one launch: the power-of-two column scales of
+// gemm3_body<TWO>.  A block OWNS four float4 columns (64 bytes of every row) of one matrix for ALL rows -- 256 row lanes, eight
+// rows' loads in flight per lane, the lanes folded through LDS -- and stores its sixteen maxima: no atomics, nothing to clear.  (The
+// first version split the rows over blocks and folded by atomic maximum: 211 blocks arriving together serialise on the 113 cache
+// lines of the four vectors -- 87 us for a pass that reads 48 MB out of L2.)  Non-negative floats order like unsigned integers; a
+// NaN's pattern is above every number's and leaves the column unscaled, as an inf does.  For the row counts where the operands sit
+// in L2 / MALL (the paired launch: below 24 576 rows).
 struct ColmaxJob {
   const float* x;
   int64_t ld;
@@ -1716,54 +1741,60 @@ struct ColmaxJob {
 };
 struct ColmaxJobs {
   ColmaxJob j[4];
+  int first_block[5];  // blocks first_block[i] .. first_block[i + 1] - 1 belong to matrix i
 };
-constexpr int kColmaxThreads = 640;  // 4 row lanes x 150 float4 columns (600 columns: the widest operand of the chem mlp)
-__global__ void __launch_bounds__(kColmaxThreads) k_colmax_jobs(ColmaxJobs jobs, int n, int rows_per_block) {
-  const ColmaxJob jb = jobs.j[blockIdx.y];
-  const int d4 = jb.cols >> 2, t = threadIdx.x, rl = t / d4, c4 = t - rl * d4;
+constexpr int kColmaxThreads = 1024;
+__global__ void __launch_bounds__(kColmaxThreads) k_colmax_jobs(ColmaxJobs jobs, int n) {
+  int z = 0;
+  while (z < 3 && (int)blockIdx.x >= jobs.first_block[z + 1]) ++z;
+  const ColmaxJob jb = jobs.j[z];
+  const int d4 = jb.cols >> 2, t = threadIdx.x, q = t & 3, rl = t >> 2;  // a wave = 16 rows x 64 bytes
+  const int c4 = ((int)blockIdx.x - jobs.first_block[z]) * 4 + q;
   __shared__ uint4 red[kColmaxThreads];
   uint4 m = make_uint4(0u, 0u, 0u, 0u);
-  const int r0 = blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
   auto fold = [&](const float4& v) {
     m.x = max(m.x, __float_as_uint(fabsf(v.x))); m.y = max(m.y, __float_as_uint(fabsf(v.y)));
     m.z = max(m.z, __float_as_uint(fabsf(v.z))); m.w = max(m.w, __float_as_uint(fabsf(v.w)));
   };
-  if (rl < 4) {
-    int r = r0 + rl;
-    for (; r + 12 < r1; r += 16) {
-      const float4 v0 = reinterpret_cast<const float4*>(jb.x + (int64_t)r * jb.ld)[c4];
-      const float4 v1 = reinterpret_cast<const float4*>(jb.x + (int64_t)(r + 4) * jb.ld)[c4];
-      const float4 v2 = reinterpret_cast<const float4*>(jb.x + (int64_t)(r + 8) * jb.ld)[c4];
-      const float4 v3 = reinterpret_cast<const float4*>(jb.x + (int64_t)(r + 12) * jb.ld)[c4];
-      fold(v0); fold(v1); fold(v2); fold(v3);
+  if (c4 < d4) {
+    constexpr int L = kColmaxThreads / 4;  // row lanes
+    const float* base = jb.x + 4 * c4;
+    int r = rl;
+    for (; r + 7 * L < n; r += 8 * L) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(base + (int64_t)(r + u * L) * jb.ld);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) fold(v[u]);
     }
-    for (; r < r1; r += 4) fold(reinterpret_cast<const float4*>(jb.x + (int64_t)r * jb.ld)[c4]);
+    for (; r < n; r += L) fold(*reinterpret_cast<const float4*>(base + (int64_t)r * jb.ld));
   }
   red[t] = m;
   __syncthreads();
-  if (rl == 0) {
-#pragma unroll
-    for (int q = 1; q < 4; ++q) {
-      const uint4 o = red[q * d4 + c4];
+  for (int s = kColmaxThreads / 2; s >= 4; s >>= 1) {  // (lanes t and t + s own the same column quad: s is a multiple of 4)
+    if (t < s) {
+      const uint4 o = red[t + s];
       m.x = max(m.x, o.x); m.y = max(m.y, o.y); m.z = max(m.z, o.z); m.w = max(m.w, o.w);
+      red[t] = m;
     }
-    uint32_t* o = jb.out + 4 * c4;
-    if (m.x > o[0]) atomicMax(o + 0, m.x);
-    if (m.y > o[1]) atomicMax(o + 1, m.y);
-    if (m.z > o[2]) atomicMax(o + 2, m.z);
-    if (m.w > o[3]) atomicMax(o + 3, m.w);
+    __syncthreads();
   }
+  if (t < 4 && c4 < d4) *reinterpret_cast<uint4*>(jb.out + 4 * c4) = m;
 }
 int launch_colmax(const ColmaxJob* jobs, int count, int64_t n, hipStream_t st) {
   ColmaxJobs cj{};
-  for (int i = 0; i < count; ++i) {
-    PGNN_REQUIRE(jobs[i].cols % 4 == 0 && jobs[i].cols > 0 && jobs[i].cols * 1 <= kColmaxThreads && jobs[i].ld % 4 == 0, "colmax: bad shape");
-    cj.j[i] = jobs[i];
+  int blocks = 0;
+  for (int i = 0; i < 4; ++i) {
+    cj.first_block[i] = blocks;
+    if (i < count) {
+      PGNN_REQUIRE(jobs[i].cols % 4 == 0 && jobs[i].cols > 0 && jobs[i].ld % 4 == 0 && (reinterpret_cast<uintptr_t>(jobs[i].out) & 15) == 0,
+                   "colmax: bad shape");
+      cj.j[i] = jobs[i];
+      blocks += (int)ceil_div(jobs[i].cols / 4, 4);
+    }
   }
-  // slabs of >= 32 rows, at most four blocks per CU and matrix
-  const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, 32), (int64_t)num_cu() * 4));
-  const int rpb = (int)(ceil_div(ceil_div(n, blocks), 4) * 4);
-  hipLaunchKernelGGL(k_colmax_jobs, dim3((int)ceil_div(n, rpb), count), dim3(kColmaxThreads), 0, st, cj, (int)n, rpb);
+  cj.first_block[4] = blocks;
+  hipLaunchKernelGGL(k_colmax_jobs, dim3(blocks), dim3(kColmaxThreads), 0, st, cj, (int)n);
   return check_launch("colmax");
 }
 
@@ -1994,46 +2025,34 @@ int pgnn::linear_bwd_weight_pair_ext(const float* dy_a, int64_t lddy_a, const fl
         }
       }
       q.tiles[0] = (int)tiles_a; q.tiles[1] = (int)tiles_b;
+      const int pfd = env_knob("PGNN_DW_PFD", 2) == 2 ? 2 : 1;  // register stages of the staging loads (gemm3_body PFD)
       if (two) {
-        PGNN_HIP(hipMemsetAsync(cms[0], 0, cma, st));
-        PGNN_HIP(hipMemsetAsync(cms[1], 0, cmb, st));
         const ColmaxJob cj[4] = {{dy_a, lddy_a, (int)n_a, cms[0]}, {x_a, ldx_a, (int)k_a, cms[0] + n_a},
                                  {dy_b, lddy_b, (int)n_b, cms[1]}, {x_b, ldx_b, (int)k_b, cms[1] + n_b}};
         if ((rc = launch_colmax(cj, 4, m, st))) return rc;
-        using TA2 = RowMajorTile<64>;
-        using TB2 = RowMajorTile<160>;
-        constexpr size_t lds2 = (size_t)2 * (TA2::PLANE + TB2::PLANE);
-        if (ext) {
-          allow_big_lds((const void*)k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true, true, true>, lds2);
-          hipLaunchKernelGGL((k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true, true, true>), dim3((int)std::max(tiles_a, tiles_b), used, 2),
-                             dim3(512), lds2, st, q);
-          *g_done = true;
-        } else {
-          allow_big_lds((const void*)k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true, false, true>, lds2);
-          hipLaunchKernelGGL((k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true, false, true>), dim3((int)std::max(tiles_a, tiles_b), used, 2),
-                             dim3(512), lds2, st, q);
-        }
-        const int64_t work2 = std::max(jobs.j[0].n4a + jobs.j[0].n4b + jobs.j[0].n4c, jobs.j[1].n4a + jobs.j[1].n4b + jobs.j[1].n4c);
-        hipLaunchKernelGGL(k_splitk_reduce_jobs, dim3((int)std::min<int64_t>(ceil_div(work2, 256), 1024), 2), dim3(256), 0, st, jobs);
-        return check_launch("linear_bwd_weight_pair_2p");
       }
-      // (Measured and NOT kept, profiles/r04/wgrad2p_and_ctx_two_streams_ab.txt: the same launch on two fp16 planes under column
-      // scales that every workgroup takes from its own chunk of rows in a pass in front of its k-loop, two LDS stages, one barrier
-      // per 32 rows -- correct to the same bar, 78.7 us against 50.4: the pass re-reads the chunk and costs more than three MFMA
-      // products per k-step save in a loop that is bound by its staging, not by the matrix pipes.)
-      using TA = RowMajorTile<64>;
-      using TB = RowMajorTile<160>;
+      // (Round 4 built and removed a two-plane version whose workgroups took the column maxima of THEIR chunk of rows in a pass in front
+      // of the k-loop: 78.7 us against 50.4, profiles/r04/wgrad2p_and_ctx_two_streams_ab.txt.)
       // (512 workgroups, two per CU: 384 / 768 / 256 aimed at, or one resident per CU, all measured slower -- profiles/r05/dw_pair_grid_ab.txt)
-      constexpr size_t lds = (size_t)3 * (TA::PLANE + TB::PLANE);
+      const dim3 grid((int)std::max(tiles_a, tiles_b), used, 2);
+      auto launch = [&](auto ext_tag, auto two_tag, auto pfd_tag) {
+        constexpr bool E = decltype(ext_tag)::value, T2 = decltype(two_tag)::value;
+        constexpr int PF = decltype(pfd_tag)::value;
+        constexpr size_t lds = (size_t)(T2 ? 2 : 3) * (RowMajorTile<64>::PLANE + RowMajorTile<160>::PLANE);
+        allow_big_lds((const void*)k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true, E, T2, PF>, lds);
+        hipLaunchKernelGGL((k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true, E, T2, PF>), grid, dim3(512), lds, st, q);
+      };
+      using Tt = std::true_type;
+      using Ff = std::false_type;
+      using P1 = std::integral_constant<int, 1>;
+      using P2 = std::integral_constant<int, 2>;
       if (ext) {
-        allow_big_lds((const void*)k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true, true>, lds);
-        hipLaunchKernelGGL((k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true, true>), dim3((int)std::max(tiles_a, tiles_b), used, 2), dim3(512),
-                           lds, st, q);
+        if (two) { if (pfd == 2) launch(Tt{}, Tt{}, P2{}); else launch(Tt{}, Tt{}, P1{}); }
+        else     { if (pfd == 2) launch(Tt{}, Ff{}, P2{}); else launch(Tt{}, Ff{}, P1{}); }
         *g_done = true;
       } else {
-        allow_big_lds((const void*)k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true>, lds);
-        hipLaunchKernelGGL((k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true>), dim3((int)std::max(tiles_a, tiles_b), used, 2), dim3(512), lds,
-                           st, q);
+        if (two) { if (pfd == 2) launch(Ff{}, Tt{}, P2{}); else launch(Ff{}, Tt{}, P1{}); }
+        else     { if (pfd == 2) launch(Ff{}, Ff{}, P2{}); else launch(Ff{}, Ff{}, P1{}); }
       }
       const int64_t work = std::max(jobs.j[0].n4a + jobs.j[0].n4b + jobs.j[0].n4c, jobs.j[1].n4a + jobs.j[1].n4b + jobs.j[1].n4c);
       hipLaunchKernelGGL(k_splitk_reduce_jobs, dim3((int)std::min<int64_t>(ceil_div(work, 256), 1024), 2), dim3(256), 0, st, jobs);
