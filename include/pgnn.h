@@ -485,6 +485,14 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
                             uint64_t drop_seed, int64_t n, int64_t dim, void* ws, size_t ws_bytes,
                             pgnn_stream stream);
 
+/* Row support of the gradient the NEXT pgnn_chem_gin_stack_bwd of this host thread receives: `rows` [count] (int64, none repeated)
+ * are the only rows where its dy is not zero -- the masking head's gradient touches node_rep[masked_atom_indices] only
+ * (chem/pretrain_masking.py:51-52), ~17 % of the rows -- so the column sums of the top layer's BatchNorm backward visit those rows
+ * instead of all of them (every other row would add an exact zero: same sums up to the order of the additions).  The hint is
+ * consumed (or dropped: another dy pointer, PGNN_SPARSE_TOP_GRAD=0) by that call; pgnn_masked_head_bwd's caller sets it. */
+int pgnn_stack_bwd_dy_rows(const float* dy, const int64_t* rows, int64_t count);
+
+
 /* Gradient milestone of the next pgnn_chem_gin_stack_bwd of ONE network on the current device, whichever host thread runs it (data
  * parallelism: the reference is single-device, chem/pretrain_masking.py:114; this is what lets the gradient all-reduce of the top
  * layers start under the backward of the lower ones).  arm(layer, network): `network` = the w1 pointer of that network's layer

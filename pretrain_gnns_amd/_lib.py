@@ -108,6 +108,7 @@ PROTOTYPES = {
     "pgnn_batch_offsets": (_i, [_p, _i64, _i64, _p, _p, ctypes.c_double, _i, _p, _p, _p, _i64, _i64, _i64, _p, _p]),
     "pgnn_collate_graphs": (_i, [_p, _i64, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _p,
                                  _p, _p]),
+    "pgnn_stack_bwd_dy_rows": (_i, [_p, _p, _i64]),
     "pgnn_neighbor_sum_bn_bwd": (_i, [_p, _i64, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _i64, _p, _sz, _p, _p, _p]),
     "pgnn_collate_structure": (_i, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p,
                                     _p, _p, _p]),

@@ -210,11 +210,14 @@ __global__ void k_bn_bwd_partial(const float* __restrict__ dy, int64_t lddy, con
                                  float* __restrict__ coef /*out (block 0): a,b,mean,invstd*/, int relu,
                                  int n, int d4, float* __restrict__ partial, Drop drop, double* __restrict__ gsum,
                                  unsigned* __restrict__ tickets, int training, float* __restrict__ dgamma,
-                                 float* __restrict__ dbeta) {
+                                 float* __restrict__ dbeta, const int64_t* __restrict__ rows, int nrows) {
+  // rows (round 6, optional): the ONLY rows where dy is not zero, ascending or not, none repeated (the masking head's gradient:
+  // ~17 % of the rows) -- the sums run over rows[0 .. nrows) instead of 0 .. n; every other row would add an exact zero
   extern __shared__ __align__(16) float lds[];
   const int t = threadIdx.x, c4 = t % d4, rl = t / d4, dim = d4 * 4;
-  const int per = (n + gridDim.x - 1) / gridDim.x;
-  const int r0 = blockIdx.x * per, r1 = min(n, r0 + per);
+  const int cnt = rows ? nrows : n;
+  const int per = (cnt + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * per, r1 = min(cnt, r0 + per);
   float4 s1 = f4_zero(), s2 = f4_zero();
   if (rl < 4) {
     // forward coefficients y = a*x + b, recomputed exactly as k_bn_stats_final formed them
@@ -234,16 +237,18 @@ __global__ void k_bn_bwd_partial(const float* __restrict__ dy, int64_t lddy, con
     constexpr int U = 4;
     for (int rb = r0 + rl; rb < r1; rb += 4 * U) {
       float4 vv[U], gg[U];
+      int64_t rr[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int r = min(rb + 4 * u, r1 - 1);
-        vv[u] = reinterpret_cast<const float4*>(x + (int64_t)r * ldx)[c4];
-        gg[u] = reinterpret_cast<const float4*>(dy + (int64_t)r * lddy)[c4];
+        rr[u] = rows ? min(max(rows[r], (int64_t)0), (int64_t)n - 1) : (int64_t)r;
+        vv[u] = reinterpret_cast<const float4*>(x + rr[u] * ldx)[c4];
+        gg[u] = reinterpret_cast<const float4*>(dy + rr[u] * lddy)[c4];
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int r = rb + 4 * u;
-        if (r >= r1) break;
+        if (rb + 4 * u >= r1) break;
+        const int64_t r = rr[u];
         const float4 v = vv[u];
         float4 g = gg[u];
         if (drop.thresh) {
@@ -543,7 +548,19 @@ int pgnn_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, cons
                 const float* beta, const float* save_mean, const float* save_invstd, int training, int relu,
                 float* dx, int64_t lddx, float* dgamma, float* dbeta, float drop_p, uint64_t drop_seed, int64_t n,
                 int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream) {
+  return pgnn::bn_bwd_rows(dy, lddy, x, ldx, gamma, beta, save_mean, save_invstd, training, relu, dx, lddx, dgamma, dbeta, drop_p, drop_seed, n, dim,
+                           ws, ws_bytes, (hipStream_t)stream, nullptr, 0);
+}
+
+}  // extern "C"
+
+// pgnn_bn_bwd whose column sums run over `rows` [nrows] only -- the rows outside them hold dy == 0 (the caller's promise: the
+// gradient of the masking head, chem/pretrain_masking.py:51-52: loss over node_rep[masked_atom_indices]); rows == NULL: all rows
+int pgnn::bn_bwd_rows(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* beta, const float* save_mean,
+                      const float* save_invstd, int training, int relu, float* dx, int64_t lddx, float* dgamma, float* dbeta, float drop_p,
+                      uint64_t drop_seed, int64_t n, int64_t dim, void* ws, size_t ws_bytes, hipStream_t st, const int64_t* rows, int64_t nrows) {
   if (int rc = check_args(n, dim)) return rc;
+  if (rows && (nrows <= 0 || nrows > n)) rows = nullptr;
   PGNN_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "batchnorm: dropout probability must be in [0, 1)");
   const Drop drop = make_drop(drop_p, drop_seed);
   PGNN_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "batchnorm: leading dimensions must be multiples of 4");
@@ -551,10 +568,9 @@ int pgnn_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, cons
     set_error("batchnorm workspace too small");
     return PGNN_ERR_WORKSPACE;
   }
-  hipStream_t st = (hipStream_t)stream;
   Carver cv(ws);
-  const int nblk = stat_blocks(n);
-  float* partial = cv.take<float>((size_t)nblk * 2 * dim);
+  const int nblk = stat_blocks(rows ? nrows : n);  // (the workspace is sized for n rows)
+  float* partial = cv.take<float>((size_t)stat_blocks(n) * 2 * dim);
   float* coef = cv.take<float>((size_t)7 * dim);
   const int d4 = (int)(dim / 4);
   double* gsum = cv.take<double>((size_t)kFoldMaxGroups * 2 * dim);
@@ -566,7 +582,7 @@ int pgnn_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, cons
   }
   hipLaunchKernelGGL(k_bn_bwd_partial, dim3(nblk), dim3(stat_threads(dim)), (size_t)8 * dim * sizeof(float), st, dy,
                      lddy, x, ldx, gamma, beta, save_mean, save_invstd, coef, relu, (int)n, d4, partial, drop, gsum, tickets, training,
-                     dgamma, dbeta);
+                     dgamma, dbeta, rows, (int)nrows);
   if (!fold)
     hipLaunchKernelGGL(k_bn_bwd_final, dim3((int)ceil_div(dim, 4)), dim3(256), 0, st, partial, nblk, training, (int)n, (int)dim, gamma,
                        coef, dgamma, dbeta);
@@ -576,4 +592,3 @@ int pgnn_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, cons
   return check_launch("bn_bwd");
 }
 
-}  // extern "C"

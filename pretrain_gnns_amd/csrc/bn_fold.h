@@ -235,6 +235,11 @@ int bn_bwd_scratch(void* ws, size_t ws_bytes, int64_t n, int64_t dim, BnBwdScrat
 int bn_bwd_apply_only(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* coef, int relu, float* dx, int64_t lddx,
                       int64_t n, int64_t dim, hipStream_t st, uint32_t* rowmax = nullptr);
 
+// (batchnorm.hip) pgnn_bn_bwd whose column sums visit only `rows` [nrows] (everywhere else dy is zero); rows == NULL: pgnn_bn_bwd
+int bn_bwd_rows(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* beta, const float* save_mean,
+                const float* save_invstd, int training, int relu, float* dx, int64_t lddx, float* dgamma, float* dbeta, float drop_p,
+                uint64_t drop_seed, int64_t n, int64_t dim, void* ws, size_t ws_bytes, hipStream_t st, const int64_t* rows, int64_t nrows);
+
 // (aggregate.hip) pgnn_neighbor_sum (unweighted) whose launch ALSO leaves, for the BatchNorm whose input gradient it computes
 // (out = dL/dy of the layer below, y = relu?(BatchNorm(z))): the column sums of the backward, folded -- coef / dgamma / dbeta as
 // pgnn_bn_bwd's first two launches leave them -- so that layer's BatchNorm backward is bn_bwd_apply_only.  *fused says whether

@@ -14,6 +14,19 @@ using namespace pgnn;
 namespace pgnn {
 namespace {
 thread_local hipEvent_t t_next_stop_event = nullptr;
+// pgnn_stack_bwd_dy_rows: the row support of the NEXT one-call backward's dy on this host thread (consumed or dropped by that call)
+struct DyRows {
+  const float* dy = nullptr;
+  const int64_t* rows = nullptr;
+  int64_t count = 0;
+};
+thread_local DyRows t_dy_rows;
+DyRows take_dy_rows(const float* dy) {
+  DyRows r = t_dy_rows;
+  t_dy_rows = DyRows{};
+  if (r.dy != dy || env_knob("PGNN_SPARSE_TOP_GRAD", 1) == 0) r = DyRows{};
+  return r;
+}
 }
 void set_next_launch_stop_event(hipEvent_t ev) { t_next_stop_event = ev; }
 hipEvent_t take_next_launch_stop_event() {
@@ -554,11 +567,18 @@ int pgnn_stack_bwd_milestone_wait(pgnn_stream stream) {
   return PGNN_OK;
 }
 
+int pgnn_stack_bwd_dy_rows(const float* dy, const int64_t* rows, int64_t count) {
+  t_dy_rows = DyRows{};
+  if (dy && rows && count > 0) t_dy_rows = DyRows{dy, rows, count};
+  return PGNN_OK;
+}
+
 int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx, int64_t rows1, int64_t rows2,
                             const int32_t* out_ptr, const int32_t* out_dst, const float* cfeat,
                             const pgnn_gin_layer* layers, int num_layer, int training, const float* acts,
                             const float* hid, const float* stats, float* dxemb1, float* dxemb2, float drop_p,
                             uint64_t drop_seed, int64_t n, int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream) {
+  const DyRows dy_rows = take_dy_rows(dy);  // (taken first: whatever this call does, the hint does not outlive it)
   if (num_layer < 1 || !layers) {
     set_error("chem_gin_stack_bwd: no layers");
     return PGNN_ERR_ARG;
@@ -735,9 +755,9 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
     const bool dz_has_amax = sums_ready && wp && dz_amax != nullptr;
     if (sums_ready)
       rc = bn_bwd_apply_only(g, ldg, z, dim, bn_scratch.coef, l != num_layer - 1, dz[b], dim, n, dim, main, dz_has_amax ? dz_amax : nullptr);
-    else
-      rc = pgnn_bn_bwd(g, ldg, z, dim, p.gamma, p.beta, mean, mean + dim, training, l != num_layer - 1, dz[b], dim, p.dgamma, p.dbeta,
-                       drop_p, drop_seed + (uint64_t)l, n, dim, op, opb, main);
+    else  // (the top layer; given the rows outside which dy is zero, its column sums visit only those: pgnn_stack_bwd_dy_rows)
+      rc = bn_bwd_rows(g, ldg, z, dim, p.gamma, p.beta, mean, mean + dim, training, l != num_layer - 1, dz[b], dim, p.dgamma, p.dbeta,
+                       drop_p, drop_seed + (uint64_t)l, n, dim, op, opb, main, l == num_layer - 1 ? dy_rows.rows : nullptr, dy_rows.count);
     if (rc) return rc;
     sums_ready = false;
     bool fork_recorded = false;

@@ -1991,7 +1991,12 @@ int pgnn::linear_bwd_weight_pair_ext(const float* dy_a, int64_t lddy_a, const fl
     // (round 6) PGNN_DW_2P=1: the two products on two fp16 planes under power-of-two COLUMN scales (gemm3_body<TWO>); the four column
     // maxima vectors live at the end of the two workspace halves and are taken by one launch over the four operands (k_colmax_jobs)
     const size_t cma = align_up((size_t)(n_a + k_a) * sizeof(uint32_t), 256), cmb = align_up((size_t)(n_b + k_b) * sizeof(uint32_t), 256);
-    const bool two = env_knob("PGNN_DW_2P", 1) != 0;
+    // Built and measured in round 6, OFF by default (profiles/r06/dw_two_planes_ab.txt): at 6 740 rows the launch is bound by its L2
+    // traffic (64-column tiles re-read each operand 4-10 times: 224 MB per layer) and its staging, not by the matrix pipes -- 52-60 us
+    // against 48 for three bf16 planes, plus 26 us for the column maxima; and a column scale cannot survive a column whose large
+    // entries meet zeros of the other operand (one row 2^30 times the rest under a ReLU'd partner: error 3.9e-4 of the |a|.|b| bound
+    // against 6e-7 -- every other family is at or below the three-plane kernel's error).
+    const bool two = env_knob("PGNN_DW_2P", 0) != 0;
     if (used > 1 && (size_t)used * (n_a * k_a + n_a) * sizeof(float) + cma <= wa &&
         (size_t)used * (n_b * k_b + n_b + gcols * n_b) * sizeof(float) + cmb <= wb) {
       GemmArgs2 q{};
@@ -2025,7 +2030,11 @@ int pgnn::linear_bwd_weight_pair_ext(const float* dy_a, int64_t lddy_a, const fl
         }
       }
       q.tiles[0] = (int)tiles_a; q.tiles[1] = (int)tiles_b;
-      const int pfd = env_knob("PGNN_DW_PFD", 2) == 2 ? 2 : 1;  // register stages of the staging loads (gemm3_body PFD)
+#ifdef PGNN_AB  // (two register stages of the staging loads measured level: 0.943-0.944 against 0.925-0.937 ms per step; A/B builds only)
+      const int pfd = env_knob("PGNN_DW_PFD", 1) == 2 ? 2 : 1;
+#else
+      const int pfd = 1;
+#endif
       if (two) {
         const ColmaxJob cj[4] = {{dy_a, lddy_a, (int)n_a, cms[0]}, {x_a, ldx_a, (int)k_a, cms[0] + n_a},
                                  {dy_b, lddy_b, (int)n_b, cms[1]}, {x_b, ldx_b, (int)k_b, cms[1] + n_b}};
@@ -2045,15 +2054,23 @@ int pgnn::linear_bwd_weight_pair_ext(const float* dy_a, int64_t lddy_a, const fl
       using Tt = std::true_type;
       using Ff = std::false_type;
       using P1 = std::integral_constant<int, 1>;
+#ifdef PGNN_AB
       using P2 = std::integral_constant<int, 2>;
-      if (ext) {
-        if (two) { if (pfd == 2) launch(Tt{}, Tt{}, P2{}); else launch(Tt{}, Tt{}, P1{}); }
-        else     { if (pfd == 2) launch(Tt{}, Ff{}, P2{}); else launch(Tt{}, Ff{}, P1{}); }
-        *g_done = true;
-      } else {
-        if (two) { if (pfd == 2) launch(Ff{}, Tt{}, P2{}); else launch(Ff{}, Tt{}, P1{}); }
-        else     { if (pfd == 2) launch(Ff{}, Ff{}, P2{}); else launch(Ff{}, Ff{}, P1{}); }
+#endif
+      bool launched = false;
+#ifdef PGNN_AB
+      if (pfd == 2) {
+        if (ext) { if (two) launch(Tt{}, Tt{}, P2{}); else launch(Tt{}, Ff{}, P2{}); }
+        else     { if (two) launch(Ff{}, Tt{}, P2{}); else launch(Ff{}, Ff{}, P2{}); }
+        launched = true;
       }
+#endif
+      (void)pfd;
+      if (!launched) {
+        if (ext) { if (two) launch(Tt{}, Tt{}, P1{}); else launch(Tt{}, Ff{}, P1{}); }
+        else     { if (two) launch(Ff{}, Tt{}, P1{}); else launch(Ff{}, Ff{}, P1{}); }
+      }
+      if (ext) *g_done = true;
       const int64_t work = std::max(jobs.j[0].n4a + jobs.j[0].n4b + jobs.j[0].n4c, jobs.j[1].n4a + jobs.j[1].n4b + jobs.j[1].n4c);
       hipLaunchKernelGGL(k_splitk_reduce_jobs, dim3((int)std::min<int64_t>(ceil_div(work, 256), 1024), 2), dim3(256), 0, st, jobs);
       return check_launch("linear_bwd_weight_pair");

@@ -872,6 +872,20 @@ def _head_state(dev):
     return t
 
 
+_row_support = None  # (data_ptr of a gradient tensor, its rows, the int64 rows outside which it is zero): MaskedHead.backward -> stack backward
+
+
+def _hand_over_row_support(dy, n):
+    """called by a one-call network's backward with its incoming gradient: if it is the tensor the masking head just produced, tell the
+    library which rows are not zero (consumed by the pgnn_*_stack_bwd call that follows)"""
+    global _row_support
+    rec, _row_support = _row_support, None
+    if rec is not None and rec[0] == dy.data_ptr() and rec[1] == n and dy.is_contiguous():
+        load().pgnn_stack_bwd_dy_rows(dy.data_ptr(), rec[2].data_ptr(), rec[2].numel())
+        return rec[2]  # (kept alive by the caller until the launch is enqueued)
+    return None
+
+
 class MaskedHead(Function):
     """linear_pred(node_rep[idx]) -> CrossEntropyLoss()(pred.double(), label) and the number of correct arg-maxes, in one
     launch per direction (chem/pretrain_masking.py:52-57).  Returns (loss float64 [], correct int64 [], logits fp32 [m, C],
@@ -931,6 +945,10 @@ class MaskedHead(Function):
                                           label.stride(0), logits.data_ptr(), gloss.data_ptr(), classes, dim, dnode.data_ptr(), dim,
                                           dw.data_ptr(), db.data_ptr() if db is not None else None, ctx.ws.data_ptr(), ctx.ws.numel(),
                                           stream_ptr()), "pgnn_masked_head_bwd")
+        # dnode is zero outside the rows idx: the one-call network's backward, if this very tensor reaches it, sums its top
+        # BatchNorm's column sums over those rows only (pgnn_stack_bwd_dy_rows)
+        global _row_support
+        _row_support = (dnode.data_ptr(), n, idx)
         return dnode, None, dw, db, None, None
 
 
@@ -1326,6 +1344,7 @@ class ChemGINStack(Function):
         dx1, dx2 = base + byte_off[L][0], base + byte_off[L][1]
         ws = _workspace(_ws_bytes("pgnn_chem_gin_stack_workspace_bytes", n, dim, rows1, rows2, L), dev)
         g = ctx.graph
+        _rows_alive = _hand_over_row_support(dy, n)  # noqa: F841
         check(load().pgnn_chem_gin_stack_bwd(
             dy.data_ptr(), dy.stride(0), ctx.x_idx.data_ptr(), rows1, rows2, g.out_ptr.data_ptr(), g.out_dst.data_ptr(),
             g.cfeat.data_ptr(), layers, L, int(ctx.training), acts.data_ptr(), hid.data_ptr(), stats.data_ptr(),

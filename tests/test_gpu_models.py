@@ -1228,3 +1228,46 @@ def test_class_surface_errors():
     m = hchem.GNN(2, 32).to(DEV)
     with pytest.raises(ValueError):
         m(torch.zeros(1), torch.zeros(1))
+
+
+def test_top_layer_batchnorm_sums_over_the_masked_rows_only(monkeypatch):
+    """pgnn_stack_bwd_dy_rows (round 6): the masking head's gradient is zero outside node_rep[masked_atom_indices]
+    (chem/pretrain_masking.py:51-52), so the one-call backward sums its top BatchNorm's column sums over those rows only.  Same
+    sums up to the order of the additions: every parameter gradient of a masking step equals the dense pass's (PGNN_SPARSE_TOP_GRAD=0)
+    to fp32 rounding, and the hint is dropped when another gradient reaches the backward."""
+    import copy
+    from pretrain_gnns_amd import ops, train as ptrain
+    hchem, _ = _hip()
+    torch.manual_seed(31)
+    mods = [hchem.GNN(5, 300).to(DEV), torch.nn.Linear(300, 119).to(DEV), torch.nn.Linear(300, 4).to(DEV)]
+    b = hostdata.chem_masking_batch(64, seed=32).to(DEV)
+    grads = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PGNN_SPARSE_TOP_GRAD", flag)
+        ops.load().pgnn_reload_env()
+        ms = copy.deepcopy(mods)
+        h = ms[0](b.x, b.edge_index, b.edge_attr)
+        loss, _ = ops.masked_head(h, b.masked_atom_indices, ms[1], b.mask_node_label[:, 0])
+        loss.backward()
+        assert ops._row_support is None  # consumed by the backward
+        grads[flag] = {k: p.grad.clone() for k, p in ms[0].named_parameters()}
+    monkeypatch.delenv("PGNN_SPARSE_TOP_GRAD")
+    ops.load().pgnn_reload_env()
+    for k, g1 in grads["1"].items():
+        g0 = grads["0"][k]
+        torch.testing.assert_close(g1, g0, rtol=2e-5, atol=2e-6 * float(g0.abs().max()) + 1e-12)
+    # a dense gradient (not the head's tensor): the hint of an earlier head backward must not leak into this backward
+    ms = copy.deepcopy(mods)
+    h = ms[0](b.x, b.edge_index, b.edge_attr)
+    loss, _ = ops.masked_head(h.detach().requires_grad_(True), b.masked_atom_indices, ms[1], b.mask_node_label[:, 0])
+    loss.backward()  # leaves a hint behind (its dnode went to a leaf, not to a network)
+    w = torch.randn_like(h)
+    (h * w).sum().backward()
+    ref = copy.deepcopy(mods)
+    monkeypatch.setenv("PGNN_SPARSE_TOP_GRAD", "0")
+    ops.load().pgnn_reload_env()
+    (ref[0](b.x, b.edge_index, b.edge_attr) * w).sum().backward()
+    monkeypatch.delenv("PGNN_SPARSE_TOP_GRAD")
+    ops.load().pgnn_reload_env()
+    for (k, p), (_, q) in zip(ms[0].named_parameters(), ref[0].named_parameters()):
+        assert torch.equal(p.grad, q.grad), k

@@ -625,9 +625,14 @@ def _adversarial_cols(case, m, k, seed=0):
 def test_weight_gradients_on_two_fp16_planes_under_column_scales(case, m, monkeypatch):
     """Round 6: the paired weight gradients (chem/model.py:29 under autograd: dW2 = dz^T hid, dW1 = dhid^T agg,
     bias gradients as the ones column) on TWO fp16 planes under a power-of-two scale per COLUMN (gemm3_body<TWO>, column maxima by
-    k_colmax_jobs) against float64 -- error over the |a|.|b| bound of each entry, the statistic of the other product tests -- on
-    operand families chosen against a per-column scale, and against the three-bf16-plane kernel (PGNN_DW_2P=0) on the same inputs:
-    rms <= 1.25 x, max <= 2 x of its error.  Reproducible bit for bit."""
+    k_colmax_jobs; PGNN_DW_2P=1 -- built in round 6 and NOT the default) against float64 -- error over the |a|.|b| bound of each entry,
+    the statistic of the other product tests -- on operand families chosen against a per-column scale, and against the three-bf16-plane
+    kernel (the default) on the same inputs: rms <= 1.25 x, max <= 2 x of its error.  Reproducible bit for bit.  ONE family defeats a
+    column scale and is held to what was measured, not to the bar: one ROW 2^30 times the others -- every column's maximum is that
+    row's entry, the rest of the column sits 30 binades below it in fp16's subnormals, and where the partner operand is zero in that
+    row (a ReLU'd activation) the result is made of those entries alone: 2.5e-4 .. 8.6e-4 of the bound against 6e-7 .. 1e-6 for three
+    bf16 planes (which keep fp32's exponent range).  That, and a launch that is not faster (profiles/r06/dw_two_planes_ab.txt), is why
+    the weight gradients stay on three bf16 planes."""
     ops = _ops()
     lib, sp = ops.load(), ops.stream_ptr()
     d = 300
@@ -656,17 +661,24 @@ def test_weight_gradients_on_two_fp16_planes_under_column_scales(case, m, monkey
             mx, sq, cnt = max(mx, float(err.max())), sq + float(err.pow(2).sum()), cnt + err.numel()
         return mx, (sq / cnt) ** 0.5
 
-    got, again = pair(), pair()
+    three = pair()  # (the default: three bf16 planes)
+    monkeypatch.setenv("PGNN_DW_2P", "1")
+    lib.pgnn_reload_env()
+    try:
+        got, again = pair(), pair()
+    finally:
+        monkeypatch.delenv("PGNN_DW_2P")
+        lib.pgnn_reload_env()
     for a, b in zip(got, again):
         assert torch.equal(a, b)
-    monkeypatch.setenv("PGNN_DW_2P", "0")
-    lib.pgnn_reload_env()
-    three = pair()
-    monkeypatch.delenv("PGNN_DW_2P")
-    lib.pgnn_reload_env()
     (mx2, rms2), (mx3, rms3) = stats(got), stats(three)
     _log_two_plane({"test": "weight_gradients_two_planes", "case": case, "m": m, "max": mx2, "rms": rms2, "max_three_bf16_planes": mx3, "rms_three_bf16_planes": rms3})
-    assert mx2 < (3e-6 if case in ("outlier_rows",) else 2e-6) and rms2 < 3e-7, (mx2, rms2, mx3, rms3)
+    if case != "subnormal_cols":  # (fp32-subnormal operands: the bf16 split loses them -- measured 1e-3 -- where the column scale lifts them into range)
+        assert mx3 < 3e-6 and rms3 < 3e-7, (mx3, rms3)
+    if case == "outlier_rows":  # the family that defeats a scale per column (see the docstring): recorded, bounded by what was measured
+        assert 1e-5 < mx2 < 2e-3 and mx3 < 2e-6, (mx2, rms2, mx3, rms3)
+        return
+    assert mx2 < 2e-6 and rms2 < 3e-7, (mx2, rms2, mx3, rms3)
     assert rms2 <= 1.25 * rms3 + 1e-9 and mx2 <= 2.0 * mx3 + 1e-9, (mx2, rms2, mx3, rms3)
 
 
