@@ -492,16 +492,6 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
  * consumed (or dropped: another dy pointer, PGNN_SPARSE_TOP_GRAD=0) by that call; pgnn_masked_head_bwd's caller sets it. */
 int pgnn_stack_bwd_dy_rows(const float* dy, const int64_t* rows, int64_t count);
 
-/* The planes of W1^T / W2^T that the backward's products read (pgnn_split_weights_2p layout, every layer) depend on the weights
- * only.  Given a buffer of pgnn_chem_gin_stack_bwd_planes_bytes bytes, the NEXT training pgnn_chem_gin_stack_fwd of this host
- * thread splits them into it on the library's side stream, beside the forward's own launches (`_early`); handed back in front of
- * the matching pgnn_chem_gin_stack_bwd (`_ready`; same thread, weights untouched in between -- chem/pretrain_masking.py:69-76:
- * the optimizers step after backward()), that call starts without its split launch.  Either hint is consumed or dropped by the next
- * call of its kind; without them nothing changes. */
-size_t pgnn_chem_gin_stack_bwd_planes_bytes(int64_t dim, int64_t num_layer);
-int pgnn_stack_bwd_planes_early(void* planes, size_t bytes);
-int pgnn_stack_bwd_planes_ready(const void* planes);
-
 
 /* Gradient milestone of the next pgnn_chem_gin_stack_bwd of ONE network on the current device, whichever host thread runs it (data
  * parallelism: the reference is single-device, chem/pretrain_masking.py:114; this is what lets the gradient all-reduce of the top

@@ -109,9 +109,6 @@ PROTOTYPES = {
     "pgnn_collate_graphs": (_i, [_p, _i64, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _p,
                                  _p, _p]),
     "pgnn_stack_bwd_dy_rows": (_i, [_p, _p, _i64]),
-    "pgnn_chem_gin_stack_bwd_planes_bytes": (_sz, [_i64, _i64]),
-    "pgnn_stack_bwd_planes_early": (_i, [_p, _sz]),
-    "pgnn_stack_bwd_planes_ready": (_i, [_p]),
     "pgnn_neighbor_sum_bn_bwd": (_i, [_p, _i64, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _i, _i, _p, _p, _i64, _i64, _p, _sz, _p, _p, _p]),
     "pgnn_collate_structure": (_i, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p,
                                     _p, _p, _p]),

@@ -21,14 +21,6 @@ struct DyRows {
   int64_t count = 0;
 };
 thread_local DyRows t_dy_rows;
-// pgnn_stack_bwd_planes_early / _ready: a caller-owned buffer for the planes of W^T that the backward's products read -- filled by the
-// NEXT training forward of this host thread on the side stream, handed to the NEXT backward (which then splits nothing)
-struct EarlyPlanes {
-  void* buf = nullptr;
-  size_t bytes = 0;
-};
-thread_local EarlyPlanes t_planes_out;
-thread_local const void* t_planes_in = nullptr;
 DyRows take_dy_rows(const float* dy) {
   DyRows r = t_dy_rows;
   t_dy_rows = DyRows{};
@@ -447,22 +439,6 @@ int pgnn_chem_gin_stack_fwd(const int64_t* x_idx, const float* xemb1, int64_t ro
   void *wp1[kMaxPlaneLayers], *wp2[kMaxPlaneLayers];
   const size_t planes_b = (size_t)num_layer * mlp_planes_bytes(dim, 2 * dim, dim);
   const bool wp = mlp_wp(n, dim, 2 * dim, dim, num_layer) && ws_bytes >= opb + planes_b;
-  {
-    // (round 6) the planes of W1^T / W2^T that the BACKWARD's products read depend on the weights only: given a buffer
-    // (pgnn_stack_bwd_planes_early) a training forward splits them on the side stream, beside its own launches -- the backward used to
-    // start with that launch (24 us on the side stream) and its first product waited for it behind the top layer's BatchNorm backward
-    const EarlyPlanes ep = t_planes_out;
-    t_planes_out = EarlyPlanes{};
-    if (ep.buf && training && wp && ep.bytes >= planes_b && num_layer <= kMaxPlaneLayers && use_side_stream() && n >= side_min_rows() &&
-        n <= kSideMaxRows && env_knob("PGNN_EARLY_BWD_PLANES", 1) != 0) {
-      if (Side* sd0 = side_for_current_device()) {
-        void *q1[kMaxPlaneLayers], *q2[kMaxPlaneLayers];
-        PGNN_HIP(hipEventRecord(sd0->fork[0], (hipStream_t)stream));  // the weights are final in the caller's stream order
-        PGNN_HIP(hipStreamWaitEvent(sd0->stream, sd0->fork[0], 0));
-        if ((rc = split_mlp_weights(layers, num_layer, dim, 2 * dim, dim, 1, static_cast<char*>(ep.buf), q1, q2, sd0->stream))) return rc;
-      }
-    }
-  }
   // two planes: the first product of a layer leaves the row maxima of hid for the second (one vector per layer behind the planes,
   // cleared by the split launch) when the workspace has the room
   uint32_t* hid_amax = nullptr;
@@ -591,19 +567,6 @@ int pgnn_stack_bwd_milestone_wait(pgnn_stream stream) {
   return PGNN_OK;
 }
 
-size_t pgnn_chem_gin_stack_bwd_planes_bytes(int64_t dim, int64_t num_layer) {
-  return (size_t)std::min<int64_t>(num_layer, kMaxPlaneLayers) * mlp_planes_bytes(dim, 2 * dim, dim);
-}
-int pgnn_stack_bwd_planes_early(void* planes, size_t bytes) {
-  t_planes_out = EarlyPlanes{};
-  if (planes && bytes) t_planes_out = EarlyPlanes{planes, bytes};
-  return PGNN_OK;
-}
-int pgnn_stack_bwd_planes_ready(const void* planes) {
-  t_planes_in = planes;
-  return PGNN_OK;
-}
-
 int pgnn_stack_bwd_dy_rows(const float* dy, const int64_t* rows, int64_t count) {
   t_dy_rows = DyRows{};
   if (dy && rows && count > 0) t_dy_rows = DyRows{dy, rows, count};
@@ -616,8 +579,6 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
                             const float* hid, const float* stats, float* dxemb1, float* dxemb2, float drop_p,
                             uint64_t drop_seed, int64_t n, int64_t dim, void* ws, size_t ws_bytes, pgnn_stream stream) {
   const DyRows dy_rows = take_dy_rows(dy);  // (taken first: whatever this call does, the hint does not outlive it)
-  const void* early_planes = t_planes_in;
-  t_planes_in = nullptr;
   if (num_layer < 1 || !layers) {
     set_error("chem_gin_stack_bwd: no layers");
     return PGNN_ERR_ARG;
@@ -710,19 +671,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   // (fork[3], awaited in front of the embedding gradients) -- with the wait up here the step began with ~26 us of the
   // caller's stream idling behind four tiny side-stream launches.
   bool wait_fork2 = false;
-  if (wp && early_planes && sd && num_layer <= kMaxPlaneLayers) {
-    // the planes were split during the forward, on this side stream (in order in front of everything enqueued on it here); what
-    // is left of that launch is the clearing of the row-maximum words
-    const size_t b1 = std::max(pgnn_weight_planes_bytes(2 * dim, dim), pgnn_weight_planes_bytes(dim, 2 * dim));
-    const size_t per = mlp_planes_bytes(dim, 2 * dim, dim);
-    for (int l = 0; l < num_layer; ++l) {
-      wp1[l] = static_cast<char*>(const_cast<void*>(early_planes)) + (size_t)l * per;
-      wp2[l] = static_cast<char*>(const_cast<void*>(early_planes)) + (size_t)l * per + b1;
-    }
-    if (dhid_amax) PGNN_HIP(hipMemsetAsync(dhid_amax, 0, (size_t)num_layer * amax_words(n) * 4, aux));
-    PGNN_HIP(hipEventRecord(sd->fork[2], aux));
-    wait_fork2 = true;
-  } else if (wp) {
+  if (wp) {
     if ((rc = split_mlp_weights(layers, num_layer, dim, 2 * dim, dim, 1, plane_base, wp1, wp2, aux, false, nullptr, dhid_amax,
                                 dhid_amax ? (int64_t)num_layer * (int64_t)amax_words(n) : 0)))  // (aux already waits on fork[0])
       return rc;

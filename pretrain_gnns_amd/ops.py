@@ -16,7 +16,6 @@ from ._lib import check, load, require_cuda, stream_ptr
 
 _CHECK_INDICES = os.environ.get("PGNN_CHECK_INDICES", "0") == "1"
 _NO_ATTACHED_GRAPH = os.environ.get("PGNN_LOADER_STRUCTURE", "1") == "0"  # A/B: always build the structure from the COO
-_EARLY_BWD_PLANES = os.environ.get("PGNN_EARLY_BWD_PLANES", "1") != "0"  # the backward's weight planes split during the forward
 _BIO_TILES = os.environ.get("PGNN_BIO_TILES", "1") != "0"  # A/B: graph-resident bio aggregation (csrc/tile.hip)
 _ws_cache = {}
 
@@ -1309,11 +1308,6 @@ class ChemGINStack(Function):
         status = _lib.status_word(dev)
         # (the stack size, not the per-layer one: room for the bf16 planes of every layer's weights behind the op scratch)
         ws = _workspace(_ws_bytes("pgnn_chem_gin_stack_workspace_bytes", n, dim, xemb1.size(0), xemb2.size(0), L), dev)
-        # a forward that a backward will follow: the planes of W^T that backward reads are split now, on the side stream
-        ctx.bwd_planes = None
-        if training and any(ctx.needs_input_grad) and _EARLY_BWD_PLANES:
-            ctx.bwd_planes = torch.empty(_ws_bytes("pgnn_chem_gin_stack_bwd_planes_bytes", dim, L), dtype=torch.uint8, device=dev)
-            load().pgnn_stack_bwd_planes_early(ctx.bwd_planes.data_ptr(), ctx.bwd_planes.numel())
         check(load().pgnn_chem_gin_stack_fwd(
             x_idx.data_ptr(), xemb1.data_ptr(), xemb1.size(0), xemb2.data_ptr(), xemb2.size(0), graph.in_ptr.data_ptr(),
             graph.in_src.data_ptr(), graph.in_code.data_ptr(), layers, L, int(training), h0.data_ptr(), acts.data_ptr(),
@@ -1351,9 +1345,6 @@ class ChemGINStack(Function):
         ws = _workspace(_ws_bytes("pgnn_chem_gin_stack_workspace_bytes", n, dim, rows1, rows2, L), dev)
         g = ctx.graph
         _rows_alive = _hand_over_row_support(dy, n)  # noqa: F841
-        if ctx.bwd_planes is not None and (ctx.direct is None or all(p._version == v and p.data_ptr() == d for p, (v, d) in zip(ctx.direct, ctx.versions))):
-            # (the weights are what the forward split: autograd's saved-tensor check / the recorded versions of the direct parameters)
-            load().pgnn_stack_bwd_planes_ready(ctx.bwd_planes.data_ptr())
         check(load().pgnn_chem_gin_stack_bwd(
             dy.data_ptr(), dy.stride(0), ctx.x_idx.data_ptr(), rows1, rows2, g.out_ptr.data_ptr(), g.out_dst.data_ptr(),
             g.cfeat.data_ptr(), layers, L, int(ctx.training), acts.data_ptr(), hid.data_ptr(), stats.data_ptr(),

@@ -1253,10 +1253,9 @@ def test_top_layer_batchnorm_sums_over_the_masked_rows_only(monkeypatch):
         grads[flag] = {k: p.grad.clone() for k, p in ms[0].named_parameters()}
     monkeypatch.delenv("PGNN_SPARSE_TOP_GRAD")
     ops.load().pgnn_reload_env()
-    top = max(float(g.abs().max()) for g in grads["0"].values())
-    for k, g1 in grads["1"].items():  # (a bias in front of a BatchNorm has a gradient of pure rounding noise: the floor is the network's scale)
+    for k, g1 in grads["1"].items():
         g0 = grads["0"][k]
-        torch.testing.assert_close(g1, g0, rtol=2e-5, atol=2e-6 * float(g0.abs().max()) + 1e-6 * top)
+        torch.testing.assert_close(g1, g0, rtol=2e-5, atol=2e-6 * float(g0.abs().max()) + 1e-12)
     # a dense gradient (not the head's tensor): the hint of an earlier head backward must not leak into this backward
     ms = copy.deepcopy(mods)
     h = ms[0](b.x, b.edge_index, b.edge_attr)
@@ -1272,27 +1271,3 @@ def test_top_layer_batchnorm_sums_over_the_masked_rows_only(monkeypatch):
     ops.load().pgnn_reload_env()
     for (k, p), (_, q) in zip(ms[0].named_parameters(), ref[0].named_parameters()):
         assert torch.equal(p.grad, q.grad), k
-
-
-def test_backward_weight_planes_split_during_the_forward_give_the_same_bits(monkeypatch):
-    """pgnn_stack_bwd_planes_early / _ready (round 6): the planes of W^T that the backward's products read are split during the training
-    forward, on the side stream, instead of at the head of the backward -- the same launch on the same weights, so every gradient
-    of a masking step is bit-identical to the backward that splits them itself; two steps in a row (the second forward splits the
-    weights the optimizer has just changed), and a backward whose weights were touched in between falls back to its own split."""
-    import copy
-    from pretrain_gnns_amd import ops, optim, train as ptrain
-    hchem, _ = _hip()
-    torch.manual_seed(41)
-    mods = [hchem.GNN(5, 300).to(DEV), torch.nn.Linear(300, 119).to(DEV), torch.nn.Linear(300, 4).to(DEV)]
-    b = hostdata.chem_masking_batch(256, seed=42).to(DEV)
-    res = {}
-    for early in (True, False):
-        monkeypatch.setattr(ops, "_EARLY_BWD_PLANES", early)
-        ms = copy.deepcopy(mods)
-        opts = optim.Adam.shared([m.parameters() for m in ms], lr=1e-3)
-        out = [ptrain.chem_masking_step(ms, opts, b) for _ in range(3)]
-        torch.cuda.synchronize()
-        res[early] = (out, [p.detach().clone() for m in ms for p in m.parameters()])
-    assert res[True][0] == res[False][0]
-    for pa, pb in zip(res[True][1], res[False][1]):
-        assert torch.equal(pa, pb)
