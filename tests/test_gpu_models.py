@@ -1253,9 +1253,10 @@ def test_top_layer_batchnorm_sums_over_the_masked_rows_only(monkeypatch):
         grads[flag] = {k: p.grad.clone() for k, p in ms[0].named_parameters()}
     monkeypatch.delenv("PGNN_SPARSE_TOP_GRAD")
     ops.load().pgnn_reload_env()
-    for k, g1 in grads["1"].items():
+    top = max(float(g.abs().max()) for g in grads["0"].values())
+    for k, g1 in grads["1"].items():  # (a bias in front of a BatchNorm has a gradient of pure rounding noise: the floor is the network's scale)
         g0 = grads["0"][k]
-        torch.testing.assert_close(g1, g0, rtol=2e-5, atol=2e-6 * float(g0.abs().max()) + 1e-12)
+        torch.testing.assert_close(g1, g0, rtol=2e-5, atol=2e-6 * float(g0.abs().max()) + 1e-6 * top)
     # a dense gradient (not the head's tensor): the hint of an earlier head backward must not leak into this backward
     ms = copy.deepcopy(mods)
     h = ms[0](b.x, b.edge_index, b.edge_attr)
