@@ -237,7 +237,8 @@ def roofline_aggregation(dev, graphs):
         else:
             ms_i, per_i, _, _, _, alg_i = _time_aggregation(dev, big, which)
         in_step[which] = {"kernel": kernel, "launches_per_step": count, "ms": round(ms_i, 4), "ms_std": round(float(per_i.std()), 4),
-                          "bytes": int(alg_i), "frac": round(alg_i / (ms_i * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                          "bytes": int(alg_i), "frac": round(alg_i / (ms_i * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "traffic": pmc_traffic_instance(n, e, which)}
         t_sum += count * ms_i
         b_sum += count * alg_i
     in_step["all_ten_launches"] = {"ms": round(t_sum, 4), "bytes": int(b_sum), "frac": round(b_sum / (t_sum * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
@@ -343,6 +344,20 @@ def knob_leg(dev, args, batch, steps_n, knobs, note):
         except Exception:
             pass
     return out
+
+
+def pmc_traffic_instance(n, e, which, name="agg_pmc_traffic_instances.json"):
+    """HBM bytes per launch of one aggregation instance (profiles/rNN/agg_pmc_traffic_instances.json: the same separate FETCH_SIZE /
+    WRITE_SIZE passes over tools/agg_instances.py), quoted only when the recorded batch is this run's; else null"""
+    for rnd in ("r06",):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", rnd, name)
+        try:
+            rec = json.load(open(path))
+            if rec["nodes"] == n and rec["edges"] == e:
+                return int(rec["instances"][which]["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
+    return None
 
 
 def three_plane_products_leg(dev, args, batch, steps_n):

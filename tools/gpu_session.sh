@@ -37,7 +37,7 @@ for action in "$@"; do
       tail -n 1 $O/$name.log | cut -c1-300 ;;
     pmc)
       name=${rest%% *}; r2=${rest#* }; ctr=${r2%% *}; cmd=${r2#* }
-      (cd /tmp && export TMPDIR=/tmp && timeout ${T:-900} rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_$name -o $name -- python $R/$cmd > $O/${name}_pmc_$ctr.log 2>&1)
+      (cd /tmp && export TMPDIR=/tmp && timeout ${T:-900} rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $O/pmc_$name -o $name -- python $R/$cmd > $O/${name}_pmc_$ctr.log 2>&1)
       cp $(find $O/pmc_$name -name "*counter_collection.csv" | head -1) $O/${name}_pmc_$ctr.csv; gzip -f $O/${name}_pmc_$ctr.csv
       rm -rf $O/pmc_$name ;;
     run)
