@@ -712,6 +712,9 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
   // The parameter gradients of layer l on `aux` behind fork[1]: both weight-gradient products in one launch + the fold of their
   // split-K partials (with bond_in_dw the dW1 product carries G = dhid^T cfeat along -- twelve columns of its tile padding -- and the
   // bond-table gradient demb = G^T W1 needs no pass over dagg: one launch for all layers behind the loop), else the bond tables' own pass
+  // sampled ONCE per call: an arm issued by another thread half way through this backward must not split the layers
+  // between the immediate and the deferred bond-table launches -- the milestone's events would then not cover the deferred ones
+  const bool armed_at_entry = milestone_armed();
   auto side_work = [&](int l, bool demb_on_main) -> int {
     const pgnn_gin_layer& p = layers[l];
     const int b = per_layer ? l : (l & 1);
@@ -725,7 +728,7 @@ int pgnn_chem_gin_stack_bwd(const float* dy, int64_t lddy, const int64_t* x_idx,
       return r;
     if (g_done) {
       bond_jobs[n_bond_jobs++] = BondTableJob{gbond[l], p.w1, dim, p.demb, dim};
-      if (milestone_armed()) {  // a communication stream may be waiting for this layer's gradients: no deferral
+      if (armed_at_entry) {  // a communication stream may be waiting for this layer's gradients: no deferral
         if ((r = bond_tables_from_g(bond_jobs + n_bond_jobs - 1, 1, 2 * dim, dim, 9, aux))) return r;
         --n_bond_jobs;
       }

@@ -127,7 +127,7 @@ class ResidentDataset:
         self._structure = tuple(cat)
         return self._structure
 
-    def _collate_structure(self, out, ids, b, n, e, offs):
+    def _collate_structure(self, out, ids, b, n, e, offs, sp):
         """attach the batch's ``ops.GraphStruct`` to the ``edge_index`` tensor it describes (``ops.attach_graph``): ``GNN.forward`` finds
         it there as long as that very tensor (and ``edge_attr``) arrives unmodified, and builds from the COO as before otherwise."""
         ds = self.dataset_structure()
@@ -149,7 +149,7 @@ class ResidentDataset:
                                             offs[0].data_ptr(), offs[1].data_ptr(), ds[0].data_ptr(), ds[1].data_ptr(), ds[2].data_ptr(),
                                             ds[3].data_ptr(), ds[4].data_ptr(), ds[5].data_ptr(), ds[6].data_ptr(), 9, n, e,
                                             g.in_ptr.data_ptr(), g.in_src.data_ptr(), g.in_code.data_ptr(), g.out_ptr.data_ptr(),
-                                            g.out_dst.data_ptr(), g.dinv.data_ptr(), g.cfeat.data_ptr(), stream_ptr()),
+                                            g.out_dst.data_ptr(), g.dinv.data_ptr(), g.cfeat.data_ptr(), sp),
               "pgnn_collate_structure")
         ops.attach_graph(out.edge_index, out.edge_attr, g)
 
@@ -202,7 +202,7 @@ class ResidentDataset:
         return ids_host, ids_device
 
     def collate(self, graph_ids, mask_rate=0.0, seed=0, mask_edge=False, masked_atom_indices=None,
-                masked_edge_idx=None, mask_target=None, ids_device=None, structure=True):
+                masked_edge_idx=None, mask_target=None, ids_device=None, structure=True, launch_stream=None):
         """BatchMasking.from_data_list over ``graph_ids``, plus the masking transform when ``mask_rate`` > 0:
         ``mask_target`` "atom" = chem MaskAtom (default for integer node features; ``mask_edge`` adds its
         bond masking), "edge" = bio MaskEdge (default for float features).  Explicit
@@ -210,8 +210,13 @@ class ResidentDataset:
         replace the random draw.  ``ids_device``: the same ids already on the GPU (ResidentLoader uploads a
         whole epoch's permutation once instead of one small copy per step).  ``structure`` (chem): the batch's int32 CSRs, bond
         codes and bond counts come with it, by offset-add from the dataset's (``dataset_structure``), attached to
-        ``edge_index`` for ``GNN.forward`` to pick up -- False leaves the batch as the reference's collate would."""
-        lib, sp, dev = load(), stream_ptr(), self.device
+        ``edge_index`` for ``GNN.forward`` to pick up -- False leaves the batch as the reference's collate would.
+        ``launch_stream`` (ResidentLoader's prefetch): the kernels go to that stream while the outputs are ALLOCATED under the
+        current one -- the caller orders the two streams (see ResidentLoader.__iter__); not with ``mask_edge`` (torch ops)."""
+        lib, dev = load(), self.device
+        sp = stream_ptr() if launch_stream is None else launch_stream.cuda_stream
+        if launch_stream is not None and mask_edge:
+            raise ValueError("launch_stream and mask_edge do not combine")
         ids_host, ids = self._ids(graph_ids, ids_device)
         b = ids_host.size
         n, e = int(self._nodes[ids_host].sum()), int(self._edges[ids_host].sum())
@@ -249,7 +254,7 @@ class ResidentDataset:
         out._num_graphs = b
         out._status, out._node_off, out._edge_off = status, offs[0], offs[1]
         if structure and not mask_edge:  # (bond masking rewrites edge_attr: the bond codes and counts would be stale)
-            self._collate_structure(out, ids, b, n, e, offs)
+            self._collate_structure(out, ids, b, n, e, offs, sp)
         if unit == 0 and explicit is None:
             return out
         if explicit is not None:
@@ -404,22 +409,6 @@ def _mask_connected_edges(batch):
     batch.connected_edge_indices = first
 
 
-def _hand_over(batch, stream):
-    """a batch collated on another stream: tell the caching allocator that ``stream`` uses its tensors (the structure attached to
-    ``edge_index`` included)"""
-    seen = []
-    for v in batch.__dict__.values():
-        if torch.is_tensor(v):
-            seen.append(v)
-    rec = getattr(getattr(batch, "edge_index", None), "_pgnn_graph", None)
-    if rec is not None:
-        g = rec[0]
-        seen += [t for t in (g.in_ptr, g.in_src, g.in_code, g.out_ptr, g.out_dst, g.dinv, g.cfeat) if torch.is_tensor(t)]
-    for t in seen:
-        if t.is_cuda and t.numel():
-            t.record_stream(stream)
-
-
 class ResidentLoader:
     """Epoch iterator over a ResidentDataset: the host draws the permutation (seeded, identical on
     every rank), each rank takes its contiguous share of every global batch (``parallel.shard_graphs``
@@ -520,33 +509,32 @@ class ResidentLoader:
                 and os.environ.get("PGNN_LOADER_PREFETCH", "1") != "0"):
             # Batch t + 1 is collated (offsets, gathers, structure by offset-add, MaskAtom: six small launches, ~60 us of launch
             # latency end to end) on a SIDE stream, enqueued before batch t is handed out -- i.e. in front of step t's launches on the
-            # host and beside them on the device -- so the step that consumes it never waits for its own collate (round 6: the loader
-            # leg of bench.py ran 62-78 us per step behind the fixed-batch step).  Same kernels, same seeds: the batches are bit-identical
-            # to the in-line ones.  Outputs are allocated under the side stream and handed to the consumer's stream with an event wait +
-            # record_stream (the caching allocator then keeps their memory until that stream is done with it).
+            # host and beside them on the device -- so the step that consumes it never waits for its own collate.  Same kernels, same
+            # seeds: the batches are bit-identical to the in-line ones.  The outputs are allocated under the CONSUMER's stream (no
+            # record_stream: that costs an event per tensor per step on the consumer's stream) and only the launches go to the side
+            # stream, which first waits for the consumer's stream as of NOW: a block the allocator hands out here was freed in the
+            # consumer's stream order before this point, so nothing enqueued there can still be reading it when the side stream writes.
             dev = torch.device(self.ds.device)
             if self._side is None:
                 self._side = torch.cuda.Stream(dev)
             side = self._side
             self.ds.dataset_structure()  # (built on the caller's stream, once)
-            side.wait_stream(torch.cuda.current_stream(dev))  # the epoch's ids, the dataset structure
             offs_ = np.concatenate([[0], np.cumsum([ids.size for ids in batches])])
 
             def ahead(step):
                 seed = (self.seed * 1000003 + epoch) * 1000003 + step
-                with torch.cuda.stream(side):
-                    b = self.ds.collate(batches[step], mask_rate=self.mask_rate, seed=seed, ids_device=flat[offs_[step]:offs_[step + 1]])
-                    ev = torch.cuda.Event()
-                    ev.record(side)
+                side.wait_stream(torch.cuda.current_stream(dev))  # the epoch's ids, the dataset structure, every block freed so far
+                b = self.ds.collate(batches[step], mask_rate=self.mask_rate, seed=seed, ids_device=flat[offs_[step]:offs_[step + 1]],
+                                    launch_stream=side)
+                ev = torch.cuda.Event()
+                ev.record(side)
                 return b, ev
 
             pending = ahead(0)
             for step in range(len(batches)):
                 nxt = ahead(step + 1) if step + 1 < len(batches) else None
                 b, ev = pending
-                main = torch.cuda.current_stream(dev)
-                main.wait_event(ev)
-                _hand_over(b, main)
+                torch.cuda.current_stream(dev).wait_event(ev)
                 yield b
                 pending = nxt
             return

@@ -862,13 +862,16 @@ def _head_state(dev):
     """[status, -, arrival tickets (PGNN_TICKET_WORDS)]: int32 words per (device, stream), zeroed once (the kernels leave the
     tickets at zero).  Per stream like the workspace: two heads launched concurrently on two streams of one device (a side stream,
     two ranks in threads on one GPU) must not count their blocks in the same words."""
+    if torch.cuda.is_current_stream_capturing():  # a captured launch writes its words on every replay: its own, never cached or evicted (ADVICE r05)
+        return torch.zeros(64, dtype=torch.int32, device=dev)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     key = (idx, stream_ptr(idx))
-    t = _head_words.get(key)
+    t = _head_words.pop(key, None)
     if t is None:
-        if len(_head_words) >= 16:  # streams come and go (ADVICE r04): keep the most recent few, oldest out first
-            _head_words.pop(next(iter(_head_words)))
-        t = _head_words[key] = torch.zeros(64, dtype=torch.int32, device=dev)
+        if len(_head_words) >= 16:  # streams come and go (ADVICE r04): the least recently USED entry goes (dicts keep insertion order;
+            _head_words.pop(next(iter(_head_words)))  # a hit re-inserts its key at the end)
+        t = torch.zeros(64, dtype=torch.int32, device=dev)
+    _head_words[key] = t
     return t
 
 

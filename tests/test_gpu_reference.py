@@ -111,6 +111,17 @@ def grad_stats(got_fn, tree, against, per_tensor_out=None):
     return worst
 
 
+# ref_bio_masking_b8/gin: 8 PPI ego nets.  The whole excess sits in TWO tensors, gnns.0.edge_encoder.{bias, weight} (median 3.1e-4 /
+# 1.1e-4 against the reference fp32 run's 4.0e-5 / 2.3e-5; every other tensor is at or below that run's error, e.g. head.weight 7.7e-7
+# against 8.8e-7): the bottom layer's edge encoder feeds a BatchNorm(2D) whose input columns are near-degenerate on 8 graphs (every
+# node enters with the SAME embedding row, bio/model.py:30-33,49-50, so a column varies only through degree and edge flags), and its
+# gradient is what is left after that BatchNorm's backward subtracts two almost equal column sums.  It is not the plane arithmetic:
+# at this size (~320 rows) every product runs the fp32-MFMA kernel already, and PGNN_GEMM_2P=0 / PGNN_GEMM_SPLIT=0 / the per-layer
+# path give the SAME numbers to every digit (profiles/r06/parity_attribution.txt, tools/parity_attribution.py); on the 256-graph
+# fixture of the same network the HIP path is the closer one (9.6e-5 against 1.2e-4).
+GRAD_FLOORS = {"ref_bio_masking_b8/gin/grads": {"median": 1e-3, "q99": 2e-2, "tensors": ("gnns.0.edge_encoder.",)}}
+
+
 def check_grads(named, want, what):
     """gradients against the reference code run in FLOAT64.  Yardstick: the reference's own fp32 run measured against
     the same float64 run with the same statistic (ReLU inputs within rounding of zero flip in ANY fp32 run; at 256
@@ -143,12 +154,17 @@ def check_grads(named, want, what):
     # attribution: the three tensors with the largest median error, HIP and the reference's fp32 run side by side
     top3 = sorted(pt_mine, key=lambda n: -pt_mine[n]["median"])[:3]
     log(test=what + "/per_tensor", worst_median=[{"tensor": n, "hip": pt_mine[n], "ref32": pt_yard.get(n)} for n in top3])
-    # floors: on ill-conditioned inputs (8 PPI graphs whose first-layer features are near-constant columns under a
-    # BatchNorm) which fp32 implementation lands closer to float64 is arithmetic luck -- measured 3e-4 (HIP) vs 4e-5
-    # (torch CPU) there, and the other way round, 9e-5 vs 5.5e-4, on the 256-molecule batch
-    assert mine["median"] <= max(3 * yard["median"] + 1e-4, 1e-3), (mine, yard)
-    assert mine["q99"] <= max(3 * yard["q99"] + 1e-4, 2e-2), (mine, yard)
+    # No global floor (round 6): every fixture but one sits inside 3 x the reference's own fp32 run + 1e-4 --
+    # measured hip / ref32 medians: chem b256 gin 1.9e-5 / 5.5e-4, gcn 3.1e-6 / 6.3e-5; chem b32 gin 5.8e-5 / 2.3e-5, gcn 2.6e-7 /
+    # 9.0e-7; bio b256 gin 9.6e-5 / 1.2e-4; bio b8 gcn 9.2e-8 / 5.2e-8.  The exception carries its own bound and its attribution:
+    floor = GRAD_FLOORS.get(what, {"median": 0.0, "q99": 0.0})
+    assert mine["median"] <= max(3 * yard["median"] + 1e-4, floor["median"]), (mine, yard)
+    assert mine["q99"] <= max(3 * yard["q99"] + 1e-4, floor["q99"]), (mine, yard)
     assert mine["max"] <= 5e-2, (mine, yard)
+    if floor["median"] > 0.0:  # the exception stays an exception: every tensor outside the attributed ones is inside the plain bar
+        for n, st in pt_mine.items():
+            if not any(n.startswith(a) for a in floor["tensors"]):
+                assert st["median"] <= 3 * pt_yard[n]["median"] + 1e-4 and st["q99"] <= 3 * pt_yard[n]["q99"] + 1e-4, (n, st, pt_yard[n])
     for n, p in named:  # norms: a missing term or a wrong scale shows here regardless of rounding
         r = rf.unpack_params(want["f64"]["grads"]).get(n)
         if r is not None and p.grad is not None and r["norm"] > 1e-3 * max(q["norm"] for q in ref32.values()):
