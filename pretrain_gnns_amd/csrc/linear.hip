@@ -420,9 +420,9 @@ struct KMajorTile {
 // either way, 36 instead of 55 KB per 64x160 workgroup; the epilogue's rescale is exact.  The column maxima come from the caller
 // (p.a_colmax / p.b_colmax: k_colmax_jobs, or the producers of the operands).
 // PFD (round 6): register stages of the staging loads.  1: the loads of k-step t + 2 are issued behind the stores of t + 1 and waited
-// for one k-step later -- a lead of ONE compute phase (30 MFMAs at the 64x160 tile: ~0.2 us) against a memory round trip of 1-2 us: a
-// k-step of the paired weight gradients took 2.7 us with matrix pipes and LDS idle.  2: two register sets, k-step t + 3 is issued
-// where t + 2 was -- the wait in front of a store covers loads that are two k-steps old.
+// for one k-step later.  2: two register sets, k-step t + 3 is issued where t + 2 was -- the wait in front of a store covers loads that
+// are two k-steps old.  Measured level at the paired weight gradients (0.943-0.944 against 0.925-0.937 ms per step,
+// profiles/r06/dw_two_planes_ab.txt: the two resident workgroups of a CU already cover each other's waits): -DPGNN_AB builds only.
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, bool EXTRA = false, bool TWO = false, int PFD = 1>
 __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x, const int grid_x, const int split = -1, const int tile_direct = -1) {
   static_assert(PFD == 1 || PFD == 2, "one or two register stages");
