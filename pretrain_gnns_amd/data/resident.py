@@ -27,6 +27,9 @@ ATOM_MASK_TOKEN = 119  # num_atom_type - 1 (chem/pretrain_masking.py:122)
 BOND_MASK_TOKEN = 5    # num_edge_type - 1
 
 
+_AUTO_RELABEL_WARNED = False
+
+
 def mask_counts(nodes_per_graph, mask_rate):
     """int(n * rate + 1) per graph, evaluated like the reference (Python float = IEEE double)."""
     n = np.asarray(nodes_per_graph, dtype=np.int64)
@@ -56,6 +59,14 @@ class ResidentDataset:
         relabel=False keeps the rows as fed -- what a comparison against the reference's own collate, row for row, needs."""
         if relabel is None:
             relabel = not torch.as_tensor(edge_attr).is_floating_point()
+            global _AUTO_RELABEL_WARNED
+            if relabel and not _AUTO_RELABEL_WARNED:  # (ADVICE r05: callers of rounds 1-4 got the rows as fed)
+                _AUTO_RELABEL_WARNED = True
+                import warnings
+                warnings.warn("ResidentDataset: molecule dataset (integer edge_attr) -- the atoms of every graph are renumbered once "
+                              "(Cuthill-McKee; relabel=None means True here).  Node rows of collated batches are in the NEW order: map "
+                              "original positions through .new_of_old, results back through .old_of_new / batch_rows_in_original_order(); "
+                              "pass relabel=False to keep the rows as fed.", stacklevel=2)
         node_slice = torch.as_tensor(node_slice, dtype=torch.int64).cpu()
         edge_slice = torch.as_tensor(edge_slice, dtype=torch.int64).cpu()
         self.new_of_old = self.old_of_new = None
