@@ -1127,6 +1127,9 @@ def main():
     if wd > 0:
         import faulthandler
         faulthandler.dump_traceback_later(wd, exit=True)
+    hang = os.environ.get("PGNN_BENCH_TEST_HANG_RANK")  # tests only: a rank that never comes back ("all" or a rank number)
+    if hang is not None and hang in ("all", os.environ.get("RANK", "0")):
+        time.sleep(10 ** 6)
     with _StdoutToStderr():
         line = _run()
     if line is not None:

@@ -234,3 +234,24 @@ def test_bench_gpus_n_starts_its_own_ranks(tmp_path):
     assert "--gpus 2 without a launcher: starting" in p.stderr and "--nproc-per-node 2" in p.stderr
     assert p.stderr.count("bench.py needs an MI355X") >= 2, p.stderr[-3000:]  # both ranks got as far as the device check
     assert "needs a torchrun launch" not in p.stderr
+
+
+def test_bench_ranks_that_never_return_are_dumped_and_ended(tmp_path):
+    """A rank that does not come back must not hang the job: every rank of `python bench.py --gpus 2` arms a
+    faulthandler watchdog (PGNN_BENCH_WATCHDOG seconds: all thread stacks to stderr, exit 1) and the self-launcher ends its process
+    group 60 s after that.  Here both ranks sleep forever (PGNN_BENCH_TEST_HANG_RANK=all, a hook in front of everything else): the command
+    comes back non-zero within the watchdog's time with the stack dumps on stderr."""
+    import subprocess
+    import sys
+    import time as _time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PGNN_BENCH_WATCHDOG="12", PGNN_BENCH_TEST_HANG_RANK="all")
+    t0 = _time.time()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode != 0
+    assert _time.time() - t0 < 120
+    assert "Timeout (0:00:12)" in p.stderr, p.stderr[-2000:]  # faulthandler's dump header (the launcher ends the other rank when the first one exits)
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
