@@ -19,9 +19,6 @@
 // The block->tile map is XCD-aware (tiles sharing an A row-panel run on one XCD's L2).
 #include <stdlib.h>
 
-#include <atomic>
-#include <mutex>
-
 #include <type_traits>
 
 #include <hip/hip_ext.h>
@@ -61,15 +58,6 @@ struct GemmArgs {
   float* extra;              //                    their products [M][12] (same split stride as C)
   const uint32_t* a_colmax;  // gemm3_body<TWO>: [M] bit patterns of max_k |Aop(m, k)| (the column maxima of the row-contiguous A)
   const uint32_t* b_colmax;  //                  [N] the same for B; the ones column and the twelve extra columns run unscaled
-};
-// gemm3_body<FOLD> (round 6): the split-K partials folded INSIDE the launch -- the last workgroup of a tile to finish adds the
-// partials of all `splits` splits in split order and writes the final tile to these destinations
-struct FoldArgs {
-  unsigned* tickets;  // one arrival word per tile: zero before the launch, left zero
-  int splits;
-  float* C;           // [M][ldc]
-  float* colsum;      // [M] (ONES) or NULL
-  float* extra;       // [M][12] (EXTRA) or NULL
 };
 
 enum { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_MASK = 2 };
@@ -435,17 +423,9 @@ struct KMajorTile {
 // for one k-step later.  2: two register sets, k-step t + 3 is issued where t + 2 was -- the wait in front of a store covers loads that
 // are two k-steps old.  Measured level at the paired weight gradients (0.943-0.944 against 0.925-0.937 ms per step,
 // profiles/r06/dw_two_planes_ab.txt: the two resident workgroups of a CU already cover each other's waits): -DPGNN_AB builds only.
-// FOLD (round 6; the paired weight gradients): no second launch for the sum over the splits.  Every workgroup writes its partial tile
-// with agent-scope (write-through) stores, commits them, and takes a ticket of its TILE; the workgroup that draws the last one adds
-// the tile's partials in split order -- its own values from its registers where its split comes up, the others' by agent-scope loads --
-// and writes dW / db / the twelve extra columns.  Each thread folds exactly the positions it computed (the same in every split).  The
-// order of the additions is k_splitk_reduce_jobs' (p[0] + p[1] + ...), whoever arrives last: bit-identical to the separate launch.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, bool EXTRA = false, bool TWO = false, int PFD = 1,
-          bool FOLD = false>
-__device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x, const int grid_x, const int split = -1, const int tile_direct = -1,
-                                           const FoldArgs* fa = nullptr) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, bool EXTRA = false, bool TWO = false, int PFD = 1>
+__device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x, const int grid_x, const int split = -1, const int tile_direct = -1) {
   static_assert(PFD == 1 || PFD == 2, "one or two register stages");
-  static_assert(!FOLD || (EPI == EPI_PLAIN && ONES && !A_KMAJOR && !B_KMAJOR), "the in-launch fold is the weight-gradient instances'");
   static_assert(!EXTRA || (ONES && !B_KMAJOR), "EXTRA rides behind the ones column of a row-contiguous B");
   static_assert(!TWO || (!A_KMAJOR && !B_KMAJOR && EPI == EPI_PLAIN), "column scales: both operands row-contiguous, plain epilogue");
   constexpr int PL = TWO ? 2 : 3;  // planes per operand
@@ -720,87 +700,6 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
       }
     }
   }
-  if constexpr (FOLD) {
-    // where this lane's results live: kind 0 = C (float4 at m * ldc + n), 1 = the ones column (one float at colsum[m]), 2 = extra
-    // (float4 at m * 12 + n - N - 4), -1 = padding
-    const int my = split >= 0 ? split : (int)blockIdx.y;
-    float* const Cz = p.C + (int64_t)my * p.split_stride;
-    float* const csz = p.colsum + (int64_t)my * p.split_stride;
-    float* const gxz = EXTRA && p.F != nullptr ? p.extra + (int64_t)my * p.split_stride : nullptr;
-    auto where = [&](int i, int j, int64_t& off, int& kind) {
-      const int m = m0 + wm0 + i * 16 + fr, n = n0 + wn0 + j * 16 + fk * 4;
-      kind = -1;
-      off = 0;
-      if (m >= p.M) return;
-      if (n < p.N) { kind = 0; off = (int64_t)m * p.ldc + n; }
-      else if (n == p.N) { kind = 1; off = m; }
-      else if (EXTRA && p.F != nullptr && n >= p.N + 4 && n < p.N + 16) { kind = 2; off = (int64_t)m * 12 + (n - p.N - 4); }
-    };
-    auto st4 = [&](float* q, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(q), "v"(v) : "memory"); };
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        int64_t off;
-        int kind;
-        where(i, j, off, kind);
-        if (kind == 0) st4(Cz + off, acc[i][j]);
-        else if (kind == 1) publish(csz + off, acc[i][j][0]);
-        else if (kind == 2) st4(gxz + off, acc[i][j]);
-      }
-    publish_commit();
-    __shared__ int fold_last;
-    __syncthreads();
-    if (tid == 0) {
-      const unsigned got = __hip_atomic_fetch_add(fa->tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      fold_last = got == (unsigned)fa->splits - 1u ? 1 : 0;
-      if (fold_last) publish(fa->tickets + tile, 0u);
-    }
-    __syncthreads();
-    if (!fold_last) return;
-    asm volatile("" ::: "memory");
-    const float *pC = p.C, *pcs = p.colsum, *pgx = EXTRA ? p.extra : nullptr;  // (values, not addresses of kernel-argument fields)
-    const int64_t stride = p.split_stride;
-    const int nsp = fa->splits;
-    auto ld4 = [&](const float* q) {
-      f32x4 v;
-      asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(q) : "memory");
-      return v;
-    };
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        int64_t off;
-        int kind;
-        where(i, j, off, kind);
-        if (kind < 0) continue;
-        const float* base = kind == 0 ? pC : kind == 1 ? pcs : pgx;
-        f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int z0 = 0; z0 < nsp; z0 += 4) {  // four partials in flight, added in split order
-          f32x4 v[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int z = min(z0 + u, nsp - 1);
-            if (kind == 1) v[u] = f32x4{fetch_published(base + (int64_t)z * stride + off), 0.f, 0.f, 0.f};
-            else v[u] = ld4(base + (int64_t)z * stride + off);
-          }
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int z = z0 + u;
-            if (z >= nsp) break;
-            const f32x4 t = z == my ? (kind == 1 ? f32x4{acc[i][j][0], 0.f, 0.f, 0.f} : acc[i][j]) : v[u];
-            if (z == 0) sum = t;
-            else { sum[0] += t[0]; sum[1] += t[1]; sum[2] += t[2]; sum[3] += t[3]; }
-          }
-        }
-        if (kind == 0) *reinterpret_cast<float4*>(fa->C + off) = make_float4(sum[0], sum[1], sum[2], sum[3]);
-        else if (kind == 1) { if (fa->colsum) fa->colsum[off] = sum[0]; }
-        else if (fa->extra) *reinterpret_cast<float4*>(fa->extra + off) = make_float4(sum[0], sum[1], sum[2], sum[3]);
-      }
-    return;
-  }
   if constexpr (EPI == EPI_MASK) gemm_epilogue_pre<EPI, ONES, MI, NI, MI>(p, acc, m0 + wm0, n0 + wn0, lane, mk);
   else gemm_epilogue<EPI, ONES, MI, NI>(p, acc, m0 + wm0, n0 + wn0, lane);
   if constexpr (EXTRA) {  // Bop columns N + 4 .. N + 15 (the epilogue above skips everything beyond the ones column)
@@ -846,14 +745,12 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3_xg(GemmArgs p,
 struct GemmArgs2 {
   GemmArgs a[2];
   int tiles[2];
-  FoldArgs f[2];
 };
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, bool EXTRA = false, bool TWO = false, int PFD = 1,
-          bool FOLD = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES, bool EXTRA = false, bool TWO = false, int PFD = 1>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3_pair(GemmArgs2 q) {
   const int z = blockIdx.z;
   if ((int)blockIdx.x >= q.tiles[z]) return;
-  gemm3_body<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, EXTRA, TWO, PFD, FOLD>(q.a[z], blockIdx.x, q.tiles[z], -1, -1, &q.f[z]);
+  gemm3_body<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES, EXTRA, TWO, PFD>(q.a[z], blockIdx.x, q.tiles[z]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1901,23 +1798,6 @@ int launch_colmax(const ColmaxJob* jobs, int count, int64_t n, hipStream_t st) {
   return check_launch("colmax");
 }
 
-// arrival words of the in-launch fold of the paired weight gradients (gemm3_body<FOLD>): [slot][product][tile], zero, left zero by every
-// launch; a launch takes the next slot (host counter), so launches in flight on different streams never share one
-constexpr int kFoldSlots = 256, kFoldTiles = 64;
-__device__ unsigned g_fold_tickets[kFoldSlots][2][kFoldTiles];
-inline unsigned* fold_ticket_slot() {
-  static std::atomic<unsigned> next{0};
-  static unsigned* base = nullptr;
-  static std::once_flag once;
-  std::call_once(once, [] {
-    void* q = nullptr;
-    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_fold_tickets)) == hipSuccess) base = static_cast<unsigned*>(q);
-    else (void)hipGetLastError();
-  });
-  if (!base) return nullptr;
-  return base + (size_t)(next.fetch_add(1, std::memory_order_relaxed) % kFoldSlots) * 2 * kFoldTiles;
-}
-
 // ---- the bond-table gradient of a chem GIN layer without a pass of its own (round 5) ------------------------------------------
 // chem/model.py:37-52 under autograd: demb [9, D] = cfeat^T [9, n] . dagg [n, D] with dagg = dhid . W1, i.e. (cfeat^T . dhid) . W1.
 // G = dhid^T . cfeat [2D, 9] is twelve more columns of the dW1 product (dhid^T . [agg | 1 | cfeat]): they sit in the column padding of
@@ -2164,28 +2044,12 @@ int pgnn::linear_bwd_weight_pair_ext(const float* dy_a, int64_t lddy_a, const fl
       // of the k-loop: 78.7 us against 50.4, profiles/r04/wgrad2p_and_ctx_two_streams_ab.txt.)
       // (512 workgroups, two per CU: 384 / 768 / 256 aimed at, or one resident per CU, all measured slower -- profiles/r05/dw_pair_grid_ab.txt)
       const dim3 grid((int)std::max(tiles_a, tiles_b), used, 2);
-      // (round 6) PGNN_DW_FOLD=1: the sum over the splits inside this launch (gemm3_body<FOLD>) instead of k_splitk_reduce_jobs behind it
-      unsigned* ftk = (env_knob("PGNN_DW_FOLD", 1) != 0 && tiles_a <= kFoldTiles && tiles_b <= kFoldTiles) ? fold_ticket_slot() : nullptr;
-      if (ftk) {
-        for (int z = 0; z < 2; ++z) {
-          q.f[z].tickets = ftk + (size_t)z * kFoldTiles;
-          q.f[z].splits = used;
-          q.f[z].C = dws[z];
-          q.f[z].colsum = dbs[z];
-          q.f[z].extra = (z == 1 && ext) ? g_out : nullptr;
-        }
-      }
       auto launch = [&](auto ext_tag, auto two_tag, auto pfd_tag) {
         constexpr bool E = decltype(ext_tag)::value, T2 = decltype(two_tag)::value;
         constexpr int PF = decltype(pfd_tag)::value;
         constexpr size_t lds = (size_t)(T2 ? 2 : 3) * (RowMajorTile<64>::PLANE + RowMajorTile<160>::PLANE);
-        if (ftk) {
-          allow_big_lds((const void*)k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true, E, T2, PF, true>, lds);
-          hipLaunchKernelGGL((k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true, E, T2, PF, true>), grid, dim3(512), lds, st, q);
-        } else {
-          allow_big_lds((const void*)k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true, E, T2, PF>, lds);
-          hipLaunchKernelGGL((k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true, E, T2, PF>), grid, dim3(512), lds, st, q);
-        }
+        allow_big_lds((const void*)k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true, E, T2, PF>, lds);
+        hipLaunchKernelGGL((k_gemm3_pair<64, 160, 4, 2, false, false, EPI_PLAIN, true, E, T2, PF>), grid, dim3(512), lds, st, q);
       };
       using Tt = std::true_type;
       using Ff = std::false_type;
@@ -2207,7 +2071,6 @@ int pgnn::linear_bwd_weight_pair_ext(const float* dy_a, int64_t lddy_a, const fl
         else     { if (two) launch(Ff{}, Tt{}, P1{}); else launch(Ff{}, Ff{}, P1{}); }
       }
       if (ext) *g_done = true;
-      if (ftk) return check_launch("linear_bwd_weight_pair_fold");
       const int64_t work = std::max(jobs.j[0].n4a + jobs.j[0].n4b + jobs.j[0].n4c, jobs.j[1].n4a + jobs.j[1].n4b + jobs.j[1].n4c);
       hipLaunchKernelGGL(k_splitk_reduce_jobs, dim3((int)std::min<int64_t>(ceil_div(work, 256), 1024), 2), dim3(256), 0, st, jobs);
       return check_launch("linear_bwd_weight_pair");
