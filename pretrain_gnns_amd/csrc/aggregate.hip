@@ -402,7 +402,7 @@ __device__ __forceinline__ void agg_tail_finish(const AggTail& tail, float* redL
 }
 
 template <bool TABLE, int P, int NROW, bool PRE, int POL, bool WEIGHT, bool TAIL = false>
-__global__ void __launch_bounds__(704, (PRE || TAIL) ? 6 : 1)
+__global__ void __launch_bounds__(704, ((PRE && (POL & 32) == 0) || TAIL) ? 6 : 1)
 k_aggregate_dma(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ ptr,
                 const int32_t* __restrict__ nbr, const uint8_t* __restrict__ code,
                 const float* __restrict__ emb1, const float* __restrict__ emb2, float* __restrict__ out,
@@ -891,6 +891,10 @@ int launch_aggregate_dma_pre(const float* z, int64_t ldz, const float* coef, int
   const bool small_ld = ldz * 4 * kDmaG < (1ll << 31);
   if (nrow == 10 && small_ld) {
     const bool nt = env_int("PGNN_DMA_POL", (int64_t)n * dim * 4 >= (128ll << 20) ? 3 : 0) == 3;
+#ifdef PGNN_AB  // rounds 3-5: every gathered row activated by the consumers (86 VGPRs: one workgroup per CU) -- A/B builds only
+    if (env_int("PGNN_DMA_ACT_CONSUMER", 0) != 0 && nt && !tail)
+      return launch_aggregate_dma_p<true, 2, 10, true, 19 | 32>(z, ldz, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, coef, relu);
+#endif
     if (env_int("PGNN_DMA_PF", 1) != 0) {
       if (nt) return launch_aggregate_dma_p<true, 2, 10, true, 19>(z, ldz, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, coef, relu);
       return launch_aggregate_dma_p<true, 2, 10, true, 16>(z, ldz, ptr, nbr, code, emb1, emb2, out, ldo, n, dim, st, coef, relu, nullptr, tail);
