@@ -1292,7 +1292,7 @@ int launch_gemm3_s(const GemmArgs& p, int nsplit, hipStream_t st) {
   using TB = typename std::conditional<B_KMAJOR, KMajorTile<BN>, RowMajorTile<BN>>::type;
   constexpr size_t lds = (size_t)3 * (TA::PLANE + TB::PLANE);
   const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N + (ONES ? 4 : 0), BN));
-  if constexpr (!A_KMAJOR && !B_KMAJOR && EPI == EPI_PLAIN && BM == 320) {
+  if constexpr (!A_KMAJOR && !B_KMAJOR && EPI == EPI_PLAIN && BM >= 128) {
     if (nsplit > 1 && p.nxcd > 1 && nsplit % p.nxcd == 0 && env_knob("PGNN_DW_XCD_GROUP", 1) != 0) {
       allow_big_lds((const void*)k_gemm3_xg<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES>, lds);
       hipLaunchKernelGGL((k_gemm3_xg<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES>), dim3(tiles * nsplit), dim3(64 * WAVES_M * WAVES_N),
@@ -1873,7 +1873,12 @@ int weight_product(const float* dy, int64_t lddy, const float* x, int64_t ldx, f
   const TileCfg cfg = weight_cfg(m);
   const bool split3 = weight_split(m);
   const bool big3 = split3 && m >= kWeightBigRows;
-  const int nsplit = split3 ? weight_splits(m, k, n, big3 ? 320 : 64, 160) : weight_splits(m, k, n, kCfg[cfg].bm, kCfg[cfg].bn);
+  // (round 6, A/B) PGNN_DW_BIG_TILE: the tile of the large weight gradients -- 320 (shipped: 104 KB of LDS, ONE workgroup per CU, every
+  // operand byte wanted twice), 160 (10 waves, 60 KB: two workgroups per CU overlap each other's staging and product phases; operand
+  // bytes wanted 2-4 times) or 128 (8 waves, 60 KB)
+  const int big_tile = big3 ? env_knob("PGNN_DW_BIG_TILE", 320) : 64;
+  const int bm_sel = big3 ? (big_tile == 160 ? 160 : big_tile == 128 ? 128 : 320) : 64;
+  const int nsplit = split3 ? weight_splits(m, k, n, bm_sel, 160) : weight_splits(m, k, n, kCfg[cfg].bm, kCfg[cfg].bn);
   float* partial = cv.take<float>((size_t)nsplit * (n * k + n));
   GemmArgs p{};
   p.nxcd = num_xcd();
@@ -1891,6 +1896,8 @@ int weight_product(const float* dy, int64_t lddy, const float* x, int64_t ldx, f
   p.split_stride = direct ? 0 : n * k + n;
   p.colsum = direct ? db : partial + n * k;
   job = ReduceJob{partial, used, n * k + n, dw, n * k / 4, db, db ? n / 4 : 0};
+  if (split3 && big3 && bm_sel == 160 && db) return launch_gemm3_s<160, 160, 5, 2, false, false, EPI_PLAIN, true>(p, used, st);
+  if (split3 && big3 && bm_sel == 128 && db) return launch_gemm3_s<128, 160, 4, 2, false, false, EPI_PLAIN, true>(p, used, st);
   if (split3 && big3)
     return db ? launch_gemm3_s<320, 160, 4, 2, false, false, EPI_PLAIN, true>(p, used, st)
               : launch_gemm3_s<320, 160, 4, 2, false, false, EPI_PLAIN, false>(p, used, st);
