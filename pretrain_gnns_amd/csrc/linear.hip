@@ -731,9 +731,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3(GemmArgs p) {
 // HBM / MALL itself.  Here workgroup id = xcd + nxcd * j is tile j % tiles of split xcd + nxcd * (j / tiles): the tiles of a split are
 // neighbours in dispatch order on ONE XCD, walk the rows at the same pace, and the second reader of a panel finds it in that L2.
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES>
-__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3_xg(GemmArgs p, int tiles) {
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3_xg(GemmArgs p, int tiles, int nsplit) {
   const int id = blockIdx.x, xcd = id % p.nxcd, j = id / p.nxcd;
   const int tile = j % tiles, split = xcd + p.nxcd * (j / tiles);
+  if (split >= nsplit) return;  // (the grid is rounded up to whole XCD rows when the split count is not a multiple of the XCD count)
   GemmArgs q = p;  // (the epilogues index the partial matrices by blockIdx.y, which is 0 here)
   q.C = p.C + (int64_t)split * p.split_stride;
   if (ONES) q.colsum = p.colsum + (int64_t)split * p.split_stride;
@@ -1293,10 +1294,11 @@ int launch_gemm3_s(const GemmArgs& p, int nsplit, hipStream_t st) {
   constexpr size_t lds = (size_t)3 * (TA::PLANE + TB::PLANE);
   const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N + (ONES ? 4 : 0), BN));
   if constexpr (!A_KMAJOR && !B_KMAJOR && EPI == EPI_PLAIN && BM >= 128) {
-    if (nsplit > 1 && p.nxcd > 1 && nsplit % p.nxcd == 0 && env_knob("PGNN_DW_XCD_GROUP", 1) != 0) {
+    if (nsplit > 1 && p.nxcd > 1 && env_knob("PGNN_DW_XCD_GROUP", 1) != 0) {
       allow_big_lds((const void*)k_gemm3_xg<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES>, lds);
-      hipLaunchKernelGGL((k_gemm3_xg<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES>), dim3(tiles * nsplit), dim3(64 * WAVES_M * WAVES_N),
-                         lds, st, p, tiles);
+      const int grid = tiles * (int)ceil_div(nsplit, p.nxcd) * p.nxcd;  // every XCD gets ceil(nsplit / nxcd) splits' worth of slots
+      hipLaunchKernelGGL((k_gemm3_xg<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES>), dim3(grid), dim3(64 * WAVES_M * WAVES_N),
+                         lds, st, p, tiles, nsplit);
       return check_launch("gemm3_xg");
     }
   }
