@@ -1878,7 +1878,11 @@ int weight_product(const float* dy, int64_t lddy, const float* x, int64_t ldx, f
   // (round 6, A/B) PGNN_DW_BIG_TILE: the tile of the large weight gradients -- 320 (shipped: 104 KB of LDS, ONE workgroup per CU, every
   // operand byte wanted twice), 160 (10 waves, 60 KB: two workgroups per CU overlap each other's staging and product phases; operand
   // bytes wanted 2-4 times) or 128 (8 waves, 60 KB)
+#ifdef PGNN_AB  // (measured level / slower, profiles/r06/dw_two_planes_ab.txt: A/B builds only)
   const int big_tile = big3 ? env_knob("PGNN_DW_BIG_TILE", 320) : 64;
+#else
+  const int big_tile = big3 ? 320 : 64;
+#endif
   const int bm_sel = big3 ? (big_tile == 160 ? 160 : big_tile == 128 ? 128 : 320) : 64;
   const int nsplit = split3 ? weight_splits(m, k, n, bm_sel, 160) : weight_splits(m, k, n, kCfg[cfg].bm, kCfg[cfg].bn);
   float* partial = cv.take<float>((size_t)nsplit * (n * k + n));
@@ -1898,8 +1902,10 @@ int weight_product(const float* dy, int64_t lddy, const float* x, int64_t ldx, f
   p.split_stride = direct ? 0 : n * k + n;
   p.colsum = direct ? db : partial + n * k;
   job = ReduceJob{partial, used, n * k + n, dw, n * k / 4, db, db ? n / 4 : 0};
+#ifdef PGNN_AB
   if (split3 && big3 && bm_sel == 160 && db) return launch_gemm3_s<160, 160, 5, 2, false, false, EPI_PLAIN, true>(p, used, st);
   if (split3 && big3 && bm_sel == 128 && db) return launch_gemm3_s<128, 160, 4, 2, false, false, EPI_PLAIN, true>(p, used, st);
+#endif
   if (split3 && big3)
     return db ? launch_gemm3_s<320, 160, 4, 2, false, false, EPI_PLAIN, true>(p, used, st)
               : launch_gemm3_s<320, 160, 4, 2, false, false, EPI_PLAIN, false>(p, used, st);
