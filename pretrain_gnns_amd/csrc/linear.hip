@@ -576,17 +576,29 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
 
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
   const int fr = lane & 15, fk = lane >> 4;
-  // fragment of the 16 tile rows / columns starting at `c0`, plane q
-  auto frag = [&](auto kmajor, auto cols_tag, const unsigned char* base, int plane, int c0, int q) -> bf16x8 {
+  // fragment of the 16 tile rows / columns starting at `c0`, plane q.  The lane's byte offset inside a plane does not depend on the
+  // k-step: it is formed ONCE per 16-row / 16-column block in front of the loop (round 6: hipcc re-formed the wrapped column -- add,
+  // compare, select -- for every block in every k-step, ~30 of the 144 VALU instructions per k-step and wave of the paired weight
+  // gradients, whose VALU issue is 0.44 of their busy cycles); inside the loop a fragment is base + q * plane (an immediate) + that offset.
+  auto frag_off = [&](auto kmajor, auto cols_tag, int c0) -> int {
     constexpr int COLS = decltype(cols_tag)::value;
     if constexpr (decltype(kmajor)::value) {
-      return *reinterpret_cast<const bf16x8*>(base + q * plane + (c0 + fr) * 64 + ((fk ^ ((-(fr >> 2)) & 3)) * 16));
+      return (c0 + fr) * 64 + ((fk ^ ((-(fr >> 2)) & 3)) * 16);
     } else {
       // lane (i = fr, g = fk): k-blocks 2g and 2g+1 (rows 8g .. 8g+7, all with the same bit 3 = g & 1), row 4 kb + i / 4,
       // its address = four consecutive columns of that row; the group's 16 lanes receive one column each
       using L = RowMajorTile<COLS>;
       const int col = (c0 + 4 * (fr & 3) + 16 * (fk & 1)) % L::S;
-      const unsigned char* a0 = base + q * plane + ((8 * fk + (fr >> 2)) * L::S + col) * 2;
+      return ((8 * fk + (fr >> 2)) * L::S + col) * 2;
+    }
+  };
+  auto frag = [&](auto kmajor, auto cols_tag, const unsigned char* base, int plane, int off, int q) -> bf16x8 {
+    constexpr int COLS = decltype(cols_tag)::value;
+    if constexpr (decltype(kmajor)::value) {
+      return *reinterpret_cast<const bf16x8*>(base + q * plane + off);
+    } else {
+      using L = RowMajorTile<COLS>;
+      const unsigned char* a0 = base + q * plane + off;
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
       const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * L::S * 2));
       return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -596,6 +608,11 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
   using KB = std::integral_constant<bool, B_KMAJOR>;
   using CA = std::integral_constant<int, BM>;
   using CB = std::integral_constant<int, BN>;
+  int foA[MI], foB[NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) foA[i] = frag_off(KA{}, CA{}, wm0 + i * 16);
+#pragma unroll
+  for (int j = 0; j < NI; ++j) foB[j] = frag_off(KB{}, CB{}, wn0 + j * 16);
 
   auto compute = [&]() {
     if constexpr (TWO) {
@@ -603,12 +620,12 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) a[i][q] = __builtin_bit_cast(f16x8, frag(KA{}, CA{}, ldsA, PA, wm0 + i * 16, q));
+        for (int q = 0; q < 2; ++q) a[i][q] = __builtin_bit_cast(f16x8, frag(KA{}, CA{}, ldsA, PA, foA[i], q));
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         f16x8 b[2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) b[q] = __builtin_bit_cast(f16x8, frag(KB{}, CB{}, ldsB, PB, wn0 + j * 16, q));
+        for (int q = 0; q < 2; ++q) b[q] = __builtin_bit_cast(f16x8, frag(KB{}, CB{}, ldsB, PB, foB[j], q));
         // smallest terms first (the order of k_gemm2pw); operands swapped (D = B x A) as below
 #pragma unroll
         for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[1], a[i][0], acc[i][j], 0, 0, 0);
@@ -623,12 +640,12 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int q = 0; q < 3; ++q) a[i][q] = frag(KA{}, CA{}, ldsA, PA, wm0 + i * 16, q);
+      for (int q = 0; q < 3; ++q) a[i][q] = frag(KA{}, CA{}, ldsA, PA, foA[i], q);
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       bf16x8 b[3];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) b[q] = frag(KB{}, CB{}, ldsB, PB, wn0 + j * 16, q);
+      for (int q = 0; q < 3; ++q) b[q] = frag(KB{}, CB{}, ldsB, PB, foB[j], q);
       // smallest terms first; operands swapped (D = B x A) so a lane ends up with 4 consecutive columns of one C row
 #pragma unroll
       for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i][2], acc[i][j], 0, 0, 0);
