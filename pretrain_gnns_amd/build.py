@@ -67,4 +67,5 @@ def build(verbose=False, force=False, extra_flags=()):
 if __name__ == "__main__":
     # --ab: the A/B build (-DPGNN_AB): compile-time ablation instances behind PGNN_* knobs (tools/, profiles/): not what ships
     ab = "--ab" in sys.argv
-    print(build(verbose=True, force="--force" in sys.argv or ab, extra_flags=("-DPGNN_AB",) if ab else ()))
+    defs = tuple("-D" + sys.argv[i + 1] for i, a in enumerate(sys.argv[:-1]) if a == "--define")  # --define NAME: one more -D (same-box A/Bs of compile-time choices)
+    print(build(verbose=True, force="--force" in sys.argv or ab or bool(defs), extra_flags=(("-DPGNN_AB",) if ab else ()) + defs))
