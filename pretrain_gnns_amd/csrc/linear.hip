@@ -577,9 +577,10 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
   const int fr = lane & 15, fk = lane >> 4;
   // fragment of the 16 tile rows / columns starting at `c0`, plane q.  The lane's byte offset inside a plane does not depend on the
-  // k-step: it is formed ONCE per 16-row / 16-column block in front of the loop (round 6: hipcc re-formed the wrapped column -- add,
-  // compare, select -- for every block in every k-step, ~30 of the 144 VALU instructions per k-step and wave of the paired weight
-  // gradients, whose VALU issue is 0.44 of their busy cycles); inside the loop a fragment is base + q * plane (an immediate) + that offset.
+  // k-step: it is formed once per 16-row / 16-column block in front of the loop (round 6: hipcc re-formed the wrapped column -- add,
+  // compare, select -- for every block in every k-step; hoisted, the large weight gradient measures level in isolation and the
+  // 16 384-graph step 27.56 -> 27.42 ms on one box, profiles/r06/dw_two_planes_ab.txt); inside the loop a fragment is
+  // base + q * plane (an immediate) + that offset.
   auto frag_off = [&](auto kmajor, auto cols_tag, int c0) -> int {
     constexpr int COLS = decltype(cols_tag)::value;
     if constexpr (decltype(kmajor)::value) {
@@ -608,18 +609,11 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
   using KB = std::integral_constant<bool, B_KMAJOR>;
   using CA = std::integral_constant<int, BM>;
   using CB = std::integral_constant<int, BN>;
-#ifdef PGNN_NO_FRAG_HOIST  // (same-box A/B of the hoist: python -m pretrain_gnns_amd.build --force --define PGNN_NO_FRAG_HOIST)
-#define foA_(i) frag_off(KA{}, CA{}, wm0 + (i) * 16)
-#define foB_(j) frag_off(KB{}, CB{}, wn0 + (j) * 16)
-#else
   int foA[MI], foB[NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) foA[i] = frag_off(KA{}, CA{}, wm0 + i * 16);
 #pragma unroll
   for (int j = 0; j < NI; ++j) foB[j] = frag_off(KB{}, CB{}, wn0 + j * 16);
-#define foA_(i) foA[i]
-#define foB_(j) foB[j]
-#endif
 
   auto compute = [&]() {
     if constexpr (TWO) {
@@ -627,12 +621,12 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) a[i][q] = __builtin_bit_cast(f16x8, frag(KA{}, CA{}, ldsA, PA, foA_(i), q));
+        for (int q = 0; q < 2; ++q) a[i][q] = __builtin_bit_cast(f16x8, frag(KA{}, CA{}, ldsA, PA, foA[i], q));
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         f16x8 b[2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) b[q] = __builtin_bit_cast(f16x8, frag(KB{}, CB{}, ldsB, PB, foB_(j), q));
+        for (int q = 0; q < 2; ++q) b[q] = __builtin_bit_cast(f16x8, frag(KB{}, CB{}, ldsB, PB, foB[j], q));
         // smallest terms first (the order of k_gemm2pw); operands swapped (D = B x A) as below
 #pragma unroll
         for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[1], a[i][0], acc[i][j], 0, 0, 0);
@@ -647,12 +641,12 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int q = 0; q < 3; ++q) a[i][q] = frag(KA{}, CA{}, ldsA, PA, foA_(i), q);
+      for (int q = 0; q < 3; ++q) a[i][q] = frag(KA{}, CA{}, ldsA, PA, foA[i], q);
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       bf16x8 b[3];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) b[q] = frag(KB{}, CB{}, ldsB, PB, foB_(j), q);
+      for (int q = 0; q < 3; ++q) b[q] = frag(KB{}, CB{}, ldsB, PB, foB[j], q);
       // smallest terms first; operands swapped (D = B x A) so a lane ends up with 4 consecutive columns of one C row
 #pragma unroll
       for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i][2], acc[i][j], 0, 0, 0);
@@ -743,8 +737,6 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int block_x,
   }
 }
 
-#undef foA_
-#undef foB_
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool ONES>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gemm3(GemmArgs p) {
   gemm3_body<BM, BN, WAVES_M, WAVES_N, A_KMAJOR, B_KMAJOR, EPI, ONES>(p, blockIdx.x, gridDim.x);
