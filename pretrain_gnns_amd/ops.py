@@ -875,14 +875,17 @@ def _head_state(dev):
     return t
 
 
-_row_support = None  # (data_ptr of a gradient tensor, its rows, the int64 rows outside which it is zero): MaskedHead.backward -> stack backward
+import threading as _threading
+
+_row_support_tls = _threading.local()  # .rec = (data_ptr of a gradient tensor, its rows, the int64 rows outside which it is zero):
+                                       # MaskedHead.backward -> stack backward, per host thread (autograd runs a device's backward on one thread)
 
 
 def _hand_over_row_support(dy, n):
     """called by a one-call network's backward with its incoming gradient: if it is the tensor the masking head just produced, tell the
     library which rows are not zero (consumed by the pgnn_*_stack_bwd call that follows)"""
-    global _row_support
-    rec, _row_support = _row_support, None
+    rec = getattr(_row_support_tls, "rec", None)
+    _row_support_tls.rec = None
     if rec is not None and rec[0] == dy.data_ptr() and rec[1] == n and dy.is_contiguous():
         load().pgnn_stack_bwd_dy_rows(dy.data_ptr(), rec[2].data_ptr(), rec[2].numel())
         return rec[2]  # (kept alive by the caller until the launch is enqueued)
@@ -950,8 +953,7 @@ class MaskedHead(Function):
                                           stream_ptr()), "pgnn_masked_head_bwd")
         # dnode is zero outside the rows idx: the one-call network's backward, if this very tensor reaches it, sums its top
         # BatchNorm's column sums over those rows only (pgnn_stack_bwd_dy_rows)
-        global _row_support
-        _row_support = (dnode.data_ptr(), n, idx)
+        _row_support_tls.rec = (dnode.data_ptr(), n, idx)
         return dnode, None, dw, db, None, None
 
 
