@@ -22,7 +22,7 @@ for action in "$@"; do
   echo "== [$k] $action"
   case $verb in
     tests)
-      timeout ${T:-1500} python -X faulthandler -m pytest $rest -m gpu -q > $O/tests_$k.txt 2>&1; tail -n 4 $O/tests_$k.txt ;;
+      eval "timeout ${T:-1500} python -X faulthandler -m pytest $rest -m gpu -q" > $O/tests_$k.txt 2>&1; tail -n 4 $O/tests_$k.txt ;;  # (eval: -k \"a or b\" keeps its quotes)
     smoke)
       python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -n 2 $O/smoke.txt ;;
     bench)
