@@ -659,10 +659,11 @@ def roofline_mlp(dev, rows):
 # collect them (the counters need the profiler around the process).  Wave counters are 4-cycle quanta; the clock under these
 # kernels is 1.5-1.85 GHz (SQ_BUSY_CU_CYCLES / 256 over the event time), not the 2.4 GHz behind the 2 500 TFLOP/s peak.
 MFMA_UTIL_PMC = {"k_mlp2p_fused fwd (262144 rows)": 0.517, "k_mlp2p_fused bwd (262144 rows)": 0.430, "k_gemm2pr<10,120>": 0.417,
-                 "k_gemm2pr<19,64>": 0.340, "k_gemm2pw<112,160> (6740 rows)": 0.239, "k_gemm2pw<64,160> (6740 rows)": 0.240,
-                 "k_gemm3_pair<64,160> (6740 rows)": 0.360}  # (the last three: tools/gpu_r05af.sh, the final binary's instances)
-MFMA_UTIL_SOURCE = ("profiles/r05/mlp_fused_pmc_summary.txt (large M), profiles/r05/step_b256_gemm_pmc_summary.txt (the 256-graph step): "
-                    "SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) per launch, rocprofv3 --pmc")
+                 "k_gemm2pr<19,64>": 0.340, "k_gemm2pw<112,160> (6740 rows)": 0.235, "k_gemm2pw<64,160> (6740 rows)": 0.238,
+                 "k_gemm3_pair<64,160> (6740 rows)": 0.358}  # (the last three re-taken in round 6: profiles/r06/step_b256_gemm_pmc_summary.txt)
+MFMA_UTIL_SOURCE = "profiles/r05/mlp_fused_pmc_summary.txt (large M), profiles/r06/step_b256_gemm_pmc_summary.txt: MFMA_BUSY / (4 CU_BUSY)"
+MFMA_UTIL_HOW = "SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) per launch, rocprofv3 --pmc, one counter pair per pass"
+
 
 
 def fused_mlp_pair(dev, rows, planes_peak):
